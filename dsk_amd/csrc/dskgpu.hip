@@ -1,0 +1,647 @@
+// dskgpu.hip -- C-ABI (include/dskgpu.h) over the HIP kernels in kernels.h.
+// Host-side orchestration of the count path that stands where
+// SortingCountAlgorithm<span>::execute() is called (src/DSK.cpp:60).
+// gfx950 only; there is no CPU fallback: every entry point needs a HIP device.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dskgpu.h"
+#include "kernels.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#define DSKGPU_VERSION "dskgpu 0.1 (gfx950)"
+
+namespace {
+
+thread_local std::string g_create_err;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = (bytes + 255) & ~size_t(255);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want; else p = nullptr;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_COUNT = 8 };
+
+struct Stage { const char* name; hipEvent_t ev; };
+
+}  // namespace
+
+struct dskgpu_ctx {
+    dskgpu_config cfg{};
+    int W = 1;
+    int gbits = 0;                 // log2(world_size): owner digit
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+    std::string err;
+
+    // input
+    DevBuf reads_own; u64 reads_len = 0;
+    const uint8_t* d_reads = nullptr; u64 n_bytes = 0;
+
+    DevBuf packed, inval;          // K1 output
+    DevBuf bufA, bufB;             // partition ping-pong
+    DevBuf mat1, mat2, sums, descs1, descs2, seg, fstart, nsolid, scalars, ghist, gstats;
+    DevBuf out_lo, out_hi, out_ab, srt_lo, srt_hi, srt_ab, srt_tmp, srt_idx, srt_idx2;
+    std::vector<ChunkDesc> h_descs1;
+    u32 h_sc[SC_COUNT] = {0};      // host mirror of the device scalars (kept alive across async copies)
+
+    // results
+    bool have_result = false;
+    u64 n_rows = 0;
+    const u64* res_lo = nullptr; const u64* res_hi = nullptr; const u32* res_ab = nullptr;
+    dskgpu_stats stats{};
+    std::vector<u64> hist;
+
+    // timing
+    std::vector<Stage> marks;
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+    std::vector<const char*> st_names; std::vector<float> st_ms;
+
+    void mark(const char* name) {
+        if (!(cfg.flags & DSKGPU_F_TIMING)) return;
+        if (ev_used == ev_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
+        hipEvent_t e = ev_pool[ev_used++];
+        (void)hipEventRecord(e, stream);
+        marks.push_back({name, e});
+    }
+    void resolve_marks() {   // after a stream sync; appends to st_names/st_ms
+        for (size_t i = 0; i + 1 < marks.size(); ++i) {
+            float ms = 0; (void)hipEventElapsedTime(&ms, marks[i].ev, marks[i + 1].ev);
+            st_names.push_back(marks[i + 1].name); st_ms.push_back(ms);
+        }
+        marks.clear(); ev_used = 0;
+    }
+};
+
+namespace {
+
+#define CK(expr)                                                                             \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            return (e_ == hipErrorOutOfMemory) ? DSKGPU_E_NOMEM : DSKGPU_E_DEVICE;           \
+        }                                                                                    \
+    } while (0)
+
+#define CKL(what)                                                                            \
+    do {                                                                                     \
+        hipError_t e_ = hipGetLastError();                                                   \
+        if (e_ != hipSuccess) {                                                              \
+            ctx->err = std::string(what) + ": " + hipGetErrorString(e_);                     \
+            return DSKGPU_E_DEVICE;                                                          \
+        }                                                                                    \
+    } while (0)
+
+int fail(dskgpu_ctx* ctx, int code, const std::string& msg) { ctx->err = msg; return code; }
+
+inline int ceil_log2_u64(u64 x) { int b = 0; while ((1ull << b) < x) ++b; return b; }
+
+// ---- K1 launcher
+int run_encode(dskgpu_ctx* ctx, const uint8_t* d_bytes, u64 n, u64* nwords_out) {
+    const u64 nwords = (n + 31) / 32;
+    CK(ctx->packed.ensure((nwords + 1) * 8));
+    CK(ctx->inval.ensure((nwords + 1) * 4));
+    if (nwords) {
+        const u64 nb = (nwords + 255) / 256;
+        const unsigned grid = (unsigned)std::min<u64>(nb, (u64)ctx->num_cu * 16);
+        if ((reinterpret_cast<uintptr_t>(d_bytes) & 15) == 0)
+            hipLaunchKernelGGL(k_encode<true>, dim3(grid), dim3(256), 0, ctx->stream, d_bytes, n,
+                               ctx->packed.as<u64>(), ctx->inval.as<u32>(), nwords);
+        else
+            hipLaunchKernelGGL(k_encode<false>, dim3(grid), dim3(256), 0, ctx->stream, d_bytes, n,
+                               ctx->packed.as<u64>(), ctx->inval.as<u32>(), nwords);
+        CKL("k_encode");
+    }
+    *nwords_out = nwords;
+    return DSKGPU_OK;
+}
+
+// ---- scan launcher: exclusive scan of a[0..*d_len) in place, total -> a[*d_len]
+int run_scan(dskgpu_ctx* ctx, u32* a, const u32* d_len, u64 max_len) {
+    const u64 nb = std::max<u64>(1, (max_len + SCAN_BLK - 1) / SCAN_BLK);
+    CK(ctx->sums.ensure((nb + 1) * 4));
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_NT), 0, ctx->stream, a, d_len, ctx->sums.as<u32>());
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, ctx->sums.as<u32>(), d_len, a);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_NT), 0, ctx->stream, a, d_len, ctx->sums.as<u32>());
+    CKL("k_scan");
+    return DSKGPU_OK;
+}
+
+size_t scatter_lds(int W, u32 P) { return (size_t)SC_TILE * 8 * W + (size_t)P * 12 + 17 * 4 + 64; }
+
+template <int W, int SRC>
+int launch_hist(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
+                u64 max_chunks, u32* matrix, int shift, u32 P) {
+    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * 2));
+    hipLaunchKernelGGL((k_hist<W, SRC>), dim3(grid), dim3(SC_NT), 0, ctx->stream, ctx->packed.as<u64>(),
+                       ctx->inval.as<u32>(), keys, descs, d_nch, matrix, (int)ctx->cfg.kmer_size, shift, P);
+    CKL("k_hist");
+    return DSKGPU_OK;
+}
+
+template <int W, int SRC>
+int launch_scatter(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
+                   u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, int shift, u32 P) {
+    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * 2));
+    const size_t lds = scatter_lds(W, P);
+    static bool attr_set[3][2] = {{false, false}, {false, false}, {false, false}};
+    if (!attr_set[W][SRC]) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter<W, SRC>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[W][SRC] = true;
+    }
+    hipLaunchKernelGGL((k_scatter<W, SRC>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->packed.as<u64>(),
+                       ctx->inval.as<u32>(), keys, descs, d_nch, scanned, out, (int)ctx->cfg.kmer_size, shift, P);
+    CKL("k_scatter");
+    return DSKGPU_OK;
+}
+
+struct Plan {
+    int fb, b1, b2, levels;
+    u32 P1, P2, F;
+    int shift1, shift2, slot_shift;
+};
+
+#define TARGET_KEYS 2048      // mean keys per final sub-partition (table has 4096 slots)
+#define MAX_LEVEL_BITS 10
+#define CH2 65536u            // keys per level-2 chunk
+
+bool make_plan(int gbits, u64 n_upper, int extra_bits, Plan* pl) {
+    int fb = ceil_log2_u64((n_upper + TARGET_KEYS - 1) / TARGET_KEYS) + extra_bits;
+    if (fb < 1) fb = 1;
+    if (fb > 2 * MAX_LEVEL_BITS + 2) return false;
+    pl->fb = fb;
+    if (fb <= MAX_LEVEL_BITS) { pl->levels = 1; pl->b1 = fb; pl->b2 = 0; }
+    else { pl->levels = 2; pl->b1 = (fb + 1) / 2; pl->b2 = fb - pl->b1; }
+    pl->P1 = 1u << pl->b1; pl->P2 = 1u << pl->b2; pl->F = 1u << fb;
+    pl->shift1 = 64 - gbits - pl->b1;
+    pl->shift2 = pl->shift1 - pl->b2;
+    pl->slot_shift = 64 - gbits - fb - 12;
+    return pl->slot_shift >= 0;
+}
+
+// Build level-1 chunk descriptors on the host (ranges are static).
+// unit = tile granularity of the source (SC_TILE_WORDS words or SC_TILE keys).
+void build_descs1(dskgpu_ctx* ctx, u64 n_units_total, u64 tile, u64 max_chunks, u32* nch_out) {
+    const u64 ntiles = std::max<u64>(1, (n_units_total + tile - 1) / tile);
+    u64 nch = std::min<u64>(ntiles, max_chunks);
+    const u64 tpc = (ntiles + nch - 1) / nch;
+    nch = (ntiles + tpc - 1) / tpc;
+    ctx->h_descs1.resize(nch);
+    for (u64 c = 0; c < nch; ++c) {
+        ChunkDesc d;
+        d.begin = c * tpc * tile;
+        d.end = std::min<u64>(n_units_total, (c + 1) * tpc * tile);
+        if (d.begin > d.end) d.begin = d.end;
+        d.flat_base = (u32)c;
+        d.stride = (u32)nch;
+        ctx->h_descs1[c] = d;
+    }
+    *nch_out = (u32)nch;
+}
+
+// The pipeline behind dskgpu_count / dskgpu_mg_count.
+template <int W>
+int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_keys_in, u64 nkeys_in);
+
+}  // namespace
+
+// W == 1 result post-processing: sort rows by k-mer value
+static int sort_rows_1(dskgpu_ctx* ctx, u64 n) {
+    if (n == 0) { ctx->res_lo = ctx->out_lo.as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>(); ctx->res_hi = nullptr; return DSKGPU_OK; }
+    if (ctx->cfg.flags & DSKGPU_F_NO_SORT) {
+        ctx->res_lo = ctx->out_lo.as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>(); ctx->res_hi = nullptr;
+        return DSKGPU_OK;
+    }
+    CK(ctx->srt_lo.ensure(n * 8));
+    CK(ctx->srt_ab.ensure(n * 4));
+    size_t tmp = 0;
+    const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
+    CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->out_lo.as<u64>(), ctx->srt_lo.as<u64>(), ctx->out_ab.as<u32>(),
+                                 ctx->srt_ab.as<u32>(), (size_t)n, 0u, end_bit, ctx->stream));
+    CK(ctx->srt_tmp.ensure(tmp));
+    CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->out_lo.as<u64>(), ctx->srt_lo.as<u64>(), ctx->out_ab.as<u32>(),
+                                 ctx->srt_ab.as<u32>(), (size_t)n, 0u, end_bit, ctx->stream));
+    ctx->res_lo = ctx->srt_lo.as<u64>(); ctx->res_ab = ctx->srt_ab.as<u32>(); ctx->res_hi = nullptr;
+    return DSKGPU_OK;
+}
+
+namespace {
+
+template <>
+int run_pipeline<1>(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u64 nkeys_in) {
+    constexpr int W = 1;
+    ctx->have_result = false;
+    ctx->st_names.clear(); ctx->st_ms.clear(); ctx->marks.clear(); ctx->ev_used = 0;
+    const u64 n_upper = from_reads ? ctx->n_bytes : nkeys_in;
+    if (n_upper >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "more than 2^32 k-mers in one pass is not supported yet");
+    u64 nwords = 0;
+    ctx->mark("start");
+    if (from_reads) {
+        int rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords);
+        if (rc) return rc;
+        ctx->mark("encode");
+    }
+    CK(ctx->scalars.ensure(SC_COUNT * 4));
+    CK(ctx->ghist.ensure(((size_t)ctx->cfg.histo_max + 1) * 8));
+    CK(ctx->gstats.ensure(4 * 8));
+    CK(ctx->bufA.ensure((n_upper + 1) * 8 * W));
+    CK(ctx->bufB.ensure((n_upper + 1) * 8 * W));
+    u32* sc = ctx->scalars.as<u32>();
+
+    int extra_bits = 0;
+    for (int attempt = 0;; ++attempt) {
+        Plan pl;
+        if (!make_plan(ctx->gbits, n_upper, extra_bits, &pl))
+            return fail(ctx, DSKGPU_E_OVERFLOW, "cannot partition finer (table overflow persists)");
+        // ---------------- level 1
+        u32 nch1 = 0;
+        const u64 max_chunks1 = (u64)ctx->num_cu * 8;
+        if (from_reads) build_descs1(ctx, nwords, SC_TILE_WORDS, max_chunks1, &nch1);
+        else build_descs1(ctx, nkeys_in, SC_TILE, max_chunks1, &nch1);
+        const u64 M1 = (u64)pl.P1 * nch1;
+        CK(ctx->descs1.ensure(ctx->h_descs1.size() * sizeof(ChunkDesc)));
+        CK(hipMemcpyAsync(ctx->descs1.p, ctx->h_descs1.data(), ctx->h_descs1.size() * sizeof(ChunkDesc),
+                          hipMemcpyHostToDevice, ctx->stream));
+        u32* h_sc = ctx->h_sc;
+        std::memset(h_sc, 0, sizeof(ctx->h_sc));
+        h_sc[SC_NCH1] = nch1; h_sc[SC_MLEN1] = (u32)M1; h_sc[SC_F] = pl.F;
+        CK(hipMemcpyAsync(sc, h_sc, sizeof(ctx->h_sc), hipMemcpyHostToDevice, ctx->stream));
+        CK(ctx->mat1.ensure((M1 + 1) * 4));
+        CK(hipMemsetAsync(ctx->ghist.p, 0, ((size_t)ctx->cfg.histo_max + 1) * 8, ctx->stream));
+        CK(hipMemsetAsync(ctx->gstats.p, 0, 4 * 8, ctx->stream));
+        ctx->mark("setup");
+        int rc;
+        if (from_reads) rc = launch_hist<W, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), pl.shift1, pl.P1);
+        else rc = launch_hist<W, 1>(ctx, d_keys_in, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), pl.shift1, pl.P1);
+        if (rc) return rc;
+        ctx->mark("hist1");
+        if ((rc = run_scan(ctx, ctx->mat1.as<u32>(), sc + SC_MLEN1, M1))) return rc;
+        ctx->mark("scan1");
+        if (from_reads) rc = launch_scatter<W, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<u64>(), pl.shift1, pl.P1);
+        else rc = launch_scatter<W, 1>(ctx, d_keys_in, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<u64>(), pl.shift1, pl.P1);
+        if (rc) return rc;
+        ctx->mark("scatter1");
+        u64* fkeys = ctx->bufA.as<u64>();
+        u32* scratch = ctx->bufB.as<u32>();
+        CK(ctx->fstart.ensure(((size_t)pl.F + 2) * 4));
+        CK(ctx->nsolid.ensure(((size_t)pl.F + 2) * 4));
+        // ---------------- level 2
+        if (pl.levels == 2) {
+            const u64 max_chunks2 = n_upper / CH2 + pl.P1 + 1;
+            const u64 M2 = max_chunks2 * pl.P2;
+            if (M2 >= 0xFFFFFFFFull) return fail(ctx, DSKGPU_E_ARG, "level-2 matrix too large");
+            CK(ctx->descs2.ensure(max_chunks2 * sizeof(ChunkDesc)));
+            CK(ctx->seg.ensure((size_t)pl.P1 * sizeof(SegInfo)));
+            CK(ctx->mat2.ensure((M2 + 1) * 4));
+            hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, ctx->stream, ctx->mat1.as<u32>(), nch1, pl.P1, CH2, pl.P2,
+                               ctx->seg.as<SegInfo>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, sc + SC_MLEN2);
+            CKL("k_plan");
+            ctx->mark("plan2");
+            if ((rc = launch_hist<W, 1>(ctx, ctx->bufA.as<u64>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, max_chunks2, ctx->mat2.as<u32>(), pl.shift2, pl.P2))) return rc;
+            ctx->mark("hist2");
+            if ((rc = run_scan(ctx, ctx->mat2.as<u32>(), sc + SC_MLEN2, M2))) return rc;
+            ctx->mark("scan2");
+            if ((rc = launch_scatter<W, 1>(ctx, ctx->bufA.as<u64>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, max_chunks2, ctx->mat2.as<u32>(), ctx->bufB.as<u64>(), pl.shift2, pl.P2))) return rc;
+            ctx->mark("scatter2");
+            fkeys = ctx->bufB.as<u64>();
+            scratch = ctx->bufA.as<u32>();
+            hipLaunchKernelGGL(k_final_offsets, dim3((pl.F + 256) / 256), dim3(256), 0, ctx->stream, ctx->mat2.as<u32>(),
+                               ctx->seg.as<SegInfo>(), pl.P2, 0u, sc + SC_MLEN2, ctx->fstart.as<u32>(), pl.F);
+        } else {
+            hipLaunchKernelGGL(k_final_offsets, dim3((pl.F + 256) / 256), dim3(256), 0, ctx->stream, ctx->mat1.as<u32>(),
+                               (const SegInfo*)nullptr, pl.P1, nch1, sc + SC_MLEN1, ctx->fstart.as<u32>(), pl.F);
+        }
+        CKL("k_final_offsets");
+        ctx->mark("offsets");
+        // ---------------- count
+        CountParams cp;
+        cp.F = pl.F; cp.slot_shift = pl.slot_shift;
+        cp.amin = ctx->cfg.abundance_min; cp.amax = ctx->cfg.abundance_max; cp.histo_max = ctx->cfg.histo_max;
+        const unsigned cgrid = (unsigned)std::min<u64>(pl.F, (u64)ctx->num_cu * 3);
+        hipLaunchKernelGGL(k_count<W>, dim3(cgrid), dim3(CNT_NT), 0, ctx->stream, fkeys, ctx->fstart.as<u32>(), scratch,
+                           ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), sc + SC_OVERFLOW, cp);
+        CKL("k_count");
+        ctx->mark("count");
+        if ((rc = run_scan(ctx, ctx->nsolid.as<u32>(), sc + SC_F, pl.F))) return rc;
+        ctx->mark("scan_solid");
+        // ---------------- host sync: sizes
+        u32 h_ovf = 0, h_nsolid = 0, h_nk = 0; u64 h_stats[4];
+        CK(hipMemcpyAsync(&h_ovf, sc + SC_OVERFLOW, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(&h_nsolid, ctx->nsolid.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(&h_nk, ctx->fstart.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(h_stats, ctx->gstats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        if (h_ovf) {
+            ctx->resolve_marks();
+            if (attempt >= 3) return fail(ctx, DSKGPU_E_OVERFLOW, "hash table overflow after 3 retries");
+            extra_bits += 1;
+            ctx->stats.n_retries += 1;
+            ctx->mark("start");
+            continue;
+        }
+        // ---------------- dense rows + sort
+        const u64 ns = h_nsolid;
+        CK(ctx->out_lo.ensure((ns + 1) * 8));
+        CK(ctx->out_ab.ensure((ns + 1) * 4));
+        hipLaunchKernelGGL(k_compact<W>, dim3((pl.F + 3) / 4), dim3(256), 0, ctx->stream, fkeys, scratch, ctx->fstart.as<u32>(),
+                           ctx->nsolid.as<u32>(), pl.F, ctx->out_lo.as<u64>(), (u64*)nullptr, ctx->out_ab.as<u32>());
+        CKL("k_compact");
+        ctx->mark("compact");
+        if ((rc = sort_rows_1(ctx, ns))) return rc;
+        ctx->mark("sort");
+        ctx->hist.assign((size_t)ctx->cfg.histo_max + 1, 0);
+        CK(hipMemcpyAsync(ctx->hist.data(), ctx->ghist.p, ctx->hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        ctx->resolve_marks();
+        ctx->n_rows = ns;
+        ctx->stats.n_bytes = from_reads ? ctx->n_bytes : 0;
+        ctx->stats.n_kmers = h_nk;
+        ctx->stats.n_distinct = h_stats[0];
+        ctx->stats.n_solid = ns;
+        ctx->stats.n_levels = (u32)pl.levels;
+        ctx->stats.n_final_bins = pl.F;
+        u32 np = ctx->cfg.nb_partitions ? ctx->cfg.nb_partitions : 4u;
+        ctx->stats.n_partitions = np;
+        ctx->have_result = true;
+        return DSKGPU_OK;
+    }
+}
+
+}  // namespace
+
+// =============================================================== C-ABI
+extern "C" {
+
+const char* dskgpu_version(void) { return DSKGPU_VERSION; }
+
+const char* dskgpu_last_error(const dskgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out) {
+    if (!cfg || !out) { g_create_err = "null argument"; return DSKGPU_E_ARG; }
+    *out = nullptr;
+    if (cfg->kmer_size < 1 || cfg->kmer_size > 64) { g_create_err = "kmer_size must be in 1..64"; return DSKGPU_E_ARG; }
+    const u32 ws = cfg->world_size ? cfg->world_size : 1;
+    if ((ws & (ws - 1)) != 0 || ws > 64 || cfg->rank >= ws) { g_create_err = "world_size must be a power of two <= 64 and rank < world_size"; return DSKGPU_E_ARG; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) { g_create_err = std::string("no HIP device: ") + hipGetErrorString(e); return DSKGPU_E_DEVICE; }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_err = "bad device ordinal"; return DSKGPU_E_ARG; }
+    e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return DSKGPU_E_DEVICE; }
+    dskgpu_ctx* ctx = new dskgpu_ctx();
+    ctx->cfg = *cfg;
+    ctx->cfg.world_size = ws;
+    if (ctx->cfg.histo_max == 0) ctx->cfg.histo_max = 10000;
+    if (ctx->cfg.abundance_max == 0) ctx->cfg.abundance_max = 0x7FFFFFFFu;
+    if (ctx->cfg.minimizer_size == 0) ctx->cfg.minimizer_size = 10;
+    ctx->W = cfg->kmer_size <= 32 ? 1 : 2;
+    ctx->gbits = ceil_log2_u64(ws);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_create_err = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete ctx; return DSKGPU_E_DEVICE; }
+    ctx->own_stream = true;
+    *out = ctx;
+    return DSKGPU_OK;
+}
+
+void dskgpu_destroy(dskgpu_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = {&ctx->reads_own, &ctx->packed, &ctx->inval, &ctx->bufA, &ctx->bufB, &ctx->mat1, &ctx->mat2, &ctx->sums,
+                      &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats,
+                      &ctx->out_lo, &ctx->out_hi, &ctx->out_ab, &ctx->srt_lo, &ctx->srt_hi, &ctx->srt_ab, &ctx->srt_tmp,
+                      &ctx->srt_idx, &ctx->srt_idx2};
+    for (DevBuf* b : bufs) b->release();
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int dskgpu_set_stream(dskgpu_ctx* ctx, void* hip_stream) {
+    if (!ctx) return DSKGPU_E_ARG;
+    CK(hipSetDevice(ctx->cfg.device));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (hip_stream) {
+        if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+        ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    } else if (!ctx->own_stream) {
+        CK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return DSKGPU_OK;
+}
+
+int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
+    if (!ctx || (!bytes && nbytes)) return DSKGPU_E_ARG;
+    CK(hipSetDevice(ctx->cfg.device));
+    const u64 need = ctx->reads_len + nbytes + 1;
+    if (need > ctx->reads_own.cap) {
+        DevBuf nb;
+        CK(nb.ensure(std::max<u64>(need, ctx->reads_own.cap * 2)));
+        if (ctx->reads_len) CK(hipMemcpyAsync(nb.p, ctx->reads_own.p, ctx->reads_len, hipMemcpyDeviceToDevice, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        ctx->reads_own.release();
+        ctx->reads_own = nb;
+    }
+    uint8_t* dst = ctx->reads_own.as<uint8_t>();
+    if (nbytes) CK(hipMemcpyAsync(dst + ctx->reads_len, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemsetAsync(dst + ctx->reads_len + nbytes, '\n', 1, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->reads_len += nbytes + 1;
+    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len;
+    return DSKGPU_OK;
+}
+
+int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes) {
+    if (!ctx || (!d_bytes && nbytes)) return DSKGPU_E_ARG;
+    ctx->d_reads = static_cast<const uint8_t*>(d_bytes);
+    ctx->n_bytes = nbytes;
+    ctx->reads_len = 0;
+    return DSKGPU_OK;
+}
+
+int dskgpu_count(dskgpu_ctx* ctx) {
+    if (!ctx) return DSKGPU_E_ARG;
+    if (ctx->cfg.world_size != 1) return fail(ctx, DSKGPU_E_STATE, "dskgpu_count needs world_size == 1; use dskgpu_mg_scatter/_mg_count");
+    CK(hipSetDevice(ctx->cfg.device));
+    ctx->stats = dskgpu_stats{};
+    if (ctx->W == 1) return run_pipeline<1>(ctx, true, nullptr, 0);
+    return fail(ctx, DSKGPU_E_ARG, "kmer_size > 32 not implemented yet");
+}
+
+uint64_t dskgpu_mg_send_capacity_words(const dskgpu_ctx* ctx) {
+    return ctx ? (ctx->n_bytes + 1) * (u64)ctx->W : 0;
+}
+
+int dskgpu_mg_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t* send_words) {
+    if (!ctx || !d_send || !send_words) return DSKGPU_E_ARG;
+    if (ctx->cfg.world_size < 2) return fail(ctx, DSKGPU_E_STATE, "dskgpu_mg_scatter needs world_size >= 2");
+    if (ctx->W != 1) return fail(ctx, DSKGPU_E_ARG, "kmer_size > 32 not implemented yet");
+    if (capacity_words < dskgpu_mg_send_capacity_words(ctx)) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
+    CK(hipSetDevice(ctx->cfg.device));
+    ctx->st_names.clear(); ctx->st_ms.clear(); ctx->marks.clear(); ctx->ev_used = 0;
+    ctx->mark("start");
+    u64 nwords = 0;
+    int rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords);
+    if (rc) return rc;
+    ctx->mark("encode");
+    const u32 G = ctx->cfg.world_size;
+    u32 nch1 = 0;
+    build_descs1(ctx, nwords, SC_TILE_WORDS, (u64)ctx->num_cu * 8, &nch1);
+    const u64 M1 = (u64)G * nch1;
+    CK(ctx->scalars.ensure(SC_COUNT * 4));
+    CK(ctx->descs1.ensure(ctx->h_descs1.size() * sizeof(ChunkDesc)));
+    CK(hipMemcpyAsync(ctx->descs1.p, ctx->h_descs1.data(), ctx->h_descs1.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
+    u32* h_sc = ctx->h_sc;
+    std::memset(h_sc, 0, sizeof(ctx->h_sc));
+    h_sc[SC_NCH1] = nch1; h_sc[SC_MLEN1] = (u32)M1;
+    u32* sc = ctx->scalars.as<u32>();
+    CK(hipMemcpyAsync(sc, h_sc, sizeof(ctx->h_sc), hipMemcpyHostToDevice, ctx->stream));
+    CK(ctx->mat1.ensure((M1 + 1) * 4));
+    const int shift = 64 - ctx->gbits;
+    if ((rc = launch_hist<1, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), shift, G))) return rc;
+    ctx->mark("mg_hist");
+    if ((rc = run_scan(ctx, ctx->mat1.as<u32>(), sc + SC_MLEN1, M1))) return rc;
+    if ((rc = launch_scatter<1, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), static_cast<u64*>(d_send), shift, G))) return rc;
+    ctx->mark("mg_scatter");
+    std::vector<u32> starts(G + 1);
+    for (u32 o = 0; o <= G; ++o)
+        CK(hipMemcpyAsync(&starts[o], ctx->mat1.as<u32>() + (u64)o * nch1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->resolve_marks();
+    for (u32 o = 0; o < G; ++o) send_words[o] = (u64)(starts[o + 1] - starts[o]);
+    return DSKGPU_OK;
+}
+
+int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words) {
+    if (!ctx || (!d_recv && recv_words)) return DSKGPU_E_ARG;
+    if (ctx->W != 1) return fail(ctx, DSKGPU_E_ARG, "kmer_size > 32 not implemented yet");
+    CK(hipSetDevice(ctx->cfg.device));
+    ctx->stats = dskgpu_stats{};
+    return run_pipeline<1>(ctx, false, static_cast<const u64*>(d_recv), recv_words);
+}
+
+int dskgpu_get_stats(const dskgpu_ctx* ctx, dskgpu_stats* out) {
+    if (!ctx || !out) return DSKGPU_E_ARG;
+    if (!ctx->have_result) return DSKGPU_E_STATE;
+    *out = ctx->stats;
+    return DSKGPU_OK;
+}
+
+int dskgpu_histogram(const dskgpu_ctx* ctx, uint64_t* out, uint32_t nbins) {
+    if (!ctx || !out) return DSKGPU_E_ARG;
+    if (!ctx->have_result) return DSKGPU_E_STATE;
+    if (nbins != ctx->cfg.histo_max + 1) return DSKGPU_E_ARG;
+    std::memcpy(out, ctx->hist.data(), (size_t)nbins * 8);
+    return DSKGPU_OK;
+}
+
+uint32_t dskgpu_num_partitions(const dskgpu_ctx* ctx) { return (ctx && ctx->have_result) ? ctx->stats.n_partitions : 0; }
+
+static void part_range(const dskgpu_ctx* ctx, uint32_t p, u64* b, u64* e) {
+    const u64 P = ctx->stats.n_partitions, n = ctx->n_rows;
+    *b = n * p / P; *e = n * (p + 1) / P;
+}
+
+uint64_t dskgpu_partition_size(const dskgpu_ctx* ctx, uint32_t p) {
+    if (!ctx || !ctx->have_result || p >= ctx->stats.n_partitions) return 0;
+    u64 b, e; part_range(ctx, p, &b, &e); return e - b;
+}
+
+int dskgpu_partition_copy(const dskgpu_ctx* cctx, uint32_t p, uint64_t* kmers, uint32_t* abundance) {
+    dskgpu_ctx* ctx = const_cast<dskgpu_ctx*>(cctx);
+    if (!ctx) return DSKGPU_E_ARG;
+    if (!ctx->have_result) return DSKGPU_E_STATE;
+    if (p >= ctx->stats.n_partitions) return DSKGPU_E_ARG;
+    u64 b, e; part_range(ctx, p, &b, &e);
+    const u64 n = e - b;
+    if (n == 0) return DSKGPU_OK;
+    CK(hipSetDevice(ctx->cfg.device));
+    if (kmers) {
+        if (ctx->W == 1) CK(hipMemcpy(kmers, ctx->res_lo + b, n * 8, hipMemcpyDeviceToHost));
+        else {
+            // rows are (lo, hi) pairs on the host side
+            std::vector<u64> lo(n), hi(n);
+            CK(hipMemcpy(lo.data(), ctx->res_lo + b, n * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hi.data(), ctx->res_hi + b, n * 8, hipMemcpyDeviceToHost));
+            for (u64 i = 0; i < n; ++i) { kmers[2 * i] = lo[i]; kmers[2 * i + 1] = hi[i]; }
+        }
+    }
+    if (abundance) CK(hipMemcpy(abundance, ctx->res_ab + b, n * 4, hipMemcpyDeviceToHost));
+    return DSKGPU_OK;
+}
+
+int dskgpu_result_device(const dskgpu_ctx* ctx, const void** d_kmers, const void** d_abundance, uint64_t* n_rows) {
+    if (!ctx) return DSKGPU_E_ARG;
+    if (!ctx->have_result) return DSKGPU_E_STATE;
+    if (d_kmers) *d_kmers = ctx->res_lo;
+    if (d_abundance) *d_abundance = ctx->res_ab;
+    if (n_rows) *n_rows = ctx->n_rows;
+    return DSKGPU_OK;
+}
+
+int dskgpu_stage_times(const dskgpu_ctx* ctx, const char** names, float* ms, int cap) {
+    if (!ctx) return DSKGPU_E_ARG;
+    const int n = (int)ctx->st_names.size();
+    for (int i = 0; i < n && i < cap; ++i) { if (names) names[i] = ctx->st_names[i]; if (ms) ms[i] = ctx->st_ms[i]; }
+    return n;
+}
+
+int dskgpu_k_encode(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, void* d_packed, void* d_invalid) {
+    if (!ctx || !d_packed || !d_invalid) return DSKGPU_E_ARG;
+    CK(hipSetDevice(ctx->cfg.device));
+    u64 nwords = 0;
+    int rc = run_encode(ctx, static_cast<const uint8_t*>(d_bytes), nbytes, &nwords);
+    if (rc) return rc;
+    CK(hipMemcpyAsync(d_packed, ctx->packed.p, nwords * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    CK(hipMemcpyAsync(d_invalid, ctx->inval.p, nwords * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return DSKGPU_OK;
+}
+
+int dskgpu_k_enumerate(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, void* d_kmers, void* d_valid) {
+    if (!ctx || !d_kmers || !d_valid) return DSKGPU_E_ARG;
+    CK(hipSetDevice(ctx->cfg.device));
+    u64 nwords = 0;
+    int rc = run_encode(ctx, static_cast<const uint8_t*>(d_bytes), nbytes, &nwords);
+    if (rc) return rc;
+    if (nwords) {
+        const unsigned grid = (unsigned)((nwords * 2 + 255) / 256);
+        if (ctx->W == 1)
+            hipLaunchKernelGGL(k_enumerate<1>, dim3(grid), dim3(256), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(),
+                               nwords, (u64)nbytes, (int)ctx->cfg.kmer_size, static_cast<u64*>(d_kmers), static_cast<uint8_t*>(d_valid));
+        else
+            hipLaunchKernelGGL(k_enumerate<2>, dim3(grid), dim3(256), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(),
+                               nwords, (u64)nbytes, (int)ctx->cfg.kmer_size, static_cast<u64*>(d_kmers), static_cast<uint8_t*>(d_valid));
+        CKL("k_enumerate");
+    }
+    CK(hipStreamSynchronize(ctx->stream));
+    return DSKGPU_OK;
+}
+
+int dskgpu_k_minimizers(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, void* d_minim, void* d_valid) {
+    (void)d_bytes; (void)nbytes; (void)d_minim; (void)d_valid;
+    if (!ctx) return DSKGPU_E_ARG;
+    return fail(ctx, DSKGPU_E_ARG, "k_minimizers not implemented yet");
+}
+
+}  // extern "C"

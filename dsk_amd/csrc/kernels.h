@@ -1,0 +1,547 @@
+// kernels.h -- HIP kernels of the count path (gfx950 / MI355X, wave64).
+//
+// Pipeline (all buffers resident in HBM; replaces the disk partitions of
+// doc/paper.tex:60-97 and gatb-core's fillPartitions / fillSolidKmers stages
+// named at scripts/quick-build.sh:52-57):
+//
+//   k_encode        ASCII read stream -> 2-bit packed + invalid mask          (K1)
+//   k_hist_*        per-chunk digit histogram  (LDS histogram, no global atomics) (K3, "PartiInfo")
+//   k_scan_*        exclusive scan of the (bin-major) chunk x bin matrix
+//   k_scatter_*     LDS-staged radix scatter into partition-contiguous HBM    (K4)
+//   k_plan_*        chunk descriptors of the next level from the scanned matrix
+//   k_count         per-sub-partition open-addressing hash aggregate in LDS,
+//                   histogram + solidity filter fused into the table sweep    (K5+K6)
+//   k_compact       gather solid rows to a dense array, un-mix the keys
+//
+// Keys in the partition arrays are h = kmix(canonical k-mer) (bijective), so a
+// radix digit is (h >> shift) & mask and the table slot another bit field of h.
+// Work is split into static "chunks"; chunk c of segment s owns matrix entries
+// flat_base + bin*stride, laid out so that ONE linear exclusive scan yields
+// every (segment, bin, chunk) destination offset: no global atomics, and the
+// output order of each level is deterministic.
+#pragma once
+#include "kmer_device.h"
+
+#define SC_NT 512            // threads of hist/scatter blocks
+#define SC_KPT 16            // keys per thread per tile
+#define SC_TILE (SC_NT * SC_KPT)   // 8192 keys (or read positions) per tile
+#define SC_TILE_WORDS (SC_TILE / 32)
+#define MAX_BINS 2048
+
+struct ChunkDesc {
+    u64 begin, end;          // source range: packed words (reads) or keys
+    u32 flat_base;           // matrix entry of bin 0
+    u32 stride;              // matrix stride between bins (= chunks in the segment)
+};
+
+// ------------------------------------------------------------------ K1
+// One thread encodes 32 bases (two 16-byte loads) into one packed word.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void k_encode(const uint8_t* __restrict__ s, u64 n,
+                                                u64* __restrict__ packed, u32* __restrict__ inval, u64 nwords) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += stride) {
+        const u64 base = w * 32;
+        u32 x[8];
+        if (ALIGNED && base + 32 <= n) {
+            const uint4 a = *reinterpret_cast<const uint4*>(s + base);
+            const uint4 b = *reinterpret_cast<const uint4*>(s + base + 16);
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                u32 v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const u64 p = base + q * 4 + b;
+                    const u32 c = p < n ? s[p] : (u32)'\n';
+                    v |= c << (8 * b);
+                }
+                x[q] = v;
+            }
+        }
+        u64 pk = 0; u32 iv = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const u32 c = (x[q] >> (8 * b)) & 0xFFu;
+                const u32 code = (c >> 1) & 3u;
+                // upper-cased byte must equal "ACTG"[code]
+                const u32 expect = (0x47544341u >> (8 * code)) & 0xFFu;
+                const u32 bad = ((c & 0xDFu) != expect) ? 1u : 0u;
+                const int j = q * 4 + b;
+                pk |= (u64)code << (62 - 2 * j);
+                iv |= bad << (31 - j);
+            }
+        }
+        packed[w] = pk;
+        inval[w] = iv;
+    }
+}
+
+// ------------------------------------------------------------------ block scan helper
+// Exclusive scan of cnt[0..P) (LDS) into off[0..P); returns the total in *tot.
+template <int NT>
+__device__ __forceinline__ void block_excl_scan(const u32* cnt, u32* off, int P, u32* wsum, u32* tot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ipt = (P + NT - 1) / NT;
+    const int base = tid * ipt;
+    u32 v[4]; u32 s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = base + j;
+        v[j] = (j < ipt && idx < P) ? cnt[idx] : 0u;
+        s += v[j];
+    }
+    u32 inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        const u32 x = lane < NT / 64 ? wsum[lane] : 0u;
+        u32 y = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(y, d); if (lane >= d) y += t; }
+        if (lane < NT / 64) wsum[lane] = y - x;
+        if (lane == NT / 64 - 1) *tot = y;
+    }
+    __syncthreads();
+    u32 run = wsum[wave] + inc - s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = base + j;
+        if (j < ipt && idx < P) { off[idx] = run; run += v[j]; }
+    }
+}
+
+// ------------------------------------------------------------------ key sources
+// READS: chunk range is in packed words; a tile is SC_TILE_WORDS words; thread
+// tid handles word (tid>>1), half (tid&1) -> 16 window end positions.
+template <int W> struct KeyT;
+template <> struct KeyT<1> { typedef u64 T; };
+template <> struct KeyT<2> { typedef K2 T; };
+
+__device__ __forceinline__ u64 digit_word(u64 h) { return h; }
+__device__ __forceinline__ u64 digit_word(const K2& h) { return h.hi; }
+
+template <int W>
+__device__ __forceinline__ u32 tile_keys_reads(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                               u64 w0, u64 wend, int k, typename KeyT<W>::T (&h)[SC_KPT]);
+template <>
+__device__ __forceinline__ u32 tile_keys_reads<1>(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                                  u64 w0, u64 wend, int k, u64 (&h)[SC_KPT]) {
+    const u64 wi = w0 + (threadIdx.x >> 1);
+    if (wi >= wend) return 0u;
+    const u32 vm = gen_kmers1<SC_KPT>(packed, inval, wi, (threadIdx.x & 1) * 16, k, h);
+#pragma unroll
+    for (int j = 0; j < SC_KPT; ++j) h[j] = kmix(h[j]);
+    return vm;
+}
+template <>
+__device__ __forceinline__ u32 tile_keys_reads<2>(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                                  u64 w0, u64 wend, int k, K2 (&h)[SC_KPT]) {
+    const u64 wi = w0 + (threadIdx.x >> 1);
+    if (wi >= wend) return 0u;
+    const u32 vm = gen_kmers2<SC_KPT>(packed, inval, wi, (threadIdx.x & 1) * 16, k, h);
+#pragma unroll
+    for (int j = 0; j < SC_KPT; ++j) kmix2(h[j].hi, h[j].lo);
+    return vm;
+}
+
+// KEYS: chunk range is in keys; tile t covers keys [begin + t*SC_TILE, ...);
+// thread loads keys tid + j*SC_NT (coalesced).
+template <int W>
+__device__ __forceinline__ u32 tile_keys_array(const typename KeyT<W>::T* __restrict__ in, u64 k0, u64 kend,
+                                               typename KeyT<W>::T (&h)[SC_KPT]) {
+    u32 vm = 0;
+#pragma unroll
+    for (int j = 0; j < SC_KPT; ++j) {
+        const u64 i = k0 + threadIdx.x + (u64)j * SC_NT;
+        if (i < kend) { h[j] = in[i]; vm |= 1u << j; }
+    }
+    return vm;
+}
+
+// ------------------------------------------------------------------ K3: histogram
+// SRC 0 = reads, 1 = key array.  Persistent blocks walk chunks; per chunk an
+// LDS histogram over P bins is written to the matrix row of that chunk.
+template <int W, int SRC>
+__global__ __launch_bounds__(SC_NT) void k_hist(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                                const typename KeyT<W>::T* __restrict__ keys,
+                                                const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
+                                                u32* __restrict__ matrix, int k, int shift, u32 P) {
+    __shared__ u32 lh[MAX_BINS];
+    const u32 nchunks = *d_nchunks;
+    const u32 mask = P - 1;
+    for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
+        const ChunkDesc d = descs[g];
+        for (u32 b = threadIdx.x; b < P; b += SC_NT) lh[b] = 0;
+        __syncthreads();
+        const u64 step = SRC == 0 ? SC_TILE_WORDS : SC_TILE;
+        for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
+            typename KeyT<W>::T h[SC_KPT];
+            u32 vm;
+            if (SRC == 0) vm = tile_keys_reads<W>(packed, inval, t0, d.end, k, h);
+            else vm = tile_keys_array<W>(keys, t0, d.end, h);
+#pragma unroll
+            for (int j = 0; j < SC_KPT; ++j)
+                if (vm & (1u << j)) atomicAdd(&lh[(u32)(digit_word(h[j]) >> shift) & mask], 1u);
+        }
+        __syncthreads();
+        for (u32 b = threadIdx.x; b < P; b += SC_NT) matrix[d.flat_base + (u64)b * d.stride] = lh[b];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ scan (3 kernels)
+#define SCAN_NT 256
+#define SCAN_IPT 16
+#define SCAN_BLK (SCAN_NT * SCAN_IPT)
+
+__global__ __launch_bounds__(SCAN_NT) void k_scan_reduce(const u32* __restrict__ a, const u32* __restrict__ d_len,
+                                                         u32* __restrict__ sums) {
+    __shared__ u32 ws[SCAN_NT / 64];
+    const u64 len = *d_len;
+    const u64 b0 = (u64)blockIdx.x * SCAN_BLK;
+    if (b0 >= len) return;
+    u32 s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; ++j) {
+        const u64 i = b0 + threadIdx.x + (u64)j * SCAN_NT;
+        if (i < len) s += a[i];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 t = 0; for (int i = 0; i < SCAN_NT / 64; ++i) t += ws[i]; sums[blockIdx.x] = t; }
+}
+
+// single block: exclusive scan of the block sums; total -> a[len]
+__global__ __launch_bounds__(1024) void k_scan_sums(u32* __restrict__ sums, const u32* __restrict__ d_len,
+                                                    u32* __restrict__ a) {
+    __shared__ u32 ws[16]; __shared__ u32 carry_s;
+    const u64 len = *d_len;
+    const u32 nb = (u32)((len + SCAN_BLK - 1) / SCAN_BLK);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (u32 c0 = 0; c0 < nb; c0 += 1024) {
+        const u32 i = c0 + threadIdx.x;
+        const u32 x = i < nb ? sums[i] : 0u;
+        u32 y = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(y, d); if (lane >= d) y += t; }
+        if (lane == 63) ws[wave] = y;
+        __syncthreads();
+        if (wave == 0) {
+            const u32 wx = lane < 16 ? ws[lane] : 0u; u32 wy = wx;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) { const u32 t = __shfl_up(wy, d); if (lane >= d) wy += t; }
+            if (lane < 16) ws[lane] = wy - wx;
+        }
+        __syncthreads();
+        const u32 carry = carry_s;
+        const u32 excl = carry + ws[wave] + y - x;
+        if (i < nb) sums[i] = excl;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = excl + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a[len] = carry_s;
+}
+
+__global__ __launch_bounds__(SCAN_NT) void k_scan_apply(u32* __restrict__ a, const u32* __restrict__ d_len,
+                                                        const u32* __restrict__ sums) {
+    __shared__ u32 ws[SCAN_NT / 64];
+    const u64 len = *d_len;
+    const u64 b0 = (u64)blockIdx.x * SCAN_BLK;
+    if (b0 >= len) return;
+    // thread owns SCAN_IPT consecutive entries
+    const u64 i0 = b0 + (u64)threadIdx.x * SCAN_IPT;
+    u32 v[SCAN_IPT]; u32 s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; ++j) { v[j] = (i0 + j < len) ? a[i0 + j] : 0u; s += v[j]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 y = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(y, d); if (lane >= d) y += t; }
+    if (lane == 63) ws[wave] = y;
+    __syncthreads();
+    u32 wpre = 0;
+    for (int w = 0; w < wave; ++w) wpre += ws[w];
+    u32 run = sums[blockIdx.x] + wpre + y - s;
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; ++j) { if (i0 + j < len) a[i0 + j] = run; run += v[j]; }
+}
+
+// ------------------------------------------------------------------ K4: scatter
+// Per tile: rank keys inside their bin with one LDS atomic each, scan the tile
+// histogram, stage the tile bin-sorted in LDS, then write runs to HBM so that
+// consecutive lanes hit consecutive addresses.  Per-chunk cursors live in LDS.
+template <int W, int SRC>
+__global__ __launch_bounds__(SC_NT) void k_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                                   const typename KeyT<W>::T* __restrict__ keys,
+                                                   const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
+                                                   const u32* __restrict__ scanned,
+                                                   typename KeyT<W>::T* __restrict__ out, int k, int shift, u32 P) {
+    typedef typename KeyT<W>::T Key;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Key* stage = reinterpret_cast<Key*>(smem);                       // SC_TILE keys
+    u32* cnt = reinterpret_cast<u32*>(smem + sizeof(Key) * SC_TILE); // P
+    u32* off = cnt + P;                                              // P
+    u32* cur = off + P;                                              // P
+    u32* wsum = cur + P;                                             // 16 (+1 total)
+    u32* tot = wsum + 16;
+    const u32 nchunks = *d_nchunks;
+    const u32 mask = P - 1;
+    for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
+        const ChunkDesc d = descs[g];
+        for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] = scanned[d.flat_base + (u64)b * d.stride]; cnt[b] = 0; }
+        __syncthreads();
+        const u64 step = SRC == 0 ? SC_TILE_WORDS : SC_TILE;
+        for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
+            Key h[SC_KPT]; u32 rk[SC_KPT];
+            u32 vm;
+            if (SRC == 0) vm = tile_keys_reads<W>(packed, inval, t0, d.end, k, h);
+            else vm = tile_keys_array<W>(keys, t0, d.end, h);
+#pragma unroll
+            for (int j = 0; j < SC_KPT; ++j)
+                if (vm & (1u << j)) rk[j] = atomicAdd(&cnt[(u32)(digit_word(h[j]) >> shift) & mask], 1u);
+            __syncthreads();
+            block_excl_scan<SC_NT>(cnt, off, (int)P, wsum, tot);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < SC_KPT; ++j)
+                if (vm & (1u << j)) stage[off[(u32)(digit_word(h[j]) >> shift) & mask] + rk[j]] = h[j];
+            __syncthreads();
+            const u32 ntile = *tot;
+            for (u32 i = threadIdx.x; i < ntile; i += SC_NT) {
+                const Key hk = stage[i];
+                const u32 b = (u32)(digit_word(hk) >> shift) & mask;
+                out[(u64)cur[b] + (i - off[b])] = hk;
+            }
+            __syncthreads();
+            for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] += cnt[b]; cnt[b] = 0; }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------ plan of the next level
+// Segments of the next level = bins of this level.  seg s spans
+// [src[s*sstride], src[(s+1)*sstride]) of the key array.  One block.
+struct SegInfo { u32 start, nch, chunk_base, pad; };
+
+__global__ __launch_bounds__(1024) void k_plan(const u32* __restrict__ src, u32 sstride, u32 S, u32 CH, u32 P,
+                                               SegInfo* __restrict__ seg, ChunkDesc* __restrict__ descs,
+                                               u32* __restrict__ d_nchunks, u32* __restrict__ d_mlen) {
+    __shared__ u32 ws[16]; __shared__ u32 carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (u32 s0 = 0; s0 < S; s0 += 1024) {
+        const u32 s = s0 + threadIdx.x;
+        u32 start = 0, size = 0, nch = 0;
+        if (s < S) { start = src[(u64)s * sstride]; size = src[(u64)(s + 1) * sstride] - start; nch = (size + CH - 1) / CH; }
+        u32 y = nch;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(y, d); if (lane >= d) y += t; }
+        if (lane == 63) ws[wave] = y;
+        __syncthreads();
+        if (wave == 0) {
+            const u32 wx = lane < 16 ? ws[lane] : 0u; u32 wy = wx;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) { const u32 t = __shfl_up(wy, d); if (lane >= d) wy += t; }
+            if (lane < 16) ws[lane] = wy - wx;
+        }
+        __syncthreads();
+        const u32 cb = carry_s + ws[wave] + y - nch;
+        if (s < S) {
+            SegInfo si; si.start = start; si.nch = nch; si.chunk_base = cb; si.pad = 0;
+            seg[s] = si;
+            for (u32 c = 0; c < nch; ++c) {
+                ChunkDesc d;
+                d.begin = (u64)start + (u64)c * CH;
+                const u64 e = d.begin + CH, lim = (u64)start + size;
+                d.end = e < lim ? e : lim;
+                d.flat_base = cb * P + c;
+                d.stride = nch;
+                descs[cb + c] = d;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = cb + nch;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { *d_nchunks = carry_s; *d_mlen = carry_s * P; }
+}
+
+// start offset of every final sub-partition q (F+1 entries)
+// one level  (seg == nullptr): fstart[q] = scanned[q * stride1]            (q == F -> total)
+// two levels: q = s*P + b -> scanned[chunk_base[s]*P + b*nch[s]]  (empty segment: its start)
+__global__ void k_final_offsets(const u32* __restrict__ scanned, const SegInfo* __restrict__ seg,
+                                u32 P, u32 stride1, const u32* __restrict__ d_mlen,
+                                u32* __restrict__ fstart, u32 F) {
+    const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > F) return;
+    if (seg == nullptr) { fstart[q] = scanned[(u64)q * stride1]; return; }
+    if (q == F) { fstart[q] = scanned[*d_mlen]; return; }
+    const u32 s = q / P, b = q % P;
+    const SegInfo si = seg[s];
+    fstart[q] = si.nch ? scanned[(u64)si.chunk_base * P + (u64)b * si.nch] : si.start;
+}
+
+// ------------------------------------------------------------------ K5+K6: hash aggregate
+#define CNT_NT 512
+#define CNT_SLOTS 4096
+#define CNT_MAXLOAD 3584          // distinct keys allowed per table (0.875)
+#define CNT_LH 512                // histogram bins kept in LDS
+
+struct CountParams {
+    u32 F; int slot_shift;
+    u32 amin, amax, histo_max;
+};
+
+// One persistent block per sub-partition in turn: insert keys (64-bit LDS CAS +
+// LDS add), then sweep the table once: histogram every distinct key, keep the
+// solid ones (wave ballot + prefix for the slot claim) and write them IN PLACE
+// over the partition's own key range, abundance to `abund` at the same index.
+template <int W>
+__global__ __launch_bounds__(CNT_NT) void k_count(typename KeyT<W>::T* __restrict__ keys, const u32* __restrict__ fstart,
+                                                  u32* __restrict__ abund, u32* __restrict__ nsolid,
+                                                  u64* __restrict__ ghist, u64* __restrict__ gstats,
+                                                  u32* __restrict__ overflow, CountParams cp);
+
+template <>
+__global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* __restrict__ keys, const u32* __restrict__ fstart,
+                                                     u32* __restrict__ abund, u32* __restrict__ nsolid,
+                                                     u64* __restrict__ ghist, u64* __restrict__ gstats,
+                                                     u32* __restrict__ overflow, CountParams cp) {
+    __shared__ u64 tk[CNT_SLOTS];
+    __shared__ u32 tc[CNT_SLOTS];
+    __shared__ u32 lh[CNT_LH];
+    __shared__ u32 s_ndist, s_out, s_ovf;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int b = tid; b < CNT_LH; b += CNT_NT) lh[b] = 0;
+    u32 ones = 0;          // per-lane-0 count of abundance-1 keys (register, flushed at the end)
+    u64 ndist_acc = 0;
+    for (u32 q = blockIdx.x; q < cp.F; q += gridDim.x) {
+        const u32 begin = fstart[q], end = fstart[q + 1];
+        if (begin == end) { if (tid == 0) nsolid[q] = 0; continue; }
+        for (int s = tid; s < CNT_SLOTS; s += CNT_NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
+        if (tid == 0) { s_ndist = 0; s_out = 0; s_ovf = 0; }
+        __syncthreads();
+        for (u32 i = begin + tid; i < end; i += CNT_NT) {
+            const u64 h = keys[i];
+            u32 slot = (u32)(h >> cp.slot_shift) & (CNT_SLOTS - 1);
+            int probe = 0;
+            for (; probe < CNT_SLOTS; ++probe) {
+                u64 old = tk[slot];
+                if (old == DSK_EMPTY) {
+                    old = atomicCAS(&tk[slot], DSK_EMPTY, h);
+                    if (old == DSK_EMPTY) { atomicAdd(&s_ndist, 1u); old = h; }
+                }
+                if (old == h) { atomicAdd(&tc[slot], 1u); break; }
+                slot = (slot + 1) & (CNT_SLOTS - 1);
+            }
+            if (probe == CNT_SLOTS) s_ovf = 1;
+        }
+        __syncthreads();
+        const u32 nd = s_ndist;
+        if (s_ovf || nd > CNT_MAXLOAD) {          // block-uniform
+            if (tid == 0) { *overflow = 1; nsolid[q] = 0; }
+            __syncthreads();
+            continue;
+        }
+        for (int s0 = 0; s0 < CNT_SLOTS; s0 += CNT_NT) {
+            const u64 key = tk[s0 + tid];
+            const u32 c = tc[s0 + tid];
+            const bool occ = key != DSK_EMPTY;
+            const u64 m1 = __ballot(occ && c == 1);
+            if (lane == 0) ones += __popcll(m1);
+            if (occ && c > 1) {
+                const u32 bin = c < cp.histo_max ? c : cp.histo_max;
+                if (bin < CNT_LH) atomicAdd(&lh[bin], 1u);
+                else atomicAdd(&ghist[bin], 1ull);
+            }
+            const bool solid = occ && c >= cp.amin && c <= cp.amax;
+            const u64 ms = __ballot(solid);
+            if (ms) {
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(&s_out, (u32)__popcll(ms));
+                base = __shfl(base, 0);
+                if (solid) {
+                    const u32 pos = base + __popcll(ms & ((1ull << lane) - 1));
+                    keys[begin + pos] = key;
+                    abund[begin + pos] = c;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { nsolid[q] = s_out; ndist_acc += nd; }
+        __syncthreads();
+    }
+    // flush block-local histogram
+    if (lane == 0 && ones) atomicAdd(&lh[1], ones);
+    __syncthreads();
+    for (int b = tid; b < CNT_LH; b += CNT_NT) {
+        const u32 v = lh[b];
+        if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
+    }
+    if (tid == 0 && ndist_acc) atomicAdd(&gstats[0], ndist_acc);
+}
+
+// ------------------------------------------------------------------ compaction
+// One wave per sub-partition: copy its solid rows to the dense output and
+// restore the k-mer from the mixed key.  soff = exclusive scan of the per-
+// sub-partition solid counts (F+1 entries).
+template <int W>
+__global__ __launch_bounds__(256) void k_compact(const typename KeyT<W>::T* __restrict__ keys, const u32* __restrict__ abund,
+                                                 const u32* __restrict__ fstart, const u32* __restrict__ soff, u32 F,
+                                                 u64* __restrict__ out_lo, u64* __restrict__ out_hi, u32* __restrict__ out_ab);
+template <>
+__global__ __launch_bounds__(256) void k_compact<1>(const u64* __restrict__ keys, const u32* __restrict__ abund,
+                                                    const u32* __restrict__ fstart, const u32* __restrict__ soff, u32 F,
+                                                    u64* __restrict__ out_lo, u64* __restrict__ out_hi, u32* __restrict__ out_ab) {
+    const u32 q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= F) return;
+    const u32 o = soff[q], ns = soff[q + 1] - o, b = fstart[q];
+    for (u32 i = lane; i < ns; i += 64) {
+        out_lo[o + i] = kunmix(keys[b + i]);
+        out_ab[o + i] = abund[b + i];
+    }
+}
+
+// ------------------------------------------------------------------ test kernels
+// canonical k-mer + validity for the window ending at every byte
+template <int W>
+__global__ __launch_bounds__(256) void k_enumerate(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                                   u64 nwords, u64 nbytes, int k, u64* __restrict__ out, uint8_t* __restrict__ valid) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 wi = t >> 1;
+    if (wi >= nwords) return;
+    const int t0 = (int)(t & 1) * 16;
+    u32 vm;
+    if (W == 1) {
+        u64 c[16];
+        vm = gen_kmers1<16>(packed, inval, wi, t0, k, c);
+        for (int j = 0; j < 16; ++j) {
+            const u64 p = wi * 32 + t0 + j;
+            if (p < nbytes) { const bool v = vm & (1u << j); out[p] = v ? c[j] : 0ull; valid[p] = v; }
+        }
+    } else {
+        K2 c[16];
+        vm = gen_kmers2<16>(packed, inval, wi, t0, k, c);
+        for (int j = 0; j < 16; ++j) {
+            const u64 p = wi * 32 + t0 + j;
+            if (p < nbytes) {
+                const bool v = vm & (1u << j);
+                out[2 * p] = v ? c[j].lo : 0ull; out[2 * p + 1] = v ? c[j].hi : 0ull; valid[p] = v;
+            }
+        }
+    }
+}

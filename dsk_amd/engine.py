@@ -1,0 +1,252 @@
+"""ctypes binding of include/dskgpu.h.
+
+`KmerCounter` mirrors the one call the reference makes on this path,
+`SortingCountAlgorithm<span>(bank, props).execute()` (src/DSK.cpp:55-60), and
+the read-back done by dsk2ascii (utils/dsk2ascii.cpp:61-104): rows of
+(kmer value, abundance) per "solid" partition plus the abundance histogram.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class DskGpuError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"dskgpu error {code}: {msg}")
+        self.code = code
+
+
+class _Config(C.Structure):
+    _fields_ = [
+        ("kmer_size", C.c_uint32),
+        ("abundance_min", C.c_uint32),
+        ("abundance_max", C.c_uint32),
+        ("histo_max", C.c_uint32),
+        ("device", C.c_int32),
+        ("nb_partitions", C.c_uint32),
+        ("minimizer_size", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("world_size", C.c_uint32),
+        ("rank", C.c_uint32),
+        ("reserved", C.c_uint32 * 6),
+    ]
+
+
+class _Stats(C.Structure):
+    _fields_ = [
+        ("n_bytes", C.c_uint64),
+        ("n_kmers", C.c_uint64),
+        ("n_distinct", C.c_uint64),
+        ("n_solid", C.c_uint64),
+        ("n_partitions", C.c_uint32),
+        ("n_levels", C.c_uint32),
+        ("n_final_bins", C.c_uint32),
+        ("n_retries", C.c_uint32),
+        ("reserved", C.c_uint64 * 4),
+    ]
+
+
+F_TIMING = 1
+F_NO_SORT = 2
+
+# every symbol include/dskgpu.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "dskgpu_create", "dskgpu_destroy", "dskgpu_last_error", "dskgpu_version", "dskgpu_set_stream",
+    "dskgpu_push_reads", "dskgpu_set_reads_device", "dskgpu_count", "dskgpu_mg_scatter",
+    "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_get_stats", "dskgpu_histogram",
+    "dskgpu_num_partitions", "dskgpu_partition_size", "dskgpu_partition_copy", "dskgpu_result_device",
+    "dskgpu_stage_times", "dskgpu_k_encode", "dskgpu_k_enumerate", "dskgpu_k_minimizers",
+]
+
+_lib = None
+
+
+def library_path() -> str:
+    return os.environ.get("DSKGPU_LIB", os.path.join(_HERE, "libdskgpu.so"))
+
+
+def load_library():
+    """Load libdskgpu.so; fails loudly (no fallback) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C dsk_amd/csrc` (there is no CPU fallback for the count path)")
+    lib = C.CDLL(path)
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    lib.dskgpu_create.argtypes = [C.POINTER(_Config), C.POINTER(vp)]
+    lib.dskgpu_create.restype = C.c_int
+    lib.dskgpu_destroy.argtypes = [vp]
+    lib.dskgpu_destroy.restype = None
+    lib.dskgpu_last_error.argtypes = [vp]
+    lib.dskgpu_last_error.restype = C.c_char_p
+    lib.dskgpu_version.argtypes = []
+    lib.dskgpu_version.restype = C.c_char_p
+    lib.dskgpu_set_stream.argtypes = [vp, vp]
+    lib.dskgpu_push_reads.argtypes = [vp, C.c_char_p, u64]
+    lib.dskgpu_set_reads_device.argtypes = [vp, vp, u64]
+    lib.dskgpu_count.argtypes = [vp]
+    lib.dskgpu_mg_scatter.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    lib.dskgpu_mg_send_capacity_words.argtypes = [vp]
+    lib.dskgpu_mg_send_capacity_words.restype = u64
+    lib.dskgpu_mg_count.argtypes = [vp, vp, u64]
+    lib.dskgpu_get_stats.argtypes = [vp, C.POINTER(_Stats)]
+    lib.dskgpu_histogram.argtypes = [vp, C.POINTER(u64), u32]
+    lib.dskgpu_num_partitions.argtypes = [vp]
+    lib.dskgpu_num_partitions.restype = u32
+    lib.dskgpu_partition_size.argtypes = [vp, u32]
+    lib.dskgpu_partition_size.restype = u64
+    lib.dskgpu_partition_copy.argtypes = [vp, u32, vp, vp]
+    lib.dskgpu_result_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+    lib.dskgpu_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    lib.dskgpu_k_encode.argtypes = [vp, vp, u64, vp, vp]
+    lib.dskgpu_k_enumerate.argtypes = [vp, vp, u64, vp, vp]
+    lib.dskgpu_k_minimizers.argtypes = [vp, vp, u64, vp, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("dskgpu_stage_times",):
+            pass
+    _lib = lib
+    return lib
+
+
+class KmerCounter:
+    """One counting context on one GPU (not thread-safe; one per device)."""
+
+    def __init__(self, kmer_size: int = 31, abundance_min: int = 2, abundance_max: int = 2147483647,
+                 histo_max: int = 10000, device: int = 0, nb_partitions: int = 0, timing: bool = False,
+                 sort: bool = True, world_size: int = 1, rank: int = 0, stream: Optional[int] = None):
+        self._lib = load_library()
+        cfg = _Config()
+        cfg.kmer_size = kmer_size
+        cfg.abundance_min = abundance_min
+        cfg.abundance_max = abundance_max
+        cfg.histo_max = histo_max
+        cfg.device = device
+        cfg.nb_partitions = nb_partitions
+        cfg.flags = (F_TIMING if timing else 0) | (0 if sort else F_NO_SORT)
+        cfg.world_size = world_size
+        cfg.rank = rank
+        self.kmer_size = kmer_size
+        self.histo_max = histo_max
+        self.words = 1 if kmer_size <= 32 else 2
+        self.world_size = world_size
+        h = C.c_void_p()
+        rc = self._lib.dskgpu_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise DskGpuError(rc, self._lib.dskgpu_last_error(None).decode())
+        self._h = h
+        if stream is not None:
+            self._ck(self._lib.dskgpu_set_stream(self._h, C.c_void_p(stream)))
+
+    # -- plumbing
+    def _ck(self, rc: int) -> None:
+        if rc != 0:
+            raise DskGpuError(rc, self._lib.dskgpu_last_error(self._h).decode())
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.dskgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- input
+    def push_reads(self, data: bytes) -> None:
+        self._ck(self._lib.dskgpu_push_reads(self._h, data, len(data)))
+
+    def set_reads_device(self, ptr: int, nbytes: int) -> None:
+        self._ck(self._lib.dskgpu_set_reads_device(self._h, C.c_void_p(ptr), nbytes))
+
+    # -- hot path
+    def count(self) -> None:
+        self._ck(self._lib.dskgpu_count(self._h))
+
+    def mg_send_capacity_words(self) -> int:
+        return int(self._lib.dskgpu_mg_send_capacity_words(self._h))
+
+    def mg_scatter(self, send_ptr: int, capacity_words: int) -> List[int]:
+        counts = (C.c_uint64 * self.world_size)()
+        self._ck(self._lib.dskgpu_mg_scatter(self._h, C.c_void_p(send_ptr), capacity_words, counts))
+        return [int(c) for c in counts]
+
+    def mg_count(self, recv_ptr: int, recv_words: int) -> None:
+        self._ck(self._lib.dskgpu_mg_count(self._h, C.c_void_p(recv_ptr), recv_words))
+
+    # -- results
+    def stats(self) -> dict:
+        s = _Stats()
+        self._ck(self._lib.dskgpu_get_stats(self._h, C.byref(s)))
+        return {k: int(getattr(s, k)) for k, _ in _Stats._fields_ if k != "reserved"}
+
+    def histogram(self) -> np.ndarray:
+        out = np.zeros(self.histo_max + 1, dtype=np.uint64)
+        self._ck(self._lib.dskgpu_histogram(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), self.histo_max + 1))
+        return out
+
+    def num_partitions(self) -> int:
+        return int(self._lib.dskgpu_num_partitions(self._h))
+
+    def partition(self, p: int) -> Tuple[np.ndarray, np.ndarray]:
+        n = int(self._lib.dskgpu_partition_size(self._h, p))
+        kmers = np.zeros((n, self.words), dtype=np.uint64)
+        ab = np.zeros(n, dtype=np.uint32)
+        self._ck(self._lib.dskgpu_partition_copy(self._h, p, C.c_void_p(kmers.ctypes.data), C.c_void_p(ab.ctypes.data)))
+        return kmers, ab
+
+    def rows(self) -> Tuple[np.ndarray, np.ndarray]:
+        """All solid rows, partitions concatenated in index order (what dsk2ascii walks)."""
+        ks, abs_ = [], []
+        for p in range(self.num_partitions()):
+            k, a = self.partition(p)
+            ks.append(k)
+            abs_.append(a)
+        if not ks:
+            return np.zeros((0, self.words), np.uint64), np.zeros(0, np.uint32)
+        return np.concatenate(ks), np.concatenate(abs_)
+
+    def result_device(self) -> Tuple[int, int, int]:
+        k, a, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._ck(self._lib.dskgpu_result_device(self._h, C.byref(k), C.byref(a), C.byref(n)))
+        return int(k.value or 0), int(a.value or 0), int(n.value)
+
+    def stage_times(self) -> List[Tuple[str, float]]:
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        n = self._lib.dskgpu_stage_times(self._h, names, ms, cap)
+        return [(names[i].decode(), float(ms[i])) for i in range(min(n, cap))]
+
+    # -- kernel-level entry points (parity tests)
+    def k_encode(self, d_bytes: int, nbytes: int, d_packed: int, d_invalid: int) -> None:
+        self._ck(self._lib.dskgpu_k_encode(self._h, C.c_void_p(d_bytes), nbytes, C.c_void_p(d_packed), C.c_void_p(d_invalid)))
+
+    def k_enumerate(self, d_bytes: int, nbytes: int, d_kmers: int, d_valid: int) -> None:
+        self._ck(self._lib.dskgpu_k_enumerate(self._h, C.c_void_p(d_bytes), nbytes, C.c_void_p(d_kmers), C.c_void_p(d_valid)))
+
+    def k_minimizers(self, d_bytes: int, nbytes: int, d_minim: int, d_valid: int) -> None:
+        self._ck(self._lib.dskgpu_k_minimizers(self._h, C.c_void_p(d_bytes), nbytes, C.c_void_p(d_minim), C.c_void_p(d_valid)))
+
+
+def kmer_to_string(value: int, k: int) -> str:
+    """Kmer<span>::ModelCanonical::toString (utils/dsk2ascii.cpp:104): MSB-first, A C T G = 0 1 2 3."""
+    return "".join("ACTG"[(value >> (2 * (k - 1 - i))) & 3] for i in range(k))

@@ -1,0 +1,141 @@
+/*
+ * dskgpu.h -- C-ABI of the MI355X k-mer counting engine (libdskgpu.so).
+ *
+ * This is the drop-in boundary for the DSK count path.  In the reference the
+ * whole path is ONE C++ call, `SortingCountAlgorithm<span>::execute()`
+ * (src/DSK.cpp:55-60), fed by `Bank::open(-file)` (src/DSK.cpp:51) and read
+ * back through `Partition<Kmer<span>::Count> "solid"` + the histogram
+ * (utils/dsk2ascii.cpp:61-104; scripts/simple_test.sh:37).  The reference has
+ * no FFI of its own (it is all in-process C++), so each entry point below cites
+ * the reference interface it stands in for.  Plain pointers and sizes only; no
+ * C++/torch types cross.  Every function returns DSKGPU_OK (0) or a negative
+ * error code; `dskgpu_last_error` gives the text.  One ctx per device; a ctx
+ * is not thread-safe, distinct ctxs are independent.
+ *
+ * Input convention ("read stream"): a byte string in which every maximal run
+ * of [ACGTacgt] is one sequence fragment; ANY other byte (N, IUPAC codes,
+ * '\n' between reads) ends the current k-mer window (test/readN.fasta +
+ * test/readN.histo).  A bank front-end therefore only has to concatenate the
+ * sequence lines of its records separated by one non-ACGT byte.
+ *
+ * K-mer value convention (README.md:104-112, utils/dsk2ascii.cpp:104): A=0,
+ * C=1, T=2, G=3, first base most significant; canonical = min(fwd, revcomp).
+ * A k-mer is `words` 64-bit words, least-significant word first
+ * (words = 1 for k <= 32, 2 for k <= 64).
+ */
+#ifndef DSKGPU_H
+#define DSKGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSKGPU_OK 0
+#define DSKGPU_E_ARG (-1)       /* bad argument / unsupported k            */
+#define DSKGPU_E_DEVICE (-2)    /* HIP error (text in dskgpu_last_error)   */
+#define DSKGPU_E_NOMEM (-3)     /* device allocation failed                */
+#define DSKGPU_E_STATE (-4)     /* call out of order                       */
+#define DSKGPU_E_OVERFLOW (-5)  /* internal table overflow after retries   */
+
+typedef struct dskgpu_ctx dskgpu_ctx;
+
+/* Options of SortingCountAlgorithm<>::getOptionsParser() that reach the
+ * count path (src/DSK.cpp:83; README.md:12,56; scripts/simple_test.sh:36,88). */
+typedef struct dskgpu_config {
+    uint32_t kmer_size;       /* -kmer-size, 1..63 (span 32: k<32, span 64: k<64; README.md:115-122) */
+    uint32_t abundance_min;   /* -abundance-min (solid <=> min <= count <= max) */
+    uint32_t abundance_max;   /* -abundance-max                                */
+    uint32_t histo_max;       /* -histo-max: histogram rows 1..histo_max (10000) */
+    int32_t  device;          /* HIP device ordinal                            */
+    uint32_t nb_partitions;   /* number of output partitions (dsk/solid/<p>); 0 = auto */
+    uint32_t minimizer_size;  /* -minimizer-size (used by the owner map), 0 = default 10 */
+    uint32_t flags;           /* DSKGPU_F_* */
+    uint32_t world_size;      /* number of GPUs sharing the k-mer space (1 = single) */
+    uint32_t rank;            /* this GPU's index in [0, world_size)           */
+    uint32_t reserved[6];
+} dskgpu_config;
+
+#define DSKGPU_F_TIMING 1u        /* record per-stage HIP-event timings        */
+#define DSKGPU_F_NO_SORT 2u       /* leave solid rows unsorted (bench ablation) */
+
+/* Lifetime: stands where `SortingCountAlgorithm<span> sortingCount(bank, props)`
+ * is constructed / destroyed (src/DSK.cpp:55). */
+int  dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out);
+void dskgpu_destroy(dskgpu_ctx* ctx);
+const char* dskgpu_last_error(const dskgpu_ctx* ctx);   /* ctx may be NULL: create-time error */
+const char* dskgpu_version(void);
+
+/* Launch all device work of this ctx on an existing HIP stream (hipStream_t
+ * passed as void*); NULL = a stream owned by the ctx. */
+int dskgpu_set_stream(dskgpu_ctx* ctx, void* hip_stream);
+
+/* ---- input: replaces the Bank iteration inside execute() (src/DSK.cpp:51,60) */
+/* Append host bytes of the read stream (copied to the device; may be called
+ * repeatedly; a separator is implied between calls). */
+int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes);
+/* Use a read stream already resident in HBM (caller keeps ownership and must
+ * keep it alive until dskgpu_count returns).  Replaces any pushed reads. */
+int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes);
+
+/* ---- the hot path: replaces SortingCountAlgorithm<span>::execute() (src/DSK.cpp:60) */
+/* Single-GPU: encode -> canonical k-mers -> partition -> count -> histogram +
+ * solidity filter (+ sort).  Synchronous on return. */
+int dskgpu_count(dskgpu_ctx* ctx);
+
+/* Multi-GPU (world_size > 1): the k-mer space is split by owner(kmer) in
+ * [0, world_size).  Step 1 writes this rank's k-mer records grouped by owner
+ * into caller memory `d_send` (capacity in 8-byte words) and the per-owner
+ * word counts into send_words[world_size] (host).  The caller exchanges the
+ * groups (RCCL all-to-all) and hands the received records to step 2. */
+int dskgpu_mg_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t* send_words);
+uint64_t dskgpu_mg_send_capacity_words(const dskgpu_ctx* ctx);   /* upper bound for d_send */
+int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words);
+
+/* ---- results: replace the CountProcessor outputs read back through
+ * Storage (src/DSK.cpp:68; utils/dsk2ascii.cpp:61-104; simple_test.sh:37) */
+typedef struct dskgpu_stats {
+    uint64_t n_bytes;        /* read-stream bytes processed              */
+    uint64_t n_kmers;        /* valid k-mer occurrences                  */
+    uint64_t n_distinct;     /* distinct canonical k-mers                */
+    uint64_t n_solid;        /* rows passing the abundance filter        */
+    uint32_t n_partitions;   /* output partitions                        */
+    uint32_t n_levels;       /* radix-partition levels used              */
+    uint32_t n_final_bins;   /* hash-aggregate sub-partitions            */
+    uint32_t n_retries;      /* table-overflow retries                   */
+    uint64_t reserved[4];
+} dskgpu_stats;
+int dskgpu_get_stats(const dskgpu_ctx* ctx, dskgpu_stats* out);
+
+/* out[0..nbins-1]; out[i] = number of distinct k-mers whose
+ * min(count, histo_max) == i; nbins must be histo_max+1 (out[0] == 0).
+ * Same content as the `histogram/histogram` dataset (test/k27.histo). */
+int dskgpu_histogram(const dskgpu_ctx* ctx, uint64_t* out, uint32_t nbins);
+
+/* Output partitions = `Partition<Count> "solid"` (utils/dsk2ascii.cpp:61,77).
+ * Rows are ascending by k-mer value inside a partition and partitions are
+ * ascending value ranges, so the concatenation is globally sorted. */
+uint32_t dskgpu_num_partitions(const dskgpu_ctx* ctx);
+uint64_t dskgpu_partition_size(const dskgpu_ctx* ctx, uint32_t p);
+/* kmers: size*words u64 (row-major, LSW first); abundance: size u32. Host memory. */
+int dskgpu_partition_copy(const dskgpu_ctx* ctx, uint32_t p, uint64_t* kmers, uint32_t* abundance);
+/* Device pointers to the full sorted result (valid until the next count/destroy). */
+int dskgpu_result_device(const dskgpu_ctx* ctx, const void** d_kmers, const void** d_abundance, uint64_t* n_rows);
+
+/* Per-stage device time of the last count (flag DSKGPU_F_TIMING).  Returns the
+ * number of stages; fills up to `cap` entries.  names[i] are static strings. */
+int dskgpu_stage_times(const dskgpu_ctx* ctx, const char** names, float* ms, int cap);
+
+/* ---- kernel-level entry points used by the parity tests (device pointers) */
+/* ASCII -> 2-bit packed words + invalid mask, one u64 / u32 per 32 bases. */
+int dskgpu_k_encode(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, void* d_packed, void* d_invalid);
+/* Canonical k-mer (words u64, LSW first) + validity byte for the window ending at every byte. */
+int dskgpu_k_enumerate(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, void* d_kmers, void* d_valid);
+/* Minimizer (u32) of the window ending at every byte (0 when invalid). */
+int dskgpu_k_minimizers(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, void* d_minim, void* d_valid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
