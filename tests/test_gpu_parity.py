@@ -23,7 +23,7 @@ def dev():
 
 def gpu_count(stream_np, k, dev, amin=2, amax=2147483647, **kw):
     from dsk_amd import KmerCounter
-    t = torch.from_numpy(np.ascontiguousarray(stream_np)).to(dev)
+    t = torch.from_numpy(np.array(stream_np, dtype=np.uint8)).to(dev)
     with KmerCounter(kmer_size=k, abundance_min=amin, abundance_max=amax, **kw) as kc:
         kc.set_reads_device(t.data_ptr(), t.numel())
         kc.count()
@@ -131,7 +131,7 @@ def test_poly_a_skew(oracle, dev):
     # one k-mer repeated ~2M times plus noise: a single sub-partition takes all the duplicates
     rng = np.random.default_rng(7)
     noise = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=200_000)
-    s = np.concatenate([np.full(2_000_000, 65, np.uint8), [10], noise, [10], np.full(500_000, 84, np.uint8)])
+    s = np.concatenate([np.full(2_000_000, 65, np.uint8), [10], noise, [10], np.full(500_000, 84, np.uint8)]).astype(np.uint8)
     check_against_oracle(oracle, s, 31, dev, amin=1)
 
 
