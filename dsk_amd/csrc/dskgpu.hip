@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -143,21 +144,23 @@ int run_scan(dskgpu_ctx* ctx, u32* a, const u32* d_len, u64 max_len) {
     return DSKGPU_OK;
 }
 
-size_t scatter_lds(int W, u32 P) { return (size_t)SC_TILE * 8 * W + (size_t)P * 12 + 17 * 4 + 64; }
+u32 dbg_flags() { static int v = -1; if (v < 0) { const char* e = getenv("DSKGPU_DBG"); v = e ? atoi(e) : 0; } return (u32)v; }
+
+size_t scatter_lds(int W, u32 P) { return (size_t)SC_TILE * 8 * W + (size_t)P * 16 + 17 * 4 + 16; }
 
 template <int W, int SRC>
 int launch_hist(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                u64 max_chunks, u32* matrix, int shift, u32 P) {
-    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * 2));
+                u64 max_chunks, u32* matrix, DigitSpec ds, u32 P) {
+    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * (SRC == 1 ? 4 : 2)));
     hipLaunchKernelGGL((k_hist<W, SRC>), dim3(grid), dim3(SC_NT), 0, ctx->stream, ctx->packed.as<u64>(),
-                       ctx->inval.as<u32>(), keys, descs, d_nch, matrix, (int)ctx->cfg.kmer_size, shift, P);
+                       ctx->inval.as<u32>(), keys, descs, d_nch, matrix, (int)ctx->cfg.kmer_size, ds, P);
     CKL("k_hist");
     return DSKGPU_OK;
 }
 
 template <int W, int SRC>
 int launch_scatter(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                   u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, int shift, u32 P) {
+                   u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P) {
     const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * 2));
     const size_t lds = scatter_lds(W, P);
     static bool attr_set[3][2] = {{false, false}, {false, false}, {false, false}};
@@ -167,33 +170,38 @@ int launch_scatter(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chunk
         attr_set[W][SRC] = true;
     }
     hipLaunchKernelGGL((k_scatter<W, SRC>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->packed.as<u64>(),
-                       ctx->inval.as<u32>(), keys, descs, d_nch, scanned, out, (int)ctx->cfg.kmer_size, shift, P);
+                       ctx->inval.as<u32>(), keys, descs, d_nch, scanned, out, (int)ctx->cfg.kmer_size, ds, P, dbg_flags());
     CKL("k_scatter");
     return DSKGPU_OK;
 }
 
 struct Plan {
-    int fb, b1, b2, levels;
+    int levels;
     u32 P1, P2, F;
-    int shift1, shift2, slot_shift;
+    DigitSpec d1, d2;
 };
 
-#define TARGET_KEYS 2048      // mean keys per final sub-partition (table has 4096 slots)
-#define MAX_LEVEL_BITS 10
+#define TARGET_KEYS 2560      // worst-case mean keys per final sub-partition (table: 4096 slots, 3584 usable)
+#define MAX_LEVEL_BINS 2048
+#define ONE_LEVEL_BINS 1024
 #define CH2 65536u            // keys per level-2 chunk
 
-bool make_plan(int gbits, u64 n_upper, int extra_bits, Plan* pl) {
-    int fb = ceil_log2_u64((n_upper + TARGET_KEYS - 1) / TARGET_KEYS) + extra_bits;
-    if (fb < 1) fb = 1;
-    if (fb > 2 * MAX_LEVEL_BITS + 2) return false;
-    pl->fb = fb;
-    if (fb <= MAX_LEVEL_BITS) { pl->levels = 1; pl->b1 = fb; pl->b2 = 0; }
-    else { pl->levels = 2; pl->b1 = (fb + 1) / 2; pl->b2 = fb - pl->b1; }
-    pl->P1 = 1u << pl->b1; pl->P2 = 1u << pl->b2; pl->F = 1u << fb;
-    pl->shift1 = 64 - gbits - pl->b1;
-    pl->shift2 = pl->shift1 - pl->b2;
-    pl->slot_shift = 64 - gbits - fb - 12;
-    return pl->slot_shift >= 0;
+// Final sub-partitions F = P1 * P2 sized to the input (any integer, not a power
+// of two: digits use the multiply-shift reduction of key_digit()).
+bool make_plan(u64 n_upper, int extra_bits, Plan* pl) {
+    u64 F = ((n_upper + TARGET_KEYS - 1) / TARGET_KEYS) << extra_bits;
+    if (F < 2) F = 2;
+    if (F <= ONE_LEVEL_BINS) { pl->levels = 1; pl->P1 = (u32)F; pl->P2 = 1; }
+    else {
+        u64 p1 = 1; while (p1 * p1 < F) ++p1;
+        u64 p2 = (F + p1 - 1) / p1;
+        if (p1 > MAX_LEVEL_BINS || p2 > MAX_LEVEL_BINS) return false;
+        pl->levels = 2; pl->P1 = (u32)p1; pl->P2 = (u32)p2;
+    }
+    pl->F = pl->P1 * pl->P2;
+    pl->d1 = DigitSpec{1u, pl->P1, 0u};
+    pl->d2 = DigitSpec{2u, pl->P1, pl->P2};
+    return true;
 }
 
 // Build level-1 chunk descriptors on the host (ranges are static).
@@ -268,7 +276,7 @@ int run_pipeline<1>(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u64 
     int extra_bits = 0;
     for (int attempt = 0;; ++attempt) {
         Plan pl;
-        if (!make_plan(ctx->gbits, n_upper, extra_bits, &pl))
+        if (!make_plan(n_upper, extra_bits, &pl))
             return fail(ctx, DSKGPU_E_OVERFLOW, "cannot partition finer (table overflow persists)");
         // ---------------- level 1
         u32 nch1 = 0;
@@ -288,14 +296,14 @@ int run_pipeline<1>(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u64 
         CK(hipMemsetAsync(ctx->gstats.p, 0, 4 * 8, ctx->stream));
         ctx->mark("setup");
         int rc;
-        if (from_reads) rc = launch_hist<W, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), pl.shift1, pl.P1);
-        else rc = launch_hist<W, 1>(ctx, d_keys_in, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), pl.shift1, pl.P1);
+        if (from_reads) rc = launch_hist<W, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), pl.d1, pl.P1);
+        else rc = launch_hist<W, 1>(ctx, d_keys_in, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), pl.d1, pl.P1);
         if (rc) return rc;
         ctx->mark("hist1");
         if ((rc = run_scan(ctx, ctx->mat1.as<u32>(), sc + SC_MLEN1, M1))) return rc;
         ctx->mark("scan1");
-        if (from_reads) rc = launch_scatter<W, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<u64>(), pl.shift1, pl.P1);
-        else rc = launch_scatter<W, 1>(ctx, d_keys_in, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<u64>(), pl.shift1, pl.P1);
+        if (from_reads) rc = launch_scatter<W, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<u64>(), pl.d1, pl.P1);
+        else rc = launch_scatter<W, 1>(ctx, d_keys_in, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<u64>(), pl.d1, pl.P1);
         if (rc) return rc;
         ctx->mark("scatter1");
         u64* fkeys = ctx->bufA.as<u64>();
@@ -314,11 +322,11 @@ int run_pipeline<1>(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u64 
                                ctx->seg.as<SegInfo>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, sc + SC_MLEN2);
             CKL("k_plan");
             ctx->mark("plan2");
-            if ((rc = launch_hist<W, 1>(ctx, ctx->bufA.as<u64>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, max_chunks2, ctx->mat2.as<u32>(), pl.shift2, pl.P2))) return rc;
+            if ((rc = launch_hist<W, 1>(ctx, ctx->bufA.as<u64>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, max_chunks2, ctx->mat2.as<u32>(), pl.d2, pl.P2))) return rc;
             ctx->mark("hist2");
             if ((rc = run_scan(ctx, ctx->mat2.as<u32>(), sc + SC_MLEN2, M2))) return rc;
             ctx->mark("scan2");
-            if ((rc = launch_scatter<W, 1>(ctx, ctx->bufA.as<u64>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, max_chunks2, ctx->mat2.as<u32>(), ctx->bufB.as<u64>(), pl.shift2, pl.P2))) return rc;
+            if ((rc = launch_scatter<W, 1>(ctx, ctx->bufA.as<u64>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, max_chunks2, ctx->mat2.as<u32>(), ctx->bufB.as<u64>(), pl.d2, pl.P2))) return rc;
             ctx->mark("scatter2");
             fkeys = ctx->bufB.as<u64>();
             scratch = ctx->bufA.as<u32>();
@@ -332,9 +340,9 @@ int run_pipeline<1>(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u64 
         ctx->mark("offsets");
         // ---------------- count
         CountParams cp;
-        cp.F = pl.F; cp.slot_shift = pl.slot_shift;
+        cp.F = pl.F;
         cp.amin = ctx->cfg.abundance_min; cp.amax = ctx->cfg.abundance_max; cp.histo_max = ctx->cfg.histo_max;
-        const unsigned cgrid = (unsigned)std::min<u64>(pl.F, (u64)ctx->num_cu * 3);
+        const unsigned cgrid = (unsigned)std::min<u64>(pl.F, (u64)ctx->num_cu * 2);
         hipLaunchKernelGGL(k_count<W>, dim3(cgrid), dim3(CNT_NT), 0, ctx->stream, fkeys, ctx->fstart.as<u32>(), scratch,
                            ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), sc + SC_OVERFLOW, cp);
         CKL("k_count");
@@ -517,7 +525,7 @@ int dskgpu_mg_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, ui
     u32* sc = ctx->scalars.as<u32>();
     CK(hipMemcpyAsync(sc, h_sc, sizeof(ctx->h_sc), hipMemcpyHostToDevice, ctx->stream));
     CK(ctx->mat1.ensure((M1 + 1) * 4));
-    const int shift = 64 - ctx->gbits;
+    const DigitSpec shift = DigitSpec{0u, G, 0u};
     if ((rc = launch_hist<1, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), shift, G))) return rc;
     ctx->mark("mg_hist");
     if ((rc = run_scan(ctx, ctx->mat1.as<u32>(), sc + SC_MLEN1, M1))) return rc;

@@ -126,6 +126,20 @@ template <> struct KeyT<2> { typedef K2 T; };
 __device__ __forceinline__ u64 digit_word(u64 h) { return h; }
 __device__ __forceinline__ u64 digit_word(const K2& h) { return h.hi; }
 
+// Radix digits are bit fields of the mixed key, mapped onto an ARBITRARY number
+// of bins with the multiply-shift range reduction (one v_mul_hi_u32):
+//   level 1 : d1 = mulhi(h[63:32], P1)
+//   level 2 : d2 = mulhi(lo32(h[63:32] * P1), P2)        (the fraction left over by d1)
+//   owner   : g  = (h[31:12] * G) >> 20                  (multi-GPU owner of the k-mer)
+//   slot    : h[11:0]                                    (home slot of the LDS table)
+// so final sub-partition q = d1 * P2 + d2 and the fields are independent.
+struct DigitSpec { u32 mode, pa, pb; };   // mode 0: owner(pa=G)  1: level1(pa=P1)  2: level2(pa=P1,pb=P2)
+__device__ __forceinline__ u32 key_digit(u64 w, const DigitSpec& ds) {
+    if (ds.mode == 1) return __umulhi((u32)(w >> 32), ds.pa);
+    if (ds.mode == 2) return __umulhi((u32)(w >> 32) * ds.pa, ds.pb);
+    return (((u32)(w >> 12) & 0xFFFFFu) * ds.pa) >> 20;
+}
+
 template <int W>
 __device__ __forceinline__ u32 tile_keys_reads(const u64* __restrict__ packed, const u32* __restrict__ inval,
                                                u64 w0, u64 wend, int k, typename KeyT<W>::T (&h)[SC_KPT]);
@@ -171,23 +185,30 @@ template <int W, int SRC>
 __global__ __launch_bounds__(SC_NT) void k_hist(const u64* __restrict__ packed, const u32* __restrict__ inval,
                                                 const typename KeyT<W>::T* __restrict__ keys,
                                                 const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
-                                                u32* __restrict__ matrix, int k, int shift, u32 P) {
+                                                u32* __restrict__ matrix, int k, DigitSpec ds, u32 P) {
     __shared__ u32 lh[MAX_BINS];
     const u32 nchunks = *d_nchunks;
-    const u32 mask = P - 1;
     for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
         const ChunkDesc d = descs[g];
         for (u32 b = threadIdx.x; b < P; b += SC_NT) lh[b] = 0;
         __syncthreads();
         const u64 step = SRC == 0 ? SC_TILE_WORDS : SC_TILE;
+        typename KeyT<W>::T hn[SC_KPT]; u32 vmn = 0;
+        if (SRC == 1 && d.begin < d.end) vmn = tile_keys_array<W>(keys, d.begin, d.end, hn);
         for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
             typename KeyT<W>::T h[SC_KPT];
             u32 vm;
             if (SRC == 0) vm = tile_keys_reads<W>(packed, inval, t0, d.end, k, h);
-            else vm = tile_keys_array<W>(keys, t0, d.end, h);
+            else {
+                vm = vmn;
+#pragma unroll
+                for (int j = 0; j < SC_KPT; ++j) h[j] = hn[j];
+                vmn = 0;
+                if (t0 + step < d.end) vmn = tile_keys_array<W>(keys, t0 + step, d.end, hn);   // keep HBM reads in flight
+            }
 #pragma unroll
             for (int j = 0; j < SC_KPT; ++j)
-                if (vm & (1u << j)) atomicAdd(&lh[(u32)(digit_word(h[j]) >> shift) & mask], 1u);
+                if (vm & (1u << j)) atomicAdd(&lh[key_digit(digit_word(h[j]), ds)], 1u);
         }
         __syncthreads();
         for (u32 b = threadIdx.x; b < P; b += SC_NT) matrix[d.flat_base + (u64)b * d.stride] = lh[b];
@@ -281,51 +302,108 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan_apply(u32* __restrict__ a, con
 // Per tile: rank keys inside their bin with one LDS atomic each, scan the tile
 // histogram, stage the tile bin-sorted in LDS, then write runs to HBM so that
 // consecutive lanes hit consecutive addresses.  Per-chunk cursors live in LDS.
+// The next tile's keys are loaded (key array) before the current tile enters
+// its LDS phases, so HBM reads stay in flight across the barriers.
+
+// Exclusive scan of cnt[0..P) fused with the cursor bookkeeping of the tile:
+//   off[b]   = start of bin b inside the staged tile
+//   delta[b] = cur[b] - off[b]   (HBM index of staged element i of bin b is delta[b] + i)
+//   cur[b]  += cnt[b];  cnt[b] = 0
+template <int NT>
+__device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* cur, int P, u32* wsum, u32* tot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ipt = (P + NT - 1) / NT;
+    const int base = tid * ipt;
+    u32 v[4]; u32 s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = base + j;
+        v[j] = (j < ipt && idx < P) ? cnt[idx] : 0u;
+        s += v[j];
+    }
+    u32 inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        const u32 x = lane < NT / 64 ? wsum[lane] : 0u;
+        u32 y = x;
+#pragma unroll
+        for (int d = 1; d < NT / 64; d <<= 1) { const u32 t = __shfl_up(y, d); if (lane >= d) y += t; }
+        if (lane < NT / 64) wsum[lane] = y - x;
+        if (lane == NT / 64 - 1) *tot = y;
+    }
+    __syncthreads();
+    u32 run = wsum[wave] + inc - s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = base + j;
+        if (j < ipt && idx < P) {
+            const u32 c = cur[idx];
+            off[idx] = run; delta[idx] = c - run; cur[idx] = c + v[j]; cnt[idx] = 0;
+            run += v[j];
+        }
+    }
+}
+
 template <int W, int SRC>
 __global__ __launch_bounds__(SC_NT) void k_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
                                                    const typename KeyT<W>::T* __restrict__ keys,
                                                    const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
                                                    const u32* __restrict__ scanned,
-                                                   typename KeyT<W>::T* __restrict__ out, int k, int shift, u32 P) {
+                                                   typename KeyT<W>::T* __restrict__ out, int k, DigitSpec ds, u32 P, u32 dbg) {
     typedef typename KeyT<W>::T Key;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Key* stage = reinterpret_cast<Key*>(smem);                       // SC_TILE keys
     u32* cnt = reinterpret_cast<u32*>(smem + sizeof(Key) * SC_TILE); // P
     u32* off = cnt + P;                                              // P
     u32* cur = off + P;                                              // P
-    u32* wsum = cur + P;                                             // 16 (+1 total)
+    u32* delta = cur + P;                                            // P
+    u32* wsum = delta + P;                                           // 16 (+1 total)
     u32* tot = wsum + 16;
     const u32 nchunks = *d_nchunks;
-    const u32 mask = P - 1;
     for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
         const ChunkDesc d = descs[g];
+        __syncthreads();   // previous chunk's write-out reads delta/off/stage
         for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] = scanned[d.flat_base + (u64)b * d.stride]; cnt[b] = 0; }
-        __syncthreads();
         const u64 step = SRC == 0 ? SC_TILE_WORDS : SC_TILE;
+        Key hn[SC_KPT]; u32 vmn = 0;
+        if (SRC == 1 && d.begin < d.end) vmn = tile_keys_array<W>(keys, d.begin, d.end, hn);
+        __syncthreads();
         for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
             Key h[SC_KPT]; u32 rk[SC_KPT];
             u32 vm;
             if (SRC == 0) vm = tile_keys_reads<W>(packed, inval, t0, d.end, k, h);
-            else vm = tile_keys_array<W>(keys, t0, d.end, h);
+            else {
+                vm = vmn;
+#pragma unroll
+                for (int j = 0; j < SC_KPT; ++j) h[j] = hn[j];
+                vmn = 0;
+                if (t0 + step < d.end) vmn = tile_keys_array<W>(keys, t0 + step, d.end, hn);   // prefetch
+            }
 #pragma unroll
             for (int j = 0; j < SC_KPT; ++j)
-                if (vm & (1u << j)) rk[j] = atomicAdd(&cnt[(u32)(digit_word(h[j]) >> shift) & mask], 1u);
+                if (vm & (1u << j)) rk[j] = atomicAdd(&cnt[key_digit(digit_word(h[j]), ds)], 1u);
             __syncthreads();
-            block_excl_scan<SC_NT>(cnt, off, (int)P, wsum, tot);
+            tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot);
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < SC_KPT; ++j)
-                if (vm & (1u << j)) stage[off[(u32)(digit_word(h[j]) >> shift) & mask] + rk[j]] = h[j];
+                if (vm & (1u << j)) {
+                    if (dbg & 2u) out[(u64)(delta[key_digit(digit_word(h[j]), ds)] + off[key_digit(digit_word(h[j]), ds)] + rk[j])] = h[j];
+                    else stage[off[key_digit(digit_word(h[j]), ds)] + rk[j]] = h[j];
+                }
             __syncthreads();
             const u32 ntile = *tot;
+            if (!(dbg & 1u))
             for (u32 i = threadIdx.x; i < ntile; i += SC_NT) {
                 const Key hk = stage[i];
-                const u32 b = (u32)(digit_word(hk) >> shift) & mask;
-                out[(u64)cur[b] + (i - off[b])] = hk;
+                out[(u64)(delta[key_digit(digit_word(hk), ds)] + i)] = hk;
             }
-            __syncthreads();
-            for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] += cnt[b]; cnt[b] = 0; }
-            __syncthreads();
+            // no barrier here: the next tile's rank phase only touches cnt (zeroed
+            // by tile_scan); its first barrier orders this write-out before the
+            // next tile_scan / stage writes.
         }
     }
 }
@@ -399,21 +477,41 @@ __global__ void k_final_offsets(const u32* __restrict__ scanned, const SegInfo* 
 #define CNT_SLOTS 4096
 #define CNT_MAXLOAD 3584          // distinct keys allowed per table (0.875)
 #define CNT_LH 512                // histogram bins kept in LDS
+#define CNT_KPT 8                 // keys per thread prefetched for the next sub-partition
 
 struct CountParams {
-    u32 F; int slot_shift;
+    u32 F;
     u32 amin, amax, histo_max;
 };
 
-// One persistent block per sub-partition in turn: insert keys (64-bit LDS CAS +
-// LDS add), then sweep the table once: histogram every distinct key, keep the
-// solid ones (wave ballot + prefix for the slot claim) and write them IN PLACE
-// over the partition's own key range, abundance to `abund` at the same index.
+// One persistent block per sub-partition in turn.  Insert = 64-bit LDS CAS on
+// the key + LDS add on the count; the slot of every newly claimed key is
+// appended to a list, so the sweep (histogram every distinct key, keep the
+// solid ones via wave ballot + prefix, reset the slot) costs O(distinct), not
+// O(table).  Solid rows are written IN PLACE over the sub-partition's own key
+// range (abundance to `abund` at the same index).  The keys of the block's
+// next sub-partition are loaded into registers before the sweep, so HBM reads
+// overlap the LDS work.
 template <int W>
 __global__ __launch_bounds__(CNT_NT) void k_count(typename KeyT<W>::T* __restrict__ keys, const u32* __restrict__ fstart,
                                                   u32* __restrict__ abund, u32* __restrict__ nsolid,
                                                   u64* __restrict__ ghist, u64* __restrict__ gstats,
                                                   u32* __restrict__ overflow, CountParams cp);
+
+__device__ __forceinline__ void table_insert1(u64* tk, u32* tc, unsigned short* lst, u32* ndist, u32* ovf, u64 h) {
+    u32 slot = (u32)h & (CNT_SLOTS - 1);
+    int probe = 0;
+    for (; probe < CNT_SLOTS; ++probe) {
+        u64 old = tk[slot];
+        if (old == DSK_EMPTY) {
+            old = atomicCAS(&tk[slot], DSK_EMPTY, h);
+            if (old == DSK_EMPTY) { lst[atomicAdd(ndist, 1u)] = (unsigned short)slot; old = h; }
+        }
+        if (old == h) { atomicAdd(&tc[slot], 1u); return; }
+        slot = (slot + 1) & (CNT_SLOTS - 1);
+    }
+    *ovf = 1;
+}
 
 template <>
 __global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* __restrict__ keys, const u32* __restrict__ fstart,
@@ -422,68 +520,98 @@ __global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* __restrict__ keys, con
                                                      u32* __restrict__ overflow, CountParams cp) {
     __shared__ u64 tk[CNT_SLOTS];
     __shared__ u32 tc[CNT_SLOTS];
+    __shared__ unsigned short lst[CNT_SLOTS];
     __shared__ u32 lh[CNT_LH];
-    __shared__ u32 s_ndist, s_out, s_ovf;
+    __shared__ u32 s_ctr[2][4];                 // [parity][ndist, out, ovf]
     const int tid = threadIdx.x, lane = tid & 63;
+    for (int s = tid; s < CNT_SLOTS; s += CNT_NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
     for (int b = tid; b < CNT_LH; b += CNT_NT) lh[b] = 0;
-    u32 ones = 0;          // per-lane-0 count of abundance-1 keys (register, flushed at the end)
+    if (tid < 8) s_ctr[tid >> 2][tid & 3] = 0;
+    u32 ones = 0;          // lane 0 of each wave: abundance-1 keys seen (flushed at the end)
     u64 ndist_acc = 0;
-    for (u32 q = blockIdx.x; q < cp.F; q += gridDim.x) {
-        const u32 begin = fstart[q], end = fstart[q + 1];
-        if (begin == end) { if (tid == 0) nsolid[q] = 0; continue; }
-        for (int s = tid; s < CNT_SLOTS; s += CNT_NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
-        if (tid == 0) { s_ndist = 0; s_out = 0; s_ovf = 0; }
-        __syncthreads();
-        for (u32 i = begin + tid; i < end; i += CNT_NT) {
-            const u64 h = keys[i];
-            u32 slot = (u32)(h >> cp.slot_shift) & (CNT_SLOTS - 1);
-            int probe = 0;
-            for (; probe < CNT_SLOTS; ++probe) {
-                u64 old = tk[slot];
-                if (old == DSK_EMPTY) {
-                    old = atomicCAS(&tk[slot], DSK_EMPTY, h);
-                    if (old == DSK_EMPTY) { atomicAdd(&s_ndist, 1u); old = h; }
-                }
-                if (old == h) { atomicAdd(&tc[slot], 1u); break; }
-                slot = (slot + 1) & (CNT_SLOTS - 1);
-            }
-            if (probe == CNT_SLOTS) s_ovf = 1;
-        }
-        __syncthreads();
-        const u32 nd = s_ndist;
-        if (s_ovf || nd > CNT_MAXLOAD) {          // block-uniform
-            if (tid == 0) { *overflow = 1; nsolid[q] = 0; }
-            __syncthreads();
-            continue;
-        }
-        for (int s0 = 0; s0 < CNT_SLOTS; s0 += CNT_NT) {
-            const u64 key = tk[s0 + tid];
-            const u32 c = tc[s0 + tid];
-            const bool occ = key != DSK_EMPTY;
-            const u64 m1 = __ballot(occ && c == 1);
-            if (lane == 0) ones += __popcll(m1);
-            if (occ && c > 1) {
-                const u32 bin = c < cp.histo_max ? c : cp.histo_max;
-                if (bin < CNT_LH) atomicAdd(&lh[bin], 1u);
-                else atomicAdd(&ghist[bin], 1ull);
-            }
-            const bool solid = occ && c >= cp.amin && c <= cp.amax;
-            const u64 ms = __ballot(solid);
-            if (ms) {
-                u32 base = 0;
-                if (lane == 0) base = atomicAdd(&s_out, (u32)__popcll(ms));
-                base = __shfl(base, 0);
-                if (solid) {
-                    const u32 pos = base + __popcll(ms & ((1ull << lane) - 1));
-                    keys[begin + pos] = key;
-                    abund[begin + pos] = c;
-                }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) { nsolid[q] = s_out; ndist_acc += nd; }
-        __syncthreads();
+    u32 q = blockIdx.x;
+    u32 begin = 0, end = 0;
+    u64 pk[CNT_KPT];
+    if (q < cp.F) {
+        begin = fstart[q]; end = fstart[q + 1];
+#pragma unroll
+        for (int j = 0; j < CNT_KPT; ++j) { const u32 i = begin + tid + j * CNT_NT; if (i < end) pk[j] = keys[i]; }
     }
+    __syncthreads();
+    int par = 0;
+    while (q < cp.F) {
+        u32* ctr = s_ctr[par];
+        const u32 n = end - begin;
+        // fast path first for ILP: CNT_KPT independent probes of the home slot;
+        // a hit (key already present: the common case at high coverage) is one
+        // fire-and-forget LDS add.  Misses take the CAS/probe loop afterwards.
+        u64 seen[CNT_KPT];
+#pragma unroll
+        for (int j = 0; j < CNT_KPT; ++j)
+            seen[j] = ((u32)(tid + j * CNT_NT) < n) ? tk[(u32)pk[j] & (CNT_SLOTS - 1)] : pk[j] + 1;
+#pragma unroll
+        for (int j = 0; j < CNT_KPT; ++j)
+            if ((u32)(tid + j * CNT_NT) < n) {
+                if (seen[j] == pk[j]) atomicAdd(&tc[(u32)pk[j] & (CNT_SLOTS - 1)], 1u);
+                else table_insert1(tk, tc, lst, &ctr[0], &ctr[2], pk[j]);
+            }
+        for (u32 i = begin + CNT_KPT * CNT_NT + tid; i < end; i += CNT_NT)      // oversized sub-partition
+            table_insert1(tk, tc, lst, &ctr[0], &ctr[2], keys[i]);
+        // prefetch the block's next sub-partition
+        const u32 qn = q + gridDim.x;
+        u32 nbeg = 0, nend = 0;
+        if (qn < cp.F) {
+            nbeg = fstart[qn]; nend = fstart[qn + 1];
+#pragma unroll
+            for (int j = 0; j < CNT_KPT; ++j) { const u32 i = nbeg + tid + j * CNT_NT; if (i < nend) pk[j] = keys[i]; }
+        }
+        __syncthreads();
+        const u32 nd = ctr[0];
+        const bool bad = ctr[2] || nd > CNT_MAXLOAD;           // block-uniform
+        if (bad) {
+            for (int s = tid; s < CNT_SLOTS; s += CNT_NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
+            if (tid == 0) *overflow = 1;
+        } else {
+            for (u32 i0 = 0; i0 < nd; i0 += CNT_NT) {
+                const u32 i = i0 + tid;
+                const bool act = i < nd;
+                u64 key = 0; u32 c = 0;
+                if (act) {
+                    const u32 slot = lst[i];
+                    key = tk[slot]; c = tc[slot];
+                    tk[slot] = DSK_EMPTY; tc[slot] = 0;
+                }
+                const u64 m1 = __ballot(act && c == 1);
+                if (lane == 0) ones += __popcll(m1);
+                if (act && c > 1) {
+                    const u32 bin = c < cp.histo_max ? c : cp.histo_max;
+                    if (bin < CNT_LH) atomicAdd(&lh[bin], 1u);
+                    else atomicAdd(&ghist[bin], 1ull);
+                }
+                const bool solid = act && c >= cp.amin && c <= cp.amax;
+                const u64 ms = __ballot(solid);
+                if (ms) {
+                    u32 base = 0;
+                    if (lane == 0) base = atomicAdd(&ctr[1], (u32)__popcll(ms));
+                    base = __shfl(base, 0);
+                    if (solid) {
+                        const u32 pos = base + __popcll(ms & ((1ull << lane) - 1));
+                        keys[begin + pos] = key;
+                        abund[begin + pos] = c;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            nsolid[q] = bad ? 0u : ctr[1];
+            ndist_acc += bad ? 0u : nd;
+            ctr[0] = 0; ctr[1] = 0; ctr[2] = 0;     // this parity is next used two barriers from now
+        }
+        par ^= 1;
+        q = qn; begin = nbeg; end = nend;
+    }
+    __syncthreads();
     // flush block-local histogram
     if (lane == 0 && ones) atomicAdd(&lh[1], ones);
     __syncthreads();
