@@ -1,0 +1,40 @@
+// bank.hpp -- sequence banks: FASTA / FASTQ, plain or gzip'ed, comma lists and
+// file-of-files ("albums").  Stands in for gatb-core's Bank::open / BankFasta /
+// BankAlbum on the count path (call site src/DSK.cpp:51; formats README.md:50-61;
+// multi-line records test/longread.fasta; album fixtures test/file_index*).
+//
+// A bank does not hand out per-sequence objects: the count path only needs the
+// "read stream" of include/dskgpu.h (sequence bytes, records separated by one
+// '\n'), so banks stream chunks of that form, cut at record boundaries.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace dsk {
+
+class IBank {
+public:
+    typedef std::function<void(const char* data, size_t nbytes)> Sink;
+    virtual ~IBank() {}
+    virtual std::string getId() const = 0;
+    // total size in bytes of the underlying files (compressed size for .gz)
+    virtual uint64_t getSize() const = 0;
+    // Push the whole bank through `sink` in chunks of about chunkBytes, each
+    // chunk a whole number of records.  Returns the number of sequences.
+    virtual uint64_t stream(size_t chunkBytes, const Sink& sink) = 0;
+    // (number of sequences, total bases, longest sequence); exact, by a full pass
+    virtual void estimate(uint64_t& number, uint64_t& totalSize, uint64_t& maxSize);
+    // file names (flattened)
+    virtual std::vector<std::string> files() const = 0;
+};
+
+class Bank {
+public:
+    // uri: "a.fa", "a.fa,b.fq.gz", or a file whose lines are file names
+    // (README.md:52-61).  Throws dsk::Exception when a file cannot be read.
+    static IBank* open(const std::string& uri);
+};
+
+}  // namespace dsk

@@ -1,0 +1,45 @@
+// count_backend.hpp -- seam between the host layer and the counting engine.
+// The product backend is GpuBackend (gpu_backend.cpp -> C-ABI of
+// include/dskgpu.h -> HIP kernels).  The interface exists so that the host
+// plumbing (bank, options, HDF5) can be exercised on a machine without a GPU by
+// tests that plug a checker backend; no product binary links anything else.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "tool.hpp"
+
+namespace dsk {
+
+struct CountConfig {
+    unsigned kmer_size = 31;
+    unsigned abundance_min = 2;
+    unsigned abundance_max = 2147483647u;
+    unsigned histo_max = 10000;
+    unsigned nb_partitions = 0;   // 0 = engine default
+    int device = 0;
+};
+
+class ICountBackend {
+public:
+    virtual ~ICountBackend() {}
+    virtual std::string name() const = 0;
+    virtual void configure(const CountConfig& cfg) = 0;
+    virtual void push(const char* data, size_t nbytes) = 0;   // read-stream chunk, whole records
+    virtual void finish() = 0;                                // run the count; results valid afterwards
+    virtual void histogram(std::vector<uint64_t>& h) = 0;     // histo_max + 1 entries, h[0] == 0
+    virtual uint32_t numPartitions() = 0;
+    virtual uint64_t partitionSize(uint32_t p) = 0;
+    // kmers: n * words u64 (least significant word first); abundance: n u32; ascending k-mer order
+    virtual void partitionCopy(uint32_t p, uint64_t* kmers, uint32_t* abundance) = 0;
+    virtual void stats(IProperties& info, size_t depth) = 0;
+};
+
+typedef ICountBackend* (*BackendFactory)();
+void setBackendFactory(BackendFactory f);     // set once by the executable's main()
+ICountBackend* createBackend();               // throws dsk::Exception when none was set
+
+ICountBackend* createGpuBackend();            // gpu_backend.cpp (links libdskgpu.so)
+
+}  // namespace dsk

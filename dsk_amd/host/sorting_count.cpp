@@ -1,0 +1,190 @@
+// sorting_count.cpp -- see sorting_count.hpp.
+#include "sorting_count.hpp"
+
+#include <sys/time.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <fstream>
+
+namespace dsk {
+
+namespace {
+BackendFactory g_factory = nullptr;
+double now_s() { struct timeval tv; gettimeofday(&tv, nullptr); return tv.tv_sec + 1e-6 * tv.tv_usec; }
+}
+
+void setBackendFactory(BackendFactory f) { g_factory = f; }
+ICountBackend* createBackend() {
+    if (!g_factory) throw Exception("no counting backend registered (the dsk binary registers the GPU engine)");
+    return g_factory();
+}
+
+// Options of the count path (src/DSK.cpp:83; names evidenced at README.md:12,56,92,98,127,130,
+// scripts/simple_test.sh:36,88, CHANGELOG.md:22; defaults per gatb-core 1.4.x).
+IOptionsParser* SortingCountBase::makeOptionsParser() {
+    OptionsParser* p = new OptionsParser("kmer count");
+    p->push_back(new OptionOneParam(STR_URI_INPUT, "reads file", true));
+    p->push_back(new OptionOneParam(STR_KMER_SIZE, "size of a kmer", false, "31"));
+    p->push_back(new OptionOneParam(STR_KMER_ABUNDANCE_MIN, "min abundance threshold for solid kmers (or 'auto')", false, "2"));
+    p->push_back(new OptionOneParam(STR_KMER_ABUNDANCE_MAX, "max abundance threshold for solid kmers", false, "2147483647"));
+    p->push_back(new OptionOneParam("-abundance-min-threshold", "min abundance hard threshold (only used when min abundance is 'auto')", false, "2"));
+    p->push_back(new OptionOneParam(STR_HISTOGRAM_MAX, "max number of values in kmers histogram", false, "10000"));
+    p->push_back(new OptionOneParam("-solidity-kind", "way to compute counts of several files (sum only)", false, "sum"));
+    p->push_back(new OptionOneParam(STR_MAX_MEMORY, "max memory (in MBytes); accepted, the engine sizes itself to HBM", false, "5000"));
+    p->push_back(new OptionOneParam(STR_MAX_DISK, "max disk (in MBytes); accepted and ignored: partitions live in HBM", false, "0"));
+    p->push_back(new OptionOneParam(STR_URI_OUTPUT, "output file for solid kmers", false, ""));
+    p->push_back(new OptionOneParam(STR_URI_OUTPUT_DIR, "output directory", false, "."));
+    p->push_back(new OptionOneParam(STR_URI_OUTPUT_TMP, "output directory for temporary files; accepted and ignored", false, "."));
+    p->push_back(new OptionOneParam("-out-compress", "h5 compression level (0:none, 9:best)", false, "0"));
+    p->push_back(new OptionOneParam("-storage-type", "storage type of kmer counts (hdf5 only)", false, "hdf5"));
+    p->push_back(new OptionOneParam("-histo2D", "compute the 2D histogram (with first file = genome, remaining files = reads)", false, "0"));
+    p->push_back(new OptionOneParam("-histo", "output the kmer abundance histogram as <out>.histo", false, "0"));
+    p->push_back(new OptionOneParam("-minimizer-type", "minimizer type; accepted, does not change results", false, "0", false));
+    p->push_back(new OptionOneParam("-minimizer-size", "size of a minimizer", false, "10", false));
+    p->push_back(new OptionOneParam("-repartition-type", "minimizer repartition; accepted, does not change results", false, "0", false));
+    p->push_back(new OptionOneParam("-nb-partitions", "number of output partitions under dsk/solid (0 = default)", false, "0", false));
+    p->push_back(new OptionOneParam("-device", "GPU ordinal", false, "0", false));
+    return p;
+}
+
+SortingCountBase::SortingCountBase(IBank* bank, IProperties* params, size_t words, size_t span)
+    : bank_(bank), words_(words), span_(span) {
+    if (params) input_.add(0, params);
+}
+SortingCountBase::~SortingCountBase() {}
+
+std::string SortingCountBase::outputName(const IProperties& in, const std::vector<std::string>& files) {
+    std::string out = in.has(STR_URI_OUTPUT) ? in.getStr(STR_URI_OUTPUT) : "";
+    if (out.empty()) {   // basename of the first input without its extensions (test/test_ERR039477.sh:11-12)
+        std::string f = files.empty() ? "output" : files[0];
+        size_t s = f.find_last_of('/'); if (s != std::string::npos) f = f.substr(s + 1);
+        for (const char* ext : {".gz", ".fasta", ".fastq", ".fa", ".fq", ".fna", ".txt"}) {
+            std::string e = ext;
+            if (f.size() > e.size() && f.compare(f.size() - e.size(), e.size(), e) == 0) f.resize(f.size() - e.size());
+        }
+        out = f;
+    }
+    std::string dir = in.has(STR_URI_OUTPUT_DIR) ? in.getStr(STR_URI_OUTPUT_DIR) : ".";
+    if (out.find('/') == std::string::npos && dir != "." && !dir.empty()) out = dir + "/" + out;
+    return out;
+}
+
+void SortingCountBase::autoCutoff(const std::vector<uint64_t>& h, unsigned& cutoff, unsigned& firstPeak) {
+    cutoff = 0; firstPeak = 0;
+    size_t n = h.size();
+    if (n < 4) return;
+    size_t i = 1;
+    while (i + 1 < n && h[i + 1] < h[i]) ++i;           // descend the error tail
+    size_t valley = i;
+    size_t peak = valley;
+    for (size_t j = valley; j < n; ++j) if (h[j] > h[peak]) peak = j;
+    if (peak == valley || h[peak] == 0) return;          // no genomic peak: leave cutoff 0
+    cutoff = (unsigned)valley; firstPeak = (unsigned)peak;
+}
+
+void SortingCountBase::execute() {
+    const double t0 = now_s();
+    const size_t k = (size_t)input_.getInt(STR_KMER_SIZE);
+    if (k < 1 || k > span_) throw Exception("bad kmer size %zu", k);
+    const std::string aminStr = input_.has(STR_KMER_ABUNDANCE_MIN) ? input_.getStr(STR_KMER_ABUNDANCE_MIN) : "2";
+    const bool autoMin = (aminStr == "auto");
+    const unsigned thresh = input_.has("-abundance-min-threshold") ? (unsigned)input_.getInt("-abundance-min-threshold") : 2u;
+    CountConfig cfg;
+    cfg.kmer_size = (unsigned)k;
+    cfg.abundance_min = autoMin ? std::max(1u, thresh) : (unsigned)std::max<long long>(0, atoll(aminStr.c_str()));
+    cfg.abundance_max = input_.has(STR_KMER_ABUNDANCE_MAX) ? (unsigned)std::min<long long>(input_.getInt(STR_KMER_ABUNDANCE_MAX), 4294967295LL) : 2147483647u;
+    cfg.histo_max = input_.has(STR_HISTOGRAM_MAX) ? (unsigned)input_.getInt(STR_HISTOGRAM_MAX) : 10000u;
+    cfg.nb_partitions = input_.has("-nb-partitions") ? (unsigned)input_.getInt("-nb-partitions") : 0u;
+    cfg.device = input_.has("-device") ? (int)input_.getInt("-device") : 0;
+    if (input_.has("-solidity-kind") && input_.getStr("-solidity-kind") != "sum")
+        throw Exception("-solidity-kind '%s' is not supported (only 'sum')", input_.getStr("-solidity-kind").c_str());
+    if (input_.has("-histo2D") && input_.getInt("-histo2D") != 0)
+        throw Exception("-histo2D is not supported yet");
+    if (input_.has("-storage-type") && input_.getStr("-storage-type") != "hdf5")
+        throw Exception("-storage-type '%s' is not supported (only 'hdf5')", input_.getStr("-storage-type").c_str());
+    const int compress = input_.has("-out-compress") ? (int)input_.getInt("-out-compress") : 0;
+
+    std::string firstUri = bank_->getId();
+    if (firstUri.find(',') != std::string::npos) firstUri = firstUri.substr(0, firstUri.find(','));
+    const std::string out = outputName(input_, {firstUri});
+    storage_.reset(StorageFactory(STORAGE_HDF5).create(out, true, false));
+
+    std::unique_ptr<ICountBackend> be(createBackend());
+    be->configure(cfg);
+    uint64_t nbytes = 0;
+    const double t1 = now_s();
+    const uint64_t nseq = bank_->stream((size_t)64 << 20, [&](const char* d, size_t n) { be->push(d, n); nbytes += n; });
+    const double t2 = now_s();
+    be->finish();
+    const double t3 = now_s();
+
+    be->histogram(histo_);
+    unsigned cutoff = 0, firstPeak = 0;
+    autoCutoff(histo_, cutoff, firstPeak);
+    unsigned amin = cfg.abundance_min;
+    if (autoMin) amin = std::max(cfg.abundance_min, cutoff);
+
+    // CountProcessor chain outputs: histogram ...
+    {
+        std::vector<HistoEntry> rows(cfg.histo_max);
+        for (unsigned i = 1; i <= cfg.histo_max; ++i) { rows[i - 1].index = (uint16_t)i; rows[i - 1].abundance = histo_[i]; }
+        hid_t t = H5Row<HistoEntry>::make();
+        Group& hg = storage_->getGroup("histogram");
+        hg.writeDataset("histogram", t, rows.data(), rows.size(), 0);
+        H5Tclose(t);
+        hg.setProperty("cutoff", std::to_string(cutoff));
+        hg.setProperty("first_peak", std::to_string(firstPeak));
+        uint64_t autoSolids = 0; for (size_t i = std::max(1u, cutoff); i < histo_.size(); ++i) autoSolids += histo_[i];
+        hg.setProperty("nbsolids_auto", std::to_string(autoSolids));
+    }
+    // ... and the solid rows, one dataset per partition
+    const uint32_t np = be->numPartitions();
+    openPartitions(np);
+    nb_solid_ = 0;
+    std::vector<uint64_t> kbuf; std::vector<uint32_t> abuf;
+    for (uint32_t p = 0; p < np; ++p) {
+        const uint64_t n = be->partitionSize(p);
+        kbuf.resize(n * words_ + 1); abuf.resize(n + 1);
+        if (n) be->partitionCopy(p, kbuf.data(), abuf.data());
+        writePartition(p, kbuf.data(), abuf.data(), n, amin, compress);
+    }
+    Group& dg = storage_->getGroup("dsk");
+    dg.setProperty("kmer_size", std::to_string(k));
+    const double t4 = now_s();
+
+    if (input_.has("-histo") && input_.getInt("-histo") != 0) {   // README.md:90-96, utils/plot-histo.R:24
+        std::ofstream hf(out + ".histo");
+        for (unsigned i = 1; i <= cfg.histo_max; ++i) hf << i << "\t" << histo_[i] << "\n";
+    }
+
+    config_.props_ = IProperties();
+    config_.props_.add(0, "config");
+    config_.props_.add(1, "kmer_size", "%zu", k);
+    config_.props_.add(1, "abundance_min", "%u", amin);
+    config_.props_.add(1, "abundance_max", "%u", cfg.abundance_max);
+    config_.props_.add(1, "histo_max", "%u", cfg.histo_max);
+    config_.props_.add(1, "storage_type", "hdf5");
+    config_.props_.add(1, "nb_passes", "1");
+    config_.props_.add(1, "nb_partitions", "%u", np);
+    config_.props_.add(1, "partition_medium", "HBM (no disk spill)");
+
+    info_ = IProperties();
+    info_.add(0, getName());
+    info_.add(1, "bank");
+    info_.add(2, "uri", bank_->getId());
+    info_.add(2, "nb_sequences", "%llu", (unsigned long long)nseq);
+    info_.add(2, "read_stream_bytes", "%llu", (unsigned long long)nbytes);
+    info_.add(1, "stats");
+    be->stats(info_, 2);
+    info_.add(2, "solid_kmers_written", "%llu", (unsigned long long)nb_solid_);
+    info_.add(2, "cutoff_auto", "%u", cutoff);
+    info_.add(1, "time");
+    info_.add(2, "setup_s", "%.3f", t1 - t0);
+    info_.add(2, "ingest_s", "%.3f", t2 - t1);
+    info_.add(2, "count_s", "%.3f", t3 - t2);
+    info_.add(2, "write_s", "%.3f", t4 - t3);
+    info_.add(2, "total_s", "%.3f", t4 - t0);
+}
+
+}  // namespace dsk

@@ -1,0 +1,86 @@
+// sorting_count.hpp -- SortingCountAlgorithm<span>: the object the DSK wrapper
+// drives (src/DSK.cpp:55-68):
+//     SortingCountAlgorithm<span> sortingCount (bank, props);
+//     sortingCount.getInput()->add (0, STR_VERBOSE, ...);
+//     sortingCount.execute();
+//     sortingCount.getConfig().getProperties();  sortingCount.getInfo();
+//     sortingCount.getStorage()->getGroup(sortingCount.getName()).setProperty("xml", ...);
+// and `SortingCountAlgorithm<>::getOptionsParser()` (src/DSK.cpp:83).
+// Here execute() streams the bank into the counting engine (GPU backend), then
+// plays the CountProcessor chain's outputs into HDF5: histogram -> solidity ->
+// dump (README.md:12,70-78).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "bank.hpp"
+#include "count_backend.hpp"
+#include "kmer.hpp"
+#include "storage.hpp"
+#include "tool.hpp"
+
+namespace dsk {
+
+class Configuration {
+public:
+    IProperties getProperties() const { return props_; }
+    IProperties props_;
+};
+
+// span-independent part (the engine works on `words` 64-bit words per k-mer)
+class SortingCountBase {
+public:
+    SortingCountBase(IBank* bank, IProperties* params, size_t words, size_t span);
+    virtual ~SortingCountBase();
+    static IOptionsParser* makeOptionsParser();
+    IProperties* getInput() { return &input_; }
+    IProperties* getInfo() { return &info_; }
+    const Configuration& getConfig() const { return config_; }
+    Storage* getStorage() { return storage_.get(); }
+    std::string getName() const { return "dsk"; }
+    void execute();
+    // results kept for callers that want them without re-reading the file
+    const std::vector<uint64_t>& histogram() const { return histo_; }
+    uint64_t nbSolid() const { return nb_solid_; }
+    static std::string outputName(const IProperties& in, const std::vector<std::string>& files);
+    // histogram cutoff used by "-abundance-min auto": first local minimum, then
+    // the following maximum (the genomic peak); returns (cutoff, first_peak)
+    static void autoCutoff(const std::vector<uint64_t>& h, unsigned& cutoff, unsigned& firstPeak);
+protected:
+    virtual void writePartition(size_t p, const uint64_t* kmers, const uint32_t* ab, uint64_t n, unsigned amin, int compress) = 0;
+    virtual void openPartitions(size_t nb) = 0;
+    IBank* bank_; size_t words_, span_;
+    IProperties input_, info_;
+    Configuration config_;
+    std::unique_ptr<Storage> storage_;
+    std::vector<uint64_t> histo_;
+    uint64_t nb_solid_ = 0;
+};
+
+template <size_t span = 32>
+class SortingCountAlgorithm : public SortingCountBase {
+public:
+    typedef typename Kmer<span>::Type Type;
+    typedef typename Kmer<span>::Count Count;
+    SortingCountAlgorithm(IBank* bank, IProperties* params) : SortingCountBase(bank, params, Kmer<span>::WORDS, span) {}
+    static IOptionsParser* getOptionsParser() { return makeOptionsParser(); }
+protected:
+    void openPartitions(size_t nb) override { part_.reset(getStorage()->template solidPartition<span>(nb)); }
+    void writePartition(size_t p, const uint64_t* kmers, const uint32_t* ab, uint64_t n, unsigned amin, int compress) override {
+        std::vector<Count> rows; rows.reserve(n);
+        for (uint64_t i = 0; i < n; ++i) {
+            if (ab[i] < amin) continue;                      // only when -abundance-min auto raised the bar
+            Count c;
+            for (size_t w = 0; w < Kmer<span>::WORDS; ++w) c.value.w[w] = kmers[i * words_ + w];
+            c.abundance = (int32_t)std::min<uint32_t>(ab[i], 0x7FFFFFFFu);
+            rows.push_back(c);
+        }
+        part_->insert(p, rows.data(), rows.size(), compress);
+        nb_solid_ += rows.size();
+    }
+private:
+    std::unique_ptr<Partition<Count>> part_;
+};
+
+}  // namespace dsk

@@ -1,0 +1,169 @@
+"""Host-layer tests (CPU): the six cases of scripts/simple_test.sh:35-135 run
+through this repo's `dsk` tool wrapper + `dsk2ascii` + stock h5dump, with the
+CPU oracle plugged in as counting backend (tests/host/dsk_cpu_check.cpp -- test
+infrastructure).  They pin bank parsing, option handling, the HDF5 layout and
+the dsk2ascii text format against the reference's golden files.  The same six
+commands run against the real GPU `dsk` binary in tests/test_cli_gpu.py.
+"""
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+H5DUMP = "/opt/conda/bin/h5dump"
+
+
+@pytest.fixture(scope="module")
+def bins():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dsk_amd", "host"), "bin/dsk2ascii", "bin/libdskhost.a"],
+                          stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "host")], stdout=subprocess.DEVNULL)
+    return {"dsk": os.path.join(ROOT, "tests", "host", "dsk_cpu_check"),
+            "dsk2ascii": os.path.join(ROOT, "dsk_amd", "host", "bin", "dsk2ascii")}
+
+
+def h5_histo(h5, cwd):
+    """scripts/simple_test.sh:37 with stock h5dump standing in for gatb-h5dump."""
+    cmd = f"{H5DUMP} -y -d histogram/histogram {h5} | grep '^\\ *[0-9]' | tr -d ' ' | tr -d ',' | paste - -"
+    return subprocess.check_output(cmd, shell=True, cwd=cwd).decode()
+
+
+def run_six_cases(dsk, dsk2ascii, tmp):
+    def run(*args, **kw):
+        return subprocess.run(list(args), cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, **kw)
+    # T1 single gz
+    r = run(dsk, "-file", f"{G}/read50x_ref10K_e001.fasta.gz", "-kmer-size", "27", "-out", "test_dsk27", "-max-memory", "200", "-verbose", "0")
+    assert r.returncode == 0, r.stderr
+    assert h5_histo("test_dsk27.h5", tmp) == open(f"{G}/k27.histo").read()
+    # T2 multiple gz
+    files = ",".join(f"{G}/c{i}.fasta.gz" for i in (1, 2, 3, 4))
+    r = run(dsk, "-file", files, "-kmer-size", "27", "-out", "test_dsk27", "-max-memory", "200", "-verbose", "0")
+    assert r.returncode == 0, r.stderr
+    assert h5_histo("test_dsk27.h5", tmp) == open(f"{G}/k27.histo").read()
+    # T3 long reads
+    r = run(dsk, "-file", f"{G}/longread.fasta", "-kmer-size", "27", "-out", "test_long", "-verbose", "0", "-max-memory", "200")
+    assert r.returncode == 0, r.stderr
+    assert h5_histo("test_long.h5", tmp) == open(f"{G}/rlong.histo").read()
+    # T4 k = readlen; dsk2ascii accepts the name without .h5 (simple_test.sh:89)
+    r = run(dsk, "-file", f"{G}/shortread.fasta", "-kmer-size", "15", "-abundance-min", "1", "-out", "test_short", "-verbose", "0", "-max-memory", "200")
+    assert r.returncode == 0, r.stderr
+    r = run(dsk2ascii, "-file", "test_short", "-out", "test_short.parse_results", "-verbose", "0")
+    assert r.returncode == 0, r.stdout
+    assert open(os.path.join(tmp, "test_short.parse_results")).read() == open(f"{G}/short.parse_results").read()
+    # T5 k = readlen + 1: no k-mer, no hang, empty dump
+    r = run(dsk, "-file", f"{G}/shortread.fasta", "-kmer-size", "16", "-out", "test_short16", "-max-memory", "200")
+    assert r.returncode == 0, r.stderr
+    r = run(dsk2ascii, "-file", "test_short16.h5", "-out", "test_short16.parse_results", "-verbose", "0")
+    assert r.returncode == 0 and os.path.getsize(os.path.join(tmp, "test_short16.parse_results")) == 0
+    # T6 reads with N
+    r = run(dsk, "-file", f"{G}/readN.fasta", "-kmer-size", "20", "-out", "test_N", "-verbose", "0", "-max-memory", "200")
+    assert r.returncode == 0, r.stderr
+    assert h5_histo("test_N.h5", tmp) == open(f"{G}/readN.histo").read()
+
+
+def known_answer_dump(dsk, dsk2ascii, tmp, k, md5, nlines):
+    r = subprocess.run([dsk, "-file", f"{G}/read50x_ref10K_e001.fasta.gz", "-kmer-size", str(k), "-abundance-min", "2",
+                        "-out", f"ka{k}", "-verbose", "0"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([dsk2ascii, "-file", f"ka{k}.h5", "-out", f"ka{k}.txt", "-verbose", "0"], cwd=tmp)
+    assert r.returncode == 0
+    txt = open(os.path.join(tmp, f"ka{k}.txt"), "rb").read()
+    assert txt.count(b"\n") == nlines
+    assert hashlib.md5(txt).hexdigest() == md5     # rows globally ascending => same md5 as SURVEY.md App. A
+
+
+def test_simple_test_sh_cases(bins, tmp_path):
+    run_six_cases(bins["dsk"], bins["dsk2ascii"], str(tmp_path))
+
+
+@pytest.mark.parametrize("k,md5,n", [(31, "5b4da4c690bb00783eb5fdc49fc19466", 13096),
+                                     (63, "ed2b871b9bbbdd93479ef66330c0b563", 10945)])
+def test_known_answer_dumps(bins, tmp_path, k, md5, n):
+    known_answer_dump(bins["dsk"], bins["dsk2ascii"], str(tmp_path), k, md5, n)
+
+
+def test_layout_and_attributes(bins, tmp_path):
+    tmp = str(tmp_path)
+    subprocess.check_call([bins["dsk"], "-file", f"{G}/longread.fasta", "-kmer-size", "31", "-out", "lay", "-verbose", "0",
+                           "-nb-partitions", "3", "-histo", "1"], cwd=tmp)
+    hdr = subprocess.check_output([H5DUMP, "-H", "lay.h5"], cwd=tmp).decode()
+    for needle in ('GROUP "dsk"', 'ATTRIBUTE "kmer_size"', 'ATTRIBUTE "xml"', 'GROUP "solid"', 'ATTRIBUTE "nb_partitions"',
+                   'DATASET "0"', 'DATASET "2"', 'H5T_STD_U64LE "value"', 'H5T_STD_I32LE "abundance"',
+                   'GROUP "histogram"', 'DATASET "histogram"', 'H5T_STD_U16LE "index"', 'H5T_STD_U64LE "abundance"', "( 10000 )"):
+        assert needle in hdr, needle
+    assert 'DATASET "3"' not in hdr
+    attr = subprocess.check_output([H5DUMP, "-a", "/dsk/kmer_size", "lay.h5"], cwd=tmp).decode()
+    assert '"31"' in attr
+    histo = open(os.path.join(tmp, "lay.histo")).read().splitlines()
+    assert len(histo) == 10000 and histo[0].split("\t")[0] == "1"
+    assert h5_histo("lay.h5", tmp).splitlines() == histo
+
+
+def test_fastq_multiline_album_and_default_out(bins, tmp_path, oracle):
+    import gzip
+    tmp = str(tmp_path)
+    seqs = ["ACGTACGTACGTTTGACCA", "GGGTTTAAACCCNACGTACGTAGCTAGCTAGCAT", "TTTTTTTTTTTTTTTTTTTTTTTT"]
+    with open(os.path.join(tmp, "a.fastq"), "w") as f:
+        for i, s in enumerate(seqs):
+            f.write(f"@r{i} desc\n{s}\n+\n{'I' * len(s)}\n")
+    with gzip.open(os.path.join(tmp, "b.fa.gz"), "wt") as f:     # multi-line FASTA, CRLF, lower case
+        f.write(">x\r\nacgtacgtacgt\r\nttgacca\r\n>y\nGGGTTTAAACCC\nNACGTACGTAG\n")
+    with open(os.path.join(tmp, "album.txt"), "w") as f:
+        f.write("a.fastq\nb.fa.gz\n")
+    subprocess.check_call([bins["dsk"], "-file", "album.txt", "-kmer-size", "7", "-abundance-min", "1", "-verbose", "0"], cwd=tmp)
+    assert os.path.exists(os.path.join(tmp, "album.h5"))          # default -out = input basename without extension
+    subprocess.check_call([bins["dsk2ascii"], "-file", "album.h5", "-out", "album.out", "-verbose", "0"], cwd=tmp)
+    got = open(os.path.join(tmp, "album.out")).read().splitlines()
+    import numpy as np
+    stream = ("\n".join(seqs) + "\n" + "acgtacgtacgtttgacca\nGGGTTTAAACCCNACGTACGTAG\n").encode()
+    want = oracle.ascii_lines(oracle.count(np.frombuffer(stream, dtype=np.uint8), 7), amin=1)
+    assert got == want
+    # comma list of the same files gives the same dump
+    subprocess.check_call([bins["dsk"], "-file", "a.fastq,b.fa.gz", "-kmer-size", "7", "-abundance-min", "1", "-out", "cl", "-verbose", "0"], cwd=tmp)
+    subprocess.check_call([bins["dsk2ascii"], "-file", "cl", "-out", "cl.out", "-verbose", "0"], cwd=tmp)
+    assert open(os.path.join(tmp, "cl.out")).read().splitlines() == want
+
+
+def test_error_paths(bins, tmp_path):
+    tmp = str(tmp_path)
+    r = subprocess.run([bins["dsk"], "-file", "/nonexistent.fa"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and r.stderr.startswith(b"EXCEPTION: ")           # src/main.cpp:42-46
+    r = subprocess.run([bins["dsk"]], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"-file" in r.stdout and b"mandatory" in r.stdout   # src/main.cpp:37-40
+    r = subprocess.run([bins["dsk"], "-file", f"{G}/shortread.fasta", "-bogus", "1"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"Unknown parameter" in r.stdout
+    r = subprocess.run([bins["dsk"], "-file", f"{G}/shortread.fasta", "-kmer-size", "64"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"EXCEPTION" in r.stderr
+    r = subprocess.run([bins["dsk2ascii"], "-file", "nope", "-out", "x"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and r.stdout.startswith(b"EXCEPTION: ")           # utils/dsk2ascii.cpp:129-133 (stdout)
+    r = subprocess.run([bins["dsk"], "-help"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and b"-kmer-size" in r.stdout
+
+
+def test_dsk2ascii_variants(bins, tmp_path):
+    tmp = str(tmp_path)
+    subprocess.check_call([bins["dsk"], "-file", f"{G}/shortread.fasta", "-kmer-size", "15", "-abundance-min", "1", "-out", "s", "-verbose", "0"], cwd=tmp)
+    out = subprocess.check_output([bins["dsk2ascii"], "-file", "s", "-out", "unused", "-c", "-verbose", "0"], cwd=tmp).decode()
+    assert out == "ACTGTACGTATAAGA 1\n"
+    subprocess.check_call([bins["dsk2ascii"], "-file", "s", "-out", "s.fa", "-fasta", "-verbose", "0"], cwd=tmp)
+    assert open(os.path.join(tmp, "s.fa")).read() == ">\nACTGTACGTATAAGA\n"
+    subprocess.check_call([bins["dsk2ascii"], "-file", "s", "-out", "s.fq", "-fastq", "-verbose", "0"], cwd=tmp)
+    assert open(os.path.join(tmp, "s.fq")).read() == "@\nACTGTACGTATAAGA\n+\n" + "-" * 15 + "\n"
+
+
+def test_abundance_min_auto(bins, tmp_path, oracle):
+    tmp = str(tmp_path)
+    subprocess.check_call([bins["dsk"], "-file", f"{G}/read50x_ref10K_e001.fasta.gz", "-kmer-size", "27", "-abundance-min", "auto",
+                           "-out", "auto", "-verbose", "0"], cwd=tmp)
+    cutoff = subprocess.check_output([H5DUMP, "-a", "/histogram/cutoff", "auto.h5"], cwd=tmp).decode()
+    s, _ = oracle.load_bank(f"{G}/read50x_ref10K_e001.fasta.gz")
+    h = oracle.count(s, 27).histogram(10000)
+    i = 1
+    while h[i + 1] < h[i]:
+        i += 1
+    assert f'"{i}"' in cutoff
+    subprocess.check_call([bins["dsk2ascii"], "-file", "auto", "-out", "auto.txt", "-verbose", "0"], cwd=tmp)
+    assert sum(1 for _ in open(os.path.join(tmp, "auto.txt"))) == int(h[i:].sum())
