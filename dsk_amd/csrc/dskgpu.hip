@@ -57,7 +57,9 @@ struct dskgpu_ctx {
     DevBuf packed, inval;          // K1 output
     DevBuf bufA, bufB;             // partition ping-pong
     DevBuf mat1, mat2, sums, descs1, descs2, seg, fstart, nsolid, scalars, ghist, gstats;
-    DevBuf out_lo, out_hi, out_ab, srt_lo, srt_hi, srt_ab, srt_tmp, srt_idx, srt_idx2;
+    DevBuf out_lo, out_hi, out_ab, srt_lo, srt_hi, srt_ab, srt_tmp, srt_idx, srt_idx2, srt_k, abund2;
+    std::vector<u32> h_starts;
+    u32 h_back[4] = {0}; u64 h_stats[4] = {0};   // host landing zone of the async size read-back
     std::vector<ChunkDesc> h_descs1;
     u32 h_sc[SC_COUNT] = {0};      // host mirror of the device scalars (kept alive across async copies)
 
@@ -146,7 +148,7 @@ int run_scan(dskgpu_ctx* ctx, u32* a, const u32* d_len, u64 max_len) {
 
 u32 dbg_flags() { static int v = -1; if (v < 0) { const char* e = getenv("DSKGPU_DBG"); v = e ? atoi(e) : 0; } return (u32)v; }
 
-size_t scatter_lds(int W, u32 P) { return (size_t)SC_TILE * 8 * W + (size_t)P * 16 + 17 * 4 + 16; }
+size_t scatter_lds(int W, u32 P) { return (size_t)(W == 1 ? Tile<1>::KEYS * 8 : Tile<2>::KEYS * 16) + (size_t)P * 16 + 17 * 4 + 16; }
 
 template <int W, int SRC>
 int launch_hist(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
@@ -182,14 +184,16 @@ struct Plan {
 };
 
 #define TARGET_KEYS 2560      // worst-case mean keys per final sub-partition (table: 4096 slots, 3584 usable)
+#define TARGET_KEYS2 1280     // two-word keys: 2048-slot index table, 1792 usable
 #define MAX_LEVEL_BINS 2048
 #define ONE_LEVEL_BINS 1024
 #define CH2 65536u            // keys per level-2 chunk
 
 // Final sub-partitions F = P1 * P2 sized to the input (any integer, not a power
 // of two: digits use the multiply-shift reduction of key_digit()).
-bool make_plan(u64 n_upper, int extra_bits, Plan* pl) {
-    u64 F = ((n_upper + TARGET_KEYS - 1) / TARGET_KEYS) << extra_bits;
+bool make_plan(u64 n_upper, int extra_bits, int W, Plan* pl) {
+    const u64 target = W == 1 ? TARGET_KEYS : TARGET_KEYS2;
+    u64 F = ((n_upper + target - 1) / target) << extra_bits;
     if (F < 2) F = 2;
     if (F <= ONE_LEVEL_BINS) { pl->levels = 1; pl->P1 = (u32)F; pl->P2 = 1; }
     else {
@@ -205,7 +209,7 @@ bool make_plan(u64 n_upper, int extra_bits, Plan* pl) {
 }
 
 // Build level-1 chunk descriptors on the host (ranges are static).
-// unit = tile granularity of the source (SC_TILE_WORDS words or SC_TILE keys).
+// unit = tile granularity of the source (Tile<W>::WORDS words or Tile<W>::KEYS keys).
 void build_descs1(dskgpu_ctx* ctx, u64 n_units_total, u64 tile, u64 max_chunks, u32* nch_out) {
     const u64 ntiles = std::max<u64>(1, (n_units_total + tile - 1) / tile);
     u64 nch = std::min<u64>(ntiles, max_chunks);
@@ -224,37 +228,55 @@ void build_descs1(dskgpu_ctx* ctx, u64 n_units_total, u64 tile, u64 max_chunks, 
     *nch_out = (u32)nch;
 }
 
-// The pipeline behind dskgpu_count / dskgpu_mg_count.
-template <int W>
-int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_keys_in, u64 nkeys_in);
-
 }  // namespace
-
-// W == 1 result post-processing: sort rows by k-mer value
-static int sort_rows_1(dskgpu_ctx* ctx, u64 n) {
-    if (n == 0) { ctx->res_lo = ctx->out_lo.as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>(); ctx->res_hi = nullptr; return DSKGPU_OK; }
-    if (ctx->cfg.flags & DSKGPU_F_NO_SORT) {
-        ctx->res_lo = ctx->out_lo.as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>(); ctx->res_hi = nullptr;
-        return DSKGPU_OK;
-    }
-    CK(ctx->srt_lo.ensure(n * 8));
-    CK(ctx->srt_ab.ensure(n * 4));
-    size_t tmp = 0;
-    const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
-    CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->out_lo.as<u64>(), ctx->srt_lo.as<u64>(), ctx->out_ab.as<u32>(),
-                                 ctx->srt_ab.as<u32>(), (size_t)n, 0u, end_bit, ctx->stream));
-    CK(ctx->srt_tmp.ensure(tmp));
-    CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->out_lo.as<u64>(), ctx->srt_lo.as<u64>(), ctx->out_ab.as<u32>(),
-                                 ctx->srt_ab.as<u32>(), (size_t)n, 0u, end_bit, ctx->stream));
-    ctx->res_lo = ctx->srt_lo.as<u64>(); ctx->res_ab = ctx->srt_ab.as<u32>(); ctx->res_hi = nullptr;
-    return DSKGPU_OK;
-}
 
 namespace {
 
-template <>
-int run_pipeline<1>(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u64 nkeys_in) {
-    constexpr int W = 1;
+// ---- result post-processing: sort rows by k-mer value
+int sort_rows(dskgpu_ctx* ctx, u64 n) {
+    const bool two = ctx->W == 2;
+    ctx->res_lo = ctx->out_lo.as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>();
+    ctx->res_hi = two ? ctx->out_hi.as<u64>() : nullptr;
+    if (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT)) return DSKGPU_OK;
+    CK(ctx->srt_lo.ensure(n * 8));
+    CK(ctx->srt_ab.ensure(n * 4));
+    size_t tmp = 0;
+    if (!two) {
+        const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
+        CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->out_lo.as<u64>(), ctx->srt_lo.as<u64>(), ctx->out_ab.as<u32>(),
+                                     ctx->srt_ab.as<u32>(), (size_t)n, 0u, end_bit, ctx->stream));
+        CK(ctx->srt_tmp.ensure(tmp));
+        CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->out_lo.as<u64>(), ctx->srt_lo.as<u64>(), ctx->out_ab.as<u32>(),
+                                     ctx->srt_ab.as<u32>(), (size_t)n, 0u, end_bit, ctx->stream));
+        ctx->res_lo = ctx->srt_lo.as<u64>(); ctx->res_ab = ctx->srt_ab.as<u32>();
+        return DSKGPU_OK;
+    }
+    // 128-bit order = stable sort by the low word, then stable sort by the high word
+    CK(ctx->srt_hi.ensure(n * 8));
+    CK(ctx->srt_k.ensure(n * 8));
+    CK(ctx->srt_idx.ensure(n * 4));
+    CK(ctx->srt_idx2.ensure(n * 4));
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    const unsigned hi_bits = std::max(1u, 2u * ctx->cfg.kmer_size - 64u);
+    u32* idx = ctx->srt_idx.as<u32>(); u32* idx2 = ctx->srt_idx2.as<u32>();
+    hipLaunchKernelGGL(k_iota, dim3(gb), dim3(256), 0, ctx->stream, idx, n);
+    size_t tmp2 = 0;
+    CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->out_lo.as<u64>(), ctx->srt_k.as<u64>(), idx, idx2, (size_t)n, 0u, 64u, ctx->stream));
+    CK(rocprim::radix_sort_pairs(nullptr, tmp2, ctx->srt_k.as<u64>(), ctx->srt_hi.as<u64>(), idx2, idx, (size_t)n, 0u, hi_bits, ctx->stream));
+    CK(ctx->srt_tmp.ensure(std::max(tmp, tmp2)));
+    CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->out_lo.as<u64>(), ctx->srt_k.as<u64>(), idx, idx2, (size_t)n, 0u, 64u, ctx->stream));
+    hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_k.as<u64>(), ctx->out_hi.as<u64>(), idx2, n);
+    CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp2, ctx->srt_k.as<u64>(), ctx->srt_hi.as<u64>(), idx2, idx, (size_t)n, 0u, hi_bits, ctx->stream));
+    hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_lo.as<u64>(), ctx->out_lo.as<u64>(), idx, n);
+    hipLaunchKernelGGL(k_gather<u32>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_ab.as<u32>(), ctx->out_ab.as<u32>(), idx, n);
+    CKL("sort_rows");
+    ctx->res_lo = ctx->srt_lo.as<u64>(); ctx->res_hi = ctx->srt_hi.as<u64>(); ctx->res_ab = ctx->srt_ab.as<u32>();
+    return DSKGPU_OK;
+}
+
+template <int W>
+int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_keys_in, u64 nkeys_in) {
+    typedef typename KeyT<W>::T Key;
     ctx->have_result = false;
     ctx->st_names.clear(); ctx->st_ms.clear(); ctx->marks.clear(); ctx->ev_used = 0;
     const u64 n_upper = from_reads ? ctx->n_bytes : nkeys_in;
@@ -269,20 +291,21 @@ int run_pipeline<1>(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u64 
     CK(ctx->scalars.ensure(SC_COUNT * 4));
     CK(ctx->ghist.ensure(((size_t)ctx->cfg.histo_max + 1) * 8));
     CK(ctx->gstats.ensure(4 * 8));
-    CK(ctx->bufA.ensure((n_upper + 1) * 8 * W));
-    CK(ctx->bufB.ensure((n_upper + 1) * 8 * W));
+    CK(ctx->bufA.ensure((n_upper + 1) * sizeof(Key)));
+    CK(ctx->bufB.ensure((n_upper + 1) * sizeof(Key)));
+    if (W == 2) CK(ctx->abund2.ensure((n_upper + 1) * 4));
     u32* sc = ctx->scalars.as<u32>();
 
     int extra_bits = 0;
     for (int attempt = 0;; ++attempt) {
         Plan pl;
-        if (!make_plan(n_upper, extra_bits, &pl))
+        if (!make_plan(n_upper, extra_bits, W, &pl))
             return fail(ctx, DSKGPU_E_OVERFLOW, "cannot partition finer (table overflow persists)");
         // ---------------- level 1
         u32 nch1 = 0;
         const u64 max_chunks1 = (u64)ctx->num_cu * 8;
-        if (from_reads) build_descs1(ctx, nwords, SC_TILE_WORDS, max_chunks1, &nch1);
-        else build_descs1(ctx, nkeys_in, SC_TILE, max_chunks1, &nch1);
+        if (from_reads) build_descs1(ctx, nwords, Tile<W>::WORDS, max_chunks1, &nch1);
+        else build_descs1(ctx, nkeys_in, Tile<W>::KEYS, max_chunks1, &nch1);
         const u64 M1 = (u64)pl.P1 * nch1;
         CK(ctx->descs1.ensure(ctx->h_descs1.size() * sizeof(ChunkDesc)));
         CK(hipMemcpyAsync(ctx->descs1.p, ctx->h_descs1.data(), ctx->h_descs1.size() * sizeof(ChunkDesc),
@@ -296,18 +319,19 @@ int run_pipeline<1>(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u64 
         CK(hipMemsetAsync(ctx->gstats.p, 0, 4 * 8, ctx->stream));
         ctx->mark("setup");
         int rc;
-        if (from_reads) rc = launch_hist<W, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), pl.d1, pl.P1);
-        else rc = launch_hist<W, 1>(ctx, d_keys_in, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), pl.d1, pl.P1);
+        const ChunkDesc* dd1 = ctx->descs1.as<ChunkDesc>();
+        if (from_reads) rc = launch_hist<W, 0>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), pl.d1, pl.P1);
+        else rc = launch_hist<W, 1>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), pl.d1, pl.P1);
         if (rc) return rc;
         ctx->mark("hist1");
         if ((rc = run_scan(ctx, ctx->mat1.as<u32>(), sc + SC_MLEN1, M1))) return rc;
         ctx->mark("scan1");
-        if (from_reads) rc = launch_scatter<W, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<u64>(), pl.d1, pl.P1);
-        else rc = launch_scatter<W, 1>(ctx, d_keys_in, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<u64>(), pl.d1, pl.P1);
+        if (from_reads) rc = launch_scatter<W, 0>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<Key>(), pl.d1, pl.P1);
+        else rc = launch_scatter<W, 1>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<Key>(), pl.d1, pl.P1);
         if (rc) return rc;
         ctx->mark("scatter1");
-        u64* fkeys = ctx->bufA.as<u64>();
-        u32* scratch = ctx->bufB.as<u32>();
+        Key* fkeys = ctx->bufA.as<Key>();
+        DevBuf* scratch = &ctx->bufB;
         CK(ctx->fstart.ensure(((size_t)pl.F + 2) * 4));
         CK(ctx->nsolid.ensure(((size_t)pl.F + 2) * 4));
         // ---------------- level 2
@@ -322,14 +346,15 @@ int run_pipeline<1>(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u64 
                                ctx->seg.as<SegInfo>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, sc + SC_MLEN2);
             CKL("k_plan");
             ctx->mark("plan2");
-            if ((rc = launch_hist<W, 1>(ctx, ctx->bufA.as<u64>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, max_chunks2, ctx->mat2.as<u32>(), pl.d2, pl.P2))) return rc;
+            const ChunkDesc* dd2 = ctx->descs2.as<ChunkDesc>();
+            if ((rc = launch_hist<W, 1>(ctx, ctx->bufA.as<Key>(), dd2, sc + SC_NCH2, max_chunks2, ctx->mat2.as<u32>(), pl.d2, pl.P2))) return rc;
             ctx->mark("hist2");
             if ((rc = run_scan(ctx, ctx->mat2.as<u32>(), sc + SC_MLEN2, M2))) return rc;
             ctx->mark("scan2");
-            if ((rc = launch_scatter<W, 1>(ctx, ctx->bufA.as<u64>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, max_chunks2, ctx->mat2.as<u32>(), ctx->bufB.as<u64>(), pl.d2, pl.P2))) return rc;
+            if ((rc = launch_scatter<W, 1>(ctx, ctx->bufA.as<Key>(), dd2, sc + SC_NCH2, max_chunks2, ctx->mat2.as<u32>(), ctx->bufB.as<Key>(), pl.d2, pl.P2))) return rc;
             ctx->mark("scatter2");
-            fkeys = ctx->bufB.as<u64>();
-            scratch = ctx->bufA.as<u32>();
+            fkeys = ctx->bufB.as<Key>();
+            scratch = &ctx->bufA;
             hipLaunchKernelGGL(k_final_offsets, dim3((pl.F + 256) / 256), dim3(256), 0, ctx->stream, ctx->mat2.as<u32>(),
                                ctx->seg.as<SegInfo>(), pl.P2, 0u, sc + SC_MLEN2, ctx->fstart.as<u32>(), pl.F);
         } else {
@@ -338,24 +363,27 @@ int run_pipeline<1>(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u64 
         }
         CKL("k_final_offsets");
         ctx->mark("offsets");
-        // ---------------- count
+        // ---------------- count: one-word keys write solid rows in place (+ abundance into the
+        // free ping-pong buffer); two-word keys write rows into the free buffer (+ abund2)
         CountParams cp;
         cp.F = pl.F;
         cp.amin = ctx->cfg.abundance_min; cp.amax = ctx->cfg.abundance_max; cp.histo_max = ctx->cfg.histo_max;
         const unsigned cgrid = (unsigned)std::min<u64>(pl.F, (u64)ctx->num_cu * 2);
-        hipLaunchKernelGGL(k_count<W>, dim3(cgrid), dim3(CNT_NT), 0, ctx->stream, fkeys, ctx->fstart.as<u32>(), scratch,
+        Key* solid_keys = W == 1 ? fkeys : scratch->as<Key>();
+        u32* solid_ab = W == 1 ? scratch->as<u32>() : ctx->abund2.as<u32>();
+        hipLaunchKernelGGL(k_count<W>, dim3(cgrid), dim3(CNT_NT), 0, ctx->stream, fkeys, solid_keys, ctx->fstart.as<u32>(), solid_ab,
                            ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), sc + SC_OVERFLOW, cp);
         CKL("k_count");
         ctx->mark("count");
         if ((rc = run_scan(ctx, ctx->nsolid.as<u32>(), sc + SC_F, pl.F))) return rc;
         ctx->mark("scan_solid");
         // ---------------- host sync: sizes
-        u32 h_ovf = 0, h_nsolid = 0, h_nk = 0; u64 h_stats[4];
-        CK(hipMemcpyAsync(&h_ovf, sc + SC_OVERFLOW, 4, hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipMemcpyAsync(&h_nsolid, ctx->nsolid.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipMemcpyAsync(&h_nk, ctx->fstart.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipMemcpyAsync(h_stats, ctx->gstats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(&ctx->h_back[0], sc + SC_OVERFLOW, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(&ctx->h_back[1], ctx->nsolid.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(&ctx->h_back[2], ctx->fstart.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(&ctx->h_stats[0], ctx->gstats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
+        const u32 h_ovf = ctx->h_back[0], h_nsolid = ctx->h_back[1], h_nk = ctx->h_back[2];
         if (h_ovf) {
             ctx->resolve_marks();
             if (attempt >= 3) return fail(ctx, DSKGPU_E_OVERFLOW, "hash table overflow after 3 retries");
@@ -368,11 +396,13 @@ int run_pipeline<1>(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u64 
         const u64 ns = h_nsolid;
         CK(ctx->out_lo.ensure((ns + 1) * 8));
         CK(ctx->out_ab.ensure((ns + 1) * 4));
-        hipLaunchKernelGGL(k_compact<W>, dim3((pl.F + 3) / 4), dim3(256), 0, ctx->stream, fkeys, scratch, ctx->fstart.as<u32>(),
-                           ctx->nsolid.as<u32>(), pl.F, ctx->out_lo.as<u64>(), (u64*)nullptr, ctx->out_ab.as<u32>());
+        if (W == 2) CK(ctx->out_hi.ensure((ns + 1) * 8));
+        hipLaunchKernelGGL(k_compact<W>, dim3((pl.F + 3) / 4), dim3(256), 0, ctx->stream, (const Key*)solid_keys, (const u32*)solid_ab,
+                           ctx->fstart.as<u32>(), ctx->nsolid.as<u32>(), pl.F, ctx->out_lo.as<u64>(),
+                           W == 2 ? ctx->out_hi.as<u64>() : (u64*)nullptr, ctx->out_ab.as<u32>());
         CKL("k_compact");
         ctx->mark("compact");
-        if ((rc = sort_rows_1(ctx, ns))) return rc;
+        if ((rc = sort_rows(ctx, ns))) return rc;
         ctx->mark("sort");
         ctx->hist.assign((size_t)ctx->cfg.histo_max + 1, 0);
         CK(hipMemcpyAsync(ctx->hist.data(), ctx->ghist.p, ctx->hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -381,7 +411,7 @@ int run_pipeline<1>(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u64 
         ctx->n_rows = ns;
         ctx->stats.n_bytes = from_reads ? ctx->n_bytes : 0;
         ctx->stats.n_kmers = h_nk;
-        ctx->stats.n_distinct = h_stats[0];
+        ctx->stats.n_distinct = ctx->h_stats[0];
         ctx->stats.n_solid = ns;
         ctx->stats.n_levels = (u32)pl.levels;
         ctx->stats.n_final_bins = pl.F;
@@ -390,6 +420,46 @@ int run_pipeline<1>(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u64 
         ctx->have_result = true;
         return DSKGPU_OK;
     }
+}
+
+}  // namespace
+
+namespace {
+template <int W>
+int mg_scatter_impl(dskgpu_ctx* ctx, void* d_send, uint64_t* send_words) {
+    typedef typename KeyT<W>::T Key;
+    ctx->st_names.clear(); ctx->st_ms.clear(); ctx->marks.clear(); ctx->ev_used = 0;
+    ctx->mark("start");
+    u64 nwords = 0;
+    int rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords);
+    if (rc) return rc;
+    ctx->mark("encode");
+    const u32 G = ctx->cfg.world_size;
+    u32 nch1 = 0;
+    build_descs1(ctx, nwords, Tile<W>::WORDS, (u64)ctx->num_cu * 8, &nch1);
+    const u64 M1 = (u64)G * nch1;
+    CK(ctx->scalars.ensure(SC_COUNT * 4));
+    CK(ctx->descs1.ensure(ctx->h_descs1.size() * sizeof(ChunkDesc)));
+    CK(hipMemcpyAsync(ctx->descs1.p, ctx->h_descs1.data(), ctx->h_descs1.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
+    u32* h_sc = ctx->h_sc;
+    std::memset(h_sc, 0, sizeof(ctx->h_sc));
+    h_sc[SC_NCH1] = nch1; h_sc[SC_MLEN1] = (u32)M1;
+    u32* sc = ctx->scalars.as<u32>();
+    CK(hipMemcpyAsync(sc, h_sc, sizeof(ctx->h_sc), hipMemcpyHostToDevice, ctx->stream));
+    CK(ctx->mat1.ensure((M1 + 1) * 4));
+    const DigitSpec owner = DigitSpec{0u, G, 0u};
+    if ((rc = launch_hist<W, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), owner, G))) return rc;
+    ctx->mark("mg_hist");
+    if ((rc = run_scan(ctx, ctx->mat1.as<u32>(), sc + SC_MLEN1, M1))) return rc;
+    if ((rc = launch_scatter<W, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), static_cast<Key*>(d_send), owner, G))) return rc;
+    ctx->mark("mg_scatter");
+    ctx->h_starts.assign(G + 1, 0);
+    for (u32 o = 0; o <= G; ++o)
+        CK(hipMemcpyAsync(&ctx->h_starts[o], ctx->mat1.as<u32>() + (u64)o * nch1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->resolve_marks();
+    for (u32 o = 0; o < G; ++o) send_words[o] = (u64)(ctx->h_starts[o + 1] - ctx->h_starts[o]) * W;
+    return DSKGPU_OK;
 }
 
 }  // namespace
@@ -437,7 +507,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->reads_own, &ctx->packed, &ctx->inval, &ctx->bufA, &ctx->bufB, &ctx->mat1, &ctx->mat2, &ctx->sums,
                       &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats,
                       &ctx->out_lo, &ctx->out_hi, &ctx->out_ab, &ctx->srt_lo, &ctx->srt_hi, &ctx->srt_ab, &ctx->srt_tmp,
-                      &ctx->srt_idx, &ctx->srt_idx2};
+                      &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->abund2};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -493,7 +563,7 @@ int dskgpu_count(dskgpu_ctx* ctx) {
     CK(hipSetDevice(ctx->cfg.device));
     ctx->stats = dskgpu_stats{};
     if (ctx->W == 1) return run_pipeline<1>(ctx, true, nullptr, 0);
-    return fail(ctx, DSKGPU_E_ARG, "kmer_size > 32 not implemented yet");
+    return run_pipeline<2>(ctx, true, nullptr, 0);
 }
 
 uint64_t dskgpu_mg_send_capacity_words(const dskgpu_ctx* ctx) {
@@ -503,49 +573,18 @@ uint64_t dskgpu_mg_send_capacity_words(const dskgpu_ctx* ctx) {
 int dskgpu_mg_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t* send_words) {
     if (!ctx || !d_send || !send_words) return DSKGPU_E_ARG;
     if (ctx->cfg.world_size < 2) return fail(ctx, DSKGPU_E_STATE, "dskgpu_mg_scatter needs world_size >= 2");
-    if (ctx->W != 1) return fail(ctx, DSKGPU_E_ARG, "kmer_size > 32 not implemented yet");
     if (capacity_words < dskgpu_mg_send_capacity_words(ctx)) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
     CK(hipSetDevice(ctx->cfg.device));
-    ctx->st_names.clear(); ctx->st_ms.clear(); ctx->marks.clear(); ctx->ev_used = 0;
-    ctx->mark("start");
-    u64 nwords = 0;
-    int rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords);
-    if (rc) return rc;
-    ctx->mark("encode");
-    const u32 G = ctx->cfg.world_size;
-    u32 nch1 = 0;
-    build_descs1(ctx, nwords, SC_TILE_WORDS, (u64)ctx->num_cu * 8, &nch1);
-    const u64 M1 = (u64)G * nch1;
-    CK(ctx->scalars.ensure(SC_COUNT * 4));
-    CK(ctx->descs1.ensure(ctx->h_descs1.size() * sizeof(ChunkDesc)));
-    CK(hipMemcpyAsync(ctx->descs1.p, ctx->h_descs1.data(), ctx->h_descs1.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
-    u32* h_sc = ctx->h_sc;
-    std::memset(h_sc, 0, sizeof(ctx->h_sc));
-    h_sc[SC_NCH1] = nch1; h_sc[SC_MLEN1] = (u32)M1;
-    u32* sc = ctx->scalars.as<u32>();
-    CK(hipMemcpyAsync(sc, h_sc, sizeof(ctx->h_sc), hipMemcpyHostToDevice, ctx->stream));
-    CK(ctx->mat1.ensure((M1 + 1) * 4));
-    const DigitSpec shift = DigitSpec{0u, G, 0u};
-    if ((rc = launch_hist<1, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), shift, G))) return rc;
-    ctx->mark("mg_hist");
-    if ((rc = run_scan(ctx, ctx->mat1.as<u32>(), sc + SC_MLEN1, M1))) return rc;
-    if ((rc = launch_scatter<1, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), static_cast<u64*>(d_send), shift, G))) return rc;
-    ctx->mark("mg_scatter");
-    std::vector<u32> starts(G + 1);
-    for (u32 o = 0; o <= G; ++o)
-        CK(hipMemcpyAsync(&starts[o], ctx->mat1.as<u32>() + (u64)o * nch1, 4, hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
-    ctx->resolve_marks();
-    for (u32 o = 0; o < G; ++o) send_words[o] = (u64)(starts[o + 1] - starts[o]);
-    return DSKGPU_OK;
+    return ctx->W == 1 ? mg_scatter_impl<1>(ctx, d_send, send_words) : mg_scatter_impl<2>(ctx, d_send, send_words);
 }
 
 int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words) {
     if (!ctx || (!d_recv && recv_words)) return DSKGPU_E_ARG;
-    if (ctx->W != 1) return fail(ctx, DSKGPU_E_ARG, "kmer_size > 32 not implemented yet");
+    if (recv_words % (u64)ctx->W) return fail(ctx, DSKGPU_E_ARG, "recv_words is not a whole number of k-mer records");
     CK(hipSetDevice(ctx->cfg.device));
     ctx->stats = dskgpu_stats{};
-    return run_pipeline<1>(ctx, false, static_cast<const u64*>(d_recv), recv_words);
+    if (ctx->W == 1) return run_pipeline<1>(ctx, false, static_cast<const u64*>(d_recv), recv_words);
+    return run_pipeline<2>(ctx, false, static_cast<const K2*>(d_recv), recv_words / 2);
 }
 
 int dskgpu_get_stats(const dskgpu_ctx* ctx, dskgpu_stats* out) {

@@ -23,9 +23,12 @@
 #include "kmer_device.h"
 
 #define SC_NT 512            // threads of hist/scatter blocks
-#define SC_KPT 16            // keys per thread per tile
-#define SC_TILE (SC_NT * SC_KPT)   // 8192 keys (or read positions) per tile
-#define SC_TILE_WORDS (SC_TILE / 32)
+// Tile geometry: 64 KB of keys staged in LDS per tile whatever the key width.
+template <int W> struct Tile {
+    static constexpr int KPT = 16 / W;            // keys (or read positions) per thread per tile
+    static constexpr int KEYS = SC_NT * KPT;      // 8192 one-word / 4096 two-word keys
+    static constexpr int WORDS = KEYS / 32;       // packed read words per tile
+};
 #define MAX_BINS 2048
 
 struct ChunkDesc {
@@ -117,8 +120,8 @@ __device__ __forceinline__ void block_excl_scan(const u32* cnt, u32* off, int P,
 }
 
 // ------------------------------------------------------------------ key sources
-// READS: chunk range is in packed words; a tile is SC_TILE_WORDS words; thread
-// tid handles word (tid>>1), half (tid&1) -> 16 window end positions.
+// READS: chunk range is in packed words; a tile is Tile<W>::WORDS words; each
+// thread generates Tile<W>::KPT consecutive window end positions of one word.
 template <int W> struct KeyT;
 template <> struct KeyT<1> { typedef u64 T; };
 template <> struct KeyT<2> { typedef K2 T; };
@@ -142,36 +145,36 @@ __device__ __forceinline__ u32 key_digit(u64 w, const DigitSpec& ds) {
 
 template <int W>
 __device__ __forceinline__ u32 tile_keys_reads(const u64* __restrict__ packed, const u32* __restrict__ inval,
-                                               u64 w0, u64 wend, int k, typename KeyT<W>::T (&h)[SC_KPT]);
+                                               u64 w0, u64 wend, int k, typename KeyT<W>::T (&h)[Tile<W>::KPT]);
 template <>
 __device__ __forceinline__ u32 tile_keys_reads<1>(const u64* __restrict__ packed, const u32* __restrict__ inval,
-                                                  u64 w0, u64 wend, int k, u64 (&h)[SC_KPT]) {
-    const u64 wi = w0 + (threadIdx.x >> 1);
+                                                  u64 w0, u64 wend, int k, u64 (&h)[16]) {
+    const u64 wi = w0 + (threadIdx.x >> 1);             // 2 threads per packed word, 16 windows each
     if (wi >= wend) return 0u;
-    const u32 vm = gen_kmers1<SC_KPT>(packed, inval, wi, (threadIdx.x & 1) * 16, k, h);
+    const u32 vm = gen_kmers1<16>(packed, inval, wi, (threadIdx.x & 1) * 16, k, h);
 #pragma unroll
-    for (int j = 0; j < SC_KPT; ++j) h[j] = kmix(h[j]);
+    for (int j = 0; j < 16; ++j) h[j] = kmix(h[j]);
     return vm;
 }
 template <>
 __device__ __forceinline__ u32 tile_keys_reads<2>(const u64* __restrict__ packed, const u32* __restrict__ inval,
-                                                  u64 w0, u64 wend, int k, K2 (&h)[SC_KPT]) {
-    const u64 wi = w0 + (threadIdx.x >> 1);
+                                                  u64 w0, u64 wend, int k, K2 (&h)[8]) {
+    const u64 wi = w0 + (threadIdx.x >> 2);             // 4 threads per packed word, 8 windows each
     if (wi >= wend) return 0u;
-    const u32 vm = gen_kmers2<SC_KPT>(packed, inval, wi, (threadIdx.x & 1) * 16, k, h);
+    const u32 vm = gen_kmers2<8>(packed, inval, wi, (threadIdx.x & 3) * 8, k, h);
 #pragma unroll
-    for (int j = 0; j < SC_KPT; ++j) kmix2(h[j].hi, h[j].lo);
+    for (int j = 0; j < 8; ++j) kmix2(h[j].hi, h[j].lo);
     return vm;
 }
 
-// KEYS: chunk range is in keys; tile t covers keys [begin + t*SC_TILE, ...);
+// KEYS: chunk range is in keys; tile t covers keys [begin + t*Tile<W>::KEYS, ...);
 // thread loads keys tid + j*SC_NT (coalesced).
 template <int W>
 __device__ __forceinline__ u32 tile_keys_array(const typename KeyT<W>::T* __restrict__ in, u64 k0, u64 kend,
-                                               typename KeyT<W>::T (&h)[SC_KPT]) {
+                                               typename KeyT<W>::T (&h)[Tile<W>::KPT]) {
     u32 vm = 0;
 #pragma unroll
-    for (int j = 0; j < SC_KPT; ++j) {
+    for (int j = 0; j < Tile<W>::KPT; ++j) {
         const u64 i = k0 + threadIdx.x + (u64)j * SC_NT;
         if (i < kend) { h[j] = in[i]; vm |= 1u << j; }
     }
@@ -192,22 +195,22 @@ __global__ __launch_bounds__(SC_NT) void k_hist(const u64* __restrict__ packed, 
         const ChunkDesc d = descs[g];
         for (u32 b = threadIdx.x; b < P; b += SC_NT) lh[b] = 0;
         __syncthreads();
-        const u64 step = SRC == 0 ? SC_TILE_WORDS : SC_TILE;
-        typename KeyT<W>::T hn[SC_KPT]; u32 vmn = 0;
+        const u64 step = SRC == 0 ? Tile<W>::WORDS : Tile<W>::KEYS;
+        typename KeyT<W>::T hn[Tile<W>::KPT]; u32 vmn = 0;
         if (SRC == 1 && d.begin < d.end) vmn = tile_keys_array<W>(keys, d.begin, d.end, hn);
         for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
-            typename KeyT<W>::T h[SC_KPT];
+            typename KeyT<W>::T h[Tile<W>::KPT];
             u32 vm;
             if (SRC == 0) vm = tile_keys_reads<W>(packed, inval, t0, d.end, k, h);
             else {
                 vm = vmn;
 #pragma unroll
-                for (int j = 0; j < SC_KPT; ++j) h[j] = hn[j];
+                for (int j = 0; j < Tile<W>::KPT; ++j) h[j] = hn[j];
                 vmn = 0;
                 if (t0 + step < d.end) vmn = tile_keys_array<W>(keys, t0 + step, d.end, hn);   // keep HBM reads in flight
             }
 #pragma unroll
-            for (int j = 0; j < SC_KPT; ++j)
+            for (int j = 0; j < Tile<W>::KPT; ++j)
                 if (vm & (1u << j)) atomicAdd(&lh[key_digit(digit_word(h[j]), ds)], 1u);
         }
         __syncthreads();
@@ -355,8 +358,8 @@ __global__ __launch_bounds__(SC_NT) void k_scatter(const u64* __restrict__ packe
                                                    typename KeyT<W>::T* __restrict__ out, int k, DigitSpec ds, u32 P, u32 dbg) {
     typedef typename KeyT<W>::T Key;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Key* stage = reinterpret_cast<Key*>(smem);                       // SC_TILE keys
-    u32* cnt = reinterpret_cast<u32*>(smem + sizeof(Key) * SC_TILE); // P
+    Key* stage = reinterpret_cast<Key*>(smem);                       // Tile<W>::KEYS keys
+    u32* cnt = reinterpret_cast<u32*>(smem + sizeof(Key) * Tile<W>::KEYS); // P
     u32* off = cnt + P;                                              // P
     u32* cur = off + P;                                              // P
     u32* delta = cur + P;                                            // P
@@ -367,29 +370,29 @@ __global__ __launch_bounds__(SC_NT) void k_scatter(const u64* __restrict__ packe
         const ChunkDesc d = descs[g];
         __syncthreads();   // previous chunk's write-out reads delta/off/stage
         for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] = scanned[d.flat_base + (u64)b * d.stride]; cnt[b] = 0; }
-        const u64 step = SRC == 0 ? SC_TILE_WORDS : SC_TILE;
-        Key hn[SC_KPT]; u32 vmn = 0;
+        const u64 step = SRC == 0 ? Tile<W>::WORDS : Tile<W>::KEYS;
+        Key hn[Tile<W>::KPT]; u32 vmn = 0;
         if (SRC == 1 && d.begin < d.end) vmn = tile_keys_array<W>(keys, d.begin, d.end, hn);
         __syncthreads();
         for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
-            Key h[SC_KPT]; u32 rk[SC_KPT];
+            Key h[Tile<W>::KPT]; u32 rk[Tile<W>::KPT];
             u32 vm;
             if (SRC == 0) vm = tile_keys_reads<W>(packed, inval, t0, d.end, k, h);
             else {
                 vm = vmn;
 #pragma unroll
-                for (int j = 0; j < SC_KPT; ++j) h[j] = hn[j];
+                for (int j = 0; j < Tile<W>::KPT; ++j) h[j] = hn[j];
                 vmn = 0;
                 if (t0 + step < d.end) vmn = tile_keys_array<W>(keys, t0 + step, d.end, hn);   // prefetch
             }
 #pragma unroll
-            for (int j = 0; j < SC_KPT; ++j)
+            for (int j = 0; j < Tile<W>::KPT; ++j)
                 if (vm & (1u << j)) rk[j] = atomicAdd(&cnt[key_digit(digit_word(h[j]), ds)], 1u);
             __syncthreads();
             tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot);
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < SC_KPT; ++j)
+            for (int j = 0; j < Tile<W>::KPT; ++j)
                 if (vm & (1u << j)) {
                     if (dbg & 2u) out[(u64)(delta[key_digit(digit_word(h[j]), ds)] + off[key_digit(digit_word(h[j]), ds)] + rk[j])] = h[j];
                     else stage[off[key_digit(digit_word(h[j]), ds)] + rk[j]] = h[j];
@@ -492,8 +495,13 @@ struct CountParams {
 // range (abundance to `abund` at the same index).  The keys of the block's
 // next sub-partition are loaded into registers before the sweep, so HBM reads
 // overlap the LDS work.
+// keys      : mixed keys grouped by sub-partition (fstart)
+// solid_keys: where the solid rows' (still mixed) keys go, at index begin+pos.
+//             one-word keys: == keys (in place); two-word keys: the free ping-pong buffer
+// abund     : abundance of the solid rows at the same index
 template <int W>
-__global__ __launch_bounds__(CNT_NT) void k_count(typename KeyT<W>::T* __restrict__ keys, const u32* __restrict__ fstart,
+__global__ __launch_bounds__(CNT_NT) void k_count(typename KeyT<W>::T* keys, typename KeyT<W>::T* solid_keys,
+                                                  const u32* __restrict__ fstart,
                                                   u32* __restrict__ abund, u32* __restrict__ nsolid,
                                                   u64* __restrict__ ghist, u64* __restrict__ gstats,
                                                   u32* __restrict__ overflow, CountParams cp);
@@ -514,7 +522,7 @@ __device__ __forceinline__ void table_insert1(u64* tk, u32* tc, unsigned short* 
 }
 
 template <>
-__global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* __restrict__ keys, const u32* __restrict__ fstart,
+__global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* keys, u64* solid_keys, const u32* __restrict__ fstart,
                                                      u32* __restrict__ abund, u32* __restrict__ nsolid,
                                                      u64* __restrict__ ghist, u64* __restrict__ gstats,
                                                      u32* __restrict__ overflow, CountParams cp) {
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* __restrict__ keys, con
                     base = __shfl(base, 0);
                     if (solid) {
                         const u32 pos = base + __popcll(ms & ((1ull << lane) - 1));
-                        keys[begin + pos] = key;
+                        solid_keys[begin + pos] = key;
                         abund[begin + pos] = c;
                     }
                 }
@@ -613,6 +621,138 @@ __global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* __restrict__ keys, con
     }
     __syncthreads();
     // flush block-local histogram
+    if (lane == 0 && ones) atomicAdd(&lh[1], ones);
+    __syncthreads();
+    for (int b = tid; b < CNT_LH; b += CNT_NT) {
+        const u32 v = lh[b];
+        if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
+    }
+    if (tid == 0 && ndist_acc) atomicAdd(&gstats[0], ndist_acc);
+}
+
+// ---- two-word keys (k in 33..64): no 128-bit LDS CAS exists, so the table holds
+// 32-bit INDICES: slot value v = 1 + (index of the representative key inside the
+// sub-partition).  The sub-partition's keys are staged immutably in LDS (the
+// first C2_STAGE of them; later ones are re-read from HBM), a slot is claimed
+// with a 32-bit CAS on the index, and equality is checked against the staged
+// representative -- no thread ever waits on another.
+#define C2_SLOTS 2048
+#define C2_MAXLOAD 1792
+#define C2_STAGE 2048
+#define C2_KPT (C2_STAGE / CNT_NT)
+
+__device__ __forceinline__ void table_insert2(const K2* sk, const K2* __restrict__ gkeys, u32* slots, u32* tc,
+                                              unsigned short* lst, u32* ndist, u32* ovf, const K2& key, u32 idx) {
+    u32 slot = (u32)key.hi & (C2_SLOTS - 1);
+    for (int probe = 0; probe < C2_SLOTS; ++probe) {
+        u32 v = slots[slot];
+        if (v == 0) {
+            v = atomicCAS(&slots[slot], 0u, idx + 1);
+            if (v == 0) { lst[atomicAdd(ndist, 1u)] = (unsigned short)slot; atomicAdd(&tc[slot], 1u); return; }
+        }
+        const u32 r = v - 1;
+        K2 rep;
+        if (r < C2_STAGE) rep = sk[r]; else rep = gkeys[r];
+        if (rep.hi == key.hi && rep.lo == key.lo) { atomicAdd(&tc[slot], 1u); return; }
+        slot = (slot + 1) & (C2_SLOTS - 1);
+    }
+    *ovf = 1;
+}
+
+template <>
+__global__ __launch_bounds__(CNT_NT) void k_count<2>(K2* keys, K2* solid_keys, const u32* __restrict__ fstart,
+                                                     u32* __restrict__ abund, u32* __restrict__ nsolid,
+                                                     u64* __restrict__ ghist, u64* __restrict__ gstats,
+                                                     u32* __restrict__ overflow, CountParams cp) {
+    __shared__ K2 sk[C2_STAGE];
+    __shared__ u32 slots[C2_SLOTS];
+    __shared__ u32 tc[C2_SLOTS];
+    __shared__ unsigned short lst[C2_SLOTS];
+    __shared__ u32 lh[CNT_LH];
+    __shared__ u32 ctr[4];                      // ndist, out, ovf
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int s = tid; s < C2_SLOTS; s += CNT_NT) { slots[s] = 0; tc[s] = 0; }
+    for (int b = tid; b < CNT_LH; b += CNT_NT) lh[b] = 0;
+    if (tid < 4) ctr[tid] = 0;
+    u32 ones = 0; u64 ndist_acc = 0;
+    u32 q = blockIdx.x, begin = 0, end = 0;
+    K2 pk[C2_KPT];
+    if (q < cp.F) {
+        begin = fstart[q]; end = fstart[q + 1];
+#pragma unroll
+        for (int j = 0; j < C2_KPT; ++j) { const u32 i = begin + tid + j * CNT_NT; if (i < end) pk[j] = keys[i]; }
+    }
+    __syncthreads();
+    while (q < cp.F) {
+        const u32 n = end - begin;
+        const K2* gk = keys + begin;
+#pragma unroll
+        for (int j = 0; j < C2_KPT; ++j) { const u32 i = tid + j * CNT_NT; if (i < n) sk[i] = pk[j]; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < C2_KPT; ++j) {
+            const u32 i = tid + j * CNT_NT;
+            if (i < n) table_insert2(sk, gk, slots, tc, lst, &ctr[0], &ctr[2], pk[j], i);
+        }
+        for (u32 i = C2_STAGE + tid; i < n; i += CNT_NT) {                 // oversized sub-partition
+            const K2 kx = gk[i];
+            table_insert2(sk, gk, slots, tc, lst, &ctr[0], &ctr[2], kx, i);
+        }
+        const u32 qn = q + gridDim.x;
+        u32 nbeg = 0, nend = 0;
+        if (qn < cp.F) {
+            nbeg = fstart[qn]; nend = fstart[qn + 1];
+#pragma unroll
+            for (int j = 0; j < C2_KPT; ++j) { const u32 i = nbeg + tid + j * CNT_NT; if (i < nend) pk[j] = keys[i]; }
+        }
+        __syncthreads();
+        const u32 nd = ctr[0];
+        const bool bad = ctr[2] || nd > C2_MAXLOAD;
+        if (bad) {
+            for (int s = tid; s < C2_SLOTS; s += CNT_NT) { slots[s] = 0; tc[s] = 0; }
+            if (tid == 0) *overflow = 1;
+        } else {
+            for (u32 i0 = 0; i0 < nd; i0 += CNT_NT) {
+                const u32 i = i0 + tid;
+                const bool act = i < nd;
+                K2 key; key.hi = 0; key.lo = 0; u32 c = 0;
+                if (act) {
+                    const u32 slot = lst[i];
+                    const u32 r = slots[slot] - 1;
+                    if (r < C2_STAGE) key = sk[r]; else key = gk[r];
+                    c = tc[slot];
+                    slots[slot] = 0; tc[slot] = 0;
+                }
+                const u64 m1 = __ballot(act && c == 1);
+                if (lane == 0) ones += __popcll(m1);
+                if (act && c > 1) {
+                    const u32 bin = c < cp.histo_max ? c : cp.histo_max;
+                    if (bin < CNT_LH) atomicAdd(&lh[bin], 1u);
+                    else atomicAdd(&ghist[bin], 1ull);
+                }
+                const bool solid = act && c >= cp.amin && c <= cp.amax;
+                const u64 ms = __ballot(solid);
+                if (ms) {
+                    u32 base = 0;
+                    if (lane == 0) base = atomicAdd(&ctr[1], (u32)__popcll(ms));
+                    base = __shfl(base, 0);
+                    if (solid) {
+                        const u32 pos = base + __popcll(ms & ((1ull << lane) - 1));
+                        solid_keys[begin + pos] = key;
+                        abund[begin + pos] = c;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            nsolid[q] = bad ? 0u : ctr[1];
+            ndist_acc += bad ? 0u : nd;
+            ctr[0] = 0; ctr[1] = 0; ctr[2] = 0;
+        }
+        q = qn; begin = nbeg; end = nend;
+    }
+    __syncthreads();
     if (lane == 0 && ones) atomicAdd(&lh[1], ones);
     __syncthreads();
     for (int b = tid; b < CNT_LH; b += CNT_NT) {
@@ -642,6 +782,33 @@ __global__ __launch_bounds__(256) void k_compact<1>(const u64* __restrict__ keys
         out_lo[o + i] = kunmix(keys[b + i]);
         out_ab[o + i] = abund[b + i];
     }
+}
+
+template <>
+__global__ __launch_bounds__(256) void k_compact<2>(const K2* __restrict__ keys, const u32* __restrict__ abund,
+                                                    const u32* __restrict__ fstart, const u32* __restrict__ soff, u32 F,
+                                                    u64* __restrict__ out_lo, u64* __restrict__ out_hi, u32* __restrict__ out_ab) {
+    const u32 q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= F) return;
+    const u32 o = soff[q], ns = soff[q + 1] - o, b = fstart[q];
+    for (u32 i = lane; i < ns; i += 64) {
+        K2 kx = keys[b + i];
+        kunmix2(kx.hi, kx.lo);
+        out_lo[o + i] = kx.lo; out_hi[o + i] = kx.hi;
+        out_ab[o + i] = abund[b + i];
+    }
+}
+
+// helpers of the two-word row sort (two stable 64-bit radix passes over an index permutation)
+__global__ void k_iota(u32* __restrict__ idx, u64 n) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = (u32)i;
+}
+template <class T>
+__global__ void k_gather(T* __restrict__ dst, const T* __restrict__ src, const u32* __restrict__ idx, u64 n) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
 }
 
 // ------------------------------------------------------------------ test kernels

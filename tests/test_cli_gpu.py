@@ -26,7 +26,7 @@ def test_simple_test_sh_cases_on_gpu(bins, tmp_path):
     run_six_cases(bins["dsk"], bins["dsk2ascii"], str(tmp_path))
 
 
-@pytest.mark.parametrize("k,md5,n", [(31, "5b4da4c690bb00783eb5fdc49fc19466", 13096)])
+@pytest.mark.parametrize("k,md5,n", [(31, "5b4da4c690bb00783eb5fdc49fc19466", 13096), (63, "ed2b871b9bbbdd93479ef66330c0b563", 10945)])
 def test_known_answer_dump_on_gpu(bins, tmp_path, k, md5, n):
     from tests.test_host_cli import known_answer_dump
     known_answer_dump(bins["dsk"], bins["dsk2ascii"], str(tmp_path), k, md5, n)

@@ -152,6 +152,31 @@ def test_synthetic_two_levels(oracle, dev):
     assert st["n_levels"] == 2
 
 
+@pytest.mark.parametrize("k", [33, 47, 63, 64])
+def test_two_word_kmers_golden(oracle, golden_dir, dev, k):
+    s, _ = oracle.load_bank(os.path.join(golden_dir, "read50x_ref10K_e001.fasta.gz"))
+    st = check_against_oracle(oracle, s, k, dev)
+    if k == 63:   # SURVEY.md App. A known answer
+        assert (st["n_kmers"], st["n_distinct"], st["n_solid"]) == (190000, 97702, 10945)
+
+
+def test_two_word_kmers_synthetic_two_levels(oracle, dev):
+    from dsk_amd import synth
+    g = synth.make_genome(500_000, dev)
+    reads = synth.make_reads(g, 150_000, 150)
+    st = check_against_oracle(oracle, reads.cpu().numpy(), 63, dev)
+    assert st["n_levels"] == 2
+
+
+def test_two_word_edge_cases(oracle, golden_dir, dev):
+    s, _ = oracle.load_bank(os.path.join(golden_dir, "longread.fasta"))
+    check_against_oracle(oracle, s, 41, dev, amin=1)
+    s = np.concatenate([np.full(300_000, 65, np.uint8), np.array([10], np.uint8), np.full(100_000, 67, np.uint8)])
+    check_against_oracle(oracle, s, 63, dev, amin=1)          # one k-mer x 300k: oversized sub-partition path
+    for raw in (b"", b"ACGT" * 10, b"ACGT" * 16 + b"N" + b"TTGCA" * 20):
+        check_against_oracle(oracle, np.frombuffer(raw, dtype=np.uint8), 40, dev, amin=1)
+
+
 def test_abundance_window_and_histo_max(oracle, dev):
     from dsk_amd import synth, KmerCounter
     g = synth.make_genome(20_000, dev)
