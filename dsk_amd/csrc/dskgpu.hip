@@ -278,7 +278,8 @@ template <int W>
 int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_keys_in, u64 nkeys_in) {
     typedef typename KeyT<W>::T Key;
     ctx->have_result = false;
-    ctx->st_names.clear(); ctx->st_ms.clear(); ctx->marks.clear(); ctx->ev_used = 0;
+    if (from_reads) { ctx->st_names.clear(); ctx->st_ms.clear(); }   // from keys: keep the mg_scatter stages of this step
+    ctx->marks.clear(); ctx->ev_used = 0;
     const u64 n_upper = from_reads ? ctx->n_bytes : nkeys_in;
     if (n_upper >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "more than 2^32 k-mers in one pass is not supported yet");
     u64 nwords = 0;

@@ -1,0 +1,72 @@
+"""Multi-GPU count: one process per GPU, k-mer space sharded by owner(kmer).
+
+    rank r:  reads shard --mg_scatter--> k-mer records grouped by owner
+             --RCCL all-to-all (torch.distributed)--> records this rank owns
+             --mg_count--> partition + hash-aggregate + histogram + solid rows
+
+The reference has no distributed mode (single process, disk partitions:
+doc/paper.tex:60-97); the owner map plays the role of its partition function
+across GPUs and the all-to-all replaces the partition files.  torch is
+plumbing here: it owns the exchange buffers and the process group.  `stage` is
+a `KmerCounter` on a GPU; the CPU tests pass a stand-in with the same two
+methods to exercise this driver under gloo.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def exchange(send: torch.Tensor, send_counts: Sequence[int], group=None,
+             recv: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, List[int]]:
+    """Variable-size all-to-all of 8-byte words.  send[: sum(send_counts)] is grouped by
+    destination rank.  Returns (recv buffer view, per-source counts)."""
+    world = dist.get_world_size(group)
+    assert len(send_counts) == world
+    dev = send.device
+    sc = torch.tensor(list(send_counts), dtype=torch.int64, device=dev)
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = [int(x) for x in rc.tolist()]
+    n_recv = sum(recv_counts)
+    if recv is None or recv.numel() < n_recv:
+        recv = torch.empty(max(n_recv, 1), dtype=send.dtype, device=dev)
+    out = recv[:n_recv]
+    dist.all_to_all_single(out, send[: sum(send_counts)], recv_counts, list(send_counts), group=group)
+    return out, recv_counts
+
+
+class ShardedCounter:
+    """Drives one rank of the sharded count.  After `count()`, the stage holds
+    this rank's share of the result (its owned k-mers)."""
+
+    def __init__(self, stage, device: torch.device, group=None):
+        self.stage = stage
+        self.device = device
+        self.group = group
+        self.send: Optional[torch.Tensor] = None
+        self.recv: Optional[torch.Tensor] = None
+        self.last_send_counts: List[int] = []
+        self.last_recv_counts: List[int] = []
+
+    def count(self) -> None:
+        cap = int(self.stage.mg_send_capacity_words())
+        if self.send is None or self.send.numel() < cap:
+            self.send = torch.empty(max(cap, 1), dtype=torch.int64, device=self.device)
+        counts = self.stage.mg_scatter(self.send.data_ptr(), self.send.numel())
+        out, rcounts = exchange(self.send, counts, self.group, self.recv)
+        if self.recv is None or out.data_ptr() != self.recv.data_ptr():
+            self.recv = out if out.numel() else self.recv
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        self.last_send_counts, self.last_recv_counts = list(counts), rcounts
+        self.stage.mg_count(out.data_ptr() if out.numel() else 0, int(out.numel()))
+
+
+def gather_histogram(hist: torch.Tensor, group=None) -> torch.Tensor:
+    """Whole-job histogram = element-wise sum of the ranks' histograms (owners are disjoint)."""
+    h = hist.clone()
+    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+    return h

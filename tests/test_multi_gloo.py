@@ -1,0 +1,149 @@
+"""N>1 path on CPU: world_size-2 (and 4) `gloo` runs of the sharded-count driver
+(dsk_amd/multi.py).  The device stages are replaced by a numpy/oracle stand-in
+with the same interface and the same owner map as the HIP kernels
+(kernels.h key_digit mode 0: owner = (kmix(kmer)[31:12] * G) >> 20); the test
+checks that the union of the ranks' results equals the single-process oracle.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def kmix(x):
+    x = x.astype(np.uint64).copy()
+    x ^= x >> np.uint64(33)
+    x *= np.uint64(0xff51afd7ed558ccd)
+    x ^= x >> np.uint64(33)
+    x *= np.uint64(0xc4ceb9fe1a85ec53)
+    x ^= x >> np.uint64(33)
+    return x
+
+
+def kunmix(x):
+    x = x.astype(np.uint64).copy()
+    x ^= x >> np.uint64(33)
+    x *= np.uint64(0x9cb4b2f8129337db)
+    x ^= x >> np.uint64(33)
+    x *= np.uint64(0x4f74430c22a54005)
+    x ^= x >> np.uint64(33)
+    return x
+
+
+def owner_of(h, G):
+    return ((((h >> np.uint64(12)) & np.uint64(0xFFFFF)) * np.uint64(G)) >> np.uint64(20)).astype(np.int64)
+
+
+class CpuStage:
+    """Stand-in for KmerCounter's multi-GPU entry points (test only)."""
+
+    def __init__(self, oracle, stream, k, world):
+        self.oracle, self.stream, self.k, self.world = oracle, stream, k, world
+        self.rows = None
+
+    def mg_send_capacity_words(self):
+        return len(self.stream) + 1
+
+    def mg_scatter(self, ptr, cap):
+        lo, hi, valid = self.oracle.enumerate(self.stream, self.k)
+        h = kmix(lo[valid.astype(bool)])
+        own = owner_of(h, self.world)
+        order = np.argsort(own, kind="stable")
+        h = h[order]
+        counts = np.bincount(own, minlength=self.world).tolist()
+        import ctypes
+        buf = (ctypes.c_uint64 * max(1, len(h))).from_address(ptr)
+        np.ctypeslib.as_array(buf)[: len(h)] = h
+        return counts
+
+    def mg_count(self, ptr, n):
+        import ctypes
+        if n:
+            h = np.ctypeslib.as_array((ctypes.c_uint64 * n).from_address(ptr)).copy()
+        else:
+            h = np.zeros(0, np.uint64)
+        keys, cnt = np.unique(kunmix(h), return_counts=True)
+        self.rows = (keys, cnt.astype(np.uint32), h)
+
+
+def _worker(rank, world, port, k, tmpdir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dsk_amd.multi import ShardedCounter, gather_histogram
+    from tests.oracle_py import Oracle
+    oracle = Oracle(os.path.join(ROOT, "oracle", "libdsk_oracle.so"))
+    stream, _ = oracle.load_bank(os.path.join(ROOT, "tests", "golden", "read50x_ref10K_e001.fasta.gz"))
+    # shard reads by record: rank r takes records r, r+world, ...
+    recs = bytes(stream).split(b"\n")
+    mine = b"\n".join(recs[rank::world]) + b"\n"
+    shard = np.frombuffer(mine, dtype=np.uint8)
+    stage = CpuStage(oracle, shard, k, world)
+    sc = ShardedCounter(stage, torch.device("cpu"))
+    sc.count()
+    keys, cnt, h = stage.rows
+    assert (owner_of(h, world) == rank).all()            # every received record is owned by this rank
+    assert sum(sc.last_recv_counts) == len(h)
+    hist = np.bincount(np.minimum(cnt, 10000), minlength=10001).astype(np.int64)
+    total = gather_histogram(torch.from_numpy(hist))
+    np.save(os.path.join(tmpdir, f"keys{rank}.npy"), keys)
+    np.save(os.path.join(tmpdir, f"cnt{rank}.npy"), cnt)
+    if rank == 0:
+        np.save(os.path.join(tmpdir, "hist.npy"), total.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_count_equals_single_process(oracle, golden_dir, tmp_path, world):
+    k = 31
+    mp.spawn(_worker, args=(world, _free_port(), k, str(tmp_path)), nprocs=world, join=True)
+    keys = np.concatenate([np.load(tmp_path / f"keys{r}.npy") for r in range(world)])
+    cnt = np.concatenate([np.load(tmp_path / f"cnt{r}.npy") for r in range(world)])
+    order = np.argsort(keys)
+    keys, cnt = keys[order], cnt[order]
+    s, _ = oracle.load_bank(os.path.join(golden_dir, "read50x_ref10K_e001.fasta.gz"))
+    ref = oracle.count(s, k)
+    assert len(np.unique(keys)) == len(keys)              # owners are disjoint
+    assert (keys == ref.lo).all() and (cnt == ref.ab).all()
+    assert (np.load(tmp_path / "hist.npy") == ref.histogram(10000).astype(np.int64)).all()
+    assert (ref.total, ref.distinct) == (350000, 99957)   # BASELINE.json configs[0]
+
+
+def test_exchange_ragged_and_empty(tmp_path):
+    mp.spawn(_exchange_worker, args=(3, _free_port()), nprocs=3, join=True)
+
+
+def _exchange_worker(rank, world, port):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dsk_amd.multi import exchange
+    # rank r sends (r + d) % 3 words to rank d, tagged with (src, dst); rank 2 sends nothing to itself ... etc.
+    counts = [(rank + d) % 3 for d in range(world)]
+    send = torch.tensor([rank * 100 + d for d in range(world) for _ in range(counts[d])] + [0], dtype=torch.int64)
+    out, rc = exchange(send, counts)
+    assert rc == [(s + rank) % 3 for s in range(world)]
+    want = [s * 100 + rank for s in range(world) for _ in range((s + rank) % 3)]
+    assert out.tolist() == want
+    dist.barrier()
+    dist.destroy_process_group()
