@@ -146,35 +146,55 @@ int run_scan(dskgpu_ctx* ctx, u32* a, const u32* d_len, u64 max_len) {
     return DSKGPU_OK;
 }
 
-u32 dbg_flags() { static int v = -1; if (v < 0) { const char* e = getenv("DSKGPU_DBG"); v = e ? atoi(e) : 0; } return (u32)v; }
+// experiment switches (timing ablations only; results are wrong when set): DSKGPU_DBG1 = level-1 scatter, DSKGPU_DBG2 = key-array scatter
+u32 dbg_flags(int src) { const char* e = getenv(src == 0 ? "DSKGPU_DBG1" : "DSKGPU_DBG2"); return e ? (u32)atoi(e) : 0u; }
 
-size_t scatter_lds(int W, u32 P) { return (size_t)(W == 1 ? Tile<1>::KEYS * 8 : Tile<2>::KEYS * 16) + (size_t)P * 16 + 17 * 4 + 16; }
+size_t scatter_lds(int W, u32 P) { return (size_t)(W == 1 ? Tile<1>::KEYS * 8 : Tile<2>::KEYS * 16) + (size_t)P * 16 + 4 + 17 * 4 + 16; }
 
-template <int W, int SRC>
-int launch_hist(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                u64 max_chunks, u32* matrix, DigitSpec ds, u32 P) {
-    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * (SRC == 1 ? 4 : 2)));
-    hipLaunchKernelGGL((k_hist<W, SRC>), dim3(grid), dim3(SC_NT), 0, ctx->stream, ctx->packed.as<u64>(),
+template <int W, int SRC, int MODE>
+int launch_hist_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
+                  u64 max_chunks, u32* matrix, DigitSpec ds, u32 P) {
+    static int hmul = getenv("DSKGPU_HMUL") ? atoi(getenv("DSKGPU_HMUL")) : 0;
+    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * (hmul ? hmul : 2)));
+    hipLaunchKernelGGL((k_hist<W, SRC, MODE>), dim3(grid), dim3(SC_NT), 0, ctx->stream, ctx->packed.as<u64>(),
                        ctx->inval.as<u32>(), keys, descs, d_nch, matrix, (int)ctx->cfg.kmer_size, ds, P);
     CKL("k_hist");
     return DSKGPU_OK;
 }
+// digit modes in use: reads -> owner (0) or level 1 (1); key array -> level 1 (1, multi-GPU receive side) or level 2 (2)
+template <int W, int SRC>
+int launch_hist(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
+                u64 max_chunks, u32* matrix, DigitSpec ds, u32 P) {
+    if (SRC == 0) return ds.mode == 0 ? launch_hist_m<W, 0, 0>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P)
+                                      : launch_hist_m<W, 0, 1>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P);
+    return ds.mode == 1 ? launch_hist_m<W, 1, 1>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P)
+                        : launch_hist_m<W, 1, 2>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P);
+}
 
+template <int W, int SRC, int MODE>
+int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
+                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P) {
+    const size_t lds = scatter_lds(W, P);
+    const u64 per_cu = std::max<u64>(1, std::min<u64>(2048 / SC_NT, (160 * 1024) / lds));   // resident blocks per CU
+    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * per_cu));
+    static bool attr_set = false;
+    if (!attr_set) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter<W, SRC, MODE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_scatter<W, SRC, MODE>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->packed.as<u64>(),
+                       ctx->inval.as<u32>(), keys, descs, d_nch, scanned, out, (int)ctx->cfg.kmer_size, ds, P, dbg_flags(SRC));
+    CKL("k_scatter");
+    return DSKGPU_OK;
+}
 template <int W, int SRC>
 int launch_scatter(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
                    u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P) {
-    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * 2));
-    const size_t lds = scatter_lds(W, P);
-    static bool attr_set[3][2] = {{false, false}, {false, false}, {false, false}};
-    if (!attr_set[W][SRC]) {
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter<W, SRC>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[W][SRC] = true;
-    }
-    hipLaunchKernelGGL((k_scatter<W, SRC>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->packed.as<u64>(),
-                       ctx->inval.as<u32>(), keys, descs, d_nch, scanned, out, (int)ctx->cfg.kmer_size, ds, P, dbg_flags());
-    CKL("k_scatter");
-    return DSKGPU_OK;
+    if (SRC == 0) return ds.mode == 0 ? launch_scatter_m<W, 0, 0>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P)
+                                      : launch_scatter_m<W, 0, 1>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P);
+    return ds.mode == 1 ? launch_scatter_m<W, 1, 1>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P)
+                        : launch_scatter_m<W, 1, 2>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P);
 }
 
 struct Plan {
@@ -368,6 +388,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         // free ping-pong buffer); two-word keys write rows into the free buffer (+ abund2)
         CountParams cp;
         cp.F = pl.F;
+        { const char* e = getenv("DSKGPU_DBGC"); cp.dbg = e ? (u32)atoi(e) : 0u; }
         cp.amin = ctx->cfg.abundance_min; cp.amax = ctx->cfg.abundance_max; cp.histo_max = ctx->cfg.histo_max;
         const unsigned cgrid = (unsigned)std::min<u64>(pl.F, (u64)ctx->num_cu * 2);
         Key* solid_keys = W == 1 ? fkeys : scratch->as<Key>();

@@ -22,14 +22,25 @@
 #pragma once
 #include "kmer_device.h"
 
-#define SC_NT 512            // threads of hist/scatter blocks
-// Tile geometry: 64 KB of keys staged in LDS per tile whatever the key width.
+#ifndef SC_NT
+#define SC_NT 1024           // threads of hist/scatter blocks: one block per CU stages a 128 KB tile in LDS
+#endif
+// Tile geometry: 128 KB of keys staged in LDS per tile whatever the key width
+// (longer runs per bin and fewer open write streams per XCD L2 than 2 x 64 KB tiles: measured -2.9 ms).
 template <int W> struct Tile {
     static constexpr int KPT = 16 / W;            // keys (or read positions) per thread per tile
-    static constexpr int KEYS = SC_NT * KPT;      // 8192 one-word / 4096 two-word keys
+    static constexpr int KEYS = SC_NT * KPT;      // 16384 one-word / 8192 two-word keys = 128 KB
     static constexpr int WORDS = KEYS / 32;       // packed read words per tile
 };
 #define MAX_BINS 2048
+
+// Workgroup barrier that orders LDS traffic only.  HIP's __syncthreads() also
+// drains every outstanding global load (s_waitcnt vmcnt(0)), which would kill
+// the register prefetch of the next tile / sub-partition; this one waits for
+// LDS (lgkmcnt) and leaves HBM reads in flight across the barrier
+// (cdna_hip_programming.md "Pipelining across barriers").  Global data is never
+// exchanged between threads inside these kernels, so no vmcnt wait is needed.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct ChunkDesc {
     u64 begin, end;          // source range: packed words (reads) or keys
@@ -137,9 +148,10 @@ __device__ __forceinline__ u64 digit_word(const K2& h) { return h.hi; }
 //   slot    : h[11:0]                                    (home slot of the LDS table)
 // so final sub-partition q = d1 * P2 + d2 and the fields are independent.
 struct DigitSpec { u32 mode, pa, pb; };   // mode 0: owner(pa=G)  1: level1(pa=P1)  2: level2(pa=P1,pb=P2)
+template <int MODE>
 __device__ __forceinline__ u32 key_digit(u64 w, const DigitSpec& ds) {
-    if (ds.mode == 1) return __umulhi((u32)(w >> 32), ds.pa);
-    if (ds.mode == 2) return __umulhi((u32)(w >> 32) * ds.pa, ds.pb);
+    if (MODE == 1) return __umulhi((u32)(w >> 32), ds.pa);
+    if (MODE == 2) return __umulhi((u32)(w >> 32) * ds.pa, ds.pb);
     return (((u32)(w >> 12) & 0xFFFFFu) * ds.pa) >> 20;
 }
 
@@ -172,46 +184,63 @@ __device__ __forceinline__ u32 tile_keys_reads<2>(const u64* __restrict__ packed
 template <int W>
 __device__ __forceinline__ u32 tile_keys_array(const typename KeyT<W>::T* __restrict__ in, u64 k0, u64 kend,
                                                typename KeyT<W>::T (&h)[Tile<W>::KPT]) {
+    // branch-free: out-of-range lanes re-read the tile's last key (masked out by the
+    // returned bits), so the loads stay one straight-line burst the compiler can count
+    const typename KeyT<W>::T* base = in + k0;                       // wave-uniform
+    const u64 left = kend - k0;                                      // >= 1
+    const u32 n = left < (u64)Tile<W>::KEYS ? (u32)left : (u32)Tile<W>::KEYS;
     u32 vm = 0;
 #pragma unroll
     for (int j = 0; j < Tile<W>::KPT; ++j) {
-        const u64 i = k0 + threadIdx.x + (u64)j * SC_NT;
-        if (i < kend) { h[j] = in[i]; vm |= 1u << j; }
+        const u32 o = threadIdx.x + (u32)j * SC_NT;
+        const bool ok = o < n;
+        h[j] = base[ok ? o : n - 1];
+        vm |= (ok ? 1u : 0u) << j;
     }
     return vm;
 }
 
 // ------------------------------------------------------------------ K3: histogram
-// SRC 0 = reads, 1 = key array.  Persistent blocks walk chunks; per chunk an
-// LDS histogram over P bins is written to the matrix row of that chunk.
-template <int W, int SRC>
+// SRC 0 = reads, 1 = key array; MODE = which digit (compile time, so the tile
+// body is straight-line code).  Persistent blocks walk chunks; per chunk an LDS
+// histogram over P bins (+1 dummy bin for invalid windows) is written to the
+// matrix row of that chunk.
+template <int W, int SRC, int MODE>
 __global__ __launch_bounds__(SC_NT) void k_hist(const u64* __restrict__ packed, const u32* __restrict__ inval,
                                                 const typename KeyT<W>::T* __restrict__ keys,
                                                 const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
                                                 u32* __restrict__ matrix, int k, DigitSpec ds, u32 P) {
-    __shared__ u32 lh[MAX_BINS];
+    __shared__ u32 lh[MAX_BINS + 1];
+    constexpr int KPT = Tile<W>::KPT;
     const u32 nchunks = *d_nchunks;
     for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
         const ChunkDesc d = descs[g];
-        for (u32 b = threadIdx.x; b < P; b += SC_NT) lh[b] = 0;
+        for (u32 b = threadIdx.x; b <= P; b += SC_NT) lh[b] = 0;
         __syncthreads();
         const u64 step = SRC == 0 ? Tile<W>::WORDS : Tile<W>::KEYS;
-        typename KeyT<W>::T hn[Tile<W>::KPT]; u32 vmn = 0;
-        if (SRC == 1 && d.begin < d.end) vmn = tile_keys_array<W>(keys, d.begin, d.end, hn);
-        for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
-            typename KeyT<W>::T h[Tile<W>::KPT];
-            u32 vm;
-            if (SRC == 0) vm = tile_keys_reads<W>(packed, inval, t0, d.end, k, h);
-            else {
-                vm = vmn;
+        typename KeyT<W>::T ha[KPT], hb[KPT]; u32 vma = 0, vmb = 0;
+        auto process = [&](typename KeyT<W>::T (&h)[KPT], u32 vm) {
+            u32 dg[KPT];
 #pragma unroll
-                for (int j = 0; j < Tile<W>::KPT; ++j) h[j] = hn[j];
-                vmn = 0;
-                if (t0 + step < d.end) vmn = tile_keys_array<W>(keys, t0 + step, d.end, hn);   // keep HBM reads in flight
+            for (int j = 0; j < KPT; ++j) dg[j] = (vm & (1u << j)) ? key_digit<MODE>(digit_word(h[j]), ds) : P;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) atomicAdd(&lh[dg[j]], 1u);
+        };
+        if (SRC == 0) {
+            for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
+                vma = tile_keys_reads<W>(packed, inval, t0, d.end, k, ha);
+                process(ha, vma);
             }
-#pragma unroll
-            for (int j = 0; j < Tile<W>::KPT; ++j)
-                if (vm & (1u << j)) atomicAdd(&lh[key_digit(digit_word(h[j]), ds)], 1u);
+        } else {
+            if (d.begin < d.end) vma = tile_keys_array<W>(keys, d.begin, d.end, ha);
+            for (u64 t0 = d.begin; t0 < d.end; t0 += 2 * step) {   // two tiles per trip: register ping-pong, no copies
+                if (t0 + step < d.end) vmb = tile_keys_array<W>(keys, t0 + step, d.end, hb);
+                process(ha, vma);
+                const u64 t1 = t0 + step;
+                if (t1 >= d.end) break;
+                if (t1 + step < d.end) vma = tile_keys_array<W>(keys, t1 + step, d.end, ha);
+                process(hb, vmb);
+            }
         }
         __syncthreads();
         for (u32 b = threadIdx.x; b < P; b += SC_NT) matrix[d.flat_base + (u64)b * d.stride] = lh[b];
@@ -328,7 +357,7 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
     if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
+    lds_barrier();
     if (wave == 0) {
         const u32 x = lane < NT / 64 ? wsum[lane] : 0u;
         u32 y = x;
@@ -337,7 +366,7 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
         if (lane < NT / 64) wsum[lane] = y - x;
         if (lane == NT / 64 - 1) *tot = y;
     }
-    __syncthreads();
+    lds_barrier();
     u32 run = wsum[wave] + inc - s;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -350,17 +379,18 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
     }
 }
 
-template <int W, int SRC>
-__global__ __launch_bounds__(SC_NT) void k_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
+template <int W, int SRC, int MODE>
+__global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
                                                    const typename KeyT<W>::T* __restrict__ keys,
                                                    const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
                                                    const u32* __restrict__ scanned,
                                                    typename KeyT<W>::T* __restrict__ out, int k, DigitSpec ds, u32 P, u32 dbg) {
     typedef typename KeyT<W>::T Key;
+    constexpr int KPT = Tile<W>::KPT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Key* stage = reinterpret_cast<Key*>(smem);                       // Tile<W>::KEYS keys
-    u32* cnt = reinterpret_cast<u32*>(smem + sizeof(Key) * Tile<W>::KEYS); // P
-    u32* off = cnt + P;                                              // P
+    u32* cnt = reinterpret_cast<u32*>(smem + sizeof(Key) * Tile<W>::KEYS); // P + 1 (dummy bin P: invalid windows)
+    u32* off = cnt + (P + 1);                                        // P
     u32* cur = off + P;                                              // P
     u32* delta = cur + P;                                            // P
     u32* wsum = delta + P;                                           // 16 (+1 total)
@@ -368,45 +398,67 @@ __global__ __launch_bounds__(SC_NT) void k_scatter(const u64* __restrict__ packe
     const u32 nchunks = *d_nchunks;
     for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
         const ChunkDesc d = descs[g];
-        __syncthreads();   // previous chunk's write-out reads delta/off/stage
+        lds_barrier();   // previous chunk's write-out reads delta/off/stage
         for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] = scanned[d.flat_base + (u64)b * d.stride]; cnt[b] = 0; }
+        if (threadIdx.x == 0) cnt[P] = 0;
         const u64 step = SRC == 0 ? Tile<W>::WORDS : Tile<W>::KEYS;
-        Key hn[Tile<W>::KPT]; u32 vmn = 0;
-        if (SRC == 1 && d.begin < d.end) vmn = tile_keys_array<W>(keys, d.begin, d.end, hn);
-        __syncthreads();
-        for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
-            Key h[Tile<W>::KPT]; u32 rk[Tile<W>::KPT];
-            u32 vm;
-            if (SRC == 0) vm = tile_keys_reads<W>(packed, inval, t0, d.end, k, h);
-            else {
-                vm = vmn;
+        Key ha[KPT], hb[KPT]; u32 vma = 0, vmb = 0;
+        auto process = [&](Key (&h)[KPT], u32 vm) {
+            u32 rk[KPT];
 #pragma unroll
-                for (int j = 0; j < Tile<W>::KPT; ++j) h[j] = hn[j];
-                vmn = 0;
-                if (t0 + step < d.end) vmn = tile_keys_array<W>(keys, t0 + step, d.end, hn);   // prefetch
+            for (int j = 0; j < KPT; ++j) {
+                const u32 dj = (vm & (1u << j)) ? key_digit<MODE>(digit_word(h[j]), ds) : P;
+                rk[j] = dj << 16;                                    // (digit, rank) packed: rank < 8192, digit <= 2048
             }
+            if (!(dbg & 64u)) {
 #pragma unroll
-            for (int j = 0; j < Tile<W>::KPT; ++j)
-                if (vm & (1u << j)) rk[j] = atomicAdd(&cnt[key_digit(digit_word(h[j]), ds)], 1u);
-            __syncthreads();
-            tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot);
-            __syncthreads();
+            for (int j = 0; j < KPT; ++j) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
+            }
+            if (!(dbg & 32u)) lds_barrier();
+            if (!(dbg & 16u)) tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot);
+            if (!(dbg & 32u)) lds_barrier();
+            if (!(dbg & 4u)) {
 #pragma unroll
-            for (int j = 0; j < Tile<W>::KPT; ++j)
-                if (vm & (1u << j)) {
-                    if (dbg & 2u) out[(u64)(delta[key_digit(digit_word(h[j]), ds)] + off[key_digit(digit_word(h[j]), ds)] + rk[j])] = h[j];
-                    else stage[off[key_digit(digit_word(h[j]), ds)] + rk[j]] = h[j];
-                }
-            __syncthreads();
+            for (int j = 0; j < KPT; ++j) {
+                const u32 dj = rk[j] >> 16;
+                const u32 o = off[dj < P ? dj : 0];
+                if (dj < P) stage[o + (rk[j] & 0xFFFFu)] = h[j];
+            }
+            }
+            if (threadIdx.x == 0) cnt[P] = 0;
+            if (!(dbg & 32u)) lds_barrier();
             const u32 ntile = *tot;
-            if (!(dbg & 1u))
-            for (u32 i = threadIdx.x; i < ntile; i += SC_NT) {
-                const Key hk = stage[i];
-                out[(u64)(delta[key_digit(digit_word(hk), ds)] + i)] = hk;
+            if (!(dbg & 1u)) {
+                for (u32 i0 = 0; i0 < ntile; i0 += 4 * SC_NT) {
+                    Key hk[4]; u32 dd[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const u32 i = i0 + u * SC_NT + threadIdx.x; hk[u] = stage[i < ntile ? i : 0]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) dd[u] = delta[key_digit<MODE>(digit_word(hk[u]), ds)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const u32 i = i0 + u * SC_NT + threadIdx.x; if (i < ntile) out[(dbg & 128u) ? (u64)(blockIdx.x * Tile<W>::KEYS + i + (dd[u] & 1u)) : (u64)(dd[u] + i)] = hk[u]; }
+                }
             }
             // no barrier here: the next tile's rank phase only touches cnt (zeroed
             // by tile_scan); its first barrier orders this write-out before the
             // next tile_scan / stage writes.
+        };
+        if (SRC == 1 && d.begin < d.end) vma = tile_keys_array<W>(keys, d.begin, d.end, ha);
+        lds_barrier();
+        if (SRC == 0) {
+            for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
+                vma = tile_keys_reads<W>(packed, inval, t0, d.end, k, ha);
+                process(ha, vma);
+            }
+        } else {
+            for (u64 t0 = d.begin; t0 < d.end; t0 += 2 * step) {   // two tiles per trip: register ping-pong, no copies
+                if (t0 + step < d.end) vmb = tile_keys_array<W>(keys, t0 + step, d.end, hb);   // prefetch under the LDS phases
+                process(ha, vma);
+                const u64 t1 = t0 + step;
+                if (t1 >= d.end) break;
+                if (t1 + step < d.end) vma = tile_keys_array<W>(keys, t1 + step, d.end, ha);
+                process(hb, vmb);
+            }
         }
     }
 }
@@ -485,6 +537,7 @@ __global__ void k_final_offsets(const u32* __restrict__ scanned, const SegInfo* 
 struct CountParams {
     u32 F;
     u32 amin, amax, histo_max;
+    u32 dbg;                  // experiment switches (timing ablations only)
 };
 
 // One persistent block per sub-partition in turn.  Insert = 64-bit LDS CAS on
@@ -542,10 +595,12 @@ __global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* keys, u64* solid_keys,
     u64 pk[CNT_KPT];
     if (q < cp.F) {
         begin = fstart[q]; end = fstart[q + 1];
+        if (end > begin) {
 #pragma unroll
-        for (int j = 0; j < CNT_KPT; ++j) { const u32 i = begin + tid + j * CNT_NT; if (i < end) pk[j] = keys[i]; }
+            for (int j = 0; j < CNT_KPT; ++j) { const u32 i = begin + tid + j * CNT_NT; pk[j] = keys[i < end ? i : end - 1]; }
+        }
     }
-    __syncthreads();
+    lds_barrier();
     int par = 0;
     while (q < cp.F) {
         u32* ctr = s_ctr[par];
@@ -570,10 +625,12 @@ __global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* keys, u64* solid_keys,
         u32 nbeg = 0, nend = 0;
         if (qn < cp.F) {
             nbeg = fstart[qn]; nend = fstart[qn + 1];
+            if (nend > nbeg) {
 #pragma unroll
-            for (int j = 0; j < CNT_KPT; ++j) { const u32 i = nbeg + tid + j * CNT_NT; if (i < nend) pk[j] = keys[i]; }
+                for (int j = 0; j < CNT_KPT; ++j) { const u32 i = nbeg + tid + j * CNT_NT; pk[j] = keys[i < nend ? i : nend - 1]; }
+            }
         }
-        __syncthreads();
+        lds_barrier();
         const u32 nd = ctr[0];
         const bool bad = ctr[2] || nd > CNT_MAXLOAD;           // block-uniform
         if (bad) {
@@ -610,7 +667,7 @@ __global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* keys, u64* solid_keys,
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) {
             nsolid[q] = bad ? 0u : ctr[1];
             ndist_acc += bad ? 0u : nd;
@@ -619,10 +676,10 @@ __global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* keys, u64* solid_keys,
         par ^= 1;
         q = qn; begin = nbeg; end = nend;
     }
-    __syncthreads();
+    lds_barrier();
     // flush block-local histogram
     if (lane == 0 && ones) atomicAdd(&lh[1], ones);
-    __syncthreads();
+    lds_barrier();
     for (int b = tid; b < CNT_LH; b += CNT_NT) {
         const u32 v = lh[b];
         if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
@@ -682,13 +739,13 @@ __global__ __launch_bounds__(CNT_NT) void k_count<2>(K2* keys, K2* solid_keys, c
 #pragma unroll
         for (int j = 0; j < C2_KPT; ++j) { const u32 i = begin + tid + j * CNT_NT; if (i < end) pk[j] = keys[i]; }
     }
-    __syncthreads();
+    lds_barrier();
     while (q < cp.F) {
         const u32 n = end - begin;
         const K2* gk = keys + begin;
 #pragma unroll
         for (int j = 0; j < C2_KPT; ++j) { const u32 i = tid + j * CNT_NT; if (i < n) sk[i] = pk[j]; }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int j = 0; j < C2_KPT; ++j) {
             const u32 i = tid + j * CNT_NT;
@@ -705,7 +762,7 @@ __global__ __launch_bounds__(CNT_NT) void k_count<2>(K2* keys, K2* solid_keys, c
 #pragma unroll
             for (int j = 0; j < C2_KPT; ++j) { const u32 i = nbeg + tid + j * CNT_NT; if (i < nend) pk[j] = keys[i]; }
         }
-        __syncthreads();
+        lds_barrier();
         const u32 nd = ctr[0];
         const bool bad = ctr[2] || nd > C2_MAXLOAD;
         if (bad) {
@@ -744,7 +801,7 @@ __global__ __launch_bounds__(CNT_NT) void k_count<2>(K2* keys, K2* solid_keys, c
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) {
             nsolid[q] = bad ? 0u : ctr[1];
             ndist_acc += bad ? 0u : nd;
@@ -752,9 +809,9 @@ __global__ __launch_bounds__(CNT_NT) void k_count<2>(K2* keys, K2* solid_keys, c
         }
         q = qn; begin = nbeg; end = nend;
     }
-    __syncthreads();
+    lds_barrier();
     if (lane == 0 && ones) atomicAdd(&lh[1], ones);
-    __syncthreads();
+    lds_barrier();
     for (int b = tid; b < CNT_LH; b += CNT_NT) {
         const u32 v = lh[b];
         if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
