@@ -36,9 +36,9 @@ fetch = pmc(os.path.join(src, "fetch", "f_counter_collection.csv"), "FETCH_SIZE"
 write = pmc(os.path.join(src, "write", "w_counter_collection.csv"), "WRITE_SIZE")
 avg_ns = {r["Name"]: float(r["AverageNs"]) for r in rows}
 
-# kernel -> bench stage name.  k_hist/k_scatter: <W, SRC>; SRC 0 = reads (level 1), 1 = key array (level 2)
-stage_of = [("k_encode", "encode"), ("k_hist<1, 0>", "hist1"), ("k_scatter<1, 0>", "scatter1"), ("k_hist<1, 1>", "hist2"),
-            ("k_scatter<1, 1>", "scatter2"), ("k_count<1>", "count"), ("k_compact<1>", "compact")]
+# kernel -> bench stage name.  k_hist/k_scatter: <W, SRC, MODE>; SRC 0 = reads (level 1), 1 = key array (level 2)
+stage_of = [("k_encode", "encode"), ("k_hist<1, 0,", "hist1"), ("k_scatter<1, 0,", "scatter1"), ("k_hist<1, 1,", "hist2"),
+            ("k_scatter<1, 1,", "scatter2"), ("k_count<1>", "count"), ("k_compact<1>", "compact")]
 summary = {}
 lines = [f"# PMC summary ({tag})", "",
          "rocprofv3 `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes (TCC slots), values are KiB per dispatch,",
