@@ -708,9 +708,21 @@ int dskgpu_k_enumerate(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, vo
 }
 
 int dskgpu_k_minimizers(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, void* d_minim, void* d_valid) {
-    (void)d_bytes; (void)nbytes; (void)d_minim; (void)d_valid;
-    if (!ctx) return DSKGPU_E_ARG;
-    return fail(ctx, DSKGPU_E_ARG, "k_minimizers not implemented yet");
+    if (!ctx || !d_minim || !d_valid) return DSKGPU_E_ARG;
+    const int m = (int)ctx->cfg.minimizer_size, k = (int)ctx->cfg.kmer_size;
+    if (m < 1 || m > 16 || m > k) return fail(ctx, DSKGPU_E_ARG, "minimizer_size must be in 1..16 and <= kmer_size");
+    CK(hipSetDevice(ctx->cfg.device));
+    u64 nwords = 0;
+    int rc = run_encode(ctx, static_cast<const uint8_t*>(d_bytes), nbytes, &nwords);
+    if (rc) return rc;
+    if (nbytes) {
+        const u64 nthreads = (nbytes + 15) / 16;
+        hipLaunchKernelGGL(k_minimizers, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream, ctx->packed.as<u64>(),
+                           ctx->inval.as<u32>(), nwords, (u64)nbytes, k, m, static_cast<u32*>(d_minim), static_cast<uint8_t*>(d_valid));
+        CKL("k_minimizers");
+    }
+    CK(hipStreamSynchronize(ctx->stream));
+    return DSKGPU_OK;
 }
 
 }  // extern "C"

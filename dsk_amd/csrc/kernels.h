@@ -897,3 +897,44 @@ __global__ __launch_bounds__(256) void k_enumerate(const u64* __restrict__ packe
         }
     }
 }
+
+// Minimizer (m <= 16) of the k-mer window ending at every byte: the smallest canonical
+// m-mer (A<C<T<G numeric order) inside the window.  Stands in for gatb-core's
+// ModelMinimizer on the path (named in BASELINE.json; call site src/DSK.cpp:63 getConfig);
+// used by the parity tests today and by the super-k-mer exchange planned next.
+// One thread = 16 consecutive end positions; rolling m-mers over the 2-bit stream.
+__global__ __launch_bounds__(256) void k_minimizers(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                                    u64 nwords, u64 nbytes, int k, int m,
+                                                    u32* __restrict__ minim, uint8_t* __restrict__ valid) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 p0 = t * 16;
+    if (p0 >= nbytes) return;
+    const u32 mmask = (m == 16) ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1);
+    const int halo = k - 1;                                 // bases needed before p0
+    const long long s0 = (long long)p0 - halo;
+    u32 cm[16 + 63];                                        // canonical m-mer ending at s0 + i
+    u32 f = 0, r = 0; int run = 0;
+    int runs[16];
+    for (int i = 0; i < halo + 16; ++i) {
+        const long long pos = s0 + i;
+        bool ok = false; u32 c = 0;
+        if (pos >= 0 && (u64)pos < nbytes) {
+            const u64 w = (u64)pos >> 5; const int j = (int)(pos & 31);
+            ok = !((inval[w] >> (31 - j)) & 1u);
+            c = (u32)(packed[w] >> (62 - 2 * j)) & 3u;
+        }
+        if (!ok) { run = 0; f = 0; r = 0; }
+        else { f = ((f << 2) | c) & mmask; r = (r >> 2) | ((c ^ 2u) << (2 * (m - 1))); ++run; }
+        cm[i] = f < r ? f : r;
+        if (i >= halo) runs[i - halo] = run;
+    }
+    for (int j = 0; j < 16; ++j) {
+        const u64 p = p0 + j;
+        if (p >= nbytes) break;
+        const bool v = runs[j] >= k;
+        u32 best = 0xFFFFFFFFu;
+        if (v) for (int e = halo + j - (k - m); e <= halo + j; ++e) best = cm[e] < best ? cm[e] : best;
+        minim[p] = v ? best : 0u;
+        valid[p] = v ? 1 : 0;
+    }
+}

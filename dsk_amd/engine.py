@@ -124,7 +124,8 @@ class KmerCounter:
 
     def __init__(self, kmer_size: int = 31, abundance_min: int = 2, abundance_max: int = 2147483647,
                  histo_max: int = 10000, device: int = 0, nb_partitions: int = 0, timing: bool = False,
-                 sort: bool = True, world_size: int = 1, rank: int = 0, stream: Optional[int] = None):
+                 sort: bool = True, world_size: int = 1, rank: int = 0, stream: Optional[int] = None,
+                 minimizer_size: int = 0):
         self._lib = load_library()
         cfg = _Config()
         cfg.kmer_size = kmer_size
@@ -133,6 +134,7 @@ class KmerCounter:
         cfg.histo_max = histo_max
         cfg.device = device
         cfg.nb_partitions = nb_partitions
+        cfg.minimizer_size = minimizer_size
         cfg.flags = (F_TIMING if timing else 0) | (0 if sort else F_NO_SORT)
         cfg.world_size = world_size
         cfg.rank = rank

@@ -58,6 +58,7 @@ def workload(name: str):
         "c2_10Mx150": (30_000_000, 10_000_000, 150),      # configs[1]: 50x of a 30 Mbp genome
         "ecoli50x": (4_640_000, 1_550_000, 150),          # E. coli stand-in for the >=10x goal
         "c3_200Mx150": (600_000_000, 200_000_000, 150),   # configs[2] (whole node)
+        "c3_shard_25Mx150": (75_000_000, 25_000_000, 150),  # one GPU's share of configs[2] (200 M reads / 8 GPUs)
         "tiny": (20_000, 10_000, 150),
         "small": (1_000_000, 333_334, 150),
     }

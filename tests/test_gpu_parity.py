@@ -289,3 +289,18 @@ def test_multi_gpu_path_on_one_device(oracle, golden_dir, dev, world, k):
     assert sum(c.stats()["n_kmers"] for c in ctxs) == ref.total
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("k,m", [(31, 10), (21, 8), (63, 10), (11, 4), (16, 16), (5, 1)])
+def test_minimizers_match_oracle(oracle, golden_dir, dev, k, m):
+    from dsk_amd import KmerCounter
+    s, _ = oracle.load_bank(os.path.join(golden_dir, "longread.fasta"))
+    s = np.concatenate([s[:20000], np.frombuffer(b"ACGTNNNNacgtacgtACGTRYKMAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA" * 3, dtype=np.uint8)])
+    t = torch.from_numpy(s.copy()).to(dev)
+    mm = torch.zeros(len(s), dtype=torch.int32, device=dev)
+    val = torch.zeros(len(s), dtype=torch.uint8, device=dev)
+    with KmerCounter(kmer_size=k, minimizer_size=m) as kc:
+        kc.k_minimizers(t.data_ptr(), len(s), mm.data_ptr(), val.data_ptr())
+    ref_m, ref_v = oracle.minimizers(s, k, m)
+    assert (val.cpu().numpy() == ref_v).all()
+    assert (mm.cpu().numpy().view(np.uint32) == ref_m).all()
