@@ -25,6 +25,14 @@ def exchange(send: torch.Tensor, send_counts: Sequence[int], group=None,
     destination rank.  Returns (recv buffer view, per-source counts)."""
     world = dist.get_world_size(group)
     assert len(send_counts) == world
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        # development path (several ranks sharing one GPU, no RCCL): stage the exchange through host memory
+        out_cpu, rcounts = exchange(send[: sum(send_counts)].cpu(), send_counts, group)
+        n = out_cpu.numel()
+        if recv is None or recv.numel() < n:
+            recv = torch.empty(max(n, 1), dtype=send.dtype, device=send.device)
+        recv[:n].copy_(out_cpu)
+        return recv[:n], rcounts
     dev = send.device
     sc = torch.tensor(list(send_counts), dtype=torch.int64, device=dev)
     rc = torch.empty_like(sc)

@@ -219,11 +219,13 @@ def test_determinism_and_reuse(dev):
         assert (k == outs[0][0]).all() and (a == outs[0][1]).all() and (h == outs[0][2]).all()
 
 
-def test_full_size_invariants(dev):
-    """Size-independent properties on a workload too big for the oracle in seconds:
-    sum(abundance * hist) == n_kmers, sum(hist) == n_distinct, sortedness, solid count == hist tail."""
+@pytest.mark.parametrize("workload", ["ecoli50x", "c2_10Mx150"])
+def test_full_size_invariants(dev, workload):
+    """Size-independent properties at BASELINE.json's full sizes (configs[1] = c2_10Mx150), too big for
+    the oracle in seconds: sum(abundance * hist) == n_kmers, sum(hist) == n_distinct, sortedness,
+    solid count == hist tail, n_kmers == number of full ACGT windows in the stream."""
     from dsk_amd import synth, KmerCounter
-    gl, nr, rl = synth.workload("ecoli50x")
+    gl, nr, rl = synth.workload(workload)
     g = synth.make_genome(gl, dev)
     reads = synth.make_reads(g, nr, rl)
     with KmerCounter(kmer_size=31, abundance_min=2) as kc:

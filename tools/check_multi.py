@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""End-to-end check of the sharded count with real processes on ONE GPU (development aid):
+   python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/check_multi.py
+Ranks share cuda:0 and exchange over gloo (staged through the host); the summed result must equal a
+single-context count of the concatenated reads."""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, ".")
+from dsk_amd import KmerCounter, synth
+from dsk_amd.multi import ShardedCounter, gather_histogram
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+dev = torch.device("cuda:0")
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 31
+genome = synth.make_genome(300_000 * world, dev)
+shards = [synth.make_reads(genome, 100_000, 150, seed=synth.SEED + 1 + r) for r in range(world)]
+kc = KmerCounter(kmer_size=k, abundance_min=2, world_size=world, rank=rank)
+kc.set_reads_device(shards[rank].data_ptr(), shards[rank].numel())
+sc = ShardedCounter(kc, dev)
+sc.count(); sc.count()
+st = kc.stats()
+hist = gather_histogram(torch.from_numpy(kc.histogram().astype(np.int64)))
+tot = torch.tensor([st["n_kmers"], st["n_distinct"], st["n_solid"]], dtype=torch.int64)
+dist.all_reduce(tot)
+if rank == 0:
+    allreads = torch.cat(shards)
+    with KmerCounter(kmer_size=k, abundance_min=2) as one:
+        one.set_reads_device(allreads.data_ptr(), allreads.numel())
+        one.count()
+        s1 = one.stats(); h1 = one.histogram().astype(np.int64)
+    assert tot.tolist() == [s1["n_kmers"], s1["n_distinct"], s1["n_solid"]], (tot.tolist(), s1)
+    assert (hist.numpy() == h1).all()
+    print(f"multi ok: world={world} k={k} kmers={s1['n_kmers']} distinct={s1['n_distinct']} solid={s1['n_solid']}")
+dist.barrier()
+dist.destroy_process_group()
