@@ -221,6 +221,8 @@ bool make_plan(u64 n_upper, int extra_bits, int W, Plan* pl) {
         u64 p2 = (F + p1 - 1) / p1;
         if (p1 > MAX_LEVEL_BINS || p2 > MAX_LEVEL_BINS) return false;
         pl->levels = 2; pl->P1 = (u32)p1; pl->P2 = (u32)p2;
+        if (const char* e = getenv("DSKGPU_P2")) pl->P2 = (u32)atoi(e);   // experiment: timing of the scatter vs run length (results invalid)
+        if (const char* e = getenv("DSKGPU_P1")) pl->P1 = (u32)atoi(e);
     }
     pl->F = pl->P1 * pl->P2;
     pl->d1 = DigitSpec{1u, pl->P1, 0u};
