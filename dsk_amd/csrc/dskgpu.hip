@@ -35,7 +35,8 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_COUNT = 8 };
+enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_COUNT = 8 };
+#define SORT_TOP_BITS 40u
 
 struct Stage { const char* name; hipEvent_t ev; };
 
@@ -65,6 +66,7 @@ struct dskgpu_ctx {
 
     // results
     bool have_result = false;
+    bool sort_partial = false;
     u64 n_rows = 0;
     const u64* res_lo = nullptr; const u64* res_hi = nullptr; const u32* res_ab = nullptr;
     dskgpu_stats stats{};
@@ -259,17 +261,31 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     const bool two = ctx->W == 2;
     ctx->res_lo = ctx->out_lo.as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>();
     ctx->res_hi = two ? ctx->out_hi.as<u64>() : nullptr;
+    ctx->sort_partial = false;
     if (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT)) return DSKGPU_OK;
     CK(ctx->srt_lo.ensure(n * 8));
     CK(ctx->srt_ab.ensure(n * 4));
     size_t tmp = 0;
     if (!two) {
         const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
+        // Sort on the top SORT_TOP_BITS of the value only (5 radix passes instead of 8), then fix the
+        // (rare, short) runs of equal prefix; exactness is kept by the full-width fallback in finish_sort().
+        // (k = 32 uses all 64 bits: rocPRIM's partial-range sort misbehaved with end_bit == 64 on ROCm 7.2, so it sorts full width)
+        const unsigned begin_bit = (end_bit > SORT_TOP_BITS && end_bit < 64u && !getenv("DSKGPU_FULLSORT")) ? end_bit - SORT_TOP_BITS : 0u;
         CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->out_lo.as<u64>(), ctx->srt_lo.as<u64>(), ctx->out_ab.as<u32>(),
-                                     ctx->srt_ab.as<u32>(), (size_t)n, 0u, end_bit, ctx->stream));
+                                     ctx->srt_ab.as<u32>(), (size_t)n, begin_bit, end_bit, ctx->stream));
         CK(ctx->srt_tmp.ensure(tmp));
         CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->out_lo.as<u64>(), ctx->srt_lo.as<u64>(), ctx->out_ab.as<u32>(),
-                                     ctx->srt_ab.as<u32>(), (size_t)n, 0u, end_bit, ctx->stream));
+                                     ctx->srt_ab.as<u32>(), (size_t)n, begin_bit, end_bit, ctx->stream));
+        ctx->sort_partial = begin_bit != 0;
+        if (ctx->sort_partial) {
+            u32* flag = ctx->scalars.as<u32>() + SC_SORTFLAG;
+            CK(hipMemsetAsync(flag, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_fix_runs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->srt_lo.as<u64>(),
+                               ctx->srt_ab.as<u32>(), n, (int)begin_bit, flag);
+            CKL("k_fix_runs");
+            CK(hipMemcpyAsync(&ctx->h_back[3], flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
         ctx->res_lo = ctx->srt_lo.as<u64>(); ctx->res_ab = ctx->srt_ab.as<u32>();
         return DSKGPU_OK;
     }
@@ -431,6 +447,20 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         ctx->hist.assign((size_t)ctx->cfg.histo_max + 1, 0);
         CK(hipMemcpyAsync(ctx->hist.data(), ctx->ghist.p, ctx->hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
+        if (W == 1 && ctx->sort_partial && ns && ctx->h_back[3]) {
+            // a run of equal 40-bit prefixes was too long for the in-place fix-up: sort full width
+            // (srt_* holds a permutation of the rows; sort it back into out_*)
+            size_t tmp = 0;
+            const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
+            CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->srt_lo.as<u64>(), ctx->out_lo.as<u64>(), ctx->srt_ab.as<u32>(),
+                                         ctx->out_ab.as<u32>(), (size_t)ns, 0u, end_bit, ctx->stream));
+            CK(ctx->srt_tmp.ensure(tmp));
+            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->srt_lo.as<u64>(), ctx->out_lo.as<u64>(), ctx->srt_ab.as<u32>(),
+                                         ctx->out_ab.as<u32>(), (size_t)ns, 0u, end_bit, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+            ctx->res_lo = ctx->out_lo.as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>();
+            ctx->stats.sort_fallback = 1;
+        }
         ctx->resolve_marks();
         ctx->n_rows = ns;
         ctx->stats.n_bytes = from_reads ? ctx->n_bytes : 0;

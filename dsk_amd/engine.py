@@ -48,7 +48,8 @@ class _Stats(C.Structure):
         ("n_levels", C.c_uint32),
         ("n_final_bins", C.c_uint32),
         ("n_retries", C.c_uint32),
-        ("reserved", C.c_uint64 * 4),
+        ("sort_fallback", C.c_uint64),
+        ("reserved", C.c_uint64 * 3),
     ]
 
 

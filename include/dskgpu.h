@@ -104,7 +104,8 @@ typedef struct dskgpu_stats {
     uint32_t n_levels;       /* radix-partition levels used              */
     uint32_t n_final_bins;   /* hash-aggregate sub-partitions            */
     uint32_t n_retries;      /* table-overflow retries                   */
-    uint64_t reserved[4];
+    uint64_t sort_fallback;  /* 1 if the row sort needed its full-width fallback */
+    uint64_t reserved[3];
 } dskgpu_stats;
 int dskgpu_get_stats(const dskgpu_ctx* ctx, dskgpu_stats* out);
 

@@ -306,3 +306,28 @@ def test_minimizers_match_oracle(oracle, golden_dir, dev, k, m):
     ref_m, ref_v = oracle.minimizers(s, k, m)
     assert (val.cpu().numpy() == ref_v).all()
     assert (mm.cpu().numpy().view(np.uint32) == ref_m).all()
+
+
+def test_row_sort_fallback_on_shared_prefixes(oracle, dev):
+    """The row sort orders the top 40 bits with a radix sort and fixes runs of equal prefix in place;
+    more than 32 rows sharing their first 20 bases must take the exact full-width fallback."""
+    from dsk_amd import KmerCounter
+    rng = np.random.default_rng(11)
+    tails = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(300, 11))
+    recs = [b"AAAAAAAAAAAAAAAAAAAC" + t.tobytes() for t in tails]          # 300 31-mers with one 20-base prefix
+    noise = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=50_000).tobytes()
+    s = np.frombuffer(b"\n".join(recs) + b"\n" + noise + b"\n", dtype=np.uint8)
+    t = torch.from_numpy(s.copy()).to(dev)
+    with KmerCounter(kmer_size=31, abundance_min=1) as kc:
+        kc.set_reads_device(t.data_ptr(), t.numel())
+        kc.count()
+        kmers, ab = kc.rows()
+        st = kc.stats()
+    lo, hi, rab = oracle.count(s, 31).solid(1)
+    assert st["sort_fallback"] == 1
+    assert (kmers[:, 0] == lo).all() and (ab == rab).all()
+    # short runs (<= 32 rows per prefix) are fixed in place, no fallback
+    recs = [b"AAAAAAAAAAAAAAAAAAAC" + t.tobytes() for t in tails[:20]] + [b"CCCCCCCCCCCCCCCCCCCA" + t.tobytes() for t in tails[:25]]
+    s = np.frombuffer(b"\n".join(recs) + b"\n" + noise + b"\n", dtype=np.uint8)
+    st = check_against_oracle(oracle, s, 31, dev, amin=1)
+    assert st["sort_fallback"] == 0

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""End-to-end wall clock of the `dsk` binary (file -> .h5) on a synthetic FASTQ, next to the CPU oracle CLI.
+usage (GPU box): python tools/e2e.py [workload=ecoli50x] [k=31]"""
+import os, subprocess, sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from dsk_amd import synth
+name = sys.argv[1] if len(sys.argv) > 1 else "ecoli50x"
+k = sys.argv[2] if len(sys.argv) > 2 else "31"
+gl, nr, rl = synth.workload(name)
+dev = torch.device("cuda:0")
+reads = synth.make_reads(synth.make_genome(gl, dev), nr, rl).cpu().numpy().reshape(nr, rl + 1)[:, :rl]
+os.makedirs("/tmp/e2e", exist_ok=True)
+fq = f"/tmp/e2e/{name}.fastq"
+t0 = time.time()
+qual = b"I" * rl
+with open(fq, "wb") as f:
+    buf = []
+    for i in range(nr):
+        buf.append(b"@r%d\n" % i + reads[i].tobytes() + b"\n+\n" + qual + b"\n")
+        if len(buf) == 65536:
+            f.write(b"".join(buf)); buf = []
+    f.write(b"".join(buf))
+print(f"wrote {fq}: {os.path.getsize(fq)/1e6:.0f} MB in {time.time()-t0:.1f} s")
+root = os.path.abspath(".")
+for attempt in range(2):
+    t0 = time.time()
+    out = subprocess.run([f"{root}/dsk_amd/host/bin/dsk", "-file", fq, "-kmer-size", k, "-out", "/tmp/e2e/out", "-verbose", "1"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+    dt = time.time() - t0
+    keep = [l for l in out.splitlines() if any(s in l for s in ("_s ", "kmers_nb", "solid_kmers", "EXCEPTION"))]
+    print(f"dsk run {attempt}: {dt:.2f} s wall"); print("\n".join(keep))
+t0 = time.time()
+out = subprocess.run([f"{root}/oracle/dsk_oracle_cli", "-file", fq, "-kmer-size", k, "-nb-cores", str(os.cpu_count())],
+                     stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+print(f"cpu oracle cli ({os.cpu_count()} threads): {time.time()-t0:.2f} s wall  |  {out.strip()}")
+print("h5 size MB:", os.path.getsize("/tmp/e2e/out.h5") / 1e6)
