@@ -5,9 +5,15 @@
 #include <sys/stat.h>
 #include <zlib.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstring>
 #include <fstream>
+#include <mutex>
+#include <thread>
 
 namespace dsk {
 
@@ -28,7 +34,94 @@ namespace {
 uint64_t file_size(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0; }
 bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
 
-// One FASTA/FASTQ file, line-driven state machine over the inflated bytes.
+// Line-driven FASTA/FASTQ state machine; emits "<sequence>\n" per record into `out`.
+struct RecordParser {
+    enum { HEADER, SEQ_FA, SEQ_FQ, QUAL } st = HEADER;
+    std::string out, line;
+    uint64_t nseq = 0; size_t seqlen = 0, qleft = 0; bool open_rec = false;
+    size_t chunkBytes; const IBank::Sink* sink; std::mutex* mu;
+    RecordParser(size_t chunk, const IBank::Sink* s, std::mutex* m) : chunkBytes(chunk), sink(s), mu(m) { out.reserve(chunk + (1 << 20)); }
+    void flush() {
+        if (out.empty()) return;
+        if (mu) { std::lock_guard<std::mutex> g(*mu); (*sink)(out.data(), out.size()); }
+        else (*sink)(out.data(), out.size());
+        out.clear();
+    }
+    void end_record() {
+        if (!open_rec) return;
+        out.push_back('\n'); ++nseq; open_rec = false; seqlen = 0;
+        if (out.size() >= chunkBytes) flush();
+    }
+    void append_seq(const char* p, size_t n) {
+        for (size_t i = 0; i < n; ++i) { char c = p[i]; if (c != '\r' && c != ' ' && c != '\t') { out.push_back(c); ++seqlen; } }
+    }
+    void on_line(const char* p, size_t n) {
+        switch (st) {
+            case HEADER:
+                if (n == 0) return;
+                if (p[0] == '>') { st = SEQ_FA; open_rec = true; seqlen = 0; }
+                else if (p[0] == '@') { st = SEQ_FQ; open_rec = true; seqlen = 0; }
+                return;
+            case SEQ_FA:
+                if (n && p[0] == '>') { end_record(); st = SEQ_FA; open_rec = true; seqlen = 0; return; }
+                append_seq(p, n); return;
+            case SEQ_FQ:
+                if (n && p[0] == '+') { st = QUAL; qleft = seqlen; if (qleft == 0) { end_record(); st = HEADER; } return; }
+                append_seq(p, n); return;
+            case QUAL: {
+                size_t q = 0; for (size_t i = 0; i < n; ++i) if (p[i] != '\r') ++q;
+                if (q >= qleft) { end_record(); st = HEADER; } else qleft -= q;
+                return;
+            }
+        }
+    }
+    void feed(const char* p, size_t n) {
+        const char* e = p + n;
+        while (p < e) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+            if (!nl) { line.append(p, (size_t)(e - p)); break; }
+            if (line.empty()) on_line(p, (size_t)(nl - p));
+            else { line.append(p, (size_t)(nl - p)); on_line(line.data(), line.size()); line.clear(); }
+            p = nl + 1;
+        }
+    }
+    void finish() {
+        if (!line.empty()) { on_line(line.data(), line.size()); line.clear(); }
+        end_record();
+        flush();
+    }
+};
+
+// First record start at or after `from` in an uncompressed buffer (used to cut a file into
+// independently parsable ranges).  FASTA: a line starting with '>'.  FASTQ (4-line records): a line
+// starting with '@' whose second following line starts with '+' -- a quality line that happens to
+// start with '@' fails that test because two lines below it comes a sequence line.
+const char* next_record_start(const char* base, const char* from, const char* end, char kind) {
+    const char* p = from;
+    if (p > base) {                               // move to the next line start
+        const char* nl = (const char*)memchr(p - 1, '\n', (size_t)(end - (p - 1)));
+        if (!nl) return end;
+        p = nl + 1;
+    }
+    while (p < end) {
+        if (*p == kind) {
+            if (kind == '>') return p;
+            const char* l1 = (const char*)memchr(p, '\n', (size_t)(end - p));
+            if (!l1) return end;
+            const char* l2 = (const char*)memchr(l1 + 1, '\n', (size_t)(end - (l1 + 1)));
+            if (!l2) return end;
+            if (l2 + 1 < end && l2[1] == '+') return p;
+        }
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        if (!nl) return end;
+        p = nl + 1;
+    }
+    return end;
+}
+
+// One FASTA/FASTQ file.  gzip'ed: single inflate stream (zlib).  Plain and large: memory-mapped
+// and parsed by several threads on record-aligned ranges (the sink is serialised by a mutex;
+// counting does not depend on record order).
 class BankFasta : public IBank {
 public:
     explicit BankFasta(const std::string& path) : path_(path) {
@@ -39,63 +132,69 @@ public:
     std::vector<std::string> files() const override { return {path_}; }
 
     uint64_t stream(size_t chunkBytes, const Sink& sink) override {
+        const uint64_t size = file_size(path_);
+        unsigned char magic[2] = {0, 0};
+        { FILE* f = fopen(path_.c_str(), "rb"); if (f) { size_t got = fread(magic, 1, 2, f); (void)got; fclose(f); } }
+        const bool gz = magic[0] == 0x1f && magic[1] == 0x8b;
+        unsigned nthreads = Bank::parseThreads();
+        uint64_t min_bytes = 16u << 20;                       // below this a single thread is as fast
+        if (const char* e = getenv("DSK_PARSE_MIN_BYTES")) min_bytes = (uint64_t)atoll(e);
+        if (!gz && size >= min_bytes && nthreads > 1) {
+            uint64_t n = 0;
+            if (stream_parallel(chunkBytes, sink, size, nthreads, n)) return n;
+        }
+        return stream_serial(chunkBytes, sink);
+    }
+private:
+    uint64_t stream_serial(size_t chunkBytes, const Sink& sink) {
         gzFile f = gzopen(path_.c_str(), "rb");
         if (!f) throw Exception("unable to open file '%s'", path_.c_str());
         gzbuffer(f, 1 << 20);
         std::vector<char> raw(1 << 22);
-        std::string out; out.reserve(chunkBytes + (1 << 20));
-        std::string line;                       // carry of an incomplete line
-        enum { HEADER, SEQ_FA, SEQ_FQ, QUAL } st = HEADER;
-        uint64_t nseq = 0; size_t seqlen = 0, qleft = 0; bool open_rec = false;
-
-        auto end_record = [&]() {
-            if (!open_rec) return;
-            out.push_back('\n'); ++nseq; open_rec = false; seqlen = 0;
-            if (out.size() >= chunkBytes) { sink(out.data(), out.size()); out.clear(); }
-        };
-        auto append_seq = [&](const char* p, size_t n) {
-            for (size_t i = 0; i < n; ++i) { char c = p[i]; if (c != '\r' && c != ' ' && c != '\t') { out.push_back(c); ++seqlen; } }
-        };
-        auto on_line = [&](const char* p, size_t n) {
-            switch (st) {
-                case HEADER:
-                    if (n == 0) return;
-                    if (p[0] == '>') { st = SEQ_FA; open_rec = true; seqlen = 0; }
-                    else if (p[0] == '@') { st = SEQ_FQ; open_rec = true; seqlen = 0; }
-                    return;
-                case SEQ_FA:
-                    if (n && p[0] == '>') { end_record(); st = SEQ_FA; open_rec = true; seqlen = 0; return; }
-                    append_seq(p, n); return;
-                case SEQ_FQ:
-                    if (n && p[0] == '+') { st = QUAL; qleft = seqlen; if (qleft == 0) { end_record(); st = HEADER; } return; }
-                    append_seq(p, n); return;
-                case QUAL: {
-                    size_t q = 0; for (size_t i = 0; i < n; ++i) if (p[i] != '\r') ++q;
-                    if (q >= qleft) { end_record(); st = HEADER; } else qleft -= q;
-                    return;
-                }
-            }
-        };
+        RecordParser ps(chunkBytes, &sink, nullptr);
         for (;;) {
             int got = gzread(f, raw.data(), (unsigned)raw.size());
             if (got < 0) { gzclose(f); throw Exception("read error in file '%s'", path_.c_str()); }
             if (got == 0) break;
-            const char* p = raw.data(); const char* e = p + got;
-            while (p < e) {
-                const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
-                if (!nl) { line.append(p, (size_t)(e - p)); break; }
-                if (line.empty()) on_line(p, (size_t)(nl - p));
-                else { line.append(p, (size_t)(nl - p)); on_line(line.data(), line.size()); line.clear(); }
-                p = nl + 1;
-            }
+            ps.feed(raw.data(), (size_t)got);
         }
-        if (!line.empty()) { on_line(line.data(), line.size()); line.clear(); }
-        end_record();
         gzclose(f);
-        if (!out.empty()) sink(out.data(), out.size());
-        return nseq;
+        ps.finish();
+        return ps.nseq;
     }
-private:
+    bool stream_parallel(size_t chunkBytes, const Sink& sink, uint64_t size, unsigned nthreads, uint64_t& nseq) {
+        int fd = open(path_.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) return false;
+        const char* base = (const char*)m; const char* end = base + size;
+        const char* p = base; while (p < end && (*p == '\n' || *p == '\r' || *p == ' ')) ++p;
+        const char kind = p < end ? *p : 0;
+        if (kind != '>' && kind != '@') { munmap(m, size); return false; }
+        if (kind == '@') {          // the range cutter assumes 4-line FASTQ records: check the first one
+            const char* l1 = (const char*)memchr(p, '\n', (size_t)(end - p));
+            const char* l2 = l1 ? (const char*)memchr(l1 + 1, '\n', (size_t)(end - (l1 + 1))) : nullptr;
+            if (!l2 || l2 + 1 >= end || l2[1] != '+') { munmap(m, size); return false; }
+        }
+        nthreads = (unsigned)std::min<uint64_t>(nthreads, std::max<uint64_t>(1, size / std::max<uint64_t>(1, std::min<uint64_t>(8u << 20, size / 4 + 1))));
+        std::vector<const char*> cut(nthreads + 1);
+        cut[0] = p; cut[nthreads] = end;
+        for (unsigned t = 1; t < nthreads; ++t) cut[t] = next_record_start(base, base + size * t / nthreads, end, kind);
+        std::mutex mu; std::vector<uint64_t> counts(nthreads, 0); std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthreads; ++t)
+            th.emplace_back([&, t]() {
+                if (cut[t] >= cut[t + 1]) return;
+                RecordParser ps(chunkBytes, &sink, &mu);
+                ps.feed(cut[t], (size_t)(cut[t + 1] - cut[t]));
+                ps.finish();
+                counts[t] = ps.nseq;
+            });
+        for (auto& x : th) x.join();
+        munmap(m, size);
+        nseq = 0; for (auto c : counts) nseq += c;
+        return true;
+    }
     std::string path_;
 };
 
@@ -156,6 +255,14 @@ IBank* open_one(const std::string& path) {
 }
 
 }  // namespace
+
+namespace { unsigned g_parse_threads = 0; }
+void Bank::setParseThreads(unsigned n) { g_parse_threads = n; }
+unsigned Bank::parseThreads() {
+    unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1;
+    unsigned n = g_parse_threads ? g_parse_threads : hw;
+    return std::min(n, 32u);
+}
 
 IBank* Bank::open(const std::string& uri) {
     std::vector<std::string> parts;

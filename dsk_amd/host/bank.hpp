@@ -35,6 +35,9 @@ public:
     // uri: "a.fa", "a.fa,b.fq.gz", or a file whose lines are file names
     // (README.md:52-61).  Throws dsk::Exception when a file cannot be read.
     static IBank* open(const std::string& uri);
+    // host threads used to parse large uncompressed files (-nb-cores; 0 = all, capped at 32)
+    static void setParseThreads(unsigned n);
+    static unsigned parseThreads();
 };
 
 }  // namespace dsk

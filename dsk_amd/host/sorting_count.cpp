@@ -110,6 +110,7 @@ void SortingCountBase::execute() {
     const std::string out = outputName(input_, {firstUri});
     storage_.reset(StorageFactory(STORAGE_HDF5).create(out, true, false));
 
+    if (input_.has(STR_NB_CORES)) Bank::setParseThreads((unsigned)std::max<long long>(0, input_.getInt(STR_NB_CORES)));
     std::unique_ptr<ICountBackend> be(createBackend());
     be->configure(cfg);
     uint64_t nbytes = 0;

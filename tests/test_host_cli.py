@@ -167,3 +167,36 @@ def test_abundance_min_auto(bins, tmp_path, oracle):
     assert f'"{i}"' in cutoff
     subprocess.check_call([bins["dsk2ascii"], "-file", "auto", "-out", "auto.txt", "-verbose", "0"], cwd=tmp)
     assert sum(1 for _ in open(os.path.join(tmp, "auto.txt"))) == int(h[i:].sum())
+
+
+def test_parallel_parser_equals_serial(bins, tmp_path):
+    """Large uncompressed files are memory-mapped and parsed by several threads on record-aligned
+    ranges (bank.cpp); quality lines starting with '@' or '+', multi-line FASTA and CRLF must not
+    confuse the range cutter.  Same dump as the single-thread parse."""
+    import hashlib
+    import random
+    random.seed(5)
+    tmp = str(tmp_path)
+
+    def rnd(n):
+        return "".join(random.choice("ACGT") for _ in range(n))
+    with open(os.path.join(tmp, "big.fastq"), "w") as f:
+        for i in range(20000):
+            s = rnd(random.randint(30, 160))
+            q = "".join(random.choice("@+I#5") for _ in s)
+            f.write(f"@r{i}\n{s}\n+\n{q}\n")
+    with open(os.path.join(tmp, "big.fa"), "w") as f:
+        for i in range(8000):
+            s = rnd(random.randint(50, 400))
+            f.write(f">s{i} x\r\n")
+            for j in range(0, len(s), 70):
+                f.write(s[j:j + 70] + "\r\n")
+    env = dict(os.environ, DSK_PARSE_MIN_BYTES="1")
+    for fn in ("big.fastq", "big.fa"):
+        md5 = []
+        for cores in ("1", "7"):
+            subprocess.check_call([bins["dsk"], "-file", fn, "-kmer-size", "21", "-abundance-min", "1", "-out", f"o{cores}",
+                                   "-verbose", "0", "-nb-cores", cores], cwd=tmp, env=env)
+            subprocess.check_call([bins["dsk2ascii"], "-file", f"o{cores}", "-out", f"o{cores}.txt", "-verbose", "0"], cwd=tmp)
+            md5.append(hashlib.md5(open(os.path.join(tmp, f"o{cores}.txt"), "rb").read()).hexdigest())
+        assert md5[0] == md5[1], fn
