@@ -31,6 +31,17 @@ struct DevBuf {
         if (e == hipSuccess) cap = want; else p = nullptr;
         return e;
     }
+    // grow, keeping the first `keep` bytes (device-to-device copy on `stream`); returns 0 on success
+    int ensure_keep(size_t bytes, size_t keep, hipStream_t stream) {
+        if (bytes <= cap) return 0;
+        void* np = nullptr;
+        size_t want = ((std::max(bytes, cap + cap / 2) + 255) & ~size_t(255));
+        if (hipMalloc(&np, want) != hipSuccess) return -1;
+        if (keep && p) { if (hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1; (void)hipStreamSynchronize(stream); }
+        if (p) (void)hipFree(p);
+        p = np; cap = want;
+        return 0;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -58,7 +69,8 @@ struct dskgpu_ctx {
     DevBuf packed, inval;          // K1 output
     DevBuf bufA, bufB;             // partition ping-pong
     DevBuf mat1, mat2, sums, descs1, descs2, seg, fstart, nsolid, scalars, ghist, gstats;
-    DevBuf out_lo, out_hi, out_ab, srt_lo, srt_hi, srt_ab, srt_tmp, srt_idx, srt_idx2, srt_k, abund2;
+    DevBuf out_lo, out_hi, out_ab, srt_lo, srt_hi, srt_ab, srt_tmp, srt_idx, srt_idx2, srt_k, abund2, acc_lo, acc_hi, acc_ab;
+    u64 max_keys_per_pass = 0;     // 0 = as many as 32-bit offsets allow
     std::vector<u32> h_starts;
     u32 h_back[4] = {0}; u64 h_stats[4] = {0};   // host landing zone of the async size read-back
     std::vector<ChunkDesc> h_descs1;
@@ -227,8 +239,8 @@ bool make_plan(u64 n_upper, int extra_bits, int W, Plan* pl) {
         if (const char* e = getenv("DSKGPU_P1")) pl->P1 = (u32)atoi(e);
     }
     pl->F = pl->P1 * pl->P2;
-    pl->d1 = DigitSpec{1u, pl->P1, 0u};
-    pl->d2 = DigitSpec{2u, pl->P1, pl->P2};
+    pl->d1 = DigitSpec{1u, pl->P1, 0u, 1u, 1u, 0u};
+    pl->d2 = DigitSpec{2u, pl->P1, pl->P2, 1u, 1u, 0u};
     return true;
 }
 
@@ -312,34 +324,20 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     return DSKGPU_OK;
 }
 
+// One pass: partition + count the keys of pass `pass` (of `npass`) and leave its solid rows
+// (unsorted) in out_lo/out_hi/out_ab.  Returns PASS_TOO_BIG when the pass holds more keys than `cap`.
+#define PASS_TOO_BIG 1000
 template <int W>
-int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_keys_in, u64 nkeys_in) {
+int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_keys_in, u64 nkeys_in, u64 nwords,
+                 u32 pass, u32 npass, u64 cap, u64* ns_out, u64* nk_out, Plan* plan_out) {
     typedef typename KeyT<W>::T Key;
-    ctx->have_result = false;
-    if (from_reads) { ctx->st_names.clear(); ctx->st_ms.clear(); }   // from keys: keep the mg_scatter stages of this step
-    ctx->marks.clear(); ctx->ev_used = 0;
-    const u64 n_upper = from_reads ? ctx->n_bytes : nkeys_in;
-    if (n_upper >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "more than 2^32 k-mers in one pass is not supported yet");
-    u64 nwords = 0;
-    ctx->mark("start");
-    if (from_reads) {
-        int rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords);
-        if (rc) return rc;
-        ctx->mark("encode");
-    }
-    CK(ctx->scalars.ensure(SC_COUNT * 4));
-    CK(ctx->ghist.ensure(((size_t)ctx->cfg.histo_max + 1) * 8));
-    CK(ctx->gstats.ensure(4 * 8));
-    CK(ctx->bufA.ensure((n_upper + 1) * sizeof(Key)));
-    CK(ctx->bufB.ensure((n_upper + 1) * sizeof(Key)));
-    if (W == 2) CK(ctx->abund2.ensure((n_upper + 1) * 4));
     u32* sc = ctx->scalars.as<u32>();
-
     int extra_bits = 0;
     for (int attempt = 0;; ++attempt) {
         Plan pl;
-        if (!make_plan(n_upper, extra_bits, W, &pl))
+        if (!make_plan(cap, extra_bits, W, &pl))
             return fail(ctx, DSKGPU_E_OVERFLOW, "cannot partition finer (table overflow persists)");
+        pl.d1.world = pl.d2.world = ctx->cfg.world_size; pl.d1.npass = pl.d2.npass = npass; pl.d1.pass = pl.d2.pass = pass;
         // ---------------- level 1
         u32 nch1 = 0;
         const u64 max_chunks1 = (u64)ctx->num_cu * 8;
@@ -354,6 +352,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         h_sc[SC_NCH1] = nch1; h_sc[SC_MLEN1] = (u32)M1; h_sc[SC_F] = pl.F;
         CK(hipMemcpyAsync(sc, h_sc, sizeof(ctx->h_sc), hipMemcpyHostToDevice, ctx->stream));
         CK(ctx->mat1.ensure((M1 + 1) * 4));
+        // histogram / distinct counters of THIS pass attempt (a table-overflow retry must not double count)
         CK(hipMemsetAsync(ctx->ghist.p, 0, ((size_t)ctx->cfg.histo_max + 1) * 8, ctx->stream));
         CK(hipMemsetAsync(ctx->gstats.p, 0, 4 * 8, ctx->stream));
         ctx->mark("setup");
@@ -365,6 +364,11 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         ctx->mark("hist1");
         if ((rc = run_scan(ctx, ctx->mat1.as<u32>(), sc + SC_MLEN1, M1))) return rc;
         ctx->mark("scan1");
+        if (npass > 1) {      // the pass must fit the buffers sized for it (skewed inputs can overfill one pass)
+            CK(hipMemcpyAsync(&ctx->h_back[2], ctx->mat1.as<u32>() + M1, 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+            if ((u64)ctx->h_back[2] > cap) { ctx->resolve_marks(); return PASS_TOO_BIG; }
+        }
         if (from_reads) rc = launch_scatter<W, 0>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<Key>(), pl.d1, pl.P1);
         else rc = launch_scatter<W, 1>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<Key>(), pl.d1, pl.P1);
         if (rc) return rc;
@@ -375,7 +379,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         CK(ctx->nsolid.ensure(((size_t)pl.F + 2) * 4));
         // ---------------- level 2
         if (pl.levels == 2) {
-            const u64 max_chunks2 = n_upper / CH2 + pl.P1 + 1;
+            const u64 max_chunks2 = cap / CH2 + pl.P1 + 1;
             const u64 M2 = max_chunks2 * pl.P2;
             if (M2 >= 0xFFFFFFFFull) return fail(ctx, DSKGPU_E_ARG, "level-2 matrix too large");
             CK(ctx->descs2.ensure(max_chunks2 * sizeof(ChunkDesc)));
@@ -432,7 +436,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             ctx->mark("start");
             continue;
         }
-        // ---------------- dense rows + sort
+        // ---------------- dense rows of this pass
         const u64 ns = h_nsolid;
         CK(ctx->out_lo.ensure((ns + 1) * 8));
         CK(ctx->out_ab.ensure((ns + 1) * 4));
@@ -442,33 +446,104 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                            W == 2 ? ctx->out_hi.as<u64>() : (u64*)nullptr, ctx->out_ab.as<u32>());
         CKL("k_compact");
         ctx->mark("compact");
-        if ((rc = sort_rows(ctx, ns))) return rc;
-        ctx->mark("sort");
+        *ns_out = ns; *nk_out = h_nk; *plan_out = pl;
+        return DSKGPU_OK;
+    }
+}
+
+// The pipeline behind dskgpu_count / dskgpu_mg_count: encode once, then one or several passes over
+// the key space (several when the input holds more k-mers than a pass may: < 2^32 offsets, and the
+// ping-pong buffers must fit HBM -- the in-memory counterpart of DSK's disk passes), then the row sort.
+template <int W>
+int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_keys_in, u64 nkeys_in) {
+    typedef typename KeyT<W>::T Key;
+    ctx->have_result = false;
+    if (from_reads) { ctx->st_names.clear(); ctx->st_ms.clear(); }   // from keys: keep the mg_scatter stages of this step
+    ctx->marks.clear(); ctx->ev_used = 0;
+    const u64 n_upper = from_reads ? ctx->n_bytes : nkeys_in;
+    u64 nwords = 0;
+    ctx->mark("start");
+    if (from_reads) {
+        int rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords);
+        if (rc) return rc;
+        ctx->mark("encode");
+    }
+    CK(ctx->scalars.ensure(SC_COUNT * 4));
+    CK(ctx->ghist.ensure(((size_t)ctx->cfg.histo_max + 1) * 8));
+    CK(ctx->gstats.ensure(4 * 8));
+    const u64 max_keys = ctx->max_keys_per_pass ? ctx->max_keys_per_pass : 0xF0000000ull;
+    u32 npass = (u32)std::max<u64>(1, (n_upper + max_keys - 1) / max_keys);
+    for (;; npass *= 2) {
+        if (npass > 4096) return fail(ctx, DSKGPU_E_OVERFLOW, "too many passes (one k-mer alone exceeds a pass)");
+        // buffers of one pass: every position could yield a key when there is a single pass; with
+        // several, the hash spreads keys evenly and 25 % + 1 M head-room is checked after the histogram
+        const u64 cap = npass == 1 ? n_upper : std::min<u64>(n_upper, n_upper / npass + n_upper / npass / 4 + (1u << 20));
+        if (cap >= 0xFFFF0000ull) continue;
+        CK(ctx->bufA.ensure((cap + 1) * sizeof(Key)));
+        CK(ctx->bufB.ensure((cap + 1) * sizeof(Key)));
+        if (W == 2) CK(ctx->abund2.ensure((cap + 1) * 4));
         ctx->hist.assign((size_t)ctx->cfg.histo_max + 1, 0);
-        CK(hipMemcpyAsync(ctx->hist.data(), ctx->ghist.p, ctx->hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<u64> pass_hist(ctx->hist.size());
+        u64 tot_rows = 0, tot_kmers = 0, tot_distinct = 0;
+        Plan pl{};
+        bool too_big = false;
+        for (u32 p = 0; p < npass; ++p) {
+            u64 ns = 0, nk = 0;
+            int rc = run_one_pass<W>(ctx, from_reads, d_keys_in, nkeys_in, nwords, p, npass, cap, &ns, &nk, &pl);
+            if (rc == PASS_TOO_BIG) { too_big = true; break; }
+            if (rc) return rc;
+            tot_kmers += nk; tot_distinct += ctx->h_stats[0];
+            if (npass > 1) {      // append this pass's rows and histogram to the job's
+                CK(hipMemcpyAsync(pass_hist.data(), ctx->ghist.p, pass_hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+                if (ctx->acc_lo.ensure_keep((tot_rows + ns + 1) * 8, tot_rows * 8, ctx->stream)) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
+                if (ctx->acc_ab.ensure_keep((tot_rows + ns + 1) * 4, tot_rows * 4, ctx->stream)) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
+                if (W == 2 && ctx->acc_hi.ensure_keep((tot_rows + ns + 1) * 8, tot_rows * 8, ctx->stream)) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
+                if (ns) {
+                    CK(hipMemcpyAsync(ctx->acc_lo.as<u64>() + tot_rows, ctx->out_lo.p, ns * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                    CK(hipMemcpyAsync(ctx->acc_ab.as<u32>() + tot_rows, ctx->out_ab.p, ns * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                    if (W == 2) CK(hipMemcpyAsync(ctx->acc_hi.as<u64>() + tot_rows, ctx->out_hi.p, ns * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                }
+                CK(hipStreamSynchronize(ctx->stream));
+                for (size_t i = 0; i < pass_hist.size(); ++i) ctx->hist[i] += pass_hist[i];
+                ctx->resolve_marks();
+                ctx->mark("start");
+            }
+            tot_rows += ns;
+        }
+        if (too_big) continue;
+        // ---------------- row sort over all passes
+        if (npass > 1) {      // make the accumulated rows the sort input
+            std::swap(ctx->out_lo, ctx->acc_lo); std::swap(ctx->out_ab, ctx->acc_ab);
+            if (W == 2) std::swap(ctx->out_hi, ctx->acc_hi);
+        }
+        int rc;
+        if ((rc = sort_rows(ctx, tot_rows))) return rc;
+        ctx->mark("sort");
+        if (npass == 1) CK(hipMemcpyAsync(ctx->hist.data(), ctx->ghist.p, ctx->hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
-        if (W == 1 && ctx->sort_partial && ns && ctx->h_back[3]) {
+        if (W == 1 && ctx->sort_partial && tot_rows && ctx->h_back[3]) {
             // a run of equal 40-bit prefixes was too long for the in-place fix-up: sort full width
             // (srt_* holds a permutation of the rows; sort it back into out_*)
             size_t tmp = 0;
             const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
             CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->srt_lo.as<u64>(), ctx->out_lo.as<u64>(), ctx->srt_ab.as<u32>(),
-                                         ctx->out_ab.as<u32>(), (size_t)ns, 0u, end_bit, ctx->stream));
+                                         ctx->out_ab.as<u32>(), (size_t)tot_rows, 0u, end_bit, ctx->stream));
             CK(ctx->srt_tmp.ensure(tmp));
             CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->srt_lo.as<u64>(), ctx->out_lo.as<u64>(), ctx->srt_ab.as<u32>(),
-                                         ctx->out_ab.as<u32>(), (size_t)ns, 0u, end_bit, ctx->stream));
+                                         ctx->out_ab.as<u32>(), (size_t)tot_rows, 0u, end_bit, ctx->stream));
             CK(hipStreamSynchronize(ctx->stream));
             ctx->res_lo = ctx->out_lo.as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>();
             ctx->stats.sort_fallback = 1;
         }
         ctx->resolve_marks();
-        ctx->n_rows = ns;
+        ctx->n_rows = tot_rows;
         ctx->stats.n_bytes = from_reads ? ctx->n_bytes : 0;
-        ctx->stats.n_kmers = h_nk;
-        ctx->stats.n_distinct = ctx->h_stats[0];
-        ctx->stats.n_solid = ns;
+        ctx->stats.n_kmers = tot_kmers;
+        ctx->stats.n_distinct = tot_distinct;
+        ctx->stats.n_solid = tot_rows;
         ctx->stats.n_levels = (u32)pl.levels;
         ctx->stats.n_final_bins = pl.F;
+        ctx->stats.n_passes = npass;
         u32 np = ctx->cfg.nb_partitions ? ctx->cfg.nb_partitions : 4u;
         ctx->stats.n_partitions = np;
         ctx->have_result = true;
@@ -501,7 +576,7 @@ int mg_scatter_impl(dskgpu_ctx* ctx, void* d_send, uint64_t* send_words) {
     u32* sc = ctx->scalars.as<u32>();
     CK(hipMemcpyAsync(sc, h_sc, sizeof(ctx->h_sc), hipMemcpyHostToDevice, ctx->stream));
     CK(ctx->mat1.ensure((M1 + 1) * 4));
-    const DigitSpec owner = DigitSpec{0u, G, 0u};
+    const DigitSpec owner = DigitSpec{0u, G, 0u, G, 1u, 0u};
     if ((rc = launch_hist<W, 0>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), owner, G))) return rc;
     ctx->mark("mg_hist");
     if ((rc = run_scan(ctx, ctx->mat1.as<u32>(), sc + SC_MLEN1, M1))) return rc;
@@ -545,6 +620,7 @@ int dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out) {
     if (ctx->cfg.minimizer_size == 0) ctx->cfg.minimizer_size = 10;
     ctx->W = cfg->kmer_size <= 32 ? 1 : 2;
     ctx->gbits = ceil_log2_u64(ws);
+    ctx->max_keys_per_pass = (u64)cfg->max_pass_mkeys * 1000000ull;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -561,7 +637,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->reads_own, &ctx->packed, &ctx->inval, &ctx->bufA, &ctx->bufB, &ctx->mat1, &ctx->mat2, &ctx->sums,
                       &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats,
                       &ctx->out_lo, &ctx->out_hi, &ctx->out_ab, &ctx->srt_lo, &ctx->srt_hi, &ctx->srt_ab, &ctx->srt_tmp,
-                      &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->abund2};
+                      &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->abund2, &ctx->acc_lo, &ctx->acc_hi, &ctx->acc_ab};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

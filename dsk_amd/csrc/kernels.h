@@ -147,12 +147,23 @@ __device__ __forceinline__ u64 digit_word(const K2& h) { return h.hi; }
 //   owner   : g  = (h[31:12] * G) >> 20                  (multi-GPU owner of the k-mer)
 //   slot    : h[11:0]                                    (home slot of the LDS table)
 // so final sub-partition q = d1 * P2 + d2 and the fields are independent.
-struct DigitSpec { u32 mode, pa, pb; };   // mode 0: owner(pa=G)  1: level1(pa=P1)  2: level2(pa=P1,pb=P2)
+//   pass    : the fraction left over by the owner in h[31:12], mapped onto npass passes: inputs with more
+//             k-mers than one pass may hold (2^32 offsets / the HBM budget) are counted in several
+//             passes over the encoded reads, each keeping only its share of the key space -- the
+//             in-HBM counterpart of DSK's disk passes (doc/paper.tex:65-67, README.md:126-130).
+struct DigitSpec { u32 mode, pa, pb, world, npass, pass; };   // mode 0: owner(pa=G)  1: level1(pa=P1)  2: level2(pa=P1,pb=P2)
 template <int MODE>
 __device__ __forceinline__ u32 key_digit(u64 w, const DigitSpec& ds) {
     if (MODE == 1) return __umulhi((u32)(w >> 32), ds.pa);
     if (MODE == 2) return __umulhi((u32)(w >> 32) * ds.pa, ds.pb);
     return (((u32)(w >> 12) & 0xFFFFFu) * ds.pa) >> 20;
+}
+// does this key belong to the pass being counted?  (level-1 kernels only; wave-uniform test on npass)
+template <int MODE>
+__device__ __forceinline__ bool key_in_pass(u64 w, const DigitSpec& ds) {
+    if (MODE != 1 || ds.npass <= 1) return true;
+    const u32 frac = (((u32)(w >> 12) & 0xFFFFFu) * ds.world) & 0xFFFFFu;
+    return ((frac * ds.npass) >> 20) == ds.pass;
 }
 
 template <int W>
@@ -222,7 +233,8 @@ __global__ __launch_bounds__(SC_NT) void k_hist(const u64* __restrict__ packed, 
         auto process = [&](typename KeyT<W>::T (&h)[KPT], u32 vm) {
             u32 dg[KPT];
 #pragma unroll
-            for (int j = 0; j < KPT; ++j) dg[j] = (vm & (1u << j)) ? key_digit<MODE>(digit_word(h[j]), ds) : P;
+            for (int j = 0; j < KPT; ++j)
+                dg[j] = ((vm & (1u << j)) && key_in_pass<MODE>(digit_word(h[j]), ds)) ? key_digit<MODE>(digit_word(h[j]), ds) : P;
 #pragma unroll
             for (int j = 0; j < KPT; ++j) atomicAdd(&lh[dg[j]], 1u);
         };
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
             u32 rk[KPT];
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
-                const u32 dj = (vm & (1u << j)) ? key_digit<MODE>(digit_word(h[j]), ds) : P;
+                const u32 dj = ((vm & (1u << j)) && key_in_pass<MODE>(digit_word(h[j]), ds)) ? key_digit<MODE>(digit_word(h[j]), ds) : P;
                 rk[j] = dj << 16;                                    // (digit, rank) packed: rank < 8192, digit <= 2048
             }
             if (!(dbg & 64u)) {

@@ -34,7 +34,8 @@ class _Config(C.Structure):
         ("flags", C.c_uint32),
         ("world_size", C.c_uint32),
         ("rank", C.c_uint32),
-        ("reserved", C.c_uint32 * 6),
+        ("max_pass_mkeys", C.c_uint32),
+        ("reserved", C.c_uint32 * 5),
     ]
 
 
@@ -49,7 +50,8 @@ class _Stats(C.Structure):
         ("n_final_bins", C.c_uint32),
         ("n_retries", C.c_uint32),
         ("sort_fallback", C.c_uint64),
-        ("reserved", C.c_uint64 * 3),
+        ("n_passes", C.c_uint64),
+        ("reserved", C.c_uint64 * 2),
     ]
 
 
@@ -126,7 +128,7 @@ class KmerCounter:
     def __init__(self, kmer_size: int = 31, abundance_min: int = 2, abundance_max: int = 2147483647,
                  histo_max: int = 10000, device: int = 0, nb_partitions: int = 0, timing: bool = False,
                  sort: bool = True, world_size: int = 1, rank: int = 0, stream: Optional[int] = None,
-                 minimizer_size: int = 0):
+                 minimizer_size: int = 0, max_pass_mkeys: int = 0):
         self._lib = load_library()
         cfg = _Config()
         cfg.kmer_size = kmer_size
@@ -136,6 +138,7 @@ class KmerCounter:
         cfg.device = device
         cfg.nb_partitions = nb_partitions
         cfg.minimizer_size = minimizer_size
+        cfg.max_pass_mkeys = max_pass_mkeys
         cfg.flags = (F_TIMING if timing else 0) | (0 if sort else F_NO_SORT)
         cfg.world_size = world_size
         cfg.rank = rank

@@ -54,7 +54,10 @@ typedef struct dskgpu_config {
     uint32_t flags;           /* DSKGPU_F_* */
     uint32_t world_size;      /* number of GPUs sharing the k-mer space (1 = single) */
     uint32_t rank;            /* this GPU's index in [0, world_size)           */
-    uint32_t reserved[6];
+    uint32_t max_pass_mkeys;  /* most k-mers (in millions) one pass may hold; 0 = 4026 (32-bit offsets).
+                                 Larger inputs are counted in several passes over the key space, the
+                                 in-HBM counterpart of DSK's disk passes (README.md:126-130) */
+    uint32_t reserved[5];
 } dskgpu_config;
 
 #define DSKGPU_F_TIMING 1u        /* record per-stage HIP-event timings        */
@@ -105,7 +108,8 @@ typedef struct dskgpu_stats {
     uint32_t n_final_bins;   /* hash-aggregate sub-partitions            */
     uint32_t n_retries;      /* table-overflow retries                   */
     uint64_t sort_fallback;  /* 1 if the row sort needed its full-width fallback */
-    uint64_t reserved[3];
+    uint64_t n_passes;       /* passes over the key space (1 unless the input exceeds a pass) */
+    uint64_t reserved[2];
 } dskgpu_stats;
 int dskgpu_get_stats(const dskgpu_ctx* ctx, dskgpu_stats* out);
 

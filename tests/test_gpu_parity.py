@@ -331,3 +331,33 @@ def test_row_sort_fallback_on_shared_prefixes(oracle, dev):
     s = np.frombuffer(b"\n".join(recs) + b"\n" + noise + b"\n", dtype=np.uint8)
     st = check_against_oracle(oracle, s, 31, dev, amin=1)
     assert st["sort_fallback"] == 0
+
+
+@pytest.mark.parametrize("k,mkeys,n_reads", [(31, 2, 100_000), (27, 1, 60_000), (63, 1, 60_000)])
+def test_multi_pass_over_key_space(oracle, dev, k, mkeys, n_reads):
+    """Inputs with more k-mers than one pass may hold are counted in several passes over the key
+    space (BASELINE.json configs[4] "multi-pass HBM partitioning"); forced here with a tiny pass size."""
+    from dsk_amd import synth
+    g = synth.make_genome(300_000, dev)
+    reads = synth.make_reads(g, n_reads, 150).cpu().numpy()
+    st = check_against_oracle(oracle, reads, k, dev, max_pass_mkeys=mkeys)
+    assert st["n_passes"] >= len(reads) // (mkeys * 1_000_000)
+    assert st["n_passes"] > 1
+    st1 = check_against_oracle(oracle, reads, k, dev)
+    assert st1["n_passes"] == 1
+
+
+def test_multi_pass_skew_doubles_passes(oracle, dev):
+    # 600k copies of one k-mer land in ONE pass whatever the pass count: the pass-capacity check must
+    # grow the pass count until that pass fits (or fail loudly), never write out of bounds
+    from dsk_amd import synth, KmerCounter, DskGpuError
+    g = synth.make_genome(200_000, dev)
+    noise = synth.make_reads(g, 40_000, 150).cpu().numpy()
+    s = np.concatenate([np.full(600_000, 65, np.uint8), np.array([10], np.uint8), noise]).astype(np.uint8)
+    st = check_against_oracle(oracle, s, 31, dev, amin=1, max_pass_mkeys=2)      # 6.6 M positions / 2 M per pass
+    assert st["n_passes"] >= 4
+    t = torch.from_numpy(np.full(3_000_000, 65, np.uint8)).to(dev)             # one k-mer x 3 M can never fit a 1 M pass
+    with KmerCounter(kmer_size=31, max_pass_mkeys=1) as kc:
+        kc.set_reads_device(t.data_ptr(), t.numel())
+        with pytest.raises(DskGpuError):
+            kc.count()
