@@ -200,3 +200,9 @@ def test_parallel_parser_equals_serial(bins, tmp_path):
             subprocess.check_call([bins["dsk2ascii"], "-file", f"o{cores}", "-out", f"o{cores}.txt", "-verbose", "0"], cwd=tmp)
             md5.append(hashlib.md5(open(os.path.join(tmp, f"o{cores}.txt"), "rb").read()).hexdigest())
         assert md5[0] == md5[1], fn
+
+
+def test_kmer_model_unit(bins):
+    """C++ unit test of host/kmer.hpp (Kmer<span>::ModelCanonical, Integer::apply) against the oracle."""
+    out = subprocess.run([os.path.join(ROOT, "tests", "host", "test_kmer")], stdout=subprocess.PIPE).stdout.decode()
+    assert "ALL OK" in out, out
