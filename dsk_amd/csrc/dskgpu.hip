@@ -56,7 +56,6 @@ struct Stage { const char* name; hipEvent_t ev; };
 struct dskgpu_ctx {
     dskgpu_config cfg{};
     int W = 1;
-    int gbits = 0;                 // log2(world_size): owner digit
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 256;
@@ -127,7 +126,6 @@ namespace {
 
 int fail(dskgpu_ctx* ctx, int code, const std::string& msg) { ctx->err = msg; return code; }
 
-inline int ceil_log2_u64(u64 x) { int b = 0; while ((1ull << b) < x) ++b; return b; }
 
 // ---- K1 launcher
 int run_encode(dskgpu_ctx* ctx, const uint8_t* d_bytes, u64 n, u64* nwords_out) {
@@ -168,8 +166,7 @@ size_t scatter_lds(int W, u32 P) { return (size_t)(W == 1 ? Tile<1>::KEYS * 8 : 
 template <int W, int SRC, int MODE>
 int launch_hist_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
                   u64 max_chunks, u32* matrix, DigitSpec ds, u32 P) {
-    static int hmul = getenv("DSKGPU_HMUL") ? atoi(getenv("DSKGPU_HMUL")) : 0;
-    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * (hmul ? hmul : 2)));
+    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * 2));
     hipLaunchKernelGGL((k_hist<W, SRC, MODE>), dim3(grid), dim3(SC_NT), 0, ctx->stream, ctx->packed.as<u64>(),
                        ctx->inval.as<u32>(), keys, descs, d_nch, matrix, (int)ctx->cfg.kmer_size, ds, P);
     CKL("k_hist");
@@ -235,8 +232,6 @@ bool make_plan(u64 n_upper, int extra_bits, int W, Plan* pl) {
         u64 p2 = (F + p1 - 1) / p1;
         if (p1 > MAX_LEVEL_BINS || p2 > MAX_LEVEL_BINS) return false;
         pl->levels = 2; pl->P1 = (u32)p1; pl->P2 = (u32)p2;
-        if (const char* e = getenv("DSKGPU_P2")) pl->P2 = (u32)atoi(e);   // experiment: timing of the scatter vs run length (results invalid)
-        if (const char* e = getenv("DSKGPU_P1")) pl->P1 = (u32)atoi(e);
     }
     pl->F = pl->P1 * pl->P2;
     pl->d1 = DigitSpec{1u, pl->P1, 0u, 1u, 1u, 0u};
@@ -619,7 +614,6 @@ int dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out) {
     if (ctx->cfg.abundance_max == 0) ctx->cfg.abundance_max = 0x7FFFFFFFu;
     if (ctx->cfg.minimizer_size == 0) ctx->cfg.minimizer_size = 10;
     ctx->W = cfg->kmer_size <= 32 ? 1 : 2;
-    ctx->gbits = ceil_log2_u64(ws);
     ctx->max_keys_per_pass = (u64)cfg->max_pass_mkeys * 1000000ull;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;

@@ -94,42 +94,6 @@ __global__ __launch_bounds__(256) void k_encode(const uint8_t* __restrict__ s, u
     }
 }
 
-// ------------------------------------------------------------------ block scan helper
-// Exclusive scan of cnt[0..P) (LDS) into off[0..P); returns the total in *tot.
-template <int NT>
-__device__ __forceinline__ void block_excl_scan(const u32* cnt, u32* off, int P, u32* wsum, u32* tot) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ipt = (P + NT - 1) / NT;
-    const int base = tid * ipt;
-    u32 v[4]; u32 s = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int idx = base + j;
-        v[j] = (j < ipt && idx < P) ? cnt[idx] : 0u;
-        s += v[j];
-    }
-    u32 inc = s;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    if (wave == 0) {
-        const u32 x = lane < NT / 64 ? wsum[lane] : 0u;
-        u32 y = x;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(y, d); if (lane >= d) y += t; }
-        if (lane < NT / 64) wsum[lane] = y - x;
-        if (lane == NT / 64 - 1) *tot = y;
-    }
-    __syncthreads();
-    u32 run = wsum[wave] + inc - s;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int idx = base + j;
-        if (j < ipt && idx < P) { off[idx] = run; run += v[j]; }
-    }
-}
-
 // ------------------------------------------------------------------ key sources
 // READS: chunk range is in packed words; a tile is Tile<W>::WORDS words; each
 // thread generates Tile<W>::KPT consecutive window end positions of one word.

@@ -17,7 +17,10 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-#define DSK_EMPTY 0xFFFFFFFFFFFFFFFFull   // never a canonical k-mer (G..G > C..C)
+// Empty-slot sentinel of the one-word LDS table.  Tables hold MIXED keys, so what matters is the
+// pre-image kunmix(~0) = 0x89a5850e63c5f8aa: it has bit 63 set (not a k-mer for k <= 31) and as a
+// 32-mer it is larger than its reverse complement, i.e. never canonical -- no real key collides.
+#define DSK_EMPTY 0xFFFFFFFFFFFFFFFFull
 
 // ---------------------------------------------------------------- hashing
 // Bijective 64-bit mixer (murmur3 finalizer).  Partition arrays hold
@@ -87,9 +90,6 @@ __device__ __forceinline__ u32 gen_kmers1(const u64* __restrict__ packed, const 
 
 // ---------------------------------------------------------------- two-word k-mers (33 <= k <= 64)
 struct K2 { u64 hi, lo; };
-__device__ __forceinline__ bool k2_less(const K2& a, const K2& b) {
-    return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo);
-}
 
 // Windows ending at bases 32*wi + t0 + j, j < NP.  Needs packed[wi-2..wi].
 template <int NP>

@@ -114,10 +114,8 @@ def load_library():
     lib.dskgpu_k_encode.argtypes = [vp, vp, u64, vp, vp]
     lib.dskgpu_k_enumerate.argtypes = [vp, vp, u64, vp, vp]
     lib.dskgpu_k_minimizers.argtypes = [vp, vp, u64, vp, vp]
-    for name in EXPORTS:
-        fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("dskgpu_stage_times",):
-            pass
+    for name in EXPORTS:          # every declared symbol must resolve (fails loudly on a stale build)
+        getattr(lib, name)
     _lib = lib
     return lib
 
