@@ -176,10 +176,13 @@ int launch_hist_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkD
 template <int W, int SRC>
 int launch_hist(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
                 u64 max_chunks, u32* matrix, DigitSpec ds, u32 P) {
+    const bool mp = ds.mode == 1 && ds.npass > 1;     // level 1 of a multi-pass count: instantiation with the pass filter
     if (SRC == 0) return ds.mode == 0 ? launch_hist_m<W, 0, 0>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P)
-                                      : launch_hist_m<W, 0, 1>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P);
-    return ds.mode == 1 ? launch_hist_m<W, 1, 1>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P)
-                        : launch_hist_m<W, 1, 2>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P);
+                       : mp ? launch_hist_m<W, 0, 3>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P)
+                            : launch_hist_m<W, 0, 1>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P);
+    return ds.mode == 2 ? launch_hist_m<W, 1, 2>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P)
+                   : mp ? launch_hist_m<W, 1, 3>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P)
+                        : launch_hist_m<W, 1, 1>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P);
 }
 
 template <int W, int SRC, int MODE>
@@ -199,13 +202,37 @@ int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chu
     CKL("k_scatter");
     return DSKGPU_OK;
 }
+// key-array source with aligned write-out (k_scatter_al) when its LDS footprint fits one CU
+template <int W, int MODE>
+int launch_scatter_al(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
+                      u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P) {
+    const size_t lds = ascatter_lds(W, P);
+    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu));
+    static bool attr_set = false;
+    if (!attr_set) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_al<W, MODE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_scatter_al<W, MODE>), dim3(grid), dim3(SC_NT), lds, ctx->stream, keys, descs, d_nch, scanned, out, ds, P, dbg_flags(1));
+    CKL("k_scatter_al");
+    return DSKGPU_OK;
+}
+
 template <int W, int SRC>
 int launch_scatter(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
                    u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P) {
+    const bool mp = ds.mode == 1 && ds.npass > 1;
+    if (SRC == 1 && ascatter_lds(W, P) <= 160 * 1024 && !getenv("DSKGPU_NO_ALIGNED"))
+        return ds.mode == 2 ? launch_scatter_al<W, 2>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P)
+                       : mp ? launch_scatter_al<W, 3>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P)
+                            : launch_scatter_al<W, 1>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P);
     if (SRC == 0) return ds.mode == 0 ? launch_scatter_m<W, 0, 0>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P)
-                                      : launch_scatter_m<W, 0, 1>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P);
-    return ds.mode == 1 ? launch_scatter_m<W, 1, 1>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P)
-                        : launch_scatter_m<W, 1, 2>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P);
+                       : mp ? launch_scatter_m<W, 0, 3>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P)
+                            : launch_scatter_m<W, 0, 1>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P);
+    return ds.mode == 2 ? launch_scatter_m<W, 1, 2>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P)
+                   : mp ? launch_scatter_m<W, 1, 3>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P)
+                        : launch_scatter_m<W, 1, 1>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P);
 }
 
 struct Plan {
