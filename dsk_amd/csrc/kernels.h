@@ -460,17 +460,17 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
 //   rn[b]   keys of bin b waiting in carry[b][0..rn)          (next key goes to pos + rn)
 // per tile and bin: t = rn + c new keys; everything below the last group boundary is emitted:
 //   bound = (pos + t) & ~(G-1);  e = bound > pos ? bound - pos : 0;  rn' = t - e;  pos' = pos + e
-// 16-bit per-bin state keeps LDS within 160 KB: 96 KB stage + P*(G-1) keys of carry + 16 B per bin.
+// Write-out is bin-centric: a lane group of G lanes owns a bin for the tile, writes its complete
+// groups and then refreshes its carry, so no barrier separates the two.
 template <int W> struct ATile {
     static constexpr int G = 8 / W;              // keys per 64-byte group
     static constexpr int CARRY = G - 1;
     static constexpr int KPT = 12 / W;           // 12288 one-word / 6144 two-word keys per tile = 96 KB
     static constexpr int KEYS = SC_NT * KPT;
-    static constexpr int MAXG = KEYS / G;        // groups a tile can emit, + 1 partial group per bin
 };
 __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
     const size_t key = W == 1 ? 8 : 16, keys = W == 1 ? ATile<1>::KEYS : ATile<2>::KEYS, G = W == 1 ? ATile<1>::G : ATile<2>::G;
-    return keys * key + (size_t)P * (G - 1) * key + (size_t)(P + 1) * 4 + (size_t)P * 4 + (size_t)P * 12 + (size_t)P * 2 + (keys / G + P + 2) * 2 + 20 * 4 + 32;
+    return keys * key + (size_t)P * (G - 1) * key + (size_t)(P + 1) * 4 + (size_t)P * 4 + (size_t)P * 12 + (size_t)P * 2 + 20 * 4 + 32;
 }
 
 template <int W, int MODE>
@@ -487,14 +487,13 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
     Key* carry = stage + TKEYS;                                       // [P][CARRY]
     u32* cnt = reinterpret_cast<u32*>(carry + (size_t)P * CARRY);     // P + 1 (dummy bin P)
     u32* pos = cnt + (P + 1);                                         // P   (persistent across tiles)
-    // per-bin record of the current tile, read with one LDS access by the write-out / carry update:
-    //   x = pos before this tile   y = emitted (lo16) | carry fill before (hi16)   z = tile offset (lo16) | first gtab entry (hi16)
+    // per-bin record of the current tile, read with one LDS access by the write-out:
+    //   x = pos before this tile   y = emitted (lo16) | carry fill before (hi16)   z = offset of the bin in the staged tile
     uint3* rec = reinterpret_cast<uint3*>(pos + P);                   // P
     u16* rn = reinterpret_cast<u16*>(rec + P);                        // P   carry fill after this tile (persistent)
-    u16* gtab = rn + P;                                               // MAXG + P: bin of every emitted group
-    u32* wsum = reinterpret_cast<u32*>(smem + ((reinterpret_cast<char*>(gtab + (ATile<W>::MAXG + P + 2)) - smem + 3) & ~size_t(3)));
-    u32* tot = wsum + 16;                                             // [0] keys staged, [1] groups emitted
+    u32* wsum = reinterpret_cast<u32*>(smem + ((reinterpret_cast<char*>(rn + P) - smem + 3) & ~size_t(3)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 gi = tid / G, gl = tid % G;
     const u32 nchunks = *d_nchunks;
     const int ipt = (int)((P + SC_NT - 1) / SC_NT);
     for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
@@ -503,19 +502,19 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
         for (u32 b = tid; b < P; b += SC_NT) { pos[b] = scanned[d.flat_base + (u64)b * d.stride]; cnt[b] = 0; rn[b] = 0; }
         if (tid == 0) cnt[P] = 0;
         Key h[KPT]; u32 vm = 0;       // one register set: the next tile is loaded as soon as the stage writes have consumed this one
-        auto load = [&](u64 k0, Key (&h)[KPT]) -> u32 {
+        auto load = [&](u64 k0, Key (&hh)[KPT]) -> u32 {
             const Key* base = keys + k0;
             const u64 left = d.end - k0;
             const u32 n = left < (u64)TKEYS ? (u32)left : (u32)TKEYS;
-            u32 vm = 0;
+            u32 m = 0;
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const u32 o = tid + (u32)j * SC_NT;
                 const bool ok = o < n;
-                h[j] = base[ok ? o : n - 1];
-                vm |= (ok ? 1u : 0u) << j;
+                hh[j] = base[ok ? o : n - 1];
+                m |= (ok ? 1u : 0u) << j;
             }
-            return vm;
+            return m;
         };
         auto process = [&](u64 tnext) {
             u32 rk[KPT];
@@ -527,26 +526,24 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
 #pragma unroll
             for (int j = 0; j < KPT; ++j) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
             lds_barrier();
-            // ---- fused scan of (keys, groups) per bin + carry bookkeeping + group table
+            // ---- scan of the tile histogram fused with the carry bookkeeping
             {
                 const int base = tid * ipt;
-                u32 c[4], ng[4], pe[4], er[4], s = 0;
+                u32 c[4], pe[4], er[4], s = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int b = base + j;
-                    c[j] = 0; ng[j] = 0; pe[j] = 0; er[j] = 0;
+                    c[j] = 0; pe[j] = 0; er[j] = 0;
                     if (j < ipt && b < (int)P) {
                         c[j] = cnt[b];
                         const u32 r = rn[b], p = pos[b];
-                        const u32 end = p + r + c[j];
-                        const u32 bound = end & ~(u32)(G - 1);
+                        const u32 bound = (p + r + c[j]) & ~(u32)(G - 1);
                         const u32 e = bound > p ? bound - p : 0u;
-                        ng[j] = e ? (bound - (p & ~(u32)(G - 1))) / G : 0u;
                         pe[j] = p; er[j] = e | (r << 16);
                         rn[b] = (u16)(r + c[j] - e);
                         pos[b] = p + e; cnt[b] = 0;
                     }
-                    s += c[j] | (ng[j] << 16);
+                    s += c[j];
                 }
                 u32 inc = s;
 #pragma unroll
@@ -559,63 +556,49 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
 #pragma unroll
                     for (int dd = 1; dd < SC_NT / 64; dd <<= 1) { const u32 t = __shfl_up(y, dd); if (lane >= dd) y += t; }
                     if (lane < SC_NT / 64) wsum[lane] = y - x;
-                    if (lane == SC_NT / 64 - 1) { tot[0] = y & 0xFFFFu; tot[1] = y >> 16; }
                 }
                 lds_barrier();
                 u32 run = wsum[wave] + inc - s;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int b = base + j;
-                    if (j < ipt && b < (int)P) {
-                        const u32 l0 = run >> 16;
-                        rec[b] = make_uint3(pe[j], er[j], (run & 0xFFFFu) | (l0 << 16));
-                        for (u32 q = 0; q < ng[j]; ++q) gtab[l0 + q] = (u16)b;
-                        run += c[j] | (ng[j] << 16);
-                    }
+                    if (j < ipt && b < (int)P) { rec[b] = make_uint3(pe[j], er[j], run); run += c[j]; }
                 }
             }
             lds_barrier();
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const u32 dj = rk[j] >> 16;
-                if (dj < P) stage[(rec[dj].z & 0xFFFFu) + (rk[j] & 0xFFFFu)] = h[j];
+                if (dj < P) stage[rec[dj].z + (rk[j] & 0xFFFFu)] = h[j];
             }
-            if (tnext < d.end) vm = load(tnext, h);       // HBM reads of the next tile fly under the write-out + carry phases
+            if (tnext < d.end) vm = load(tnext, h);       // HBM reads of the next tile fly under the write-out phase
             lds_barrier();
-            // ---- write-out: one lane group per aligned group of G keys
-            if (!(dbg & 4u)) {
-                const u32 ngr = tot[1];
-                const u32 gi = tid / G, gl = tid % G;
-                for (u32 L0 = 0; L0 < ngr; L0 += 2 * NGRP) {
-                    Key kv[2]; u32 a[2]; bool ok[2];
+            // ---- write-out + carry refresh, one lane group per bin
+            if (!(dbg & 4u))
+            for (u32 b0 = 0; b0 < P; b0 += 2 * NGRP) {
+                uint3 rb[2]; u32 rnew[2]; bool act[2];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const u32 L = L0 + u * NGRP + gi;
-                        ok[u] = false; a[u] = 0;
-                        if (L < ngr) {
-                            const u32 b = gtab[L];
-                            const uint3 rb = rec[b];
-                            const u32 pold = rb.x, e = rb.y & 0xFFFFu, r = rb.y >> 16;
-                            a[u] = (pold & ~(u32)(G - 1)) + (L - (rb.z >> 16)) * G + gl;
-                            ok[u] = a[u] >= pold && a[u] < pold + e;
-                            const u32 idx = a[u] - pold;
-                            if (ok[u]) kv[u] = idx < r ? carry[(size_t)b * CARRY + idx] : stage[(rb.z & 0xFFFFu) + idx - r];
+                for (int u = 0; u < 2; ++u) {
+                    const u32 b = b0 + u * NGRP + gi;
+                    act[u] = b < P;
+                    rb[u] = rec[act[u] ? b : 0]; rnew[u] = rn[act[u] ? b : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (!act[u]) continue;
+                    const u32 b = b0 + u * NGRP + gi;
+                    const u32 pold = rb[u].x, e = rb[u].y & 0xFFFFu, r = rb[u].y >> 16, o = rb[u].z;
+                    Key* cb = carry + (size_t)b * CARRY;
+                    for (u32 a = (pold & ~(u32)(G - 1)) + gl; a < pold + e; a += G) {      // complete groups of this bin
+                        if (a >= pold) {
+                            const u32 idx = a - pold;
+                            const Key kv = idx < r ? cb[idx] : stage[o + idx - r];
+                            if (!(dbg & 1u)) out[a] = kv;
                         }
                     }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) if (ok[u] && !(dbg & 1u)) out[a[u]] = kv[u];
-                }
-            }
-            lds_barrier();
-            // ---- carry update: the keys that stay behind (G lanes per bin)
-            if (!(dbg & 2u)) {
-                const u32 gi = tid / G, gl = tid % G;
-                for (u32 b = gi; b < P; b += NGRP) {
-                    const uint3 rb = rec[b];
-                    const u32 e = rb.y & 0xFFFFu, r = rb.y >> 16, rnew = rn[b], o = rb.z & 0xFFFFu;
-                    const u32 c = rnew + e - r;                         // keys this tile gave the bin
-                    if (e) { if (gl < rnew) carry[(size_t)b * CARRY + gl] = stage[o + c - rnew + gl]; }
-                    else if (gl < c) carry[(size_t)b * CARRY + r + gl] = stage[o + gl];
+                    const u32 c = rnew[u] + e - r;                        // keys this tile gave the bin
+                    if (e) { if (gl < rnew[u]) cb[gl] = stage[o + c - rnew[u] + gl]; }
+                    else if (gl < c) cb[r + gl] = stage[o + gl];
                 }
             }
             // no barrier: the next tile's rank phase only touches cnt; its barriers order the rest
@@ -625,12 +608,9 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
         for (u64 t0 = d.begin; t0 < d.end; t0 += (u64)TKEYS) process(t0 + TKEYS);
         // ---- end of chunk: flush what is left in the carries (one partial group per bin)
         lds_barrier();
-        {
-            const u32 gi = tid / G, gl = tid % G;
-            for (u32 b = gi; b < P; b += NGRP) {
-                const u32 r = rn[b];
-                if (gl < r) out[pos[b] + gl] = carry[(size_t)b * CARRY + gl];
-            }
+        for (u32 b = gi; b < P; b += NGRP) {
+            const u32 r = rn[b];
+            if (gl < r) out[pos[b] + gl] = carry[(size_t)b * CARRY + gl];
         }
     }
 }
