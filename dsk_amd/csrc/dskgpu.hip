@@ -70,6 +70,10 @@ struct dskgpu_ctx {
     DevBuf mat1, mat2, sums, descs1, descs2, seg, fstart, nsolid, scalars, ghist, gstats;
     DevBuf out_lo, out_hi, out_ab, srt_lo, srt_hi, srt_ab, srt_tmp, srt_idx, srt_idx2, srt_k, abund2, acc_lo, acc_hi, acc_ab;
     u64 max_keys_per_pass = 0;     // 0 = as many as 32-bit offsets allow
+    // multi-bank mode (solidity kinds, 2-D histogram)
+    std::vector<u64> bank_ends;    // end offset of every declared bank in the read stream
+    DevBuf u_lo, u_hi, u_val, s_lo, s_hi, s_val, m_flag, m_pos, m_sum, gh2d;
+    std::vector<u64> hist2d;
     std::vector<u32> h_starts;
     u32 h_back[4] = {0}; u64 h_stats[4] = {0};   // host landing zone of the async size read-back
     std::vector<ChunkDesc> h_descs1;
@@ -615,6 +619,113 @@ int mg_scatter_impl(dskgpu_ctx* ctx, void* d_send, uint64_t* send_words) {
 
 }  // namespace
 
+namespace {
+
+// Multi-bank count: every bank is counted on its own (all distinct k-mers kept), the per-bank rows are
+// united and sorted by k-mer, and k_merge_banks applies the solidity kind / builds the histograms.
+template <int W>
+int run_banks(dskgpu_ctx* ctx) {
+    std::vector<u64> ends = ctx->bank_ends;
+    if (ends.empty() || ends.back() < ctx->n_bytes) ends.push_back(ctx->n_bytes);
+    const u32 B = (u32)ends.size();
+    if (B > 32) return fail(ctx, DSKGPU_E_ARG, "at most 32 banks are supported by the solidity kinds");
+    const dskgpu_config saved = ctx->cfg;
+    const uint8_t* base = ctx->d_reads; const u64 total = ctx->n_bytes;
+    ctx->cfg.abundance_min = 1; ctx->cfg.abundance_max = 0xFFFFFFFFu; ctx->cfg.flags |= DSKGPU_F_NO_SORT;
+    u64 nu = 0, tot_kmers = 0; u32 passes = 1, retries = 0;
+    int rc = DSKGPU_OK;
+    for (u32 b = 0; b < B && rc == DSKGPU_OK; ++b) {
+        const u64 beg = b ? ends[b - 1] : 0;
+        ctx->d_reads = base + beg; ctx->n_bytes = ends[b] - beg;
+        rc = run_pipeline<W>(ctx, true, nullptr, 0);
+        if (rc) break;
+        const u64 n = ctx->n_rows;
+        tot_kmers += ctx->stats.n_kmers; passes = std::max<u32>(passes, (u32)ctx->stats.n_passes); retries += ctx->stats.n_retries;
+        if (ctx->u_lo.ensure_keep((nu + n + 1) * 8, nu * 8, ctx->stream) || ctx->u_val.ensure_keep((nu + n + 1) * 8, nu * 8, ctx->stream) ||
+            (W == 2 && ctx->u_hi.ensure_keep((nu + n + 1) * 8, nu * 8, ctx->stream))) { rc = fail(ctx, DSKGPU_E_NOMEM, "bank rows"); break; }
+        if (n) {
+            CK(hipMemcpyAsync(ctx->u_lo.as<u64>() + nu, ctx->res_lo, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            if (W == 2) CK(hipMemcpyAsync(ctx->u_hi.as<u64>() + nu, ctx->res_hi, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_pack_bank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->u_val.as<u64>() + nu, ctx->res_ab, n, b);
+            CK(hipStreamSynchronize(ctx->stream));
+        }
+        nu += n;
+    }
+    ctx->cfg = saved; ctx->d_reads = base; ctx->n_bytes = total;
+    if (rc) return rc;
+    ctx->have_result = false;
+    if (nu >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "too many distinct k-mers over the banks for the merge");
+    // ---- sort the union by k-mer
+    CK(ctx->s_lo.ensure((nu + 1) * 8)); CK(ctx->s_val.ensure((nu + 1) * 8));
+    const unsigned gb = (unsigned)std::max<u64>(1, (nu + 255) / 256);
+    if (nu) {
+        size_t tmp = 0, tmp2 = 0;
+        if (W == 1) {
+            const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
+            CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->u_lo.as<u64>(), ctx->s_lo.as<u64>(), ctx->u_val.as<u64>(), ctx->s_val.as<u64>(), (size_t)nu, 0u, end_bit, ctx->stream));
+            CK(ctx->srt_tmp.ensure(tmp));
+            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->u_lo.as<u64>(), ctx->s_lo.as<u64>(), ctx->u_val.as<u64>(), ctx->s_val.as<u64>(), (size_t)nu, 0u, end_bit, ctx->stream));
+        } else {
+            CK(ctx->s_hi.ensure((nu + 1) * 8)); CK(ctx->srt_k.ensure((nu + 1) * 8));
+            CK(ctx->srt_idx.ensure((nu + 1) * 4)); CK(ctx->srt_idx2.ensure((nu + 1) * 4));
+            u32* idx = ctx->srt_idx.as<u32>(); u32* idx2 = ctx->srt_idx2.as<u32>();
+            const unsigned hi_bits = std::max(1u, 2u * ctx->cfg.kmer_size - 64u);
+            hipLaunchKernelGGL(k_iota, dim3(gb), dim3(256), 0, ctx->stream, idx, nu);
+            CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->u_lo.as<u64>(), ctx->srt_k.as<u64>(), idx, idx2, (size_t)nu, 0u, 64u, ctx->stream));
+            CK(rocprim::radix_sort_pairs(nullptr, tmp2, ctx->srt_k.as<u64>(), ctx->s_hi.as<u64>(), idx2, idx, (size_t)nu, 0u, hi_bits, ctx->stream));
+            CK(ctx->srt_tmp.ensure(std::max(tmp, tmp2)));
+            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->u_lo.as<u64>(), ctx->srt_k.as<u64>(), idx, idx2, (size_t)nu, 0u, 64u, ctx->stream));
+            hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_k.as<u64>(), ctx->u_hi.as<u64>(), idx2, nu);
+            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp2, ctx->srt_k.as<u64>(), ctx->s_hi.as<u64>(), idx2, idx, (size_t)nu, 0u, hi_bits, ctx->stream));
+            hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->s_lo.as<u64>(), ctx->u_lo.as<u64>(), idx, nu);
+            hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->s_val.as<u64>(), ctx->u_val.as<u64>(), idx, nu);
+        }
+        CKL("bank sort");
+    }
+    // ---- merge: solidity + histograms
+    const size_t nh = (size_t)ctx->cfg.histo_max + 1;
+    CK(ctx->m_flag.ensure((nu + 2) * 4)); CK(ctx->m_pos.ensure((nu + 2) * 4)); CK(ctx->m_sum.ensure((nu + 2) * 4));
+    CK(ctx->gh2d.ensure(nh * 11 * 8));
+    CK(hipMemsetAsync(ctx->ghist.p, 0, nh * 8, ctx->stream));
+    CK(hipMemsetAsync(ctx->gh2d.p, 0, nh * 11 * 8, ctx->stream));
+    CK(hipMemsetAsync(ctx->gstats.p, 0, 32, ctx->stream));
+    MergeParams mp{B, ctx->cfg.solidity_kind, ctx->cfg.solidity_custom, ctx->cfg.abundance_min, ctx->cfg.abundance_max, ctx->cfg.histo_max,
+                   (ctx->cfg.flags & DSKGPU_F_HISTO2D) ? 1u : 0u};
+    u64 n_solid = 0;
+    if (nu) {
+        hipLaunchKernelGGL(k_merge_banks<W>, dim3(gb), dim3(256), 0, ctx->stream, ctx->s_lo.as<u64>(), W == 2 ? ctx->s_hi.as<u64>() : (const u64*)nullptr,
+                           ctx->s_val.as<u64>(), nu, mp, ctx->m_flag.as<u32>(), ctx->m_sum.as<u32>(), ctx->ghist.as<u64>(), ctx->gh2d.as<u64>(), ctx->gstats.as<u64>());
+        hipLaunchKernelGGL(k_copy_u32, dim3(gb), dim3(256), 0, ctx->stream, ctx->m_pos.as<u32>(), ctx->m_flag.as<u32>(), nu);
+        CKL("k_merge_banks");
+        ctx->h_sc[SC_F] = (u32)nu;
+        CK(hipMemcpyAsync(ctx->scalars.as<u32>() + SC_F, &ctx->h_sc[SC_F], 4, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = run_scan(ctx, ctx->m_pos.as<u32>(), ctx->scalars.as<u32>() + SC_F, nu))) return rc;
+        CK(hipMemcpyAsync(&ctx->h_back[1], ctx->m_pos.as<u32>() + nu, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        n_solid = ctx->h_back[1];
+        CK(ctx->out_lo.ensure((n_solid + 1) * 8)); CK(ctx->out_ab.ensure((n_solid + 1) * 4));
+        if (W == 2) CK(ctx->out_hi.ensure((n_solid + 1) * 8));
+        hipLaunchKernelGGL(k_pick_rows<W>, dim3(gb), dim3(256), 0, ctx->stream, ctx->s_lo.as<u64>(), W == 2 ? ctx->s_hi.as<u64>() : (const u64*)nullptr,
+                           ctx->m_sum.as<u32>(), ctx->m_flag.as<u32>(), ctx->m_pos.as<u32>(), nu, ctx->out_lo.as<u64>(),
+                           W == 2 ? ctx->out_hi.as<u64>() : (u64*)nullptr, ctx->out_ab.as<u32>());
+        CKL("k_pick_rows");
+    }
+    ctx->hist.assign(nh, 0); ctx->hist2d.assign(nh * 11, 0);
+    CK(hipMemcpyAsync(ctx->hist.data(), ctx->ghist.p, nh * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(ctx->hist2d.data(), ctx->gh2d.p, nh * 11 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(&ctx->h_stats[0], ctx->gstats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->res_lo = ctx->out_lo.as<u64>(); ctx->res_hi = W == 2 ? ctx->out_hi.as<u64>() : nullptr; ctx->res_ab = ctx->out_ab.as<u32>();
+    ctx->n_rows = n_solid;
+    ctx->stats.n_bytes = total; ctx->stats.n_kmers = tot_kmers; ctx->stats.n_distinct = ctx->h_stats[0]; ctx->stats.n_solid = n_solid;
+    ctx->stats.n_passes = passes; ctx->stats.n_retries = retries;
+    ctx->stats.n_partitions = ctx->cfg.nb_partitions ? ctx->cfg.nb_partitions : 4u;
+    ctx->have_result = true;
+    return DSKGPU_OK;
+}
+
+}  // namespace
+
 // =============================================================== C-ABI
 extern "C" {
 
@@ -626,6 +737,7 @@ int dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out) {
     if (!cfg || !out) { g_create_err = "null argument"; return DSKGPU_E_ARG; }
     *out = nullptr;
     if (cfg->kmer_size < 1 || cfg->kmer_size > 64) { g_create_err = "kmer_size must be in 1..64"; return DSKGPU_E_ARG; }
+    if (cfg->solidity_kind > DSKGPU_SOLIDITY_CUSTOM) { g_create_err = "unknown solidity_kind"; return DSKGPU_E_ARG; }
     const u32 ws = cfg->world_size ? cfg->world_size : 1;
     if ((ws & (ws - 1)) != 0 || ws > 64 || cfg->rank >= ws) { g_create_err = "world_size must be a power of two <= 64 and rank < world_size"; return DSKGPU_E_ARG; }
     int ndev = 0;
@@ -658,7 +770,8 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->reads_own, &ctx->packed, &ctx->inval, &ctx->bufA, &ctx->bufB, &ctx->mat1, &ctx->mat2, &ctx->sums,
                       &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats,
                       &ctx->out_lo, &ctx->out_hi, &ctx->out_ab, &ctx->srt_lo, &ctx->srt_hi, &ctx->srt_ab, &ctx->srt_tmp,
-                      &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->abund2, &ctx->acc_lo, &ctx->acc_hi, &ctx->acc_ab};
+                      &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->abund2, &ctx->acc_lo, &ctx->acc_hi, &ctx->acc_ab, &ctx->u_lo, &ctx->u_hi, &ctx->u_val,
+                      &ctx->s_lo, &ctx->s_hi, &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -705,6 +818,7 @@ int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbyte
     ctx->d_reads = static_cast<const uint8_t*>(d_bytes);
     ctx->n_bytes = nbytes;
     ctx->reads_len = 0;
+    ctx->bank_ends.clear();
     return DSKGPU_OK;
 }
 
@@ -713,8 +827,34 @@ int dskgpu_count(dskgpu_ctx* ctx) {
     if (ctx->cfg.world_size != 1) return fail(ctx, DSKGPU_E_STATE, "dskgpu_count needs world_size == 1; use dskgpu_mg_scatter/_mg_count");
     CK(hipSetDevice(ctx->cfg.device));
     ctx->stats = dskgpu_stats{};
+    const bool banks = ctx->bank_ends.size() > 1 || (!ctx->bank_ends.empty() && ctx->bank_ends.back() < ctx->n_bytes);
+    if (banks && (ctx->cfg.solidity_kind != DSKGPU_SOLIDITY_SUM || (ctx->cfg.flags & DSKGPU_F_HISTO2D)))
+        return ctx->W == 1 ? run_banks<1>(ctx) : run_banks<2>(ctx);
+    if (ctx->cfg.flags & DSKGPU_F_HISTO2D) ctx->hist2d.clear();
     if (ctx->W == 1) return run_pipeline<1>(ctx, true, nullptr, 0);
     return run_pipeline<2>(ctx, true, nullptr, 0);
+}
+
+int dskgpu_next_bank(dskgpu_ctx* ctx) {
+    if (!ctx) return DSKGPU_E_ARG;
+    if (ctx->bank_ends.empty() || ctx->bank_ends.back() != ctx->reads_len) ctx->bank_ends.push_back(ctx->reads_len);
+    return DSKGPU_OK;
+}
+
+int dskgpu_set_banks(dskgpu_ctx* ctx, const uint64_t* end_offsets, uint32_t n_banks) {
+    if (!ctx || (!end_offsets && n_banks)) return DSKGPU_E_ARG;
+    ctx->bank_ends.assign(end_offsets, end_offsets + n_banks);
+    for (size_t i = 1; i < ctx->bank_ends.size(); ++i)
+        if (ctx->bank_ends[i] < ctx->bank_ends[i - 1]) { ctx->bank_ends.clear(); return fail(ctx, DSKGPU_E_ARG, "bank end offsets must be non-decreasing"); }
+    return DSKGPU_OK;
+}
+
+int dskgpu_histogram2d(const dskgpu_ctx* ctx, uint64_t* out, uint32_t nrows) {
+    if (!ctx || !out) return DSKGPU_E_ARG;
+    if (!ctx->have_result || ctx->hist2d.empty()) return DSKGPU_E_STATE;
+    if (nrows != ctx->cfg.histo_max + 1) return DSKGPU_E_ARG;
+    std::memcpy(out, ctx->hist2d.data(), ctx->hist2d.size() * 8);
+    return DSKGPU_OK;
 }
 
 uint64_t dskgpu_mg_send_capacity_words(const dskgpu_ctx* ctx) {

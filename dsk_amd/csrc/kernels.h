@@ -1116,3 +1116,92 @@ __global__ __launch_bounds__(256) void k_fix_runs(u64* __restrict__ lo, u32* __r
         lo[b] = kv; ab[b] = av;
     }
 }
+
+// ------------------------------------------------------------------ multi-bank merge (solidity kinds, 2-D histogram)
+// Input: the union of the per-bank rows, sorted by k-mer, value = (bank << 32) | abundance.  One thread per
+// row; the first row of every k-mer walks its run (<= number of banks) and decides solidity:
+//   kind 0 sum  : amin <= sum <= amax            3 one : some bank has amin <= c <= amax
+//   kind 1 min  : amin <= min over banks <= amax 4 all : every bank has amin <= c <= amax
+//   kind 2 max  : amin <= max over banks <= amax 5 custom: banks in `mask` have c >= amin, the others c == 0
+// (README.md:12 documents the default; the other kinds are named by the -solidity-kind option of gatb-core and
+// are NOT pinned by any reference test -- see DESIGN.md).  The abundance written is the sum over banks.
+// hist[min(sum, hmax)]++ for every distinct k-mer; h2d[min(reads, hmax)][min(genome, 10)]++ with genome = bank 0
+// and reads = the other banks (README.md:98-102, utils/plot-histo2D.R:22-30).
+struct MergeParams { u32 nbanks, kind, mask, amin, amax, hmax, want2d; };
+#define MB_LH 256
+#define MB_L2 32
+template <int W>
+__global__ __launch_bounds__(256) void k_merge_banks(const u64* __restrict__ lo, const u64* __restrict__ hi, const u64* __restrict__ val,
+                                                     u64 n, MergeParams mp, u32* __restrict__ flag, u32* __restrict__ sumv,
+                                                     u64* __restrict__ ghist, u64* __restrict__ gh2d, u64* __restrict__ gstats) {
+    __shared__ u32 lh[MB_LH];
+    __shared__ u32 l2[MB_L2 * 11];
+    for (int b = threadIdx.x; b < MB_LH; b += 256) lh[b] = 0;
+    for (int b = threadIdx.x; b < MB_L2 * 11; b += 256) l2[b] = 0;
+    __syncthreads();
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    u32 ndist = 0;
+    if (i < n) {
+        const u64 kl = lo[i], kh = W == 2 ? hi[i] : 0ull;
+        const bool head = i == 0 || lo[i - 1] != kl || (W == 2 && hi[i - 1] != kh);
+        u32 f = 0, sv = 0;
+        if (head) {
+            u64 sum = 0; u32 mx = 0, genome = 0, present = 0, inwin = 0, nonzero = 0, nb = 0; u32 mn = 0xFFFFFFFFu;
+            for (u64 j = i; j < n && lo[j] == kl && (W == 1 || hi[j] == kh) && nb < mp.nbanks; ++j, ++nb) {
+                const u64 v = val[j]; const u32 bank = (u32)(v >> 32), c = (u32)v;
+                sum += c; mx = c > mx ? c : mx; mn = c < mn ? c : mn;
+                if (bank == 0) genome = c;
+                nonzero |= 1u << bank;
+                if (c >= mp.amin) present |= 1u << bank;
+                if (c >= mp.amin && c <= mp.amax) inwin |= 1u << bank;
+            }
+            if (nb < mp.nbanks) mn = 0;                             // absent from some bank
+            const u32 all = mp.nbanks >= 32 ? 0xFFFFFFFFu : ((1u << mp.nbanks) - 1);
+            const u32 s32 = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sum;
+            bool solid;
+            switch (mp.kind) {
+                case 1: solid = mn >= mp.amin && mn <= mp.amax; break;
+                case 2: solid = mx >= mp.amin && mx <= mp.amax; break;
+                case 3: solid = inwin != 0; break;
+                case 4: solid = inwin == all; break;
+                case 5: solid = (present & mp.mask) == (mp.mask & all) && (nonzero & ~mp.mask) == 0; break;
+                default: solid = s32 >= mp.amin && s32 <= mp.amax;
+            }
+            f = solid ? 1u : 0u; sv = s32; ndist = 1;
+            const u32 hb = s32 < mp.hmax ? s32 : mp.hmax;
+            if (hb < MB_LH) atomicAdd(&lh[hb], 1u); else atomicAdd(&ghist[hb], 1ull);
+            if (mp.want2d) {
+                const u64 reads = sum - genome;
+                const u32 r = reads < mp.hmax ? (u32)reads : mp.hmax, gcol = genome < 10 ? genome : 10u;
+                if (r < MB_L2) atomicAdd(&l2[r * 11 + gcol], 1u); else atomicAdd(&gh2d[(u64)r * 11 + gcol], 1ull);
+            }
+        }
+        flag[i] = f; sumv[i] = sv;
+    }
+    // block totals
+    for (int d = 32; d >= 1; d >>= 1) ndist += __shfl_down(ndist, d);
+    if ((threadIdx.x & 63) == 0 && ndist) atomicAdd(&gstats[0], (u64)ndist);
+    __syncthreads();
+    for (int b = threadIdx.x; b < MB_LH; b += 256) if (lh[b]) atomicAdd(&ghist[b < (int)mp.hmax ? b : (int)mp.hmax], (u64)lh[b]);
+    if (mp.want2d) for (int b = threadIdx.x; b < MB_L2 * 11; b += 256) if (l2[b]) atomicAdd(&gh2d[b], (u64)l2[b]);
+}
+
+// keep the flagged rows (order preserved): pos = exclusive scan of flag
+template <int W>
+__global__ __launch_bounds__(256) void k_pick_rows(const u64* __restrict__ lo, const u64* __restrict__ hi, const u32* __restrict__ sumv,
+                                                   const u32* __restrict__ flag_in, const u32* __restrict__ posx, u64 n,
+                                                   u64* __restrict__ out_lo, u64* __restrict__ out_hi, u32* __restrict__ out_ab) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !flag_in[i]) return;
+    const u32 p = posx[i];
+    out_lo[p] = lo[i]; if (W == 2) out_hi[p] = hi[i];
+    out_ab[p] = sumv[i];
+}
+__global__ void k_pack_bank(u64* __restrict__ dst, const u32* __restrict__ ab, u64 n, u32 bank) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = ((u64)bank << 32) | ab[i];
+}
+__global__ void k_copy_u32(u32* __restrict__ dst, const u32* __restrict__ src, u64 n) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}

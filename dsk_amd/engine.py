@@ -35,7 +35,9 @@ class _Config(C.Structure):
         ("world_size", C.c_uint32),
         ("rank", C.c_uint32),
         ("max_pass_mkeys", C.c_uint32),
-        ("reserved", C.c_uint32 * 5),
+        ("solidity_kind", C.c_uint32),
+        ("solidity_custom", C.c_uint32),
+        ("reserved", C.c_uint32 * 3),
     ]
 
 
@@ -57,11 +59,14 @@ class _Stats(C.Structure):
 
 F_TIMING = 1
 F_NO_SORT = 2
+F_HISTO2D = 4
+SOLIDITY = {"sum": 0, "min": 1, "max": 2, "one": 3, "all": 4, "custom": 5}
 
 # every symbol include/dskgpu.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "dskgpu_create", "dskgpu_destroy", "dskgpu_last_error", "dskgpu_version", "dskgpu_set_stream",
-    "dskgpu_push_reads", "dskgpu_set_reads_device", "dskgpu_count", "dskgpu_mg_scatter",
+    "dskgpu_push_reads", "dskgpu_set_reads_device", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
+    "dskgpu_count", "dskgpu_mg_scatter",
     "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_get_stats", "dskgpu_histogram",
     "dskgpu_num_partitions", "dskgpu_partition_size", "dskgpu_partition_copy", "dskgpu_result_device",
     "dskgpu_stage_times", "dskgpu_k_encode", "dskgpu_k_enumerate", "dskgpu_k_minimizers",
@@ -98,6 +103,9 @@ def load_library():
     lib.dskgpu_push_reads.argtypes = [vp, C.c_char_p, u64]
     lib.dskgpu_set_reads_device.argtypes = [vp, vp, u64]
     lib.dskgpu_count.argtypes = [vp]
+    lib.dskgpu_next_bank.argtypes = [vp]
+    lib.dskgpu_set_banks.argtypes = [vp, C.POINTER(u64), u32]
+    lib.dskgpu_histogram2d.argtypes = [vp, C.POINTER(u64), u32]
     lib.dskgpu_mg_scatter.argtypes = [vp, vp, u64, C.POINTER(u64)]
     lib.dskgpu_mg_send_capacity_words.argtypes = [vp]
     lib.dskgpu_mg_send_capacity_words.restype = u64
@@ -126,7 +134,8 @@ class KmerCounter:
     def __init__(self, kmer_size: int = 31, abundance_min: int = 2, abundance_max: int = 2147483647,
                  histo_max: int = 10000, device: int = 0, nb_partitions: int = 0, timing: bool = False,
                  sort: bool = True, world_size: int = 1, rank: int = 0, stream: Optional[int] = None,
-                 minimizer_size: int = 0, max_pass_mkeys: int = 0):
+                 minimizer_size: int = 0, max_pass_mkeys: int = 0, solidity_kind: str = "sum", solidity_custom: int = 0,
+                 histo2d: bool = False):
         self._lib = load_library()
         cfg = _Config()
         cfg.kmer_size = kmer_size
@@ -137,7 +146,9 @@ class KmerCounter:
         cfg.nb_partitions = nb_partitions
         cfg.minimizer_size = minimizer_size
         cfg.max_pass_mkeys = max_pass_mkeys
-        cfg.flags = (F_TIMING if timing else 0) | (0 if sort else F_NO_SORT)
+        cfg.flags = (F_TIMING if timing else 0) | (0 if sort else F_NO_SORT) | (F_HISTO2D if histo2d else 0)
+        cfg.solidity_kind = SOLIDITY[solidity_kind]
+        cfg.solidity_custom = solidity_custom
         cfg.world_size = world_size
         cfg.rank = rank
         self.kmer_size = kmer_size
@@ -180,6 +191,18 @@ class KmerCounter:
 
     def set_reads_device(self, ptr: int, nbytes: int) -> None:
         self._ck(self._lib.dskgpu_set_reads_device(self._h, C.c_void_p(ptr), nbytes))
+
+    def next_bank(self) -> None:
+        self._ck(self._lib.dskgpu_next_bank(self._h))
+
+    def set_banks(self, end_offsets) -> None:
+        arr = (C.c_uint64 * len(end_offsets))(*end_offsets)
+        self._ck(self._lib.dskgpu_set_banks(self._h, arr, len(end_offsets)))
+
+    def histogram2d(self) -> np.ndarray:
+        out = np.zeros((self.histo_max + 1, 11), dtype=np.uint64)
+        self._ck(self._lib.dskgpu_histogram2d(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), self.histo_max + 1))
+        return out
 
     # -- hot path
     def count(self) -> None:

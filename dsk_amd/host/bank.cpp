@@ -212,6 +212,7 @@ public:
     uint64_t stream(size_t chunkBytes, const Sink& sink) override {
         uint64_t n = 0; for (auto* b : banks_) n += b->stream(chunkBytes, sink); return n;
     }
+    std::vector<IBank*> banks() override { return banks_; }
 private:
     std::string id_; std::vector<IBank*> banks_;
 };

@@ -28,6 +28,8 @@ public:
     virtual void estimate(uint64_t& number, uint64_t& totalSize, uint64_t& maxSize);
     // file names (flattened)
     virtual std::vector<std::string> files() const = 0;
+    // the banks this one is made of (comma-separated inputs / album lines); a plain file is its own single bank
+    virtual std::vector<IBank*> banks() { return std::vector<IBank*>(1, this); }
 };
 
 class Bank {

@@ -19,6 +19,9 @@ struct CountConfig {
     unsigned histo_max = 10000;
     unsigned nb_partitions = 0;   // 0 = engine default
     int device = 0;
+    unsigned solidity_kind = 0;   // 0 sum, 1 min, 2 max, 3 one, 4 all, 5 custom (include/dskgpu.h DSKGPU_SOLIDITY_*)
+    unsigned solidity_custom = 0; // custom: bit b = bank b must hold the k-mer
+    bool histo2d = false;         // also build the 2-D histogram (bank 0 = genome, others = reads)
 };
 
 class ICountBackend {
@@ -27,8 +30,10 @@ public:
     virtual std::string name() const = 0;
     virtual void configure(const CountConfig& cfg) = 0;
     virtual void push(const char* data, size_t nbytes) = 0;   // read-stream chunk, whole records
+    virtual void nextBank() = 0;                              // what was pushed so far is one bank (comma-separated input)
     virtual void finish() = 0;                                // run the count; results valid afterwards
     virtual void histogram(std::vector<uint64_t>& h) = 0;     // histo_max + 1 entries, h[0] == 0
+    virtual void histogram2d(std::vector<uint64_t>& h) = 0;   // (histo_max + 1) x 11, row-major; empty when not requested
     virtual uint32_t numPartitions() = 0;
     virtual uint64_t partitionSize(uint32_t p) = 0;
     // kmers: n * words u64 (least significant word first); abundance: n u32; ascending k-mer order

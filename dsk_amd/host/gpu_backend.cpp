@@ -18,14 +18,22 @@ public:
         dskgpu_config g{};
         g.kmer_size = c.kmer_size; g.abundance_min = c.abundance_min; g.abundance_max = c.abundance_max;
         g.histo_max = c.histo_max; g.device = c.device; g.nb_partitions = c.nb_partitions;
-        g.flags = DSKGPU_F_TIMING; g.world_size = 1; g.rank = 0;
+        g.flags = DSKGPU_F_TIMING | (c.histo2d ? DSKGPU_F_HISTO2D : 0u); g.world_size = 1; g.rank = 0;
+        g.solidity_kind = c.solidity_kind; g.solidity_custom = c.solidity_custom;
         cfg_ = c;
         int rc = dskgpu_create(&g, &ctx_);
         if (rc != DSKGPU_OK) { std::string m = dskgpu_last_error(nullptr); ctx_ = nullptr; throw Exception("GPU engine: %s (code %d)", m.c_str(), rc); }
     }
     void push(const char* data, size_t n) override { ck(dskgpu_push_reads(ctx_, data, n)); }
+    void nextBank() override { ck(dskgpu_next_bank(ctx_)); }
     void finish() override { ck(dskgpu_count(ctx_)); }
     void histogram(std::vector<uint64_t>& h) override { h.assign(cfg_.histo_max + 1, 0); ck(dskgpu_histogram(ctx_, h.data(), cfg_.histo_max + 1)); }
+    void histogram2d(std::vector<uint64_t>& h) override {
+        h.clear();
+        if (!cfg_.histo2d) return;
+        h.assign((size_t)(cfg_.histo_max + 1) * 11, 0);
+        if (dskgpu_histogram2d(ctx_, h.data(), cfg_.histo_max + 1) != DSKGPU_OK) h.clear();   // single bank: nothing to cross
+    }
     uint32_t numPartitions() override { return dskgpu_num_partitions(ctx_); }
     uint64_t partitionSize(uint32_t p) override { return dskgpu_partition_size(ctx_, p); }
     void partitionCopy(uint32_t p, uint64_t* kmers, uint32_t* ab) override { ck(dskgpu_partition_copy(ctx_, p, kmers, ab)); }

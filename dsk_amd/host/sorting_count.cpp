@@ -30,7 +30,8 @@ IOptionsParser* SortingCountBase::makeOptionsParser() {
     p->push_back(new OptionOneParam(STR_KMER_ABUNDANCE_MAX, "max abundance threshold for solid kmers", false, "2147483647"));
     p->push_back(new OptionOneParam("-abundance-min-threshold", "min abundance hard threshold (only used when min abundance is 'auto')", false, "2"));
     p->push_back(new OptionOneParam(STR_HISTOGRAM_MAX, "max number of values in kmers histogram", false, "10000"));
-    p->push_back(new OptionOneParam("-solidity-kind", "way to compute counts of several files (sum only)", false, "sum"));
+    p->push_back(new OptionOneParam("-solidity-kind", "way to consider a solid kmer with several input files (sum, min, max, one, all, custom)", false, "sum"));
+    p->push_back(new OptionOneParam("-solidity-custom", "when solidity-kind is custom: one 0/1 per input file, e.g. 101 = present in files 1 and 3, absent from file 2", false, ""));
     p->push_back(new OptionOneParam(STR_MAX_MEMORY, "max memory (in MBytes); accepted, the engine sizes itself to HBM", false, "5000"));
     p->push_back(new OptionOneParam(STR_MAX_DISK, "max disk (in MBytes); accepted and ignored: partitions live in HBM", false, "0"));
     p->push_back(new OptionOneParam(STR_URI_OUTPUT, "output file for solid kmers", false, ""));
@@ -97,10 +98,21 @@ void SortingCountBase::execute() {
     cfg.histo_max = input_.has(STR_HISTOGRAM_MAX) ? (unsigned)input_.getInt(STR_HISTOGRAM_MAX) : 10000u;
     cfg.nb_partitions = input_.has("-nb-partitions") ? (unsigned)input_.getInt("-nb-partitions") : 0u;
     cfg.device = input_.has("-device") ? (int)input_.getInt("-device") : 0;
-    if (input_.has("-solidity-kind") && input_.getStr("-solidity-kind") != "sum")
-        throw Exception("-solidity-kind '%s' is not supported (only 'sum')", input_.getStr("-solidity-kind").c_str());
-    if (input_.has("-histo2D") && input_.getInt("-histo2D") != 0)
-        throw Exception("-histo2D is not supported yet");
+    {   // -solidity-kind / -solidity-custom / -histo2D: per-bank counts (banks = the comma-separated inputs)
+        const std::string kind = input_.has("-solidity-kind") ? input_.getStr("-solidity-kind") : "sum";
+        static const char* names[] = {"sum", "min", "max", "one", "all", "custom"};
+        int found = -1;
+        for (int i = 0; i < 6; ++i) if (kind == names[i]) found = i;
+        if (found < 0) throw Exception("unknown -solidity-kind '%s' (sum|min|max|one|all|custom)", kind.c_str());
+        cfg.solidity_kind = (unsigned)found;
+        if (found == 5) {
+            const std::string m = input_.has("-solidity-custom") ? input_.getStr("-solidity-custom") : "";
+            unsigned bit = 0;
+            for (char ch : m) { if (ch == '1') cfg.solidity_custom |= 1u << bit; if (ch == '0' || ch == '1') ++bit; }
+            if (bit == 0) throw Exception("-solidity-kind custom needs -solidity-custom <0/1 per input file, e.g. 101>");
+        }
+        cfg.histo2d = input_.has("-histo2D") && input_.getInt("-histo2D") != 0;
+    }
     if (input_.has("-storage-type") && input_.getStr("-storage-type") != "hdf5")
         throw Exception("-storage-type '%s' is not supported (only 'hdf5')", input_.getStr("-storage-type").c_str());
     const int compress = input_.has("-out-compress") ? (int)input_.getInt("-out-compress") : 0;
@@ -115,7 +127,11 @@ void SortingCountBase::execute() {
     be->configure(cfg);
     uint64_t nbytes = 0;
     const double t1 = now_s();
-    const uint64_t nseq = bank_->stream((size_t)64 << 20, [&](const char* d, size_t n) { be->push(d, n); nbytes += n; });
+    uint64_t nseq = 0;
+    for (IBank* sub : bank_->banks()) {          // one bank per comma-separated input (README.md:52-58)
+        nseq += sub->stream((size_t)64 << 20, [&](const char* d, size_t n) { be->push(d, n); nbytes += n; });
+        be->nextBank();
+    }
     const double t2 = now_s();
     be->finish();
     const double t3 = now_s();
@@ -154,6 +170,17 @@ void SortingCountBase::execute() {
     dg.setProperty("kmer_size", std::to_string(k));
     const double t4 = now_s();
 
+    if (cfg.histo2d) {   // README.md:98-102, utils/plot-histo2D.R:22-30: rows = abundance in the reads, columns = in the genome (0..10)
+        std::vector<uint64_t> h2;
+        be->histogram2d(h2);
+        if (h2.empty()) throw Exception("-histo2D needs at least two input files (genome first, then reads)");
+        std::ofstream hf(out + ".histo2D");
+        for (unsigned i = 0; i <= cfg.histo_max; ++i) {
+            hf << i;
+            for (unsigned g = 0; g < 11; ++g) hf << "\t" << h2[(size_t)i * 11 + g];
+            hf << "\n";
+        }
+    }
     if (input_.has("-histo") && input_.getInt("-histo") != 0) {   // README.md:90-96, utils/plot-histo.R:24
         std::ofstream hf(out + ".histo");
         for (unsigned i = 1; i <= cfg.histo_max; ++i) hf << i << "\t" << histo_[i] << "\n";

@@ -57,11 +57,23 @@ typedef struct dskgpu_config {
     uint32_t max_pass_mkeys;  /* most k-mers (in millions) one pass may hold; 0 = 4026 (32-bit offsets).
                                  Larger inputs are counted in several passes over the key space, the
                                  in-HBM counterpart of DSK's disk passes (README.md:126-130) */
-    uint32_t reserved[5];
+    uint32_t solidity_kind;   /* DSKGPU_SOLIDITY_*: how the counts of several banks decide solidity (-solidity-kind) */
+    uint32_t solidity_custom; /* DSKGPU_SOLIDITY_CUSTOM: bit b set = bank b must hold the k-mer (-solidity-custom) */
+    uint32_t reserved[3];
 } dskgpu_config;
 
 #define DSKGPU_F_TIMING 1u        /* record per-stage HIP-event timings        */
 #define DSKGPU_F_NO_SORT 2u       /* leave solid rows unsorted (bench ablation) */
+#define DSKGPU_F_HISTO2D 4u       /* also build the 2-D histogram: bank 0 (genome) x the other banks (reads), -histo2D */
+
+/* -solidity-kind (gatb-core option; only `sum` is exercised by the reference's tests, README.md:12).
+ * Banks = the inputs separated with dskgpu_next_bank / dskgpu_set_banks; one bank => plain counting. */
+#define DSKGPU_SOLIDITY_SUM 0u    /* amin <= sum of the banks' counts <= amax (default)            */
+#define DSKGPU_SOLIDITY_MIN 1u    /* amin <= smallest per-bank count <= amax                       */
+#define DSKGPU_SOLIDITY_MAX 2u    /* amin <= largest per-bank count <= amax                        */
+#define DSKGPU_SOLIDITY_ONE 3u    /* at least one bank has amin <= count <= amax                   */
+#define DSKGPU_SOLIDITY_ALL 4u    /* every bank has amin <= count <= amax                          */
+#define DSKGPU_SOLIDITY_CUSTOM 5u /* banks in solidity_custom have count >= amin, the others 0     */
 
 /* Lifetime: stands where `SortingCountAlgorithm<span> sortingCount(bank, props)`
  * is constructed / destroyed (src/DSK.cpp:55). */
@@ -81,6 +93,12 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes);
 /* Use a read stream already resident in HBM (caller keeps ownership and must
  * keep it alive until dskgpu_count returns).  Replaces any pushed reads. */
 int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes);
+
+/* Banks: the comma-separated inputs of `-file` are separate banks (README.md:52-58).  Call
+ * dskgpu_next_bank between the pushes of two banks, or give the end offset of every bank of a
+ * device-resident stream.  Only needed for -solidity-kind != sum and -histo2D; at most 32 banks. */
+int dskgpu_next_bank(dskgpu_ctx* ctx);
+int dskgpu_set_banks(dskgpu_ctx* ctx, const uint64_t* end_offsets, uint32_t n_banks);
 
 /* ---- the hot path: replaces SortingCountAlgorithm<span>::execute() (src/DSK.cpp:60) */
 /* Single-GPU: encode -> canonical k-mers -> partition -> count -> histogram +
@@ -117,6 +135,11 @@ int dskgpu_get_stats(const dskgpu_ctx* ctx, dskgpu_stats* out);
  * min(count, histo_max) == i; nbins must be histo_max+1 (out[0] == 0).
  * Same content as the `histogram/histogram` dataset (test/k27.histo). */
 int dskgpu_histogram(const dskgpu_ctx* ctx, uint64_t* out, uint32_t nbins);
+
+/* 2-D histogram (flag DSKGPU_F_HISTO2D): out[r * 11 + g] = number of distinct k-mers seen min(r, histo_max)
+ * times in the read banks (banks 1..) and min(g, 10) times in bank 0; nrows must be histo_max + 1.
+ * Text form `<out>.histo2D` (README.md:98-102; utils/plot-histo2D.R:22-30). */
+int dskgpu_histogram2d(const dskgpu_ctx* ctx, uint64_t* out, uint32_t nrows);
 
 /* Output partitions = `Partition<Count> "solid"` (utils/dsk2ascii.cpp:61,77).
  * Rows are ascending by k-mer value inside a partition and partitions are

@@ -37,3 +37,8 @@ def test_engine_is_the_hip_library(bins, tmp_path):
     g = os.path.join(ROOT, "tests", "golden")
     out = subprocess.check_output([bins["dsk"], "-file", f"{g}/longread.fasta", "-kmer-size", "27", "-out", "v"], cwd=str(tmp_path)).decode()
     assert "gfx950" in out and "kmers_nb_valid" in out and "71130" in out
+
+
+def test_solidity_kinds_and_histo2d_cli_on_gpu(bins, tmp_path, oracle):
+    from tests.test_host_cli import run_solidity_cases
+    run_solidity_cases(bins["dsk"], bins["dsk2ascii"], str(tmp_path), oracle)

@@ -361,3 +361,72 @@ def test_multi_pass_skew_doubles_passes(oracle, dev):
         kc.set_reads_device(t.data_ptr(), t.numel())
         with pytest.raises(DskGpuError):
             kc.count()
+
+
+def _bank_reference(oracle, streams, k, kind, amin, amax, mask, hmax=10000):
+    """numpy restatement of the multi-bank semantics of include/dskgpu.h (DSKGPU_SOLIDITY_*), from per-bank oracle counts."""
+    B = len(streams)
+    per = [oracle.count(s, k) for s in streams]
+    keys = np.unique(np.concatenate([p.values() if k > 32 else p.lo for p in per]))
+    counts = np.zeros((len(keys), B), dtype=np.int64)
+    for b, p in enumerate(per):
+        kb = p.values() if k > 32 else p.lo
+        idx = np.searchsorted(keys, kb)
+        counts[idx, b] = p.ab
+    tot = counts.sum(1)
+    inwin = (counts >= amin) & (counts <= amax)
+    if kind == "sum":
+        solid = (tot >= amin) & (tot <= amax)
+    elif kind == "min":
+        solid = (counts.min(1) >= amin) & (counts.min(1) <= amax)
+    elif kind == "max":
+        solid = (counts.max(1) >= amin) & (counts.max(1) <= amax)
+    elif kind == "one":
+        solid = inwin.any(1)
+    elif kind == "all":
+        solid = inwin.all(1)
+    else:
+        m = np.array([(mask >> b) & 1 for b in range(B)], dtype=bool)
+        solid = (counts[:, m] >= amin).all(1) & (counts[:, ~m] == 0).all(1)
+    hist = np.bincount(np.minimum(tot, hmax), minlength=hmax + 1).astype(np.uint64)
+    h2d = np.zeros((hmax + 1, 11), dtype=np.uint64)
+    np.add.at(h2d, (np.minimum(tot - counts[:, 0], hmax), np.minimum(counts[:, 0], 10)), 1)
+    return keys[solid], tot[solid], hist, h2d, sum(p.total for p in per)
+
+
+@pytest.mark.parametrize("kind,mask", [("min", 0), ("max", 0), ("one", 0), ("all", 0), ("custom", 0b0101), ("sum", 0)])
+def test_solidity_kinds_and_histo2d(oracle, golden_dir, dev, kind, mask):
+    """-solidity-kind / -histo2D over several banks (unpinned by the reference's tests:
+    checked against a numpy restatement built from per-bank oracle counts)."""
+    from dsk_amd import KmerCounter
+    streams = [oracle.load_bank(os.path.join(golden_dir, f"c{i}.fasta.gz"))[0] for i in (1, 2, 3, 4)]
+    k, amin, amax = 27, 2, 40
+    want_k, want_a, want_h, want_h2, want_total = _bank_reference(oracle, streams, k, kind, amin, amax, mask)
+    whole = torch.from_numpy(np.concatenate(streams)).to(dev)
+    ends = list(np.cumsum([len(s) for s in streams]))
+    with KmerCounter(kmer_size=k, abundance_min=amin, abundance_max=amax, solidity_kind=kind, solidity_custom=mask, histo2d=True) as kc:
+        kc.set_reads_device(whole.data_ptr(), whole.numel())
+        kc.set_banks([int(e) for e in ends])
+        kc.count()
+        kmers, ab = kc.rows()
+        st = kc.stats()
+        assert (kc.histogram() == want_h).all()
+        assert (kc.histogram2d() == want_h2).all()
+    assert st["n_kmers"] == want_total and st["n_solid"] == len(want_k)
+    assert (kmers[:, 0] == want_k).all() and (ab == want_a).all()
+
+
+def test_solidity_two_word_and_push_path(oracle, golden_dir, dev):
+    from dsk_amd import KmerCounter
+    streams = [oracle.load_bank(os.path.join(golden_dir, f"c{i}.fasta.gz"))[0] for i in (1, 2)]
+    k = 41
+    want_k, want_a, want_h, want_h2, _ = _bank_reference(oracle, streams, k, "all", 1, 2**31 - 1, 0)
+    with KmerCounter(kmer_size=k, abundance_min=1, solidity_kind="all", histo2d=True) as kc:
+        for s in streams:                       # host path: one bank per push, separated by next_bank()
+            kc.push_reads(s.tobytes())
+            kc.next_bank()
+        kc.count()
+        kmers, ab = kc.rows()
+        assert (kc.histogram() == want_h).all() and (kc.histogram2d() == want_h2).all()
+    vals = np.array([(int(h) << 64) | int(l) for l, h in zip(kmers[:, 0], kmers[:, 1])], dtype=object)
+    assert (vals == want_k).all() and (ab == want_a).all()

@@ -206,3 +206,46 @@ def test_kmer_model_unit(bins):
     """C++ unit test of host/kmer.hpp (Kmer<span>::ModelCanonical, Integer::apply) against the oracle."""
     out = subprocess.run([os.path.join(ROOT, "tests", "host", "test_kmer")], stdout=subprocess.PIPE).stdout.decode()
     assert "ALL OK" in out, out
+
+
+def run_solidity_cases(dsk, dsk2ascii, tmp, oracle):
+    """-solidity-kind / -solidity-custom / -histo2D through the CLI (shared by the CPU and GPU variants)."""
+    import numpy as np
+    files = [f"{G}/c{i}.fasta.gz" for i in (1, 2, 3)]
+    streams = [oracle.load_bank(f)[0] for f in files]
+    k, amin = 27, 2
+    per = [oracle.count(s, k) for s in streams]
+    keys = np.unique(np.concatenate([p.lo for p in per]))
+    counts = np.zeros((len(keys), 3), dtype=np.int64)
+    for b, p in enumerate(per):
+        counts[np.searchsorted(keys, p.lo), b] = p.ab
+    tot = counts.sum(1)
+    expect = {
+        "sum": tot >= amin, "min": counts.min(1) >= amin, "max": counts.max(1) >= amin,
+        "one": (counts >= amin).any(1), "all": (counts >= amin).all(1),
+        "custom": (counts[:, 0] >= amin) & (counts[:, 2] >= amin) & (counts[:, 1] == 0),
+    }
+    for kind, solid in expect.items():
+        args = [dsk, "-file", ",".join(files), "-kmer-size", str(k), "-abundance-min", str(amin), "-solidity-kind", kind,
+                "-out", f"sol_{kind}", "-verbose", "0", "-histo2D", "1"]
+        if kind == "custom":
+            args += ["-solidity-custom", "101"]
+        r = subprocess.run(args, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr
+        subprocess.check_call([dsk2ascii, "-file", f"sol_{kind}", "-out", f"sol_{kind}.txt", "-verbose", "0"], cwd=tmp)
+        got = open(os.path.join(tmp, f"sol_{kind}.txt")).read().splitlines()
+        want = [f"{oracle.kmer_to_string(int(v), 0, k)} {int(c)}" for v, c in zip(keys[solid], tot[solid])]
+        assert got == want, kind
+        h2 = np.loadtxt(os.path.join(tmp, f"sol_{kind}.histo2D"), dtype=np.int64)
+        assert h2.shape == (10001, 12) and (h2[:, 0] == np.arange(10001)).all()
+        ref = np.zeros((10001, 11), dtype=np.int64)
+        np.add.at(ref, (np.minimum(tot - counts[:, 0], 10000), np.minimum(counts[:, 0], 10)), 1)
+        assert (h2[:, 1:] == ref).all(), kind
+    r = subprocess.run([dsk, "-file", files[0], "-kmer-size", "27", "-solidity-kind", "bogus", "-out", "x"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"solidity-kind" in r.stderr
+    r = subprocess.run([dsk, "-file", files[0], "-kmer-size", "27", "-histo2D", "1", "-out", "x", "-verbose", "0"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"histo2D" in r.stderr          # needs genome + reads
+
+
+def test_solidity_kinds_and_histo2d_cli(bins, tmp_path, oracle):
+    run_solidity_cases(bins["dsk"], bins["dsk2ascii"], str(tmp_path), oracle)
