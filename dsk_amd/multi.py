@@ -40,7 +40,7 @@ def exchange(send: torch.Tensor, send_counts: Sequence[int], group=None,
     recv_counts = [int(x) for x in rc.tolist()]
     n_recv = sum(recv_counts)
     if recv is None or recv.numel() < n_recv:
-        recv = torch.empty(max(n_recv, 1), dtype=send.dtype, device=dev)
+        recv = torch.empty(int(n_recv * 1.1) + 1024, dtype=send.dtype, device=dev)   # head-room: sizes wobble step to step
     out = recv[:n_recv]
     dist.all_to_all_single(out, send[: sum(send_counts)], recv_counts, list(send_counts), group=group)
     return out, recv_counts
@@ -65,8 +65,8 @@ class ShardedCounter:
             self.send = torch.empty(max(cap, 1), dtype=torch.int64, device=self.device)
         counts = self.stage.mg_scatter(self.send.data_ptr(), self.send.numel())
         out, rcounts = exchange(self.send, counts, self.group, self.recv)
-        if self.recv is None or out.data_ptr() != self.recv.data_ptr():
-            self.recv = out if out.numel() else self.recv
+        if self.recv is None or self.recv.numel() < out.numel() or out.data_ptr() != self.recv.data_ptr():
+            self.recv = out._base if out._base is not None else out        # keep the (larger) backing buffer for the next step
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
         self.last_send_counts, self.last_recv_counts = list(counts), rcounts
