@@ -4,8 +4,11 @@
 #include <sys/time.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <fstream>
+#include <mutex>
+#include <thread>
 
 namespace dsk {
 
@@ -128,9 +131,31 @@ void SortingCountBase::execute() {
     uint64_t nbytes = 0;
     const double t1 = now_s();
     uint64_t nseq = 0;
-    for (IBank* sub : bank_->banks()) {          // one bank per comma-separated input (README.md:52-58)
-        nseq += sub->stream((size_t)64 << 20, [&](const char* d, size_t n) { be->push(d, n); nbytes += n; });
-        be->nextBank();
+    std::vector<IBank*> subs = bank_->banks();   // one bank per comma-separated input (README.md:52-58)
+    const bool per_bank = cfg.solidity_kind != 0 || cfg.histo2d;
+    if (per_bank || subs.size() < 2) {           // bank boundaries matter: stream the banks in order
+        for (IBank* sub : subs) {
+            nseq += sub->stream((size_t)64 << 20, [&](const char* d, size_t n) { be->push(d, n); nbytes += n; });
+            be->nextBank();
+        }
+    } else {                                     // plain sum: inflate / parse the files concurrently (host thread pool)
+        std::mutex mu; std::atomic<size_t> next(0); std::atomic<uint64_t> seqs(0);
+        std::string err;
+        auto worker = [&]() {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= subs.size()) return;
+                try {
+                    seqs += subs[i]->stream((size_t)32 << 20, [&](const char* d, size_t n) { std::lock_guard<std::mutex> g(mu); be->push(d, n); nbytes += n; });
+                } catch (Exception& e) { std::lock_guard<std::mutex> g(mu); err = e.getMessage(); }
+            }
+        };
+        const unsigned nt = (unsigned)std::min<size_t>(subs.size(), std::max(1u, Bank::parseThreads()));
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(worker);
+        for (auto& x : th) x.join();
+        if (!err.empty()) throw Exception(err);
+        nseq = seqs;
     }
     const double t2 = now_s();
     be->finish();
