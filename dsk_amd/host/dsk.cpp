@@ -1,46 +1,44 @@
-// dsk.cpp -- see dsk.hpp.  Same control flow as src/DSK.cpp:45-104, written
-// against this repo's host layer.
+// dsk.cpp -- the `dsk` tool: option wiring + span dispatch around the counting engine.
+// Plays the role of src/DSK.cpp in the reference (parser splice and -in -> -file rename at :80-87,
+// k-span dispatch at :97-104, run + statistics + "xml" property at :45-70) on this repo's host layer.
 #include "dsk.hpp"
 
 namespace dsk {
 
-namespace {
-struct Parameter {
-    Parameter(DSK& d, IProperties* p) : dsk(d), props(p) {}
-    DSK& dsk; IProperties* props;
-};
-
-template <size_t span>
-struct Functor {
-    void operator()(Parameter parameter) {
-        DSK& tool = parameter.dsk;
-        IProperties* props = parameter.props;
-
-        IBank* bank = Bank::open(props->getStr(STR_URI_FILE));          // src/DSK.cpp:51
-        LOCAL(bank);
-
-        SortingCountAlgorithm<span> sortingCount(bank, props);           // src/DSK.cpp:55
-        sortingCount.getInput()->set(STR_VERBOSE, props->getStr(STR_VERBOSE));
-        sortingCount.execute();                                          // src/DSK.cpp:60  (GPU engine)
-
-        tool.getInfo()->add(1, sortingCount.getConfig().getProperties());  // src/DSK.cpp:63-64
-        tool.getInfo()->add(1, sortingCount.getInfo());
-
-        // src/DSK.cpp:68: run info stored as the "xml" attribute of group "dsk"
-        sortingCount.getStorage()->getGroup(sortingCount.getName()).setProperty("xml", std::string("\n") + sortingCount.getInfo()->getXML());
-    }
-};
-}  // namespace
-
 DSK::DSK() : Tool("dsk") {
-    getParser()->push_back(SortingCountAlgorithm<>::getOptionsParser(), 1);          // src/DSK.cpp:83
-    if (IOptionsParser* input = getParser()->getParser(STR_URI_INPUT)) input->setName(STR_URI_FILE);   // src/DSK.cpp:86
+    // every option of the counting algorithm becomes an option of the tool ...
+    OptionsParser* mine = getParser();
+    mine->push_back(SortingCountAlgorithm<>::getOptionsParser(), 1);
+    // ... except that the reads are given with -file instead of -in
+    IOptionsParser* reads = mine->getParser(STR_URI_INPUT);
+    if (reads != nullptr) reads->setName(STR_URI_FILE);
+}
+
+// Count with the k-mer integer width `span` bits / 2 bases that fits the requested k.
+template <size_t span>
+static void countWithSpan(DSK& tool, IProperties& options) {
+    std::unique_ptr<IBank> reads(Bank::open(options.getStr(STR_URI_FILE)));
+    SortingCountAlgorithm<span> counter(reads.get(), &options);
+    counter.getInput()->set(STR_VERBOSE, options.getStr(STR_VERBOSE));
+
+    counter.execute();      // reads -> HBM -> (kmer, abundance) partitions + histogram -> HDF5
+
+    // what -verbose 1 prints at exit, and what is kept inside the output file
+    IProperties* report = tool.getInfo();
+    report->add(1, counter.getConfig().getProperties());
+    report->add(1, counter.getInfo());
+    Group& home = counter.getStorage()->getGroup(counter.getName());
+    home.setProperty("xml", "\n" + counter.getInfo()->getXML());
 }
 
 void DSK::execute() {
-    size_t kmerSize = (size_t)getInput()->getInt(STR_KMER_SIZE);                     // src/DSK.cpp:100
-    try { Integer::apply<Functor, Parameter>(kmerSize, Parameter(*this, getInput())); }   // src/DSK.cpp:103
-    catch (std::runtime_error& e) { throw Exception(std::string(e.what())); }
+    IProperties& options = *getInput();
+    const size_t k = (size_t)options.getInt(STR_KMER_SIZE);
+    try {
+        Integer::dispatch(k, [&](auto width) { countWithSpan<decltype(width)::value>(*this, options); });
+    } catch (std::runtime_error& problem) {
+        throw Exception(std::string(problem.what()));
+    }
 }
 
 }  // namespace dsk

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 
 namespace dsk {
 
@@ -131,6 +132,13 @@ struct Integer {
     static void apply(size_t kmerSize, Parameter p) {
         if (kmerSize < 32) Functor<32>()(p);
         else if (kmerSize < 64) Functor<64>()(p);
+        else throw std::runtime_error("kmer size too large for the compiled spans (KSIZE_LIST=32 64): k must be < 64");
+    }
+    // Same dispatch for C++17 callers: fct(std::integral_constant<size_t, span>()).
+    template <class F>
+    static void dispatch(size_t kmerSize, F&& fct) {
+        if (kmerSize < 32) fct(std::integral_constant<size_t, 32>());
+        else if (kmerSize < 64) fct(std::integral_constant<size_t, 64>());
         else throw std::runtime_error("kmer size too large for the compiled spans (KSIZE_LIST=32 64): k must be < 64");
     }
 };
