@@ -63,6 +63,7 @@ struct dskgpu_ctx {
 
     // input
     DevBuf reads_own; u64 reads_len = 0;
+    void* pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_used[2] = {false, false};   // pinned H2D staging
     const uint8_t* d_reads = nullptr; u64 n_bytes = 0;
 
     DevBuf packed, inval;          // K1 output
@@ -774,6 +775,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
                       &ctx->s_lo, &ctx->s_hi, &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) { if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]); if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -798,18 +800,51 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
     const u64 need = ctx->reads_len + nbytes + 1;
     if (need > ctx->reads_own.cap) {
         DevBuf nb;
-        CK(nb.ensure(std::max<u64>(need, ctx->reads_own.cap * 2)));
+        CK(nb.ensure(std::max<u64>(need, std::max<u64>(ctx->reads_own.cap * 2, (u64)256 << 20))));
         if (ctx->reads_len) CK(hipMemcpyAsync(nb.p, ctx->reads_own.p, ctx->reads_len, hipMemcpyDeviceToDevice, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
         ctx->reads_own.release();
         ctx->reads_own = nb;
     }
     uint8_t* dst = ctx->reads_own.as<uint8_t>();
-    if (nbytes) CK(hipMemcpyAsync(dst + ctx->reads_len, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    if (nbytes) {
+        // pageable host memory -> two pinned staging buffers -> HBM: the CPU copy of one chunk
+        // overlaps the DMA of the previous one (a direct pageable hipMemcpy reached 4.5 GB/s)
+        const size_t CH = (size_t)32 << 20;
+        if (!ctx->pin[0]) {
+            for (int i = 0; i < 2; ++i) {
+                CK(hipHostMalloc(&ctx->pin[i], CH, hipHostMallocDefault));
+                CK(hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
+            }
+        }
+        int slot = 0;
+        for (u64 off = 0; off < nbytes; off += CH, slot ^= 1) {
+            const size_t len = (size_t)std::min<u64>(CH, nbytes - off);
+            if (ctx->pin_used[slot]) CK(hipEventSynchronize(ctx->pin_ev[slot]));
+            std::memcpy(ctx->pin[slot], bytes + off, len);
+            CK(hipMemcpyAsync(dst + ctx->reads_len + off, ctx->pin[slot], len, hipMemcpyHostToDevice, ctx->stream));
+            CK(hipEventRecord(ctx->pin_ev[slot], ctx->stream));
+            ctx->pin_used[slot] = true;
+        }
+    }
     CK(hipMemsetAsync(dst + ctx->reads_len + nbytes, '\n', 1, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     ctx->reads_len += nbytes + 1;
     ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len;
+    return DSKGPU_OK;
+}
+
+int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes) {
+    if (!ctx) return DSKGPU_E_ARG;
+    CK(hipSetDevice(ctx->cfg.device));
+    if (nbytes + 1 <= ctx->reads_own.cap) return DSKGPU_OK;
+    DevBuf nb;
+    CK(nb.ensure(nbytes + 1));
+    if (ctx->reads_len) CK(hipMemcpyAsync(nb.p, ctx->reads_own.p, ctx->reads_len, hipMemcpyDeviceToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->reads_own.release();
+    ctx->reads_own = nb;
+    if (ctx->reads_len) ctx->d_reads = nb.as<uint8_t>();
     return DSKGPU_OK;
 }
 

@@ -65,7 +65,7 @@ SOLIDITY = {"sum": 0, "min": 1, "max": 2, "one": 3, "all": 4, "custom": 5}
 # every symbol include/dskgpu.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "dskgpu_create", "dskgpu_destroy", "dskgpu_last_error", "dskgpu_version", "dskgpu_set_stream",
-    "dskgpu_push_reads", "dskgpu_set_reads_device", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
+    "dskgpu_push_reads", "dskgpu_reserve_reads", "dskgpu_set_reads_device", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
     "dskgpu_count", "dskgpu_mg_scatter",
     "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_get_stats", "dskgpu_histogram",
     "dskgpu_num_partitions", "dskgpu_partition_size", "dskgpu_partition_copy", "dskgpu_result_device",
@@ -100,7 +100,8 @@ def load_library():
     lib.dskgpu_version.argtypes = []
     lib.dskgpu_version.restype = C.c_char_p
     lib.dskgpu_set_stream.argtypes = [vp, vp]
-    lib.dskgpu_push_reads.argtypes = [vp, C.c_char_p, u64]
+    lib.dskgpu_push_reads.argtypes = [vp, vp, u64]
+    lib.dskgpu_reserve_reads.argtypes = [vp, u64]
     lib.dskgpu_set_reads_device.argtypes = [vp, vp, u64]
     lib.dskgpu_count.argtypes = [vp]
     lib.dskgpu_next_bank.argtypes = [vp]
@@ -186,8 +187,17 @@ class KmerCounter:
         self.close()
 
     # -- input
-    def push_reads(self, data: bytes) -> None:
-        self._ck(self._lib.dskgpu_push_reads(self._h, data, len(data)))
+    def push_reads(self, data) -> None:
+        """data: bytes, or a C-contiguous uint8 numpy array (no copy)."""
+        if isinstance(data, (bytes, bytearray)):
+            buf = (C.c_char * len(data)).from_buffer_copy(data) if isinstance(data, bytes) else (C.c_char * len(data)).from_buffer(data)
+            self._ck(self._lib.dskgpu_push_reads(self._h, C.addressof(buf), len(data)))
+        else:
+            arr = np.ascontiguousarray(data, dtype=np.uint8)
+            self._ck(self._lib.dskgpu_push_reads(self._h, arr.ctypes.data, arr.size))
+
+    def reserve_reads(self, nbytes: int) -> None:
+        self._ck(self._lib.dskgpu_reserve_reads(self._h, nbytes))
 
     def set_reads_device(self, ptr: int, nbytes: int) -> None:
         self._ck(self._lib.dskgpu_set_reads_device(self._h, C.c_void_p(ptr), nbytes))

@@ -29,6 +29,7 @@ public:
     virtual ~ICountBackend() {}
     virtual std::string name() const = 0;
     virtual void configure(const CountConfig& cfg) = 0;
+    virtual void reserve(uint64_t nbytes) {}                  // optional hint: total read-stream bytes to come
     virtual void push(const char* data, size_t nbytes) = 0;   // read-stream chunk, whole records
     virtual void nextBank() = 0;                              // what was pushed so far is one bank (comma-separated input)
     virtual void finish() = 0;                                // run the count; results valid afterwards

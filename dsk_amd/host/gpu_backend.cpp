@@ -24,6 +24,7 @@ public:
         int rc = dskgpu_create(&g, &ctx_);
         if (rc != DSKGPU_OK) { std::string m = dskgpu_last_error(nullptr); ctx_ = nullptr; throw Exception("GPU engine: %s (code %d)", m.c_str(), rc); }
     }
+    void reserve(uint64_t n) override { ck(dskgpu_reserve_reads(ctx_, n)); }
     void push(const char* data, size_t n) override { ck(dskgpu_push_reads(ctx_, data, n)); }
     void nextBank() override { ck(dskgpu_next_bank(ctx_)); }
     void finish() override { ck(dskgpu_count(ctx_)); }

@@ -130,6 +130,15 @@ void SortingCountBase::execute() {
     be->configure(cfg);
     uint64_t nbytes = 0;
     const double t1 = now_s();
+    {   // size the device read buffer once: plain files hold at most their size in sequence bytes, gzip ~4x
+        uint64_t hint = 0;
+        for (const std::string& f : bank_->files()) {
+            const bool gz = f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0;
+            std::unique_ptr<IBank> one(Bank::open(f));
+            hint += one->getSize() * (gz ? 4 : 1);
+        }
+        be->reserve(hint + 4096);
+    }
     uint64_t nseq = 0;
     std::vector<IBank*> subs = bank_->banks();   // one bank per comma-separated input (README.md:52-58)
     const bool per_bank = cfg.solidity_kind != 0 || cfg.histo2d;

@@ -90,6 +90,8 @@ int dskgpu_set_stream(dskgpu_ctx* ctx, void* hip_stream);
 /* Append host bytes of the read stream (copied to the device; may be called
  * repeatedly; a separator is implied between calls). */
 int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes);
+/* Optional: size the device-side read buffer once (e.g. from Bank::getSize) instead of growing it push by push. */
+int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes);
 /* Use a read stream already resident in HBM (caller keeps ownership and must
  * keep it alive until dskgpu_count returns).  Replaces any pushed reads. */
 int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes);
