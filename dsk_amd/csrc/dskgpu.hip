@@ -11,6 +11,7 @@
 
 #include "../../include/dskgpu.h"
 #include "kernels.h"
+#include "superkmer.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -76,6 +77,11 @@ struct dskgpu_ctx {
     DevBuf u_lo, u_hi, u_val, s_lo, s_hi, s_val, m_flag, m_pos, m_sum, gh2d;
     std::vector<u64> hist2d;
     std::vector<u32> h_starts;
+    // multi-GPU exchange as super-k-mer records (superkmer.h)
+    bool sk_mode = false, sk_prepared = false;
+    SkParams sk_sp{};
+    DevBuf sk_sums, sk_cbase, sk_keys;
+    std::vector<u32> h_sk_sums; std::vector<u64> h_sk_cbase;
     u32 h_back[4] = {0}; u64 h_stats[4] = {0};   // host landing zone of the async size read-back
     std::vector<ChunkDesc> h_descs1;
     u32 h_sc[SC_COUNT] = {0};      // host mirror of the device scalars (kept alive across async copies)
@@ -618,6 +624,102 @@ int mg_scatter_impl(dskgpu_ctx* ctx, void* d_send, uint64_t* send_words) {
     return DSKGPU_OK;
 }
 
+// ---- multi-GPU exchange as super-k-mer records (superkmer.h)
+// Sender, step 1: encode + count the records per (owner, chunk) + scan.  Leaves the record range of every
+// owner in h_starts; the exact send size is known before the caller allocates the send buffer.
+int sk_prepare(dskgpu_ctx* ctx) {
+    ctx->st_names.clear(); ctx->st_ms.clear(); ctx->marks.clear(); ctx->ev_used = 0;
+    ctx->sk_prepared = false;
+    if (ctx->n_bytes >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "read shard too large for 32-bit record offsets");
+    ctx->mark("start");
+    u64 nwords = 0;
+    int rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords);
+    if (rc) return rc;
+    ctx->mark("encode");
+    SkParams& sp = ctx->sk_sp;
+    sp.ngroups = nwords * 2;
+    sp.ntiles = std::max<u64>(1, (sp.ngroups + SK_GROUPS - 1) / SK_GROUPS);
+    u64 nch = std::min<u64>(sp.ntiles, (u64)ctx->num_cu * 8);
+    const u64 tpc = (sp.ntiles + nch - 1) / nch;
+    nch = (sp.ntiles + tpc - 1) / tpc;
+    sp.tiles_per_chunk = (u32)tpc; sp.nchunks = (u32)nch;
+    const u64 M = (u64)sp.G * nch;
+    CK(ctx->scalars.ensure(SC_COUNT * 4));
+    u32* h_sc = ctx->h_sc;
+    std::memset(h_sc, 0, sizeof(ctx->h_sc));
+    h_sc[SC_MLEN1] = (u32)M;
+    u32* sc = ctx->scalars.as<u32>();
+    CK(hipMemcpyAsync(sc, h_sc, sizeof(ctx->h_sc), hipMemcpyHostToDevice, ctx->stream));
+    CK(ctx->mat1.ensure((M + 1) * 4));
+    hipLaunchKernelGGL(k_sk_hist, dim3((unsigned)nch), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, ctx->mat1.as<u32>());
+    CKL("k_sk_hist");
+    ctx->mark("mg_hist");
+    if ((rc = run_scan(ctx, ctx->mat1.as<u32>(), sc + SC_MLEN1, M))) return rc;
+    ctx->h_starts.assign(sp.G + 1, 0);
+    for (u32 o = 0; o <= sp.G; ++o)
+        CK(hipMemcpyAsync(&ctx->h_starts[o], ctx->mat1.as<u32>() + (u64)o * nch, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->resolve_marks();
+    ctx->sk_prepared = true;
+    return DSKGPU_OK;
+}
+
+// Sender, step 2: write the records, grouped by owner, into the caller's buffer.
+int sk_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t* send_words) {
+    int rc;
+    if (!ctx->sk_prepared && (rc = sk_prepare(ctx))) return rc;
+    const SkParams& sp = ctx->sk_sp;
+    if (capacity_words < (u64)ctx->h_starts[sp.G] * sp.R) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
+    ctx->marks.clear(); ctx->ev_used = 0;
+    ctx->mark("start");
+    hipLaunchKernelGGL(k_sk_scatter, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
+                       ctx->mat1.as<u32>(), static_cast<u64*>(d_send));
+    CKL("k_sk_scatter");
+    ctx->mark("mg_scatter");
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->resolve_marks();
+    for (u32 o = 0; o < sp.G; ++o) send_words[o] = (u64)(ctx->h_starts[o + 1] - ctx->h_starts[o]) * sp.R;
+    ctx->sk_prepared = false;      // packed/mat1 are scratch of the next call
+    return DSKGPU_OK;
+}
+
+// Receiver: records -> dense mixed keys -> the ordinary partition + count over a key array.
+template <int W>
+int sk_count(dskgpu_ctx* ctx, const u64* d_rec, u64 recv_words) {
+    typedef typename KeyT<W>::T Key;
+    const u32 R = ctx->sk_sp.R;
+    if (recv_words % R) return fail(ctx, DSKGPU_E_ARG, "recv_words is not a whole number of super-k-mer records");
+    const u64 nrec = recv_words / R;
+    ctx->marks.clear(); ctx->ev_used = 0;
+    ctx->mark("start");
+    u64 total = 0;
+    if (nrec) {
+        u64 nch = std::min<u64>((nrec + SKX_NT - 1) / SKX_NT, (u64)ctx->num_cu * 16);
+        u64 rpc = (nrec + nch - 1) / nch;
+        rpc = (rpc + SKX_NT - 1) / SKX_NT * SKX_NT;
+        nch = (nrec + rpc - 1) / rpc;
+        if (rpc * 16 >= 0xFFFFFFFFull) return fail(ctx, DSKGPU_E_ARG, "too many records per chunk");
+        CK(ctx->sk_sums.ensure(nch * 4)); CK(ctx->sk_cbase.ensure(nch * 8));
+        ctx->h_sk_sums.assign(nch, 0); ctx->h_sk_cbase.assign(nch, 0);
+        hipLaunchKernelGGL(k_sk_count, dim3((unsigned)nch), dim3(SKX_NT), 0, ctx->stream, d_rec, nrec, R, (u32)rpc, ctx->sk_sums.as<u32>());
+        CKL("k_sk_count");
+        CK(hipMemcpyAsync(ctx->h_sk_sums.data(), ctx->sk_sums.p, nch * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        for (u64 c = 0; c < nch; ++c) { ctx->h_sk_cbase[c] = total; total += ctx->h_sk_sums[c]; }
+        CK(hipMemcpyAsync(ctx->sk_cbase.p, ctx->h_sk_cbase.data(), nch * 8, hipMemcpyHostToDevice, ctx->stream));
+        CK(ctx->sk_keys.ensure((total + 1) * sizeof(Key)));
+        hipLaunchKernelGGL(k_sk_expand<W>, dim3((unsigned)nch), dim3(SKX_NT), 0, ctx->stream, d_rec, nrec, R, (int)ctx->cfg.kmer_size, (u32)rpc,
+                           ctx->sk_cbase.as<u64>(), ctx->sk_keys.as<Key>());
+        CKL("k_sk_expand");
+    } else {
+        CK(ctx->sk_keys.ensure(sizeof(Key)));
+    }
+    ctx->mark("mg_expand");
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->resolve_marks();
+    return run_pipeline<W>(ctx, false, ctx->sk_keys.as<Key>(), total);
+}
+
 }  // namespace
 
 namespace {
@@ -755,6 +857,13 @@ int dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out) {
     if (ctx->cfg.minimizer_size == 0) ctx->cfg.minimizer_size = 10;
     ctx->W = cfg->kmer_size <= 32 ? 1 : 2;
     ctx->max_keys_per_pass = (u64)cfg->max_pass_mkeys * 1000000ull;
+    // super-k-mer records need >= 16 m-mers per window (superkmer.h); shorter k-mers travel as explicit keys
+    ctx->sk_mode = ws > 1 && cfg->kmer_size >= 20 && !(cfg->flags & DSKGPU_F_MG_EXPLICIT);
+    if (ctx->sk_mode) {
+        ctx->sk_sp.k = cfg->kmer_size; ctx->sk_sp.G = ws;
+        ctx->sk_sp.m = std::min<u32>(std::min<u32>(ctx->cfg.minimizer_size, 16u), cfg->kmer_size - 15u);
+        ctx->sk_sp.R = sk_record_words(cfg->kmer_size);
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -772,7 +881,8 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
                       &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats,
                       &ctx->out_lo, &ctx->out_hi, &ctx->out_ab, &ctx->srt_lo, &ctx->srt_hi, &ctx->srt_ab, &ctx->srt_tmp,
                       &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->abund2, &ctx->acc_lo, &ctx->acc_hi, &ctx->acc_ab, &ctx->u_lo, &ctx->u_hi, &ctx->u_val,
-                      &ctx->s_lo, &ctx->s_hi, &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d};
+                      &ctx->s_lo, &ctx->s_hi, &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,
+                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) { if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]); if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]); }
@@ -830,7 +940,7 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
     CK(hipMemsetAsync(dst + ctx->reads_len + nbytes, '\n', 1, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     ctx->reads_len += nbytes + 1;
-    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len;
+    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->sk_prepared = false;
     return DSKGPU_OK;
 }
 
@@ -850,7 +960,7 @@ int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes) {
 
 int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes) {
     if (!ctx || (!d_bytes && nbytes)) return DSKGPU_E_ARG;
-    ctx->d_reads = static_cast<const uint8_t*>(d_bytes);
+    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->sk_prepared = false;
     ctx->n_bytes = nbytes;
     ctx->reads_len = 0;
     ctx->bank_ends.clear();
@@ -892,23 +1002,30 @@ int dskgpu_histogram2d(const dskgpu_ctx* ctx, uint64_t* out, uint32_t nrows) {
     return DSKGPU_OK;
 }
 
-uint64_t dskgpu_mg_send_capacity_words(const dskgpu_ctx* ctx) {
-    return ctx ? (ctx->n_bytes + 1) * (u64)ctx->W : 0;
+uint64_t dskgpu_mg_send_capacity_words(dskgpu_ctx* ctx) {
+    if (!ctx) return 0;
+    if (!ctx->sk_mode) return (ctx->n_bytes + 1) * (u64)ctx->W;
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return 0;
+    if (!ctx->sk_prepared && sk_prepare(ctx) != DSKGPU_OK) return 0;     // the error text stays in the ctx; dskgpu_mg_scatter reports it
+    return (u64)ctx->h_starts[ctx->sk_sp.G] * ctx->sk_sp.R + 1;
 }
 
 int dskgpu_mg_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t* send_words) {
     if (!ctx || !d_send || !send_words) return DSKGPU_E_ARG;
     if (ctx->cfg.world_size < 2) return fail(ctx, DSKGPU_E_STATE, "dskgpu_mg_scatter needs world_size >= 2");
-    if (capacity_words < dskgpu_mg_send_capacity_words(ctx)) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
     CK(hipSetDevice(ctx->cfg.device));
+    if (ctx->sk_mode) return sk_scatter(ctx, d_send, capacity_words, send_words);
+    if (capacity_words < dskgpu_mg_send_capacity_words(ctx)) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
     return ctx->W == 1 ? mg_scatter_impl<1>(ctx, d_send, send_words) : mg_scatter_impl<2>(ctx, d_send, send_words);
 }
 
 int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words) {
     if (!ctx || (!d_recv && recv_words)) return DSKGPU_E_ARG;
-    if (recv_words % (u64)ctx->W) return fail(ctx, DSKGPU_E_ARG, "recv_words is not a whole number of k-mer records");
     CK(hipSetDevice(ctx->cfg.device));
     ctx->stats = dskgpu_stats{};
+    if (ctx->sk_mode)
+        return ctx->W == 1 ? sk_count<1>(ctx, static_cast<const u64*>(d_recv), recv_words) : sk_count<2>(ctx, static_cast<const u64*>(d_recv), recv_words);
+    if (recv_words % (u64)ctx->W) return fail(ctx, DSKGPU_E_ARG, "recv_words is not a whole number of k-mer records");
     if (ctx->W == 1) return run_pipeline<1>(ctx, false, static_cast<const u64*>(d_recv), recv_words);
     return run_pipeline<2>(ctx, false, static_cast<const K2*>(d_recv), recv_words / 2);
 }

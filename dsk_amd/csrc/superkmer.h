@@ -1,0 +1,289 @@
+// superkmer.h -- super-k-mer records for the multi-GPU exchange (gfx950, wave64).
+//
+// DSK v2 partitions k-mers by MINIMIZER and spills runs of consecutive k-mers that share one
+// ("super-k-mers") 2-bit packed (CHANGELOG.md:13; gatb-core's Sequence2SuperKmer, named at
+// scripts/quick-build.sh:53-57).  Here the same idea is the wire format between GPUs: the owner of
+// a k-mer is a function of the minimizer of its window, so consecutive windows mostly share an
+// owner and travel as one record of packed bases instead of one 8/16-byte key per k-mer.
+//
+//   sender   : k_sk_hist -> scan -> k_sk_scatter      (reads only the 2-bit stream; never forms k-mers)
+//   receiver : k_sk_count -> prefix -> k_sk_expand    (records -> dense array of mixed keys)
+//
+// Minimizer order: the m-mers of a window are compared by a 32-bit hash of their canonical value
+// (a random order balances the owners better than the lexicographic one, which favours poly-A);
+// owner = low 16 bits of the winning hash scaled to [0, G).  Results never depend on this choice:
+// any function of the window that is the same on every rank is a valid owner map.
+//
+// Record = R 64-bit words (R = 2 for k <= 45, 3 for k <= 64):
+//   bases  : n + k - 1 bases, 2 bits each, first base in bits 63..62 of word 0, continuing MSB first
+//   header : low 8 bits of word R-1 = n, the number of k-mers (1..16)
+// One thread owns 16 consecutive window end positions and cuts records at its own borders, so a
+// record never spans threads: 2 * (k + 15) + 8 <= 64 * R.
+#pragma once
+#include "kmer_device.h"
+
+#define SK_NT 512
+#define SK_HALO 4                         // leading groups of a tile that only contribute m-mer hashes (64 positions >= k - m)
+#define SK_GROUPS (SK_NT - SK_HALO)       // groups (16 window ends each) a tile emits records for
+#define SK_MAX_OWNERS 64
+
+struct SkParams {
+    u64 ngroups;          // 2 * packed words
+    u64 ntiles;
+    u32 tiles_per_chunk, nchunks;
+    u32 k, m, G, R;
+};
+
+__host__ __device__ __forceinline__ u32 sk_record_words(u32 k) { return (2u * (k + 15u) + 8u + 63u) / 64u; }
+
+__device__ __forceinline__ u32 fmix32(u32 h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h;
+}
+
+__device__ __forceinline__ void sk_lds_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// What one thread knows about its 16 windows after the minimizer phase.
+struct SkThread {
+    u32 vm;               // bit i: window i is a valid k-mer
+    u32 bm;               // bit i: a record starts at window i
+    u64 ow_lo, ow_hi;     // owner of window i in byte i (lo: 0..7, hi: 8..15)
+};
+
+__device__ __forceinline__ u32 sk_owner(const SkThread& s, int i) {
+    return (u32)((i < 8 ? s.ow_lo >> (8 * i) : s.ow_hi >> (8 * (i - 8))) & 0xFFu);
+}
+
+// Minimizer phase of one tile.  Thread t handles group gfirst + t.  H = SK_NT * 17 words of LDS.
+__device__ __forceinline__ SkThread sk_tile(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                            const SkParams& sp, long long gfirst, u32* H) {
+    const int t = threadIdx.x;
+    const long long g = gfirst + t;
+    const bool live = g >= 0 && (u64)g < sp.ngroups;
+    const int k = (int)sp.k, m = (int)sp.m;
+    u32 h[16];
+    u64 wi = 0; int t0 = 0;
+    if (live) {
+        wi = (u64)g >> 1; t0 = (int)(g & 1) << 4;
+        const u64 cur = packed[wi];
+        const u64 prev = wi ? packed[wi - 1] : 0ull;
+        // x = the 32 bases ending at the group's last position, first base most significant
+        const u64 x = t0 ? cur : ((prev << 32) | (cur >> 32));
+        const u64 rcx = rev_pairs(x) ^ 0xAAAAAAAAAAAAAAAAull;
+        const u32 mmask = (m == 16) ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const u32 fw = (u32)(x >> (2 * (15 - j))) & mmask;          // m-mer ending at position j of the group
+            const u32 rv = (u32)(rcx >> (2 * (17 + j - m))) & mmask;    // its reverse complement
+            h[j] = fmix32(fw < rv ? fw : rv);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) h[j] = 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) H[17 * t + j] = h[j];                   // 1 pad word per 16: lane stride 17, conflict free
+    sk_lds_barrier();
+    SkThread r; r.vm = 0; r.bm = 0; r.ow_lo = 0; r.ow_hi = 0;
+    if (live && t >= SK_HALO) {
+        const int w = k - m + 1;                                         // m-mers per window, 16 <= w <= 64
+        const int q0 = 16 * t;                                           // tile-local position of window 0
+        // window i covers hash positions [q0 + i - w + 1, q0 + i]:
+        //   L = [q0 - w + 1, q0 - w + 15] (suffix from i), common = [q0 - w + 16, q0], R = own h[1..i]
+        u32 sl[15];
+#pragma unroll
+        for (int j = 0; j < 15; ++j) { const int i = q0 - w + 1 + j; sl[j] = H[i + (i >> 4)]; }
+#pragma unroll
+        for (int j = 13; j >= 0; --j) sl[j] = sl[j] < sl[j + 1] ? sl[j] : sl[j + 1];
+        u32 cm = h[0];
+        for (int c = q0 - w + 16; c < q0; ++c) { const u32 v = H[c + (c >> 4)]; cm = v < cm ? v : cm; }
+        // validity of the 16 windows: no invalid base among the last k (frame of 96 bases: words wi-2 .. wi)
+        const u32 ic = inval[wi];
+        const u32 i1 = wi >= 1 ? inval[wi - 1] : 0xFFFFFFFFu;
+        const u32 i2 = wi >= 2 ? inval[wi - 2] : 0xFFFFFFFFu;
+        const u64 inv_lo = ((u64)i1 << 32) | ic;
+        u32 pr = 0xFFFFFFFFu, prev_owner = 0xFFFFu; bool prev_valid = false;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i > 0) pr = h[i] < pr ? h[i] : pr;
+            u32 mn = cm < pr ? cm : pr;
+            if (i < 15) mn = sl[i] < mn ? sl[i] : mn;
+            const u32 owner = ((mn & 0xFFFFu) * sp.G) >> 16;
+            const int b0 = 31 - (t0 + i);
+            const u64 lo_bits = (k + b0 >= 64) ? (~0ull << b0) : (((1ull << k) - 1ull) << b0);
+            const int over = k + b0 - 64;
+            const u32 hi_bits = over > 0 ? ((over >= 32) ? 0xFFFFFFFFu : ((1u << over) - 1u)) : 0u;
+            const bool valid = ((inv_lo & lo_bits) == 0) && ((i2 & hi_bits) == 0);
+            if (valid) {
+                r.vm |= 1u << i;
+                if (!prev_valid || owner != prev_owner) r.bm |= 1u << i;
+            }
+            if (i < 8) r.ow_lo |= (u64)owner << (8 * i); else r.ow_hi |= (u64)owner << (8 * (i - 8));
+            prev_valid = valid; prev_owner = owner;
+        }
+    }
+    return r;
+}
+
+// number of k-mers of the record starting at window i
+__device__ __forceinline__ u32 sk_run_length(const SkThread& s, int i) {
+    const u32 stop = ((~s.vm | s.bm) & 0xFFFFu) >> (i + 1);
+    return stop ? (u32)__builtin_ctz(stop) + 1u : (u32)(16 - i);
+}
+
+// ---------------------------------------------------------------- sender: records per (owner, chunk)
+__global__ __launch_bounds__(SK_NT) void k_sk_hist(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                                   SkParams sp, u32* __restrict__ mat) {
+    __shared__ u32 H[SK_NT * 17];
+    __shared__ u32 cnt[SK_MAX_OWNERS];
+    const u32 c = blockIdx.x;
+    if (threadIdx.x < SK_MAX_OWNERS) cnt[threadIdx.x] = 0;
+    const u64 tbeg = (u64)c * sp.tiles_per_chunk;
+    const u64 tend = tbeg + sp.tiles_per_chunk < sp.ntiles ? tbeg + sp.tiles_per_chunk : sp.ntiles;
+    for (u64 tile = tbeg; tile < tend; ++tile) {
+        const SkThread s = sk_tile(packed, inval, sp, (long long)(tile * SK_GROUPS) - SK_HALO, H);
+        u32 bm = s.bm;
+        while (bm) {
+            const int i = __builtin_ctz(bm); bm &= bm - 1;
+            atomicAdd(&cnt[sk_owner(s, i)], 1u);
+        }
+        sk_lds_barrier();
+    }
+    __syncthreads();
+    if (threadIdx.x < sp.G) mat[(u64)threadIdx.x * sp.nchunks + c] = cnt[threadIdx.x];
+}
+
+// ---------------------------------------------------------------- sender: write the records
+// `mat` holds the exclusive scan of the (owner-major) count matrix: record index of (owner, chunk).
+__global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                                      SkParams sp, const u32* __restrict__ mat, u64* __restrict__ send) {
+    __shared__ u32 H[SK_NT * 17];
+    __shared__ u32 cur[SK_MAX_OWNERS];
+    const u32 c = blockIdx.x;
+    if (threadIdx.x < sp.G) cur[threadIdx.x] = mat[(u64)threadIdx.x * sp.nchunks + c];
+    const u64 tbeg = (u64)c * sp.tiles_per_chunk;
+    const u64 tend = tbeg + sp.tiles_per_chunk < sp.ntiles ? tbeg + sp.tiles_per_chunk : sp.ntiles;
+    const int k = (int)sp.k;
+    const u32 R = sp.R;
+    for (u64 tile = tbeg; tile < tend; ++tile) {
+        const long long gfirst = (long long)(tile * SK_GROUPS) - SK_HALO;
+        const SkThread s = sk_tile(packed, inval, sp, gfirst, H);
+        u32 bm = s.bm;
+        if (bm) {
+            const u64 g = (u64)(gfirst + threadIdx.x);
+            const u64 wi = g >> 1; const int t0 = (int)(g & 1) << 4;
+            const u64 w0 = packed[wi];
+            const u64 w1 = wi >= 1 ? packed[wi - 1] : 0ull;
+            const u64 w2 = wi >= 2 ? packed[wi - 2] : 0ull;
+            while (bm) {
+                const int i = __builtin_ctz(bm); bm &= bm - 1;
+                const u32 n = sk_run_length(s, i);
+                const u32 slot = atomicAdd(&cur[sk_owner(s, i)], 1u);
+                // bases [bs, bs + nb) of the 96-base frame (w2 : w1 : w0), shifted to the top of the record
+                const int bs = 64 + t0 + i - k + 1;
+                const int nb = (int)n + k - 1;
+                const int sh = 2 * bs, ws = sh >> 6, b = sh & 63;
+                const u64 a = ws == 0 ? w2 : ws == 1 ? w1 : w0;
+                const u64 bb = ws == 0 ? w1 : ws == 1 ? w0 : 0ull;
+                const u64 cc = ws == 0 ? w0 : 0ull;
+                u64 o[3];
+                o[0] = b ? (a << b) | (bb >> (64 - b)) : a;
+                o[1] = b ? (bb << b) | (cc >> (64 - b)) : bb;
+                o[2] = b ? (cc << b) : cc;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int keep = 2 * nb - 64 * j;
+                    o[j] = keep <= 0 ? 0ull : keep >= 64 ? o[j] : (o[j] & ~(~0ull >> keep));
+                }
+                u64* dst = send + (u64)slot * R;
+                if (R == 2) { dst[0] = o[0]; dst[1] = o[1] | n; }
+                else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2] | n; }
+            }
+        }
+        sk_lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------- receiver: k-mers per chunk of records
+#define SKX_NT 256
+__global__ __launch_bounds__(SKX_NT) void k_sk_count(const u64* __restrict__ rec, u64 nrec, u32 R, u32 rpc, u32* __restrict__ sums) {
+    __shared__ u32 ws[SKX_NT / 64];
+    const u64 rbeg = (u64)blockIdx.x * rpc;
+    const u64 rend = rbeg + rpc < nrec ? rbeg + rpc : nrec;
+    u32 s = 0;
+    for (u64 r = rbeg + threadIdx.x; r < rend; r += SKX_NT) s += (u32)(rec[r * R + R - 1] & 0xFFu);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 t = 0; for (int i = 0; i < SKX_NT / 64; ++i) t += ws[i]; sums[blockIdx.x] = t; }
+}
+
+// k-mer `j` of a staged record -> mixed key (same key as tile_keys_reads would give for that window)
+__device__ __forceinline__ u64 sk_key1(const u64* r, int j, int k) {
+    const u64 x = j ? (r[0] << (2 * j)) | (r[1] >> (64 - 2 * j)) : r[0];
+    const u64 kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
+    const u64 fwd = x >> (64 - 2 * k);
+    const u64 rc = (rev_pairs(fwd) >> (64 - 2 * k)) ^ (0xAAAAAAAAAAAAAAAAull & kmask);
+    return kmix(fwd < rc ? fwd : rc);
+}
+__device__ __forceinline__ K2 sk_key2(const u64* r, int j, int k) {
+    const u64 y0 = j ? (r[0] << (2 * j)) | (r[1] >> (64 - 2 * j)) : r[0];
+    const u64 y1 = j ? (r[1] << (2 * j)) | (r[2] >> (64 - 2 * j)) : r[1];
+    const int sh = 128 - 2 * k;                                // 0..62
+    const int kh = 2 * k - 64;
+    const u64 hmask = (kh == 64) ? ~0ull : ((1ull << kh) - 1);
+    const u64 flo = sh ? (y1 >> sh) | (y0 << (64 - sh)) : y1;
+    const u64 fhi = sh ? (y0 >> sh) : y0;
+    u64 rhi = rev_pairs(flo), rlo = rev_pairs(fhi);
+    if (sh) { rlo = (rlo >> sh) | (rhi << (64 - sh)); rhi >>= sh; }
+    rlo ^= 0xAAAAAAAAAAAAAAAAull;
+    rhi ^= (0xAAAAAAAAAAAAAAAAull & hmask);
+    const bool fl = fhi < rhi || (fhi == rhi && flo < rlo);
+    K2 o; o.hi = fl ? fhi : rhi; o.lo = fl ? flo : rlo;
+    kmix2(o.hi, o.lo);
+    return o;
+}
+
+// ---------------------------------------------------------------- receiver: records -> dense mixed keys
+// One block per chunk of records.  A tile of SKX_NT records is staged in LDS together with a slot map
+// (output slot -> record, k-mer index), then every thread builds ONE k-mer per trip straight from the
+// staged bases (a funnel shift + rev_pairs; no rolling, no idle lanes) and stores it coalesced.
+template <int W>
+__global__ __launch_bounds__(SKX_NT) void k_sk_expand(const u64* __restrict__ rec, u64 nrec, u32 R, int k, u32 rpc,
+                                                      const u64* __restrict__ chunk_base, typename KeyT<W>::T* __restrict__ out) {
+    __shared__ u64 srec[SKX_NT * 3];
+    __shared__ unsigned short smap[SKX_NT * 16];
+    __shared__ u32 wsum[SKX_NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 rbeg = (u64)blockIdx.x * rpc;
+    const u64 rend = rbeg + rpc < nrec ? rbeg + rpc : nrec;
+    u64 obase = chunk_base[blockIdx.x];
+    for (u64 r0 = rbeg; r0 < rend; r0 += SKX_NT) {
+        const u64 r = r0 + tid;
+        u32 n = 0;
+        if (r < rend) {
+            const u64* p = rec + r * R;
+            const u64 a = p[0], b = p[1], c = (R == 3) ? p[2] : 0ull;
+            srec[tid * 3] = a; srec[tid * 3 + 1] = b; srec[tid * 3 + 2] = c;
+            n = (u32)((R == 3 ? c : b) & 0xFFu);
+        }
+        u32 inc = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 v = __shfl_up(inc, d); if (lane >= d) inc += v; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        u32 off = inc - n, total = 0;
+#pragma unroll
+        for (int x = 0; x < SKX_NT / 64; ++x) { const u32 v = wsum[x]; if (x < wave) off += v; total += v; }
+        for (u32 j = 0; j < n; ++j) smap[off + j] = (unsigned short)((tid << 4) | j);
+        __syncthreads();
+        for (u32 i = tid; i < total; i += SKX_NT) {
+            const u32 e = smap[i];
+            const u64* rr = srec + (e >> 4) * 3;
+            if (W == 1) reinterpret_cast<u64*>(out)[obase + i] = sk_key1(rr, (int)(e & 15u), k);
+            else reinterpret_cast<K2*>(out)[obase + i] = sk_key2(rr, (int)(e & 15u), k);
+        }
+        obase += total;
+        __syncthreads();
+    }
+}

@@ -60,6 +60,7 @@ class _Stats(C.Structure):
 F_TIMING = 1
 F_NO_SORT = 2
 F_HISTO2D = 4
+F_MG_EXPLICIT = 8
 SOLIDITY = {"sum": 0, "min": 1, "max": 2, "one": 3, "all": 4, "custom": 5}
 
 # every symbol include/dskgpu.h declares (checked by tests/test_abi.py)
@@ -136,7 +137,7 @@ class KmerCounter:
                  histo_max: int = 10000, device: int = 0, nb_partitions: int = 0, timing: bool = False,
                  sort: bool = True, world_size: int = 1, rank: int = 0, stream: Optional[int] = None,
                  minimizer_size: int = 0, max_pass_mkeys: int = 0, solidity_kind: str = "sum", solidity_custom: int = 0,
-                 histo2d: bool = False):
+                 histo2d: bool = False, mg_explicit: bool = False):
         self._lib = load_library()
         cfg = _Config()
         cfg.kmer_size = kmer_size
@@ -147,7 +148,7 @@ class KmerCounter:
         cfg.nb_partitions = nb_partitions
         cfg.minimizer_size = minimizer_size
         cfg.max_pass_mkeys = max_pass_mkeys
-        cfg.flags = (F_TIMING if timing else 0) | (0 if sort else F_NO_SORT) | (F_HISTO2D if histo2d else 0)
+        cfg.flags = (F_TIMING if timing else 0) | (0 if sort else F_NO_SORT) | (F_HISTO2D if histo2d else 0) | (F_MG_EXPLICIT if mg_explicit else 0)
         cfg.solidity_kind = SOLIDITY[solidity_kind]
         cfg.solidity_custom = solidity_custom
         cfg.world_size = world_size
@@ -219,7 +220,10 @@ class KmerCounter:
         self._ck(self._lib.dskgpu_count(self._h))
 
     def mg_send_capacity_words(self) -> int:
-        return int(self._lib.dskgpu_mg_send_capacity_words(self._h))
+        n = int(self._lib.dskgpu_mg_send_capacity_words(self._h))
+        if n == 0:
+            raise DskGpuError(-2, "dskgpu_mg_send_capacity_words: " + (self._lib.dskgpu_last_error(self._h) or b"").decode())
+        return n
 
     def mg_scatter(self, send_ptr: int, capacity_words: int) -> List[int]:
         counts = (C.c_uint64 * self.world_size)()

@@ -1,8 +1,9 @@
 """Multi-GPU count: one process per GPU, k-mer space sharded by owner(kmer).
 
-    rank r:  reads shard --mg_scatter--> k-mer records grouped by owner
+    rank r:  reads shard --mg_scatter--> super-k-mer records grouped by owner (owner = f(minimizer);
+                                          explicit keys for k < 20), ~2.3 B per k-mer instead of 8
              --RCCL all-to-all (torch.distributed)--> records this rank owns
-             --mg_count--> partition + hash-aggregate + histogram + solid rows
+             --mg_count--> expand + partition + hash-aggregate + histogram + solid rows
 
 The reference has no distributed mode (single process, disk partitions:
 doc/paper.tex:60-97); the owner map plays the role of its partition function

@@ -64,6 +64,7 @@ typedef struct dskgpu_config {
 
 #define DSKGPU_F_TIMING 1u        /* record per-stage HIP-event timings        */
 #define DSKGPU_F_NO_SORT 2u       /* leave solid rows unsorted (bench ablation) */
+#define DSKGPU_F_MG_EXPLICIT 8u   /* multi-GPU: exchange one explicit key per k-mer instead of super-k-mer records */
 #define DSKGPU_F_HISTO2D 4u       /* also build the 2-D histogram: bank 0 (genome) x the other banks (reads), -histo2D */
 
 /* -solidity-kind (gatb-core option; only `sum` is exercised by the reference's tests, README.md:12).
@@ -107,13 +108,18 @@ int dskgpu_set_banks(dskgpu_ctx* ctx, const uint64_t* end_offsets, uint32_t n_ba
  * solidity filter (+ sort).  Synchronous on return. */
 int dskgpu_count(dskgpu_ctx* ctx);
 
-/* Multi-GPU (world_size > 1): the k-mer space is split by owner(kmer) in
- * [0, world_size).  Step 1 writes this rank's k-mer records grouped by owner
- * into caller memory `d_send` (capacity in 8-byte words) and the per-owner
- * word counts into send_words[world_size] (host).  The caller exchanges the
- * groups (RCCL all-to-all) and hands the received records to step 2. */
+/* Multi-GPU (world_size > 1): the k-mer space is split over owners in [0, world_size).  The owner of a
+ * k-mer is a function of the MINIMIZER of its window (m = minimizer_size), so runs of consecutive k-mers
+ * share an owner and travel as one super-k-mer record of 2-bit packed bases (2-3 words for up to 16
+ * k-mers) -- DSK v2's minimizer repartition + super-k-mers (CHANGELOG.md:13) used as the wire format.
+ * For k < 20 or with DSKGPU_F_MG_EXPLICIT the records are explicit keys (1-2 words per k-mer, owner =
+ * a bit field of the mixed k-mer).  Step 1 writes this rank's records grouped by owner into caller
+ * memory `d_send` (capacity in 8-byte words) and the per-owner word counts into send_words[world_size]
+ * (host).  The caller exchanges the groups (RCCL all-to-all) and hands the received words to step 2.
+ * dskgpu_mg_send_capacity_words runs the sizing pass over the current reads and returns the words
+ * dskgpu_mg_scatter will need (0 on error). */
 int dskgpu_mg_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t* send_words);
-uint64_t dskgpu_mg_send_capacity_words(const dskgpu_ctx* ctx);   /* upper bound for d_send */
+uint64_t dskgpu_mg_send_capacity_words(dskgpu_ctx* ctx);
 int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words);
 
 /* ---- results: replace the CountProcessor outputs read back through

@@ -252,8 +252,9 @@ def test_full_size_invariants(dev, workload):
     assert n_valid == st["n_kmers"]
 
 
-@pytest.mark.parametrize("world,k", [(2, 31), (4, 27), (2, 63)])
-def test_multi_gpu_path_on_one_device(oracle, golden_dir, dev, world, k):
+@pytest.mark.parametrize("world,k,explicit", [(2, 31, False), (4, 27, False), (2, 63, False), (8, 20, False), (4, 46, False), (2, 64, False),
+                                              (2, 32, False), (2, 31, True), (2, 63, True), (4, 15, False)])
+def test_multi_gpu_path_on_one_device(oracle, golden_dir, dev, world, k, explicit):
     """dskgpu_mg_scatter / dskgpu_mg_count with the exchange done by hand: `world` contexts on the
     same GPU, each fed its shard of the reads; the union of their results must equal the oracle."""
     from dsk_amd import KmerCounter
@@ -263,11 +264,15 @@ def test_multi_gpu_path_on_one_device(oracle, golden_dir, dev, world, k):
     ctxs, sends, counts, shards = [], [], [], []
     for r in range(world):
         shard = torch.from_numpy(np.frombuffer(b"\n".join(recs[r::world]) + b"\n", dtype=np.uint8).copy()).to(dev)
-        kc = KmerCounter(kmer_size=k, abundance_min=1, world_size=world, rank=r)
+        kc = KmerCounter(kmer_size=k, abundance_min=1, world_size=world, rank=r, mg_explicit=explicit)
         kc.set_reads_device(shard.data_ptr(), shard.numel())
         send = torch.zeros(kc.mg_send_capacity_words(), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()      # the contexts run on their own streams
         c = kc.mg_scatter(send.data_ptr(), send.numel())
-        assert all(x % W == 0 for x in c)
+        records = not explicit and k >= 20          # super-k-mer records of 2 (k <= 45) or 3 words
+        assert all(x % ((2 if k <= 45 else 3) if records else W) == 0 for x in c)
+        if records:   # a record carries up to 16 k-mers: far fewer words than one key per k-mer
+            assert sum(c) < 0.6 * W * (shard.numel() - len(recs[r::world]) * k)
         ctxs.append(kc); sends.append(send); counts.append(c); shards.append(shard)
     rows_k, rows_a, hist = [], [], np.zeros(10001, np.uint64)
     for d in range(world):
@@ -276,6 +281,7 @@ def test_multi_gpu_path_on_one_device(oracle, golden_dir, dev, world, k):
             off = sum(counts[src][:d])
             parts.append(sends[src][off: off + counts[src][d]])
         recv = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
         ctxs[d].mg_count(recv.data_ptr(), recv.numel())
         kk, aa = ctxs[d].rows()
         rows_k.append(kk); rows_a.append(aa); hist += ctxs[d].histogram()

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Per-rank device time of the multi-GPU path, emulated on ONE GPU (no exchange):
+one context acts as rank 0 of `world`, scatters the bench shard (10 M x 150 bp) into records for all
+owners, then counts ALL of its own records -- the same number of k-mers a rank receives in the
+weak-scaling bench.  Prints stage times and the exchange volume per rank.
+   python tools/mg_stage_times.py [world=8] [k=31] [explicit=0] [workload=c2_10Mx150]"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dsk_amd import KmerCounter, synth
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 31
+explicit = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
+wl = sys.argv[4] if len(sys.argv) > 4 else "c2_10Mx150"
+dev = torch.device("cuda", 0)
+gl, nr, rl = synth.workload(wl)
+reads = synth.make_reads(synth.make_genome(gl, dev), nr, rl)
+torch.cuda.synchronize()
+kc = KmerCounter(kmer_size=k, abundance_min=2, world_size=world, rank=0, timing=True, mg_explicit=explicit,
+                 stream=torch.cuda.current_stream().cuda_stream)
+kc.set_reads_device(reads.data_ptr(), reads.numel())
+send = None
+for it in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    cap = kc.mg_send_capacity_words()
+    if send is None or send.numel() < cap:
+        send = torch.empty(cap, dtype=torch.int64, device=dev)
+    counts = kc.mg_scatter(send.data_ptr(), send.numel())
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    kc.mg_count(send.data_ptr(), sum(counts))
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+st = kc.stats()
+print(f"world={world} k={k} explicit={explicit}: scatter side {1e3*(t1-t0):.2f} ms, count side {1e3*(t2-t1):.2f} ms, total {1e3*(t2-t0):.2f} ms")
+print(f"  send words per owner: {counts}  ({8*sum(counts)/1e9:.2f} GB total, {8*sum(counts)/st['n_kmers']:.2f} B per k-mer; "
+      f"leaves the GPU: {8*sum(counts)*(world-1)/world/1e9:.2f} GB)")
+print("  stages:", ", ".join(f"{n} {ms:.2f}" for n, ms in kc.stage_times()))
+print("  stats:", st)
+kc.close()
