@@ -57,6 +57,7 @@ struct Stage { const char* name; hipEvent_t ev; };
 struct dskgpu_ctx {
     dskgpu_config cfg{};
     int W = 1;
+    int words_out = 1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 256;
@@ -70,11 +71,12 @@ struct dskgpu_ctx {
     DevBuf packed, inval;          // K1 output
     DevBuf bufA, bufB;             // partition ping-pong
     DevBuf mat1, mat2, sums, descs1, descs2, seg, fstart, nsolid, scalars, ghist, gstats;
-    DevBuf out_lo, out_hi, out_ab, srt_lo, srt_hi, srt_ab, srt_tmp, srt_idx, srt_idx2, srt_k, abund2, acc_lo, acc_hi, acc_ab;
+    DevBuf out_w[4], srt_w[4], acc_w[4];   // rows as struct-of-arrays: word i of every row in [i]
+    DevBuf out_ab, srt_ab, srt_tmp, srt_idx, srt_idx2, srt_k, abund2, acc_ab;
     u64 max_keys_per_pass = 0;     // 0 = as many as 32-bit offsets allow
     // multi-bank mode (solidity kinds, 2-D histogram)
     std::vector<u64> bank_ends;    // end offset of every declared bank in the read stream
-    DevBuf u_lo, u_hi, u_val, s_lo, s_hi, s_val, m_flag, m_pos, m_sum, gh2d;
+    DevBuf u_w[4], s_w[4], u_val, s_val, m_flag, m_pos, m_sum, gh2d;
     std::vector<u64> hist2d;
     std::vector<u32> h_starts;
     // multi-GPU exchange as super-k-mer records (superkmer.h)
@@ -90,7 +92,7 @@ struct dskgpu_ctx {
     bool have_result = false;
     bool sort_partial = false;
     u64 n_rows = 0;
-    const u64* res_lo = nullptr; const u64* res_hi = nullptr; const u32* res_ab = nullptr;
+    const u64* res_w[4] = {nullptr, nullptr, nullptr, nullptr}; const u32* res_ab = nullptr;
     dskgpu_stats stats{};
     std::vector<u64> hist;
 
@@ -172,7 +174,7 @@ int run_scan(dskgpu_ctx* ctx, u32* a, const u32* d_len, u64 max_len) {
 // experiment switches (timing ablations only; results are wrong when set): DSKGPU_DBG1 = level-1 scatter, DSKGPU_DBG2 = key-array scatter
 u32 dbg_flags(int src) { const char* e = getenv(src == 0 ? "DSKGPU_DBG1" : "DSKGPU_DBG2"); return e ? (u32)atoi(e) : 0u; }
 
-size_t scatter_lds(int W, u32 P) { return (size_t)(W == 1 ? Tile<1>::KEYS * 8 : Tile<2>::KEYS * 16) + (size_t)P * 16 + 4 + 17 * 4 + 16; }
+size_t scatter_lds(int W, u32 P) { return (size_t)SC_NT * (16 / W) * 8 * W + (size_t)P * 16 + 4 + 17 * 4 + 16; }
 
 template <int W, int SRC, int MODE>
 int launch_hist_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
@@ -261,7 +263,7 @@ struct Plan {
 // Final sub-partitions F = P1 * P2 sized to the input (any integer, not a power
 // of two: digits use the multiply-shift reduction of key_digit()).
 bool make_plan(u64 n_upper, int extra_bits, int W, Plan* pl) {
-    const u64 target = W == 1 ? TARGET_KEYS : TARGET_KEYS2;
+    const u64 target = W == 1 ? TARGET_KEYS : W == 2 ? TARGET_KEYS2 : TARGET_KEYS2 / 2;   // four-word keys: 1024 staged per sub-partition
     u64 F = ((n_upper + target - 1) / target) << extra_bits;
     if (F < 2) F = 2;
     if (F <= ONE_LEVEL_BINS) { pl->levels = 1; pl->P1 = (u32)F; pl->P2 = 1; }
@@ -301,64 +303,90 @@ void build_descs1(dskgpu_ctx* ctx, u64 n_units_total, u64 tile, u64 max_chunks, 
 
 namespace {
 
+// Index permutation that sorts n rows of W words (struct-of-arrays in `rows`) ascending: W stable 64-bit
+// radix passes, least significant word first.  Result in ctx->srt_idx.
+int sort_index_multiword(dskgpu_ctx* ctx, DevBuf* rows, u64 n, int W) {
+    CK(ctx->srt_k.ensure(n * 8));
+    CK(ctx->srt_idx.ensure(n * 4));
+    CK(ctx->srt_idx2.ensure(n * 4));
+    DevBuf& keys_sorted = ctx->s_val;           // scratch for the sorted keys of a pass (not needed afterwards)
+    CK(keys_sorted.ensure(n * 8));
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    const unsigned top_bits = std::min(64u, std::max(1u, 2u * ctx->cfg.kmer_size - 64u * (unsigned)(W - 1)));
+    u32* idx = ctx->srt_idx.as<u32>(); u32* idx2 = ctx->srt_idx2.as<u32>();
+    hipLaunchKernelGGL(k_iota, dim3(gb), dim3(256), 0, ctx->stream, idx, n);
+    size_t tmp = 0, tmp2 = 0;
+    CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->srt_k.as<u64>(), keys_sorted.as<u64>(), idx, idx2, (size_t)n, 0u, 64u, ctx->stream));
+    CK(rocprim::radix_sort_pairs(nullptr, tmp2, ctx->srt_k.as<u64>(), keys_sorted.as<u64>(), idx, idx2, (size_t)n, 0u, top_bits, ctx->stream));
+    CK(ctx->srt_tmp.ensure(std::max(tmp, tmp2)));
+    for (int x = 0; x < W; ++x) {
+        const u64* src = rows[x].as<u64>();
+        const unsigned bits = x == W - 1 ? top_bits : 64u;
+        if (x == 0) {
+            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, src, keys_sorted.as<u64>(), idx, idx2, (size_t)n, 0u, bits, ctx->stream));
+        } else {
+            hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_k.as<u64>(), src, idx, n);
+            size_t t = x == W - 1 ? tmp2 : tmp;
+            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, t, ctx->srt_k.as<u64>(), keys_sorted.as<u64>(), idx, idx2, (size_t)n, 0u, bits, ctx->stream));
+        }
+        std::swap(idx, idx2);
+    }
+    if (idx != ctx->srt_idx.as<u32>()) std::swap(ctx->srt_idx, ctx->srt_idx2);
+    CKL("sort_index_multiword");
+    return DSKGPU_OK;
+}
+
 // ---- result post-processing: sort rows by k-mer value
 int sort_rows(dskgpu_ctx* ctx, u64 n) {
-    const bool two = ctx->W == 2;
-    ctx->res_lo = ctx->out_lo.as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>();
-    ctx->res_hi = two ? ctx->out_hi.as<u64>() : nullptr;
+    const int W = ctx->W;
+    for (int x = 0; x < 4; ++x) ctx->res_w[x] = x < W ? ctx->out_w[x].as<u64>() : nullptr;
+    ctx->res_ab = ctx->out_ab.as<u32>();
     ctx->sort_partial = false;
     if (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT)) return DSKGPU_OK;
-    CK(ctx->srt_lo.ensure(n * 8));
+    CK(ctx->srt_w[0].ensure(n * 8));
     CK(ctx->srt_ab.ensure(n * 4));
     size_t tmp = 0;
-    if (!two) {
+    if (W == 1) {
         const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
         // Sort on the top SORT_TOP_BITS of the value only (5 radix passes instead of 8), then fix the
         // (rare, short) runs of equal prefix; exactness is kept by the full-width fallback in finish_sort().
         // (k = 32 uses all 64 bits: rocPRIM's partial-range sort misbehaved with end_bit == 64 on ROCm 7.2, so it sorts full width)
         const unsigned begin_bit = (end_bit > SORT_TOP_BITS && end_bit < 64u && !getenv("DSKGPU_FULLSORT")) ? end_bit - SORT_TOP_BITS : 0u;
-        CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->out_lo.as<u64>(), ctx->srt_lo.as<u64>(), ctx->out_ab.as<u32>(),
+        CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->out_w[0].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->out_ab.as<u32>(),
                                      ctx->srt_ab.as<u32>(), (size_t)n, begin_bit, end_bit, ctx->stream));
         CK(ctx->srt_tmp.ensure(tmp));
-        CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->out_lo.as<u64>(), ctx->srt_lo.as<u64>(), ctx->out_ab.as<u32>(),
+        CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->out_w[0].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->out_ab.as<u32>(),
                                      ctx->srt_ab.as<u32>(), (size_t)n, begin_bit, end_bit, ctx->stream));
         ctx->sort_partial = begin_bit != 0;
         if (ctx->sort_partial) {
             u32* flag = ctx->scalars.as<u32>() + SC_SORTFLAG;
             CK(hipMemsetAsync(flag, 0, 4, ctx->stream));
-            hipLaunchKernelGGL(k_fix_runs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->srt_lo.as<u64>(),
+            hipLaunchKernelGGL(k_fix_runs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->srt_w[0].as<u64>(),
                                ctx->srt_ab.as<u32>(), n, (int)begin_bit, flag);
             CKL("k_fix_runs");
             CK(hipMemcpyAsync(&ctx->h_back[3], flag, 4, hipMemcpyDeviceToHost, ctx->stream));
         }
-        ctx->res_lo = ctx->srt_lo.as<u64>(); ctx->res_ab = ctx->srt_ab.as<u32>();
+        ctx->res_w[0] = ctx->srt_w[0].as<u64>(); ctx->res_ab = ctx->srt_ab.as<u32>();
         return DSKGPU_OK;
     }
-    // 128-bit order = stable sort by the low word, then stable sort by the high word
-    CK(ctx->srt_hi.ensure(n * 8));
-    CK(ctx->srt_k.ensure(n * 8));
-    CK(ctx->srt_idx.ensure(n * 4));
-    CK(ctx->srt_idx2.ensure(n * 4));
+    // multi-word order = stable sorts of an index permutation by word 0, 1, .. W-1 (least significant first)
+    int rc = sort_index_multiword(ctx, ctx->out_w, n, W);
+    if (rc) return rc;
     const unsigned gb = (unsigned)((n + 255) / 256);
-    const unsigned hi_bits = std::max(1u, 2u * ctx->cfg.kmer_size - 64u);
-    u32* idx = ctx->srt_idx.as<u32>(); u32* idx2 = ctx->srt_idx2.as<u32>();
-    hipLaunchKernelGGL(k_iota, dim3(gb), dim3(256), 0, ctx->stream, idx, n);
-    size_t tmp2 = 0;
-    CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->out_lo.as<u64>(), ctx->srt_k.as<u64>(), idx, idx2, (size_t)n, 0u, 64u, ctx->stream));
-    CK(rocprim::radix_sort_pairs(nullptr, tmp2, ctx->srt_k.as<u64>(), ctx->srt_hi.as<u64>(), idx2, idx, (size_t)n, 0u, hi_bits, ctx->stream));
-    CK(ctx->srt_tmp.ensure(std::max(tmp, tmp2)));
-    CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->out_lo.as<u64>(), ctx->srt_k.as<u64>(), idx, idx2, (size_t)n, 0u, 64u, ctx->stream));
-    hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_k.as<u64>(), ctx->out_hi.as<u64>(), idx2, n);
-    CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp2, ctx->srt_k.as<u64>(), ctx->srt_hi.as<u64>(), idx2, idx, (size_t)n, 0u, hi_bits, ctx->stream));
-    hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_lo.as<u64>(), ctx->out_lo.as<u64>(), idx, n);
+    const u32* idx = ctx->srt_idx.as<u32>();
+    for (int x = 0; x < W; ++x) {
+        CK(ctx->srt_w[x].ensure(n * 8));
+        hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_w[x].as<u64>(), ctx->out_w[x].as<u64>(), idx, n);
+        ctx->res_w[x] = ctx->srt_w[x].as<u64>();
+    }
     hipLaunchKernelGGL(k_gather<u32>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_ab.as<u32>(), ctx->out_ab.as<u32>(), idx, n);
     CKL("sort_rows");
-    ctx->res_lo = ctx->srt_lo.as<u64>(); ctx->res_hi = ctx->srt_hi.as<u64>(); ctx->res_ab = ctx->srt_ab.as<u32>();
+    ctx->res_ab = ctx->srt_ab.as<u32>();
     return DSKGPU_OK;
 }
 
 // One pass: partition + count the keys of pass `pass` (of `npass`) and leave its solid rows
-// (unsorted) in out_lo/out_hi/out_ab.  Returns PASS_TOO_BIG when the pass holds more keys than `cap`.
+// (unsorted) in out_w[0]/out_w[1]/out_ab.  Returns PASS_TOO_BIG when the pass holds more keys than `cap`.
 #define PASS_TOO_BIG 1000
 template <int W>
 int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_keys_in, u64 nkeys_in, u64 nwords,
@@ -471,12 +499,11 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         }
         // ---------------- dense rows of this pass
         const u64 ns = h_nsolid;
-        CK(ctx->out_lo.ensure((ns + 1) * 8));
         CK(ctx->out_ab.ensure((ns + 1) * 4));
-        if (W == 2) CK(ctx->out_hi.ensure((ns + 1) * 8));
+        RowsOut ro{};
+        for (int x = 0; x < W; ++x) { CK(ctx->out_w[x].ensure((ns + 1) * 8)); ro.w[x] = ctx->out_w[x].as<u64>(); }
         hipLaunchKernelGGL(k_compact<W>, dim3((pl.F + 3) / 4), dim3(256), 0, ctx->stream, (const Key*)solid_keys, (const u32*)solid_ab,
-                           ctx->fstart.as<u32>(), ctx->nsolid.as<u32>(), pl.F, ctx->out_lo.as<u64>(),
-                           W == 2 ? ctx->out_hi.as<u64>() : (u64*)nullptr, ctx->out_ab.as<u32>());
+                           ctx->fstart.as<u32>(), ctx->nsolid.as<u32>(), pl.F, ro, ctx->out_ab.as<u32>());
         CKL("k_compact");
         ctx->mark("compact");
         *ns_out = ns; *nk_out = h_nk; *plan_out = pl;
@@ -514,7 +541,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         if (cap >= 0xFFFF0000ull) continue;
         CK(ctx->bufA.ensure((cap + 1) * sizeof(Key)));
         CK(ctx->bufB.ensure((cap + 1) * sizeof(Key)));
-        if (W == 2) CK(ctx->abund2.ensure((cap + 1) * 4));
+        if (W > 1) CK(ctx->abund2.ensure((cap + 1) * 4));
         ctx->hist.assign((size_t)ctx->cfg.histo_max + 1, 0);
         std::vector<u64> pass_hist(ctx->hist.size());
         u64 tot_rows = 0, tot_kmers = 0, tot_distinct = 0;
@@ -528,13 +555,13 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             tot_kmers += nk; tot_distinct += ctx->h_stats[0];
             if (npass > 1) {      // append this pass's rows and histogram to the job's
                 CK(hipMemcpyAsync(pass_hist.data(), ctx->ghist.p, pass_hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-                if (ctx->acc_lo.ensure_keep((tot_rows + ns + 1) * 8, tot_rows * 8, ctx->stream)) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
                 if (ctx->acc_ab.ensure_keep((tot_rows + ns + 1) * 4, tot_rows * 4, ctx->stream)) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
-                if (W == 2 && ctx->acc_hi.ensure_keep((tot_rows + ns + 1) * 8, tot_rows * 8, ctx->stream)) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
+                for (int x = 0; x < W; ++x)
+                    if (ctx->acc_w[x].ensure_keep((tot_rows + ns + 1) * 8, tot_rows * 8, ctx->stream)) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
                 if (ns) {
-                    CK(hipMemcpyAsync(ctx->acc_lo.as<u64>() + tot_rows, ctx->out_lo.p, ns * 8, hipMemcpyDeviceToDevice, ctx->stream));
                     CK(hipMemcpyAsync(ctx->acc_ab.as<u32>() + tot_rows, ctx->out_ab.p, ns * 4, hipMemcpyDeviceToDevice, ctx->stream));
-                    if (W == 2) CK(hipMemcpyAsync(ctx->acc_hi.as<u64>() + tot_rows, ctx->out_hi.p, ns * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                    for (int x = 0; x < W; ++x)
+                        CK(hipMemcpyAsync(ctx->acc_w[x].as<u64>() + tot_rows, ctx->out_w[x].p, ns * 8, hipMemcpyDeviceToDevice, ctx->stream));
                 }
                 CK(hipStreamSynchronize(ctx->stream));
                 for (size_t i = 0; i < pass_hist.size(); ++i) ctx->hist[i] += pass_hist[i];
@@ -546,8 +573,8 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         if (too_big) continue;
         // ---------------- row sort over all passes
         if (npass > 1) {      // make the accumulated rows the sort input
-            std::swap(ctx->out_lo, ctx->acc_lo); std::swap(ctx->out_ab, ctx->acc_ab);
-            if (W == 2) std::swap(ctx->out_hi, ctx->acc_hi);
+            std::swap(ctx->out_ab, ctx->acc_ab);
+            for (int x = 0; x < W; ++x) std::swap(ctx->out_w[x], ctx->acc_w[x]);
         }
         int rc;
         if ((rc = sort_rows(ctx, tot_rows))) return rc;
@@ -559,13 +586,13 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             // (srt_* holds a permutation of the rows; sort it back into out_*)
             size_t tmp = 0;
             const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
-            CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->srt_lo.as<u64>(), ctx->out_lo.as<u64>(), ctx->srt_ab.as<u32>(),
+            CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->srt_w[0].as<u64>(), ctx->out_w[0].as<u64>(), ctx->srt_ab.as<u32>(),
                                          ctx->out_ab.as<u32>(), (size_t)tot_rows, 0u, end_bit, ctx->stream));
             CK(ctx->srt_tmp.ensure(tmp));
-            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->srt_lo.as<u64>(), ctx->out_lo.as<u64>(), ctx->srt_ab.as<u32>(),
+            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->srt_w[0].as<u64>(), ctx->out_w[0].as<u64>(), ctx->srt_ab.as<u32>(),
                                          ctx->out_ab.as<u32>(), (size_t)tot_rows, 0u, end_bit, ctx->stream));
             CK(hipStreamSynchronize(ctx->stream));
-            ctx->res_lo = ctx->out_lo.as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>();
+            ctx->res_w[0] = ctx->out_w[0].as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>();
             ctx->stats.sort_fallback = 1;
         }
         ctx->resolve_marks();
@@ -744,11 +771,12 @@ int run_banks(dskgpu_ctx* ctx) {
         if (rc) break;
         const u64 n = ctx->n_rows;
         tot_kmers += ctx->stats.n_kmers; passes = std::max<u32>(passes, (u32)ctx->stats.n_passes); retries += ctx->stats.n_retries;
-        if (ctx->u_lo.ensure_keep((nu + n + 1) * 8, nu * 8, ctx->stream) || ctx->u_val.ensure_keep((nu + n + 1) * 8, nu * 8, ctx->stream) ||
-            (W == 2 && ctx->u_hi.ensure_keep((nu + n + 1) * 8, nu * 8, ctx->stream))) { rc = fail(ctx, DSKGPU_E_NOMEM, "bank rows"); break; }
+        bool nomem = ctx->u_val.ensure_keep((nu + n + 1) * 8, nu * 8, ctx->stream) != 0;
+        for (int x = 0; x < W; ++x) nomem = nomem || ctx->u_w[x].ensure_keep((nu + n + 1) * 8, nu * 8, ctx->stream) != 0;
+        if (nomem) { rc = fail(ctx, DSKGPU_E_NOMEM, "bank rows"); break; }
         if (n) {
-            CK(hipMemcpyAsync(ctx->u_lo.as<u64>() + nu, ctx->res_lo, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-            if (W == 2) CK(hipMemcpyAsync(ctx->u_hi.as<u64>() + nu, ctx->res_hi, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            for (int x = 0; x < W; ++x)
+                CK(hipMemcpyAsync(ctx->u_w[x].as<u64>() + nu, ctx->res_w[x], n * 8, hipMemcpyDeviceToDevice, ctx->stream));
             hipLaunchKernelGGL(k_pack_bank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->u_val.as<u64>() + nu, ctx->res_ab, n, b);
             CK(hipStreamSynchronize(ctx->stream));
         }
@@ -759,28 +787,23 @@ int run_banks(dskgpu_ctx* ctx) {
     ctx->have_result = false;
     if (nu >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "too many distinct k-mers over the banks for the merge");
     // ---- sort the union by k-mer
-    CK(ctx->s_lo.ensure((nu + 1) * 8)); CK(ctx->s_val.ensure((nu + 1) * 8));
+    CK(ctx->s_w[0].ensure((nu + 1) * 8)); CK(ctx->s_val.ensure((nu + 1) * 8));
     const unsigned gb = (unsigned)std::max<u64>(1, (nu + 255) / 256);
     if (nu) {
         size_t tmp = 0, tmp2 = 0;
         if (W == 1) {
             const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
-            CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->u_lo.as<u64>(), ctx->s_lo.as<u64>(), ctx->u_val.as<u64>(), ctx->s_val.as<u64>(), (size_t)nu, 0u, end_bit, ctx->stream));
+            CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->u_w[0].as<u64>(), ctx->s_w[0].as<u64>(), ctx->u_val.as<u64>(), ctx->s_val.as<u64>(), (size_t)nu, 0u, end_bit, ctx->stream));
             CK(ctx->srt_tmp.ensure(tmp));
-            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->u_lo.as<u64>(), ctx->s_lo.as<u64>(), ctx->u_val.as<u64>(), ctx->s_val.as<u64>(), (size_t)nu, 0u, end_bit, ctx->stream));
+            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->u_w[0].as<u64>(), ctx->s_w[0].as<u64>(), ctx->u_val.as<u64>(), ctx->s_val.as<u64>(), (size_t)nu, 0u, end_bit, ctx->stream));
         } else {
-            CK(ctx->s_hi.ensure((nu + 1) * 8)); CK(ctx->srt_k.ensure((nu + 1) * 8));
-            CK(ctx->srt_idx.ensure((nu + 1) * 4)); CK(ctx->srt_idx2.ensure((nu + 1) * 4));
-            u32* idx = ctx->srt_idx.as<u32>(); u32* idx2 = ctx->srt_idx2.as<u32>();
-            const unsigned hi_bits = std::max(1u, 2u * ctx->cfg.kmer_size - 64u);
-            hipLaunchKernelGGL(k_iota, dim3(gb), dim3(256), 0, ctx->stream, idx, nu);
-            CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->u_lo.as<u64>(), ctx->srt_k.as<u64>(), idx, idx2, (size_t)nu, 0u, 64u, ctx->stream));
-            CK(rocprim::radix_sort_pairs(nullptr, tmp2, ctx->srt_k.as<u64>(), ctx->s_hi.as<u64>(), idx2, idx, (size_t)nu, 0u, hi_bits, ctx->stream));
-            CK(ctx->srt_tmp.ensure(std::max(tmp, tmp2)));
-            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->u_lo.as<u64>(), ctx->srt_k.as<u64>(), idx, idx2, (size_t)nu, 0u, 64u, ctx->stream));
-            hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_k.as<u64>(), ctx->u_hi.as<u64>(), idx2, nu);
-            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp2, ctx->srt_k.as<u64>(), ctx->s_hi.as<u64>(), idx2, idx, (size_t)nu, 0u, hi_bits, ctx->stream));
-            hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->s_lo.as<u64>(), ctx->u_lo.as<u64>(), idx, nu);
+            if ((rc = sort_index_multiword(ctx, ctx->u_w, nu, W))) return rc;
+            const u32* idx = ctx->srt_idx.as<u32>();
+            for (int x = 0; x < W; ++x) {
+                CK(ctx->s_w[x].ensure((nu + 1) * 8));
+                hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->s_w[x].as<u64>(), ctx->u_w[x].as<u64>(), idx, nu);
+            }
+            CK(ctx->s_val.ensure((nu + 1) * 8));
             hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->s_val.as<u64>(), ctx->u_val.as<u64>(), idx, nu);
         }
         CKL("bank sort");
@@ -796,7 +819,9 @@ int run_banks(dskgpu_ctx* ctx) {
                    (ctx->cfg.flags & DSKGPU_F_HISTO2D) ? 1u : 0u};
     u64 n_solid = 0;
     if (nu) {
-        hipLaunchKernelGGL(k_merge_banks<W>, dim3(gb), dim3(256), 0, ctx->stream, ctx->s_lo.as<u64>(), W == 2 ? ctx->s_hi.as<u64>() : (const u64*)nullptr,
+        RowsIn ri{}; RowsOut ro{};
+        for (int x = 0; x < W; ++x) ri.w[x] = ctx->s_w[x].as<u64>();
+        hipLaunchKernelGGL(k_merge_banks<W>, dim3(gb), dim3(256), 0, ctx->stream, ri,
                            ctx->s_val.as<u64>(), nu, mp, ctx->m_flag.as<u32>(), ctx->m_sum.as<u32>(), ctx->ghist.as<u64>(), ctx->gh2d.as<u64>(), ctx->gstats.as<u64>());
         hipLaunchKernelGGL(k_copy_u32, dim3(gb), dim3(256), 0, ctx->stream, ctx->m_pos.as<u32>(), ctx->m_flag.as<u32>(), nu);
         CKL("k_merge_banks");
@@ -806,11 +831,10 @@ int run_banks(dskgpu_ctx* ctx) {
         CK(hipMemcpyAsync(&ctx->h_back[1], ctx->m_pos.as<u32>() + nu, 4, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
         n_solid = ctx->h_back[1];
-        CK(ctx->out_lo.ensure((n_solid + 1) * 8)); CK(ctx->out_ab.ensure((n_solid + 1) * 4));
-        if (W == 2) CK(ctx->out_hi.ensure((n_solid + 1) * 8));
-        hipLaunchKernelGGL(k_pick_rows<W>, dim3(gb), dim3(256), 0, ctx->stream, ctx->s_lo.as<u64>(), W == 2 ? ctx->s_hi.as<u64>() : (const u64*)nullptr,
-                           ctx->m_sum.as<u32>(), ctx->m_flag.as<u32>(), ctx->m_pos.as<u32>(), nu, ctx->out_lo.as<u64>(),
-                           W == 2 ? ctx->out_hi.as<u64>() : (u64*)nullptr, ctx->out_ab.as<u32>());
+        CK(ctx->out_ab.ensure((n_solid + 1) * 4));
+        for (int x = 0; x < W; ++x) { CK(ctx->out_w[x].ensure((n_solid + 1) * 8)); ro.w[x] = ctx->out_w[x].as<u64>(); }
+        hipLaunchKernelGGL(k_pick_rows<W>, dim3(gb), dim3(256), 0, ctx->stream, ri,
+                           ctx->m_sum.as<u32>(), ctx->m_flag.as<u32>(), ctx->m_pos.as<u32>(), nu, ro, ctx->out_ab.as<u32>());
         CKL("k_pick_rows");
     }
     ctx->hist.assign(nh, 0); ctx->hist2d.assign(nh * 11, 0);
@@ -818,7 +842,8 @@ int run_banks(dskgpu_ctx* ctx) {
     CK(hipMemcpyAsync(ctx->hist2d.data(), ctx->gh2d.p, nh * 11 * 8, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipMemcpyAsync(&ctx->h_stats[0], ctx->gstats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
-    ctx->res_lo = ctx->out_lo.as<u64>(); ctx->res_hi = W == 2 ? ctx->out_hi.as<u64>() : nullptr; ctx->res_ab = ctx->out_ab.as<u32>();
+    for (int x = 0; x < 4; ++x) ctx->res_w[x] = x < W ? ctx->out_w[x].as<u64>() : nullptr;
+    ctx->res_ab = ctx->out_ab.as<u32>();
     ctx->n_rows = n_solid;
     ctx->stats.n_bytes = total; ctx->stats.n_kmers = tot_kmers; ctx->stats.n_distinct = ctx->h_stats[0]; ctx->stats.n_solid = n_solid;
     ctx->stats.n_passes = passes; ctx->stats.n_retries = retries;
@@ -839,7 +864,7 @@ const char* dskgpu_last_error(const dskgpu_ctx* ctx) { return ctx ? ctx->err.c_s
 int dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out) {
     if (!cfg || !out) { g_create_err = "null argument"; return DSKGPU_E_ARG; }
     *out = nullptr;
-    if (cfg->kmer_size < 1 || cfg->kmer_size > 64) { g_create_err = "kmer_size must be in 1..64"; return DSKGPU_E_ARG; }
+    if (cfg->kmer_size < 1 || cfg->kmer_size > 128) { g_create_err = "kmer_size must be in 1..128"; return DSKGPU_E_ARG; }
     if (cfg->solidity_kind > DSKGPU_SOLIDITY_CUSTOM) { g_create_err = "unknown solidity_kind"; return DSKGPU_E_ARG; }
     const u32 ws = cfg->world_size ? cfg->world_size : 1;
     if ((ws & (ws - 1)) != 0 || ws > 64 || cfg->rank >= ws) { g_create_err = "world_size must be a power of two <= 64 and rank < world_size"; return DSKGPU_E_ARG; }
@@ -855,10 +880,11 @@ int dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out) {
     if (ctx->cfg.histo_max == 0) ctx->cfg.histo_max = 10000;
     if (ctx->cfg.abundance_max == 0) ctx->cfg.abundance_max = 0x7FFFFFFFu;
     if (ctx->cfg.minimizer_size == 0) ctx->cfg.minimizer_size = 10;
-    ctx->W = cfg->kmer_size <= 32 ? 1 : 2;
+    ctx->W = cfg->kmer_size <= 32 ? 1 : cfg->kmer_size <= 64 ? 2 : 4;     // device keys: 1, 2 or 4 words
+    ctx->words_out = (int)((cfg->kmer_size + 31) / 32);                   // words of a k-mer at the ABI (3 for k <= 96)
     ctx->max_keys_per_pass = (u64)cfg->max_pass_mkeys * 1000000ull;
     // super-k-mer records need >= 16 m-mers per window (superkmer.h); shorter k-mers travel as explicit keys
-    ctx->sk_mode = ws > 1 && cfg->kmer_size >= 20 && !(cfg->flags & DSKGPU_F_MG_EXPLICIT);
+    ctx->sk_mode = ws > 1 && cfg->kmer_size >= 20 && cfg->kmer_size <= 64 && !(cfg->flags & DSKGPU_F_MG_EXPLICIT);
     if (ctx->sk_mode) {
         ctx->sk_sp.k = cfg->kmer_size; ctx->sk_sp.G = ws;
         ctx->sk_sp.m = std::min<u32>(std::min<u32>(ctx->cfg.minimizer_size, 16u), cfg->kmer_size - 15u);
@@ -879,11 +905,12 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->reads_own, &ctx->packed, &ctx->inval, &ctx->bufA, &ctx->bufB, &ctx->mat1, &ctx->mat2, &ctx->sums,
                       &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats,
-                      &ctx->out_lo, &ctx->out_hi, &ctx->out_ab, &ctx->srt_lo, &ctx->srt_hi, &ctx->srt_ab, &ctx->srt_tmp,
-                      &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->abund2, &ctx->acc_lo, &ctx->acc_hi, &ctx->acc_ab, &ctx->u_lo, &ctx->u_hi, &ctx->u_val,
-                      &ctx->s_lo, &ctx->s_hi, &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,
+                      &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
+                      &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
+                      &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,
                       &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys};
     for (DevBuf* b : bufs) b->release();
+    for (int i = 0; i < 4; ++i) { ctx->out_w[i].release(); ctx->srt_w[i].release(); ctx->acc_w[i].release(); ctx->u_w[i].release(); ctx->s_w[i].release(); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) { if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]); if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -974,10 +1001,11 @@ int dskgpu_count(dskgpu_ctx* ctx) {
     ctx->stats = dskgpu_stats{};
     const bool banks = ctx->bank_ends.size() > 1 || (!ctx->bank_ends.empty() && ctx->bank_ends.back() < ctx->n_bytes);
     if (banks && (ctx->cfg.solidity_kind != DSKGPU_SOLIDITY_SUM || (ctx->cfg.flags & DSKGPU_F_HISTO2D)))
-        return ctx->W == 1 ? run_banks<1>(ctx) : run_banks<2>(ctx);
+        return ctx->W == 1 ? run_banks<1>(ctx) : ctx->W == 2 ? run_banks<2>(ctx) : run_banks<4>(ctx);
     if (ctx->cfg.flags & DSKGPU_F_HISTO2D) ctx->hist2d.clear();
     if (ctx->W == 1) return run_pipeline<1>(ctx, true, nullptr, 0);
-    return run_pipeline<2>(ctx, true, nullptr, 0);
+    if (ctx->W == 2) return run_pipeline<2>(ctx, true, nullptr, 0);
+    return run_pipeline<4>(ctx, true, nullptr, 0);
 }
 
 int dskgpu_next_bank(dskgpu_ctx* ctx) {
@@ -1016,7 +1044,7 @@ int dskgpu_mg_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, ui
     CK(hipSetDevice(ctx->cfg.device));
     if (ctx->sk_mode) return sk_scatter(ctx, d_send, capacity_words, send_words);
     if (capacity_words < dskgpu_mg_send_capacity_words(ctx)) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
-    return ctx->W == 1 ? mg_scatter_impl<1>(ctx, d_send, send_words) : mg_scatter_impl<2>(ctx, d_send, send_words);
+    return ctx->W == 1 ? mg_scatter_impl<1>(ctx, d_send, send_words) : ctx->W == 2 ? mg_scatter_impl<2>(ctx, d_send, send_words) : mg_scatter_impl<4>(ctx, d_send, send_words);
 }
 
 int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words) {
@@ -1027,7 +1055,8 @@ int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words) {
         return ctx->W == 1 ? sk_count<1>(ctx, static_cast<const u64*>(d_recv), recv_words) : sk_count<2>(ctx, static_cast<const u64*>(d_recv), recv_words);
     if (recv_words % (u64)ctx->W) return fail(ctx, DSKGPU_E_ARG, "recv_words is not a whole number of k-mer records");
     if (ctx->W == 1) return run_pipeline<1>(ctx, false, static_cast<const u64*>(d_recv), recv_words);
-    return run_pipeline<2>(ctx, false, static_cast<const K2*>(d_recv), recv_words / 2);
+    if (ctx->W == 2) return run_pipeline<2>(ctx, false, static_cast<const K2*>(d_recv), recv_words / 2);
+    return run_pipeline<4>(ctx, false, static_cast<const KN<4>*>(d_recv), recv_words / 4);
 }
 
 int dskgpu_get_stats(const dskgpu_ctx* ctx, dskgpu_stats* out) {
@@ -1067,13 +1096,15 @@ int dskgpu_partition_copy(const dskgpu_ctx* cctx, uint32_t p, uint64_t* kmers, u
     if (n == 0) return DSKGPU_OK;
     CK(hipSetDevice(ctx->cfg.device));
     if (kmers) {
-        if (ctx->W == 1) CK(hipMemcpy(kmers, ctx->res_lo + b, n * 8, hipMemcpyDeviceToHost));
+        if (ctx->W == 1) CK(hipMemcpy(kmers, ctx->res_w[0] + b, n * 8, hipMemcpyDeviceToHost));
         else {
-            // rows are (lo, hi) pairs on the host side
-            std::vector<u64> lo(n), hi(n);
-            CK(hipMemcpy(lo.data(), ctx->res_lo + b, n * 8, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(hi.data(), ctx->res_hi + b, n * 8, hipMemcpyDeviceToHost));
-            for (u64 i = 0; i < n; ++i) { kmers[2 * i] = lo[i]; kmers[2 * i + 1] = hi[i]; }
+            // the device keeps one array per word; rows are words_out consecutive words on the host side
+            const int wo = ctx->words_out;
+            std::vector<u64> col(n);
+            for (int x = 0; x < wo; ++x) {
+                CK(hipMemcpy(col.data(), ctx->res_w[x] + b, n * 8, hipMemcpyDeviceToHost));
+                for (u64 i = 0; i < n; ++i) kmers[(u64)wo * i + x] = col[i];
+            }
         }
     }
     if (abundance) CK(hipMemcpy(abundance, ctx->res_ab + b, n * 4, hipMemcpyDeviceToHost));
@@ -1083,7 +1114,7 @@ int dskgpu_partition_copy(const dskgpu_ctx* cctx, uint32_t p, uint64_t* kmers, u
 int dskgpu_result_device(const dskgpu_ctx* ctx, const void** d_kmers, const void** d_abundance, uint64_t* n_rows) {
     if (!ctx) return DSKGPU_E_ARG;
     if (!ctx->have_result) return DSKGPU_E_STATE;
-    if (d_kmers) *d_kmers = ctx->res_lo;
+    if (d_kmers) *d_kmers = ctx->res_w[0];
     if (d_abundance) *d_abundance = ctx->res_ab;
     if (n_rows) *n_rows = ctx->n_rows;
     return DSKGPU_OK;
@@ -1118,10 +1149,13 @@ int dskgpu_k_enumerate(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, vo
         const unsigned grid = (unsigned)((nwords * 2 + 255) / 256);
         if (ctx->W == 1)
             hipLaunchKernelGGL(k_enumerate<1>, dim3(grid), dim3(256), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(),
-                               nwords, (u64)nbytes, (int)ctx->cfg.kmer_size, static_cast<u64*>(d_kmers), static_cast<uint8_t*>(d_valid));
-        else
+                               nwords, (u64)nbytes, (int)ctx->cfg.kmer_size, static_cast<u64*>(d_kmers), static_cast<uint8_t*>(d_valid), 1);
+        else if (ctx->W == 2)
             hipLaunchKernelGGL(k_enumerate<2>, dim3(grid), dim3(256), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(),
-                               nwords, (u64)nbytes, (int)ctx->cfg.kmer_size, static_cast<u64*>(d_kmers), static_cast<uint8_t*>(d_valid));
+                               nwords, (u64)nbytes, (int)ctx->cfg.kmer_size, static_cast<u64*>(d_kmers), static_cast<uint8_t*>(d_valid), ctx->words_out);
+        else
+            hipLaunchKernelGGL(k_enumerate<4>, dim3(grid), dim3(256), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(),
+                               nwords, (u64)nbytes, (int)ctx->cfg.kmer_size, static_cast<u64*>(d_kmers), static_cast<uint8_t*>(d_valid), ctx->words_out);
         CKL("k_enumerate");
     }
     CK(hipStreamSynchronize(ctx->stream));

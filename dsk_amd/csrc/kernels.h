@@ -97,12 +97,11 @@ __global__ __launch_bounds__(256) void k_encode(const uint8_t* __restrict__ s, u
 // ------------------------------------------------------------------ key sources
 // READS: chunk range is in packed words; a tile is Tile<W>::WORDS words; each
 // thread generates Tile<W>::KPT consecutive window end positions of one word.
-template <int W> struct KeyT;
+template <int W> struct KeyT { typedef KN<W> T; };
 template <> struct KeyT<1> { typedef u64 T; };
-template <> struct KeyT<2> { typedef K2 T; };
 
 __device__ __forceinline__ u64 digit_word(u64 h) { return h; }
-__device__ __forceinline__ u64 digit_word(const K2& h) { return h.hi; }
+template <int W> __device__ __forceinline__ u64 digit_word(const KN<W>& h) { return h.w[W - 1]; }
 
 // Radix digits are bit fields of the mixed key, mapped onto an ARBITRARY number
 // of bins with the multiply-shift range reduction (one v_mul_hi_u32):
@@ -132,27 +131,34 @@ __device__ __forceinline__ bool key_in_pass(u64 w, const DigitSpec& ds) {
     return ((frac * ds.npass) >> 20) == ds.pass;
 }
 
+// multi-word windows: the tuned two-word generator for W = 2, the general one otherwise
+template <int NP>
+__device__ __forceinline__ u32 gen_kmers_multi(const u64* __restrict__ packed, const u32* __restrict__ inval, u64 wi, int t0, int k, K2 (&c)[NP]) {
+    return gen_kmers2<NP>(packed, inval, wi, t0, k, c);
+}
+template <int W, int NP>
+__device__ __forceinline__ u32 gen_kmers_multi(const u64* __restrict__ packed, const u32* __restrict__ inval, u64 wi, int t0, int k, KN<W> (&c)[NP]) {
+    return gen_kmersN<W, NP>(packed, inval, wi, t0, k, c);
+}
+
 template <int W>
 __device__ __forceinline__ u32 tile_keys_reads(const u64* __restrict__ packed, const u32* __restrict__ inval,
-                                               u64 w0, u64 wend, int k, typename KeyT<W>::T (&h)[Tile<W>::KPT]);
-template <>
-__device__ __forceinline__ u32 tile_keys_reads<1>(const u64* __restrict__ packed, const u32* __restrict__ inval,
-                                                  u64 w0, u64 wend, int k, u64 (&h)[16]) {
+                                               u64 w0, u64 wend, int k, KN<W> (&h)[Tile<W>::KPT]) {
+    constexpr int KPT = Tile<W>::KPT, TPW = 32 / KPT;   // threads per packed word, KPT windows each
+    const u64 wi = w0 + (threadIdx.x / TPW);
+    if (wi >= wend) return 0u;
+    const u32 vm = gen_kmers_multi(packed, inval, wi, (int)(threadIdx.x % TPW) * KPT, k, h);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) kmixN(h[j]);
+    return vm;
+}
+__device__ __forceinline__ u32 tile_keys_reads(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                               u64 w0, u64 wend, int k, u64 (&h)[16]) {
     const u64 wi = w0 + (threadIdx.x >> 1);             // 2 threads per packed word, 16 windows each
     if (wi >= wend) return 0u;
     const u32 vm = gen_kmers1<16>(packed, inval, wi, (threadIdx.x & 1) * 16, k, h);
 #pragma unroll
     for (int j = 0; j < 16; ++j) h[j] = kmix(h[j]);
-    return vm;
-}
-template <>
-__device__ __forceinline__ u32 tile_keys_reads<2>(const u64* __restrict__ packed, const u32* __restrict__ inval,
-                                                  u64 w0, u64 wend, int k, K2 (&h)[8]) {
-    const u64 wi = w0 + (threadIdx.x >> 2);             // 4 threads per packed word, 8 windows each
-    if (wi >= wend) return 0u;
-    const u32 vm = gen_kmers2<8>(packed, inval, wi, (threadIdx.x & 3) * 8, k, h);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) kmix2(h[j].hi, h[j].lo);
     return vm;
 }
 
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(SC_NT) void k_hist(const u64* __restrict__ packed, 
         };
         if (SRC == 0) {
             for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
-                vma = tile_keys_reads<W>(packed, inval, t0, d.end, k, ha);
+                vma = tile_keys_reads(packed, inval, t0, d.end, k, ha);
                 process(ha, vma);
             }
         } else {
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
         lds_barrier();
         if (SRC == 0) {
             for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
-                vma = tile_keys_reads<W>(packed, inval, t0, d.end, k, ha);
+                vma = tile_keys_reads(packed, inval, t0, d.end, k, ha);
                 process(ha, vma);
             }
         } else {
@@ -469,7 +475,7 @@ template <int W> struct ATile {
     static constexpr int KEYS = SC_NT * KPT;
 };
 __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
-    const size_t key = W == 1 ? 8 : 16, keys = W == 1 ? ATile<1>::KEYS : ATile<2>::KEYS, G = W == 1 ? ATile<1>::G : ATile<2>::G;
+    const size_t key = 8 * (size_t)W, keys = (size_t)SC_NT * (12 / W), G = 8 / W;
     return keys * key + (size_t)P * (G - 1) * key + (size_t)(P + 1) * 4 + (size_t)P * 4 + (size_t)P * 12 + (size_t)P * 2 + 20 * 4 + 32;
 }
 
@@ -849,12 +855,14 @@ __global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* keys, u64* solid_keys,
 // representative -- no thread ever waits on another.
 #define C2_SLOTS 2048
 #define C2_MAXLOAD 1792
-#define C2_STAGE 2048
-#define C2_KPT (C2_STAGE / CNT_NT)
+// staged keys: 32 KB of LDS whatever the key width (2048 two-word, 1024 four-word keys)
+template <int W> struct CStage { static constexpr int N = 4096 / W; static constexpr int KPT = N / CNT_NT; };
 
-__device__ __forceinline__ void table_insert2(const K2* sk, const K2* __restrict__ gkeys, u32* slots, u32* tc,
-                                              unsigned short* lst, u32* ndist, u32* ovf, const K2& key, u32 idx) {
-    u32 slot = (u32)key.hi & (C2_SLOTS - 1);
+template <int W>
+__device__ __forceinline__ void table_insert2(const KN<W>* sk, const KN<W>* __restrict__ gkeys, u32* slots, u32* tc,
+                                              unsigned short* lst, u32* ndist, u32* ovf, const KN<W>& key, u32 idx) {
+    constexpr u32 C2_STAGE = CStage<W>::N;
+    u32 slot = (u32)key.w[W - 1] & (C2_SLOTS - 1);
     for (int probe = 0; probe < C2_SLOTS; ++probe) {
         u32 v = slots[slot];
         if (v == 0) {
@@ -862,19 +870,21 @@ __device__ __forceinline__ void table_insert2(const K2* sk, const K2* __restrict
             if (v == 0) { lst[atomicAdd(ndist, 1u)] = (unsigned short)slot; atomicAdd(&tc[slot], 1u); return; }
         }
         const u32 r = v - 1;
-        K2 rep;
+        KN<W> rep;
         if (r < C2_STAGE) rep = sk[r]; else rep = gkeys[r];
-        if (rep.hi == key.hi && rep.lo == key.lo) { atomicAdd(&tc[slot], 1u); return; }
+        if (key_eq(rep, key)) { atomicAdd(&tc[slot], 1u); return; }
         slot = (slot + 1) & (C2_SLOTS - 1);
     }
     *ovf = 1;
 }
 
-template <>
-__global__ __launch_bounds__(CNT_NT) void k_count<2>(K2* keys, K2* solid_keys, const u32* __restrict__ fstart,
-                                                     u32* __restrict__ abund, u32* __restrict__ nsolid,
-                                                     u64* __restrict__ ghist, u64* __restrict__ gstats,
-                                                     u32* __restrict__ overflow, CountParams cp) {
+template <int W>
+__global__ __launch_bounds__(CNT_NT) void k_count(typename KeyT<W>::T* keys, typename KeyT<W>::T* solid_keys, const u32* __restrict__ fstart,
+                                                  u32* __restrict__ abund, u32* __restrict__ nsolid,
+                                                  u64* __restrict__ ghist, u64* __restrict__ gstats,
+                                                  u32* __restrict__ overflow, CountParams cp) {
+    typedef KN<W> K2;                            // (multi-word key of this instantiation)
+    constexpr int C2_STAGE = CStage<W>::N, C2_KPT = CStage<W>::KPT;
     __shared__ K2 sk[C2_STAGE];
     __shared__ u32 slots[C2_SLOTS];
     __shared__ u32 tc[C2_SLOTS];
@@ -926,7 +936,7 @@ __global__ __launch_bounds__(CNT_NT) void k_count<2>(K2* keys, K2* solid_keys, c
             for (u32 i0 = 0; i0 < nd; i0 += CNT_NT) {
                 const u32 i = i0 + tid;
                 const bool act = i < nd;
-                K2 key; key.hi = 0; key.lo = 0; u32 c = 0;
+                K2 key = K2(); u32 c = 0;
                 if (act) {
                     const u32 slot = lst[i];
                     const u32 r = slots[slot] - 1;
@@ -977,36 +987,35 @@ __global__ __launch_bounds__(CNT_NT) void k_count<2>(K2* keys, K2* solid_keys, c
 // One wave per sub-partition: copy its solid rows to the dense output and
 // restore the k-mer from the mixed key.  soff = exclusive scan of the per-
 // sub-partition solid counts (F+1 entries).
+struct RowsOut { u64* w[4]; };                    // struct-of-arrays rows: word i of row r at w[i][r]
+struct RowsIn { const u64* w[4]; };
+
 template <int W>
 __global__ __launch_bounds__(256) void k_compact(const typename KeyT<W>::T* __restrict__ keys, const u32* __restrict__ abund,
                                                  const u32* __restrict__ fstart, const u32* __restrict__ soff, u32 F,
-                                                 u64* __restrict__ out_lo, u64* __restrict__ out_hi, u32* __restrict__ out_ab);
-template <>
-__global__ __launch_bounds__(256) void k_compact<1>(const u64* __restrict__ keys, const u32* __restrict__ abund,
-                                                    const u32* __restrict__ fstart, const u32* __restrict__ soff, u32 F,
-                                                    u64* __restrict__ out_lo, u64* __restrict__ out_hi, u32* __restrict__ out_ab) {
+                                                 RowsOut out, u32* __restrict__ out_ab) {
     const u32 q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= F) return;
     const u32 o = soff[q], ns = soff[q + 1] - o, b = fstart[q];
     for (u32 i = lane; i < ns; i += 64) {
-        out_lo[o + i] = kunmix(keys[b + i]);
+        KN<W> kx = keys[b + i];
+        kunmixN(kx);
+#pragma unroll
+        for (int x = 0; x < W; ++x) out.w[x][o + i] = kx.w[x];
         out_ab[o + i] = abund[b + i];
     }
 }
-
 template <>
-__global__ __launch_bounds__(256) void k_compact<2>(const K2* __restrict__ keys, const u32* __restrict__ abund,
+__global__ __launch_bounds__(256) void k_compact<1>(const u64* __restrict__ keys, const u32* __restrict__ abund,
                                                     const u32* __restrict__ fstart, const u32* __restrict__ soff, u32 F,
-                                                    u64* __restrict__ out_lo, u64* __restrict__ out_hi, u32* __restrict__ out_ab) {
+                                                    RowsOut out, u32* __restrict__ out_ab) {
     const u32 q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= F) return;
     const u32 o = soff[q], ns = soff[q + 1] - o, b = fstart[q];
     for (u32 i = lane; i < ns; i += 64) {
-        K2 kx = keys[b + i];
-        kunmix2(kx.hi, kx.lo);
-        out_lo[o + i] = kx.lo; out_hi[o + i] = kx.hi;
+        out.w[0][o + i] = kunmix(keys[b + i]);
         out_ab[o + i] = abund[b + i];
     }
 }
@@ -1026,7 +1035,7 @@ __global__ void k_gather(T* __restrict__ dst, const T* __restrict__ src, const u
 // canonical k-mer + validity for the window ending at every byte
 template <int W>
 __global__ __launch_bounds__(256) void k_enumerate(const u64* __restrict__ packed, const u32* __restrict__ inval,
-                                                   u64 nwords, u64 nbytes, int k, u64* __restrict__ out, uint8_t* __restrict__ valid) {
+                                                   u64 nwords, u64 nbytes, int k, u64* __restrict__ out, uint8_t* __restrict__ valid, int ow) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 wi = t >> 1;
     if (wi >= nwords) return;
@@ -1040,13 +1049,15 @@ __global__ __launch_bounds__(256) void k_enumerate(const u64* __restrict__ packe
             if (p < nbytes) { const bool v = vm & (1u << j); out[p] = v ? c[j] : 0ull; valid[p] = v; }
         }
     } else {
-        K2 c[16];
-        vm = gen_kmers2<16>(packed, inval, wi, t0, k, c);
+        constexpr int WW = W > 1 ? W : 2;
+        KN<WW> c[16];
+        vm = gen_kmers_multi(packed, inval, wi, t0, k, c);
         for (int j = 0; j < 16; ++j) {
             const u64 p = wi * 32 + t0 + j;
             if (p < nbytes) {
                 const bool v = vm & (1u << j);
-                out[2 * p] = v ? c[j].lo : 0ull; out[2 * p + 1] = v ? c[j].hi : 0ull; valid[p] = v;
+                for (int x = 0; x < WW; ++x) if (x < ow) out[(u64)ow * p + x] = v ? c[j].w[x] : 0ull;
+                valid[p] = v;
             }
         }
     }
@@ -1066,7 +1077,7 @@ __global__ __launch_bounds__(256) void k_minimizers(const u64* __restrict__ pack
     const u32 mmask = (m == 16) ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1);
     const int halo = k - 1;                                 // bases needed before p0
     const long long s0 = (long long)p0 - halo;
-    u32 cm[16 + 63];                                        // canonical m-mer ending at s0 + i
+    u32 cm[16 + 127];                                       // canonical m-mer ending at s0 + i
     u32 f = 0, r = 0; int run = 0;
     int runs[16];
     for (int i = 0; i < halo + 16; ++i) {
@@ -1131,7 +1142,14 @@ struct MergeParams { u32 nbanks, kind, mask, amin, amax, hmax, want2d; };
 #define MB_LH 256
 #define MB_L2 32
 template <int W>
-__global__ __launch_bounds__(256) void k_merge_banks(const u64* __restrict__ lo, const u64* __restrict__ hi, const u64* __restrict__ val,
+__device__ __forceinline__ bool rows_same(const RowsIn& r, u64 a, u64 b) {
+    bool e = true;
+#pragma unroll
+    for (int x = 0; x < W; ++x) e = e && (r.w[x][a] == r.w[x][b]);
+    return e;
+}
+template <int W>
+__global__ __launch_bounds__(256) void k_merge_banks(RowsIn rows, const u64* __restrict__ val,
                                                      u64 n, MergeParams mp, u32* __restrict__ flag, u32* __restrict__ sumv,
                                                      u64* __restrict__ ghist, u64* __restrict__ gh2d, u64* __restrict__ gstats) {
     __shared__ u32 lh[MB_LH];
@@ -1142,12 +1160,11 @@ __global__ __launch_bounds__(256) void k_merge_banks(const u64* __restrict__ lo,
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     u32 ndist = 0;
     if (i < n) {
-        const u64 kl = lo[i], kh = W == 2 ? hi[i] : 0ull;
-        const bool head = i == 0 || lo[i - 1] != kl || (W == 2 && hi[i - 1] != kh);
+        const bool head = i == 0 || !rows_same<W>(rows, i - 1, i);
         u32 f = 0, sv = 0;
         if (head) {
             u64 sum = 0; u32 mx = 0, genome = 0, present = 0, inwin = 0, nonzero = 0, nb = 0; u32 mn = 0xFFFFFFFFu;
-            for (u64 j = i; j < n && lo[j] == kl && (W == 1 || hi[j] == kh) && nb < mp.nbanks; ++j, ++nb) {
+            for (u64 j = i; j < n && rows_same<W>(rows, i, j) && nb < mp.nbanks; ++j, ++nb) {
                 const u64 v = val[j]; const u32 bank = (u32)(v >> 32), c = (u32)v;
                 sum += c; mx = c > mx ? c : mx; mn = c < mn ? c : mn;
                 if (bank == 0) genome = c;
@@ -1188,13 +1205,14 @@ __global__ __launch_bounds__(256) void k_merge_banks(const u64* __restrict__ lo,
 
 // keep the flagged rows (order preserved): pos = exclusive scan of flag
 template <int W>
-__global__ __launch_bounds__(256) void k_pick_rows(const u64* __restrict__ lo, const u64* __restrict__ hi, const u32* __restrict__ sumv,
+__global__ __launch_bounds__(256) void k_pick_rows(RowsIn rows, const u32* __restrict__ sumv,
                                                    const u32* __restrict__ flag_in, const u32* __restrict__ posx, u64 n,
-                                                   u64* __restrict__ out_lo, u64* __restrict__ out_hi, u32* __restrict__ out_ab) {
+                                                   RowsOut out, u32* __restrict__ out_ab) {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n || !flag_in[i]) return;
     const u32 p = posx[i];
-    out_lo[p] = lo[i]; if (W == 2) out_hi[p] = hi[i];
+#pragma unroll
+    for (int x = 0; x < W; ++x) out.w[x][p] = rows.w[x][i];
     out_ab[p] = sumv[i];
 }
 __global__ void k_pack_bank(u64* __restrict__ dst, const u32* __restrict__ ab, u64 n, u32 bank) {

@@ -37,17 +37,33 @@ __host__ __device__ __forceinline__ u64 kunmix(u64 x) {
     x ^= x >> 33; return x;
 }
 
-// 128-bit keys (k in 33..64): two Feistel rounds over the 64-bit mixer, still a
-// bijection on (hi, lo); digits/slots are taken from the mixed hi word.
-__host__ __device__ __forceinline__ void kmix2(u64& hi, u64& lo) {
-    lo ^= kmix(hi);            // round 1
-    hi ^= kmix(lo + 0x9e3779b97f4a7c15ULL);   // round 2
-    hi = kmix(hi);             // spread within the digit word
+// Multi-word keys (k in 33..128): KN<W>, word 0 least significant.  The mixer is an unbalanced Feistel
+// chain over the 64-bit mixer -- every word is folded into the next lower one, the lowest back into the
+// top one -- still a bijection on the W words; digits/slots are taken from the mixed top word.
+template <int W> struct KN { u64 w[W]; };
+typedef KN<2> K2;
+#define DSK_GOLD 0x9e3779b97f4a7c15ULL
+
+template <int W>
+__host__ __device__ __forceinline__ void kmixN(KN<W>& x) {
+#pragma unroll
+    for (int i = W - 2; i >= 0; --i) x.w[i] ^= kmix(x.w[i + 1] + (u64)(W - 2 - i) * DSK_GOLD);
+    x.w[W - 1] ^= kmix(x.w[0] + DSK_GOLD);
+    x.w[W - 1] = kmix(x.w[W - 1]);             // spread within the digit word
 }
-__host__ __device__ __forceinline__ void kunmix2(u64& hi, u64& lo) {
-    hi = kunmix(hi);
-    hi ^= kmix(lo + 0x9e3779b97f4a7c15ULL);
-    lo ^= kmix(hi);
+template <int W>
+__host__ __device__ __forceinline__ void kunmixN(KN<W>& x) {
+    x.w[W - 1] = kunmix(x.w[W - 1]);
+    x.w[W - 1] ^= kmix(x.w[0] + DSK_GOLD);
+#pragma unroll
+    for (int i = 0; i <= W - 2; ++i) x.w[i] ^= kmix(x.w[i + 1] + (u64)(W - 2 - i) * DSK_GOLD);
+}
+template <int W>
+__host__ __device__ __forceinline__ bool key_eq(const KN<W>& a, const KN<W>& b) {
+    bool e = true;
+#pragma unroll
+    for (int i = 0; i < W; ++i) e = e && (a.w[i] == b.w[i]);
+    return e;
 }
 
 // reverse the order of the 32 2-bit groups of x
@@ -89,7 +105,6 @@ __device__ __forceinline__ u32 gen_kmers1(const u64* __restrict__ packed, const 
 }
 
 // ---------------------------------------------------------------- two-word k-mers (33 <= k <= 64)
-struct K2 { u64 hi, lo; };
 
 // Windows ending at bases 32*wi + t0 + j, j < NP.  Needs packed[wi-2..wi].
 template <int NP>
@@ -132,14 +147,94 @@ __device__ __forceinline__ u32 gen_kmers2(const u64* __restrict__ packed, const 
         rlo = (rlo >> 2) | (rhi << 62);
         rhi = (rhi >> 2) | ((c ^ 2ull) << rcs);
         const bool fl = fhi < rhi || (fhi == rhi && flo < rlo);
-        canon[j].hi = fl ? fhi : rhi;
-        canon[j].lo = fl ? flo : rlo;
+        canon[j].w[1] = fl ? fhi : rhi;
+        canon[j].w[0] = fl ? flo : rlo;
         // window = bases [64+t-k+1, 64+t] of the 96-base frame -> bits (31-t) .. (31-t+k-1)
         const int b0 = 31 - t;                                // 0..31
         const u64 lo_bits = (k + b0 >= 64) ? (~0ull << b0) : (((1ull << k) - 1) << b0);
         const int over = k + b0 - 64;                         // bits spilling into inv_hi
         const u32 hi_bits = over > 0 ? ((over >= 32) ? 0xFFFFFFFFu : ((1u << over) - 1)) : 0u;
         if (((inv_lo & lo_bits) == 0) && ((inv_hi & hi_bits) == 0)) vmask |= (1u << j);
+    }
+    return vmask;
+}
+
+// ---------------------------------------------------------------- W-word k-mers (general; used for 65 <= k <= 128 with W = 4)
+// Windows ending at bases 32*wi + t0 + j, j < NP.  Frame = packed[wi-W .. wi].  Same scheme as gen_kmers2,
+// written over word arrays (all loops unroll; k is wave-uniform so the word-shift branches are uniform).
+template <int W, int NP>
+__device__ __forceinline__ u32 gen_kmersN(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                          u64 wi, int t0, int k, KN<W> (&canon)[NP]) {
+    u64 p[W + 1]; u32 iv[W + 1];
+#pragma unroll
+    for (int q = 0; q <= W; ++q) {
+        const bool in = wi >= (u64)q;
+        p[q] = in ? packed[wi - q] : 0ull;
+        iv[q] = in ? inval[wi - q] : 0xFFFFFFFFu;
+    }
+    u64 msk[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) { const int bits = 2 * k - 64 * i; msk[i] = bits >= 64 ? ~0ull : bits <= 0 ? 0ull : ((1ull << bits) - 1); }
+    // forward value of the 32W bases ending just before t0, cut to k bases
+    u64 f[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) f[i] = (t0 ? ((p[i + 1] << (2 * t0)) | (p[i] >> (64 - 2 * t0))) : p[i + 1]) & msk[i];
+    // reverse complement: reverse all 32W pairs, shift right by 64W - 2k bits, complement k pairs
+    u64 r[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) r[i] = rev_pairs(f[W - 1 - i]);
+    {
+        const int sh = 64 * W - 2 * k;
+        const int ws = sh >> 6, bs = sh & 63;
+#pragma unroll
+        for (int s = 0; s < W - 1; ++s)
+            if (ws > s) {
+#pragma unroll
+                for (int i = 0; i < W - 1; ++i) r[i] = r[i + 1];
+                r[W - 1] = 0ull;
+            }
+        if (bs) {
+#pragma unroll
+            for (int i = 0; i < W - 1; ++i) r[i] = (r[i] >> bs) | (r[i + 1] << (64 - bs));
+            r[W - 1] >>= bs;
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i) r[i] ^= (0xAAAAAAAAAAAAAAAAULL & msk[i]);
+    }
+    const int rcs = 2 * k - 2, rw = rcs >> 6, rb = rcs & 63;   // where the newest complement enters
+    u32 vmask = 0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int t = t0 + j;
+        const u64 c = (p[0] >> (62 - 2 * t)) & 3ull;
+#pragma unroll
+        for (int i = W - 1; i >= 1; --i) f[i] = ((f[i] << 2) | (f[i - 1] >> 62)) & msk[i];
+        f[0] = ((f[0] << 2) | c) & msk[0];
+#pragma unroll
+        for (int i = 0; i < W - 1; ++i) r[i] = (r[i] >> 2) | (r[i + 1] << 62);
+        r[W - 1] >>= 2;
+#pragma unroll
+        for (int i = 0; i < W; ++i) r[i] |= (i == rw) ? ((c ^ 2ull) << rb) : 0ull;
+        bool lt = false, decided = false;                        // f < r, most significant word first
+#pragma unroll
+        for (int i = W - 1; i >= 0; --i) { if (!decided && f[i] != r[i]) { lt = f[i] < r[i]; decided = true; } }
+#pragma unroll
+        for (int i = 0; i < W; ++i) canon[j].w[i] = lt ? f[i] : r[i];
+        // validity: frame base index e = 32W + t ends the window [e-k+1, e]; word q holds bases [32(W-q), 32(W-q)+31]
+        const int e = 32 * W + t;
+        u32 bad = 0;
+#pragma unroll
+        for (int q = 0; q <= W; ++q) {
+            const int b0 = 32 * (W - q);
+            const int lo = (e - k + 1) > b0 ? (e - k + 1) : b0;
+            const int hi = e < b0 + 31 ? e : b0 + 31;
+            if (lo <= hi) {
+                const int nb = hi - lo + 1;
+                const u32 m = (nb == 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)) << (31 - (hi - b0));
+                bad |= iv[q] & m;
+            }
+        }
+        if (!bad) vmask |= (1u << j);
     }
     return vmask;
 }

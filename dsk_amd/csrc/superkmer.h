@@ -239,8 +239,8 @@ __device__ __forceinline__ K2 sk_key2(const u64* r, int j, int k) {
     rlo ^= 0xAAAAAAAAAAAAAAAAull;
     rhi ^= (0xAAAAAAAAAAAAAAAAull & hmask);
     const bool fl = fhi < rhi || (fhi == rhi && flo < rlo);
-    K2 o; o.hi = fl ? fhi : rhi; o.lo = fl ? flo : rlo;
-    kmix2(o.hi, o.lo);
+    K2 o; o.w[1] = fl ? fhi : rhi; o.w[0] = fl ? flo : rlo;
+    kmixN(o);
     return o;
 }
 

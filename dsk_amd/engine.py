@@ -155,7 +155,7 @@ class KmerCounter:
         cfg.rank = rank
         self.kmer_size = kmer_size
         self.histo_max = histo_max
-        self.words = 1 if kmer_size <= 32 else 2
+        self.words = (kmer_size + 31) // 32          # 64-bit words of a k-mer at the ABI (1..4)
         self.world_size = world_size
         h = C.c_void_p()
         rc = self._lib.dskgpu_create(C.byref(cfg), C.byref(h))

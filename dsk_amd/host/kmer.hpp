@@ -126,20 +126,24 @@ struct Kmer {
 
 // Integer::apply<Functor,Parameter>(kmerSize, param): run Functor<span>()(param)
 // for the smallest compiled span that holds kmerSize (src/DSK.cpp:103;
-// KSIZE_LIST "32 64" here, CMakeLists.txt:42 lists up to 128).
+// KSIZE_LIST "32 64 96 128" as in CMakeLists.txt:42).
 struct Integer {
     template <template <size_t> class Functor, class Parameter>
     static void apply(size_t kmerSize, Parameter p) {
         if (kmerSize < 32) Functor<32>()(p);
         else if (kmerSize < 64) Functor<64>()(p);
-        else throw std::runtime_error("kmer size too large for the compiled spans (KSIZE_LIST=32 64): k must be < 64");
+        else if (kmerSize < 96) Functor<96>()(p);
+        else if (kmerSize < 128) Functor<128>()(p);
+        else throw std::runtime_error("kmer size too large for the compiled spans (KSIZE_LIST=32 64 96 128): k must be < 128");
     }
     // Same dispatch for C++17 callers: fct(std::integral_constant<size_t, span>()).
     template <class F>
     static void dispatch(size_t kmerSize, F&& fct) {
         if (kmerSize < 32) fct(std::integral_constant<size_t, 32>());
         else if (kmerSize < 64) fct(std::integral_constant<size_t, 64>());
-        else throw std::runtime_error("kmer size too large for the compiled spans (KSIZE_LIST=32 64): k must be < 64");
+        else if (kmerSize < 96) fct(std::integral_constant<size_t, 96>());
+        else if (kmerSize < 128) fct(std::integral_constant<size_t, 128>());
+        else throw std::runtime_error("kmer size too large for the compiled spans (KSIZE_LIST=32 64 96 128): k must be < 128");
     }
 };
 

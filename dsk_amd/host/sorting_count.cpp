@@ -193,12 +193,21 @@ void SortingCountBase::execute() {
     const uint32_t np = be->numPartitions();
     openPartitions(np);
     nb_solid_ = 0;
-    std::vector<uint64_t> kbuf; std::vector<uint32_t> abuf;
+    // the engine returns ceil(k/32) words per k-mer; the row type of this span has span/32 (one more
+    // when k is a multiple of 32, because span k serves k < span): zero-extend
+    const size_t bw = (k + 31) / 32;
+    std::vector<uint64_t> kbuf, wide; std::vector<uint32_t> abuf;
     for (uint32_t p = 0; p < np; ++p) {
         const uint64_t n = be->partitionSize(p);
-        kbuf.resize(n * words_ + 1); abuf.resize(n + 1);
+        kbuf.resize(n * bw + 1); abuf.resize(n + 1);
         if (n) be->partitionCopy(p, kbuf.data(), abuf.data());
-        writePartition(p, kbuf.data(), abuf.data(), n, amin, compress);
+        const uint64_t* rows = kbuf.data();
+        if (bw != words_) {
+            wide.assign(n * words_ + 1, 0);
+            for (uint64_t i = 0; i < n; ++i) for (size_t w = 0; w < bw; ++w) wide[i * words_ + w] = kbuf[i * bw + w];
+            rows = wide.data();
+        }
+        writePartition(p, rows, abuf.data(), n, amin, compress);
     }
     Group& dg = storage_->getGroup("dsk");
     dg.setProperty("kmer_size", std::to_string(k));

@@ -20,8 +20,8 @@
  *
  * K-mer value convention (README.md:104-112, utils/dsk2ascii.cpp:104): A=0,
  * C=1, T=2, G=3, first base most significant; canonical = min(fwd, revcomp).
- * A k-mer is `words` 64-bit words, least-significant word first
- * (words = 1 for k <= 32, 2 for k <= 64).
+ * A k-mer is `words` = ceil(k / 32) 64-bit words, least-significant word first
+ * (1 for k <= 32, 2 for k <= 64, 3 for k <= 96, 4 for k <= 128).
  */
 #ifndef DSKGPU_H
 #define DSKGPU_H
@@ -44,7 +44,7 @@ typedef struct dskgpu_ctx dskgpu_ctx;
 /* Options of SortingCountAlgorithm<>::getOptionsParser() that reach the
  * count path (src/DSK.cpp:83; README.md:12,56; scripts/simple_test.sh:36,88). */
 typedef struct dskgpu_config {
-    uint32_t kmer_size;       /* -kmer-size, 1..63 (span 32: k<32, span 64: k<64; README.md:115-122) */
+    uint32_t kmer_size;       /* -kmer-size, 1..128 (gatb spans 32/64/96/128 serve k < span; README.md:115-122, CMakeLists.txt:42) */
     uint32_t abundance_min;   /* -abundance-min (solid <=> min <= count <= max) */
     uint32_t abundance_max;   /* -abundance-max                                */
     uint32_t histo_max;       /* -histo-max: histogram rows 1..histo_max (10000) */
@@ -154,9 +154,10 @@ int dskgpu_histogram2d(const dskgpu_ctx* ctx, uint64_t* out, uint32_t nrows);
  * ascending value ranges, so the concatenation is globally sorted. */
 uint32_t dskgpu_num_partitions(const dskgpu_ctx* ctx);
 uint64_t dskgpu_partition_size(const dskgpu_ctx* ctx, uint32_t p);
-/* kmers: size*words u64 (row-major, LSW first); abundance: size u32. Host memory. */
+/* kmers: size*words u64 (row-major, LSW first, words = ceil(k/32)); abundance: size u32. Host memory. */
 int dskgpu_partition_copy(const dskgpu_ctx* ctx, uint32_t p, uint64_t* kmers, uint32_t* abundance);
-/* Device pointers to the full sorted result (valid until the next count/destroy). */
+/* Device pointers to the full sorted result (valid until the next count/destroy).  d_kmers = word 0 of
+ * every row; the device keeps one array per word (struct of arrays), higher words via dskgpu_partition_copy. */
 int dskgpu_result_device(const dskgpu_ctx* ctx, const void** d_kmers, const void** d_abundance, uint64_t* n_rows);
 
 /* Per-stage device time of the last count (flag DSKGPU_F_TIMING).  Returns the
@@ -166,7 +167,7 @@ int dskgpu_stage_times(const dskgpu_ctx* ctx, const char** names, float* ms, int
 /* ---- kernel-level entry points used by the parity tests (device pointers) */
 /* ASCII -> 2-bit packed words + invalid mask, one u64 / u32 per 32 bases. */
 int dskgpu_k_encode(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, void* d_packed, void* d_invalid);
-/* Canonical k-mer (words u64, LSW first) + validity byte for the window ending at every byte. */
+/* Canonical k-mer (words = ceil(k/32) u64, LSW first) + validity byte for the window ending at every byte. */
 int dskgpu_k_enumerate(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, void* d_kmers, void* d_valid);
 /* Minimizer (u32) of the window ending at every byte (0 when invalid). */
 int dskgpu_k_minimizers(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, void* d_minim, void* d_valid);

@@ -18,7 +18,8 @@
 struct dsko_result {
     int k;
     uint64_t total, distinct;
-    uint64_t *lo, *hi;
+    uint64_t *lo, *hi;      /* words 0 and 1 of every row */
+    uint64_t *w2, *w3;      /* words 2 and 3 (k > 64 only, else NULL) */
     uint32_t* ab;
 };
 
@@ -41,18 +42,47 @@ static void init_code(void) {
 #define KT unsigned __int128
 #define SFX 128
 #include "dsk_oracle_core.inc"
+/* k in 65..128: 256-bit keys.  C23 _BitInt needs clang (ROCm's is in the image); a gcc-11 build of the
+ * oracle simply lacks this width and dsko_count returns NULL for k > 64. */
+#if defined(__clang__) && defined(__BITINT_MAXWIDTH__) && __BITINT_MAXWIDTH__ >= 256
+#define DSKO_HAVE_256 1
+#undef KT
+#undef SFX
+#define KT unsigned _BitInt(256)
+#define SFX 256
+#include "dsk_oracle_core.inc"
+#endif
 #undef KT
 #undef SFX
 
 dsko_result* dsko_count(const uint8_t* stream, uint64_t nbytes, int k, int nthreads) {
     pthread_once(&g_once, init_code);
-    if (k < 1 || k > 64) return NULL;
+    if (k < 1 || k > 128) return NULL;
+#ifdef DSKO_HAVE_256
+    if (k > 64) return count256(stream, nbytes, k, nthreads);
+#else
+    if (k > 64) return NULL;
+#endif
     return k <= 32 ? count64(stream, nbytes, k, nthreads) : count128(stream, nbytes, k, nthreads);
+}
+
+int dsko_max_kmer_size(void) {
+#ifdef DSKO_HAVE_256
+    return 128;
+#else
+    return 64;
+#endif
 }
 
 void dsko_free(dsko_result* r) {
     if (!r) return;
-    free(r->lo); free(r->hi); free(r->ab); free(r);
+    free(r->lo); free(r->hi); free(r->w2); free(r->w3); free(r->ab); free(r);
+}
+
+void dsko_rows4(const dsko_result* r, uint64_t* w0, uint64_t* w1, uint64_t* w2, uint64_t* w3, uint32_t* abundance) {
+    dsko_rows(r, w0, w1, abundance);
+    if (w2) { if (r->w2) memcpy(w2, r->w2, r->distinct * sizeof(uint64_t)); else memset(w2, 0, r->distinct * sizeof(uint64_t)); }
+    if (w3) { if (r->w3) memcpy(w3, r->w3, r->distinct * sizeof(uint64_t)); else memset(w3, 0, r->distinct * sizeof(uint64_t)); }
 }
 
 uint64_t dsko_total_kmers(const dsko_result* r) { return r->total; }
@@ -110,6 +140,33 @@ void dsko_enumerate(const uint8_t* s, uint64_t n, int k, uint64_t* lo, uint64_t*
             if (hi) hi[i] = (uint64_t)(canon >> 64);
         }
     }
+}
+
+/* Same for k up to 128: words[4*i .. 4*i+3] = the canonical k-mer ending at byte i, least significant word first. */
+int dsko_enumerate4(const uint8_t* s, uint64_t n, int k, uint64_t* words, uint8_t* valid) {
+#ifdef DSKO_HAVE_256
+    pthread_once(&g_once, init_code);
+    typedef unsigned _BitInt(256) K;
+    const K mask = (k == 128) ? ~(K)0 : (((K)1 << (2 * k)) - 1);
+    K fwd = 0, rc = 0; int run = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        uint8_t c = g_code[s[i]];
+        valid[i] = 0;
+        for (int x = 0; x < 4; x++) words[4 * i + x] = 0;
+        if (c > 3) { run = 0; fwd = rc = 0; continue; }
+        fwd = ((fwd << 2) | c) & mask;
+        rc = (rc >> 2) | ((K)(c ^ 2) << (2 * (k - 1)));
+        if (++run >= k) {
+            K canon = fwd < rc ? fwd : rc;
+            valid[i] = 1;
+            for (int x = 0; x < 4; x++) words[4 * i + x] = (uint64_t)(canon >> (64 * x));
+        }
+    }
+    return 0;
+#else
+    (void)s; (void)n; (void)k; (void)words; (void)valid;
+    return -1;
+#endif
 }
 
 void dsko_minimizers(const uint8_t* s, uint64_t n, int k, int m, uint32_t* minim, uint8_t* valid) {

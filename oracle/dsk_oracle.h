@@ -42,8 +42,10 @@ typedef struct dsko_result dsko_result;
 int dsko_load_bank(const char* uri, uint8_t** stream, uint64_t* nbytes, uint64_t* nreads);
 void dsko_free_stream(uint8_t* stream);
 
-/* Count canonical k-mers (1 <= k <= 64) of a byte stream in which every byte
- * outside "ACGTacgt" terminates the current window.  nthreads >= 1. */
+/* Count canonical k-mers (1 <= k <= dsko_max_kmer_size()) of a byte stream in which every byte
+ * outside "ACGTacgt" terminates the current window.  nthreads >= 1.  k in 65..128 uses 256-bit keys
+ * (C23 _BitInt, clang builds only -- the Makefile picks ROCm's clang when it is there). */
+int dsko_max_kmer_size(void);                       /* 128, or 64 for a gcc build */
 dsko_result* dsko_count(const uint8_t* stream, uint64_t nbytes, int k, int nthreads);
 void dsko_free(dsko_result* r);
 
@@ -52,6 +54,8 @@ uint64_t dsko_num_distinct(const dsko_result* r);   /* distinct canonical  */
 /* Rows in ascending k-mer value (A<C<T<G, first base most significant).
  * lo = low 64 bits, hi = high 64 bits (0 when k <= 32). */
 void dsko_rows(const dsko_result* r, uint64_t* lo, uint64_t* hi, uint32_t* abundance);
+/* Same with all four 64-bit words of the value (w2 = w3 = 0 when k <= 64). */
+void dsko_rows4(const dsko_result* r, uint64_t* w0, uint64_t* w1, uint64_t* w2, uint64_t* w3, uint32_t* abundance);
 /* out[i] for i in 0..histo_max: number of distinct k-mers with
  * min(count, histo_max) == i  (out[0] is always 0). */
 void dsko_histogram(const dsko_result* r, uint64_t* out, uint32_t histo_max);
@@ -64,6 +68,8 @@ void dsko_kmer_to_string(uint64_t lo, uint64_t hi, int k, char* out /* k+1 bytes
  * valid[i]=1 and (lo[i],hi[i]) set iff a full ACGT window ends at byte i. */
 void dsko_enumerate(const uint8_t* stream, uint64_t nbytes, int k,
                     uint64_t* lo, uint64_t* hi, uint8_t* valid);
+/* k up to 128: words[4*i + x] = word x of the canonical k-mer ending at byte i.  Returns -1 in a gcc build. */
+int dsko_enumerate4(const uint8_t* stream, uint64_t nbytes, int k, uint64_t* words, uint8_t* valid);
 /* Minimizer (m <= 16) of every valid k-mer: smallest canonical m-mer value in
  * the window, A<C<T<G numeric order (restates the idea of
  * doc/paper.tex:60-76 "partition by a function of the k-mer"; the exact

@@ -5,6 +5,7 @@
 // machine without a GPU.  The product `dsk` binary registers the GPU engine
 // only and has no such fallback.
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <map>
 
@@ -20,23 +21,25 @@ public:
     void push(const char* d, size_t n) override { stream_.insert(stream_.end(), d, d + n); stream_.push_back('\n'); }
     void nextBank() override { if (ends_.empty() || ends_.back() != stream_.size()) ends_.push_back(stream_.size()); }
     void finish() override {
-        words_ = cfg_.kmer_size <= 32 ? 1 : 2;
+        words_ = (cfg_.kmer_size + 31) / 32;
         const bool banked = ends_.size() > 1 && (cfg_.solidity_kind != 0 || cfg_.histo2d);
         if (!banked) {
             r_ = dsko_count(reinterpret_cast<const uint8_t*>(stream_.data()), stream_.size(), (int)cfg_.kmer_size, 4);
             if (!r_) throw dsk::Exception("oracle: bad kmer size");
             uint64_t d = dsko_num_distinct(r_);
-            std::vector<uint64_t> lo(d + 1), hi(d + 1); std::vector<uint32_t> ab(d + 1);
-            dsko_rows(r_, lo.data(), hi.data(), ab.data());
+            std::vector<uint64_t> w[4]; for (auto& v : w) v.resize(d + 1);
+            std::vector<uint32_t> ab(d + 1);
+            dsko_rows4(r_, w[0].data(), w[1].data(), w[2].data(), w[3].data(), ab.data());
             total_ = dsko_total_kmers(r_); distinct_ = d;
             hist_.assign(cfg_.histo_max + 1, 0); dsko_histogram(r_, hist_.data(), cfg_.histo_max);
             for (uint64_t i = 0; i < d; ++i) if (ab[i] >= cfg_.abundance_min && ab[i] <= cfg_.abundance_max) {
-                k_.push_back(lo[i]); if (words_ == 2) k_.push_back(hi[i]); a_.push_back(ab[i]);
+                for (size_t x = 0; x < words_; ++x) k_.push_back(w[x][i]);
+                a_.push_back(ab[i]);
             }
             return;
         }
         // several banks: per-bank oracle counts merged on the k-mer (restatement of include/dskgpu.h DSKGPU_SOLIDITY_*)
-        typedef std::pair<uint64_t, uint64_t> K;          // (hi, lo): map order = k-mer order
+        typedef std::array<uint64_t, 4> K;                // most significant word first: map order = k-mer order
         std::map<K, std::vector<uint32_t>> m;
         const size_t B = ends_.size();
         for (size_t b = 0; b < B; ++b) {
@@ -44,9 +47,10 @@ public:
             dsko_result* r = dsko_count(reinterpret_cast<const uint8_t*>(stream_.data()) + beg, ends_[b] - beg, (int)cfg_.kmer_size, 4);
             if (!r) throw dsk::Exception("oracle: bad kmer size");
             uint64_t d = dsko_num_distinct(r); total_ += dsko_total_kmers(r);
-            std::vector<uint64_t> lo(d + 1), hi(d + 1); std::vector<uint32_t> ab(d + 1);
-            dsko_rows(r, lo.data(), hi.data(), ab.data());
-            for (uint64_t i = 0; i < d; ++i) { auto& v = m[K(hi[i], lo[i])]; v.resize(B, 0); v[b] = ab[i]; }
+            std::vector<uint64_t> w[4]; for (auto& v : w) v.resize(d + 1);
+            std::vector<uint32_t> ab(d + 1);
+            dsko_rows4(r, w[0].data(), w[1].data(), w[2].data(), w[3].data(), ab.data());
+            for (uint64_t i = 0; i < d; ++i) { auto& v = m[K{w[3][i], w[2][i], w[1][i], w[0][i]}]; v.resize(B, 0); v[b] = ab[i]; }
             dsko_free(r);
         }
         distinct_ = m.size();
@@ -71,7 +75,7 @@ public:
                 case 5: solid = custom; break;
                 default: solid = sum >= cfg_.abundance_min && sum <= cfg_.abundance_max;
             }
-            if (solid) { k_.push_back(kv.first.second); if (words_ == 2) k_.push_back(kv.first.first); a_.push_back((uint32_t)std::min<uint64_t>(sum, 0xFFFFFFFFull)); }
+            if (solid) { for (size_t x = 0; x < words_; ++x) k_.push_back(kv.first[3 - x]); a_.push_back((uint32_t)std::min<uint64_t>(sum, 0xFFFFFFFFull)); }
         }
     }
     void histogram(std::vector<uint64_t>& h) override { h = hist_; }

@@ -9,11 +9,17 @@ import numpy as np
 
 
 class OracleResult:
-    def __init__(self, k, total, lo, hi, ab, hist_fn):
+    def __init__(self, k, total, lo, hi, ab, hist_fn, w2=None, w3=None):
         self.k = k
         self.total = total
         self.lo, self.hi, self.ab = lo, hi, ab
+        self.w2, self.w3 = w2, w3          # words 2 and 3 of the value (k > 64)
         self._hist_fn = hist_fn
+
+    def words(self):
+        """uint64[n, ceil(k/32)]: the value of every row, least significant word first."""
+        cols = [self.lo, self.hi, self.w2, self.w3][: (self.k + 31) // 32]
+        return np.stack(cols, axis=1)
 
     @property
     def distinct(self):
@@ -30,7 +36,10 @@ class OracleResult:
         """k-mer values as Python ints (for k > 32) or uint64 array."""
         if self.k <= 32:
             return self.lo
-        return np.array([(int(h) << 64) | int(l) for h, l in zip(self.hi, self.lo)], dtype=object)
+        if self.k <= 64:
+            return np.array([(int(h) << 64) | int(l) for h, l in zip(self.hi, self.lo)], dtype=object)
+        return np.array([(int(d) << 192) | (int(c) << 128) | (int(h) << 64) | int(l)
+                         for d, c, h, l in zip(self.w3, self.w2, self.hi, self.lo)], dtype=object)
 
 
 class Oracle:
@@ -48,6 +57,10 @@ class Oracle:
         lib.dsko_num_distinct.argtypes = [vp]
         lib.dsko_num_distinct.restype = u64
         lib.dsko_rows.argtypes = [vp, vp, vp, vp]
+        lib.dsko_rows4.argtypes = [vp, vp, vp, vp, vp, vp]
+        lib.dsko_max_kmer_size.restype = C.c_int
+        lib.dsko_enumerate4.argtypes = [vp, u64, C.c_int, vp, vp]
+        lib.dsko_enumerate4.restype = C.c_int
         lib.dsko_histogram.argtypes = [vp, vp, u32]
         lib.dsko_num_solid.argtypes = [vp, u32, u32]
         lib.dsko_num_solid.restype = u64
@@ -78,7 +91,12 @@ class Oracle:
             lo = np.zeros(d, np.uint64)
             hi = np.zeros(d, np.uint64)
             ab = np.zeros(d, np.uint32)
-            self.lib.dsko_rows(h, lo.ctypes.data, hi.ctypes.data, ab.ctypes.data)
+            w2 = w3 = None
+            if k > 64:
+                w2 = np.zeros(d, np.uint64); w3 = np.zeros(d, np.uint64)
+                self.lib.dsko_rows4(h, lo.ctypes.data, hi.ctypes.data, w2.ctypes.data, w3.ctypes.data, ab.ctypes.data)
+            else:
+                self.lib.dsko_rows(h, lo.ctypes.data, hi.ctypes.data, ab.ctypes.data)
         finally:
             self.lib.dsko_free(h)
 
@@ -87,7 +105,7 @@ class Oracle:
             np.add.at(out, np.minimum(ab, histo_max), 1)
             return out
 
-        return OracleResult(k, total, lo, hi, ab, hist)
+        return OracleResult(k, total, lo, hi, ab, hist, w2, w3)
 
     def enumerate(self, stream: np.ndarray, k: int):
         stream = np.ascontiguousarray(stream, dtype=np.uint8)
@@ -97,6 +115,19 @@ class Oracle:
         valid = np.zeros(n, np.uint8)
         self.lib.dsko_enumerate(stream.ctypes.data, n, k, lo.ctypes.data, hi.ctypes.data, valid.ctypes.data)
         return lo, hi, valid
+
+    def enumerate_words(self, stream: np.ndarray, k: int):
+        """-> (uint64[n, 4] canonical k-mer ending at every byte, valid[n]); any k <= 128."""
+        stream = np.ascontiguousarray(stream, dtype=np.uint8)
+        n = len(stream)
+        words = np.zeros((n, 4), np.uint64)
+        valid = np.zeros(n, np.uint8)
+        if self.lib.dsko_enumerate4(stream.ctypes.data, n, k, words.ctypes.data, valid.ctypes.data) != 0:
+            raise RuntimeError("oracle built without 256-bit keys")
+        return words, valid
+
+    def max_kmer_size(self) -> int:
+        return int(self.lib.dsko_max_kmer_size())
 
     def minimizers(self, stream: np.ndarray, k: int, m: int):
         stream = np.ascontiguousarray(stream, dtype=np.uint8)
@@ -112,5 +143,10 @@ class Oracle:
         return buf.value.decode()
 
     def ascii_lines(self, res: OracleResult, amin=2, amax=2147483647):
+        if res.k > 64:      # four-word values: letters straight from the integer (A=0 C=1 T=2 G=3, first base most significant)
+            keep = (res.ab >= amin) & (res.ab <= amax)
+            k = res.k
+            return ["".join("ACTG"[(int(v) >> (2 * (k - 1 - i))) & 3] for i in range(k)) + f" {a}"
+                    for v, a in zip(res.values()[keep], res.ab[keep])]
         lo, hi, ab = res.solid(amin, amax)
         return [f"{self.kmer_to_string(l, h, res.k)} {a}" for l, h, a in zip(lo, hi, ab)]

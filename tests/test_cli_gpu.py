@@ -32,6 +32,12 @@ def test_known_answer_dump_on_gpu(bins, tmp_path, k, md5, n):
     known_answer_dump(bins["dsk"], bins["dsk2ascii"], str(tmp_path), k, md5, n)
 
 
+@pytest.mark.parametrize("k", [32, 64, 65, 96, 127])
+def test_span_borders_and_large_k_on_gpu(bins, tmp_path, oracle, k):
+    from tests.test_host_cli import test_span_borders_and_large_k
+    test_span_borders_and_large_k(bins, tmp_path, oracle, k)
+
+
 def test_engine_is_the_hip_library(bins, tmp_path):
     """-verbose 1 prints the info tree; it must name the gfx950 engine (no CPU path in the product binary)."""
     g = os.path.join(ROOT, "tests", "golden")

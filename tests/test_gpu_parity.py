@@ -41,10 +41,9 @@ def check_against_oracle(oracle, stream, k, dev, amin=2, amax=2147483647, **kw):
     assert st["n_solid"] == len(rab)
     assert (hist == ref.histogram(10000)).all()
     assert kmers.shape[0] == len(rab)
-    if k <= 32:
-        assert (kmers[:, 0] == lo).all()          # ascending order, same as the oracle
-    else:
-        assert (kmers[:, 0] == lo).all() and (kmers[:, 1] == hi).all()
+    keep = (ref.ab >= amin) & (ref.ab <= amax)
+    assert kmers.shape == (len(rab), (k + 31) // 32)
+    assert (kmers == ref.words()[keep]).all()     # ascending order, same as the oracle; every 64-bit word
     assert (ab == rab).all()
     return st
 
@@ -77,6 +76,95 @@ def test_enumerate_two_words(oracle, golden_dir, dev):
         o = out.cpu().numpy().view(np.uint64).reshape(-1, 2)
         assert (val.cpu().numpy() == valid).all(), k
         assert (o[:, 0] == lo).all() and (o[:, 1] == hi).all(), k
+
+
+@pytest.mark.parametrize("k", [65, 80, 95, 96, 97, 127, 128])
+def test_enumerate_four_words(oracle, golden_dir, dev, k):
+    """k = 65..128: four-word device keys (gen_kmersN), (k+31)/32 words per k-mer at the ABI."""
+    from dsk_amd import KmerCounter
+    s, _ = oracle.load_bank(os.path.join(golden_dir, "longread.fasta"))
+    rng = np.random.default_rng(5)
+    long_runs = rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), size=30000)
+    long_runs[rng.integers(0, 30000, size=40)] = ord("N")                                  # runs of ~750 bases
+    s = np.concatenate([s[:30000], np.frombuffer(b"ACGTNNNNacgtacgtACGTRYKM" * 9, dtype=np.uint8), long_runs, s[30000:45000]])
+    wo = (k + 31) // 32
+    t = torch.from_numpy(s).to(dev)
+    out = torch.zeros(wo * len(s), dtype=torch.int64, device=dev)
+    val = torch.zeros(len(s), dtype=torch.uint8, device=dev)
+    with KmerCounter(kmer_size=k) as kc:
+        kc.k_enumerate(t.data_ptr(), len(s), out.data_ptr(), val.data_ptr())
+    words, valid = oracle.enumerate_words(s, k)
+    assert valid.sum() > 10000
+    assert (val.cpu().numpy() == valid).all()
+    assert (out.cpu().numpy().view(np.uint64).reshape(-1, wo) == words[:, :wo]).all()
+    if wo < 4:
+        assert (words[:, wo:] == 0).all()
+
+
+@pytest.mark.parametrize("k", [65, 80, 96, 97, 127, 128])
+def test_four_word_kmers_golden(oracle, golden_dir, dev, k):
+    s, _ = oracle.load_bank(os.path.join(golden_dir, "longread.fasta"))
+    check_against_oracle(oracle, s, k, dev, amin=1)
+    s2, _ = oracle.load_bank(os.path.join(golden_dir, "read50x_ref10K_e001.fasta.gz"))     # 100 bp reads: none for k > 100
+    check_against_oracle(oracle, s2, k, dev)
+
+
+def test_four_word_kmers_synthetic_two_levels(oracle, dev):
+    from dsk_amd import synth
+    reads = synth.make_reads(synth.make_genome(300_000, dev), 100_000, 150).cpu().numpy()
+    st = check_against_oracle(oracle, reads, 101, dev)         # 5 M k-mers of 4 words: two partition levels
+    assert st["n_levels"] == 2
+    check_against_oracle(oracle, reads[: 151 * 30_000], 72, dev, amin=3, amax=40)
+    for k in (127, 128):
+        st = check_against_oracle(oracle, reads[: 151 * 30_000], k, dev)
+        assert st["n_kmers"] > 500_000
+
+
+def test_four_word_multi_pass_banks_and_exchange(oracle, golden_dir, dev):
+    """The side paths at k > 64: several passes over the key space, per-bank solidity, explicit-key exchange."""
+    from dsk_amd import KmerCounter, synth
+    reads = synth.make_reads(synth.make_genome(100_000, dev), 40_000, 150).cpu().numpy()
+    st = check_against_oracle(oracle, reads, 80, dev, max_pass_mkeys=1)
+    assert st["n_passes"] >= 3
+    # two banks, solidity "min" (numpy restatement over per-bank oracle counts)
+    a, b = reads[: 151 * 15_000], reads[151 * 15_000: 151 * 32_000]
+    both = np.concatenate([a, b])
+    t = torch.from_numpy(both).to(dev)
+    with KmerCounter(kmer_size=70, abundance_min=2, solidity_kind="min") as kc:
+        kc.set_reads_device(t.data_ptr(), t.numel())
+        kc.set_banks([len(a), len(both)])
+        kc.count()
+        rows, ab = kc.rows()
+    ra, rb = oracle.count(a, 70), oracle.count(b, 70)
+    da = {int(v): int(c) for v, c in zip(ra.values(), ra.ab)}
+    want = sorted((int(v), da[int(v)] + int(c)) for v, c in zip(rb.values(), rb.ab) if int(v) in da and min(da[int(v)], int(c)) >= 2)
+    got = [((int(r[2]) << 128) | (int(r[1]) << 64) | int(r[0]), int(c)) for r, c in zip(rows, ab)]
+    assert got == want and len(want) > 1000
+    # multi-GPU: k > 64 travels as explicit four-word keys
+    recs = bytes(reads[: 151 * 20_000]).split(b"\n")
+    ctxs, sends, counts = [], [], []
+    for r in range(2):
+        shard = torch.from_numpy(np.frombuffer(b"\n".join(recs[r::2]) + b"\n", dtype=np.uint8).copy()).to(dev)
+        kc = KmerCounter(kmer_size=90, abundance_min=1, world_size=2, rank=r)
+        kc.set_reads_device(shard.data_ptr(), shard.numel())
+        send = torch.zeros(kc.mg_send_capacity_words(), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        c = kc.mg_scatter(send.data_ptr(), send.numel())
+        assert all(x % 4 == 0 for x in c)
+        ctxs.append(kc); sends.append(send); counts.append(c)
+    got_rows, got_ab = [], []
+    for d in range(2):
+        recv = torch.cat([sends[src][sum(counts[src][:d]): sum(counts[src][:d]) + counts[src][d]] for src in range(2)])
+        torch.cuda.synchronize()
+        ctxs[d].mg_count(recv.data_ptr(), recv.numel())
+        rr, aa = ctxs[d].rows()
+        got_rows.append(rr); got_ab.append(aa)
+    rows = np.concatenate(got_rows); ab = np.concatenate(got_ab)
+    ref = oracle.count(reads[: 151 * 20_000], 90)
+    order = np.lexsort([rows[:, x] for x in range(3)])
+    assert (rows[order] == ref.words()).all() and (ab[order] == ref.ab).all()
+    for c in ctxs:
+        c.close()
 
 
 @pytest.mark.parametrize("k", [27, 31])

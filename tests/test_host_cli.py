@@ -85,6 +85,22 @@ def test_known_answer_dumps(bins, tmp_path, k, md5, n):
     known_answer_dump(bins["dsk"], bins["dsk2ascii"], str(tmp_path), k, md5, n)
 
 
+@pytest.mark.parametrize("k", [32, 64, 65, 95, 96, 127])
+def test_span_borders_and_large_k(bins, tmp_path, oracle, k):
+    """Spans 32/64/96/128 (README.md:115-122): a span serves k < span, so k = 32, 64, 96 use the next one up
+    (one more, all-zero, word per row); k up to 127 uses four-word values.  Not pinned by any reference golden:
+    checked against the oracle, whose 256-bit path is itself checked against Python integers (test_oracle_golden)."""
+    tmp = str(tmp_path)
+    subprocess.check_call([bins["dsk"], "-file", f"{G}/longread.fasta", "-kmer-size", str(k), "-abundance-min", "1", "-out", "big", "-verbose", "0"], cwd=tmp)
+    subprocess.check_call([bins["dsk2ascii"], "-file", "big", "-out", "big.txt", "-verbose", "0"], cwd=tmp)
+    s, _ = oracle.load_bank(f"{G}/longread.fasta")
+    ref = oracle.count(s, k)
+    assert open(os.path.join(tmp, "big.txt")).read().splitlines() == oracle.ascii_lines(ref, amin=1)
+    hdr = subprocess.check_output([H5DUMP, "-H", "big.h5"], cwd=tmp).decode()
+    words = k // 32 + 1
+    assert ('H5T_STD_U64LE "value"' in hdr) if words == 1 else (f"H5T_ARRAY {{ [{words}] H5T_STD_U64LE }}" in hdr)
+
+
 def test_layout_and_attributes(bins, tmp_path):
     tmp = str(tmp_path)
     subprocess.check_call([bins["dsk"], "-file", f"{G}/longread.fasta", "-kmer-size", "31", "-out", "lay", "-verbose", "0",
@@ -135,8 +151,8 @@ def test_error_paths(bins, tmp_path):
     assert r.returncode == 1 and b"-file" in r.stdout and b"mandatory" in r.stdout   # src/main.cpp:37-40
     r = subprocess.run([bins["dsk"], "-file", f"{G}/shortread.fasta", "-bogus", "1"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and b"Unknown parameter" in r.stdout
-    r = subprocess.run([bins["dsk"], "-file", f"{G}/shortread.fasta", "-kmer-size", "64"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode == 1 and b"EXCEPTION" in r.stderr
+    r = subprocess.run([bins["dsk"], "-file", f"{G}/shortread.fasta", "-kmer-size", "128"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"EXCEPTION" in r.stderr and b"k must be < 128" in r.stderr   # KSIZE_LIST 32 64 96 128 (CMakeLists.txt:42)
     r = subprocess.run([bins["dsk2ascii"], "-file", "nope", "-out", "x"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and r.stdout.startswith(b"EXCEPTION: ")           # utils/dsk2ascii.cpp:129-133 (stdout)
     r = subprocess.run([bins["dsk"], "-help"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)

@@ -113,3 +113,35 @@ def test_minimizer_bruteforce_small(oracle):
                     r |= (c ^ 2) << (2 * t)
                 best = min(f, r) if best is None else min(best, f, r)
             assert mm[i] == best
+
+
+@pytest.mark.parametrize("k", [65, 80, 96, 97, 127, 128])
+def test_oracle_256bit_keys_against_python_integers(oracle, golden_dir, k):
+    """k > 64 uses 256-bit keys (C23 _BitInt, clang build).  No reference golden covers these sizes, so the
+    width is anchored on an independent pure-Python count with unbounded integers (same rules: A=0 C=1 T=2
+    G=3, first base most significant, canonical = min(fwd, revcomp), non-ACGT breaks the window)."""
+    from collections import Counter
+    assert oracle.max_kmer_size() == 128
+    s, _ = oracle.load_bank(os.path.join(golden_dir, "longread.fasta"))
+    s = s[:2500]
+    code = {65: 0, 67: 1, 84: 2, 71: 3, 97: 0, 99: 1, 116: 2, 103: 3}
+    cnt = Counter()
+    run = []
+    for ch in bytes(s) + b"\n":
+        if ch in code:
+            run.append(code[ch])
+            continue
+        for i in range(len(run) - k + 1):
+            fw = rc = 0
+            for j in range(k):
+                fw = (fw << 2) | run[i + j]
+                rc |= (run[i + j] ^ 2) << (2 * j)
+            cnt[min(fw, rc)] += 1
+        run = []
+    r = oracle.count(s, k)
+    exp = sorted(cnt.items())
+    assert r.total == sum(cnt.values()) and r.distinct == len(exp)
+    assert [int(v) for v in r.values()] == [e[0] for e in exp]
+    assert [int(a) for a in r.ab] == [e[1] for e in exp]
+    words, valid = oracle.enumerate_words(s, k)
+    assert int(valid.sum()) == r.total
