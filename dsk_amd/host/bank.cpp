@@ -14,6 +14,8 @@
 #include <fstream>
 #include <mutex>
 #include <thread>
+#include <atomic>
+#include <condition_variable>
 
 namespace dsk {
 
@@ -119,7 +121,7 @@ const char* next_record_start(const char* base, const char* from, const char* en
     return end;
 }
 
-// One FASTA/FASTQ file.  gzip'ed: single inflate stream (zlib).  Plain and large: memory-mapped
+// One FASTA/FASTQ file.  gzip'ed: inflate overlapped with parsing, BGZF members inflated by a thread pool.  Plain and large: memory-mapped
 // and parsed by several threads on record-aligned ranges (the sink is serialised by a mutex;
 // counting does not depend on record order).
 class BankFasta : public IBank {
@@ -143,6 +145,11 @@ public:
             uint64_t n = 0;
             if (stream_parallel(chunkBytes, sink, size, nthreads, n)) return n;
         }
+        if (gz && size >= (1u << 20)) {
+            uint64_t n = 0;
+            if (nthreads > 1 && stream_bgzf(chunkBytes, sink, size, nthreads, n)) return n;
+            return stream_gz_pipelined(chunkBytes, sink);
+        }
         return stream_serial(chunkBytes, sink);
     }
 private:
@@ -162,25 +169,13 @@ private:
         ps.finish();
         return ps.nseq;
     }
-    bool stream_parallel(size_t chunkBytes, const Sink& sink, uint64_t size, unsigned nthreads, uint64_t& nseq) {
-        int fd = open(path_.c_str(), O_RDONLY);
-        if (fd < 0) return false;
-        void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-        close(fd);
-        if (m == MAP_FAILED) return false;
-        const char* base = (const char*)m; const char* end = base + size;
-        const char* p = base; while (p < end && (*p == '\n' || *p == '\r' || *p == ' ')) ++p;
-        const char kind = p < end ? *p : 0;
-        if (kind != '>' && kind != '@') { munmap(m, size); return false; }
-        if (kind == '@') {          // the range cutter assumes 4-line FASTQ records: check the first one
-            const char* l1 = (const char*)memchr(p, '\n', (size_t)(end - p));
-            const char* l2 = l1 ? (const char*)memchr(l1 + 1, '\n', (size_t)(end - (l1 + 1))) : nullptr;
-            if (!l2 || l2 + 1 >= end || l2[1] != '+') { munmap(m, size); return false; }
-        }
+    // Parse [p, end) of an uncompressed buffer with several threads on record-aligned ranges.
+    static uint64_t parse_parallel(const char* base, const char* p, const char* end, char kind, size_t chunkBytes, const Sink& sink, unsigned nthreads) {
+        const uint64_t size = (uint64_t)(end - p);
         nthreads = (unsigned)std::min<uint64_t>(nthreads, std::max<uint64_t>(1, size / std::max<uint64_t>(1, std::min<uint64_t>(8u << 20, size / 4 + 1))));
         std::vector<const char*> cut(nthreads + 1);
         cut[0] = p; cut[nthreads] = end;
-        for (unsigned t = 1; t < nthreads; ++t) cut[t] = next_record_start(base, base + size * t / nthreads, end, kind);
+        for (unsigned t = 1; t < nthreads; ++t) cut[t] = next_record_start(base, p + size * t / nthreads, end, kind);
         std::mutex mu; std::vector<uint64_t> counts(nthreads, 0); std::vector<std::thread> th;
         for (unsigned t = 0; t < nthreads; ++t)
             th.emplace_back([&, t]() {
@@ -191,9 +186,158 @@ private:
                 counts[t] = ps.nseq;
             });
         for (auto& x : th) x.join();
+        uint64_t nseq = 0; for (auto c : counts) nseq += c;
+        return nseq;
+    }
+    // '>' / '@' if the buffer starts with a FASTA record / a 4-line FASTQ record (what the range cutter assumes), else 0
+    static char record_kind(const char*& p, const char* end) {
+        while (p < end && (*p == '\n' || *p == '\r' || *p == ' ')) ++p;
+        const char kind = p < end ? *p : 0;
+        if (kind != '>' && kind != '@') return 0;
+        if (kind == '@') {
+            const char* l1 = (const char*)memchr(p, '\n', (size_t)(end - p));
+            const char* l2 = l1 ? (const char*)memchr(l1 + 1, '\n', (size_t)(end - (l1 + 1))) : nullptr;
+            if (!l2 || l2 + 1 >= end || l2[1] != '+') return 0;
+        }
+        return kind;
+    }
+    bool stream_parallel(size_t chunkBytes, const Sink& sink, uint64_t size, unsigned nthreads, uint64_t& nseq) {
+        int fd = open(path_.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) return false;
+        const char* base = (const char*)m; const char* end = base + size;
+        const char* p = base;
+        const char kind = record_kind(p, end);
+        if (!kind) { munmap(m, size); return false; }
+        nseq = parse_parallel(base, p, end, kind, chunkBytes, sink, nthreads);
         munmap(m, size);
-        nseq = 0; for (auto c : counts) nseq += c;
         return true;
+    }
+
+    // ---- gzip input
+    // BGZF (bgzip, the blocked gzip variant of htslib): every member is an independent deflate stream of
+    // <= 64 KB whose compressed size sits in the 'BC' extra field and whose inflated size in its trailer, so
+    // the members are inflated by a thread pool straight to their final offsets of a slab, and the slab is
+    // parsed like a memory-mapped plain file.  Returns false if the file is not BGZF.
+    struct BgzfBlock { uint64_t off; uint32_t csize, isize; };
+    static bool bgzf_block_at(const unsigned char* b, uint64_t left, uint32_t* csize) {
+        if (left < 18 || b[0] != 0x1f || b[1] != 0x8b || b[2] != 8 || !(b[3] & 4)) return false;
+        const uint32_t xlen = b[10] | (b[11] << 8);
+        if (left < 12 + xlen) return false;
+        for (uint32_t x = 0; x + 4 <= xlen;) {
+            const unsigned char* f = b + 12 + x;
+            const uint32_t slen = f[2] | (f[3] << 8);
+            if (f[0] == 'B' && f[1] == 'C' && slen == 2 && x + 6 <= xlen) { *csize = (uint32_t)(f[4] | (f[5] << 8)) + 1; return *csize <= left; }
+            x += 4 + slen;
+        }
+        return false;
+    }
+    bool stream_bgzf(size_t chunkBytes, const Sink& sink, uint64_t size, unsigned nthreads, uint64_t& nseq) {
+        int fd = open(path_.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) return false;
+        const unsigned char* zb = (const unsigned char*)m;
+        std::vector<BgzfBlock> blocks;
+        for (uint64_t off = 0; off < size;) {
+            uint32_t cs = 0;
+            if (!bgzf_block_at(zb + off, size - off, &cs) || cs < 26) { munmap(m, size); return false; }
+            const unsigned char* t = zb + off + cs - 4;
+            blocks.push_back({off, cs, (uint32_t)(t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24))});
+            off += cs;
+        }
+        uint64_t SLAB = 1ull << 30;                             // inflated bytes handled at once
+        if (const char* e = getenv("DSK_BGZF_SLAB_BYTES")) SLAB = std::max<uint64_t>(1, (uint64_t)atoll(e));
+        std::vector<char> slab; std::string carry;
+        nseq = 0; char kind = 0; bool first = true; bool ok = true;
+        for (size_t b0 = 0; b0 < blocks.size() && ok;) {
+            size_t b1 = b0; uint64_t bytes = 0;
+            while (b1 < blocks.size() && (bytes == 0 || bytes + blocks[b1].isize <= SLAB)) bytes += blocks[b1++].isize;
+            slab.resize(carry.size() + bytes);
+            std::memcpy(slab.data(), carry.data(), carry.size());
+            std::vector<uint64_t> dst(b1 - b0 + 1); dst[0] = carry.size();
+            for (size_t i = b0; i < b1; ++i) dst[i - b0 + 1] = dst[i - b0] + blocks[i].isize;
+            std::atomic<size_t> next(b0); std::atomic<bool> bad(false);
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < std::max(1u, nthreads); ++t)
+                th.emplace_back([&]() {
+                    z_stream zs; std::memset(&zs, 0, sizeof(zs));
+                    if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return; }
+                    for (;;) {
+                        const size_t i = next.fetch_add(1);
+                        if (i >= b1) break;
+                        const BgzfBlock& bk = blocks[i];
+                        const unsigned char* src = zb + bk.off;
+                        const uint32_t xlen = src[10] | (src[11] << 8);
+                        inflateReset(&zs);
+                        zs.next_in = const_cast<unsigned char*>(src + 12 + xlen); zs.avail_in = bk.csize - 12 - xlen - 8;
+                        zs.next_out = (unsigned char*)slab.data() + dst[i - b0]; zs.avail_out = bk.isize;
+                        const int rc = inflate(&zs, Z_FINISH);
+                        if ((rc != Z_STREAM_END && !(rc == Z_OK && bk.isize == 0)) || zs.avail_out != 0) { bad = true; break; }
+                    }
+                    inflateEnd(&zs);
+                });
+            for (auto& x : th) x.join();
+            if (bad) { ok = false; break; }
+            const char* base = slab.data(); const char* end = base + slab.size(); const char* p = base;
+            if (first) { kind = record_kind(p, end); first = false; if (!kind) { ok = false; break; } }
+            const char* stop = end;
+            if (b1 < blocks.size()) {                           // keep the (possibly cut) last record for the next slab
+                uint64_t back = 1u << 16;
+                const char* q = end;
+                for (;;) {
+                    const char* from = (uint64_t)(end - p) > back ? end - back : p;
+                    q = next_record_start(base, from, end, kind);
+                    if (q < end || from == p) break;
+                    back *= 16;
+                }
+                if (q < end) for (;;) { const char* r = next_record_start(base, q + 1, end, kind); if (r >= end) break; q = r; }
+                stop = q < end ? q : p;
+            }
+            if (stop > p) nseq += parse_parallel(base, p, stop, kind, chunkBytes, sink, nthreads);
+            carry.assign(stop, (size_t)(end - stop));
+            b0 = b1;
+        }
+        munmap(m, size);
+        if (!ok) throw Exception("corrupt BGZF file '%s'", path_.c_str());
+        return true;
+    }
+    // Ordinary gzip: one deflate stream cannot be split, but inflating and parsing overlap -- a producer
+    // thread inflates 4 MB buffers into a small queue while the caller parses and hands chunks to the sink.
+    uint64_t stream_gz_pipelined(size_t chunkBytes, const Sink& sink) {
+        gzFile f = gzopen(path_.c_str(), "rb");
+        if (!f) throw Exception("unable to open file '%s'", path_.c_str());
+        gzbuffer(f, 1 << 20);
+        const size_t NB = 4, BUF = 4u << 20;
+        std::vector<std::vector<char>> bufs(NB, std::vector<char>(BUF));
+        std::vector<int> len(NB, 0);
+        std::mutex mu; std::condition_variable cv;
+        size_t produced = 0, consumed = 0; bool done = false, failed = false;
+        std::thread producer([&]() {
+            for (;;) {
+                { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return produced - consumed < NB; }); }
+                const size_t slot = produced % NB;
+                const int got = gzread(f, bufs[slot].data(), (unsigned)BUF);
+                std::lock_guard<std::mutex> g(mu);
+                if (got <= 0) { failed = got < 0; done = true; cv.notify_all(); return; }
+                len[slot] = got; ++produced; cv.notify_all();
+            }
+        });
+        RecordParser ps(chunkBytes, &sink, nullptr);
+        for (;;) {
+            { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return consumed < produced || done; }); if (consumed == produced && done) break; }
+            const size_t slot = consumed % NB;
+            ps.feed(bufs[slot].data(), (size_t)len[slot]);
+            { std::lock_guard<std::mutex> g(mu); ++consumed; } cv.notify_all();
+        }
+        producer.join();
+        gzclose(f);
+        if (failed) throw Exception("read error in file '%s'", path_.c_str());
+        ps.finish();
+        return ps.nseq;
     }
     std::string path_;
 };

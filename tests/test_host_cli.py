@@ -265,3 +265,51 @@ def run_solidity_cases(dsk, dsk2ascii, tmp, oracle):
 
 def test_solidity_kinds_and_histo2d_cli(bins, tmp_path, oracle):
     run_solidity_cases(bins["dsk"], bins["dsk2ascii"], str(tmp_path), oracle)
+
+
+def write_bgzf(path, data, block=60000):
+    """BGZF writer (htslib's blocked gzip): independent <= 64 KB members with the 'BC' size field + the empty EOF member."""
+    import struct, zlib
+    with open(path, "wb") as f:
+        for off in list(range(0, len(data), block)) + [None]:
+            chunk = b"" if off is None else data[off: off + block]
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = c.compress(chunk) + c.flush()
+            bsize = 12 + 6 + len(body) + 8 - 1
+            f.write(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize))
+            f.write(body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+
+@pytest.mark.parametrize("fmt", ["fastq", "fasta"])
+def test_gzip_and_bgzf_inputs(bins, tmp_path, fmt):
+    """gzip input: ordinary .gz goes through the pipelined inflate, BGZF through the parallel block inflate
+    (several slabs with a carried-over partial record when DSK_BGZF_SLAB_BYTES is small); same dump as the plain file."""
+    import gzip
+    import numpy as np
+    tmp = str(tmp_path)
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(1200):
+        n = int(rng.choice([30, 150, 151, 400, 5000])) if i % 60 else 90000   # some reads longer than a BGZF block
+        a = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n)
+        a[rng.random(n) < 0.002] = ord("N")
+        seq = a.tobytes().decode()
+        if fmt == "fastq":
+            recs.append(f"@r{i}\n{seq}\n+\n{'@' * n}\n")                    # quality lines starting with '@' on purpose
+        else:
+            recs.append(f">r{i}\n" + "\n".join(seq[j: j + 70] for j in range(0, n, 70)) + "\n")
+    data = "".join(recs).encode()
+    assert len(data) > (2 << 20)
+    open(os.path.join(tmp, "plain." + fmt), "wb").write(data)
+    with gzip.open(os.path.join(tmp, "std.gz"), "wb", compresslevel=1) as f:
+        f.write(data)
+    write_bgzf(os.path.join(tmp, "blocked.gz"), data)
+    dumps = {}
+    for name, src, env in (("plain", "plain." + fmt, {"DSK_PARSE_MIN_BYTES": "100000"}), ("std", "std.gz", {}), ("bgzf", "blocked.gz", {}),
+                           ("bgzf_slabs", "blocked.gz", {"DSK_BGZF_SLAB_BYTES": "300000"}),
+                           ("serial", "plain." + fmt, {"DSK_PARSE_MIN_BYTES": str(1 << 40)})):
+        subprocess.check_call([bins["dsk"], "-file", src, "-kmer-size", "25", "-abundance-min", "1", "-out", name, "-verbose", "0"],
+                              cwd=tmp, env=dict(os.environ, **env))
+        subprocess.check_call([bins["dsk2ascii"], "-file", name, "-out", name + ".txt", "-verbose", "0"], cwd=tmp)
+        dumps[name] = hashlib.md5(open(os.path.join(tmp, name + ".txt"), "rb").read()).hexdigest()
+    assert len(set(dumps.values())) == 1, dumps

@@ -30,6 +30,28 @@ for attempt in range(2):
     dt = time.time() - t0
     keep = [l for l in out.splitlines() if any(s in l for s in ("_s ", "kmers_nb", "solid_kmers", "EXCEPTION"))]
     print(f"dsk run {attempt}: {dt:.2f} s wall"); print("\n".join(keep))
+if len(sys.argv) > 3 and sys.argv[3] == "gz":      # the same reads as ordinary gzip and as BGZF (blocked gzip)
+    import gzip, struct, zlib
+    data = open(fq, "rb").read()
+    t0 = time.time()
+    with gzip.open(fq + ".gz", "wb", compresslevel=1) as f:
+        f.write(data)
+    with open(fq + ".bgzf.gz", "wb") as f:
+        for off in list(range(0, len(data), 60000)) + [None]:
+            chunk = b"" if off is None else data[off: off + 60000]
+            c = zlib.compressobj(1, zlib.DEFLATED, -15)
+            body = c.compress(chunk) + c.flush()
+            f.write(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1))
+            f.write(body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    print(f"compressed copies written in {time.time()-t0:.1f} s: {os.path.getsize(fq + '.gz')/1e6:.0f} MB gzip, {os.path.getsize(fq + '.bgzf.gz')/1e6:.0f} MB BGZF")
+    for src in (fq + ".gz", fq + ".bgzf.gz"):
+        for attempt in range(2):
+            t0 = time.time()
+            out = subprocess.run([f"{root}/dsk_amd/host/bin/dsk", "-file", src, "-kmer-size", k, "-out", "/tmp/e2e/outz", "-verbose", "1"],
+                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+            dt = time.time() - t0
+            keep = [l for l in out.splitlines() if any(s in l for s in ("ingest_s", "total_s", "kmers_nb_valid", "EXCEPTION"))]
+            print(f"dsk {os.path.basename(src)} run {attempt}: {dt:.2f} s wall | " + " | ".join(x.strip() for x in keep))
 t0 = time.time()
 out = subprocess.run([f"{root}/oracle/dsk_oracle_cli", "-file", fq, "-kmer-size", k, "-nb-cores", str(os.cpu_count())],
                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
