@@ -47,7 +47,7 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_COUNT = 8 };
+enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_OVF2, SC_COUNT = 8 };
 #define SORT_TOP_BITS 40u
 
 struct Stage { const char* name; hipEvent_t ev; };
@@ -84,7 +84,8 @@ struct dskgpu_ctx {
     SkParams sk_sp{};
     DevBuf sk_sums, sk_cbase, sk_keys;
     std::vector<u32> h_sk_sums; std::vector<u64> h_sk_cbase;
-    u32 h_back[4] = {0}; u64 h_stats[4] = {0};   // host landing zone of the async size read-back
+    u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0;
+    bool opt2_off = false;         // the fixed-capacity level-2 scatter overflowed on these reads: use the exact path   // host landing zone of the async size read-back
     std::vector<ChunkDesc> h_descs1;
     u32 h_sc[SC_COUNT] = {0};      // host mirror of the device scalars (kept alive across async copies)
 
@@ -216,18 +217,18 @@ int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chu
     return DSKGPU_OK;
 }
 // key-array source with aligned write-out (k_scatter_al) when its LDS footprint fits one CU
-template <int W, int MODE>
+template <int W, int MODE, bool OPT = false>
 int launch_scatter_al(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                      u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P) {
+                      u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, OptSpec os = OptSpec{0u, nullptr, nullptr}) {
     const size_t lds = ascatter_lds(W, P);
     const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu));
     static bool attr_set = false;
     if (!attr_set) {
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_al<W, MODE>),
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_al<W, MODE, OPT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_scatter_al<W, MODE>), dim3(grid), dim3(SC_NT), lds, ctx->stream, keys, descs, d_nch, scanned, out, ds, P, dbg_flags(1));
+    hipLaunchKernelGGL((k_scatter_al<W, MODE, OPT>), dim3(grid), dim3(SC_NT), lds, ctx->stream, keys, descs, d_nch, scanned, out, ds, P, dbg_flags(1), os);
     CKL("k_scatter_al");
     return DSKGPU_OK;
 }
@@ -259,6 +260,9 @@ struct Plan {
 #define MAX_LEVEL_BINS 2048
 #define ONE_LEVEL_BINS 1024
 #define CH2 65536u            // keys per level-2 chunk
+#define OPT_CAP 4360u          // segment-owned level-2 scatter: keys per sub-partition region (mean <= TARGET_KEYS).
+                              // 545 groups of 64 B -- an ODD number, so the region starts (and the write fronts that advance
+                              // through all regions in step) spread over every HBM channel instead of camping on a few
 
 // Final sub-partitions F = P1 * P2 sized to the input (any integer, not a power
 // of two: digits use the multiply-shift reduction of key_digit()).
@@ -269,6 +273,11 @@ bool make_plan(u64 n_upper, int extra_bits, int W, Plan* pl) {
     if (F <= ONE_LEVEL_BINS) { pl->levels = 1; pl->P1 = (u32)F; pl->P2 = 1; }
     else {
         u64 p1 = 1; while (p1 * p1 < F) ++p1;
+        // keep level 2 inside the aligned-write-out kernel (its per-bin carry must fit LDS): more level-1 bins
+        // instead -- the level-1 scatter is ALU-bound and does not mind shorter runs
+        u64 p2max = MAX_LEVEL_BINS; while (p2max > 64 && ascatter_lds(W, (u32)p2max) > 160 * 1024) --p2max;
+        const u64 p1_al = (F + p2max - 1) / p2max;
+        if (p1_al > p1 && p1_al <= MAX_LEVEL_BINS - 8 && !getenv("DSKGPU_BALANCED_PLAN")) p1 = p1_al;
         u64 p2 = (F + p1 - 1) / p1;
         if (p1 > MAX_LEVEL_BINS || p2 > MAX_LEVEL_BINS) return false;
         pl->levels = 2; pl->P1 = (u32)p1; pl->P2 = (u32)p2;
@@ -439,7 +448,31 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         CK(ctx->fstart.ensure(((size_t)pl.F + 2) * 4));
         CK(ctx->nsolid.ensure(((size_t)pl.F + 2) * 4));
         // ---------------- level 2
-        if (pl.levels == 2) {
+        // One-word keys take the segment-owned scatter (k_scatter_al<.., OPT>): no histogram pass, every
+        // sub-partition gets a fixed region of OPT_CAP keys; a region that overflows (heavy repeats) sends the
+        // level back through the exact histogram + scan path, and the context remembers it for these reads.
+        u32 opt_cap = 0;
+        if (pl.levels == 2 && W == 1 && !ctx->opt2_off && !getenv("DSKGPU_NO_OPT2") && ascatter_lds(W, pl.P2) <= 160 * 1024 &&
+            ((u64)pl.F * OPT_CAP * 4 <= ctx->bufA.cap || getenv("DSKGPU_OPT_CAP")))          // the abundances of the solid rows reuse bufA at the same indices
+            opt_cap = OPT_CAP;
+        if (opt_cap) { if (const char* e = getenv("DSKGPU_OPT_CAP")) opt_cap = (u32)atoi(e) & ~7u; }   // experiments
+        if (pl.levels == 2 && opt_cap) {
+            CK(ctx->bufB.ensure(((u64)pl.F * opt_cap + ATile<1>::KEYS + 16) * sizeof(Key)));
+            CK(ctx->descs2.ensure(((size_t)pl.P1 * 2 + 1) * sizeof(ChunkDesc)));
+            CK(ctx->seg.ensure((size_t)pl.P1 * sizeof(SegInfo)));
+            CK(ctx->mat2.ensure(((size_t)pl.F + 1) * 4));                     // here: keys per sub-partition region
+            CK(hipMemsetAsync(ctx->mat2.p, 0, ((size_t)pl.F + 1) * 4, ctx->stream));
+            hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, ctx->stream, ctx->mat1.as<u32>(), nch1, pl.P1, 0x7FFFFFFFu, pl.P2,
+                               ctx->seg.as<SegInfo>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, sc + SC_MLEN2, 1u);
+            CKL("k_plan");
+            ctx->mark("plan2");
+            OptSpec os{opt_cap, ctx->mat2.as<u32>(), sc + SC_OVF2};
+            if ((rc = launch_scatter_al<W, 2, true>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
+                                                    ctx->bufB.as<Key>(), pl.d2, pl.P2, os))) return rc;
+            ctx->mark("scatter2");
+            fkeys = ctx->bufB.as<Key>();
+            scratch = &ctx->bufA;
+        } else if (pl.levels == 2) {
             const u64 max_chunks2 = cap / CH2 + pl.P1 + 1;
             const u64 M2 = max_chunks2 * pl.P2;
             if (M2 >= 0xFFFFFFFFull) return fail(ctx, DSKGPU_E_ARG, "level-2 matrix too large");
@@ -447,7 +480,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             CK(ctx->seg.ensure((size_t)pl.P1 * sizeof(SegInfo)));
             CK(ctx->mat2.ensure((M2 + 1) * 4));
             hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, ctx->stream, ctx->mat1.as<u32>(), nch1, pl.P1, CH2, pl.P2,
-                               ctx->seg.as<SegInfo>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, sc + SC_MLEN2);
+                               ctx->seg.as<SegInfo>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, sc + SC_MLEN2, 0u);
             CKL("k_plan");
             ctx->mark("plan2");
             const ChunkDesc* dd2 = ctx->descs2.as<ChunkDesc>();
@@ -473,6 +506,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         cp.F = pl.F;
         { const char* e = getenv("DSKGPU_DBGC"); cp.dbg = e ? (u32)atoi(e) : 0u; }
         cp.amin = ctx->cfg.abundance_min; cp.amax = ctx->cfg.abundance_max; cp.histo_max = ctx->cfg.histo_max;
+        cp.cap = opt_cap; cp.subcnt = opt_cap ? ctx->mat2.as<u32>() : nullptr;
         const unsigned cgrid = (unsigned)std::min<u64>(pl.F, (u64)ctx->num_cu * 2);
         Key* solid_keys = W == 1 ? fkeys : scratch->as<Key>();
         u32* solid_ab = W == 1 ? scratch->as<u32>() : ctx->abund2.as<u32>();
@@ -485,10 +519,20 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         // ---------------- host sync: sizes
         CK(hipMemcpyAsync(&ctx->h_back[0], sc + SC_OVERFLOW, 4, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipMemcpyAsync(&ctx->h_back[1], ctx->nsolid.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipMemcpyAsync(&ctx->h_back[2], ctx->fstart.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
+        // k-mers of the pass: the last sub-partition offset, or (fixed-capacity regions) the level-1 total
+        CK(hipMemcpyAsync(&ctx->h_back[2], opt_cap ? ctx->mat1.as<u32>() + M1 : ctx->fstart.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(&ctx->h_ovf2, sc + SC_OVF2, 4, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipMemcpyAsync(&ctx->h_stats[0], ctx->gstats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
         const u32 h_ovf = ctx->h_back[0], h_nsolid = ctx->h_back[1], h_nk = ctx->h_back[2];
+        if (opt_cap && ctx->h_ovf2) {       // a region overflowed: repeat this attempt with exact offsets
+            ctx->resolve_marks();
+            ctx->opt2_off = true;
+            ctx->stats.n_retries += 1;
+            ctx->mark("start");
+            --attempt;
+            continue;
+        }
         if (h_ovf) {
             ctx->resolve_marks();
             if (attempt >= 3) return fail(ctx, DSKGPU_E_OVERFLOW, "hash table overflow after 3 retries");
@@ -503,7 +547,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         RowsOut ro{};
         for (int x = 0; x < W; ++x) { CK(ctx->out_w[x].ensure((ns + 1) * 8)); ro.w[x] = ctx->out_w[x].as<u64>(); }
         hipLaunchKernelGGL(k_compact<W>, dim3((pl.F + 3) / 4), dim3(256), 0, ctx->stream, (const Key*)solid_keys, (const u32*)solid_ab,
-                           ctx->fstart.as<u32>(), ctx->nsolid.as<u32>(), pl.F, ro, ctx->out_ab.as<u32>());
+                           ctx->fstart.as<u32>(), ctx->nsolid.as<u32>(), pl.F, ro, ctx->out_ab.as<u32>(), opt_cap);
         CKL("k_compact");
         ctx->mark("compact");
         *ns_out = ns; *nk_out = h_nk; *plan_out = pl;
@@ -967,7 +1011,7 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
     CK(hipMemsetAsync(dst + ctx->reads_len + nbytes, '\n', 1, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     ctx->reads_len += nbytes + 1;
-    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->sk_prepared = false;
+    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->sk_prepared = false; ctx->opt2_off = false;
     return DSKGPU_OK;
 }
 
@@ -987,7 +1031,7 @@ int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes) {
 
 int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes) {
     if (!ctx || (!d_bytes && nbytes)) return DSKGPU_E_ARG;
-    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->sk_prepared = false;
+    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->sk_prepared = false; ctx->opt2_off = false;
     ctx->n_bytes = nbytes;
     ctx->reads_len = 0;
     ctx->bank_ends.clear();

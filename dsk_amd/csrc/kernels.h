@@ -479,11 +479,24 @@ __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
     return keys * key + (size_t)P * (G - 1) * key + (size_t)(P + 1) * 4 + (size_t)P * 4 + (size_t)P * 12 + (size_t)P * 2 + 20 * 4 + 32;
 }
 
-template <int W, int MODE>
+// OPT (one-word keys, level 2): "segment-owned" variant that needs NO histogram pass.  A chunk is a whole
+// segment (level-1 bin), processed by one block from start to end, and every sub-bin q = s*P + b owns the
+// fixed region [q*cap, (q+1)*cap) of `out`; pos[] starts at the region bases and simply advances, the carry
+// lives through the whole segment, and at its end the partial groups are padded with the DSK_EMPTY sentinel
+// (the count kernel skips it).  subcnt[q] = keys written to the region, pads included.  A sub-bin that would
+// outgrow its region raises *ovf (writes wrap to the region start: the result is discarded and the host
+// repeats the level with the exact histogram + scan path).  flat_base of a chunk = s*P.
+struct OptSpec { u32 cap; u32* subcnt; u32* ovf; };
+template <int W> __device__ __forceinline__ typename KeyT<W>::T empty_key();
+template <> __device__ __forceinline__ u64 empty_key<1>() { return DSK_EMPTY; }
+template <> __device__ __forceinline__ K2 empty_key<2>() { K2 k; k.w[0] = k.w[1] = DSK_EMPTY; return k; }
+template <> __device__ __forceinline__ KN<4> empty_key<4>() { KN<4> k; k.w[0] = k.w[1] = k.w[2] = k.w[3] = DSK_EMPTY; return k; }
+
+template <int W, int MODE, bool OPT = false>
 __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>::T* __restrict__ keys,
                                                          const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
                                                          const u32* __restrict__ scanned,
-                                                         typename KeyT<W>::T* __restrict__ out, DigitSpec ds, u32 P, u32 dbg) {
+                                                         typename KeyT<W>::T* __restrict__ out_all, DigitSpec ds, u32 P, u32 dbg, OptSpec os) {
     typedef typename KeyT<W>::T Key;
     typedef unsigned short u16;
     constexpr int KPT = ATile<W>::KPT, G = ATile<W>::G, CARRY = ATile<W>::CARRY, TKEYS = ATile<W>::KEYS;
@@ -504,8 +517,11 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
     const int ipt = (int)((P + SC_NT - 1) / SC_NT);
     for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
         const ChunkDesc d = descs[g];
+        // OPT: positions are relative to the segment's first region (keeps them 32-bit whatever the total)
+        Key* out = OPT ? out_all + (u64)d.flat_base * os.cap : out_all;
+        bool ovf = false;
         lds_barrier();
-        for (u32 b = tid; b < P; b += SC_NT) { pos[b] = scanned[d.flat_base + (u64)b * d.stride]; cnt[b] = 0; rn[b] = 0; }
+        for (u32 b = tid; b < P; b += SC_NT) { pos[b] = OPT ? b * os.cap : scanned[d.flat_base + (u64)b * d.stride]; cnt[b] = 0; rn[b] = 0; }
         if (tid == 0) cnt[P] = 0;
         Key h[KPT]; u32 vm = 0;       // one register set: the next tile is loaded as soon as the stage writes have consumed this one
         auto load = [&](u64 k0, Key (&hh)[KPT]) -> u32 {
@@ -542,9 +558,10 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                     c[j] = 0; pe[j] = 0; er[j] = 0;
                     if (j < ipt && b < (int)P) {
                         c[j] = cnt[b];
-                        const u32 r = rn[b], p = pos[b];
+                        const u32 r = rn[b]; u32 p = pos[b];
                         const u32 bound = (p + r + c[j]) & ~(u32)(G - 1);
                         const u32 e = bound > p ? bound - p : 0u;
+                        if (OPT && p + e > (u32)(b + 1) * os.cap) { ovf = true; p = (u32)b * os.cap; }   // region full: wrap (result discarded)
                         pe[j] = p; er[j] = e | (r << 16);
                         rn[b] = (u16)(r + c[j] - e);
                         pos[b] = p + e; cnt[b] = 0;
@@ -616,8 +633,15 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
         lds_barrier();
         for (u32 b = gi; b < P; b += NGRP) {
             const u32 r = rn[b];
-            if (gl < r) out[pos[b] + gl] = carry[(size_t)b * CARRY + gl];
+            if (!OPT) { if (gl < r) out[pos[b] + gl] = carry[(size_t)b * CARRY + gl]; }
+            else {
+                u32 p = pos[b];
+                if (r && p + G > (u32)(b + 1) * os.cap) { ovf = true; p = (u32)b * os.cap; }
+                if (r) out[p + gl] = gl < r ? carry[(size_t)b * CARRY + gl] : empty_key<W>();       // pad the last group
+                if (gl == 0) { const u32 n = p - (u32)b * os.cap + (r ? G : 0u); os.subcnt[d.flat_base + b] = n < os.cap ? n : os.cap; }
+            }
         }
+        if (OPT && ovf) *os.ovf = 1u;
     }
 }
 
@@ -628,7 +652,7 @@ struct SegInfo { u32 start, nch, chunk_base, pad; };
 
 __global__ __launch_bounds__(1024) void k_plan(const u32* __restrict__ src, u32 sstride, u32 S, u32 CH, u32 P,
                                                SegInfo* __restrict__ seg, ChunkDesc* __restrict__ descs,
-                                               u32* __restrict__ d_nchunks, u32* __restrict__ d_mlen) {
+                                               u32* __restrict__ d_nchunks, u32* __restrict__ d_mlen, u32 opt) {
     __shared__ u32 ws[16]; __shared__ u32 carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
@@ -658,7 +682,7 @@ __global__ __launch_bounds__(1024) void k_plan(const u32* __restrict__ src, u32 
                 d.begin = (u64)start + (u64)c * CH;
                 const u64 e = d.begin + CH, lim = (u64)start + size;
                 d.end = e < lim ? e : lim;
-                d.flat_base = cb * P + c;
+                d.flat_base = opt ? s * P : cb * P + c;       // segment-owned scatter: first sub-bin of the segment
                 d.stride = nch;
                 descs[cb + c] = d;
             }
@@ -698,7 +722,14 @@ struct CountParams {
     u32 F;
     u32 amin, amax, histo_max;
     u32 dbg;                  // experiment switches (timing ablations only)
+    u32 cap;                  // != 0: fixed-capacity sub-partition regions (segment-owned level-2 scatter):
+    const u32* subcnt;        //       sub-partition q = keys [q*cap, q*cap + subcnt[q]), DSK_EMPTY pads skipped
 };
+// key range of sub-partition q
+__device__ __forceinline__ void sub_range(const CountParams& cp, const u32* __restrict__ fstart, u32 q, u64* begin, u32* n) {
+    if (cp.cap) { *begin = (u64)q * cp.cap; *n = cp.subcnt[q]; }
+    else { const u32 b = fstart[q]; *begin = b; *n = fstart[q + 1] - b; }
+}
 
 // One persistent block per sub-partition in turn.  Insert = 64-bit LDS CAS on
 // the key + LDS add on the count; the slot of every newly claimed key is
@@ -751,43 +782,44 @@ __global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* keys, u64* solid_keys,
     u32 ones = 0;          // lane 0 of each wave: abundance-1 keys seen (flushed at the end)
     u64 ndist_acc = 0;
     u32 q = blockIdx.x;
-    u32 begin = 0, end = 0;
+    u64 begin = 0; u32 n = 0;
     u64 pk[CNT_KPT];
     if (q < cp.F) {
-        begin = fstart[q]; end = fstart[q + 1];
-        if (end > begin) {
+        sub_range(cp, fstart, q, &begin, &n);
+        if (n) {
 #pragma unroll
-            for (int j = 0; j < CNT_KPT; ++j) { const u32 i = begin + tid + j * CNT_NT; pk[j] = keys[i < end ? i : end - 1]; }
+            for (int j = 0; j < CNT_KPT; ++j) { const u32 i = tid + j * CNT_NT; pk[j] = keys[begin + (i < n ? i : n - 1)]; }
         }
     }
     lds_barrier();
     int par = 0;
     while (q < cp.F) {
         u32* ctr = s_ctr[par];
-        const u32 n = end - begin;
         // fast path first for ILP: CNT_KPT independent probes of the home slot;
         // a hit (key already present: the common case at high coverage) is one
         // fire-and-forget LDS add.  Misses take the CAS/probe loop afterwards.
         u64 seen[CNT_KPT];
 #pragma unroll
-        for (int j = 0; j < CNT_KPT; ++j)
-            seen[j] = ((u32)(tid + j * CNT_NT) < n) ? tk[(u32)pk[j] & (CNT_SLOTS - 1)] : pk[j] + 1;
+        for (int j = 0; j < CNT_KPT; ++j)     // (the all-ones pad of a fixed-capacity region is treated like an out-of-range lane)
+            seen[j] = ((u32)(tid + j * CNT_NT) < n && pk[j] != DSK_EMPTY) ? tk[(u32)pk[j] & (CNT_SLOTS - 1)] : pk[j] + 1;
 #pragma unroll
         for (int j = 0; j < CNT_KPT; ++j)
-            if ((u32)(tid + j * CNT_NT) < n) {
+            if ((u32)(tid + j * CNT_NT) < n && pk[j] != DSK_EMPTY) {
                 if (seen[j] == pk[j]) atomicAdd(&tc[(u32)pk[j] & (CNT_SLOTS - 1)], 1u);
                 else table_insert1(tk, tc, lst, &ctr[0], &ctr[2], pk[j]);
             }
-        for (u32 i = begin + CNT_KPT * CNT_NT + tid; i < end; i += CNT_NT)      // oversized sub-partition
-            table_insert1(tk, tc, lst, &ctr[0], &ctr[2], keys[i]);
+        for (u32 i = CNT_KPT * CNT_NT + tid; i < n; i += CNT_NT) {               // oversized sub-partition
+            const u64 kx = keys[begin + i];
+            if (kx != DSK_EMPTY) table_insert1(tk, tc, lst, &ctr[0], &ctr[2], kx);
+        }
         // prefetch the block's next sub-partition
         const u32 qn = q + gridDim.x;
-        u32 nbeg = 0, nend = 0;
+        u64 nbeg = 0; u32 nn = 0;
         if (qn < cp.F) {
-            nbeg = fstart[qn]; nend = fstart[qn + 1];
-            if (nend > nbeg) {
+            sub_range(cp, fstart, qn, &nbeg, &nn);
+            if (nn) {
 #pragma unroll
-                for (int j = 0; j < CNT_KPT; ++j) { const u32 i = nbeg + tid + j * CNT_NT; pk[j] = keys[i < nend ? i : nend - 1]; }
+                for (int j = 0; j < CNT_KPT; ++j) { const u32 i = tid + j * CNT_NT; pk[j] = keys[nbeg + (i < nn ? i : nn - 1)]; }
             }
         }
         lds_barrier();
@@ -834,7 +866,7 @@ __global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* keys, u64* solid_keys,
             ctr[0] = 0; ctr[1] = 0; ctr[2] = 0;     // this parity is next used two barriers from now
         }
         par ^= 1;
-        q = qn; begin = nbeg; end = nend;
+        q = qn; begin = nbeg; n = nn;
     }
     lds_barrier();
     // flush block-local histogram
@@ -993,7 +1025,7 @@ struct RowsIn { const u64* w[4]; };
 template <int W>
 __global__ __launch_bounds__(256) void k_compact(const typename KeyT<W>::T* __restrict__ keys, const u32* __restrict__ abund,
                                                  const u32* __restrict__ fstart, const u32* __restrict__ soff, u32 F,
-                                                 RowsOut out, u32* __restrict__ out_ab) {
+                                                 RowsOut out, u32* __restrict__ out_ab, u32 /*cap: one-word keys only*/) {
     const u32 q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= F) return;
@@ -1009,11 +1041,12 @@ __global__ __launch_bounds__(256) void k_compact(const typename KeyT<W>::T* __re
 template <>
 __global__ __launch_bounds__(256) void k_compact<1>(const u64* __restrict__ keys, const u32* __restrict__ abund,
                                                     const u32* __restrict__ fstart, const u32* __restrict__ soff, u32 F,
-                                                    RowsOut out, u32* __restrict__ out_ab) {
+                                                    RowsOut out, u32* __restrict__ out_ab, u32 cap) {
     const u32 q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= F) return;
-    const u32 o = soff[q], ns = soff[q + 1] - o, b = fstart[q];
+    const u32 o = soff[q], ns = soff[q + 1] - o;
+    const u64 b = cap ? (u64)q * cap : (u64)fstart[q];        // fixed-capacity regions or exact offsets
     for (u32 i = lane; i < ns; i += 64) {
         out.w[0][o + i] = kunmix(keys[b + i]);
         out_ab[o + i] = abund[b + i];

@@ -240,6 +240,40 @@ def test_synthetic_two_levels(oracle, dev):
     assert st["n_levels"] == 2
 
 
+def test_segment_owned_level2_scatter_and_its_fallback(oracle, dev, monkeypatch):
+    """One-word keys, two levels: the level-2 scatter owns whole segments and writes fixed-capacity regions
+    (no histogram pass).  A region that overflows must send the level through the exact histogram + scan path."""
+    from dsk_amd import KmerCounter, synth
+    reads = synth.make_reads(synth.make_genome(400_000, dev), 120_000, 150)
+    ref = oracle.count(reads.cpu().numpy(), 31)
+
+    def run():
+        with KmerCounter(kmer_size=31, abundance_min=2, timing=True) as kc:
+            kc.set_reads_device(reads.data_ptr(), reads.numel())
+            kc.count()
+            torch.cuda.synchronize()
+            rows, ab = kc.rows()
+            return rows, ab, kc.histogram(), kc.stats(), dict(kc.stage_times())
+
+    def check(rows, ab, hist, st):
+        keep = ref.ab >= 2
+        assert st["n_levels"] == 2 and st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct
+        assert (rows[:, 0] == ref.lo[keep]).all() and (ab == ref.ab[keep]).all() and (hist == ref.histogram(10000)).all()
+
+    rows, ab, hist, st, stages = run()
+    check(rows, ab, hist, st)
+    assert "hist2" not in stages and st["n_retries"] == 0            # fixed-capacity regions were used
+    monkeypatch.setenv("DSKGPU_OPT_CAP", "1024")                     # regions far too small: every one overflows
+    rows, ab, hist, st, stages = run()
+    check(rows, ab, hist, st)
+    assert "hist2" in stages and st["n_retries"] == 1                # exact path took over
+    monkeypatch.setenv("DSKGPU_NO_OPT2", "1")
+    monkeypatch.delenv("DSKGPU_OPT_CAP")
+    rows, ab, hist, st, stages = run()
+    check(rows, ab, hist, st)
+    assert "hist2" in stages and st["n_retries"] == 0
+
+
 @pytest.mark.parametrize("k", [33, 47, 63, 64])
 def test_two_word_kmers_golden(oracle, golden_dir, dev, k):
     s, _ = oracle.load_bank(os.path.join(golden_dir, "read50x_ref10K_e001.fasta.gz"))
