@@ -47,7 +47,7 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_OVF2, SC_COUNT = 8 };
+enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_OVF2, SC_OVF1, SC_COUNT = 12 };
 #define SORT_TOP_BITS 40u
 
 struct Stage { const char* name; hipEvent_t ev; };
@@ -84,9 +84,10 @@ struct dskgpu_ctx {
     SkParams sk_sp{};
     DevBuf sk_sums, sk_cbase, sk_keys;
     std::vector<u32> h_sk_sums; std::vector<u64> h_sk_cbase;
-    u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0;
+    u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0; u64 h_nvalid = 0;
+    bool opt1_off = false;         // same for the histogram-free level-1 scatter (block-owned slices)
     bool opt2_off = false;         // the fixed-capacity level-2 scatter overflowed on these reads: use the exact path   // host landing zone of the async size read-back
-    std::vector<ChunkDesc> h_descs1;
+    std::vector<ChunkDesc> h_descs1, h_descs2;
     u32 h_sc[SC_COUNT] = {0};      // host mirror of the device scalars (kept alive across async copies)
 
     // results
@@ -199,20 +200,24 @@ int launch_hist(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDes
                         : launch_hist_m<W, 1, 1>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P);
 }
 
-template <int W, int SRC, int MODE>
-int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P) {
+unsigned scatter_grid(const dskgpu_ctx* ctx, int W, u32 P, u64 max_chunks) {
     const size_t lds = scatter_lds(W, P);
     const u64 per_cu = std::max<u64>(1, std::min<u64>(2048 / SC_NT, (160 * 1024) / lds));   // resident blocks per CU
-    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * per_cu));
+    return (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * per_cu));
+}
+template <int W, int SRC, int MODE, bool OPT = false>
+int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
+                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1 = Opt1Spec{0u, 0u, nullptr}) {
+    const size_t lds = scatter_lds(W, P);
+    const unsigned grid = scatter_grid(ctx, W, P, max_chunks);
     static bool attr_set = false;
     if (!attr_set) {
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter<W, SRC, MODE>),
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter<W, SRC, MODE, OPT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_scatter<W, SRC, MODE>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->packed.as<u64>(),
-                       ctx->inval.as<u32>(), keys, descs, d_nch, scanned, out, (int)ctx->cfg.kmer_size, ds, P, dbg_flags(SRC));
+    hipLaunchKernelGGL((k_scatter<W, SRC, MODE, OPT>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->packed.as<u64>(),
+                       ctx->inval.as<u32>(), keys, descs, d_nch, scanned, out, (int)ctx->cfg.kmer_size, ds, P, dbg_flags(SRC), o1);
     CKL("k_scatter");
     return DSKGPU_OK;
 }
@@ -417,32 +422,69 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         CK(ctx->descs1.ensure(ctx->h_descs1.size() * sizeof(ChunkDesc)));
         CK(hipMemcpyAsync(ctx->descs1.p, ctx->h_descs1.data(), ctx->h_descs1.size() * sizeof(ChunkDesc),
                           hipMemcpyHostToDevice, ctx->stream));
+        // One-word keys straight from the reads, one pass, two levels: both scatters run without a histogram
+        // pass (block-owned slices at level 1, segment-owned regions at level 2); any overflow sends the whole
+        // attempt back through the exact histogram + scan path.
+        u32 opt_cap = 0;                 // level 2: keys per sub-partition region (0 = exact offsets)
+        if (pl.levels == 2 && W == 1 && !ctx->opt2_off && !getenv("DSKGPU_NO_OPT2") && ascatter_lds(W, pl.P2) <= 160 * 1024 &&
+            ((u64)pl.F * OPT_CAP * 4 <= ctx->bufA.cap || getenv("DSKGPU_OPT_CAP")))          // the abundances of the solid rows reuse bufA at the same indices
+            opt_cap = OPT_CAP;
+        if (opt_cap) { if (const char* e = getenv("DSKGPU_OPT_CAP")) opt_cap = (u32)atoi(e) & ~7u; }   // experiments / tests
+        bool opt1 = opt_cap && from_reads && npass == 1 && !ctx->opt1_off && !getenv("DSKGPU_NO_OPT1");
+        Opt1Spec o1{0u, 0u, sc + SC_OVF1};
+        unsigned grid1 = 0;
+        if (opt1) {
+            CK(hipMemsetAsync(ctx->gstats.p, 0, 4 * 8, ctx->stream));
+            hipLaunchKernelGGL(k_count_valid, dim3((unsigned)std::min<u64>((nwords + 255) / 256, (u64)ctx->num_cu * 8)), dim3(256), 0, ctx->stream,
+                               ctx->inval.as<u32>(), nwords, (int)ctx->cfg.kmer_size, ctx->gstats.as<u64>() + 3);
+            CKL("k_count_valid");
+            CK(hipMemcpyAsync(&ctx->h_nvalid, ctx->gstats.as<u64>() + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+            grid1 = scatter_grid(ctx, W, pl.P1, nch1);
+            const u64 cells = (u64)pl.P1 * grid1;
+            // a block's share of the input: it walks chunks blockIdx, blockIdx + grid, .. (equal chunks, the busiest block has ceil(nch/grid))
+            const u64 cpb = (nch1 + grid1 - 1) / grid1;
+            u64 slice = ctx->h_nvalid * cpb / ((u64)nch1 * pl.P1) + 1; slice += slice * 3 / 50 + 160; slice = (slice + 7) & ~7ull;   // mean + 6 % + 160
+            if (const char* e = getenv("DSKGPU_OPT_SLICE")) slice = (u64)atoll(e) & ~7ull;                   // experiments / tests
+            const u64 tail = ctx->h_nvalid / grid1 + 2 * Tile<W>::KEYS;                                     // worst overrun of one block
+            if (slice < 8 || cells * slice + tail >= 0xFFFF0000ull) opt1 = false;
+            else {
+                o1.slice = (u32)slice; o1.cap1 = (u32)(slice * grid1);
+                CK(ctx->bufA.ensure((cells * slice + tail + 1) * sizeof(Key)));
+            }
+        }
         u32* h_sc = ctx->h_sc;
         std::memset(h_sc, 0, sizeof(ctx->h_sc));
         h_sc[SC_NCH1] = nch1; h_sc[SC_MLEN1] = (u32)M1; h_sc[SC_F] = pl.F;
+        if (opt1) h_sc[SC_NCH2] = pl.P1;                       // level-2 chunks = the level-1 bin regions
         CK(hipMemcpyAsync(sc, h_sc, sizeof(ctx->h_sc), hipMemcpyHostToDevice, ctx->stream));
-        CK(ctx->mat1.ensure((M1 + 1) * 4));
         // histogram / distinct counters of THIS pass attempt (a table-overflow retry must not double count)
         CK(hipMemsetAsync(ctx->ghist.p, 0, ((size_t)ctx->cfg.histo_max + 1) * 8, ctx->stream));
         CK(hipMemsetAsync(ctx->gstats.p, 0, 4 * 8, ctx->stream));
         ctx->mark("setup");
         int rc;
         const ChunkDesc* dd1 = ctx->descs1.as<ChunkDesc>();
-        if (from_reads) rc = launch_hist<W, 0>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), pl.d1, pl.P1);
-        else rc = launch_hist<W, 1>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), pl.d1, pl.P1);
-        if (rc) return rc;
-        ctx->mark("hist1");
-        if ((rc = run_scan(ctx, ctx->mat1.as<u32>(), sc + SC_MLEN1, M1))) return rc;
-        ctx->mark("scan1");
-        if (npass > 1) {      // the pass must fit the buffers sized for it (skewed inputs can overfill one pass)
-            CK(hipMemcpyAsync(&ctx->h_back[2], ctx->mat1.as<u32>() + M1, 4, hipMemcpyDeviceToHost, ctx->stream));
-            CK(hipStreamSynchronize(ctx->stream));
-            if ((u64)ctx->h_back[2] > cap) { ctx->resolve_marks(); return PASS_TOO_BIG; }
+        if (opt1) {
+            if ((rc = launch_scatter_m<W, 0, 1, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1))) return rc;
+            ctx->mark("scatter1");
+        } else {
+            CK(ctx->mat1.ensure((M1 + 1) * 4));
+            if (from_reads) rc = launch_hist<W, 0>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), pl.d1, pl.P1);
+            else rc = launch_hist<W, 1>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), pl.d1, pl.P1);
+            if (rc) return rc;
+            ctx->mark("hist1");
+            if ((rc = run_scan(ctx, ctx->mat1.as<u32>(), sc + SC_MLEN1, M1))) return rc;
+            ctx->mark("scan1");
+            if (npass > 1) {      // the pass must fit the buffers sized for it (skewed inputs can overfill one pass)
+                CK(hipMemcpyAsync(&ctx->h_back[2], ctx->mat1.as<u32>() + M1, 4, hipMemcpyDeviceToHost, ctx->stream));
+                CK(hipStreamSynchronize(ctx->stream));
+                if ((u64)ctx->h_back[2] > cap) { ctx->resolve_marks(); return PASS_TOO_BIG; }
+            }
+            if (from_reads) rc = launch_scatter<W, 0>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<Key>(), pl.d1, pl.P1);
+            else rc = launch_scatter<W, 1>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<Key>(), pl.d1, pl.P1);
+            if (rc) return rc;
+            ctx->mark("scatter1");
         }
-        if (from_reads) rc = launch_scatter<W, 0>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<Key>(), pl.d1, pl.P1);
-        else rc = launch_scatter<W, 1>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, ctx->mat1.as<u32>(), ctx->bufA.as<Key>(), pl.d1, pl.P1);
-        if (rc) return rc;
-        ctx->mark("scatter1");
         Key* fkeys = ctx->bufA.as<Key>();
         DevBuf* scratch = &ctx->bufB;
         CK(ctx->fstart.ensure(((size_t)pl.F + 2) * 4));
@@ -451,20 +493,24 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         // One-word keys take the segment-owned scatter (k_scatter_al<.., OPT>): no histogram pass, every
         // sub-partition gets a fixed region of OPT_CAP keys; a region that overflows (heavy repeats) sends the
         // level back through the exact histogram + scan path, and the context remembers it for these reads.
-        u32 opt_cap = 0;
-        if (pl.levels == 2 && W == 1 && !ctx->opt2_off && !getenv("DSKGPU_NO_OPT2") && ascatter_lds(W, pl.P2) <= 160 * 1024 &&
-            ((u64)pl.F * OPT_CAP * 4 <= ctx->bufA.cap || getenv("DSKGPU_OPT_CAP")))          // the abundances of the solid rows reuse bufA at the same indices
-            opt_cap = OPT_CAP;
-        if (opt_cap) { if (const char* e = getenv("DSKGPU_OPT_CAP")) opt_cap = (u32)atoi(e) & ~7u; }   // experiments
         if (pl.levels == 2 && opt_cap) {
             CK(ctx->bufB.ensure(((u64)pl.F * opt_cap + ATile<1>::KEYS + 16) * sizeof(Key)));
             CK(ctx->descs2.ensure(((size_t)pl.P1 * 2 + 1) * sizeof(ChunkDesc)));
             CK(ctx->seg.ensure((size_t)pl.P1 * sizeof(SegInfo)));
             CK(ctx->mat2.ensure(((size_t)pl.F + 1) * 4));                     // here: keys per sub-partition region
             CK(hipMemsetAsync(ctx->mat2.p, 0, ((size_t)pl.F + 1) * 4, ctx->stream));
-            hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, ctx->stream, ctx->mat1.as<u32>(), nch1, pl.P1, 0x7FFFFFFFu, pl.P2,
-                               ctx->seg.as<SegInfo>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, sc + SC_MLEN2, 1u);
-            CKL("k_plan");
+            if (opt1) {      // segments = the level-1 bin regions (slices + sentinel tails)
+                ctx->h_descs2.resize(pl.P1);
+                for (u32 sgm = 0; sgm < pl.P1; ++sgm) {
+                    ChunkDesc d; d.begin = (u64)sgm * o1.cap1; d.end = d.begin + o1.cap1; d.flat_base = sgm * pl.P2; d.stride = 1;
+                    ctx->h_descs2[sgm] = d;
+                }
+                CK(hipMemcpyAsync(ctx->descs2.p, ctx->h_descs2.data(), (size_t)pl.P1 * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
+            } else {
+                hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, ctx->stream, ctx->mat1.as<u32>(), nch1, pl.P1, 0x7FFFFFFFu, pl.P2,
+                                   ctx->seg.as<SegInfo>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, sc + SC_MLEN2, 1u);
+                CKL("k_plan");
+            }
             ctx->mark("plan2");
             OptSpec os{opt_cap, ctx->mat2.as<u32>(), sc + SC_OVF2};
             if ((rc = launch_scatter_al<W, 2, true>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
@@ -520,14 +566,16 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         CK(hipMemcpyAsync(&ctx->h_back[0], sc + SC_OVERFLOW, 4, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipMemcpyAsync(&ctx->h_back[1], ctx->nsolid.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
         // k-mers of the pass: the last sub-partition offset, or (fixed-capacity regions) the level-1 total
-        CK(hipMemcpyAsync(&ctx->h_back[2], opt_cap ? ctx->mat1.as<u32>() + M1 : ctx->fstart.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (!opt1) CK(hipMemcpyAsync(&ctx->h_back[2], opt_cap ? ctx->mat1.as<u32>() + M1 : ctx->fstart.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipMemcpyAsync(&ctx->h_ovf2, sc + SC_OVF2, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipMemcpyAsync(&ctx->h_stats[0], ctx->gstats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
-        const u32 h_ovf = ctx->h_back[0], h_nsolid = ctx->h_back[1], h_nk = ctx->h_back[2];
-        if (opt_cap && ctx->h_ovf2) {       // a region overflowed: repeat this attempt with exact offsets
+        const u32 h_ovf = ctx->h_back[0], h_nsolid = ctx->h_back[1], h_nk = opt1 ? (u32)ctx->h_nvalid : ctx->h_back[2];
+        if ((opt_cap && ctx->h_ovf2) || (opt1 && ctx->h_ovf1)) {       // a slice / region overflowed: repeat this attempt with exact offsets
             ctx->resolve_marks();
-            ctx->opt2_off = true;
+            if (opt1 && ctx->h_ovf1) ctx->opt1_off = true;
+            else { ctx->opt2_off = true; ctx->opt1_off = true; }     // the exact level 2 cannot read sentinel-padded slices
             ctx->stats.n_retries += 1;
             ctx->mark("start");
             --attempt;
@@ -1011,7 +1059,7 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
     CK(hipMemsetAsync(dst + ctx->reads_len + nbytes, '\n', 1, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     ctx->reads_len += nbytes + 1;
-    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->sk_prepared = false; ctx->opt2_off = false;
+    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->sk_prepared = false; ctx->opt2_off = false; ctx->opt1_off = false;
     return DSKGPU_OK;
 }
 
@@ -1031,7 +1079,7 @@ int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes) {
 
 int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes) {
     if (!ctx || (!d_bytes && nbytes)) return DSKGPU_E_ARG;
-    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->sk_prepared = false; ctx->opt2_off = false;
+    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->sk_prepared = false; ctx->opt2_off = false; ctx->opt1_off = false;
     ctx->n_bytes = nbytes;
     ctx->reads_len = 0;
     ctx->bank_ends.clear();

@@ -363,12 +363,26 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
     }
 }
 
-template <int W, int SRC, int MODE>
+struct OptSpec { u32 cap; u32* subcnt; u32* ovf; };
+template <int W> __device__ __forceinline__ typename KeyT<W>::T empty_key();
+template <> __device__ __forceinline__ u64 empty_key<1>() { return DSK_EMPTY; }
+template <> __device__ __forceinline__ K2 empty_key<2>() { K2 k; k.w[0] = k.w[1] = DSK_EMPTY; return k; }
+template <> __device__ __forceinline__ KN<4> empty_key<4>() { KN<4> k; k.w[0] = k.w[1] = k.w[2] = k.w[3] = DSK_EMPTY; return k; }
+
+// OPT (one-word keys, level 1 from reads): "block-owned slices" -- no histogram pass.  Bin b owns the region
+// [b*cap1, (b+1)*cap1) of `out`, cut into one slice of `slice` keys per block (cap1 = gridDim.x * slice); a
+// block appends its keys of bin b to its own slice, the write cursors live in LDS for the whole launch.  The
+// slices are sized from the exact number of valid k-mers (k_count_valid) plus 6 % + 160 keys; what a block
+// leaves unused is filled with the DSK_EMPTY sentinel, which the level-2 scatter drops.  A slice that would
+// overflow raises *ovf (the host repeats the pass with the exact histogram + scan path).
+struct Opt1Spec { u32 slice, cap1; u32* ovf; };
+
+template <int W, int SRC, int MODE, bool OPT = false>
 __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
                                                    const typename KeyT<W>::T* __restrict__ keys,
                                                    const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
                                                    const u32* __restrict__ scanned,
-                                                   typename KeyT<W>::T* __restrict__ out, int k, DigitSpec ds, u32 P, u32 dbg) {
+                                                   typename KeyT<W>::T* __restrict__ out, int k, DigitSpec ds, u32 P, u32 dbg, Opt1Spec o1) {
     typedef typename KeyT<W>::T Key;
     constexpr int KPT = Tile<W>::KPT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -380,10 +394,11 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
     u32* wsum = delta + P;                                           // 16 (+1 total)
     u32* tot = wsum + 16;
     const u32 nchunks = *d_nchunks;
+    if (OPT) for (u32 b = threadIdx.x; b < P; b += SC_NT) cur[b] = b * o1.cap1 + blockIdx.x * o1.slice;
     for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
         const ChunkDesc d = descs[g];
         lds_barrier();   // previous chunk's write-out reads delta/off/stage
-        for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] = scanned[d.flat_base + (u64)b * d.stride]; cnt[b] = 0; }
+        for (u32 b = threadIdx.x; b < P; b += SC_NT) { if (!OPT) cur[b] = scanned[d.flat_base + (u64)b * d.stride]; cnt[b] = 0; }
         if (threadIdx.x == 0) cnt[P] = 0;
         const u64 step = SRC == 0 ? Tile<W>::WORDS : Tile<W>::KEYS;
         Key ha[KPT], hb[KPT]; u32 vma = 0, vmb = 0;
@@ -454,6 +469,38 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
             }
         }
     }
+    if (OPT) {      // pad the unused tail of every slice of this block; report a slice that was outgrown
+        lds_barrier();
+        bool ovf = false;
+        const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (u32 b = wave; b < P; b += SC_NT / 64) {
+            const u32 end = b * o1.cap1 + (blockIdx.x + 1) * o1.slice, c = cur[b];
+            if (c > end) ovf = true;
+            for (u32 i = c + lane; i < end; i += 64) out[i] = empty_key<W>();
+        }
+        if (ovf) *o1.ovf = 1u;
+    }
+}
+
+// number of valid k-mer windows of the encoded stream (k <= 32): sizes the slices of the OPT level-1 scatter
+__global__ __launch_bounds__(256) void k_count_valid(const u32* __restrict__ inval, u64 nwords, int k, u64* __restrict__ total) {
+    __shared__ u32 ws[4];
+    const u64 stride = (u64)gridDim.x * 256;
+    u32 c = 0;
+    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < nwords; w += stride) {
+        // frame of 64 bases (previous word : this word), bit (63 - i) <-> base i.  A window ending at base e is bad if
+        // an invalid base lies in [e-k+1, e]: smear every invalid bit over the k-1 following bases (log-step ORs)
+        u64 bad = ((u64)(w ? inval[w - 1] : 0xFFFFFFFFu) << 32) | inval[w];
+        int done = 1;                                   // bases covered by the smear so far
+        while (2 * done <= k) { bad |= bad >> done; done *= 2; }
+        if (k > done) bad |= bad >> (k - done);
+        c += 32u - (u32)__popc((u32)bad);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(total, (u64)ws[0] + ws[1] + ws[2] + ws[3]);
 }
 
 // ------------------------------------------------------------------ K4b: scatter with aligned write-out
@@ -486,12 +533,6 @@ __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
 // (the count kernel skips it).  subcnt[q] = keys written to the region, pads included.  A sub-bin that would
 // outgrow its region raises *ovf (writes wrap to the region start: the result is discarded and the host
 // repeats the level with the exact histogram + scan path).  flat_base of a chunk = s*P.
-struct OptSpec { u32 cap; u32* subcnt; u32* ovf; };
-template <int W> __device__ __forceinline__ typename KeyT<W>::T empty_key();
-template <> __device__ __forceinline__ u64 empty_key<1>() { return DSK_EMPTY; }
-template <> __device__ __forceinline__ K2 empty_key<2>() { K2 k; k.w[0] = k.w[1] = DSK_EMPTY; return k; }
-template <> __device__ __forceinline__ KN<4> empty_key<4>() { KN<4> k; k.w[0] = k.w[1] = k.w[2] = k.w[3] = DSK_EMPTY; return k; }
-
 template <int W, int MODE, bool OPT = false>
 __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>::T* __restrict__ keys,
                                                          const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
@@ -542,7 +583,8 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
             u32 rk[KPT];
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
-                const u32 dj = ((vm & (1u << j)) && key_in_pass<MODE>(digit_word(h[j]), ds)) ? key_digit<MODE>(digit_word(h[j]), ds) : P;
+                const bool pad = OPT && digit_word(h[j]) == DSK_EMPTY;     // sentinel of a level-1 slice tail
+                const u32 dj = ((vm & (1u << j)) && !pad && key_in_pass<MODE>(digit_word(h[j]), ds)) ? key_digit<MODE>(digit_word(h[j]), ds) : P;
                 rk[j] = dj << 16;
             }
 #pragma unroll

@@ -240,9 +240,10 @@ def test_synthetic_two_levels(oracle, dev):
     assert st["n_levels"] == 2
 
 
-def test_segment_owned_level2_scatter_and_its_fallback(oracle, dev, monkeypatch):
-    """One-word keys, two levels: the level-2 scatter owns whole segments and writes fixed-capacity regions
-    (no histogram pass).  A region that overflows must send the level through the exact histogram + scan path."""
+def test_histogram_free_scatters_and_their_fallback(oracle, dev, monkeypatch):
+    """One-word keys, two levels: level 1 writes block-owned slices, level 2 owns whole segments and writes
+    fixed-capacity regions -- no histogram pass at either level.  A slice / region that overflows must send the
+    attempt through the exact histogram + scan path."""
     from dsk_amd import KmerCounter, synth
     reads = synth.make_reads(synth.make_genome(400_000, dev), 120_000, 150)
     ref = oracle.count(reads.cpu().numpy(), 31)
@@ -262,11 +263,16 @@ def test_segment_owned_level2_scatter_and_its_fallback(oracle, dev, monkeypatch)
 
     rows, ab, hist, st, stages = run()
     check(rows, ab, hist, st)
-    assert "hist2" not in stages and st["n_retries"] == 0            # fixed-capacity regions were used
-    monkeypatch.setenv("DSKGPU_OPT_CAP", "1024")                     # regions far too small: every one overflows
+    assert "hist1" not in stages and "hist2" not in stages and st["n_retries"] == 0    # neither level ran a histogram pass
+    monkeypatch.setenv("DSKGPU_OPT_SLICE", "64")                     # level-1 slices far too small: exact level 1, level 2 unchanged
     rows, ab, hist, st, stages = run()
     check(rows, ab, hist, st)
-    assert "hist2" in stages and st["n_retries"] == 1                # exact path took over
+    assert "hist1" in stages and "hist2" not in stages and st["n_retries"] == 1
+    monkeypatch.delenv("DSKGPU_OPT_SLICE")
+    monkeypatch.setenv("DSKGPU_OPT_CAP", "1024")                     # level-2 regions far too small: every one overflows
+    rows, ab, hist, st, stages = run()
+    check(rows, ab, hist, st)
+    assert "hist1" in stages and "hist2" in stages and st["n_retries"] == 1            # exact path took over at both levels
     monkeypatch.setenv("DSKGPU_NO_OPT2", "1")
     monkeypatch.delenv("DSKGPU_OPT_CAP")
     rows, ab, hist, st, stages = run()
