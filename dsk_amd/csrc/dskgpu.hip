@@ -350,6 +350,25 @@ int sort_index_multiword(dskgpu_ctx* ctx, DevBuf* rows, u64 n, int W) {
     return DSKGPU_OK;
 }
 
+// full-width order of multi-word rows: W stable radix passes over an index permutation, then gathers
+int sort_rows_full_multiword(dskgpu_ctx* ctx, u64 n) {
+    const int W = ctx->W;
+    int rc = sort_index_multiword(ctx, ctx->out_w, n, W);
+    if (rc) return rc;
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    const u32* idx = ctx->srt_idx.as<u32>();
+    CK(ctx->srt_ab.ensure(n * 4));
+    for (int x = 0; x < W; ++x) {
+        CK(ctx->srt_w[x].ensure(n * 8));
+        hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_w[x].as<u64>(), ctx->out_w[x].as<u64>(), idx, n);
+        ctx->res_w[x] = ctx->srt_w[x].as<u64>();
+    }
+    hipLaunchKernelGGL(k_gather<u32>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_ab.as<u32>(), ctx->out_ab.as<u32>(), idx, n);
+    CKL("sort_rows");
+    ctx->res_ab = ctx->srt_ab.as<u32>();
+    return DSKGPU_OK;
+}
+
 // ---- result post-processing: sort rows by k-mer value
 int sort_rows(dskgpu_ctx* ctx, u64 n) {
     const int W = ctx->W;
@@ -383,20 +402,39 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
         ctx->res_w[0] = ctx->srt_w[0].as<u64>(); ctx->res_ab = ctx->srt_ab.as<u32>();
         return DSKGPU_OK;
     }
-    // multi-word order = stable sorts of an index permutation by word 0, 1, .. W-1 (least significant first)
-    int rc = sort_index_multiword(ctx, ctx->out_w, n, W);
-    if (rc) return rc;
-    const unsigned gb = (unsigned)((n + 255) / 256);
-    const u32* idx = ctx->srt_idx.as<u32>();
-    for (int x = 0; x < W; ++x) {
-        CK(ctx->srt_w[x].ensure(n * 8));
-        hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_w[x].as<u64>(), ctx->out_w[x].as<u64>(), idx, n);
-        ctx->res_w[x] = ctx->srt_w[x].as<u64>();
+    // multi-word rows: radix sort of (top 63 bits of the value, row index) on the key's top 40 bits, gather,
+    // then the runs of equal prefix are ordered in place by full comparison (exact fallback: sort_rows_full_multiword)
+    if (!getenv("DSKGPU_FULLSORT") && 2u * ctx->cfg.kmer_size > 64u) {
+        CK(ctx->srt_k.ensure(n * 8)); CK(ctx->s_val.ensure(n * 8));
+        CK(ctx->srt_idx.ensure(n * 4)); CK(ctx->srt_idx2.ensure(n * 4));
+        const unsigned gb = (unsigned)((n + 255) / 256);
+        RowsIn ri{}; RowsOut ro{};
+        for (int x = 0; x < W; ++x) { CK(ctx->srt_w[x].ensure(n * 8)); ri.w[x] = ctx->out_w[x].as<u64>(); ro.w[x] = ctx->srt_w[x].as<u64>(); }
+        const int bits = 2 * (int)ctx->cfg.kmer_size;
+        if (W == 2) hipLaunchKernelGGL(k_top_key<2>, dim3(gb), dim3(256), 0, ctx->stream, ri, n, bits, ctx->srt_k.as<u64>(), ctx->srt_idx.as<u32>());
+        else hipLaunchKernelGGL(k_top_key<4>, dim3(gb), dim3(256), 0, ctx->stream, ri, n, bits, ctx->srt_k.as<u64>(), ctx->srt_idx.as<u32>());
+        const unsigned begin_bit = 63u - SORT_TOP_BITS;
+        CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->srt_k.as<u64>(), ctx->s_val.as<u64>(), ctx->srt_idx.as<u32>(), ctx->srt_idx2.as<u32>(),
+                                     (size_t)n, begin_bit, 63u, ctx->stream));
+        CK(ctx->srt_tmp.ensure(tmp));
+        CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->srt_k.as<u64>(), ctx->s_val.as<u64>(), ctx->srt_idx.as<u32>(), ctx->srt_idx2.as<u32>(),
+                                     (size_t)n, begin_bit, 63u, ctx->stream));
+        const u32* idx = ctx->srt_idx2.as<u32>();
+        for (int x = 0; x < W; ++x)
+            hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_w[x].as<u64>(), ctx->out_w[x].as<u64>(), idx, n);
+        hipLaunchKernelGGL(k_gather<u32>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_ab.as<u32>(), ctx->out_ab.as<u32>(), idx, n);
+        u32* flag = ctx->scalars.as<u32>() + SC_SORTFLAG;
+        CK(hipMemsetAsync(flag, 0, 4, ctx->stream));
+        if (W == 2) hipLaunchKernelGGL(k_fix_runs_multi<2>, dim3(gb), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), ctx->s_val.as<u64>(), n, (int)begin_bit, flag);
+        else hipLaunchKernelGGL(k_fix_runs_multi<4>, dim3(gb), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), ctx->s_val.as<u64>(), n, (int)begin_bit, flag);
+        CKL("sort_rows");
+        CK(hipMemcpyAsync(&ctx->h_back[3], flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sort_partial = true;
+        for (int x = 0; x < W; ++x) ctx->res_w[x] = ctx->srt_w[x].as<u64>();
+        ctx->res_ab = ctx->srt_ab.as<u32>();
+        return DSKGPU_OK;
     }
-    hipLaunchKernelGGL(k_gather<u32>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_ab.as<u32>(), ctx->out_ab.as<u32>(), idx, n);
-    CKL("sort_rows");
-    ctx->res_ab = ctx->srt_ab.as<u32>();
-    return DSKGPU_OK;
+    return sort_rows_full_multiword(ctx, n);
 }
 
 // One pass: partition + count the keys of pass `pass` (of `npass`) and leave its solid rows
@@ -685,6 +723,10 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                                          ctx->out_ab.as<u32>(), (size_t)tot_rows, 0u, end_bit, ctx->stream));
             CK(hipStreamSynchronize(ctx->stream));
             ctx->res_w[0] = ctx->out_w[0].as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>();
+            ctx->stats.sort_fallback = 1;
+        } else if (W > 1 && ctx->sort_partial && tot_rows && ctx->h_back[3]) {
+            if ((rc = sort_rows_full_multiword(ctx, tot_rows))) return rc;      // out_w still holds the unsorted rows
+            CK(hipStreamSynchronize(ctx->stream));
             ctx->stats.sort_fallback = 1;
         }
         ctx->resolve_marks();

@@ -1203,6 +1203,54 @@ __global__ __launch_bounds__(256) void k_fix_runs(u64* __restrict__ lo, u32* __r
     }
 }
 
+// Multi-word rows: the same two-step order.  k_top_key builds the top 63 bits of every value (bit 63 stays clear:
+// rocPRIM's partial-range sort misbehaves when end_bit == 64) next to the identity permutation; after a radix sort
+// of (key, index) on the key's top 40 bits and a gather of the rows, k_fix_runs_multi orders the runs of equal
+// prefix by full multi-word comparison.
+template <int W>
+__global__ __launch_bounds__(256) void k_top_key(RowsIn rows, u64 n, int bits, u64* __restrict__ key, u32* __restrict__ idx) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int sh = bits - 63, ws = sh >> 6, b = sh & 63;     // bits > 64 for multi-word values
+    u64 lo = 0, hi = 0;
+#pragma unroll
+    for (int x = 0; x < W; ++x) { if (x == ws) lo = rows.w[x][i]; if (x == ws + 1) hi = rows.w[x][i]; }
+    key[i] = b ? (lo >> b) | (hi << (64 - b)) : lo;
+    idx[i] = (u32)i;
+}
+template <int W>
+__device__ __forceinline__ bool row_less(const u64 (&a)[W], const RowsOut& r, u64 j) {     // a < row j ?
+#pragma unroll
+    for (int x = W - 1; x >= 0; --x) { const u64 v = r.w[x][j]; if (a[x] != v) return a[x] < v; }
+    return false;
+}
+template <int W>
+__global__ __launch_bounds__(256) void k_fix_runs_multi(RowsOut rows, u32* __restrict__ ab, const u64* __restrict__ key, u64 n, int sh, u32* __restrict__ flag) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 p = key[i] >> sh;
+    if (i > 0 && (key[i - 1] >> sh) == p) return;           // not a run head
+    u64 e = i + 1;
+    while (e < n && e - i <= FIX_CAP && (key[e] >> sh) == p) ++e;
+    const u64 L = e - i;
+    if (L == 1) return;
+    if (L > FIX_CAP) { *flag = 1; return; }
+    for (u64 a = i + 1; a < e; ++a) {
+        u64 kv[W]; const u32 av = ab[a];
+#pragma unroll
+        for (int x = 0; x < W; ++x) kv[x] = rows.w[x][a];
+        u64 b = a;
+        while (b > i && row_less<W>(kv, rows, b - 1)) {
+#pragma unroll
+            for (int x = 0; x < W; ++x) rows.w[x][b] = rows.w[x][b - 1];
+            ab[b] = ab[b - 1]; --b;
+        }
+#pragma unroll
+        for (int x = 0; x < W; ++x) rows.w[x][b] = kv[x];
+        ab[b] = av;
+    }
+}
+
 // ------------------------------------------------------------------ multi-bank merge (solidity kinds, 2-D histogram)
 // Input: the union of the per-bank rows, sorted by k-mer, value = (bank << 32) | abundance.  One thread per
 // row; the first row of every k-mer walks its run (<= number of banks) and decides solidity:

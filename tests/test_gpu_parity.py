@@ -467,6 +467,21 @@ def test_row_sort_fallback_on_shared_prefixes(oracle, dev):
     assert st["sort_fallback"] == 0
 
 
+@pytest.mark.parametrize("k", [40, 63, 70, 100])
+def test_multiword_row_sort_prefix_runs_and_fallback(oracle, dev, k):
+    """Multi-word rows use the same two-step order (radix sort on the top 40 bits of the value, runs fixed in place by
+    full comparison): short runs of a shared 20-base prefix stay on that path, long ones take the full-width fallback."""
+    rng = np.random.default_rng(12)
+    tails = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(300, k - 20))
+    noise = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=60_000).tobytes()
+    head = b"AAAAAAAAAAAAAAAAAAAC"
+    for nshare, fallback in ((25, 0), (300, 1)):
+        recs = [head + t.tobytes() for t in tails[:nshare]]
+        s = np.frombuffer(b"\n".join(recs) + b"\n" + noise + b"\n", dtype=np.uint8)
+        st = check_against_oracle(oracle, s, k, dev, amin=1)
+        assert st["sort_fallback"] == fallback
+
+
 @pytest.mark.parametrize("k,mkeys,n_reads", [(31, 2, 100_000), (27, 1, 60_000), (63, 1, 60_000)])
 def test_multi_pass_over_key_space(oracle, dev, k, mkeys, n_reads):
     """Inputs with more k-mers than one pass may hold are counted in several passes over the key
