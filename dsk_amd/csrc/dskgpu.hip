@@ -85,6 +85,7 @@ struct dskgpu_ctx {
     DevBuf sk_sums, sk_cbase, sk_keys;
     std::vector<u32> h_sk_sums; std::vector<u64> h_sk_cbase;
     u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0; u64 h_nvalid = 0;
+    bool sentinel_ok = true;       // the all-ones key is not the mixed form of a canonical k-mer of this k (checked at create)
     bool opt1_off = false;         // same for the histogram-free level-1 scatter (block-owned slices)
     bool opt2_off = false;         // the fixed-capacity level-2 scatter overflowed on these reads: use the exact path   // host landing zone of the async size read-back
     std::vector<ChunkDesc> h_descs1, h_descs2;
@@ -140,6 +141,21 @@ namespace {
     } while (0)
 
 int fail(dskgpu_ctx* ctx, int code, const std::string& msg) { ctx->err = msg; return code; }
+
+// Is the all-ones key (the pad / empty-slot sentinel) the mixed form of a real canonical k-mer of this k?
+// (It never is for k <= 32; for wider keys it is checked here once and the sentinel-based paths are switched off if so.)
+bool sentinel_is_a_kmer(int W, unsigned k) {
+    u64 v[4] = {0, 0, 0, 0};
+    if (W == 1) v[0] = kunmix(~0ull);
+    else if (W == 2) { KN<2> x; x.w[0] = x.w[1] = ~0ull; kunmixN(x); v[0] = x.w[0]; v[1] = x.w[1]; }
+    else { KN<4> x; for (int i = 0; i < 4; ++i) x.w[i] = ~0ull; kunmixN(x); for (int i = 0; i < 4; ++i) v[i] = x.w[i]; }
+    auto base = [&](const u64* a, unsigned i) { return (unsigned)((a[i >> 5] >> (2 * (i & 31))) & 3u); };   // base i counted from the LAST base
+    for (unsigned i = k; i < 128; ++i) if (base(v, i)) return false;          // does not fit in 2k bits
+    u64 r[4] = {0, 0, 0, 0};                                                  // reverse complement
+    for (unsigned i = 0; i < k; ++i) { const unsigned c = base(v, i) ^ 2u, j = k - 1 - i; r[j >> 5] |= (u64)c << (2 * (j & 31)); }
+    for (int x = 3; x >= 0; --x) if (v[x] != r[x]) return v[x] < r[x];        // canonical iff value <= its reverse complement
+    return true;
+}
 
 
 // ---- K1 launcher
@@ -254,6 +270,25 @@ int launch_scatter(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chunk
                         : launch_scatter_m<W, 1, 1>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P);
 }
 
+// fixed-capacity regions or exact offsets: a compile-time switch of the count kernels (k_count1 / k_count_mw)
+inline void launch_count_impl(dskgpu_ctx* ctx, unsigned grid, u64* keys, u64* solid_keys, u32* solid_ab, u32* ovf, const CountParams& cp) {
+    if (cp.cap) hipLaunchKernelGGL(k_count1<true>, dim3(grid), dim3(CNT_NT), 0, ctx->stream, keys, solid_keys, ctx->fstart.as<u32>(), solid_ab,
+                                   ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, cp);
+    else hipLaunchKernelGGL(k_count1<false>, dim3(grid), dim3(CNT_NT), 0, ctx->stream, keys, solid_keys, ctx->fstart.as<u32>(), solid_ab,
+                            ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, cp);
+}
+template <int W>
+inline void launch_count_impl(dskgpu_ctx* ctx, unsigned grid, KN<W>* keys, KN<W>* solid_keys, u32* solid_ab, u32* ovf, const CountParams& cp) {
+    if (cp.cap) hipLaunchKernelGGL((k_count_mw<W, true>), dim3(grid), dim3(CNT_NT), 0, ctx->stream, keys, solid_keys, ctx->fstart.as<u32>(), solid_ab,
+                                   ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, cp);
+    else hipLaunchKernelGGL((k_count_mw<W, false>), dim3(grid), dim3(CNT_NT), 0, ctx->stream, keys, solid_keys, ctx->fstart.as<u32>(), solid_ab,
+                            ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, cp);
+}
+template <int W>
+inline void launch_count(dskgpu_ctx* ctx, unsigned grid, typename KeyT<W>::T* keys, typename KeyT<W>::T* solid_keys, u32* solid_ab, u32* ovf, const CountParams& cp) {
+    launch_count_impl(ctx, grid, keys, solid_keys, solid_ab, ovf, cp);
+}
+
 struct Plan {
     int levels;
     u32 P1, P2, F;
@@ -265,6 +300,7 @@ struct Plan {
 #define MAX_LEVEL_BINS 2048
 #define ONE_LEVEL_BINS 1024
 #define CH2 65536u            // keys per level-2 chunk
+#define OPT_GROUPS 545u
 #define OPT_CAP 4360u          // segment-owned level-2 scatter: keys per sub-partition region (mean <= TARGET_KEYS).
                               // 545 groups of 64 B -- an ODD number, so the region starts (and the write fronts that advance
                               // through all regions in step) spread over every HBM channel instead of camping on a few
@@ -464,10 +500,17 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         // pass (block-owned slices at level 1, segment-owned regions at level 2); any overflow sends the whole
         // attempt back through the exact histogram + scan path.
         u32 opt_cap = 0;                 // level 2: keys per sub-partition region (0 = exact offsets)
-        if (pl.levels == 2 && W == 1 && !ctx->opt2_off && !getenv("DSKGPU_NO_OPT2") && ascatter_lds(W, pl.P2) <= 160 * 1024 &&
-            ((u64)pl.F * OPT_CAP * 4 <= ctx->bufA.cap || getenv("DSKGPU_OPT_CAP")))          // the abundances of the solid rows reuse bufA at the same indices
-            opt_cap = OPT_CAP;
+        if (pl.levels == 2 && ctx->sentinel_ok && !ctx->opt2_off && !getenv("DSKGPU_NO_OPT2") && ascatter_lds(W, pl.P2) <= 160 * 1024)
+            opt_cap = OPT_GROUPS * (8u / W);                                                    // 545 groups of 64 B whatever the key width
         if (opt_cap) { if (const char* e = getenv("DSKGPU_OPT_CAP")) opt_cap = (u32)atoi(e) & ~7u; }   // experiments / tests
+        if (W > 1 && (u64)pl.F * opt_cap >= 0xFFFF0000ull) opt_cap = 0;                       // k_count<W> keeps 32-bit offsets
+        if (opt_cap) {
+            // the rows of the solid k-mers land at the region offsets too: abundances (one-word keys: in bufA, the free
+            // ping-pong buffer) or keys + abundances (multi-word keys: bufA + abund2).  Size everything BEFORE level 1 writes bufA.
+            const u64 slots = (u64)pl.F * opt_cap + ATile<W>::KEYS + 16;
+            CK(ctx->bufA.ensure(std::max<u64>(W == 1 ? slots * 4 : slots * sizeof(Key), (cap + 1) * sizeof(Key))));
+            if (W > 1) CK(ctx->abund2.ensure(slots * 4));
+        }
         bool opt1 = opt_cap && from_reads && npass == 1 && !ctx->opt1_off && !getenv("DSKGPU_NO_OPT1");
         Opt1Spec o1{0u, 0u, sc + SC_OVF1};
         unsigned grid1 = 0;
@@ -532,7 +575,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         // sub-partition gets a fixed region of OPT_CAP keys; a region that overflows (heavy repeats) sends the
         // level back through the exact histogram + scan path, and the context remembers it for these reads.
         if (pl.levels == 2 && opt_cap) {
-            CK(ctx->bufB.ensure(((u64)pl.F * opt_cap + ATile<1>::KEYS + 16) * sizeof(Key)));
+            CK(ctx->bufB.ensure(((u64)pl.F * opt_cap + ATile<W>::KEYS + 16) * sizeof(Key)));
             CK(ctx->descs2.ensure(((size_t)pl.P1 * 2 + 1) * sizeof(ChunkDesc)));
             CK(ctx->seg.ensure((size_t)pl.P1 * sizeof(SegInfo)));
             CK(ctx->mat2.ensure(((size_t)pl.F + 1) * 4));                     // here: keys per sub-partition region
@@ -594,8 +637,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         const unsigned cgrid = (unsigned)std::min<u64>(pl.F, (u64)ctx->num_cu * 2);
         Key* solid_keys = W == 1 ? fkeys : scratch->as<Key>();
         u32* solid_ab = W == 1 ? scratch->as<u32>() : ctx->abund2.as<u32>();
-        hipLaunchKernelGGL(k_count<W>, dim3(cgrid), dim3(CNT_NT), 0, ctx->stream, fkeys, solid_keys, ctx->fstart.as<u32>(), solid_ab,
-                           ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), sc + SC_OVERFLOW, cp);
+        launch_count<W>(ctx, cgrid, fkeys, solid_keys, solid_ab, sc + SC_OVERFLOW, cp);
         CKL("k_count");
         ctx->mark("count");
         if ((rc = run_scan(ctx, ctx->nsolid.as<u32>(), sc + SC_F, pl.F))) return rc;
@@ -1015,7 +1057,8 @@ int dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out) {
     if (ctx->cfg.abundance_max == 0) ctx->cfg.abundance_max = 0x7FFFFFFFu;
     if (ctx->cfg.minimizer_size == 0) ctx->cfg.minimizer_size = 10;
     ctx->W = cfg->kmer_size <= 32 ? 1 : cfg->kmer_size <= 64 ? 2 : 4;     // device keys: 1, 2 or 4 words
-    ctx->words_out = (int)((cfg->kmer_size + 31) / 32);                   // words of a k-mer at the ABI (3 for k <= 96)
+    ctx->words_out = (int)((cfg->kmer_size + 31) / 32);
+    ctx->sentinel_ok = !sentinel_is_a_kmer(ctx->W, cfg->kmer_size);                   // words of a k-mer at the ABI (3 for k <= 96)
     ctx->max_keys_per_pass = (u64)cfg->max_pass_mkeys * 1000000ull;
     // super-k-mer records need >= 16 m-mers per window (superkmer.h); shorter k-mers travel as explicit keys
     ctx->sk_mode = ws > 1 && cfg->kmer_size >= 20 && cfg->kmer_size <= 64 && !(cfg->flags & DSKGPU_F_MG_EXPLICIT);

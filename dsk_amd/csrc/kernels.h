@@ -364,6 +364,13 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
 }
 
 struct OptSpec { u32 cap; u32* subcnt; u32* ovf; };
+__device__ __forceinline__ bool is_empty_key(u64 h) { return h == DSK_EMPTY; }
+template <int W> __device__ __forceinline__ bool is_empty_key(const KN<W>& h) {
+    bool e = true;
+#pragma unroll
+    for (int x = 0; x < W; ++x) e = e && (h.w[x] == DSK_EMPTY);
+    return e;
+}
 template <int W> __device__ __forceinline__ typename KeyT<W>::T empty_key();
 template <> __device__ __forceinline__ u64 empty_key<1>() { return DSK_EMPTY; }
 template <> __device__ __forceinline__ K2 empty_key<2>() { K2 k; k.w[0] = k.w[1] = DSK_EMPTY; return k; }
@@ -482,19 +489,32 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
     }
 }
 
-// number of valid k-mer windows of the encoded stream (k <= 32): sizes the slices of the OPT level-1 scatter
+// number of valid k-mer windows of the encoded stream (any k <= 128): sizes the slices of the OPT level-1 scatter
 __global__ __launch_bounds__(256) void k_count_valid(const u32* __restrict__ inval, u64 nwords, int k, u64* __restrict__ total) {
     __shared__ u32 ws[4];
     const u64 stride = (u64)gridDim.x * 256;
     u32 c = 0;
     for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < nwords; w += stride) {
-        // frame of 64 bases (previous word : this word), bit (63 - i) <-> base i.  A window ending at base e is bad if
-        // an invalid base lies in [e-k+1, e]: smear every invalid bit over the k-1 following bases (log-step ORs)
-        u64 bad = ((u64)(w ? inval[w - 1] : 0xFFFFFFFFu) << 32) | inval[w];
-        int done = 1;                                   // bases covered by the smear so far
-        while (2 * done <= k) { bad |= bad >> done; done *= 2; }
-        if (k > done) bad |= bad >> (k - done);
-        c += 32u - (u32)__popc((u32)bad);
+        const u32 ic = inval[w];
+        if (k <= 32) {
+            // frame of 64 bases (previous word : this word), bit (63 - i) <-> base i.  A window ending at base e is bad if
+            // an invalid base lies in [e-k+1, e]: smear every invalid bit over the k-1 following bases (log-step ORs)
+            u64 bad = ((u64)(w ? inval[w - 1] : 0xFFFFFFFFu) << 32) | ic;
+            int done = 1;                                   // bases covered by the smear so far
+            while (2 * done <= k) { bad |= bad >> done; done *= 2; }
+            if (k > done) bad |= bad >> (k - done);
+            c += 32u - (u32)__popc((u32)bad);
+        } else {
+            // longer windows: run = valid bases that end just before this word (walk back over whole valid words), then roll
+            int run = 0;
+            for (int q = 1; q <= 4 && run < k; ++q) {
+                if (w < (u64)q) break;
+                const u32 iv = inval[w - q];
+                if (iv == 0) run += 32; else { run += __builtin_ctz(iv); break; }
+            }
+#pragma unroll
+            for (int t = 0; t < 32; ++t) { run = ((ic >> (31 - t)) & 1u) ? 0 : run + 1; c += run >= k ? 1u : 0u; }
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d);
@@ -530,7 +550,7 @@ __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
 // segment (level-1 bin), processed by one block from start to end, and every sub-bin q = s*P + b owns the
 // fixed region [q*cap, (q+1)*cap) of `out`; pos[] starts at the region bases and simply advances, the carry
 // lives through the whole segment, and at its end the partial groups are padded with the DSK_EMPTY sentinel
-// (the count kernel skips it).  subcnt[q] = keys written to the region, pads included.  A sub-bin that would
+// (never read: subcnt[q] = number of real keys of the region).  A sub-bin that would
 // outgrow its region raises *ovf (writes wrap to the region start: the result is discarded and the host
 // repeats the level with the exact histogram + scan path).  flat_base of a chunk = s*P.
 template <int W, int MODE, bool OPT = false>
@@ -583,7 +603,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
             u32 rk[KPT];
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
-                const bool pad = OPT && digit_word(h[j]) == DSK_EMPTY;     // sentinel of a level-1 slice tail
+                const bool pad = OPT && is_empty_key(h[j]);                 // sentinel of a level-1 slice tail
                 const u32 dj = ((vm & (1u << j)) && !pad && key_in_pass<MODE>(digit_word(h[j]), ds)) ? key_digit<MODE>(digit_word(h[j]), ds) : P;
                 rk[j] = dj << 16;
             }
@@ -680,7 +700,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                 u32 p = pos[b];
                 if (r && p + G > (u32)(b + 1) * os.cap) { ovf = true; p = (u32)b * os.cap; }
                 if (r) out[p + gl] = gl < r ? carry[(size_t)b * CARRY + gl] : empty_key<W>();       // pad the last group
-                if (gl == 0) { const u32 n = p - (u32)b * os.cap + (r ? G : 0u); os.subcnt[d.flat_base + b] = n < os.cap ? n : os.cap; }
+                if (gl == 0) { const u32 n = p - (u32)b * os.cap + r; os.subcnt[d.flat_base + b] = n < os.cap ? n : os.cap; }   // real keys: the pads are never read
             }
         }
         if (OPT && ovf) *os.ovf = 1u;
@@ -765,11 +785,12 @@ struct CountParams {
     u32 amin, amax, histo_max;
     u32 dbg;                  // experiment switches (timing ablations only)
     u32 cap;                  // != 0: fixed-capacity sub-partition regions (segment-owned level-2 scatter):
-    const u32* subcnt;        //       sub-partition q = keys [q*cap, q*cap + subcnt[q]), DSK_EMPTY pads skipped
+    const u32* subcnt;        //       sub-partition q = keys [q*cap, q*cap + subcnt[q])
 };
 // key range of sub-partition q
+template <bool REG>
 __device__ __forceinline__ void sub_range(const CountParams& cp, const u32* __restrict__ fstart, u32 q, u64* begin, u32* n) {
-    if (cp.cap) { *begin = (u64)q * cp.cap; *n = cp.subcnt[q]; }
+    if (REG) { *begin = (u64)q * cp.cap; *n = cp.subcnt[q]; }
     else { const u32 b = fstart[q]; *begin = b; *n = fstart[q + 1] - b; }
 }
 
@@ -785,13 +806,6 @@ __device__ __forceinline__ void sub_range(const CountParams& cp, const u32* __re
 // solid_keys: where the solid rows' (still mixed) keys go, at index begin+pos.
 //             one-word keys: == keys (in place); two-word keys: the free ping-pong buffer
 // abund     : abundance of the solid rows at the same index
-template <int W>
-__global__ __launch_bounds__(CNT_NT) void k_count(typename KeyT<W>::T* keys, typename KeyT<W>::T* solid_keys,
-                                                  const u32* __restrict__ fstart,
-                                                  u32* __restrict__ abund, u32* __restrict__ nsolid,
-                                                  u64* __restrict__ ghist, u64* __restrict__ gstats,
-                                                  u32* __restrict__ overflow, CountParams cp);
-
 __device__ __forceinline__ void table_insert1(u64* tk, u32* tc, unsigned short* lst, u32* ndist, u32* ovf, u64 h) {
     u32 slot = (u32)h & (CNT_SLOTS - 1);
     int probe = 0;
@@ -807,11 +821,11 @@ __device__ __forceinline__ void table_insert1(u64* tk, u32* tc, unsigned short* 
     *ovf = 1;
 }
 
-template <>
-__global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* keys, u64* solid_keys, const u32* __restrict__ fstart,
-                                                     u32* __restrict__ abund, u32* __restrict__ nsolid,
-                                                     u64* __restrict__ ghist, u64* __restrict__ gstats,
-                                                     u32* __restrict__ overflow, CountParams cp) {
+template <bool REG>      // REG: fixed-capacity regions instead of exact offsets (compile-time: see k_count_mw)
+__global__ __launch_bounds__(CNT_NT) void k_count1(u64* keys, u64* solid_keys, const u32* __restrict__ fstart,
+                                                   u32* __restrict__ abund, u32* __restrict__ nsolid,
+                                                   u64* __restrict__ ghist, u64* __restrict__ gstats,
+                                                   u32* __restrict__ overflow, CountParams cp) {
     __shared__ u64 tk[CNT_SLOTS];
     __shared__ u32 tc[CNT_SLOTS];
     __shared__ unsigned short lst[CNT_SLOTS];
@@ -827,7 +841,7 @@ __global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* keys, u64* solid_keys,
     u64 begin = 0; u32 n = 0;
     u64 pk[CNT_KPT];
     if (q < cp.F) {
-        sub_range(cp, fstart, q, &begin, &n);
+        sub_range<REG>(cp, fstart, q, &begin, &n);
         if (n) {
 #pragma unroll
             for (int j = 0; j < CNT_KPT; ++j) { const u32 i = tid + j * CNT_NT; pk[j] = keys[begin + (i < n ? i : n - 1)]; }
@@ -842,23 +856,21 @@ __global__ __launch_bounds__(CNT_NT) void k_count<1>(u64* keys, u64* solid_keys,
         // fire-and-forget LDS add.  Misses take the CAS/probe loop afterwards.
         u64 seen[CNT_KPT];
 #pragma unroll
-        for (int j = 0; j < CNT_KPT; ++j)     // (the all-ones pad of a fixed-capacity region is treated like an out-of-range lane)
-            seen[j] = ((u32)(tid + j * CNT_NT) < n && pk[j] != DSK_EMPTY) ? tk[(u32)pk[j] & (CNT_SLOTS - 1)] : pk[j] + 1;
+        for (int j = 0; j < CNT_KPT; ++j)
+            seen[j] = ((u32)(tid + j * CNT_NT) < n) ? tk[(u32)pk[j] & (CNT_SLOTS - 1)] : pk[j] + 1;
 #pragma unroll
         for (int j = 0; j < CNT_KPT; ++j)
-            if ((u32)(tid + j * CNT_NT) < n && pk[j] != DSK_EMPTY) {
+            if ((u32)(tid + j * CNT_NT) < n) {
                 if (seen[j] == pk[j]) atomicAdd(&tc[(u32)pk[j] & (CNT_SLOTS - 1)], 1u);
                 else table_insert1(tk, tc, lst, &ctr[0], &ctr[2], pk[j]);
             }
-        for (u32 i = CNT_KPT * CNT_NT + tid; i < n; i += CNT_NT) {               // oversized sub-partition
-            const u64 kx = keys[begin + i];
-            if (kx != DSK_EMPTY) table_insert1(tk, tc, lst, &ctr[0], &ctr[2], kx);
-        }
+        for (u32 i = CNT_KPT * CNT_NT + tid; i < n; i += CNT_NT)                 // oversized sub-partition
+            table_insert1(tk, tc, lst, &ctr[0], &ctr[2], keys[begin + i]);
         // prefetch the block's next sub-partition
         const u32 qn = q + gridDim.x;
         u64 nbeg = 0; u32 nn = 0;
         if (qn < cp.F) {
-            sub_range(cp, fstart, qn, &nbeg, &nn);
+            sub_range<REG>(cp, fstart, qn, &nbeg, &nn);
             if (nn) {
 #pragma unroll
                 for (int j = 0; j < CNT_KPT; ++j) { const u32 i = tid + j * CNT_NT; pk[j] = keys[nbeg + (i < nn ? i : nn - 1)]; }
@@ -952,11 +964,13 @@ __device__ __forceinline__ void table_insert2(const KN<W>* sk, const KN<W>* __re
     *ovf = 1;
 }
 
-template <int W>
-__global__ __launch_bounds__(CNT_NT) void k_count(typename KeyT<W>::T* keys, typename KeyT<W>::T* solid_keys, const u32* __restrict__ fstart,
-                                                  u32* __restrict__ abund, u32* __restrict__ nsolid,
-                                                  u64* __restrict__ ghist, u64* __restrict__ gstats,
-                                                  u32* __restrict__ overflow, CountParams cp) {
+// REG: fixed-capacity regions (q*cap, subcnt[q]) instead of exact offsets -- a compile-time switch, because this
+// kernel's speed depends on its exact instruction schedule (a run-time branch here cost 45 % at k = 63)
+template <int W, bool REG>
+__global__ __launch_bounds__(CNT_NT) void k_count_mw(KN<W>* keys, KN<W>* solid_keys, const u32* __restrict__ fstart,
+                                                     u32* __restrict__ abund, u32* __restrict__ nsolid,
+                                                     u64* __restrict__ ghist, u64* __restrict__ gstats,
+                                                     u32* __restrict__ overflow, CountParams cp) {
     typedef KN<W> K2;                            // (multi-word key of this instantiation)
     constexpr int C2_STAGE = CStage<W>::N, C2_KPT = CStage<W>::KPT;
     __shared__ K2 sk[C2_STAGE];
@@ -970,10 +984,12 @@ __global__ __launch_bounds__(CNT_NT) void k_count(typename KeyT<W>::T* keys, typ
     for (int b = tid; b < CNT_LH; b += CNT_NT) lh[b] = 0;
     if (tid < 4) ctr[tid] = 0;
     u32 ones = 0; u64 ndist_acc = 0;
+    // (32-bit offsets on purpose: this kernel is sensitive to its register / address arithmetic shape; the host keeps
+    //  F * cap below 2^32 for multi-word keys)
     u32 q = blockIdx.x, begin = 0, end = 0;
     K2 pk[C2_KPT];
     if (q < cp.F) {
-        begin = fstart[q]; end = fstart[q + 1];
+        if (REG) { begin = q * cp.cap; end = begin + cp.subcnt[q]; } else { begin = fstart[q]; end = fstart[q + 1]; }
 #pragma unroll
         for (int j = 0; j < C2_KPT; ++j) { const u32 i = begin + tid + j * CNT_NT; if (i < end) pk[j] = keys[i]; }
     }
@@ -996,7 +1012,7 @@ __global__ __launch_bounds__(CNT_NT) void k_count(typename KeyT<W>::T* keys, typ
         const u32 qn = q + gridDim.x;
         u32 nbeg = 0, nend = 0;
         if (qn < cp.F) {
-            nbeg = fstart[qn]; nend = fstart[qn + 1];
+            if (REG) { nbeg = qn * cp.cap; nend = nbeg + cp.subcnt[qn]; } else { nbeg = fstart[qn]; nend = fstart[qn + 1]; }
 #pragma unroll
             for (int j = 0; j < C2_KPT; ++j) { const u32 i = nbeg + tid + j * CNT_NT; if (i < nend) pk[j] = keys[i]; }
         }
@@ -1067,11 +1083,12 @@ struct RowsIn { const u64* w[4]; };
 template <int W>
 __global__ __launch_bounds__(256) void k_compact(const typename KeyT<W>::T* __restrict__ keys, const u32* __restrict__ abund,
                                                  const u32* __restrict__ fstart, const u32* __restrict__ soff, u32 F,
-                                                 RowsOut out, u32* __restrict__ out_ab, u32 /*cap: one-word keys only*/) {
+                                                 RowsOut out, u32* __restrict__ out_ab, u32 cap) {
     const u32 q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= F) return;
-    const u32 o = soff[q], ns = soff[q + 1] - o, b = fstart[q];
+    const u32 o = soff[q], ns = soff[q + 1] - o;
+    const u64 b = cap ? (u64)q * cap : (u64)fstart[q];        // fixed-capacity regions or exact offsets
     for (u32 i = lane; i < ns; i += 64) {
         KN<W> kx = keys[b + i];
         kunmixN(kx);

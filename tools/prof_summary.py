@@ -38,7 +38,7 @@ avg_ns = {r["Name"]: float(r["AverageNs"]) for r in rows}
 
 # kernel -> bench stage name.  k_hist/k_scatter: <W, SRC, MODE>; SRC 0 = reads (level 1), 1 = key array (level 2)
 stage_of = [("k_encode", "encode"), ("k_hist<1, 0,", "hist1"), ("k_scatter<1, 0,", "scatter1"), ("k_hist<1, 1,", "hist2"),
-            ("k_scatter<1, 1,", "scatter2"), ("k_scatter_al<1,", "scatter2"), ("k_count<1>", "count"), ("k_compact<1>", "compact")]
+            ("k_scatter<1, 1,", "scatter2"), ("k_scatter_al<1,", "scatter2"), ("k_count1<", "count"), ("k_compact<1>", "compact")]
 summary = {}
 lines = [f"# PMC summary ({tag})", "",
          "rocprofv3 `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes (TCC slots), values are KiB per dispatch,",
