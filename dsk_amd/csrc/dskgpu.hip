@@ -511,16 +511,19 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             CK(ctx->bufA.ensure(std::max<u64>(W == 1 ? slots * 4 : slots * sizeof(Key), (cap + 1) * sizeof(Key))));
             if (W > 1) CK(ctx->abund2.ensure(slots * 4));
         }
-        bool opt1 = opt_cap && from_reads && npass == 1 && !ctx->opt1_off && !getenv("DSKGPU_NO_OPT1");
+        bool opt1 = opt_cap && npass == 1 && !ctx->opt1_off && !getenv("DSKGPU_NO_OPT1");
         Opt1Spec o1{0u, 0u, sc + SC_OVF1};
         unsigned grid1 = 0;
+        if (opt1 && !from_reads) ctx->h_nvalid = nkeys_in;
         if (opt1) {
+            if (from_reads) {
             CK(hipMemsetAsync(ctx->gstats.p, 0, 4 * 8, ctx->stream));
             hipLaunchKernelGGL(k_count_valid, dim3((unsigned)std::min<u64>((nwords + 255) / 256, (u64)ctx->num_cu * 8)), dim3(256), 0, ctx->stream,
                                ctx->inval.as<u32>(), nwords, (int)ctx->cfg.kmer_size, ctx->gstats.as<u64>() + 3);
             CKL("k_count_valid");
             CK(hipMemcpyAsync(&ctx->h_nvalid, ctx->gstats.as<u64>() + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
             CK(hipStreamSynchronize(ctx->stream));
+            }
             grid1 = scatter_grid(ctx, W, pl.P1, nch1);
             const u64 cells = (u64)pl.P1 * grid1;
             // a block's share of the input: it walks chunks blockIdx, blockIdx + grid, .. (equal chunks, the busiest block has ceil(nch/grid))
@@ -546,7 +549,9 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         int rc;
         const ChunkDesc* dd1 = ctx->descs1.as<ChunkDesc>();
         if (opt1) {
-            if ((rc = launch_scatter_m<W, 0, 1, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1))) return rc;
+            if (from_reads) rc = launch_scatter_m<W, 0, 1, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+            else rc = launch_scatter_m<W, 1, 1, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+            if (rc) return rc;
             ctx->mark("scatter1");
         } else {
             CK(ctx->mat1.ensure((M1 + 1) * 4));
