@@ -238,18 +238,18 @@ int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chu
     return DSKGPU_OK;
 }
 // key-array source with aligned write-out (k_scatter_al) when its LDS footprint fits one CU
-template <int W, int MODE, bool OPT = false>
+template <int W, int MODE, bool OPT = false, bool SLICED = false>
 int launch_scatter_al(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                      u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, OptSpec os = OptSpec{0u, nullptr, nullptr}) {
+                      u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, OptSpec os = OptSpec{0u, nullptr, nullptr, nullptr, 0u, 0u}) {
     const size_t lds = ascatter_lds(W, P);
     const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu));
     static bool attr_set = false;
     if (!attr_set) {
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_al<W, MODE, OPT>),
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_al<W, MODE, OPT, SLICED>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_scatter_al<W, MODE, OPT>), dim3(grid), dim3(SC_NT), lds, ctx->stream, keys, descs, d_nch, scanned, out, ds, P, dbg_flags(1), os);
+    hipLaunchKernelGGL((k_scatter_al<W, MODE, OPT, SLICED>), dim3(grid), dim3(SC_NT), lds, ctx->stream, keys, descs, d_nch, scanned, out, ds, P, dbg_flags(1), os);
     CKL("k_scatter_al");
     return DSKGPU_OK;
 }
@@ -512,7 +512,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             if (W > 1) CK(ctx->abund2.ensure(slots * 4));
         }
         bool opt1 = opt_cap && npass == 1 && !ctx->opt1_off && !getenv("DSKGPU_NO_OPT1");
-        Opt1Spec o1{0u, 0u, sc + SC_OVF1};
+        Opt1Spec o1{0u, 0u, sc + SC_OVF1, nullptr};
         unsigned grid1 = 0;
         if (opt1 && !from_reads) ctx->h_nvalid = nkeys_in;
         if (opt1) {
@@ -534,6 +534,9 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             if (slice < 8 || cells * slice + tail >= 0xFFFF0000ull) opt1 = false;
             else {
                 o1.slice = (u32)slice; o1.cap1 = (u32)(slice * grid1);
+                CK(ctx->mat1.ensure((cells + 1) * 4));                      // here: keys per (bin, block) slice
+                o1.fill = ctx->mat1.as<u32>();
+                if (grid1 > 1024) opt1 = false;                             // the level-2 loader keeps at most 1024 slice bounds in LDS
                 CK(ctx->bufA.ensure((cells * slice + tail + 1) * sizeof(Key)));
             }
         }
@@ -598,9 +601,12 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 CKL("k_plan");
             }
             ctx->mark("plan2");
-            OptSpec os{opt_cap, ctx->mat2.as<u32>(), sc + SC_OVF2};
-            if ((rc = launch_scatter_al<W, 2, true>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
-                                                    ctx->bufB.as<Key>(), pl.d2, pl.P2, os))) return rc;
+            OptSpec os{opt_cap, ctx->mat2.as<u32>(), sc + SC_OVF2, opt1 ? o1.fill : nullptr, o1.slice, grid1};
+            if (opt1) rc = launch_scatter_al<W, 2, true, true>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
+                                                               ctx->bufB.as<Key>(), pl.d2, pl.P2, os);
+            else rc = launch_scatter_al<W, 2, true, false>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
+                                                           ctx->bufB.as<Key>(), pl.d2, pl.P2, os);
+            if (rc) return rc;
             ctx->mark("scatter2");
             fkeys = ctx->bufB.as<Key>();
             scratch = &ctx->bufA;

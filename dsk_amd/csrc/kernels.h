@@ -363,7 +363,7 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
     }
 }
 
-struct OptSpec { u32 cap; u32* subcnt; u32* ovf; };
+struct OptSpec { u32 cap; u32* subcnt; u32* ovf; const u32* fill; u32 slice, nsl; };   // fill/slice/nsl: SLICED input (below)
 __device__ __forceinline__ bool is_empty_key(u64 h) { return h == DSK_EMPTY; }
 template <int W> __device__ __forceinline__ bool is_empty_key(const KN<W>& h) {
     bool e = true;
@@ -379,10 +379,10 @@ template <> __device__ __forceinline__ KN<4> empty_key<4>() { KN<4> k; k.w[0] = 
 // OPT (one-word keys, level 1 from reads): "block-owned slices" -- no histogram pass.  Bin b owns the region
 // [b*cap1, (b+1)*cap1) of `out`, cut into one slice of `slice` keys per block (cap1 = gridDim.x * slice); a
 // block appends its keys of bin b to its own slice, the write cursors live in LDS for the whole launch.  The
-// slices are sized from the exact number of valid k-mers (k_count_valid) plus 6 % + 160 keys; what a block
-// leaves unused is filled with the DSK_EMPTY sentinel, which the level-2 scatter drops.  A slice that would
+// slices are sized from the exact number of valid k-mers (k_count_valid) plus 6 % + 160 keys; how much of
+// each slice holds keys goes to fill[b*grid + block], and the level-2 scatter (SLICED) reads exactly that much.  A slice that would
 // overflow raises *ovf (the host repeats the pass with the exact histogram + scan path).
-struct Opt1Spec { u32 slice, cap1; u32* ovf; };
+struct Opt1Spec { u32 slice, cap1; u32* ovf; u32* fill; };
 
 template <int W, int SRC, int MODE, bool OPT = false>
 __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
@@ -476,14 +476,13 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
             }
         }
     }
-    if (OPT) {      // pad the unused tail of every slice of this block; report a slice that was outgrown
+    if (OPT) {      // how much of each of its slices this block filled; report a slice that was outgrown
         lds_barrier();
         bool ovf = false;
-        const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        for (u32 b = wave; b < P; b += SC_NT / 64) {
-            const u32 end = b * o1.cap1 + (blockIdx.x + 1) * o1.slice, c = cur[b];
-            if (c > end) ovf = true;
-            for (u32 i = c + lane; i < end; i += 64) out[i] = empty_key<W>();
+        for (u32 b = threadIdx.x; b < P; b += SC_NT) {
+            const u32 beg = b * o1.cap1 + blockIdx.x * o1.slice, c = cur[b];
+            if (c > beg + o1.slice) ovf = true;
+            o1.fill[(u64)b * gridDim.x + blockIdx.x] = c > beg + o1.slice ? o1.slice : c - beg;
         }
         if (ovf) *o1.ovf = 1u;
     }
@@ -543,7 +542,8 @@ template <int W> struct ATile {
 };
 __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
     const size_t key = 8 * (size_t)W, keys = (size_t)SC_NT * (12 / W), G = 8 / W;
-    return keys * key + (size_t)P * (G - 1) * key + (size_t)(P + 1) * 4 + (size_t)P * 4 + (size_t)P * 12 + (size_t)P * 2 + 20 * 4 + 32;
+    return keys * key + (size_t)P * (G - 1) * key + (size_t)(P + 1) * 4 + (size_t)P * 4 + (size_t)P * 12 + (size_t)P * 2 + 20 * 4 + 32
+           + 1032 * 4;     // + prefix sums of up to 1024 slice fills (SLICED input)
 }
 
 // OPT (one-word keys, level 2): "segment-owned" variant that needs NO histogram pass.  A chunk is a whole
@@ -553,7 +553,11 @@ __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
 // (never read: subcnt[q] = number of real keys of the region).  A sub-bin that would
 // outgrow its region raises *ovf (writes wrap to the region start: the result is discarded and the host
 // repeats the level with the exact histogram + scan path).  flat_base of a chunk = s*P.
-template <int W, int MODE, bool OPT = false>
+// SLICED (with OPT): the input segment is a level-1 bin region written as block-owned slices -- nsl slices of
+// `slice` keys, of which the first fill[s*nsl + i] hold keys.  The loader walks the slices in order and skips their
+// unused tails: a thread's keys of consecutive tiles are monotone in the logical stream, so it only keeps the bounds
+// of its current slice in registers and touches the LDS prefix array when it crosses into the next slice.
+template <int W, int MODE, bool OPT = false, bool SLICED = false>
 __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>::T* __restrict__ keys,
                                                          const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
                                                          const u32* __restrict__ scanned,
@@ -572,6 +576,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
     uint3* rec = reinterpret_cast<uint3*>(pos + P);                   // P
     u16* rn = reinterpret_cast<u16*>(rec + P);                        // P   carry fill after this tile (persistent)
     u32* wsum = reinterpret_cast<u32*>(smem + ((reinterpret_cast<char*>(rn + P) - smem + 3) & ~size_t(3)));
+    u32* pre = wsum + 20;                                             // SLICED: nsl + 1 prefix sums of the slice fills
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 gi = tid / G, gl = tid % G;
     const u32 nchunks = *d_nchunks;
@@ -584,17 +589,44 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
         lds_barrier();
         for (u32 b = tid; b < P; b += SC_NT) { pos[b] = OPT ? b * os.cap : scanned[d.flat_base + (u64)b * d.stride]; cnt[b] = 0; rn[b] = 0; }
         if (tid == 0) cnt[P] = 0;
+        u64 lbeg = d.begin, lend = d.end;                             // range of the (logical) key stream of this chunk
+        u32 sg = 0, slo = 0, shi = 0;                                 // SLICED: this thread's current slice and its logical bounds
+        if (SLICED) {
+            if (wave == 0) {                                          // exclusive prefix of the slice fills (one wave, nsl <= 1024)
+                const u32* f = os.fill + (u64)(d.flat_base / P) * os.nsl;
+                u32 run = 0;
+                for (u32 i0 = 0; i0 < os.nsl; i0 += 64) {
+                    const u32 i = i0 + lane;
+                    const u32 v = i < os.nsl ? f[i] : 0u;
+                    u32 inc = v;
+#pragma unroll
+                    for (int dd = 1; dd < 64; dd <<= 1) { const u32 t = __shfl_up(inc, dd); if (lane >= dd) inc += t; }
+                    if (i < os.nsl) pre[i] = run + inc - v;
+                    run += __shfl(inc, 63);
+                }
+                if (lane == 0) pre[os.nsl] = run;
+            }
+            lds_barrier();
+            lbeg = 0; lend = pre[os.nsl];
+            shi = pre[1];
+        }
         Key h[KPT]; u32 vm = 0;       // one register set: the next tile is loaded as soon as the stage writes have consumed this one
         auto load = [&](u64 k0, Key (&hh)[KPT]) -> u32 {
-            const Key* base = keys + k0;
-            const u64 left = d.end - k0;
+            const Key* base = keys + (SLICED ? d.begin : k0);
+            const u64 left = lend - k0;
             const u32 n = left < (u64)TKEYS ? (u32)left : (u32)TKEYS;
             u32 m = 0;
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const u32 o = tid + (u32)j * SC_NT;
                 const bool ok = o < n;
-                hh[j] = base[ok ? o : n - 1];
+                if (!SLICED) hh[j] = base[ok ? o : n - 1];
+                else {
+                    const u32 i = (u32)k0 + (ok ? o : n - 1);                 // logical index, monotone over j and over tiles for ok lanes
+                    while (i >= shi && sg + 1 < os.nsl) { ++sg; slo = shi; shi = pre[sg + 1]; }
+                    const u32 off = i >= slo ? i - slo : 0u;                  // (a clamped, not-ok lane may point below its slice: any valid address will do)
+                    hh[j] = base[(u64)sg * os.slice + off];
+                }
                 m |= (ok ? 1u : 0u) << j;
             }
             return m;
@@ -656,7 +688,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                 const u32 dj = rk[j] >> 16;
                 if (dj < P) stage[rec[dj].z + (rk[j] & 0xFFFFu)] = h[j];
             }
-            if (tnext < d.end) vm = load(tnext, h);       // HBM reads of the next tile fly under the write-out phase
+            if (tnext < lend) vm = load(tnext, h);        // HBM reads of the next tile fly under the write-out phase
             lds_barrier();
             // ---- write-out + carry refresh, one lane group per bin
             if (!(dbg & 4u))
@@ -688,9 +720,9 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
             }
             // no barrier: the next tile's rank phase only touches cnt; its barriers order the rest
         };
-        if (d.begin < d.end) vm = load(d.begin, h);
+        if (lbeg < lend) vm = load(lbeg, h);
         lds_barrier();
-        for (u64 t0 = d.begin; t0 < d.end; t0 += (u64)TKEYS) process(t0 + TKEYS);
+        for (u64 t0 = lbeg; t0 < lend; t0 += (u64)TKEYS) process(t0 + TKEYS);
         // ---- end of chunk: flush what is left in the carries (one partial group per bin)
         lds_barrier();
         for (u32 b = gi; b < P; b += NGRP) {
