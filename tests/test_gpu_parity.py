@@ -280,6 +280,38 @@ def test_histogram_free_scatters_and_their_fallback(oracle, dev, monkeypatch):
     assert "hist2" in stages and st["n_retries"] == 0
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_randomized_two_level_inputs(oracle, dev, seed):
+    """Seeded random inputs big enough for two partition levels (the histogram-free scatters), varying k (all key
+    widths), read length, coverage, invalid-base rate, read order (shuffled / sorted by position: duplicates cluster
+    in a block's chunks) and repeat content.  Whatever path the engine takes (slices, regions or the exact fallback)
+    the rows and the histogram must equal the oracle's."""
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([15, 21, 27, 31, 32, 33, 41, 55, 63, 64, 70, 96]))
+    rl = int(rng.choice([max(k + 5, 80), 150, 251, 1000]))
+    n_kmers = int(rng.choice([3_000_000, 5_000_000]))                     # > 1024 sub-partitions for every width
+    n_reads = n_kmers // (rl - k + 1) + 1
+    cov = float(rng.choice([1.5, 8.0, 40.0]))
+    glen = max(1000, int(n_reads * rl / cov))
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=glen)
+    if rng.random() < 0.4:                                                # a tandem repeat: heavy k-mers
+        unit = genome[:37].copy(); genome[glen // 2: glen // 2 + 37 * 400] = np.tile(unit, 400)[: min(37 * 400, glen - glen // 2)]
+    starts = rng.integers(0, max(1, glen - rl), size=n_reads)
+    if rng.random() < 0.5:
+        starts.sort()                                                     # position-sorted reads
+    idx = starts[:, None] + np.arange(rl)[None, :]
+    reads = genome[np.minimum(idx, glen - 1)]
+    bad = rng.random(reads.shape) < float(rng.choice([0.0, 0.001, 0.01]))
+    reads = np.where(bad, np.uint8(ord("N")), reads)
+    flip = rng.random(n_reads) < 0.5                                      # reverse-complement half of the reads
+    comp = np.zeros(256, np.uint8); comp[list(b"ACGTN")] = list(b"TGCAN")
+    reads[flip] = comp[reads[flip]][:, ::-1]
+    stream = np.concatenate([reads, np.full((n_reads, 1), ord("\n"), np.uint8)], axis=1).reshape(-1)
+    amin = int(rng.choice([1, 2, 3]))
+    st = check_against_oracle(oracle, stream, k, dev, amin=amin)
+    assert st["n_levels"] == 2
+
+
 @pytest.mark.parametrize("k", [33, 47, 63, 64])
 def test_two_word_kmers_golden(oracle, golden_dir, dev, k):
     s, _ = oracle.load_bank(os.path.join(golden_dir, "read50x_ref10K_e001.fasta.gz"))
