@@ -48,7 +48,9 @@ struct DevBuf {
 };
 
 enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_OVF2, SC_OVF1, SC_COUNT = 12 };
-#define SORT_TOP_BITS 40u
+#ifndef SORT_TOP_BITS
+#define SORT_TOP_BITS 32u      // 4 radix passes; 40 bits (5 passes) cost 0.3 ms more on 43 M rows, the in-place run fix-up absorbs the extra ties
+#endif
 
 struct Stage { const char* name; hipEvent_t ev; };
 
@@ -417,7 +419,7 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     size_t tmp = 0;
     if (W == 1) {
         const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
-        // Sort on the top SORT_TOP_BITS of the value only (5 radix passes instead of 8), then fix the
+        // Sort on the top SORT_TOP_BITS of the value only (4 radix passes instead of 8), then fix the
         // (rare, short) runs of equal prefix; exactness is kept by the full-width fallback in finish_sort().
         // (k = 32 uses all 64 bits: rocPRIM's partial-range sort misbehaved with end_bit == 64 on ROCm 7.2, so it sorts full width)
         const unsigned begin_bit = (end_bit > SORT_TOP_BITS && end_bit < 64u && !getenv("DSKGPU_FULLSORT")) ? end_bit - SORT_TOP_BITS : 0u;
@@ -438,7 +440,7 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
         ctx->res_w[0] = ctx->srt_w[0].as<u64>(); ctx->res_ab = ctx->srt_ab.as<u32>();
         return DSKGPU_OK;
     }
-    // multi-word rows: radix sort of (top 63 bits of the value, row index) on the key's top 40 bits, gather,
+    // multi-word rows: radix sort of (top 63 bits of the value, row index) on the key's top 32 bits, gather,
     // then the runs of equal prefix are ordered in place by full comparison (exact fallback: sort_rows_full_multiword)
     if (!getenv("DSKGPU_FULLSORT") && 2u * ctx->cfg.kmer_size > 64u) {
         CK(ctx->srt_k.ensure(n * 8)); CK(ctx->s_val.ensure(n * 8));
@@ -765,7 +767,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         if (npass == 1) CK(hipMemcpyAsync(ctx->hist.data(), ctx->ghist.p, ctx->hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
         if (W == 1 && ctx->sort_partial && tot_rows && ctx->h_back[3]) {
-            // a run of equal 40-bit prefixes was too long for the in-place fix-up: sort full width
+            // a run of equal 32-bit prefixes was too long for the in-place fix-up: sort full width
             // (srt_* holds a permutation of the rows; sort it back into out_*)
             size_t tmp = 0;
             const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);

@@ -1278,7 +1278,7 @@ __global__ __launch_bounds__(256) void k_fix_runs(u64* __restrict__ lo, u32* __r
 
 // Multi-word rows: the same two-step order.  k_top_key builds the top 63 bits of every value (bit 63 stays clear:
 // rocPRIM's partial-range sort misbehaves when end_bit == 64) next to the identity permutation; after a radix sort
-// of (key, index) on the key's top 40 bits and a gather of the rows, k_fix_runs_multi orders the runs of equal
+// of (key, index) on the key's top 32 bits and a gather of the rows, k_fix_runs_multi orders the runs of equal
 // prefix by full multi-word comparison.
 template <int W>
 __global__ __launch_bounds__(256) void k_top_key(RowsIn rows, u64 n, int bits, u64* __restrict__ key, u32* __restrict__ idx) {

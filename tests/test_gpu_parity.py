@@ -475,8 +475,8 @@ def test_minimizers_match_oracle(oracle, golden_dir, dev, k, m):
 
 
 def test_row_sort_fallback_on_shared_prefixes(oracle, dev):
-    """The row sort orders the top 40 bits with a radix sort and fixes runs of equal prefix in place;
-    more than 32 rows sharing their first 20 bases must take the exact full-width fallback."""
+    """The row sort orders the top 32 bits with a radix sort and fixes runs of equal prefix in place;
+    more than 32 rows sharing their first 16 bases (here: 20) must take the exact full-width fallback."""
     from dsk_amd import KmerCounter
     rng = np.random.default_rng(11)
     tails = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(300, 11))
@@ -501,7 +501,7 @@ def test_row_sort_fallback_on_shared_prefixes(oracle, dev):
 
 @pytest.mark.parametrize("k", [40, 63, 70, 100])
 def test_multiword_row_sort_prefix_runs_and_fallback(oracle, dev, k):
-    """Multi-word rows use the same two-step order (radix sort on the top 40 bits of the value, runs fixed in place by
+    """Multi-word rows use the same two-step order (radix sort on the top 32 bits of the value, runs fixed in place by
     full comparison): short runs of a shared 20-base prefix stay on that path, long ones take the full-width fallback."""
     rng = np.random.default_rng(12)
     tails = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(300, k - 20))
