@@ -192,6 +192,12 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(cand[dom], 4)}
+            # the whole step against the same roof: algorithmic bytes of this two-level design (bases read as
+            # ASCII + 2-bit, every key written and read once per level, solid rows written) over the wall time of a step
+            W = 8 if args.kmer_size <= 32 else 16 if args.kmer_size <= 64 else 32
+            step_bytes = n_bytes * 1.375 + local_kmers * (4 * W) + st["n_solid"] * (W + 4)
+            roofline["step_algorithmic_bytes"] = int(step_bytes)
+            roofline["step_frac"] = round(step_bytes / per_step / 1e9 / HBM_PEAK_GBS, 4)
         out = {
             "metric": "distinct k-mers counted/sec (whole node), k=%d" % args.kmer_size,
             "value": n_distinct / per_step,
