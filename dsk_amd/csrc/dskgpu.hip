@@ -86,6 +86,8 @@ struct dskgpu_ctx {
     SkParams sk_sp{};
     DevBuf sk_sums, sk_cbase, sk_keys;
     std::vector<u32> h_sk_sums; std::vector<u64> h_sk_cbase;
+    // records handed to dskgpu_mg_count: the level-1 scatter reads them directly (SRC 2); expanded lazily for the exact path
+    const u64* rec_src = nullptr; u64 rec_n = 0; u64 rec_nch = 0, rec_rpc = 0; bool rec_expanded = false;
     u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0; u64 h_nvalid = 0;
     bool sentinel_ok = true;       // the all-ones key is not the mixed form of a canonical k-mer of this k (checked at create)
     bool opt1_off = false;         // same for the histogram-free level-1 scatter (block-owned slices)
@@ -239,6 +241,23 @@ int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chu
     CKL("k_scatter");
     return DSKGPU_OK;
 }
+// super-k-mer records as the source of the histogram-free level-1 scatter (one- and two-word keys)
+template <int W>
+int launch_scatter_rec(dskgpu_ctx* ctx, const ChunkDesc* descs, const u32* d_nch, u64 max_chunks, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1) {
+    const size_t lds = scatter_lds(W, P);
+    const unsigned grid = scatter_grid(ctx, W, P, max_chunks);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter<W, 2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_scatter<W, 2, 1, true>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->rec_src, (const u32*)nullptr,
+                       (const typename KeyT<W>::T*)nullptr, descs, d_nch, (const u32*)nullptr, out, (int)ctx->cfg.kmer_size, ds, P, 0u, o1);
+    CKL("k_scatter(records)");
+    return DSKGPU_OK;
+}
+template <> int launch_scatter_rec<4>(dskgpu_ctx*, const ChunkDesc*, const u32*, u64, KN<4>*, DigitSpec, u32, Opt1Spec) { return DSKGPU_E_STATE; }
+
 // key-array source with aligned write-out (k_scatter_al) when its LDS footprint fits one CU
 template <int W, int MODE, bool OPT = false, bool SLICED = false>
 int launch_scatter_al(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
@@ -475,6 +494,21 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     return sort_rows_full_multiword(ctx, n);
 }
 
+// records -> dense key array (only when the level-1 scatter cannot read the records itself: exact / multi-pass path)
+template <int W>
+int expand_records(dskgpu_ctx* ctx, u64 total) {
+    typedef typename KeyT<W>::T Key;
+    if (ctx->rec_expanded) return DSKGPU_OK;
+    CK(ctx->sk_keys.ensure((total + 1) * sizeof(Key)));
+    hipLaunchKernelGGL(k_sk_expand<W>, dim3((unsigned)ctx->rec_nch), dim3(SKX_NT), 0, ctx->stream, ctx->rec_src, ctx->rec_n, ctx->sk_sp.R,
+                       (int)ctx->cfg.kmer_size, (u32)ctx->rec_rpc, ctx->sk_cbase.as<u64>(), ctx->sk_keys.as<Key>());
+    CKL("k_sk_expand");
+    ctx->rec_expanded = true;
+    ctx->mark("mg_expand");
+    return DSKGPU_OK;
+}
+template <> int expand_records<4>(dskgpu_ctx*, u64) { return DSKGPU_E_STATE; }      // records carry k <= 64 only
+
 // One pass: partition + count the keys of pass `pass` (of `npass`) and leave its solid rows
 // (unsorted) in out_w[0]/out_w[1]/out_ab.  Returns PASS_TOO_BIG when the pass holds more keys than `cap`.
 #define PASS_TOO_BIG 1000
@@ -492,12 +526,25 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         // ---------------- level 1
         u32 nch1 = 0;
         const u64 max_chunks1 = (u64)ctx->num_cu * 8;
-        if (from_reads) build_descs1(ctx, nwords, Tile<W>::WORDS, max_chunks1, &nch1);
-        else build_descs1(ctx, nkeys_in, Tile<W>::KEYS, max_chunks1, &nch1);
-        const u64 M1 = (u64)pl.P1 * nch1;
-        CK(ctx->descs1.ensure(ctx->h_descs1.size() * sizeof(ChunkDesc)));
-        CK(hipMemcpyAsync(ctx->descs1.p, ctx->h_descs1.data(), ctx->h_descs1.size() * sizeof(ChunkDesc),
-                          hipMemcpyHostToDevice, ctx->stream));
+        // key source: the encoded reads, a key array, or (multi-GPU receive side) super-k-mer records that the
+        // histogram-free level-1 scatter reads directly; any other path expands them to a key array first
+        bool from_rec = !from_reads && d_keys_in == nullptr;
+        auto upload_descs1 = [&]() -> int {
+            if (from_reads) build_descs1(ctx, nwords, Tile<W>::WORDS, max_chunks1, &nch1);
+            else if (from_rec) build_descs1(ctx, ctx->rec_n, Tile<W>::KEYS / 8, max_chunks1, &nch1);
+            else build_descs1(ctx, nkeys_in, Tile<W>::KEYS, max_chunks1, &nch1);
+            CK(ctx->descs1.ensure(ctx->h_descs1.size() * sizeof(ChunkDesc)));
+            CK(hipMemcpyAsync(ctx->descs1.p, ctx->h_descs1.data(), ctx->h_descs1.size() * sizeof(ChunkDesc),
+                              hipMemcpyHostToDevice, ctx->stream));
+            return DSKGPU_OK;
+        };
+        auto records_to_keys = [&]() -> int {        // leave the records path: expand once, then it is a key array
+            int e = expand_records<W>(ctx, nkeys_in);
+            if (e) return e;
+            d_keys_in = ctx->sk_keys.as<Key>(); from_rec = false;
+            return upload_descs1();
+        };
+        { int e = upload_descs1(); if (e) return e; }
         // One-word keys straight from the reads, one pass, two levels: both scatters run without a histogram
         // pass (block-owned slices at level 1, segment-owned regions at level 2); any overflow sends the whole
         // attempt back through the exact histogram + scan path.
@@ -514,7 +561,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             if (W > 1) CK(ctx->abund2.ensure(slots * 4));
         }
         bool opt1 = opt_cap && npass == 1 && !ctx->opt1_off && !getenv("DSKGPU_NO_OPT1");
-        Opt1Spec o1{0u, 0u, sc + SC_OVF1, nullptr};
+        if (from_rec && (!opt1 || W > 2 || getenv("DSKGPU_NO_RECSRC"))) { int e = records_to_keys(); if (e) return e; }
+        Opt1Spec o1{0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R};
         unsigned grid1 = 0;
         if (opt1 && !from_reads) ctx->h_nvalid = nkeys_in;
         if (opt1) {
@@ -542,6 +590,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 CK(ctx->bufA.ensure((cells * slice + tail + 1) * sizeof(Key)));
             }
         }
+        if (from_rec && !opt1) { int e = records_to_keys(); if (e) return e; }
+        const u64 M1 = (u64)pl.P1 * nch1;
         u32* h_sc = ctx->h_sc;
         std::memset(h_sc, 0, sizeof(ctx->h_sc));
         h_sc[SC_NCH1] = nch1; h_sc[SC_MLEN1] = (u32)M1; h_sc[SC_F] = pl.F;
@@ -555,6 +605,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         const ChunkDesc* dd1 = ctx->descs1.as<ChunkDesc>();
         if (opt1) {
             if (from_reads) rc = launch_scatter_m<W, 0, 1, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+            else if (from_rec) rc = launch_scatter_rec<W>(ctx, dd1, sc + SC_NCH1, nch1, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
             else rc = launch_scatter_m<W, 1, 1, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
             if (rc) return rc;
             ctx->mark("scatter1");
@@ -923,18 +974,21 @@ int sk_count(dskgpu_ctx* ctx, const u64* d_rec, u64 recv_words) {
         CK(hipStreamSynchronize(ctx->stream));
         for (u64 c = 0; c < nch; ++c) { ctx->h_sk_cbase[c] = total; total += ctx->h_sk_sums[c]; }
         CK(hipMemcpyAsync(ctx->sk_cbase.p, ctx->h_sk_cbase.data(), nch * 8, hipMemcpyHostToDevice, ctx->stream));
-        CK(ctx->sk_keys.ensure((total + 1) * sizeof(Key)));
-        hipLaunchKernelGGL(k_sk_expand<W>, dim3((unsigned)nch), dim3(SKX_NT), 0, ctx->stream, d_rec, nrec, R, (int)ctx->cfg.kmer_size, (u32)rpc,
-                           ctx->sk_cbase.as<u64>(), ctx->sk_keys.as<Key>());
-        CKL("k_sk_expand");
+        ctx->rec_src = d_rec; ctx->rec_n = nrec; ctx->rec_nch = nch; ctx->rec_rpc = rpc; ctx->rec_expanded = false;
     } else {
+        ctx->rec_src = nullptr; ctx->rec_n = 0;
         CK(ctx->sk_keys.ensure(sizeof(Key)));
     }
-    ctx->mark("mg_expand");
+    ctx->mark("mg_sizes");
     CK(hipStreamSynchronize(ctx->stream));
     ctx->resolve_marks();
-    return run_pipeline<W>(ctx, false, ctx->sk_keys.as<Key>(), total);
+    if (!ctx->rec_src) return run_pipeline<W>(ctx, false, ctx->sk_keys.as<Key>(), 0);
+    const int rc = run_pipeline<W>(ctx, false, nullptr, total);      // nullptr: keys come from ctx->rec_src
+    ctx->rec_src = nullptr;
+    return rc;
 }
+
+
 
 }  // namespace
 

@@ -376,13 +376,88 @@ template <> __device__ __forceinline__ u64 empty_key<1>() { return DSK_EMPTY; }
 template <> __device__ __forceinline__ K2 empty_key<2>() { K2 k; k.w[0] = k.w[1] = DSK_EMPTY; return k; }
 template <> __device__ __forceinline__ KN<4> empty_key<4>() { KN<4> k; k.w[0] = k.w[1] = k.w[2] = k.w[3] = DSK_EMPTY; return k; }
 
+
+// SRC 2: super-k-mer records (superkmer.h) as the key source of the level-1 scatter on the multi-GPU receive side:
+// records -> mixed keys straight into the tile registers, no expanded key array in HBM.  A tile takes as many of
+// the next Tile<W>::KEYS / 8 records as fit Tile<W>::KEYS keys (a record holds <= 16), stages them in the (not yet
+// used) key staging area together with a slot map (slot -> record, k-mer index), and every thread then builds its
+// KPT keys with a funnel shift + rev_pairs.  Returns the validity mask; *taken = records consumed.
+__device__ __forceinline__ u64 sk_key1(const u64* r, int j, int k);
+__device__ __forceinline__ K2 sk_key2(const u64* r, int j, int k);
+__device__ __forceinline__ void sk_key(const u64* r, int j, int k, u64& out) { out = sk_key1(r, j, k); }
+__device__ __forceinline__ void sk_key(const u64* r, int j, int k, K2& out) { out = sk_key2(r, j, k); }
+template <int W> __device__ __forceinline__ void sk_key(const u64*, int, int, KN<W>&) {}      // (records carry k <= 64 only)
+
+template <int W>
+__device__ __forceinline__ u32 tile_keys_records(const u64* __restrict__ rec, u32 R, u64 r0, u64 rend, int k,
+                                                 typename KeyT<W>::T (&h)[Tile<W>::KPT], char* scratch, u32* wsum, u32* taken) {
+    constexpr int KPT = Tile<W>::KPT, KEYS = Tile<W>::KEYS, NR = KEYS / 8, RPT = NR / SC_NT;
+    u64* srec = reinterpret_cast<u64*>(scratch);                             // NR * 3 words
+    unsigned short* smap = reinterpret_cast<unsigned short*>(srec + (size_t)NR * 3);   // KEYS entries
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    lds_barrier();                                                           // the previous tile's write-out is done with the staging area
+    u32 n[RPT], s = 0;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const u32 l = (u32)tid * RPT + u;
+        const u64 r = r0 + l;
+        n[u] = 0;
+        if (r < rend) {
+            const u64* p = rec + r * R;
+            const u64 a = p[0], b = p[1], c = (R == 3) ? p[2] : 0ull;
+            srec[l * 3] = a; srec[l * 3 + 1] = b; srec[l * 3 + 2] = c;
+            n[u] = (u32)((R == 3 ? c : b) & 0xFFu);
+        }
+        s += n[u];
+    }
+    u32 inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[wave] = inc;
+    lds_barrier();
+    u32 off = inc - s;
+#pragma unroll
+    for (int x = 0; x < SC_NT / 64; ++x) { const u32 v = wsum[x]; if (x < wave) off += v; }
+    // records are taken in order while their keys still fit the tile; (taken << 16 | keys) summed over the block
+    u32 mine = 0, run = off;
+    bool fit[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const u64 r = r0 + (u64)tid * RPT + u;
+        fit[u] = r < rend && run + n[u] <= (u32)KEYS;
+        if (fit[u]) { mine += (1u << 16) | n[u]; for (u32 j = 0; j < n[u]; ++j) smap[run + j] = (unsigned short)((((u32)tid * RPT + u) << 4) | j); }
+        run += n[u];
+    }
+    lds_barrier();                                                           // everyone has read wsum: reuse it for the second sum
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d);
+    if (lane == 0) wsum[wave] = mine;
+    lds_barrier();
+    u32 tot = 0;
+#pragma unroll
+    for (int x = 0; x < SC_NT / 64; ++x) tot += wsum[x];
+    *taken = tot >> 16;
+    const u32 nkeys = tot & 0xFFFFu;
+    u32 vm = 0;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const u32 slot = (u32)tid + (u32)j * SC_NT;
+        if (slot < nkeys) {
+            const u32 e = smap[slot];
+            sk_key(srec + (e >> 4) * 3, (int)(e & 15u), k, h[j]);
+            vm |= 1u << j;
+        }
+    }
+    return vm;
+}
+
 // OPT (one-word keys, level 1 from reads): "block-owned slices" -- no histogram pass.  Bin b owns the region
 // [b*cap1, (b+1)*cap1) of `out`, cut into one slice of `slice` keys per block (cap1 = gridDim.x * slice); a
 // block appends its keys of bin b to its own slice, the write cursors live in LDS for the whole launch.  The
 // slices are sized from the exact number of valid k-mers (k_count_valid) plus 6 % + 160 keys; how much of
 // each slice holds keys goes to fill[b*grid + block], and the level-2 scatter (SLICED) reads exactly that much.  A slice that would
 // overflow raises *ovf (the host repeats the pass with the exact histogram + scan path).
-struct Opt1Spec { u32 slice, cap1; u32* ovf; u32* fill; };
+struct Opt1Spec { u32 slice, cap1; u32* ovf; u32* fill; u32 R; };      // R: words per super-k-mer record (SRC 2)
 
 #ifndef DSK_ABLATE
 #define DSK_ABLATE 0     // 1 (make EXTRA=-DDSK_ABLATE=1): the timing-ablation switches (DSKGPU_DBG1/2 bits) are live; 0: compiled out (-0.1 ms)
@@ -464,7 +539,14 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
         };
         if (SRC == 1 && d.begin < d.end) vma = tile_keys_array<W>(keys, d.begin, d.end, ha);
         lds_barrier();
-        if (SRC == 0) {
+        if constexpr (SRC == 2) {              // records: `packed` is the record array, the chunk range is in records
+            for (u64 r0 = d.begin; r0 < d.end;) {
+                u32 taken = 0;
+                vma = tile_keys_records<W>(packed, o1.R, r0, d.end, k, ha, smem, wsum, &taken);
+                process(ha, vma);
+                r0 += taken ? taken : 1u;
+            }
+        } else if constexpr (SRC == 0) {
             for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
                 vma = tile_keys_reads(packed, inval, t0, d.end, k, ha);
                 process(ha, vma);
