@@ -1,4 +1,4 @@
-"""Development helper: multi-GPU path emulated on one device, for a sweep of (world, k)."""
+"""Multi-GPU path emulated on one device (several contexts, exchange by hand) for a sweep of (world, k), against the oracle."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

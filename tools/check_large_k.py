@@ -1,4 +1,4 @@
-"""Development helper: device count for k > 64 against the oracle."""
+"""Enumerate + count on the device for k around the key-width borders (63..128), against the oracle."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
