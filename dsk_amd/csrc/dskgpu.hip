@@ -586,7 +586,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 o1.slice = (u32)slice; o1.cap1 = (u32)(slice * grid1);
                 CK(ctx->mat1.ensure((cells + 1) * 4));                      // here: keys per (bin, block) slice
                 o1.fill = ctx->mat1.as<u32>();
-                if (grid1 > 1024) opt1 = false;                             // the level-2 loader keeps at most 1024 slice bounds in LDS
+                if (grid1 + 1 > SLICED_MAX) opt1 = false;                   // the level-2 loader keeps the slice bounds in LDS
                 CK(ctx->bufA.ensure((cells * slice + tail + 1) * sizeof(Key)));
             }
         }

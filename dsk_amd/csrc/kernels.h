@@ -626,10 +626,11 @@ template <int W> struct ATile {
     static constexpr int KPT = 12 / W;           // 12288 one-word / 6144 two-word keys per tile = 96 KB
     static constexpr int KEYS = SC_NT * KPT;
 };
+#define SLICED_MAX 320      // most level-1 slices per bin (= blocks of the level-1 launch: 256 CUs x 1) the level-2 loader can walk
 __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
     const size_t key = 8 * (size_t)W, keys = (size_t)SC_NT * (12 / W), G = 8 / W;
     return keys * key + (size_t)P * (G - 1) * key + (size_t)(P + 1) * 4 + (size_t)P * 4 + (size_t)P * 12 + (size_t)P * 2 + 20 * 4 + 32
-           + 1032 * 4;     // + prefix sums of up to 1024 slice fills (SLICED input)
+           + SLICED_MAX * 4 + 16;     // + prefix sums of the slice fills (SLICED input)
 }
 
 // OPT (one-word keys, level 2): "segment-owned" variant that needs NO histogram pass.  A chunk is a whole
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
         u64 lbeg = d.begin, lend = d.end;                             // range of the (logical) key stream of this chunk
         u32 sg = 0, slo = 0, shi = 0;                                 // SLICED: this thread's current slice and its logical bounds
         if (SLICED) {
-            if (wave == 0) {                                          // exclusive prefix of the slice fills (one wave, nsl <= 1024)
+            if (wave == 0) {                                          // exclusive prefix of the slice fills (one wave, nsl <= SLICED_MAX)
                 const u32* f = os.fill + (u64)(d.flat_base / P) * os.nsl;
                 u32 run = 0;
                 for (u32 i0 = 0; i0 < os.nsl; i0 += 64) {

@@ -37,13 +37,12 @@ __host__ __device__ __forceinline__ u64 kunmix(u64 x) {
     x ^= x >> 33; return x;
 }
 
-// Multi-word keys (k in 33..128): KN<W>, word 0 least significant.  The mixer is an unbalanced Feistel
-// chain over the 64-bit mixer -- every word is folded into the next lower one, the lowest back into the
-// top one -- still a bijection on the W words; digits/slots are taken from the mixed top word.
+// Multi-word keys (k in 33..128): KN<W>, word 0 least significant; digits/slots are taken from the mixed top word.
 template <int W> struct KN { u64 w[W]; };
 typedef KN<2> K2;
 #define DSK_GOLD 0x9e3779b97f4a7c15ULL
 
+#ifdef DSK_MIXN_CHAIN     // the earlier form: an unbalanced Feistel chain, W + 1 rounds of the 64-bit mixer
 template <int W>
 __host__ __device__ __forceinline__ void kmixN(KN<W>& x) {
 #pragma unroll
@@ -58,6 +57,29 @@ __host__ __device__ __forceinline__ void kunmixN(KN<W>& x) {
 #pragma unroll
     for (int i = 0; i <= W - 2; ++i) x.w[i] ^= kmix(x.w[i + 1] + (u64)(W - 2 - i) * DSK_GOLD);
 }
+#else
+// Only the top word has to be mixed: radix digits, table slot and owner are bit fields of it, the other words are
+// just compared for equality.  top' = kmix(top ^ sum_i w[i] * A_i) with odd multipliers (multilinear hash of the
+// lower words folded into the top one, then the 64-bit finalizer): a bijection on the W words for any fold,
+// W + 1 multiplies instead of 2 (W + 1).
+__host__ __device__ __forceinline__ u64 kfold_mult(int i) {
+    return i == 0 ? 0x9e3779b97f4a7c15ULL : i == 1 ? 0xc2b2ae3d27d4eb4fULL : 0x165667b19e3779f9ULL;
+}
+template <int W>
+__host__ __device__ __forceinline__ void kmixN(KN<W>& x) {
+    u64 t = 0;
+#pragma unroll
+    for (int i = 0; i < W - 1; ++i) t += x.w[i] * kfold_mult(i);
+    x.w[W - 1] = kmix(x.w[W - 1] ^ t);
+}
+template <int W>
+__host__ __device__ __forceinline__ void kunmixN(KN<W>& x) {
+    u64 t = 0;
+#pragma unroll
+    for (int i = 0; i < W - 1; ++i) t += x.w[i] * kfold_mult(i);
+    x.w[W - 1] = kunmix(x.w[W - 1]) ^ t;
+}
+#endif
 template <int W>
 __host__ __device__ __forceinline__ bool key_eq(const KN<W>& a, const KN<W>& b) {
     bool e = true;
