@@ -224,6 +224,20 @@ __device__ __forceinline__ u32 gen_kmersN(const u64* __restrict__ packed, const 
         for (int i = 0; i < W; ++i) r[i] ^= (0xAAAAAAAAAAAAAAAAULL & msk[i]);
     }
     const int rcs = 2 * k - 2, rw = rcs >> 6, rb = rcs & 63;   // where the newest complement enters
+    // valid bases that end just before base t0 of this word: the bases of this word below t0, then whole words back
+    int run = 0;
+    {
+        const u32 head = t0 ? (iv[0] >> (32 - t0)) : 0u;         // invalid bits of bases 0..t0-1 (bit i <-> base t0-1-i)
+        if (t0 && head) run = __builtin_ctz(head);
+        else {
+            run = t0;
+#pragma unroll
+            for (int q = 1; q <= W; ++q) {
+                if (run >= k) break;
+                if (iv[q] == 0u) run += 32; else { run += __builtin_ctz(iv[q]); break; }
+            }
+        }
+    }
     u32 vmask = 0;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -242,20 +256,9 @@ __device__ __forceinline__ u32 gen_kmersN(const u64* __restrict__ packed, const 
         for (int i = W - 1; i >= 0; --i) { if (!decided && f[i] != r[i]) { lt = f[i] < r[i]; decided = true; } }
 #pragma unroll
         for (int i = 0; i < W; ++i) canon[j].w[i] = lt ? f[i] : r[i];
-        // validity: frame base index e = 32W + t ends the window [e-k+1, e]; word q holds bases [32(W-q), 32(W-q)+31]
-        const int e = 32 * W + t;
-        u32 bad = 0;
-#pragma unroll
-        for (int q = 0; q <= W; ++q) {
-            const int b0 = 32 * (W - q);
-            const int lo = (e - k + 1) > b0 ? (e - k + 1) : b0;
-            const int hi = e < b0 + 31 ? e : b0 + 31;
-            if (lo <= hi) {
-                const int nb = hi - lo + 1;
-                const u32 m = (nb == 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)) << (31 - (hi - b0));
-                bad |= iv[q] & m;
-            }
-        }
+        // validity: `run` = valid bases ending at this one (capped walk-back at the start, then one update per base)
+        run = ((iv[0] >> (31 - t)) & 1u) ? 0 : run + 1;
+        const bool bad = run < k;
         if (!bad) vmask |= (1u << j);
     }
     return vmask;
