@@ -560,9 +560,9 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             CK(ctx->bufA.ensure(std::max<u64>(W == 1 ? slots * 4 : slots * sizeof(Key), (cap + 1) * sizeof(Key))));
             if (W > 1) CK(ctx->abund2.ensure(slots * 4));
         }
-        bool opt1 = opt_cap && npass == 1 && !ctx->opt1_off && !getenv("DSKGPU_NO_OPT1");
+        bool opt1 = opt_cap && !ctx->opt1_off && !getenv("DSKGPU_NO_OPT1") && (npass == 1 || from_reads);   // several passes: reads only (MODE 3)
         if (from_rec && (!opt1 || W > 2 || getenv("DSKGPU_NO_RECSRC"))) { int e = records_to_keys(); if (e) return e; }
-        Opt1Spec o1{0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R};
+        Opt1Spec o1{0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2};
         unsigned grid1 = 0;
         if (opt1 && !from_reads) ctx->h_nvalid = nkeys_in;
         if (opt1) {
@@ -578,9 +578,9 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             const u64 cells = (u64)pl.P1 * grid1;
             // a block's share of the input: it walks chunks blockIdx, blockIdx + grid, .. (equal chunks, the busiest block has ceil(nch/grid))
             const u64 cpb = (nch1 + grid1 - 1) / grid1;
-            u64 slice = ctx->h_nvalid * cpb / ((u64)nch1 * pl.P1) + 1; slice += slice * 3 / 50 + 160; slice = (slice + 7) & ~7ull;   // mean + 6 % + 160
+            u64 slice = ctx->h_nvalid / npass * cpb / ((u64)nch1 * pl.P1) + 1; slice += slice * 3 / 50 + 160; slice = (slice + 7) & ~7ull;   // mean + 6 % + 160
             if (const char* e = getenv("DSKGPU_OPT_SLICE")) slice = (u64)atoll(e) & ~7ull;                   // experiments / tests
-            const u64 tail = ctx->h_nvalid / grid1 + 2 * Tile<W>::KEYS;                                     // worst overrun of one block
+            const u64 tail = ctx->h_nvalid / npass / grid1 * 2 + 2 * Tile<W>::KEYS;                                     // worst overrun of one block
             if (slice < 8 || cells * slice + tail >= 0xFFFF0000ull) opt1 = false;
             else {
                 o1.slice = (u32)slice; o1.cap1 = (u32)(slice * grid1);
@@ -604,7 +604,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         int rc;
         const ChunkDesc* dd1 = ctx->descs1.as<ChunkDesc>();
         if (opt1) {
-            if (from_reads) rc = launch_scatter_m<W, 0, 1, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+            if (from_reads && npass > 1) rc = launch_scatter_m<W, 0, 3, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+            else if (from_reads) rc = launch_scatter_m<W, 0, 1, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
             else if (from_rec) rc = launch_scatter_rec<W>(ctx, dd1, sc + SC_NCH1, nch1, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
             else rc = launch_scatter_m<W, 1, 1, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
             if (rc) return rc;
@@ -715,7 +716,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipMemcpyAsync(&ctx->h_stats[0], ctx->gstats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
-        const u32 h_ovf = ctx->h_back[0], h_nsolid = ctx->h_back[1], h_nk = opt1 ? (u32)ctx->h_nvalid : ctx->h_back[2];
+        const u32 h_ovf = ctx->h_back[0], h_nsolid = ctx->h_back[1], h_nk = opt1 ? (u32)ctx->h_stats[2] : ctx->h_back[2];
         if ((opt_cap && ctx->h_ovf2) || (opt1 && ctx->h_ovf1)) {       // a slice / region overflowed: repeat this attempt with exact offsets
             ctx->resolve_marks();
             if (opt1 && ctx->h_ovf1) ctx->opt1_off = true;
@@ -791,9 +792,11 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             tot_kmers += nk; tot_distinct += ctx->h_stats[0];
             if (npass > 1) {      // append this pass's rows and histogram to the job's
                 CK(hipMemcpyAsync(pass_hist.data(), ctx->ghist.p, pass_hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-                if (ctx->acc_ab.ensure_keep((tot_rows + ns + 1) * 4, tot_rows * 4, ctx->stream)) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
+                // grow once: the passes hold similar numbers of rows (hash-uniform), so size for all of them after the first
+                const u64 want_rows = std::max<u64>(tot_rows + ns + 1, p == 0 ? (ns + ns / 8 + 1024) * npass : 0);
+                if (ctx->acc_ab.ensure_keep(want_rows * 4, tot_rows * 4, ctx->stream)) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
                 for (int x = 0; x < W; ++x)
-                    if (ctx->acc_w[x].ensure_keep((tot_rows + ns + 1) * 8, tot_rows * 8, ctx->stream)) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
+                    if (ctx->acc_w[x].ensure_keep(want_rows * 8, tot_rows * 8, ctx->stream)) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
                 if (ns) {
                     CK(hipMemcpyAsync(ctx->acc_ab.as<u32>() + tot_rows, ctx->out_ab.p, ns * 4, hipMemcpyDeviceToDevice, ctx->stream));
                     for (int x = 0; x < W; ++x)

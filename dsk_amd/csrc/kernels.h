@@ -457,7 +457,7 @@ __device__ __forceinline__ u32 tile_keys_records(const u64* __restrict__ rec, u3
 // slices are sized from the exact number of valid k-mers (k_count_valid) plus 6 % + 160 keys; how much of
 // each slice holds keys goes to fill[b*grid + block], and the level-2 scatter (SLICED) reads exactly that much.  A slice that would
 // overflow raises *ovf (the host repeats the pass with the exact histogram + scan path).
-struct Opt1Spec { u32 slice, cap1; u32* ovf; u32* fill; u32 R; };      // R: words per super-k-mer record (SRC 2)
+struct Opt1Spec { u32 slice, cap1; u32* ovf; u32* fill; u32 R; u64* nkeys; };      // R: words per super-k-mer record (SRC 2)
 
 #ifndef DSK_ABLATE
 #define DSK_ABLATE 0     // 1 (make EXTRA=-DDSK_ABLATE=1): the timing-ablation switches (DSKGPU_DBG1/2 bits) are live; 0: compiled out (-0.1 ms)
@@ -565,12 +565,18 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
     if (OPT) {      // how much of each of its slices this block filled; report a slice that was outgrown
         lds_barrier();
         bool ovf = false;
+        u32 mine = 0;
         for (u32 b = threadIdx.x; b < P; b += SC_NT) {
             const u32 beg = b * o1.cap1 + blockIdx.x * o1.slice, c = cur[b];
             if (c > beg + o1.slice) ovf = true;
-            o1.fill[(u64)b * gridDim.x + blockIdx.x] = c > beg + o1.slice ? o1.slice : c - beg;
+            const u32 f = c > beg + o1.slice ? o1.slice : c - beg;
+            o1.fill[(u64)b * gridDim.x + blockIdx.x] = f;
+            mine += f;
         }
         if (ovf) *o1.ovf = 1u;
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) mine += __shfl_down(mine, dd);
+        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(o1.nkeys, (u64)mine);      // keys this launch placed (all of them unless a slice overflowed)
     }
 }
 
