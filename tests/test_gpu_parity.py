@@ -364,6 +364,29 @@ def test_push_reads_host_path(oracle, golden_dir, dev):
     assert (kmers[:, 0] == lo).all() and (ab == rab).all()
 
 
+def test_push_reads_staging_and_reserve(oracle, dev):
+    """Host pushes larger than the pinned staging buffers (2 x 32 MB), from bytes and from a numpy array, with the
+    device buffer reserved up front, reserved late (after the first push) and not at all: always the same count."""
+    from dsk_amd import KmerCounter, synth
+    reads = synth.make_reads(synth.make_genome(500_000, dev), 600_000, 150).cpu().numpy()      # 90 MB
+    ref = oracle.count(reads, 25)
+    cut = [0, 151 * 250_000, 151 * 250_001, len(reads)]
+    for mode in ("none", "first", "late"):
+        with KmerCounter(kmer_size=25, abundance_min=3) as kc:
+            if mode == "first":
+                kc.reserve_reads(len(reads) + 64)
+            for i in range(3):
+                piece = reads[cut[i]: cut[i + 1]]
+                kc.push_reads(piece if i != 1 else piece.tobytes())
+                if mode == "late" and i == 0:
+                    kc.reserve_reads(len(reads) + 64)
+            kc.count()
+            rows, ab = kc.rows()
+            st = kc.stats()
+        keep = ref.ab >= 3
+        assert st["n_kmers"] == ref.total and (rows[:, 0] == ref.lo[keep]).all() and (ab == ref.ab[keep]).all(), mode
+
+
 def test_determinism_and_reuse(dev):
     from dsk_amd import synth, KmerCounter
     g = synth.make_genome(200_000, dev)
