@@ -83,6 +83,8 @@ struct dskgpu_ctx {
     std::vector<u32> h_starts;
     // multi-GPU exchange as super-k-mer records (superkmer.h)
     bool sk_mode = false, sk_prepared = false;
+    bool sk_slices = false;        // the prepared send layout is slices from a sampled estimate (else exact offsets)
+    bool sk_exact = false;         // a slice overflowed on these reads: exact counts from now on
     SkParams sk_sp{};
     DevBuf sk_sums, sk_cbase, sk_keys;
     std::vector<u32> h_sk_sums; std::vector<u64> h_sk_cbase;
@@ -909,7 +911,7 @@ int sk_prepare(dskgpu_ctx* ctx) {
     SkParams& sp = ctx->sk_sp;
     sp.ngroups = nwords * 2;
     sp.ntiles = std::max<u64>(1, (sp.ngroups + SK_GROUPS - 1) / SK_GROUPS);
-    u64 nch = std::min<u64>(sp.ntiles, (u64)ctx->num_cu * 8);
+    u64 nch = std::min<u64>(std::max<u64>(1, sp.ntiles / 8), (u64)ctx->num_cu * 8);     // >= 8 tiles per chunk when there are that many
     const u64 tpc = (sp.ntiles + nch - 1) / nch;
     nch = (sp.ntiles + tpc - 1) / tpc;
     sp.tiles_per_chunk = (u32)tpc; sp.nchunks = (u32)nch;
@@ -921,6 +923,11 @@ int sk_prepare(dskgpu_ctx* ctx) {
     u32* sc = ctx->scalars.as<u32>();
     CK(hipMemcpyAsync(sc, h_sc, sizeof(ctx->h_sc), hipMemcpyHostToDevice, ctx->stream));
     CK(ctx->mat1.ensure((M + 1) * 4));
+    // Exact layout: count every record, one scan places them.  Slice layout (default): count the records of every
+    // 16th tile only, give every (owner, chunk) pair one slice of the estimated mean + 8 % + 128 records; the scatter
+    // pads the slices with zero-length records.  Saves the full counting pass (1.95 of 5 ms); ~8 % more words to send.
+    const bool slices = !ctx->sk_exact && !getenv("DSKGPU_SK_EXACT") && tpc >= 8;
+    sp.sample_step = slices ? 16u : 1u;
     hipLaunchKernelGGL(k_sk_hist, dim3((unsigned)nch), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, ctx->mat1.as<u32>());
     CKL("k_sk_hist");
     ctx->mark("mg_hist");
@@ -929,6 +936,25 @@ int sk_prepare(dskgpu_ctx* ctx) {
     for (u32 o = 0; o <= sp.G; ++o)
         CK(hipMemcpyAsync(&ctx->h_starts[o], ctx->mat1.as<u32>() + (u64)o * nch, 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
+    ctx->sk_slices = false;
+    if (slices) {
+        u64 worst = 0;                                       // sampled records of the busiest owner
+        for (u32 o = 0; o < sp.G; ++o) worst = std::max<u64>(worst, ctx->h_starts[o + 1] - ctx->h_starts[o]);
+        const u64 sampled_tiles = (tpc + sp.sample_step - 1) / sp.sample_step;            // per chunk
+        u64 slice = worst * tpc / (sampled_tiles * nch) + 1;                              // records per (owner, chunk), estimated
+        u64 min_slice = 2000; if (const char* e = getenv("DSKGPU_SK_MINSLICE")) min_slice = (u64)atoll(e);      // tests
+        const bool small = slice < min_slice || worst < 20000;    // fixed slack too visible in the send volume, or too few sampled records to trust the estimate
+        slice += slice * 2 / 25 + 128;
+        if (const char* e = getenv("DSKGPU_SK_SLICE")) slice = (u64)std::max(1, atoi(e));    // tests
+        if (!small && slice * nch * sp.G < 0xFFFF0000ull) {
+            sp.slice = (u32)slice;
+            for (u32 o = 0; o <= sp.G; ++o) ctx->h_starts[o] = (u32)(o * nch * slice);
+            ctx->sk_slices = true;
+        } else {                                             // small input, or too many records to index: count exactly after all
+            ctx->sk_exact = true;
+            return sk_prepare(ctx);
+        }
+    }
     ctx->resolve_marks();
     ctx->sk_prepared = true;
     return DSKGPU_OK;
@@ -942,12 +968,23 @@ int sk_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t*
     if (capacity_words < (u64)ctx->h_starts[sp.G] * sp.R) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
     ctx->marks.clear(); ctx->ev_used = 0;
     ctx->mark("start");
-    hipLaunchKernelGGL(k_sk_scatter, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
-                       ctx->mat1.as<u32>(), static_cast<u64*>(d_send));
+    u32* sc = ctx->scalars.as<u32>();
+    if (ctx->sk_slices)
+        hipLaunchKernelGGL(k_sk_scatter<true>, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
+                           ctx->mat1.as<u32>(), static_cast<u64*>(d_send), sc + SC_OVF1);
+    else
+        hipLaunchKernelGGL(k_sk_scatter<false>, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
+                           ctx->mat1.as<u32>(), static_cast<u64*>(d_send), sc + SC_OVF1);
     CKL("k_sk_scatter");
     ctx->mark("mg_scatter");
+    if (ctx->sk_slices) CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     ctx->resolve_marks();
+    if (ctx->sk_slices && ctx->h_ovf1) {      // a slice overflowed: exact counts for these reads from now on (and right away)
+        ctx->sk_exact = true; ctx->sk_prepared = false;
+        if ((rc = sk_prepare(ctx))) return rc;
+        return sk_scatter(ctx, d_send, capacity_words, send_words);      // may report "send buffer too small": ask for the capacity again
+    }
     for (u32 o = 0; o < sp.G; ++o) send_words[o] = (u64)(ctx->h_starts[o + 1] - ctx->h_starts[o]) * sp.R;
     ctx->sk_prepared = false;      // packed/mat1 are scratch of the next call
     return DSKGPU_OK;
@@ -1214,7 +1251,7 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
     CK(hipMemsetAsync(dst + ctx->reads_len + nbytes, '\n', 1, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     ctx->reads_len += nbytes + 1;
-    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->sk_prepared = false; ctx->opt2_off = false; ctx->opt1_off = false;
+    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false;
     return DSKGPU_OK;
 }
 
@@ -1234,7 +1271,7 @@ int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes) {
 
 int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes) {
     if (!ctx || (!d_bytes && nbytes)) return DSKGPU_E_ARG;
-    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->sk_prepared = false; ctx->opt2_off = false; ctx->opt1_off = false;
+    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false;
     ctx->n_bytes = nbytes;
     ctx->reads_len = 0;
     ctx->bank_ends.clear();

@@ -32,6 +32,8 @@ struct SkParams {
     u64 ntiles;
     u32 tiles_per_chunk, nchunks;
     u32 k, m, G, R;
+    u32 sample_step;      // k_sk_hist: look at every sample_step-th tile only (1 = exact count)
+    u32 slice;            // k_sk_scatter<true>: records per (owner, chunk) slice; owner o starts at o * nchunks * slice
 };
 
 __host__ __device__ __forceinline__ u32 sk_record_words(u32 k) { return (2u * (k + 15u) + 8u + 63u) / 64u; }
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(SK_NT) void k_sk_hist(const u64* __restrict__ packe
     if (threadIdx.x < SK_MAX_OWNERS) cnt[threadIdx.x] = 0;
     const u64 tbeg = (u64)c * sp.tiles_per_chunk;
     const u64 tend = tbeg + sp.tiles_per_chunk < sp.ntiles ? tbeg + sp.tiles_per_chunk : sp.ntiles;
-    for (u64 tile = tbeg; tile < tend; ++tile) {
+    for (u64 tile = tbeg; tile < tend; tile += sp.sample_step) {
         const SkThread s = sk_tile(packed, inval, sp, (long long)(tile * SK_GROUPS) - SK_HALO, H);
         u32 bm = s.bm;
         while (bm) {
@@ -154,12 +156,17 @@ __global__ __launch_bounds__(SK_NT) void k_sk_hist(const u64* __restrict__ packe
 
 // ---------------------------------------------------------------- sender: write the records
 // `mat` holds the exclusive scan of the (owner-major) count matrix: record index of (owner, chunk).
+// SLICES: no exact counts -- every (owner, chunk) pair owns a slice of sp.slice records (sized from a sampled
+// estimate); what a block leaves unused is filled with zero-length records (n = 0: the receiver skips them), a slice
+// that would overflow raises *ovf (nothing is written past a slice) and the host repeats with exact counts.
+template <bool SLICES>
 __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
-                                                      SkParams sp, const u32* __restrict__ mat, u64* __restrict__ send) {
+                                                      SkParams sp, const u32* __restrict__ mat, u64* __restrict__ send, u32* __restrict__ ovf) {
     __shared__ u32 H[SK_NT * 17];
     __shared__ u32 cur[SK_MAX_OWNERS];
     const u32 c = blockIdx.x;
-    if (threadIdx.x < sp.G) cur[threadIdx.x] = mat[(u64)threadIdx.x * sp.nchunks + c];
+    if (threadIdx.x < sp.G) cur[threadIdx.x] = SLICES ? (threadIdx.x * sp.nchunks + c) * sp.slice : mat[(u64)threadIdx.x * sp.nchunks + c];
+    bool over = false;
     const u64 tbeg = (u64)c * sp.tiles_per_chunk;
     const u64 tend = tbeg + sp.tiles_per_chunk < sp.ntiles ? tbeg + sp.tiles_per_chunk : sp.ntiles;
     const int k = (int)sp.k;
@@ -177,7 +184,9 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
             while (bm) {
                 const int i = __builtin_ctz(bm); bm &= bm - 1;
                 const u32 n = sk_run_length(s, i);
-                const u32 slot = atomicAdd(&cur[sk_owner(s, i)], 1u);
+                const u32 own = sk_owner(s, i);
+                const u32 slot = atomicAdd(&cur[own], 1u);
+                if (SLICES && slot >= (own * sp.nchunks + c + 1) * sp.slice) { over = true; continue; }
                 // bases [bs, bs + nb) of the 96-base frame (w2 : w1 : w0), shifted to the top of the record
                 const int bs = 64 + t0 + i - k + 1;
                 const int nb = (int)n + k - 1;
@@ -200,6 +209,14 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
             }
         }
         sk_lds_barrier();
+    }
+    if (SLICES) {
+        if (over) *ovf = 1u;
+        __syncthreads();
+        for (u32 o = 0; o < sp.G; ++o) {                      // zero-length records up to the end of each of this block's slices
+            const u64 end = (u64)(o * sp.nchunks + c + 1) * sp.slice * R;
+            for (u64 w = (u64)cur[o] * R + threadIdx.x; w < end; w += SK_NT) send[w] = 0ull;
+        }
     }
 }
 

@@ -47,6 +47,23 @@ def exchange(send: torch.Tensor, send_counts: Sequence[int], group=None,
     return out, recv_counts
 
 
+def scatter_records(stage, send: Optional[torch.Tensor], device: torch.device) -> Tuple[torch.Tensor, List[int]]:
+    """mg_send_capacity_words + mg_scatter into `send` (re-allocated when too small).  The capacity normally comes
+    from a sampled estimate; if a slice of the send layout overflows, the engine switches to exact counts, which can
+    need a larger buffer than estimated -- then the capacity is asked again and the scatter repeated once."""
+    for attempt in range(2):
+        cap = int(stage.mg_send_capacity_words())
+        if send is None or send.numel() < cap:
+            send = torch.empty(max(cap, 1), dtype=torch.int64, device=device)
+        try:
+            return send, stage.mg_scatter(send.data_ptr(), send.numel())
+        except RuntimeError as e:
+            if attempt == 0 and "send buffer too small" in str(e):
+                continue
+            raise
+    raise AssertionError("unreachable")
+
+
 class ShardedCounter:
     """Drives one rank of the sharded count.  After `count()`, the stage holds
     this rank's share of the result (its owned k-mers)."""
@@ -61,10 +78,7 @@ class ShardedCounter:
         self.last_recv_counts: List[int] = []
 
     def count(self) -> None:
-        cap = int(self.stage.mg_send_capacity_words())
-        if self.send is None or self.send.numel() < cap:
-            self.send = torch.empty(max(cap, 1), dtype=torch.int64, device=self.device)
-        counts = self.stage.mg_scatter(self.send.data_ptr(), self.send.numel())
+        self.send, counts = scatter_records(self.stage, self.send, self.device)
         out, rcounts = exchange(self.send, counts, self.group, self.recv)
         if self.recv is None or self.recv.numel() < out.numel() or out.data_ptr() != self.recv.data_ptr():
             self.recv = out._base if out._base is not None else out        # keep the (larger) backing buffer for the next step

@@ -482,6 +482,44 @@ def test_multi_gpu_path_on_one_device(oracle, golden_dir, dev, world, k, explici
         c.close()
 
 
+def test_sender_slices_and_their_exact_fallback(oracle, dev, monkeypatch):
+    """Multi-GPU sender: the records go to (owner, chunk) slices sized from a sampled count and padded with zero-length
+    records; a slice that overflows switches the context to exact counts (which may need a larger send buffer)."""
+    from dsk_amd import KmerCounter, synth
+    from dsk_amd.multi import scatter_records
+    world, k = 4, 31
+    reads = synth.make_reads(synth.make_genome(400_000, dev), 600_000, 150)
+    monkeypatch.setenv("DSKGPU_SK_MINSLICE", "100")        # (the slice layout is meant for shards of >= 3e8 bases: let it run on this small one)
+    ref = oracle.count(reads.cpu().numpy(), k)
+
+    def run():
+        ctxs, sends, counts, words = [], [], [], 0
+        for r in range(world):
+            kc = KmerCounter(kmer_size=k, abundance_min=1, world_size=world, rank=r, timing=True)
+            shard = reads[(reads.numel() // 151 // world) * 151 * r: (reads.numel() // 151 // world) * 151 * (r + 1)]
+            kc.set_reads_device(shard.data_ptr(), shard.numel())
+            torch.cuda.synchronize()
+            send, c = scatter_records(kc, None, dev)
+            ctxs.append(kc); sends.append(send); counts.append(c); words += sum(c)
+        tot, hist = 0, np.zeros(10001, np.uint64)
+        for d in range(world):
+            recv = torch.cat([sends[s_][sum(counts[s_][:d]): sum(counts[s_][:d]) + counts[s_][d]] for s_ in range(world)])
+            torch.cuda.synchronize()
+            ctxs[d].mg_count(recv.data_ptr(), recv.numel())
+            tot += ctxs[d].stats()["n_kmers"]; hist += ctxs[d].histogram()
+        for c in ctxs:
+            c.close()
+        return tot, hist, words, counts
+
+    tot, hist, words, counts = run()
+    assert tot == ref.total and (hist == ref.histogram(10000)).all()
+    assert len({tuple(c) for c in counts}) >= 1 and all(len(set(c)) == 1 for c in counts)      # slice layout: equal regions per owner
+    monkeypatch.setenv("DSKGPU_SK_SLICE", "8")                                                  # slices far too small -> exact counts
+    tot2, hist2, words2, counts2 = run()
+    assert tot2 == ref.total and (hist2 == ref.histogram(10000)).all()
+    assert any(len(set(c)) > 1 for c in counts2) and words2 < words                            # exact layout: no padding
+
+
 @pytest.mark.parametrize("k,m", [(31, 10), (21, 8), (63, 10), (11, 4), (16, 16), (5, 1)])
 def test_minimizers_match_oracle(oracle, golden_dir, dev, k, m):
     from dsk_amd import KmerCounter
