@@ -698,7 +698,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         // free ping-pong buffer); two-word keys write rows into the free buffer (+ abund2)
         CountParams cp;
         cp.F = pl.F;
-        { const char* e = getenv("DSKGPU_DBGC"); cp.dbg = e ? (u32)atoi(e) : 0u; }
+        cp.dbg = 0u;
         cp.amin = ctx->cfg.abundance_min; cp.amax = ctx->cfg.abundance_max; cp.histo_max = ctx->cfg.histo_max;
         cp.cap = opt_cap; cp.subcnt = opt_cap ? ctx->mat2.as<u32>() : nullptr;
         const unsigned cgrid = (unsigned)std::min<u64>(pl.F, (u64)ctx->num_cu * 2);
