@@ -402,8 +402,8 @@ def test_determinism_and_reuse(dev):
         assert (k == outs[0][0]).all() and (a == outs[0][1]).all() and (h == outs[0][2]).all()
 
 
-@pytest.mark.parametrize("workload", ["ecoli50x", "c2_10Mx150"])
-def test_full_size_invariants(dev, workload):
+@pytest.mark.parametrize("workload,k", [("ecoli50x", 31), ("c2_10Mx150", 31), ("c2_10Mx150", 63)])
+def test_full_size_invariants(dev, workload, k, monkeypatch):
     """Size-independent properties at BASELINE.json's full sizes (configs[1] = c2_10Mx150), too big for
     the oracle in seconds: sum(abundance * hist) == n_kmers, sum(hist) == n_distinct, sortedness,
     solid count == hist tail, n_kmers == number of full ACGT windows in the stream."""
@@ -411,18 +411,27 @@ def test_full_size_invariants(dev, workload):
     gl, nr, rl = synth.workload(workload)
     g = synth.make_genome(gl, dev)
     reads = synth.make_reads(g, nr, rl)
-    with KmerCounter(kmer_size=31, abundance_min=2) as kc:
-        kc.set_reads_device(reads.data_ptr(), reads.numel())
-        kc.count()
-        st = kc.stats()
-        h = kc.histogram().astype(np.int64)
-        kmers, ab = kc.rows()
+    def count():
+        with KmerCounter(kmer_size=k, abundance_min=2) as kc:
+            kc.set_reads_device(reads.data_ptr(), reads.numel())
+            kc.count()
+            return kc.stats(), kc.histogram().astype(np.int64), kc.rows()
+    st, h, (kmers, ab) = count()
     idx = np.arange(len(h), dtype=np.int64)
     assert h[-1] == 0                                   # nothing saturates the last row here
     assert int((h * idx).sum()) == st["n_kmers"]
     assert int(h.sum()) == st["n_distinct"]
     assert int(h[2:].sum()) == st["n_solid"] == len(ab)
-    assert (np.diff(kmers[:, 0].astype(np.uint64)) > 0).all()   # strictly ascending, no duplicates
+    if k <= 32:
+        assert (np.diff(kmers[:, 0].astype(np.uint64)) > 0).all()   # strictly ascending, no duplicates
+    else:
+        hi, lo = kmers[:, 1].astype(np.uint64), kmers[:, 0].astype(np.uint64)
+        assert ((hi[1:] > hi[:-1]) | ((hi[1:] == hi[:-1]) & (lo[1:] > lo[:-1]))).all()
+    if workload != "ecoli50x":      # the histogram-free scatters and the exact histogram + scan path must agree row for row
+        monkeypatch.setenv("DSKGPU_NO_OPT2", "1")
+        st2, h2, (kmers2, ab2) = count()
+        monkeypatch.delenv("DSKGPU_NO_OPT2")
+        assert (h2 == h).all() and (kmers2 == kmers).all() and (ab2 == ab).all() and st2["n_distinct"] == st["n_distinct"]
     assert (np.bincount(np.minimum(ab, 10000), minlength=10001)[2:] == h[2:]).all()
     # every read position with a full ACGT window contributes exactly one k-mer
     r = reads.view(nr, rl + 1)[:, :rl]
@@ -431,7 +440,7 @@ def test_full_size_invariants(dev, workload):
     run = torch.zeros(nr, dtype=torch.int32, device=dev)
     for j in range(rl):
         run = torch.where(bad[:, j], torch.zeros_like(run), run + 1)
-        n_valid += int((run >= 31).sum())
+        n_valid += int((run >= k).sum())
     assert n_valid == st["n_kmers"]
 
 
