@@ -533,7 +533,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         bool from_rec = !from_reads && d_keys_in == nullptr;
         auto upload_descs1 = [&]() -> int {
             if (from_reads) build_descs1(ctx, nwords, Tile<W>::WORDS, max_chunks1, &nch1);
-            else if (from_rec) build_descs1(ctx, ctx->rec_n, Tile<W>::KEYS / 8, max_chunks1, &nch1);
+            else if (from_rec) build_descs1(ctx, ctx->rec_n, RecTile<W>::NR, max_chunks1, &nch1);
             else build_descs1(ctx, nkeys_in, Tile<W>::KEYS, max_chunks1, &nch1);
             CK(ctx->descs1.ensure(ctx->h_descs1.size() * sizeof(ChunkDesc)));
             CK(hipMemcpyAsync(ctx->descs1.p, ctx->h_descs1.data(), ctx->h_descs1.size() * sizeof(ChunkDesc),

@@ -388,10 +388,13 @@ __device__ __forceinline__ void sk_key(const u64* r, int j, int k, u64& out) { o
 __device__ __forceinline__ void sk_key(const u64* r, int j, int k, K2& out) { out = sk_key2(r, j, k); }
 template <int W> __device__ __forceinline__ void sk_key(const u64*, int, int, KN<W>&) {}      // (records carry k <= 64 only)
 
+// candidate records per tile: 3072 for 16384 one-word key slots (more than fit on average -- the tile takes the prefix that
+// fits and is ~100 % full; 2048 candidates: 7.4 -> 6.5 ms), 1024 for 8192 two-word slots
+template <int W> struct RecTile { static constexpr int NR = W == 1 ? 3 * SC_NT : SC_NT; };
 template <int W>
 __device__ __forceinline__ u32 tile_keys_records(const u64* __restrict__ rec, u32 R, u64 r0, u64 rend, int k,
                                                  typename KeyT<W>::T (&h)[Tile<W>::KPT], char* scratch, u32* wsum, u32* taken) {
-    constexpr int KPT = Tile<W>::KPT, KEYS = Tile<W>::KEYS, NR = KEYS / 8, RPT = NR / SC_NT;
+    constexpr int KPT = Tile<W>::KPT, KEYS = Tile<W>::KEYS, NR = RecTile<W>::NR, RPT = NR / SC_NT;
     u64* srec = reinterpret_cast<u64*>(scratch);                             // NR * 3 words
     unsigned short* smap = reinterpret_cast<unsigned short*>(srec + (size_t)NR * 3);   // KEYS entries
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
