@@ -98,8 +98,36 @@ def cpu_baseline(reads_u8, read_len, n_sample_reads, k, target_s=15.0):
     }
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` started bare (no WORLD_SIZE): become the launcher of the N ranks.  This process never
+    touches the GPU (torch is not even imported here): the ranks are children of torch.distributed.run, rank 0's JSON line
+    is relayed on stdout and the launcher's exit code is theirs."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: needed by RCCL between processes on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for ln in proc.stdout.decode(errors="replace").splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line:
+        print(line)
+    sys.exit(proc.returncode if proc.returncode else (0 if line else 1))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     import torch
     import torch.distributed as dist
     from dsk_amd import KmerCounter, synth

@@ -10,6 +10,7 @@ raises.
 from .engine import (  # noqa: F401
     DskGpuError,
     KmerCounter,
+    KmerGroup,
     load_library,
     library_path,
 )

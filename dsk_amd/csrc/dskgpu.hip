@@ -38,7 +38,9 @@ struct DevBuf {
         void* np = nullptr;
         size_t want = ((std::max(bytes, cap + cap / 2) + 255) & ~size_t(255));
         if (hipMalloc(&np, want) != hipSuccess) return -1;
-        if (keep && p) { if (hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1; (void)hipStreamSynchronize(stream); }
+        if (keep && p) {
+            if (hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(np); return -1; }
+        }
         if (p) (void)hipFree(p);
         p = np; cap = want;
         return 0;
@@ -93,8 +95,11 @@ struct dskgpu_ctx {
     u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0; u64 h_nvalid = 0;
     bool sentinel_ok = true;       // the all-ones key is not the mixed form of a canonical k-mer of this k (checked at create)
     bool opt1_off = false;         // same for the histogram-free level-1 scatter (block-owned slices)
+    bool no_packed_count = false;  // DSKGPU_NO_PACKED_COUNT (read at create): the separate key / count table kernel for region layouts too
+    unsigned cp_grid = 0;          // grid of k_count1p (resident blocks, from the occupancy query)
     bool opt2_off = false;         // the fixed-capacity level-2 scatter overflowed on these reads: use the exact path   // host landing zone of the async size read-back
     std::vector<ChunkDesc> h_descs1, h_descs2;
+    std::vector<const void*> big_lds_fns;   // kernels whose dynamic-LDS limit this context has raised (allow_big_lds)
     u32 h_sc[SC_COUNT] = {0};      // host mirror of the device scalars (kept alive across async copies)
 
     // results
@@ -198,6 +203,15 @@ int run_scan(dskgpu_ctx* ctx, u32* a, const u32* d_len, u64 max_len) {
 // experiment switches (timing ablations only; results are wrong when set): DSKGPU_DBG1 = level-1 scatter, DSKGPU_DBG2 = key-array scatter
 u32 dbg_flags(int src) { const char* e = getenv(src == 0 ? "DSKGPU_DBG1" : "DSKGPU_DBG2"); return e ? (u32)atoi(e) : 0u; }
 
+// Kernels that stage a whole tile need more dynamic LDS than the 64 KB default: raise the limit once per context
+// (a context is bound to one device and driven by one thread, so no process-wide flag is involved).
+int allow_big_lds(dskgpu_ctx* ctx, const void* fn) {
+    for (const void* f : ctx->big_lds_fns) if (f == fn) return DSKGPU_OK;
+    CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ctx->big_lds_fns.push_back(fn);
+    return DSKGPU_OK;
+}
+
 size_t scatter_lds(int W, u32 P) { return (size_t)SC_NT * (16 / W) * 8 * W + (size_t)P * 16 + 4 + 17 * 4 + 16; }
 
 template <int W, int SRC, int MODE>
@@ -232,12 +246,7 @@ int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chu
                      u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1 = Opt1Spec{0u, 0u, nullptr}) {
     const size_t lds = scatter_lds(W, P);
     const unsigned grid = scatter_grid(ctx, W, P, max_chunks);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter<W, SRC, MODE, OPT>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, SRC, MODE, OPT>)); if (e) return e; }
     hipLaunchKernelGGL((k_scatter<W, SRC, MODE, OPT>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->packed.as<u64>(),
                        ctx->inval.as<u32>(), keys, descs, d_nch, scanned, out, (int)ctx->cfg.kmer_size, ds, P, dbg_flags(SRC), o1);
     CKL("k_scatter");
@@ -248,11 +257,7 @@ template <int W>
 int launch_scatter_rec(dskgpu_ctx* ctx, const ChunkDesc* descs, const u32* d_nch, u64 max_chunks, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1) {
     const size_t lds = scatter_lds(W, P);
     const unsigned grid = scatter_grid(ctx, W, P, max_chunks);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter<W, 2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, 2, 1, true>)); if (e) return e; }
     hipLaunchKernelGGL((k_scatter<W, 2, 1, true>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->rec_src, (const u32*)nullptr,
                        (const typename KeyT<W>::T*)nullptr, descs, d_nch, (const u32*)nullptr, out, (int)ctx->cfg.kmer_size, ds, P, 0u, o1);
     CKL("k_scatter(records)");
@@ -266,12 +271,7 @@ int launch_scatter_al(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Ch
                       u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, OptSpec os = OptSpec{0u, nullptr, nullptr, nullptr, 0u, 0u}) {
     const size_t lds = ascatter_lds(W, P);
     const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu));
-    static bool attr_set = false;
-    if (!attr_set) {
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_al<W, MODE, OPT, SLICED>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter_al<W, MODE, OPT, SLICED>)); if (e) return e; }
     hipLaunchKernelGGL((k_scatter_al<W, MODE, OPT, SLICED>), dim3(grid), dim3(SC_NT), lds, ctx->stream, keys, descs, d_nch, scanned, out, ds, P, dbg_flags(1), os);
     CKL("k_scatter_al");
     return DSKGPU_OK;
@@ -295,6 +295,17 @@ int launch_scatter(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chunk
 
 // fixed-capacity regions or exact offsets: a compile-time switch of the count kernels (k_count1 / k_count_mw)
 inline void launch_count_impl(dskgpu_ctx* ctx, unsigned grid, u64* keys, u64* solid_keys, u32* solid_ab, u32* ovf, const CountParams& cp) {
+    if (cp.cap && cp.cap <= (u32)CP_CMASK && cp.F >= CP_MIN_F && !ctx->no_packed_count) {      // key + count in one table word (k_count1p)
+        if (!ctx->cp_grid) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_count1p<CP_NT, CP_KPT>, CP_NT, 0) != hipSuccess || nb < 1) nb = 1;
+            ctx->cp_grid = (unsigned)(ctx->num_cu * nb);
+        }
+        CountParamsP pp{cp.F, cp.amin, cp.amax, cp.histo_max, cp.cap, cp.subcnt, ~0ull / cp.F};
+        hipLaunchKernelGGL((k_count1p<CP_NT, CP_KPT>), dim3(std::min<unsigned>(ctx->cp_grid, cp.F)), dim3(CP_NT), 0, ctx->stream, keys, solid_keys, solid_ab,
+                           ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, pp);
+        return;
+    }
     if (cp.cap) hipLaunchKernelGGL(k_count1<true>, dim3(grid), dim3(CNT_NT), 0, ctx->stream, keys, solid_keys, ctx->fstart.as<u32>(), solid_ab,
                                    ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, cp);
     else hipLaunchKernelGGL(k_count1<false>, dim3(grid), dim3(CNT_NT), 0, ctx->stream, keys, solid_keys, ctx->fstart.as<u32>(), solid_ab,
@@ -334,6 +345,7 @@ bool make_plan(u64 n_upper, int extra_bits, int W, Plan* pl) {
     const u64 target = W == 1 ? TARGET_KEYS : W == 2 ? TARGET_KEYS2 : TARGET_KEYS2 / 2;   // four-word keys: 1024 staged per sub-partition
     u64 F = ((n_upper + target - 1) / target) << extra_bits;
     if (F < 2) F = 2;
+    if (W == 1 && F > ONE_LEVEL_BINS && F < CP_MIN_F) F = CP_MIN_F;      // two levels: fine enough for the packed count table (k_count1p)
     if (F <= ONE_LEVEL_BINS) { pl->levels = 1; pl->P1 = (u32)F; pl->P2 = 1; }
     else {
         u64 p1 = 1; while (p1 * p1 < F) ++p1;
@@ -1044,6 +1056,13 @@ int run_banks(dskgpu_ctx* ctx) {
     if (B > 32) return fail(ctx, DSKGPU_E_ARG, "at most 32 banks are supported by the solidity kinds");
     const dskgpu_config saved = ctx->cfg;
     const uint8_t* base = ctx->d_reads; const u64 total = ctx->n_bytes;
+    // the per-bank counts run with their own thresholds and read range: whatever way this function is left
+    // (also the early returns of CK), the context gets its configuration and its read stream back
+    struct Restore {
+        dskgpu_ctx* c; dskgpu_config cfg; const uint8_t* reads; u64 n; bool armed = true;
+        void now() { if (armed) { c->cfg = cfg; c->d_reads = reads; c->n_bytes = n; armed = false; } }
+        ~Restore() { now(); }
+    } restore{ctx, saved, base, total};
     ctx->cfg.abundance_min = 1; ctx->cfg.abundance_max = 0xFFFFFFFFu; ctx->cfg.flags |= DSKGPU_F_NO_SORT;
     u64 nu = 0, tot_kmers = 0; u32 passes = 1, retries = 0;
     int rc = DSKGPU_OK;
@@ -1065,7 +1084,7 @@ int run_banks(dskgpu_ctx* ctx) {
         }
         nu += n;
     }
-    ctx->cfg = saved; ctx->d_reads = base; ctx->n_bytes = total;
+    restore.now();
     if (rc) return rc;
     ctx->have_result = false;
     if (nu >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "too many distinct k-mers over the banks for the merge");
@@ -1142,6 +1161,8 @@ extern "C" {
 
 const char* dskgpu_version(void) { return DSKGPU_VERSION; }
 
+int dskgpu_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+
 const char* dskgpu_last_error(const dskgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 int dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out) {
@@ -1167,8 +1188,10 @@ int dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out) {
     ctx->words_out = (int)((cfg->kmer_size + 31) / 32);
     ctx->sentinel_ok = !sentinel_is_a_kmer(ctx->W, cfg->kmer_size);                   // words of a k-mer at the ABI (3 for k <= 96)
     ctx->max_keys_per_pass = (u64)cfg->max_pass_mkeys * 1000000ull;
+    ctx->no_packed_count = getenv("DSKGPU_PACKED_COUNT") == nullptr;      // experimental kernel: opt-in until it beats k_count1
     // super-k-mer records need >= 16 m-mers per window (superkmer.h); shorter k-mers travel as explicit keys
-    ctx->sk_mode = ws > 1 && cfg->kmer_size >= 20 && cfg->kmer_size <= 64 && !(cfg->flags & DSKGPU_F_MG_EXPLICIT);
+    // (world_size == 1 is the degenerate exchange: every record goes to owner 0; dskgpu_count never looks at sk_mode)
+    ctx->sk_mode = cfg->kmer_size >= 20 && cfg->kmer_size <= 64 && !(cfg->flags & DSKGPU_F_MG_EXPLICIT);
     if (ctx->sk_mode) {
         ctx->sk_sp.k = cfg->kmer_size; ctx->sk_sp.G = ws;
         ctx->sk_sp.m = std::min<u32>(std::min<u32>(ctx->cfg.minimizer_size, 16u), cfg->kmer_size - 15u);
@@ -1324,7 +1347,6 @@ uint64_t dskgpu_mg_send_capacity_words(dskgpu_ctx* ctx) {
 
 int dskgpu_mg_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t* send_words) {
     if (!ctx || !d_send || !send_words) return DSKGPU_E_ARG;
-    if (ctx->cfg.world_size < 2) return fail(ctx, DSKGPU_E_STATE, "dskgpu_mg_scatter needs world_size >= 2");
     CK(hipSetDevice(ctx->cfg.device));
     if (ctx->sk_mode) return sk_scatter(ctx, d_send, capacity_words, send_words);
     if (capacity_words < dskgpu_mg_send_capacity_words(ctx)) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");

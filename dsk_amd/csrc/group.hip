@@ -1,0 +1,313 @@
+// group.hip -- node-level sharded count inside ONE process (C-ABI: dskgpu_group_* in include/dskgpu.h).
+//
+// The reference's one call `SortingCountAlgorithm<span>::execute()` (src/DSK.cpp:55-60) leaves ONE storage with a
+// flat list of solid partitions (read back at utils/dsk2ascii.cpp:61,77).  This file is what lets the `dsk` binary keep
+// that shape on N GPUs: N contexts (one per rank, each with its own device, stream and host thread), every rank cuts
+// its share of the reads into super-k-mer records grouped by owner (dskgpu_mg_scatter), the records are exchanged, and
+// every rank counts the k-mers it owns (dskgpu_mg_count).  The exchange is the path's one real collective:
+//   transport "rccl": one communicator per rank (ncclCommInitAll), counts through host memory (same process), payload
+//                     as grouped ncclSend / ncclRecv on the rank's stream -- an all-to-all-v over xGMI.  librccl is
+//                     loaded with dlopen the first time a group asks for it, so single-GPU runs never pay for it.
+//   transport "copy": hipMemcpyAsync from the peers' send buffers (same device, or peer access) -- used when several
+//                     ranks share one device (RCCL refuses duplicate devices), i.e. the multi-rank tests on a 1-GPU box.
+// Built only on the public entry points of dskgpu.h: no kernels here.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/dskgpu.h"
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+    bool load() {
+        if (handle) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (handle) break;
+        }
+        if (!handle) { err = std::string("dlopen(librccl): ") + dlerror(); return false; }
+        auto sym = [&](const char* n) { void* p = dlsym(handle, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString;
+    }
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+
+// all ranks meet here; reusable
+class Barrier {
+public:
+    explicit Barrier(unsigned n) : n_(n) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu_);
+        const unsigned gen = gen_;
+        if (++count_ == n_) { count_ = 0; ++gen_; cv_.notify_all(); }
+        else cv_.wait(lk, [&] { return gen_ != gen; });
+    }
+private:
+    std::mutex mu_; std::condition_variable cv_; unsigned n_, count_ = 0, gen_ = 0;
+};
+
+struct DevMem {
+    void* p = nullptr; size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = ((bytes + bytes / 8 + 4095) & ~size_t(4095));      // head-room: sizes wobble from call to call
+        if (hipMalloc(&p, want) != hipSuccess) return false;
+        cap = want;
+        return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+thread_local std::string g_group_create_err;
+
+}  // namespace
+
+struct dskgpu_group {
+    uint32_t n = 0;
+    bool use_rccl = false;
+    std::vector<int> dev;
+    std::vector<dskgpu_ctx*> ctx;
+    std::vector<hipStream_t> stream;
+    std::vector<ncclComm_t> comm;
+    std::vector<DevMem> send, recv;
+    std::vector<std::vector<uint64_t>> counts;      // counts[src][dst], 8-byte words
+    std::vector<int> rc;
+    std::vector<std::string> rank_err;
+    std::string err;
+    uint32_t histo_max = 10000;
+    uint64_t exchanged_words = 0;                    // words that crossed ranks in the last count (off-diagonal of counts)
+    bool have_result = false;
+};
+
+namespace {
+
+int group_fail(dskgpu_group* g, int code, const std::string& msg) { g->err = msg; return code; }
+
+// one rank of one sharded count
+void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
+    auto fail = [&](int code, const std::string& msg) { g->rc[r] = code; g->rank_err[r] = msg; };
+    auto any_failed = [&]() { for (int c : g->rc) if (c != DSKGPU_OK) return true; return false; };
+    const uint32_t n = g->n;
+    dskgpu_ctx* ctx = g->ctx[r];
+    if (hipSetDevice(g->dev[r]) != hipSuccess) fail(DSKGPU_E_DEVICE, "hipSetDevice");
+    // ---- step 1: this rank's records, grouped by owner
+    if (g->rc[r] == DSKGPU_OK) {
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const uint64_t cap = dskgpu_mg_send_capacity_words(ctx);
+            if (cap == 0) { fail(DSKGPU_E_DEVICE, std::string("send capacity: ") + dskgpu_last_error(ctx)); break; }
+            if (!g->send[r].ensure(cap * 8)) { fail(DSKGPU_E_NOMEM, "send buffer"); break; }
+            const int rc = dskgpu_mg_scatter(ctx, g->send[r].p, g->send[r].cap / 8, g->counts[r].data());
+            if (rc == DSKGPU_OK) break;
+            // a slice of the sampled send layout overflowed and the exact layout needs more room: ask again, once
+            if (attempt == 0 && rc == DSKGPU_E_ARG && std::strstr(dskgpu_last_error(ctx), "send buffer too small")) continue;
+            fail(rc, std::string("mg_scatter: ") + dskgpu_last_error(ctx));
+            break;
+        }
+    }
+    bar->wait();                                     // every rank's counts row is final, every send buffer complete
+    if (any_failed()) return;
+    // ---- step 2: the exchange (all-to-all-v)
+    uint64_t recv_words = 0;
+    std::vector<uint64_t> roff(n + 1, 0), soff(n + 1, 0);
+    for (uint32_t s = 0; s < n; ++s) { roff[s + 1] = roff[s] + g->counts[s][r]; soff[s + 1] = soff[s] + g->counts[r][s]; }
+    recv_words = roff[n];
+    if (!g->recv[r].ensure(std::max<uint64_t>(recv_words, 1) * 8)) fail(DSKGPU_E_NOMEM, "receive buffer");
+    bar->wait();                                     // (a failed allocation must stop everybody before RCCL would hang)
+    if (any_failed()) return;
+    uint64_t* sb = static_cast<uint64_t*>(g->send[r].p);
+    uint64_t* rb = static_cast<uint64_t*>(g->recv[r].p);
+    if (g->use_rccl) {
+        RcclApi& a = g_rccl;
+        ncclResult_t e = a.GroupStart();
+        for (uint32_t p = 0; p < n && e == ncclSuccess; ++p) {
+            if (g->counts[r][p]) e = a.Send(sb + soff[p], g->counts[r][p], ncclUint64, (int)p, g->comm[r], g->stream[r]);
+            if (e == ncclSuccess && g->counts[p][r]) e = a.Recv(rb + roff[p], g->counts[p][r], ncclUint64, (int)p, g->comm[r], g->stream[r]);
+        }
+        const ncclResult_t e2 = a.GroupEnd();
+        if (e == ncclSuccess) e = e2;
+        if (e != ncclSuccess) fail(DSKGPU_E_DEVICE, std::string("RCCL exchange: ") + a.GetErrorString(e));
+    } else {
+        for (uint32_t s = 0; s < n; ++s) {
+            const uint64_t w = g->counts[s][r];
+            if (!w) continue;
+            uint64_t off = 0;
+            for (uint32_t d = 0; d < r; ++d) off += g->counts[s][d];
+            const hipError_t e = hipMemcpyAsync(rb + roff[s], static_cast<const uint64_t*>(g->send[s].p) + off, w * 8, hipMemcpyDefault, g->stream[r]);
+            if (e != hipSuccess) { fail(DSKGPU_E_DEVICE, std::string("exchange copy: ") + hipGetErrorString(e)); break; }
+        }
+    }
+    if (g->rc[r] == DSKGPU_OK && hipStreamSynchronize(g->stream[r]) != hipSuccess) fail(DSKGPU_E_DEVICE, "exchange: stream synchronize");
+    bar->wait();                                     // nobody overwrites a send buffer a peer still reads
+    if (any_failed()) return;
+    // ---- step 3: count what this rank owns
+    const int rc = dskgpu_mg_count(ctx, recv_words ? g->recv[r].p : nullptr, recv_words);
+    if (rc != DSKGPU_OK) fail(rc, std::string("mg_count: ") + dskgpu_last_error(ctx));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dskgpu_group_last_error(const dskgpu_group* g) { return g ? g->err.c_str() : g_group_create_err.c_str(); }
+
+int dskgpu_group_create(const dskgpu_config* cfg, const int32_t* devices, uint32_t n_ranks, dskgpu_group** out) {
+    if (!cfg || !out || !devices || n_ranks == 0) { g_group_create_err = "null argument"; return DSKGPU_E_ARG; }
+    *out = nullptr;
+    if ((n_ranks & (n_ranks - 1)) != 0 || n_ranks > 64) { g_group_create_err = "the number of ranks must be a power of two <= 64"; return DSKGPU_E_ARG; }
+    dskgpu_group* g = new dskgpu_group();
+    g->n = n_ranks;
+    g->dev.assign(devices, devices + n_ranks);
+    g->histo_max = cfg->histo_max ? cfg->histo_max : 10000;
+    bool distinct = true;
+    for (uint32_t a = 0; a < n_ranks; ++a) for (uint32_t b = a + 1; b < n_ranks; ++b) distinct = distinct && devices[a] != devices[b];
+    const char* want = getenv("DSKGPU_GROUP_TRANSPORT");           // "rccl" | "copy"; default: rccl when every rank has its own device
+    g->use_rccl = want ? std::strcmp(want, "rccl") == 0 : (distinct && n_ranks > 1);
+    auto bail = [&](int code, const std::string& msg) { g_group_create_err = msg; dskgpu_group_destroy(g); return code; };
+    if (g->use_rccl && !distinct) return bail(DSKGPU_E_ARG, "transport rccl needs one device per rank");
+    g->ctx.assign(n_ranks, nullptr); g->stream.assign(n_ranks, nullptr); g->comm.assign(n_ranks, nullptr);
+    g->send.resize(n_ranks); g->recv.resize(n_ranks);
+    g->counts.assign(n_ranks, std::vector<uint64_t>(n_ranks, 0));
+    g->rc.assign(n_ranks, DSKGPU_OK); g->rank_err.assign(n_ranks, "");
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        dskgpu_config c = *cfg;
+        c.world_size = n_ranks; c.rank = r; c.device = devices[r];
+        const int rc = dskgpu_create(&c, &g->ctx[r]);
+        if (rc != DSKGPU_OK) return bail(rc, std::string("rank ") + std::to_string(r) + ": " + dskgpu_last_error(nullptr));
+        if (hipSetDevice(devices[r]) != hipSuccess || hipStreamCreateWithFlags(&g->stream[r], hipStreamNonBlocking) != hipSuccess)
+            return bail(DSKGPU_E_DEVICE, "stream of rank " + std::to_string(r));
+        if (dskgpu_set_stream(g->ctx[r], g->stream[r]) != DSKGPU_OK) return bail(DSKGPU_E_DEVICE, "set_stream");
+    }
+    if (!g->use_rccl) {                                  // the copy transport reads the peers' send buffers directly
+        for (uint32_t a = 0; a < n_ranks; ++a)
+            for (uint32_t b = 0; b < n_ranks; ++b) {
+                if (devices[a] == devices[b]) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
+                    (void)hipSetDevice(devices[a]);
+                    const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return bail(DSKGPU_E_DEVICE, "hipDeviceEnablePeerAccess");
+                    (void)hipGetLastError();
+                }
+            }
+    } else {
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
+        if (!g_rccl.load()) return bail(DSKGPU_E_DEVICE, g_rccl.err);
+        const ncclResult_t e = g_rccl.CommInitAll(g->comm.data(), (int)n_ranks, g->dev.data());
+        if (e != ncclSuccess) { for (auto& c : g->comm) c = nullptr; return bail(DSKGPU_E_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(e)); }
+    }
+    *out = g;
+    return DSKGPU_OK;
+}
+
+void dskgpu_group_destroy(dskgpu_group* g) {
+    if (!g) return;
+    for (uint32_t r = 0; r < g->ctx.size(); ++r) {
+        if (r < g->dev.size()) (void)hipSetDevice(g->dev[r]);
+        if (r < g->stream.size() && g->stream[r]) (void)hipStreamSynchronize(g->stream[r]);
+        if (r < g->comm.size() && g->comm[r]) (void)g_rccl.CommDestroy(g->comm[r]);
+        if (g->ctx[r]) { (void)dskgpu_set_stream(g->ctx[r], nullptr); dskgpu_destroy(g->ctx[r]); }
+        if (r < g->send.size()) { g->send[r].release(); g->recv[r].release(); }
+        if (r < g->stream.size() && g->stream[r]) (void)hipStreamDestroy(g->stream[r]);
+    }
+    delete g;
+}
+
+uint32_t dskgpu_group_size(const dskgpu_group* g) { return g ? g->n : 0; }
+dskgpu_ctx* dskgpu_group_ctx(dskgpu_group* g, uint32_t rank) { return (g && rank < g->n) ? g->ctx[rank] : nullptr; }
+const char* dskgpu_group_transport(const dskgpu_group* g) { return !g ? "" : g->use_rccl ? "rccl" : "copy"; }
+uint64_t dskgpu_group_exchanged_words(const dskgpu_group* g) { return g ? g->exchanged_words : 0; }
+
+int dskgpu_group_count(dskgpu_group* g) {
+    if (!g) return DSKGPU_E_ARG;
+    g->have_result = false;
+    std::fill(g->rc.begin(), g->rc.end(), DSKGPU_OK);
+    for (auto& row : g->counts) std::fill(row.begin(), row.end(), 0);
+    Barrier bar(g->n);
+    std::vector<std::thread> th;
+    for (uint32_t r = 1; r < g->n; ++r) th.emplace_back(rank_body, g, r, &bar);
+    rank_body(g, 0, &bar);
+    for (auto& t : th) t.join();
+    for (uint32_t r = 0; r < g->n; ++r)
+        if (g->rc[r] != DSKGPU_OK) return group_fail(g, g->rc[r], "rank " + std::to_string(r) + ": " + g->rank_err[r]);
+    g->exchanged_words = 0;
+    for (uint32_t s = 0; s < g->n; ++s) for (uint32_t d = 0; d < g->n; ++d) if (s != d) g->exchanged_words += g->counts[s][d];
+    g->have_result = true;
+    return DSKGPU_OK;
+}
+
+int dskgpu_group_histogram(const dskgpu_group* g, uint64_t* out, uint32_t nbins) {
+    if (!g || !out) return DSKGPU_E_ARG;
+    if (!g->have_result) return DSKGPU_E_STATE;
+    if (nbins != g->histo_max + 1) return DSKGPU_E_ARG;
+    std::vector<uint64_t> one(nbins);
+    std::memset(out, 0, (size_t)nbins * 8);
+    for (uint32_t r = 0; r < g->n; ++r) {
+        const int rc = dskgpu_histogram(g->ctx[r], one.data(), nbins);
+        if (rc != DSKGPU_OK) return rc;
+        for (uint32_t i = 0; i < nbins; ++i) out[i] += one[i];
+    }
+    return DSKGPU_OK;
+}
+
+int dskgpu_group_get_stats(const dskgpu_group* g, dskgpu_stats* out) {
+    if (!g || !out) return DSKGPU_E_ARG;
+    if (!g->have_result) return DSKGPU_E_STATE;
+    dskgpu_stats t{};
+    for (uint32_t r = 0; r < g->n; ++r) {
+        dskgpu_stats s{};
+        const int rc = dskgpu_get_stats(g->ctx[r], &s);
+        if (rc != DSKGPU_OK) return rc;
+        t.n_bytes += s.n_bytes; t.n_kmers += s.n_kmers; t.n_distinct += s.n_distinct; t.n_solid += s.n_solid;
+        t.n_partitions += s.n_partitions; t.n_retries += s.n_retries; t.sort_fallback += s.sort_fallback;
+        t.n_levels = std::max(t.n_levels, s.n_levels); t.n_final_bins += s.n_final_bins; t.n_passes = std::max(t.n_passes, s.n_passes);
+    }
+    *out = t;
+    return DSKGPU_OK;
+}
+
+// Global partition ids: rank r's local partition p is partition p * n_ranks + r of the job, so `dsk/solid/<P>` stays one
+// flat list (utils/dsk2ascii.cpp:61,77) whatever the number of GPUs; rows ascend by k-mer value inside a partition.
+uint32_t dskgpu_group_num_partitions(const dskgpu_group* g) {
+    if (!g || !g->have_result) return 0;
+    return dskgpu_num_partitions(g->ctx[0]) * g->n;          // every rank uses the same nb_partitions
+}
+uint64_t dskgpu_group_partition_size(const dskgpu_group* g, uint32_t P) {
+    if (!g || !g->have_result) return 0;
+    return dskgpu_partition_size(g->ctx[P % g->n], P / g->n);
+}
+int dskgpu_group_partition_copy(const dskgpu_group* g, uint32_t P, uint64_t* kmers, uint32_t* abundance) {
+    if (!g) return DSKGPU_E_ARG;
+    if (!g->have_result) return DSKGPU_E_STATE;
+    return dskgpu_partition_copy(g->ctx[P % g->n], P / g->n, kmers, abundance);
+}
+
+}  // extern "C"

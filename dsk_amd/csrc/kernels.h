@@ -533,7 +533,12 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { const u32 i = i0 + u * SC_NT + threadIdx.x; if (i < ntile) out[(dbg & 128u) ? (u64)(blockIdx.x * Tile<W>::KEYS + i + (dd[u] & 1u)) : (u64)(dd[u] + i)] = hk[u]; }
+                    for (int u = 0; u < 4; ++u) {
+                        const u32 i = i0 + u * SC_NT + threadIdx.x;
+                        // OPT: nothing is ever written past the block's own slice of the bin (the overflow is reported at the end of the launch)
+                        const bool fits = !OPT || dd[u] + i < key_digit<MODE>(digit_word(hk[u]), ds) * o1.cap1 + (blockIdx.x + 1) * o1.slice;
+                        if (i < ntile && fits) out[(dbg & 128u) ? (u64)(blockIdx.x * Tile<W>::KEYS + i + (dd[u] & 1u)) : (u64)(dd[u] + i)] = hk[u];
+                    }
                 }
             }
             // no barrier here: the next tile's rank phase only touches cnt (zeroed
@@ -635,7 +640,9 @@ template <int W> struct ATile {
     static constexpr int KPT = 12 / W;           // 12288 one-word / 6144 two-word keys per tile = 96 KB
     static constexpr int KEYS = SC_NT * KPT;
 };
+#ifndef SLICED_MAX
 #define SLICED_MAX 320      // most level-1 slices per bin (= blocks of the level-1 launch: 256 CUs x 1) the level-2 loader can walk
+#endif
 __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
     const size_t key = 8 * (size_t)W, keys = (size_t)SC_NT * (12 / W), G = 8 / W;
     return keys * key + (size_t)P * (G - 1) * key + (size_t)(P + 1) * 4 + (size_t)P * 4 + (size_t)P * 12 + (size_t)P * 2 + 20 * 4 + 32
@@ -1050,6 +1057,200 @@ __global__ __launch_bounds__(CNT_NT) void k_count1(u64* keys, u64* solid_keys, c
     if (lane == 0 && ones) atomicAdd(&lh[1], ones);
     lds_barrier();
     for (int b = tid; b < CNT_LH; b += CNT_NT) {
+        const u32 v = lh[b];
+        if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
+    }
+    if (tid == 0 && ndist_acc) atomicAdd(&gstats[0], ndist_acc);
+}
+
+// ---- one-word keys in fixed-capacity regions: key and count share ONE 64-bit table word.
+// All keys of sub-partition q have their top 32 bits in a window of about 2^32 / F values above
+//   lo(q) <= ceil(2^32 * q / F)        (h_hi * P1 / 2^32 lies in [q / P2, (q + 1) / P2), see key_digit)
+// so rel = h - (lo(q) << 32) fits 51 bits whenever 2^32 / F + 4 < 2^19, and a region holds at most cap < 2^13
+// keys, so a count fits 13 bits:  word = (rel << 13) | count.  A duplicate (72 % of the inserts on the bench
+// workload) then costs one LDS read + one non-returning 64-bit add, a new key one read + one CAS; the separate
+// count array, its atomic and its sweep reads/writes are gone, and the table is 32 KB instead of 48 KB.  The
+// KPT keys of a thread probe in lock step (independent LDS reads issued together).
+#define CP_CBITS 13
+#define CP_CMASK 8191ull
+#define CP_MIN_F 8208u            // 2^32 / F + 4 < 2^19
+#ifndef CP_NT
+#define CP_NT 512
+#endif
+#ifndef CP_KPT
+#define CP_KPT 6                  // prefetched keys per thread (pairs, 16-byte loads): CP_NT * CP_KPT = 3072 keys
+#endif
+#ifndef CP_LST
+#define CP_LST CNT_SLOTS          // entries of the sweep list (>= CNT_MAXLOAD; more claims than that mean overflow anyway)
+#endif
+#ifndef CP_LH
+#define CP_LH CNT_LH              // histogram bins kept in LDS
+#endif
+#ifndef CP_WPS
+#define CP_WPS 6                  // waves per SIMD the register budget allows: 3 blocks of 512 threads per CU (43 KB of LDS each)
+#endif
+struct CountParamsP {
+    u32 F, amin, amax, histo_max, cap;
+    const u32* subcnt;
+    u64 finv;                 // floor((2^64 - 1) / F): lo(q) = umul64hi(q << 32, finv)  (<= the exact bound, by < 3)
+};
+
+// CAS first: the table is empty when a sub-partition starts, so a read before the CAS only costs a round trip.  A CAS
+// that finds the slot empty has claimed it with count 1 (nothing else to do), one that finds the key adds 1 with a
+// non-returning atomic, one that finds another key moves on.  The KPT CASes of a thread are independent and issued
+// back to back (one LDS round trip for all of them); claimed slots are appended to the sweep list with one atomic per
+// WAVE (ballot + prefix).
+template <int KPT>
+__device__ __forceinline__ void table_insert_packed(u64* tk, unsigned short* lst, u32* ctr, const u64 (&rel)[KPT], u32 live) {
+    const int lane = threadIdx.x & 63;
+    u32 slot[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) slot[j] = (u32)rel[j] & (CNT_SLOTS - 1);
+    for (int round = 0; __any(live != 0); ++round) {
+        u64 old[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+            if (live & (1u << j)) old[j] = atomicCAS(&tk[slot[j]], DSK_EMPTY, (rel[j] << CP_CBITS) | 1ull);
+        u64 mc[KPT]; u32 nclaim = 0;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const bool act = live & (1u << j);
+            const bool claimed = act && old[j] == DSK_EMPTY;
+            const bool same = act && !claimed && ((old[j] ^ (rel[j] << CP_CBITS)) <= CP_CMASK);
+            if (same) atomicAdd(&tk[slot[j]], 1ull);
+            if (claimed || same) live &= ~(1u << j);
+            mc[j] = __ballot(claimed);
+            nclaim += (u32)__popcll(mc[j]);
+        }
+        if (nclaim) {                                             // wave-uniform: one list reservation per wave and round
+            u64 any = 0;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) any |= mc[j];
+            const int leader = __ffsll((long long)any) - 1;       // a claiming lane is an active one
+            u32 base = 0;
+            if (lane == leader) base = atomicAdd(&ctr[0], nclaim);
+            base = __shfl(base, leader);
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const u32 i = base + (u32)__popcll(mc[j] & ((1ull << lane) - 1));
+                if (((mc[j] >> lane) & 1ull) && i < CP_LST) lst[i] = (unsigned short)slot[j];
+                base += (u32)__popcll(mc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) if (live & (1u << j)) slot[j] = (slot[j] + 1) & (CNT_SLOTS - 1);
+        if (round >= CNT_SLOTS) { ctr[2] = 1; break; }           // table full (reported; the host partitions finer)
+    }
+}
+
+template <int NT, int KPT>
+__global__ __launch_bounds__(NT, CP_WPS) void k_count1p(u64* keys, u64* solid_keys, u32* __restrict__ abund, u32* __restrict__ nsolid,
+                                                u64* __restrict__ ghist, u64* __restrict__ gstats,
+                                                u32* __restrict__ overflow, CountParamsP cp) {
+    static_assert(KPT % 2 == 0, "keys are prefetched in pairs");
+    __shared__ __attribute__((aligned(16))) u64 tk[CNT_SLOTS];
+    __shared__ unsigned short lst[CP_LST];
+    __shared__ u32 lh[CP_LH];
+    __shared__ u32 s_ctr[2][4];                 // [parity][ndist, out, ovf]
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int s = tid; s < CNT_SLOTS; s += NT) tk[s] = DSK_EMPTY;
+    for (int b = tid; b < CP_LH; b += NT) lh[b] = 0;
+    if (tid < 8) s_ctr[tid >> 2][tid & 3] = 0;
+    u32 ones = 0;          // lane 0 of each wave: abundance-1 keys seen (flushed at the end)
+    u64 ndist_acc = 0;
+    u32 q = blockIdx.x;
+    u32 n = 0;
+    u64 pk[KPT];
+    // pairs of keys, 16-byte loads; an index past the sub-partition's keys stays inside its region (cap is a multiple of 8)
+    auto prefetch = [&](u32 qq, u32 nn) {
+        const ulonglong2* base = reinterpret_cast<const ulonglong2*>(keys + (u64)qq * cp.cap);
+        const u32 last = (cp.cap >> 1) - 1;
+        if (nn) {
+#pragma unroll
+            for (int u = 0; u < KPT / 2; ++u) {
+                const u32 i = tid + u * NT;
+                const ulonglong2 v = base[i < last ? i : last];
+                pk[2 * u] = v.x; pk[2 * u + 1] = v.y;
+            }
+        }
+    };
+    if (q < cp.F) { n = cp.subcnt[q]; prefetch(q, n); }
+    lds_barrier();
+    int par = 0;
+    while (q < cp.F) {
+        u32* ctr = s_ctr[par];
+        const u64 lobase = __umul64hi((u64)q << 32, cp.finv) << 32;
+        const u64 begin = (u64)q * cp.cap;
+        {
+            u64 rel[KPT]; u32 live = 0;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const u32 i = 2u * (tid + (j >> 1) * NT) + (j & 1);
+                rel[j] = pk[j] - lobase;
+                live |= (i < n ? 1u : 0u) << j;
+            }
+            table_insert_packed<KPT>(tk, lst, ctr, rel, live);
+        }
+        for (u32 i0 = KPT * NT; i0 < n; i0 += NT) {                    // the rest of an oversized sub-partition
+            const u32 i = i0 + tid;
+            u64 rel[1] = {i < n ? keys[begin + i] - lobase : 0ull};
+            table_insert_packed<1>(tk, lst, ctr, rel, i < n ? 1u : 0u);
+        }
+        // prefetch the block's next sub-partition
+        const u32 qn = q + gridDim.x;
+        u32 nn = 0;
+        if (qn < cp.F) { nn = cp.subcnt[qn]; prefetch(qn, nn); }
+        lds_barrier();
+        const u32 nd = ctr[0];
+        const bool bad = ctr[2] || nd > CNT_MAXLOAD;           // block-uniform
+        if (bad) {
+            for (int s = tid; s < CNT_SLOTS; s += NT) tk[s] = DSK_EMPTY;
+            if (tid == 0) *overflow = 1;
+        } else {
+            for (u32 i0 = 0; i0 < nd; i0 += NT) {
+                const u32 i = i0 + tid;
+                const bool act = i < nd;
+                u64 key = 0; u32 c = 0;
+                if (act) {
+                    const u32 slot = lst[i];
+                    const u64 v = tk[slot];
+                    tk[slot] = DSK_EMPTY;
+                    c = (u32)(v & CP_CMASK); key = (v >> CP_CBITS) + lobase;
+                }
+                const u64 m1 = __ballot(act && c == 1);
+                if (lane == 0) ones += __popcll(m1);
+                if (act && c > 1) {
+                    const u32 bin = c < cp.histo_max ? c : cp.histo_max;
+                    if (bin < CP_LH) atomicAdd(&lh[bin], 1u);
+                    else atomicAdd(&ghist[bin], 1ull);
+                }
+                const bool solid = act && c >= cp.amin && c <= cp.amax;
+                const u64 ms = __ballot(solid);
+                if (ms) {
+                    u32 base = 0;
+                    if (lane == 0) base = atomicAdd(&ctr[1], (u32)__popcll(ms));
+                    base = __shfl(base, 0);
+                    if (solid) {
+                        const u32 pos = base + __popcll(ms & ((1ull << lane) - 1));
+                        solid_keys[begin + pos] = key;
+                        abund[begin + pos] = c;
+                    }
+                }
+            }
+        }
+        lds_barrier();
+        if (tid == 0) {
+            nsolid[q] = bad ? 0u : ctr[1];
+            ndist_acc += bad ? 0u : nd;
+            ctr[0] = 0; ctr[1] = 0; ctr[2] = 0;     // this parity is next used two barriers from now
+        }
+        par ^= 1;
+        q = qn; n = nn;
+    }
+    lds_barrier();
+    if (lane == 0 && ones) atomicAdd(&lh[1], ones);
+    lds_barrier();
+    for (int b = tid; b < CP_LH; b += NT) {
         const u32 v = lh[b];
         if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
     }

@@ -65,12 +65,15 @@ SOLIDITY = {"sum": 0, "min": 1, "max": 2, "one": 3, "all": 4, "custom": 5}
 
 # every symbol include/dskgpu.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "dskgpu_create", "dskgpu_destroy", "dskgpu_last_error", "dskgpu_version", "dskgpu_set_stream",
+    "dskgpu_create", "dskgpu_destroy", "dskgpu_last_error", "dskgpu_version", "dskgpu_device_count", "dskgpu_set_stream",
     "dskgpu_push_reads", "dskgpu_reserve_reads", "dskgpu_set_reads_device", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
     "dskgpu_count", "dskgpu_mg_scatter",
     "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_get_stats", "dskgpu_histogram",
     "dskgpu_num_partitions", "dskgpu_partition_size", "dskgpu_partition_copy", "dskgpu_result_device",
     "dskgpu_stage_times", "dskgpu_k_encode", "dskgpu_k_enumerate", "dskgpu_k_minimizers",
+    "dskgpu_group_create", "dskgpu_group_destroy", "dskgpu_group_last_error", "dskgpu_group_size", "dskgpu_group_ctx",
+    "dskgpu_group_transport", "dskgpu_group_count", "dskgpu_group_exchanged_words", "dskgpu_group_histogram",
+    "dskgpu_group_get_stats", "dskgpu_group_num_partitions", "dskgpu_group_partition_size", "dskgpu_group_partition_copy",
 ]
 
 _lib = None
@@ -124,14 +127,65 @@ def load_library():
     lib.dskgpu_k_encode.argtypes = [vp, vp, u64, vp, vp]
     lib.dskgpu_k_enumerate.argtypes = [vp, vp, u64, vp, vp]
     lib.dskgpu_k_minimizers.argtypes = [vp, vp, u64, vp, vp]
+    lib.dskgpu_group_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_int32), u32, C.POINTER(vp)]
+    lib.dskgpu_group_destroy.argtypes = [vp]
+    lib.dskgpu_group_destroy.restype = None
+    lib.dskgpu_group_last_error.argtypes = [vp]
+    lib.dskgpu_group_last_error.restype = C.c_char_p
+    lib.dskgpu_group_size.argtypes = [vp]
+    lib.dskgpu_group_size.restype = u32
+    lib.dskgpu_group_ctx.argtypes = [vp, u32]
+    lib.dskgpu_group_ctx.restype = vp
+    lib.dskgpu_group_transport.argtypes = [vp]
+    lib.dskgpu_group_transport.restype = C.c_char_p
+    lib.dskgpu_group_count.argtypes = [vp]
+    lib.dskgpu_group_exchanged_words.argtypes = [vp]
+    lib.dskgpu_group_exchanged_words.restype = u64
+    lib.dskgpu_group_histogram.argtypes = [vp, C.POINTER(u64), u32]
+    lib.dskgpu_group_get_stats.argtypes = [vp, C.POINTER(_Stats)]
+    lib.dskgpu_group_num_partitions.argtypes = [vp]
+    lib.dskgpu_group_num_partitions.restype = u32
+    lib.dskgpu_group_partition_size.argtypes = [vp, u32]
+    lib.dskgpu_group_partition_size.restype = u64
+    lib.dskgpu_group_partition_copy.argtypes = [vp, u32, vp, vp]
     for name in EXPORTS:          # every declared symbol must resolve (fails loudly on a stale build)
         getattr(lib, name)
     _lib = lib
     return lib
 
 
+def _make_config(kmer_size, abundance_min, abundance_max, histo_max, device, nb_partitions, timing, sort, world_size, rank,
+                 minimizer_size, max_pass_mkeys, solidity_kind, solidity_custom, histo2d, mg_explicit) -> "_Config":
+    cfg = _Config()
+    cfg.kmer_size = kmer_size
+    cfg.abundance_min = abundance_min
+    cfg.abundance_max = abundance_max
+    cfg.histo_max = histo_max
+    cfg.device = device
+    cfg.nb_partitions = nb_partitions
+    cfg.minimizer_size = minimizer_size
+    cfg.max_pass_mkeys = max_pass_mkeys
+    cfg.flags = (F_TIMING if timing else 0) | (0 if sort else F_NO_SORT) | (F_HISTO2D if histo2d else 0) | (F_MG_EXPLICIT if mg_explicit else 0)
+    cfg.solidity_kind = SOLIDITY[solidity_kind]
+    cfg.solidity_custom = solidity_custom
+    cfg.world_size = world_size
+    cfg.rank = rank
+    return cfg
+
+
 class KmerCounter:
     """One counting context on one GPU (not thread-safe; one per device)."""
+
+    @classmethod
+    def _borrowed(cls, handle, kmer_size: int, histo_max: int, world_size: int) -> "KmerCounter":
+        """A view of a ctx owned by somebody else (a KmerGroup rank): never destroyed from here."""
+        self = cls.__new__(cls)
+        self._lib = load_library()
+        self._h = C.c_void_p(handle)
+        self._owned = False
+        self.kmer_size, self.histo_max, self.world_size = kmer_size, histo_max, world_size
+        self.words = (kmer_size + 31) // 32
+        return self
 
     def __init__(self, kmer_size: int = 31, abundance_min: int = 2, abundance_max: int = 2147483647,
                  histo_max: int = 10000, device: int = 0, nb_partitions: int = 0, timing: bool = False,
@@ -139,20 +193,9 @@ class KmerCounter:
                  minimizer_size: int = 0, max_pass_mkeys: int = 0, solidity_kind: str = "sum", solidity_custom: int = 0,
                  histo2d: bool = False, mg_explicit: bool = False):
         self._lib = load_library()
-        cfg = _Config()
-        cfg.kmer_size = kmer_size
-        cfg.abundance_min = abundance_min
-        cfg.abundance_max = abundance_max
-        cfg.histo_max = histo_max
-        cfg.device = device
-        cfg.nb_partitions = nb_partitions
-        cfg.minimizer_size = minimizer_size
-        cfg.max_pass_mkeys = max_pass_mkeys
-        cfg.flags = (F_TIMING if timing else 0) | (0 if sort else F_NO_SORT) | (F_HISTO2D if histo2d else 0) | (F_MG_EXPLICIT if mg_explicit else 0)
-        cfg.solidity_kind = SOLIDITY[solidity_kind]
-        cfg.solidity_custom = solidity_custom
-        cfg.world_size = world_size
-        cfg.rank = rank
+        self._owned = True
+        cfg = _make_config(kmer_size, abundance_min, abundance_max, histo_max, device, nb_partitions, timing, sort, world_size, rank,
+                           minimizer_size, max_pass_mkeys, solidity_kind, solidity_custom, histo2d, mg_explicit)
         self.kmer_size = kmer_size
         self.histo_max = histo_max
         self.words = (kmer_size + 31) // 32          # 64-bit words of a k-mer at the ABI (1..4)
@@ -172,7 +215,8 @@ class KmerCounter:
 
     def close(self) -> None:
         if getattr(self, "_h", None):
-            self._lib.dskgpu_destroy(self._h)
+            if getattr(self, "_owned", True):
+                self._lib.dskgpu_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -286,6 +330,85 @@ class KmerCounter:
 
     def k_minimizers(self, d_bytes: int, nbytes: int, d_minim: int, d_valid: int) -> None:
         self._ck(self._lib.dskgpu_k_minimizers(self._h, C.c_void_p(d_bytes), nbytes, C.c_void_p(d_minim), C.c_void_p(d_valid)))
+
+
+class KmerGroup:
+    """N ranks of one sharded count inside this process (include/dskgpu.h: dskgpu_group_*): what `dsk -nb-gpus N` runs.
+    `rank(r)` is a KmerCounter view of rank r for feeding reads and reading that rank's rows."""
+
+    def __init__(self, devices, kmer_size: int = 31, abundance_min: int = 2, abundance_max: int = 2147483647,
+                 histo_max: int = 10000, nb_partitions: int = 0, timing: bool = False, sort: bool = True,
+                 minimizer_size: int = 0, max_pass_mkeys: int = 0, mg_explicit: bool = False):
+        self._lib = load_library()
+        devices = list(devices)
+        cfg = _make_config(kmer_size, abundance_min, abundance_max, histo_max, 0, nb_partitions, timing, sort, len(devices), 0,
+                           minimizer_size, max_pass_mkeys, "sum", 0, False, mg_explicit)
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self._lib.dskgpu_group_create(C.byref(cfg), devs, len(devices), C.byref(h))
+        if rc != 0:
+            raise DskGpuError(rc, self._lib.dskgpu_group_last_error(None).decode())
+        self._h = h
+        self.size = len(devices)
+        self.kmer_size, self.histo_max = kmer_size, histo_max
+        self.words = (kmer_size + 31) // 32
+        self._ranks = [KmerCounter._borrowed(self._lib.dskgpu_group_ctx(self._h, r), kmer_size, histo_max, self.size)
+                       for r in range(self.size)]
+
+    def _ck(self, rc: int) -> None:
+        if rc != 0:
+            raise DskGpuError(rc, self._lib.dskgpu_group_last_error(self._h).decode())
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            for r in self._ranks:
+                r._h = None
+            self._lib.dskgpu_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def rank(self, r: int) -> KmerCounter:
+        return self._ranks[r]
+
+    def transport(self) -> str:
+        return self._lib.dskgpu_group_transport(self._h).decode()
+
+    def count(self) -> None:
+        self._ck(self._lib.dskgpu_group_count(self._h))
+
+    def exchanged_words(self) -> int:
+        return int(self._lib.dskgpu_group_exchanged_words(self._h))
+
+    def histogram(self) -> np.ndarray:
+        out = np.zeros(self.histo_max + 1, dtype=np.uint64)
+        self._ck(self._lib.dskgpu_group_histogram(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), self.histo_max + 1))
+        return out
+
+    def stats(self) -> dict:
+        s = _Stats()
+        self._ck(self._lib.dskgpu_group_get_stats(self._h, C.byref(s)))
+        return {k: int(getattr(s, k)) for k, _ in _Stats._fields_ if k != "reserved"}
+
+    def num_partitions(self) -> int:
+        return int(self._lib.dskgpu_group_num_partitions(self._h))
+
+    def partition(self, p: int) -> Tuple[np.ndarray, np.ndarray]:
+        n = int(self._lib.dskgpu_group_partition_size(self._h, p))
+        kmers = np.zeros((n, self.words), dtype=np.uint64)
+        ab = np.zeros(n, dtype=np.uint32)
+        self._ck(self._lib.dskgpu_group_partition_copy(self._h, p, C.c_void_p(kmers.ctypes.data), C.c_void_p(ab.ctypes.data)))
+        return kmers, ab
 
 
 def kmer_to_string(value: int, k: int) -> str:

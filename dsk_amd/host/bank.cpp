@@ -10,6 +10,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <exception>
 #include <cstring>
 #include <fstream>
 #include <mutex>
@@ -177,15 +178,27 @@ private:
         cut[0] = p; cut[nthreads] = end;
         for (unsigned t = 1; t < nthreads; ++t) cut[t] = next_record_start(base, p + size * t / nthreads, end, kind);
         std::mutex mu; std::vector<uint64_t> counts(nthreads, 0); std::vector<std::thread> th;
+        // An exception of the sink (e.g. the engine running out of HBM) must not leave a worker thread: the first one
+        // is kept, the other workers' chunks are dropped from then on, and it is thrown again after the join, so the
+        // tool reports `EXCEPTION: <msg>` and exits with a failure code (src/main.cpp:42-46) instead of aborting.
+        std::exception_ptr failure; std::atomic<bool> stop(false);
+        const Sink guarded = [&](const char* d, size_t n) { if (!stop.load()) sink(d, n); };      // (called under `mu`)
         for (unsigned t = 0; t < nthreads; ++t)
             th.emplace_back([&, t]() {
                 if (cut[t] >= cut[t + 1]) return;
-                RecordParser ps(chunkBytes, &sink, &mu);
-                ps.feed(cut[t], (size_t)(cut[t + 1] - cut[t]));
-                ps.finish();
-                counts[t] = ps.nseq;
+                try {
+                    RecordParser ps(chunkBytes, &guarded, &mu);
+                    ps.feed(cut[t], (size_t)(cut[t + 1] - cut[t]));
+                    ps.finish();
+                    counts[t] = ps.nseq;
+                } catch (...) {
+                    stop = true;                       // (the throwing sink call held `mu`; it is released by now)
+                    std::lock_guard<std::mutex> g(mu);
+                    if (!failure) failure = std::current_exception();
+                }
             });
         for (auto& x : th) x.join();
+        if (failure) std::rethrow_exception(failure);
         uint64_t nseq = 0; for (auto c : counts) nseq += c;
         return nseq;
     }
@@ -315,10 +328,10 @@ private:
         std::vector<std::vector<char>> bufs(NB, std::vector<char>(BUF));
         std::vector<int> len(NB, 0);
         std::mutex mu; std::condition_variable cv;
-        size_t produced = 0, consumed = 0; bool done = false, failed = false;
+        size_t produced = 0, consumed = 0; bool done = false, failed = false, cancel = false;
         std::thread producer([&]() {
             for (;;) {
-                { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return produced - consumed < NB; }); }
+                { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return produced - consumed < NB || cancel; }); if (cancel) return; }
                 const size_t slot = produced % NB;
                 const int got = gzread(f, bufs[slot].data(), (unsigned)BUF);
                 std::lock_guard<std::mutex> g(mu);
@@ -327,16 +340,21 @@ private:
             }
         });
         RecordParser ps(chunkBytes, &sink, nullptr);
-        for (;;) {
-            { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return consumed < produced || done; }); if (consumed == produced && done) break; }
-            const size_t slot = consumed % NB;
-            ps.feed(bufs[slot].data(), (size_t)len[slot]);
-            { std::lock_guard<std::mutex> g(mu); ++consumed; } cv.notify_all();
+        try {
+            for (;;) {
+                { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return consumed < produced || done; }); if (consumed == produced && done) break; }
+                const size_t slot = consumed % NB;
+                ps.feed(bufs[slot].data(), (size_t)len[slot]);
+                { std::lock_guard<std::mutex> g(mu); ++consumed; } cv.notify_all();
+            }
+            producer.join();
+            gzclose(f);
+            if (failed) throw Exception("read error in file '%s'", path_.c_str());
+            ps.finish();
+        } catch (...) {                                // the sink threw: stop the inflate thread before this frame goes away
+            if (producer.joinable()) { { std::lock_guard<std::mutex> g(mu); cancel = true; } cv.notify_all(); producer.join(); gzclose(f); }
+            throw;
         }
-        producer.join();
-        gzclose(f);
-        if (failed) throw Exception("read error in file '%s'", path_.c_str());
-        ps.finish();
         return ps.nseq;
     }
     std::string path_;

@@ -22,6 +22,8 @@ struct CountConfig {
     unsigned solidity_kind = 0;   // 0 sum, 1 min, 2 max, 3 one, 4 all, 5 custom (include/dskgpu.h DSKGPU_SOLIDITY_*)
     unsigned solidity_custom = 0; // custom: bit b = bank b must hold the k-mer
     bool histo2d = false;         // also build the 2-D histogram (bank 0 = genome, others = reads)
+    unsigned nb_gpus = 1;         // -nb-gpus: ranks of the sharded count inside this process (k-mer space split by minimizer owner)
+    unsigned minimizer_size = 0;  // -minimizer-size (owner map of the multi-GPU exchange); 0 = engine default
 };
 
 class ICountBackend {

@@ -3,45 +3,98 @@
 // does its work in the reference (src/DSK.cpp:60).  C error codes become
 // dsk::Exception (src/main.cpp:42-46 prints "EXCEPTION: <msg>").
 #include "../../include/dskgpu.h"
+#include <algorithm>
+
 #include "count_backend.hpp"
 
 namespace dsk {
 
 namespace {
+// One GPU: a dskgpu_ctx.  -nb-gpus N: a dskgpu_group of N ranks inside this process (include/dskgpu.h) -- every push is
+// cut into N pieces at record borders (ingest data-parallel), the engine exchanges super-k-mer records between the ranks
+// (RCCL over xGMI) and every rank counts the k-mers it owns; the storage still gets ONE flat list of partitions
+// (global id = local id * N + rank) and one histogram (the sum), as after the reference's single execute() call.
 class GpuBackend : public ICountBackend {
 public:
-    GpuBackend() : ctx_(nullptr) {}
-    ~GpuBackend() override { if (ctx_) dskgpu_destroy(ctx_); }
+    GpuBackend() : ctx_(nullptr), grp_(nullptr) {}
+    ~GpuBackend() override { drop(); }
     std::string name() const override { return dskgpu_version(); }
     void configure(const CountConfig& c) override {
-        if (ctx_) { dskgpu_destroy(ctx_); ctx_ = nullptr; }
+        drop();
         dskgpu_config g{};
         g.kmer_size = c.kmer_size; g.abundance_min = c.abundance_min; g.abundance_max = c.abundance_max;
         g.histo_max = c.histo_max; g.device = c.device; g.nb_partitions = c.nb_partitions;
         g.flags = DSKGPU_F_TIMING | (c.histo2d ? DSKGPU_F_HISTO2D : 0u); g.world_size = 1; g.rank = 0;
-        g.solidity_kind = c.solidity_kind; g.solidity_custom = c.solidity_custom;
+        g.solidity_kind = c.solidity_kind; g.solidity_custom = c.solidity_custom; g.minimizer_size = c.minimizer_size;
         cfg_ = c;
+        if (c.nb_gpus > 1) {
+            if (c.solidity_kind != DSKGPU_SOLIDITY_SUM || c.histo2d)
+                throw Exception("-solidity-kind other than sum and -histo2D count the banks one by one: use -nb-gpus 1");
+            const int ndev = dskgpu_device_count();
+            if (ndev < 1) throw Exception("GPU engine: no HIP device");
+            std::vector<int32_t> devs(c.nb_gpus);
+            for (unsigned r = 0; r < c.nb_gpus; ++r) devs[r] = (int32_t)((c.device + (int)r) % ndev);   // fewer devices than ranks: ranks share
+            int rc = dskgpu_group_create(&g, devs.data(), c.nb_gpus, &grp_);
+            if (rc != DSKGPU_OK) { std::string m = dskgpu_group_last_error(nullptr); grp_ = nullptr; throw Exception("GPU engine: %s (code %d)", m.c_str(), rc); }
+            pushed_.assign(c.nb_gpus, 0);
+            return;
+        }
         int rc = dskgpu_create(&g, &ctx_);
         if (rc != DSKGPU_OK) { std::string m = dskgpu_last_error(nullptr); ctx_ = nullptr; throw Exception("GPU engine: %s (code %d)", m.c_str(), rc); }
     }
-    void reserve(uint64_t n) override { ck(dskgpu_reserve_reads(ctx_, n)); }
-    void push(const char* data, size_t n) override { ck(dskgpu_push_reads(ctx_, data, n)); }
-    void nextBank() override { ck(dskgpu_next_bank(ctx_)); }
-    void finish() override { ck(dskgpu_count(ctx_)); }
-    void histogram(std::vector<uint64_t>& h) override { h.assign(cfg_.histo_max + 1, 0); ck(dskgpu_histogram(ctx_, h.data(), cfg_.histo_max + 1)); }
+    void reserve(uint64_t n) override {
+        if (!grp_) { ck(dskgpu_reserve_reads(ctx_, n)); return; }
+        const uint32_t N = dskgpu_group_size(grp_);
+        for (uint32_t r = 0; r < N; ++r) ckr(r, dskgpu_reserve_reads(dskgpu_group_ctx(grp_, r), n / N + n / (8 * N) + 4096));
+    }
+    void push(const char* data, size_t n) override {
+        if (!grp_) { ck(dskgpu_push_reads(ctx_, data, n)); return; }
+        // N pieces cut at record separators; the rank that has received least so far gets the first (largest) one
+        const uint32_t N = dskgpu_group_size(grp_);
+        uint32_t r = 0;
+        for (uint32_t i = 1; i < N; ++i) if (pushed_[i] < pushed_[r]) r = i;
+        size_t beg = 0;
+        for (uint32_t i = 0; i < N && beg < n; ++i, r = (r + 1) % N) {
+            size_t end = i + 1 == N ? n : std::max(beg, n * (i + 1) / N);
+            while (end < n && data[end - 1] != '\n') ++end;          // a piece ends after a separator: k-mers never span pieces
+            if (end == beg) continue;
+            ckr(r, dskgpu_push_reads(dskgpu_group_ctx(grp_, r), data + beg, end - beg));
+            pushed_[r] += end - beg;
+            beg = end;
+        }
+    }
+    void nextBank() override { if (!grp_) ck(dskgpu_next_bank(ctx_)); }      // (banks only matter to the per-bank modes: one GPU)
+    void finish() override {
+        if (!grp_) { ck(dskgpu_count(ctx_)); return; }
+        const int rc = dskgpu_group_count(grp_);
+        if (rc != DSKGPU_OK) throw Exception("GPU engine: %s (code %d)", dskgpu_group_last_error(grp_), rc);
+    }
+    void histogram(std::vector<uint64_t>& h) override {
+        h.assign(cfg_.histo_max + 1, 0);
+        if (grp_) { const int rc = dskgpu_group_histogram(grp_, h.data(), cfg_.histo_max + 1); if (rc) throw Exception("GPU engine: histogram (code %d)", rc); }
+        else ck(dskgpu_histogram(ctx_, h.data(), cfg_.histo_max + 1));
+    }
     void histogram2d(std::vector<uint64_t>& h) override {
         h.clear();
-        if (!cfg_.histo2d) return;
+        if (!cfg_.histo2d || grp_) return;
         h.assign((size_t)(cfg_.histo_max + 1) * 11, 0);
         if (dskgpu_histogram2d(ctx_, h.data(), cfg_.histo_max + 1) != DSKGPU_OK) h.clear();   // single bank: nothing to cross
     }
-    uint32_t numPartitions() override { return dskgpu_num_partitions(ctx_); }
-    uint64_t partitionSize(uint32_t p) override { return dskgpu_partition_size(ctx_, p); }
-    void partitionCopy(uint32_t p, uint64_t* kmers, uint32_t* ab) override { ck(dskgpu_partition_copy(ctx_, p, kmers, ab)); }
+    uint32_t numPartitions() override { return grp_ ? dskgpu_group_num_partitions(grp_) : dskgpu_num_partitions(ctx_); }
+    uint64_t partitionSize(uint32_t p) override { return grp_ ? dskgpu_group_partition_size(grp_, p) : dskgpu_partition_size(ctx_, p); }
+    void partitionCopy(uint32_t p, uint64_t* kmers, uint32_t* ab) override {
+        if (grp_) { const int rc = dskgpu_group_partition_copy(grp_, p, kmers, ab); if (rc) throw Exception("GPU engine: partition %u (code %d)", p, rc); }
+        else ck(dskgpu_partition_copy(ctx_, p, kmers, ab));
+    }
     void stats(IProperties& info, size_t d) override {
         dskgpu_stats s{};
-        if (dskgpu_get_stats(ctx_, &s) != DSKGPU_OK) return;
+        if ((grp_ ? dskgpu_group_get_stats(grp_, &s) : dskgpu_get_stats(ctx_, &s)) != DSKGPU_OK) return;
         info.add(d, "engine", "%s", dskgpu_version());
+        if (grp_) {
+            info.add(d, "nb_gpus", "%u", dskgpu_group_size(grp_));
+            info.add(d, "exchange_transport", "%s", dskgpu_group_transport(grp_));
+            info.add(d, "exchange_bytes", "%llu", (unsigned long long)dskgpu_group_exchanged_words(grp_) * 8ull);
+        }
         info.add(d, "bytes_read_stream", "%llu", (unsigned long long)s.n_bytes);
         info.add(d, "kmers_nb_valid", "%llu", (unsigned long long)s.n_kmers);
         info.add(d, "kmers_nb_distinct", "%llu", (unsigned long long)s.n_distinct);
@@ -51,15 +104,17 @@ public:
         info.add(d, "hash_sub_partitions", "%u", s.n_final_bins);
         info.add(d, "overflow_retries", "%u", s.n_retries);
         const char* names[64]; float ms[64];
-        int n = dskgpu_stage_times(ctx_, names, ms, 64);
+        int n = dskgpu_stage_times(grp_ ? dskgpu_group_ctx(grp_, 0) : ctx_, names, ms, 64);
         if (n > 0) {
-            info.add(d, "gpu_stage_ms");
+            info.add(d, grp_ ? "gpu_stage_ms_rank0" : "gpu_stage_ms");
             for (int i = 0; i < n && i < 64; ++i) info.add(d + 1, names[i], "%.3f", ms[i]);
         }
     }
 private:
+    void drop() { if (ctx_) dskgpu_destroy(ctx_); if (grp_) dskgpu_group_destroy(grp_); ctx_ = nullptr; grp_ = nullptr; }
     void ck(int rc) { if (rc != DSKGPU_OK) throw Exception("GPU engine: %s (code %d)", dskgpu_last_error(ctx_), rc); }
-    dskgpu_ctx* ctx_; CountConfig cfg_;
+    void ckr(uint32_t r, int rc) { if (rc != DSKGPU_OK) throw Exception("GPU engine, rank %u: %s (code %d)", r, dskgpu_last_error(dskgpu_group_ctx(grp_, r)), rc); }
+    dskgpu_ctx* ctx_; dskgpu_group* grp_; CountConfig cfg_; std::vector<uint64_t> pushed_;
 };
 }  // namespace
 

@@ -48,7 +48,8 @@ IOptionsParser* SortingCountBase::makeOptionsParser() {
     p->push_back(new OptionOneParam("-minimizer-size", "size of a minimizer", false, "10", false));
     p->push_back(new OptionOneParam("-repartition-type", "minimizer repartition; accepted, does not change results", false, "0", false));
     p->push_back(new OptionOneParam("-nb-partitions", "number of output partitions under dsk/solid (0 = default)", false, "0", false));
-    p->push_back(new OptionOneParam("-device", "GPU ordinal", false, "0", false));
+    p->push_back(new OptionOneParam("-device", "GPU ordinal (first one with -nb-gpus)", false, "0", false));
+    p->push_back(new OptionOneParam("-nb-gpus", "number of GPUs sharing the k-mer space (power of two; ranks share devices when the node has fewer)", false, "1", false));
     return p;
 }
 
@@ -101,6 +102,8 @@ void SortingCountBase::execute() {
     cfg.histo_max = input_.has(STR_HISTOGRAM_MAX) ? (unsigned)input_.getInt(STR_HISTOGRAM_MAX) : 10000u;
     cfg.nb_partitions = input_.has("-nb-partitions") ? (unsigned)input_.getInt("-nb-partitions") : 0u;
     cfg.device = input_.has("-device") ? (int)input_.getInt("-device") : 0;
+    cfg.nb_gpus = input_.has("-nb-gpus") ? (unsigned)std::max<long long>(1, input_.getInt("-nb-gpus")) : 1u;
+    cfg.minimizer_size = input_.has("-minimizer-size") ? (unsigned)std::max<long long>(0, input_.getInt("-minimizer-size")) : 0u;
     {   // -solidity-kind / -solidity-custom / -histo2D: per-bank counts (banks = the comma-separated inputs)
         const std::string kind = input_.has("-solidity-kind") ? input_.getStr("-solidity-kind") : "sum";
         static const char* names[] = {"sum", "min", "max", "one", "all", "custom"};
@@ -156,7 +159,9 @@ void SortingCountBase::execute() {
                 if (i >= subs.size()) return;
                 try {
                     seqs += subs[i]->stream((size_t)32 << 20, [&](const char* d, size_t n) { std::lock_guard<std::mutex> g(mu); be->push(d, n); nbytes += n; });
-                } catch (Exception& e) { std::lock_guard<std::mutex> g(mu); err = e.getMessage(); }
+                } catch (Exception& e) { std::lock_guard<std::mutex> g(mu); if (err.empty()) err = e.getMessage(); next = subs.size(); }
+                catch (std::exception& e) { std::lock_guard<std::mutex> g(mu); if (err.empty()) err = e.what(); next = subs.size(); }
+                catch (...) { std::lock_guard<std::mutex> g(mu); if (err.empty()) err = "unknown failure while reading the input"; next = subs.size(); }
             }
         };
         const unsigned nt = (unsigned)std::min<size_t>(subs.size(), std::max(1u, Bank::parseThreads()));

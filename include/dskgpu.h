@@ -82,6 +82,7 @@ int  dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out);
 void dskgpu_destroy(dskgpu_ctx* ctx);
 const char* dskgpu_last_error(const dskgpu_ctx* ctx);   /* ctx may be NULL: create-time error */
 const char* dskgpu_version(void);
+int dskgpu_device_count(void);                          /* HIP devices visible to this process (0 when there is none) */
 
 /* Launch all device work of this ctx on an existing HIP stream (hipStream_t
  * passed as void*); NULL = a stream owned by the ctx. */
@@ -163,6 +164,33 @@ int dskgpu_result_device(const dskgpu_ctx* ctx, const void** d_kmers, const void
 /* Per-stage device time of the last count (flag DSKGPU_F_TIMING).  Returns the
  * number of stages; fills up to `cap` entries.  names[i] are static strings. */
 int dskgpu_stage_times(const dskgpu_ctx* ctx, const char** names, float* ms, int cap);
+
+/* ---- the same call on N GPUs of one node, inside ONE process (what `dsk -nb-gpus N` runs): the reference's
+ * single `execute()` (src/DSK.cpp:55-60) still leaves ONE storage with a flat list of solid partitions
+ * (utils/dsk2ascii.cpp:61,77).  A group owns one ctx per rank (world_size = n_ranks, rank r on devices[r], its own
+ * stream and host thread).  Feed every rank its share of the reads through dskgpu_group_ctx(g, r) with the input
+ * calls above (any split of whole records is valid: counting is a group-by on the canonical k-mer), then
+ * dskgpu_group_count runs mg_scatter -> exchange -> mg_count on all ranks at once.  The exchange is an
+ * all-to-all-v of super-k-mer records: grouped ncclSend / ncclRecv over RCCL (one communicator per rank from
+ * ncclCommInitAll; librccl is loaded on first use) when every rank has its own device, device-to-device copies
+ * when ranks share a device (RCCL refuses duplicate devices: the multi-rank tests on a 1-GPU box).
+ * DSKGPU_GROUP_TRANSPORT=rccl|copy (environment, read at create) overrides the choice.  n_ranks: power of two <= 64.
+ * cfg->device / world_size / rank are ignored (set per rank).  Results: per rank through dskgpu_group_ctx, or merged:
+ * the histogram is the element-wise sum; global partition P = p * n_ranks + r is local partition p of rank r. */
+typedef struct dskgpu_group dskgpu_group;
+int  dskgpu_group_create(const dskgpu_config* cfg, const int32_t* devices, uint32_t n_ranks, dskgpu_group** out);
+void dskgpu_group_destroy(dskgpu_group* g);
+const char* dskgpu_group_last_error(const dskgpu_group* g);   /* g may be NULL: create-time error */
+uint32_t dskgpu_group_size(const dskgpu_group* g);
+dskgpu_ctx* dskgpu_group_ctx(dskgpu_group* g, uint32_t rank);
+const char* dskgpu_group_transport(const dskgpu_group* g);     /* "rccl" or "copy" */
+int dskgpu_group_count(dskgpu_group* g);
+uint64_t dskgpu_group_exchanged_words(const dskgpu_group* g);  /* 8-byte words that changed rank in the last count */
+int dskgpu_group_histogram(const dskgpu_group* g, uint64_t* out, uint32_t nbins);
+int dskgpu_group_get_stats(const dskgpu_group* g, dskgpu_stats* out);   /* sums over the ranks */
+uint32_t dskgpu_group_num_partitions(const dskgpu_group* g);
+uint64_t dskgpu_group_partition_size(const dskgpu_group* g, uint32_t P);
+int dskgpu_group_partition_copy(const dskgpu_group* g, uint32_t P, uint64_t* kmers, uint32_t* abundance);
 
 /* ---- kernel-level entry points used by the parity tests (device pointers) */
 /* ASCII -> 2-bit packed words + invalid mask, one u64 / u32 per 32 bases. */

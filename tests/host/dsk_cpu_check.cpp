@@ -6,6 +6,7 @@
 // only and has no such fallback.
 #include <algorithm>
 #include <array>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -18,7 +19,11 @@ public:
     ~OracleBackend() override { if (r_) dsko_free(r_); }
     std::string name() const override { return "cpu-oracle (test only)"; }
     void configure(const dsk::CountConfig& c) override { cfg_ = c; }
-    void push(const char* d, size_t n) override { stream_.insert(stream_.end(), d, d + n); stream_.push_back('\n'); }
+    void push(const char* d, size_t n) override {
+        // test hook: behave like an engine that runs out of memory after so many bytes (error path of the bank threads)
+        if (const char* e = getenv("DSK_TEST_FAIL_AFTER_BYTES")) if (stream_.size() + n > (size_t)atoll(e)) throw dsk::Exception("test backend: out of memory after %zu bytes", stream_.size());
+        stream_.insert(stream_.end(), d, d + n); stream_.push_back('\n');
+    }
     void nextBank() override { if (ends_.empty() || ends_.back() != stream_.size()) ends_.push_back(stream_.size()); }
     void finish() override {
         words_ = (cfg_.kmer_size + 31) / 32;

@@ -48,3 +48,36 @@ def test_engine_is_the_hip_library(bins, tmp_path):
 def test_solidity_kinds_and_histo2d_cli_on_gpu(bins, tmp_path, oracle):
     from tests.test_host_cli import run_solidity_cases
     run_solidity_cases(bins["dsk"], bins["dsk2ascii"], str(tmp_path), oracle)
+
+
+@pytest.mark.parametrize("ngpus", [2, 4])
+def test_nb_gpus_writes_one_storage(bins, tmp_path, ngpus):
+    """`dsk -nb-gpus N` (ranks share device 0 on the 1-GPU box): ONE .h5 with a flat list of partitions and the summed
+    histogram, as after the reference's single execute() (src/DSK.cpp:55-68; utils/dsk2ascii.cpp:61,77) -- reproduces
+    test/k27.histo and the k = 31 known-answer md5 (lines put in k-mer order first: the partitions interleave)."""
+    import hashlib
+    from tests.test_host_cli import G, h5_histo, H5DUMP
+    tmp = str(tmp_path)
+    out = subprocess.run([bins["dsk"], "-file", f"{G}/read50x_ref10K_e001.fasta.gz", "-kmer-size", "27", "-out", "mg27", "-nb-gpus", str(ngpus), "-verbose", "1"],
+                         cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert out.returncode == 0, out.stderr
+    assert h5_histo("mg27.h5", tmp) == open(f"{G}/k27.histo").read()
+    assert f"nb_gpus" in out.stdout.decode() and "exchange_bytes" in out.stdout.decode()
+    files = ",".join(f"{G}/c{i}.fasta.gz" for i in (1, 2, 3, 4))          # the same reads as four files (simple_test.sh:52)
+    subprocess.check_call([bins["dsk"], "-file", files, "-kmer-size", "31", "-abundance-min", "2", "-out", "mg31", "-nb-gpus", str(ngpus), "-nb-partitions", "2", "-verbose", "0"], cwd=tmp)
+    hdr = subprocess.check_output([H5DUMP, "-n", "mg31.h5"], cwd=tmp).decode()
+    for p in range(2 * ngpus):
+        assert f"/dsk/solid/{p}\n" in hdr or f"/dsk/solid/{p} " in hdr or hdr.rstrip().endswith(f"/dsk/solid/{p}")
+    assert f"/dsk/solid/{2 * ngpus}" not in hdr
+    subprocess.check_call([bins["dsk2ascii"], "-file", "mg31.h5", "-out", "mg31.txt", "-verbose", "0"], cwd=tmp)
+    lines = open(os.path.join(tmp, "mg31.txt"), "rb").read().splitlines()
+    assert len(lines) == 13096
+    val = lambda l: int(l.split()[0].translate(bytes.maketrans(b"ACTG", b"0123")), 4)
+    lines.sort(key=val)
+    assert hashlib.md5(b"\n".join(lines) + b"\n").hexdigest() == "5b4da4c690bb00783eb5fdc49fc19466"
+
+
+def test_abundance_min_auto_on_gpu(bins, tmp_path, oracle):
+    """f2 through the HIP binary: `-abundance-min auto` -> cutoff / nbsolids_auto attributes and the filtered rows."""
+    from tests.test_host_cli import run_abundance_min_auto
+    run_abundance_min_auto(bins, str(tmp_path), oracle)

@@ -681,3 +681,79 @@ def test_solidity_two_word_and_push_path(oracle, golden_dir, dev):
         assert (kc.histogram() == want_h).all() and (kc.histogram2d() == want_h2).all()
     vals = np.array([(int(h) << 64) | int(l) for l, h in zip(kmers[:, 0], kmers[:, 1])], dtype=object)
     assert (vals == want_k).all() and (ab == want_a).all()
+
+
+@pytest.mark.parametrize("ranks,k,transport,explicit", [(2, 31, "copy", False), (4, 27, "copy", False), (2, 63, "copy", False), (8, 20, "copy", False),
+                                                        (2, 31, "copy", True), (1, 31, "rccl", False), (1, 63, "rccl", False), (1, 31, "copy", False)])
+def test_group_count_in_one_process(oracle, golden_dir, dev, monkeypatch, ranks, k, transport, explicit):
+    """dskgpu_group_*: what `dsk -nb-gpus N` runs -- N ranks inside one process, the exchange inside the library.  On the
+    1-GPU box several ranks share device 0 (transport "copy"); the single-rank cases with transport "rccl" push the
+    degenerate exchange (every record to owner 0) through librccl's grouped ncclSend / ncclRecv."""
+    from dsk_amd import KmerGroup
+    monkeypatch.setenv("DSKGPU_GROUP_TRANSPORT", transport)
+    s, _ = oracle.load_bank(os.path.join(golden_dir, "read50x_ref10K_e001.fasta.gz"))
+    recs = bytes(s).split(b"\n")
+    ref = oracle.count(s, k)
+    with KmerGroup([0] * ranks, kmer_size=k, abundance_min=2, nb_partitions=3, mg_explicit=explicit) as g:
+        assert g.transport() == transport
+        for r in range(ranks):
+            g.rank(r).push_reads(b"\n".join(recs[r::ranks]) + b"\n")
+        for rep in range(2):                                     # a second count reuses the buffers
+            g.count()
+            st = g.stats()
+            assert st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct
+            assert (g.histogram() == ref.histogram(10000)).all()
+            assert g.num_partitions() == 3 * ranks
+            ks, abs_ = [], []
+            for p in range(g.num_partitions()):
+                kk, aa = g.partition(p)
+                key = kk[:, 0] if k <= 32 else kk[:, 1].astype(object) * (1 << 64) + kk[:, 0].astype(object)
+                assert all(key[i] < key[i + 1] for i in range(len(key) - 1))      # ascending inside every partition
+                ks.append(kk); abs_.append(aa)
+            kk = np.concatenate(ks); aa = np.concatenate(abs_)
+            order = np.argsort(kk[:, 0]) if k <= 32 else np.lexsort((kk[:, 0], kk[:, 1]))
+            lo, hi, rab = ref.solid(2)
+            assert (kk[order, 0] == lo).all() and (aa[order] == rab).all()
+            if k > 32:
+                assert (kk[order, 1] == hi).all()
+            if ranks > 1:
+                assert g.exchanged_words() > 0
+                per_rank = [g.rank(r).stats()["n_kmers"] for r in range(ranks)]
+                assert sum(per_rank) == ref.total and min(per_rank) > 0
+
+
+def test_exchange_over_rccl_single_rank(oracle, golden_dir, dev):
+    """The `nccl` branch of dsk_amd.multi.exchange (variable-size all_to_all_single on device tensors) and the whole
+    ShardedCounter step under init_process_group("nccl", world_size=1): ragged, empty and repeated exchanges."""
+    import socket
+    import torch.distributed as dist
+    from dsk_amd import KmerCounter
+    from dsk_amd.multi import ShardedCounter, exchange, gather_histogram
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        for n in (0, 1, 7, 100_003):
+            send = torch.arange(n + 5, dtype=torch.int64, device=dev)
+            out, rc = exchange(send, [n])
+            assert rc == [n] and out.numel() == n and (out == send[:n]).all()
+        recv = torch.empty(10, dtype=torch.int64, device=dev)          # a receive buffer that is too small is replaced
+        out, rc = exchange(torch.arange(1000, dtype=torch.int64, device=dev), [1000], recv=recv)
+        assert out.numel() == 1000 and int(out[-1]) == 999
+        s, _ = oracle.load_bank(os.path.join(golden_dir, "read50x_ref10K_e001.fasta.gz"))
+        t = torch.from_numpy(s).to(dev)
+        for k in (31, 63, 15):
+            ref = oracle.count(s, k)
+            with KmerCounter(kmer_size=k, abundance_min=2, world_size=1, rank=0, stream=torch.cuda.current_stream().cuda_stream) as kc:
+                kc.set_reads_device(t.data_ptr(), t.numel())
+                sc = ShardedCounter(kc, dev)
+                for _ in range(2):
+                    sc.count()
+                    kk, aa = kc.rows()
+                    lo, hi, rab = ref.solid(2)
+                    assert (kk[:, 0] == lo).all() and (aa == rab).all()
+                    h = gather_histogram(torch.from_numpy(kc.histogram().astype(np.int64)).to(dev))
+                    assert (h.cpu().numpy().astype(np.uint64) == ref.histogram(10000)).all()
+                    assert sc.last_send_counts == sc.last_recv_counts and sum(sc.last_send_counts) > 0
+    finally:
+        dist.destroy_process_group()

@@ -171,7 +171,10 @@ def test_dsk2ascii_variants(bins, tmp_path):
 
 
 def test_abundance_min_auto(bins, tmp_path, oracle):
-    tmp = str(tmp_path)
+    run_abundance_min_auto(bins, str(tmp_path), oracle)
+
+
+def run_abundance_min_auto(bins, tmp, oracle):
     subprocess.check_call([bins["dsk"], "-file", f"{G}/read50x_ref10K_e001.fasta.gz", "-kmer-size", "27", "-abundance-min", "auto",
                            "-out", "auto", "-verbose", "0"], cwd=tmp)
     cutoff = subprocess.check_output([H5DUMP, "-a", "/histogram/cutoff", "auto.h5"], cwd=tmp).decode()
@@ -181,8 +184,12 @@ def test_abundance_min_auto(bins, tmp_path, oracle):
     while h[i + 1] < h[i]:
         i += 1
     assert f'"{i}"' in cutoff
+    nbs = subprocess.check_output([H5DUMP, "-a", "/histogram/nbsolids_auto", "auto.h5"], cwd=tmp).decode()
+    assert f'"{int(h[i:].sum())}"' in nbs
     subprocess.check_call([bins["dsk2ascii"], "-file", "auto", "-out", "auto.txt", "-verbose", "0"], cwd=tmp)
-    assert sum(1 for _ in open(os.path.join(tmp, "auto.txt"))) == int(h[i:].sum())
+    rows = open(os.path.join(tmp, "auto.txt")).read().splitlines()
+    assert len(rows) == int(h[i:].sum())
+    assert rows == oracle.ascii_lines(oracle.count(s, 27), amin=i)      # exactly the k-mers at or above the cutoff
 
 
 def test_parallel_parser_equals_serial(bins, tmp_path):
@@ -216,6 +223,37 @@ def test_parallel_parser_equals_serial(bins, tmp_path):
             subprocess.check_call([bins["dsk2ascii"], "-file", f"o{cores}", "-out", f"o{cores}.txt", "-verbose", "0"], cwd=tmp)
             md5.append(hashlib.md5(open(os.path.join(tmp, f"o{cores}.txt"), "rb").read()).hexdigest())
         assert md5[0] == md5[1], fn
+
+
+def test_engine_failure_in_bank_threads_is_reported(bins, tmp_path):
+    """An exception thrown by the counting engine while the bank's worker threads feed it (e.g. HBM exhausted by
+    dskgpu_push_reads) must surface as `EXCEPTION: <msg>` + exit code 1 (src/main.cpp:42-46), not abort the process:
+    memory-mapped multi-thread parse, BGZF slabs, the gzip pipeline and the multi-file thread pool."""
+    import gzip
+    import random
+    random.seed(11)
+    tmp = str(tmp_path)
+    recs = "".join(f"@r{i}\n{''.join(random.choice('ACGT') for _ in range(100))}\n+\n{'I' * 100}\n" for i in range(30000))
+    open(os.path.join(tmp, "f.fastq"), "w").write(recs)
+    with gzip.open(os.path.join(tmp, "f.fastq.gz"), "wt") as f:
+        f.write(recs)
+    with open(os.path.join(tmp, "b.fastq.gz"), "wb") as f:               # BGZF: independent gzip members with a BC extra field
+        import struct
+        import zlib
+        data = recs.encode()
+        for off in range(0, len(data), 60000):
+            blk = data[off:off + 60000]
+            c = zlib.compressobj(6, zlib.DEFLATED, -15); body = c.compress(blk) + c.flush()
+            f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(blk), len(blk)))
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    env = dict(os.environ, DSK_PARSE_MIN_BYTES="1", DSK_TEST_FAIL_AFTER_BYTES="500000")
+    for files in ("f.fastq", "f.fastq.gz", "b.fastq.gz", "f.fastq,f.fastq.gz,b.fastq.gz"):
+        r = subprocess.run([bins["dsk"], "-file", files, "-kmer-size", "21", "-out", "x", "-verbose", "0", "-nb-cores", "6"], cwd=tmp, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 1, (files, r.returncode, r.stderr[-300:])
+        assert b"EXCEPTION: test backend: out of memory" in r.stderr, (files, r.stderr[-300:])
+    ok = subprocess.run([bins["dsk"], "-file", "b.fastq.gz", "-kmer-size", "21", "-out", "y", "-verbose", "0"], cwd=tmp, env=dict(os.environ, DSK_PARSE_MIN_BYTES="1"))
+    assert ok.returncode == 0
 
 
 def test_kmer_model_unit(bins):
