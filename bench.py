@@ -26,7 +26,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0   # MI355X_MICROARCH.md: measured float4 copy (79 % of spec)
 
 
 def parse():
@@ -40,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
     ap.add_argument("--no-sort", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file -> .h5 wall-clock block (dsk binary)")
     return ap.parse_args()
 
 
@@ -86,16 +88,144 @@ def cpu_baseline(reads_u8, read_len, n_sample_reads, k, target_s=15.0):
         t0 = time.perf_counter()
         r = oracle.count(sample, k, threads=cores)
         dt = time.perf_counter() - t0
+    # the same code on ONE thread, on a sample sized for a few seconds (DSK v1's published rates are 1-thread)
+    n1 = max(1000, min(n_reads, int(n_reads * 6.0 / max(dt, 1e-3) / max(cores, 1)) * 4))
+    s1 = reads_u8[: n1 * (read_len + 1)].cpu().numpy()
+    t0 = time.perf_counter()
+    r1 = oracle.count(s1, k, threads=1)
+    dt1 = time.perf_counter() - t0
     return {
         "value": r.distinct / dt,
         "unit": "distinct k-mers/s",
         "kmer_occurrences_per_s": r.total / dt,
         "cores": cores,
+        "one_thread": {"value": r1.distinct / dt1, "kmer_occurrences_per_s": r1.total / dt1, "cores": 1,
+                       "sample": f"first {n1} reads, {dt1:.2f} s"},
         "kind": "port",
         "sample": f"first {n_reads} reads of the same synthetic stream ({r.total} k-mer occurrences, "
                   f"{r.distinct} distinct), oracle/dsk_oracle.c partition+sort-count, {cores} threads, {dt:.2f} s",
         "note": "CPU restatement of DSK's method, NOT GATB/dsk (gatb-core submodule absent => reference unbuildable)",
     }
+
+
+def write_fastq(reads_u8, n_reads, read_len, path):
+    """The reads as a 4-line FASTQ file (id @r<idx>, quality I x read_len), built as one byte
+    matrix on the GPU (fixed-width ids) and written in a few large pieces."""
+    import torch
+    dev = reads_u8.device
+    hdr = 10                                            # "@r" + 8 digits
+    rec = hdr + 1 + read_len + 1 + 2 + read_len + 1
+    step = 1 << 20
+    with open(path, "wb") as f:
+        for r0 in range(0, n_reads, step):
+            r = min(step, n_reads - r0)
+            m = torch.empty((r, rec), dtype=torch.uint8, device=dev)
+            m[:, 0] = 64; m[:, 1] = 114                  # '@' 'r'
+            idx = torch.arange(r0, r0 + r, device=dev, dtype=torch.int64)
+            for d in range(8):
+                m[:, 2 + d] = ((idx // 10 ** (7 - d)) % 10 + 48).to(torch.uint8)
+            m[:, hdr] = 10
+            m[:, hdr + 1: hdr + 1 + read_len] = reads_u8[r0 * (read_len + 1): (r0 + r) * (read_len + 1)].view(r, read_len + 1)[:, :read_len]
+            m[:, hdr + 1 + read_len] = 10
+            m[:, hdr + 2 + read_len] = 43                # '+'
+            m[:, hdr + 3 + read_len] = 10
+            m[:, hdr + 4 + read_len: hdr + 4 + 2 * read_len] = 73     # 'I'
+            m[:, rec - 1] = 10
+            f.write(m.cpu().numpy().tobytes())
+    return os.path.getsize(path)
+
+
+def e2e_block(k, amin, budget_s=150.0):
+    """File -> .h5 wall clock of the `dsk` binary (HIP engine through the C-ABI): best of 3, page cache warm, on the
+    E. coli-like 50x stand-in (plain FASTQ, gzip, BGZF) and on the bench workload itself (plain FASTQ); next to it the
+    CPU restatement's CLI on the same E. coli file (all cores, and one thread).  north_star: >= 10x reference-DSK wall
+    clock on 50x E. coli -- the reference cannot be built here, so the comparison shown is against the restatement."""
+    import gzip
+    import shutil
+    import struct
+    import subprocess
+    import tempfile
+    import zlib
+    import torch
+    from dsk_amd import synth
+    dsk = os.path.join(ROOT, "dsk_amd", "host", "bin", "dsk")
+    cli = os.path.join(ROOT, "oracle", "dsk_oracle_cli")
+    if not os.path.exists(dsk):
+        return {"error": "dsk binary not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    t_start = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="dsk_e2e_")
+    dev = torch.device("cuda", 0)
+    out = {"note": "wall clock of the dsk binary, file -> .h5 (HIP runtime start-up, ingest, count, HDF5 write), best of 3, page cache warm"}
+
+    def run_dsk(path, extra=()):
+        best, info = None, {}
+        for _ in range(3):
+            t0 = time.perf_counter()
+            p = subprocess.run([dsk, "-file", path, "-kmer-size", str(k), "-abundance-min", str(amin), "-out", os.path.join(tmp, "o"), "-verbose", "1", *extra],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                return {"error": p.stdout.decode(errors="replace")[-300:]}
+            if best is None or dt < best:
+                best = dt
+                for ln in p.stdout.decode(errors="replace").splitlines():
+                    for key in ("ingest_s", "count_s", "write_s", "total_s", "kmers_nb_valid", "kmers_nb_distinct", "kmers_nb_solid"):
+                        if key in ln:
+                            info[key] = float(ln.split(":")[-1]) if key.endswith("_s") else int(ln.split(":")[-1])
+            if time.perf_counter() - t_start > budget_s:
+                break
+        info["wall_s"] = round(best, 3)
+        if "kmers_nb_distinct" in info:
+            info["distinct_kmers_per_s"] = info["kmers_nb_distinct"] / best
+            info["kmer_occurrences_per_s"] = info["kmers_nb_valid"] / best
+        return info
+
+    try:
+        for name in ("ecoli50x", "c2_10Mx150"):
+            if time.perf_counter() - t_start > budget_s * 0.6 and name != "ecoli50x":
+                out[name] = {"skipped": "time budget"}
+                continue
+            gl, nr, rl = synth.workload(name)
+            reads = synth.make_reads(synth.make_genome(gl, dev), nr, rl)
+            fq = os.path.join(tmp, name + ".fastq")
+            size = write_fastq(reads, nr, rl, fq)
+            del reads
+            torch.cuda.empty_cache()
+            blk = {"file_bytes": size, "plain": run_dsk(fq)}
+            if name == "ecoli50x":
+                data = open(fq, "rb").read()
+                with gzip.open(fq + ".gz", "wb", compresslevel=1) as f:
+                    f.write(data)
+                with open(fq + ".bgzf.gz", "wb") as f:          # blocked gzip (bgzip layout): independent <= 64 KB members
+                    for off in list(range(0, len(data), 60000)) + [None]:
+                        chunk = b"" if off is None else data[off: off + 60000]
+                        c = zlib.compressobj(1, zlib.DEFLATED, -15)
+                        body = c.compress(chunk) + c.flush()
+                        f.write(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1))
+                        f.write(body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+                del data
+                blk["gzip"] = run_dsk(fq + ".gz")
+                blk["bgzf"] = run_dsk(fq + ".bgzf.gz")
+                if os.path.exists(cli):                       # the CPU restatement's own CLI on the same file
+                    cpu = {}
+                    for label, threads in (("all_cores", os.cpu_count() or 1), ("one_thread", 1)):
+                        if label == "one_thread" and time.perf_counter() - t_start > budget_s * 0.5:
+                            cpu[label] = {"skipped": "time budget"}
+                            continue
+                        t0 = time.perf_counter()
+                        p = subprocess.run([cli, "-file", fq, "-kmer-size", str(k), "-abundance-min", str(amin), "-nb-cores", str(threads)],
+                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                        cpu[label] = {"wall_s": round(time.perf_counter() - t0, 3), "cores": threads, "rc": p.returncode}
+                    blk["cpu_restatement_cli"] = cpu
+                    if "wall_s" in blk["plain"] and cpu.get("all_cores", {}).get("wall_s"):
+                        blk["speedup_vs_cpu_restatement_all_cores"] = round(cpu["all_cores"]["wall_s"] / blk["plain"]["wall_s"], 2)
+                    if "wall_s" in blk["plain"] and cpu.get("one_thread", {}).get("wall_s"):
+                        blk["speedup_vs_cpu_restatement_one_thread"] = round(cpu["one_thread"]["wall_s"] / blk["plain"]["wall_s"], 2)
+            out[name] = blk
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out["reference_context"] = "DSK v1 published: E. coli k=21, one 2012 core, 58.8 s (doc/figure-1/ecoli_log:12); GATB/dsk itself cannot be built here"
+    return out
 
 
 def self_launch(args):
@@ -208,24 +338,35 @@ def main():
         dom = max(cand, key=cand.get) if cand else None
         roofline = None
         if dom:
-            ab = algorithmic_bytes(dom, n_bytes, local_kmers)
-            achieved = ab / (cand[dom] * 1e-3) / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(cand[dom], 4)}
-            # the whole step against the same roof: algorithmic bytes of this two-level design (DESIGN.md §4: bases read as
-            # ASCII + 2-bit, every key written and read once per level, solid rows written) over the wall time of a step
             W = 8 if args.kmer_size <= 32 else 16 if args.kmer_size <= 64 else 32
+
+            def price(stage):
+                ab = algorithmic_bytes(stage, n_bytes, local_kmers, W)
+                gbs = ab / (stage_ms[stage] * 1e-3) / 1e9
+                return {"algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(stage_ms[stage], 4), "achieved": round(gbs, 1),
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_vs_measured_copy": round(gbs / HBM_COPY_GBS, 4)}
+            d = price(dom)
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
+                        "traffic": None,      # PMC counters are not collected inside a timed run; see traffic_from_profiles
+                        "peak_measured_copy": HBM_COPY_GBS, "frac_vs_measured_copy": d["frac_vs_measured_copy"],
+                        "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "avg_launch_ms": d["avg_launch_ms"],
+                        # every partition + hash kernel of the step, priced the same way (HIP events on the launching stream)
+                        "kernels": {st: price(st) for st in ("encode", "scatter1", "scatter2", "count", "mg_scatter") if st in stage_ms}}
+            pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+            if os.path.exists(pmc):        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an EARLIER run of this command (profiles/)
+                try:
+                    prof = json.load(open(pmc))
+                    if prof.get("_meta", {}).get("workload") == args.workload and prof.get("_meta", {}).get("kmer_size") == args.kmer_size and world == 1:
+                        roofline["traffic_from_profiles"] = {"profile": prof["_meta"].get("id"), "commit": prof["_meta"].get("commit"),
+                                                             "hbm_bytes_per_launch": {st: prof[st]["hbm_bytes_per_launch"] for st in roofline["kernels"] if st in prof}}
+                except Exception:
+                    pass
+            # the whole step against the same roof: algorithmic bytes of this two-level design (DESIGN.md section 4: bases read as
+            # ASCII + 2-bit, every key written and read once per level, solid rows written) over the wall time of a step
             step_bytes = n_bytes * 1.375 + local_kmers * (4 * W) + st["n_solid"] * (W + 4)
             roofline["step_algorithmic_bytes"] = int(step_bytes)
             roofline["step_frac"] = round(step_bytes / per_step / 1e9 / HBM_PEAK_GBS, 4)
+            roofline["step_frac_vs_measured_copy"] = round(step_bytes / per_step / 1e9 / HBM_COPY_GBS, 4)
         out = {
             "metric": "distinct k-mers counted/sec (whole node), k=%d" % args.kmer_size,
             "value": n_distinct / per_step,
@@ -253,6 +394,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(reads, rl, args.cpu_sample_reads, args.kmer_size)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None   # rank 0 at N=1 only
+        if world == 1 and not args.no_e2e:
+            kc.close()
+            del reads
+            torch.cuda.empty_cache()
+            out["e2e"] = e2e_block(args.kmer_size, args.abundance_min)
         print(json.dumps(out))
     kc.close()
     if world > 1:

@@ -58,8 +58,33 @@ struct Stage { const char* name; hipEvent_t ev; };
 
 }  // namespace
 
+// Test / experiment switches (DESIGN.md "Environment switches"): read ONCE from the environment when a context is
+// created; none of them changes results.  The launch paths only look at this struct.
+struct Tuning {
+    bool no_opt1 = false, no_opt2 = false;      // DSKGPU_NO_OPT1 / _NO_OPT2: exact histogram + scan path at level 1 / at both levels
+    bool no_aligned = false;                    // DSKGPU_NO_ALIGNED: plain write-out for key-array scatters
+    bool balanced_plan = false;                 // DSKGPU_BALANCED_PLAN: P1 ~ P2
+    bool fullsort = false;                      // DSKGPU_FULLSORT: full-width row sort
+    bool sk_exact = false, no_recsrc = false;   // DSKGPU_SK_EXACT, DSKGPU_NO_RECSRC (multi-GPU sender layout / receiver source)
+    u32 opt_cap = 0;                            // DSKGPU_OPT_CAP: forced level-2 region size (keys)
+    u64 opt_slice = 0;                          // DSKGPU_OPT_SLICE: forced level-1 slice size (keys)
+    u64 sk_slice = 0, sk_minslice = 2000;       // DSKGPU_SK_SLICE, DSKGPU_SK_MINSLICE
+    u32 table_maxload = 0;                      // DSKGPU_TABLE_MAXLOAD: distinct keys a count table may hold (forces the finer-partition retry)
+    void read() {
+        auto on = [](const char* n) { return getenv(n) != nullptr; };
+        auto num = [](const char* n, u64 dflt) { const char* e = getenv(n); return e ? (u64)atoll(e) : dflt; };
+        no_opt1 = on("DSKGPU_NO_OPT1"); no_opt2 = on("DSKGPU_NO_OPT2"); no_aligned = on("DSKGPU_NO_ALIGNED");
+        balanced_plan = on("DSKGPU_BALANCED_PLAN"); fullsort = on("DSKGPU_FULLSORT"); sk_exact = on("DSKGPU_SK_EXACT");
+        no_recsrc = on("DSKGPU_NO_RECSRC");
+        opt_cap = (u32)num("DSKGPU_OPT_CAP", 0) & ~7u; opt_slice = num("DSKGPU_OPT_SLICE", 0) & ~7ull;
+        sk_slice = num("DSKGPU_SK_SLICE", 0); sk_minslice = num("DSKGPU_SK_MINSLICE", 2000);
+        table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
+    }
+};
+
 struct dskgpu_ctx {
     dskgpu_config cfg{};
+    Tuning tune;
     int W = 1;
     int words_out = 1;
     hipStream_t stream = nullptr;
@@ -95,8 +120,6 @@ struct dskgpu_ctx {
     u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0; u64 h_nvalid = 0;
     bool sentinel_ok = true;       // the all-ones key is not the mixed form of a canonical k-mer of this k (checked at create)
     bool opt1_off = false;         // same for the histogram-free level-1 scatter (block-owned slices)
-    bool no_packed_count = false;  // DSKGPU_NO_PACKED_COUNT (read at create): the separate key / count table kernel for region layouts too
-    unsigned cp_grid = 0;          // grid of k_count1p (resident blocks, from the occupancy query)
     bool opt2_off = false;         // the fixed-capacity level-2 scatter overflowed on these reads: use the exact path   // host landing zone of the async size read-back
     std::vector<ChunkDesc> h_descs1, h_descs2;
     std::vector<const void*> big_lds_fns;   // kernels whose dynamic-LDS limit this context has raised (allow_big_lds)
@@ -200,9 +223,6 @@ int run_scan(dskgpu_ctx* ctx, u32* a, const u32* d_len, u64 max_len) {
     return DSKGPU_OK;
 }
 
-// experiment switches (timing ablations only; results are wrong when set): DSKGPU_DBG1 = level-1 scatter, DSKGPU_DBG2 = key-array scatter
-u32 dbg_flags(int src) { const char* e = getenv(src == 0 ? "DSKGPU_DBG1" : "DSKGPU_DBG2"); return e ? (u32)atoi(e) : 0u; }
-
 // Kernels that stage a whole tile need more dynamic LDS than the 64 KB default: raise the limit once per context
 // (a context is bound to one device and driven by one thread, so no process-wide flag is involved).
 int allow_big_lds(dskgpu_ctx* ctx, const void* fn) {
@@ -248,7 +268,7 @@ int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chu
     const unsigned grid = scatter_grid(ctx, W, P, max_chunks);
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, SRC, MODE, OPT>)); if (e) return e; }
     hipLaunchKernelGGL((k_scatter<W, SRC, MODE, OPT>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->packed.as<u64>(),
-                       ctx->inval.as<u32>(), keys, descs, d_nch, scanned, out, (int)ctx->cfg.kmer_size, ds, P, dbg_flags(SRC), o1);
+                       ctx->inval.as<u32>(), keys, descs, d_nch, scanned, out, (int)ctx->cfg.kmer_size, ds, P, o1);
     CKL("k_scatter");
     return DSKGPU_OK;
 }
@@ -259,7 +279,7 @@ int launch_scatter_rec(dskgpu_ctx* ctx, const ChunkDesc* descs, const u32* d_nch
     const unsigned grid = scatter_grid(ctx, W, P, max_chunks);
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, 2, 1, true>)); if (e) return e; }
     hipLaunchKernelGGL((k_scatter<W, 2, 1, true>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->rec_src, (const u32*)nullptr,
-                       (const typename KeyT<W>::T*)nullptr, descs, d_nch, (const u32*)nullptr, out, (int)ctx->cfg.kmer_size, ds, P, 0u, o1);
+                       (const typename KeyT<W>::T*)nullptr, descs, d_nch, (const u32*)nullptr, out, (int)ctx->cfg.kmer_size, ds, P, o1);
     CKL("k_scatter(records)");
     return DSKGPU_OK;
 }
@@ -272,7 +292,7 @@ int launch_scatter_al(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Ch
     const size_t lds = ascatter_lds(W, P);
     const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu));
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter_al<W, MODE, OPT, SLICED>)); if (e) return e; }
-    hipLaunchKernelGGL((k_scatter_al<W, MODE, OPT, SLICED>), dim3(grid), dim3(SC_NT), lds, ctx->stream, keys, descs, d_nch, scanned, out, ds, P, dbg_flags(1), os);
+    hipLaunchKernelGGL((k_scatter_al<W, MODE, OPT, SLICED>), dim3(grid), dim3(SC_NT), lds, ctx->stream, keys, descs, d_nch, scanned, out, ds, P, os);
     CKL("k_scatter_al");
     return DSKGPU_OK;
 }
@@ -281,7 +301,7 @@ template <int W, int SRC>
 int launch_scatter(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
                    u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P) {
     const bool mp = ds.mode == 1 && ds.npass > 1;
-    if (SRC == 1 && ascatter_lds(W, P) <= 160 * 1024 && !getenv("DSKGPU_NO_ALIGNED"))
+    if (SRC == 1 && ascatter_lds(W, P) <= 160 * 1024 && !ctx->tune.no_aligned)
         return ds.mode == 2 ? launch_scatter_al<W, 2>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P)
                        : mp ? launch_scatter_al<W, 3>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P)
                             : launch_scatter_al<W, 1>(ctx, keys, descs, d_nch, max_chunks, scanned, out, ds, P);
@@ -295,21 +315,10 @@ int launch_scatter(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chunk
 
 // fixed-capacity regions or exact offsets: a compile-time switch of the count kernels (k_count1 / k_count_mw)
 inline void launch_count_impl(dskgpu_ctx* ctx, unsigned grid, u64* keys, u64* solid_keys, u32* solid_ab, u32* ovf, const CountParams& cp) {
-    if (cp.cap && cp.cap <= (u32)CP_CMASK && cp.F >= CP_MIN_F && !ctx->no_packed_count) {      // key + count in one table word (k_count1p)
-        if (!ctx->cp_grid) {
-            int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_count1p<CP_NT, CP_KPT>, CP_NT, 0) != hipSuccess || nb < 1) nb = 1;
-            ctx->cp_grid = (unsigned)(ctx->num_cu * nb);
-        }
-        CountParamsP pp{cp.F, cp.amin, cp.amax, cp.histo_max, cp.cap, cp.subcnt, ~0ull / cp.F};
-        hipLaunchKernelGGL((k_count1p<CP_NT, CP_KPT>), dim3(std::min<unsigned>(ctx->cp_grid, cp.F)), dim3(CP_NT), 0, ctx->stream, keys, solid_keys, solid_ab,
-                           ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, pp);
-        return;
-    }
     if (cp.cap) hipLaunchKernelGGL(k_count1<true>, dim3(grid), dim3(CNT_NT), 0, ctx->stream, keys, solid_keys, ctx->fstart.as<u32>(), solid_ab,
-                                   ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, cp);
+                                   ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, cp, cp.subcnt);
     else hipLaunchKernelGGL(k_count1<false>, dim3(grid), dim3(CNT_NT), 0, ctx->stream, keys, solid_keys, ctx->fstart.as<u32>(), solid_ab,
-                            ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, cp);
+                            ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, cp, (const u32*)ctx->fstart.as<u32>());
 }
 template <int W>
 inline void launch_count_impl(dskgpu_ctx* ctx, unsigned grid, KN<W>* keys, KN<W>* solid_keys, u32* solid_ab, u32* ovf, const CountParams& cp) {
@@ -341,11 +350,10 @@ struct Plan {
 
 // Final sub-partitions F = P1 * P2 sized to the input (any integer, not a power
 // of two: digits use the multiply-shift reduction of key_digit()).
-bool make_plan(u64 n_upper, int extra_bits, int W, Plan* pl) {
+bool make_plan(u64 n_upper, int extra_bits, int W, bool balanced, Plan* pl) {
     const u64 target = W == 1 ? TARGET_KEYS : W == 2 ? TARGET_KEYS2 : TARGET_KEYS2 / 2;   // four-word keys: 1024 staged per sub-partition
     u64 F = ((n_upper + target - 1) / target) << extra_bits;
     if (F < 2) F = 2;
-    if (W == 1 && F > ONE_LEVEL_BINS && F < CP_MIN_F) F = CP_MIN_F;      // two levels: fine enough for the packed count table (k_count1p)
     if (F <= ONE_LEVEL_BINS) { pl->levels = 1; pl->P1 = (u32)F; pl->P2 = 1; }
     else {
         u64 p1 = 1; while (p1 * p1 < F) ++p1;
@@ -353,7 +361,7 @@ bool make_plan(u64 n_upper, int extra_bits, int W, Plan* pl) {
         // instead -- the level-1 scatter is ALU-bound and does not mind shorter runs
         u64 p2max = MAX_LEVEL_BINS; while (p2max > 64 && ascatter_lds(W, (u32)p2max) > 160 * 1024) --p2max;
         const u64 p1_al = (F + p2max - 1) / p2max;
-        if (p1_al > p1 && p1_al <= MAX_LEVEL_BINS - 8 && !getenv("DSKGPU_BALANCED_PLAN")) p1 = p1_al;
+        if (p1_al > p1 && p1_al <= MAX_LEVEL_BINS - 8 && !balanced) p1 = p1_al;
         u64 p2 = (F + p1 - 1) / p1;
         if (p1 > MAX_LEVEL_BINS || p2 > MAX_LEVEL_BINS) return false;
         pl->levels = 2; pl->P1 = (u32)p1; pl->P2 = (u32)p2;
@@ -455,7 +463,7 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
         // Sort on the top SORT_TOP_BITS of the value only (4 radix passes instead of 8), then fix the
         // (rare, short) runs of equal prefix; exactness is kept by the full-width fallback in finish_sort().
         // (k = 32 uses all 64 bits: rocPRIM's partial-range sort misbehaved with end_bit == 64 on ROCm 7.2, so it sorts full width)
-        const unsigned begin_bit = (end_bit > SORT_TOP_BITS && end_bit < 64u && !getenv("DSKGPU_FULLSORT")) ? end_bit - SORT_TOP_BITS : 0u;
+        const unsigned begin_bit = (end_bit > SORT_TOP_BITS && end_bit < 64u && !ctx->tune.fullsort) ? end_bit - SORT_TOP_BITS : 0u;
         CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->out_w[0].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->out_ab.as<u32>(),
                                      ctx->srt_ab.as<u32>(), (size_t)n, begin_bit, end_bit, ctx->stream));
         CK(ctx->srt_tmp.ensure(tmp));
@@ -475,7 +483,7 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     }
     // multi-word rows: radix sort of (top 63 bits of the value, row index) on the key's top 32 bits, gather,
     // then the runs of equal prefix are ordered in place by full comparison (exact fallback: sort_rows_full_multiword)
-    if (!getenv("DSKGPU_FULLSORT") && 2u * ctx->cfg.kmer_size > 64u) {
+    if (!ctx->tune.fullsort && 2u * ctx->cfg.kmer_size > 64u) {
         CK(ctx->srt_k.ensure(n * 8)); CK(ctx->s_val.ensure(n * 8));
         CK(ctx->srt_idx.ensure(n * 4)); CK(ctx->srt_idx2.ensure(n * 4));
         const unsigned gb = (unsigned)((n + 255) / 256);
@@ -534,7 +542,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
     int extra_bits = 0;
     for (int attempt = 0;; ++attempt) {
         Plan pl;
-        if (!make_plan(cap, extra_bits, W, &pl))
+        if (!make_plan(cap, extra_bits, W, ctx->tune.balanced_plan, &pl))
             return fail(ctx, DSKGPU_E_OVERFLOW, "cannot partition finer (table overflow persists)");
         pl.d1.world = pl.d2.world = ctx->cfg.world_size; pl.d1.npass = pl.d2.npass = npass; pl.d1.pass = pl.d2.pass = pass;
         // ---------------- level 1
@@ -563,9 +571,9 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         // pass (block-owned slices at level 1, segment-owned regions at level 2); any overflow sends the whole
         // attempt back through the exact histogram + scan path.
         u32 opt_cap = 0;                 // level 2: keys per sub-partition region (0 = exact offsets)
-        if (pl.levels == 2 && ctx->sentinel_ok && !ctx->opt2_off && !getenv("DSKGPU_NO_OPT2") && ascatter_lds(W, pl.P2) <= 160 * 1024)
+        if (pl.levels == 2 && ctx->sentinel_ok && !ctx->opt2_off && !ctx->tune.no_opt2 && ascatter_lds(W, pl.P2) <= 160 * 1024)
             opt_cap = OPT_GROUPS * (8u / W);                                                    // 545 groups of 64 B whatever the key width
-        if (opt_cap) { if (const char* e = getenv("DSKGPU_OPT_CAP")) opt_cap = (u32)atoi(e) & ~7u; }   // experiments / tests
+        if (opt_cap && ctx->tune.opt_cap) opt_cap = ctx->tune.opt_cap;                       // experiments / tests
         if (W > 1 && (u64)pl.F * opt_cap >= 0xFFFF0000ull) opt_cap = 0;                       // k_count<W> keeps 32-bit offsets
         if (opt_cap) {
             // the rows of the solid k-mers land at the region offsets too: abundances (one-word keys: in bufA, the free
@@ -574,8 +582,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             CK(ctx->bufA.ensure(std::max<u64>(W == 1 ? slots * 4 : slots * sizeof(Key), (cap + 1) * sizeof(Key))));
             if (W > 1) CK(ctx->abund2.ensure(slots * 4));
         }
-        bool opt1 = opt_cap && !ctx->opt1_off && !getenv("DSKGPU_NO_OPT1") && (npass == 1 || from_reads);   // several passes: reads only (MODE 3)
-        if (from_rec && (!opt1 || W > 2 || getenv("DSKGPU_NO_RECSRC"))) { int e = records_to_keys(); if (e) return e; }
+        bool opt1 = opt_cap && !ctx->opt1_off && !ctx->tune.no_opt1 && (npass == 1 || from_reads);   // several passes: reads only (MODE 3)
+        if (from_rec && (!opt1 || W > 2 || ctx->tune.no_recsrc)) { int e = records_to_keys(); if (e) return e; }
         Opt1Spec o1{0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2};
         unsigned grid1 = 0;
         if (opt1 && !from_reads) ctx->h_nvalid = nkeys_in;
@@ -593,7 +601,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             // a block's share of the input: it walks chunks blockIdx, blockIdx + grid, .. (equal chunks, the busiest block has ceil(nch/grid))
             const u64 cpb = (nch1 + grid1 - 1) / grid1;
             u64 slice = ctx->h_nvalid / npass * cpb / ((u64)nch1 * pl.P1) + 1; slice += slice * 3 / 50 + 160; slice = (slice + 7) & ~7ull;   // mean + 6 % + 160
-            if (const char* e = getenv("DSKGPU_OPT_SLICE")) slice = (u64)atoll(e) & ~7ull;                   // experiments / tests
+            if (ctx->tune.opt_slice) slice = ctx->tune.opt_slice;                                            // experiments / tests
             const u64 tail = ctx->h_nvalid / npass / grid1 * 2 + 2 * Tile<W>::KEYS;                                     // worst overrun of one block
             if (slice < 8 || cells * slice + tail >= 0xFFFF0000ull) opt1 = false;
             else {
@@ -710,7 +718,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         // free ping-pong buffer); two-word keys write rows into the free buffer (+ abund2)
         CountParams cp;
         cp.F = pl.F;
-        cp.dbg = 0u;
+        cp.maxload = W == 1 ? CNT_MAXLOAD : C2_MAXLOAD;
+        if (ctx->tune.table_maxload) cp.maxload = std::min<u32>(cp.maxload, ctx->tune.table_maxload);
         cp.amin = ctx->cfg.abundance_min; cp.amax = ctx->cfg.abundance_max; cp.histo_max = ctx->cfg.histo_max;
         cp.cap = opt_cap; cp.subcnt = opt_cap ? ctx->mat2.as<u32>() : nullptr;
         const unsigned cgrid = (unsigned)std::min<u64>(pl.F, (u64)ctx->num_cu * 2);
@@ -938,7 +947,7 @@ int sk_prepare(dskgpu_ctx* ctx) {
     // Exact layout: count every record, one scan places them.  Slice layout (default): count the records of every
     // 16th tile only, give every (owner, chunk) pair one slice of the estimated mean + 8 % + 128 records; the scatter
     // pads the slices with zero-length records.  Saves the full counting pass (1.95 of 5 ms); ~8 % more words to send.
-    const bool slices = !ctx->sk_exact && !getenv("DSKGPU_SK_EXACT") && tpc >= 8;
+    const bool slices = !ctx->sk_exact && !ctx->tune.sk_exact && tpc >= 8;
     sp.sample_step = slices ? 16u : 1u;
     hipLaunchKernelGGL(k_sk_hist, dim3((unsigned)nch), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, ctx->mat1.as<u32>());
     CKL("k_sk_hist");
@@ -954,10 +963,10 @@ int sk_prepare(dskgpu_ctx* ctx) {
         for (u32 o = 0; o < sp.G; ++o) worst = std::max<u64>(worst, ctx->h_starts[o + 1] - ctx->h_starts[o]);
         const u64 sampled_tiles = (tpc + sp.sample_step - 1) / sp.sample_step;            // per chunk
         u64 slice = worst * tpc / (sampled_tiles * nch) + 1;                              // records per (owner, chunk), estimated
-        u64 min_slice = 2000; if (const char* e = getenv("DSKGPU_SK_MINSLICE")) min_slice = (u64)atoll(e);      // tests
+        const u64 min_slice = ctx->tune.sk_minslice;                                      // (tests lower it)
         const bool small = slice < min_slice || worst < 20000;    // fixed slack too visible in the send volume, or too few sampled records to trust the estimate
         slice += slice * 2 / 25 + 128;
-        if (const char* e = getenv("DSKGPU_SK_SLICE")) slice = (u64)std::max(1, atoi(e));    // tests
+        if (ctx->tune.sk_slice) slice = ctx->tune.sk_slice;                               // tests
         if (!small && slice * nch * sp.G < 0xFFFF0000ull) {
             sp.slice = (u32)slice;
             for (u32 o = 0; o <= sp.G; ++o) ctx->h_starts[o] = (u32)(o * nch * slice);
@@ -1188,7 +1197,7 @@ int dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out) {
     ctx->words_out = (int)((cfg->kmer_size + 31) / 32);
     ctx->sentinel_ok = !sentinel_is_a_kmer(ctx->W, cfg->kmer_size);                   // words of a k-mer at the ABI (3 for k <= 96)
     ctx->max_keys_per_pass = (u64)cfg->max_pass_mkeys * 1000000ull;
-    ctx->no_packed_count = getenv("DSKGPU_PACKED_COUNT") == nullptr;      // experimental kernel: opt-in until it beats k_count1
+    ctx->tune.read();
     // super-k-mer records need >= 16 m-mers per window (superkmer.h); shorter k-mers travel as explicit keys
     // (world_size == 1 is the degenerate exchange: every record goes to owner 0; dskgpu_count never looks at sk_mode)
     ctx->sk_mode = cfg->kmer_size >= 20 && cfg->kmer_size <= 64 && !(cfg->flags & DSKGPU_F_MG_EXPLICIT);

@@ -462,17 +462,13 @@ __device__ __forceinline__ u32 tile_keys_records(const u64* __restrict__ rec, u3
 // overflow raises *ovf (the host repeats the pass with the exact histogram + scan path).
 struct Opt1Spec { u32 slice, cap1; u32* ovf; u32* fill; u32 R; u64* nkeys; };      // R: words per super-k-mer record (SRC 2)
 
-#ifndef DSK_ABLATE
-#define DSK_ABLATE 0     // 1 (make EXTRA=-DDSK_ABLATE=1): the timing-ablation switches (DSKGPU_DBG1/2 bits) are live; 0: compiled out (-0.1 ms)
-#endif
 template <int W, int SRC, int MODE, bool OPT = false>
 __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
                                                    const typename KeyT<W>::T* __restrict__ keys,
                                                    const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
                                                    const u32* __restrict__ scanned,
-                                                   typename KeyT<W>::T* __restrict__ out, int k, DigitSpec ds, u32 P, u32 dbg_in, Opt1Spec o1) {
+                                                   typename KeyT<W>::T* __restrict__ out, int k, DigitSpec ds, u32 P, Opt1Spec o1) {
     typedef typename KeyT<W>::T Key;
-    const u32 dbg = DSK_ABLATE ? dbg_in : 0u;
     constexpr int KPT = Tile<W>::KPT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Key* stage = reinterpret_cast<Key*>(smem);                       // Tile<W>::KEYS keys
@@ -498,47 +494,32 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                 const u32 dj = ((vm & (1u << j)) && key_in_pass<MODE>(digit_word(h[j]), ds)) ? key_digit<MODE>(digit_word(h[j]), ds) : P;
                 rk[j] = dj << 16;                                    // (digit, rank) packed: rank < 8192, digit <= 2048
             }
-            if (!(dbg & 64u)) {
 #pragma unroll
             for (int j = 0; j < KPT; ++j) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
-            }
-            if (!(dbg & 32u)) lds_barrier();
-            if (!(dbg & 16u)) tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot);
-            if (!(dbg & 32u)) lds_barrier();
-            if (!(dbg & 4u)) {
+            lds_barrier();
+            tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot);
+            lds_barrier();
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const u32 dj = rk[j] >> 16;
                 const u32 o = off[dj < P ? dj : 0];
                 if (dj < P) stage[o + (rk[j] & 0xFFFFu)] = h[j];
             }
-            }
             if (threadIdx.x == 0) cnt[P] = 0;
-            if (!(dbg & 32u)) lds_barrier();
+            lds_barrier();
             const u32 ntile = *tot;
-            if (!(dbg & 1u)) {
-                for (u32 i0 = 0; i0 < ntile; i0 += 4 * SC_NT) {
-                    Key hk[4]; u32 dd[4];
+            for (u32 i0 = 0; i0 < ntile; i0 += 4 * SC_NT) {
+                Key hk[4]; u32 dd[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { const u32 i = i0 + u * SC_NT + threadIdx.x; hk[u] = stage[i < ntile ? i : 0]; }
+                for (int u = 0; u < 4; ++u) { const u32 i = i0 + u * SC_NT + threadIdx.x; hk[u] = stage[i < ntile ? i : 0]; }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) dd[u] = delta[key_digit<MODE>(digit_word(hk[u]), ds)];
-                    if (dbg & 512u) {      // timing experiment: every 16 staged keys -> one aligned 128-byte line (results invalid)
+                for (int u = 0; u < 4; ++u) dd[u] = delta[key_digit<MODE>(digit_word(hk[u]), ds)];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const u32 i = i0 + u * SC_NT + threadIdx.x;
-                            const u32 G = (dbg & 1024u) ? 7u : 15u;                          // 8-key (64 B) or 16-key (128 B) groups
-                            const u32 lead = __shfl(dd[u], (threadIdx.x & 63) & ~G);        // delta of the group's first key
-                            dd[u] = ((lead + (i & ~G)) & ~G) - (i & ~G);                    // dst = aligned(lead + group start) + (i & G)
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const u32 i = i0 + u * SC_NT + threadIdx.x;
-                        // OPT: nothing is ever written past the block's own slice of the bin (the overflow is reported at the end of the launch)
-                        const bool fits = !OPT || dd[u] + i < key_digit<MODE>(digit_word(hk[u]), ds) * o1.cap1 + (blockIdx.x + 1) * o1.slice;
-                        if (i < ntile && fits) out[(dbg & 128u) ? (u64)(blockIdx.x * Tile<W>::KEYS + i + (dd[u] & 1u)) : (u64)(dd[u] + i)] = hk[u];
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    const u32 i = i0 + u * SC_NT + threadIdx.x;
+                    // OPT: nothing is ever written past the block's own slice of the bin (the overflow is reported at the end of the launch)
+                    const bool fits = !OPT || dd[u] + i < key_digit<MODE>(digit_word(hk[u]), ds) * o1.cap1 + (blockIdx.x + 1) * o1.slice;
+                    if (i < ntile && fits) out[(u64)(dd[u] + i)] = hk[u];
                 }
             }
             // no barrier here: the next tile's rank phase only touches cnt (zeroed
@@ -664,9 +645,8 @@ template <int W, int MODE, bool OPT = false, bool SLICED = false>
 __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>::T* __restrict__ keys,
                                                          const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
                                                          const u32* __restrict__ scanned,
-                                                         typename KeyT<W>::T* __restrict__ out_all, DigitSpec ds, u32 P, u32 dbg_in, OptSpec os) {
+                                                         typename KeyT<W>::T* __restrict__ out_all, DigitSpec ds, u32 P, OptSpec os) {
     typedef typename KeyT<W>::T Key;
-    const u32 dbg = DSK_ABLATE ? dbg_in : 0u;
     typedef unsigned short u16;
     constexpr int KPT = ATile<W>::KPT, G = ATile<W>::G, CARRY = ATile<W>::CARRY, TKEYS = ATile<W>::KEYS;
     constexpr int NGRP = SC_NT / G;                                   // lane groups per block
@@ -795,7 +775,6 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
             if (tnext < lend) vm = load(tnext, h);        // HBM reads of the next tile fly under the write-out phase
             lds_barrier();
             // ---- write-out + carry refresh, one lane group per bin
-            if (!(dbg & 4u))
             for (u32 b0 = 0; b0 < P; b0 += 2 * NGRP) {
                 uint3 rb[2]; u32 rnew[2]; bool act[2];
 #pragma unroll
@@ -814,7 +793,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                         if (a >= pold) {
                             const u32 idx = a - pold;
                             const Key kv = idx < r ? cb[idx] : stage[o + idx - r];
-                            if (!(dbg & 1u)) out[a] = kv;
+                            out[a] = kv;
                         }
                     }
                     const u32 c = rnew[u] + e - r;                        // keys this tile gave the bin
@@ -921,7 +900,7 @@ __global__ void k_final_offsets(const u32* __restrict__ scanned, const SegInfo* 
 struct CountParams {
     u32 F;
     u32 amin, amax, histo_max;
-    u32 dbg;                  // experiment switches (timing ablations only)
+    u32 maxload;              // distinct keys a table may hold (CNT_MAXLOAD / C2_MAXLOAD; tests lower it to force the finer-partition retry)
     u32 cap;                  // != 0: fixed-capacity sub-partition regions (segment-owned level-2 scatter):
     const u32* subcnt;        //       sub-partition q = keys [q*cap, q*cap + subcnt[q])
 };
@@ -959,11 +938,17 @@ __device__ __forceinline__ void table_insert1(u64* tk, u32* tc, unsigned short* 
     *ovf = 1;
 }
 
-template <bool REG>      // REG: fixed-capacity regions instead of exact offsets (compile-time: see k_count_mw)
+// Memory latency is kept off the critical path: the RANGE of sub-partition q + 2 * grid (subcnt[q] / fstart[q], a scalar
+// load) is requested an iteration early, so the key loads of q + grid go out right after the inserts of q without
+// waiting for a dependent load first, and every load is unconditional (clamped indices), which lets the compiler count
+// the outstanding ones instead of draining them (4.46 -> 4.10 ms; a read-only skeleton of this loop streams the keys
+// at 6 TB/s, so the rest of the time is the LDS phases themselves).
+// REG: fixed-capacity regions (q * cap, subcnt[q]) instead of exact offsets (compile-time: see k_count_mw).
+template <bool REG>
 __global__ __launch_bounds__(CNT_NT) void k_count1(u64* keys, u64* solid_keys, const u32* __restrict__ fstart,
-                                                   u32* __restrict__ abund, u32* __restrict__ nsolid,
-                                                   u64* __restrict__ ghist, u64* __restrict__ gstats,
-                                                   u32* __restrict__ overflow, CountParams cp) {
+                                                    u32* __restrict__ abund, u32* __restrict__ nsolid,
+                                                    u64* __restrict__ ghist, u64* __restrict__ gstats,
+                                                    u32* __restrict__ overflow, CountParams cp, const u32* __restrict__ subcnt) {
     __shared__ u64 tk[CNT_SLOTS];
     __shared__ u32 tc[CNT_SLOTS];
     __shared__ unsigned short lst[CNT_SLOTS];
@@ -975,40 +960,39 @@ __global__ __launch_bounds__(CNT_NT) void k_count1(u64* keys, u64* solid_keys, c
     if (tid < 8) s_ctr[tid >> 2][tid & 3] = 0;
     u32 ones = 0;          // lane 0 of each wave: abundance-1 keys seen (flushed at the end)
     u64 ndist_acc = 0;
+    // range words of sub-partition qq (clamped to a valid index: the caller ignores them when qq >= F)
+    auto range_lo = [&](u32 qq) { const u32 c = qq < cp.F ? qq : cp.F - 1; return REG ? subcnt[c] : fstart[c]; };
+    auto range_hi = [&](u32 qq) { const u32 c = qq < cp.F ? qq : cp.F - 1; return REG ? 0u : fstart[c + 1]; };
+    auto begin_of = [&](u32 qq, u32 lo) { return REG ? (u64)qq * cp.cap : (u64)lo; };
+    auto count_of = [&](u32 qq, u32 lo, u32 hi) { return qq < cp.F ? (REG ? lo : hi - lo) : 0u; };
     u32 q = blockIdx.x;
-    u64 begin = 0; u32 n = 0;
     u64 pk[CNT_KPT];
-    if (q < cp.F) {
-        sub_range<REG>(cp, fstart, q, &begin, &n);
-        if (n) {
+    auto load_keys = [&](u64 beg, u32 nn) {      // branch-free: an index past the keys re-reads the last one (or key 0 of an empty range)
+        const u32 last = nn ? nn - 1 : 0u;
 #pragma unroll
-            for (int j = 0; j < CNT_KPT; ++j) { const u32 i = tid + j * CNT_NT; pk[j] = keys[begin + (i < n ? i : n - 1)]; }
-        }
-    }
+        for (int j = 0; j < CNT_KPT; ++j) { const u32 i = tid + j * CNT_NT; pk[j] = keys[beg + (i < nn ? i : last)]; }
+    };
+    u32 lo = range_lo(q), hi = range_hi(q);
+    u64 begin = q < cp.F ? begin_of(q, lo) : 0ull; u32 n = count_of(q, lo, hi);
+    u32 nlo = range_lo(q + gridDim.x), nhi = range_hi(q + gridDim.x);
+    load_keys(begin, n);
     lds_barrier();
     int par = 0;
     while (q < cp.F) {
         u32* ctr = s_ctr[par];
-        // (an up-front probe of all home slots for ILP was measured slower here: 5.0 vs 4.66 ms -- the table is
-        //  empty at that point, so the probes only cost LDS reads)
 #pragma unroll
         for (int j = 0; j < CNT_KPT; ++j)
             if ((u32)(tid + j * CNT_NT) < n) table_insert1(tk, tc, lst, &ctr[0], &ctr[2], pk[j]);
         for (u32 i = CNT_KPT * CNT_NT + tid; i < n; i += CNT_NT)                 // oversized sub-partition
             table_insert1(tk, tc, lst, &ctr[0], &ctr[2], keys[begin + i]);
-        // prefetch the block's next sub-partition
+        // the range two sub-partitions ahead, then the keys of the next one (its range arrived an iteration ago)
         const u32 qn = q + gridDim.x;
-        u64 nbeg = 0; u32 nn = 0;
-        if (qn < cp.F) {
-            sub_range<REG>(cp, fstart, qn, &nbeg, &nn);
-            if (nn) {
-#pragma unroll
-                for (int j = 0; j < CNT_KPT; ++j) { const u32 i = tid + j * CNT_NT; pk[j] = keys[nbeg + (i < nn ? i : nn - 1)]; }
-            }
-        }
+        const u32 flo = range_lo(qn + gridDim.x), fhi = range_hi(qn + gridDim.x);
+        const u64 nbeg = qn < cp.F ? begin_of(qn, nlo) : 0ull; const u32 nn = count_of(qn, nlo, nhi);
+        load_keys(nbeg, nn);
         lds_barrier();
         const u32 nd = ctr[0];
-        const bool bad = ctr[2] || nd > CNT_MAXLOAD;           // block-uniform
+        const bool bad = ctr[2] || nd > cp.maxload;            // block-uniform
         if (bad) {
             for (int s = tid; s < CNT_SLOTS; s += CNT_NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
             if (tid == 0) *overflow = 1;
@@ -1050,207 +1034,13 @@ __global__ __launch_bounds__(CNT_NT) void k_count1(u64* keys, u64* solid_keys, c
             ctr[0] = 0; ctr[1] = 0; ctr[2] = 0;     // this parity is next used two barriers from now
         }
         par ^= 1;
-        q = qn; begin = nbeg; n = nn;
+        q = qn; begin = nbeg; n = nn; nlo = flo; nhi = fhi;
     }
     lds_barrier();
     // flush block-local histogram
     if (lane == 0 && ones) atomicAdd(&lh[1], ones);
     lds_barrier();
     for (int b = tid; b < CNT_LH; b += CNT_NT) {
-        const u32 v = lh[b];
-        if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
-    }
-    if (tid == 0 && ndist_acc) atomicAdd(&gstats[0], ndist_acc);
-}
-
-// ---- one-word keys in fixed-capacity regions: key and count share ONE 64-bit table word.
-// All keys of sub-partition q have their top 32 bits in a window of about 2^32 / F values above
-//   lo(q) <= ceil(2^32 * q / F)        (h_hi * P1 / 2^32 lies in [q / P2, (q + 1) / P2), see key_digit)
-// so rel = h - (lo(q) << 32) fits 51 bits whenever 2^32 / F + 4 < 2^19, and a region holds at most cap < 2^13
-// keys, so a count fits 13 bits:  word = (rel << 13) | count.  A duplicate (72 % of the inserts on the bench
-// workload) then costs one LDS read + one non-returning 64-bit add, a new key one read + one CAS; the separate
-// count array, its atomic and its sweep reads/writes are gone, and the table is 32 KB instead of 48 KB.  The
-// KPT keys of a thread probe in lock step (independent LDS reads issued together).
-#define CP_CBITS 13
-#define CP_CMASK 8191ull
-#define CP_MIN_F 8208u            // 2^32 / F + 4 < 2^19
-#ifndef CP_NT
-#define CP_NT 512
-#endif
-#ifndef CP_KPT
-#define CP_KPT 6                  // prefetched keys per thread (pairs, 16-byte loads): CP_NT * CP_KPT = 3072 keys
-#endif
-#ifndef CP_LST
-#define CP_LST CNT_SLOTS          // entries of the sweep list (>= CNT_MAXLOAD; more claims than that mean overflow anyway)
-#endif
-#ifndef CP_LH
-#define CP_LH CNT_LH              // histogram bins kept in LDS
-#endif
-#ifndef CP_WPS
-#define CP_WPS 6                  // waves per SIMD the register budget allows: 3 blocks of 512 threads per CU (43 KB of LDS each)
-#endif
-struct CountParamsP {
-    u32 F, amin, amax, histo_max, cap;
-    const u32* subcnt;
-    u64 finv;                 // floor((2^64 - 1) / F): lo(q) = umul64hi(q << 32, finv)  (<= the exact bound, by < 3)
-};
-
-// CAS first: the table is empty when a sub-partition starts, so a read before the CAS only costs a round trip.  A CAS
-// that finds the slot empty has claimed it with count 1 (nothing else to do), one that finds the key adds 1 with a
-// non-returning atomic, one that finds another key moves on.  The KPT CASes of a thread are independent and issued
-// back to back (one LDS round trip for all of them); claimed slots are appended to the sweep list with one atomic per
-// WAVE (ballot + prefix).
-template <int KPT>
-__device__ __forceinline__ void table_insert_packed(u64* tk, unsigned short* lst, u32* ctr, const u64 (&rel)[KPT], u32 live) {
-    const int lane = threadIdx.x & 63;
-    u32 slot[KPT];
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) slot[j] = (u32)rel[j] & (CNT_SLOTS - 1);
-    for (int round = 0; __any(live != 0); ++round) {
-        u64 old[KPT];
-#pragma unroll
-        for (int j = 0; j < KPT; ++j)
-            if (live & (1u << j)) old[j] = atomicCAS(&tk[slot[j]], DSK_EMPTY, (rel[j] << CP_CBITS) | 1ull);
-        u64 mc[KPT]; u32 nclaim = 0;
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const bool act = live & (1u << j);
-            const bool claimed = act && old[j] == DSK_EMPTY;
-            const bool same = act && !claimed && ((old[j] ^ (rel[j] << CP_CBITS)) <= CP_CMASK);
-            if (same) atomicAdd(&tk[slot[j]], 1ull);
-            if (claimed || same) live &= ~(1u << j);
-            mc[j] = __ballot(claimed);
-            nclaim += (u32)__popcll(mc[j]);
-        }
-        if (nclaim) {                                             // wave-uniform: one list reservation per wave and round
-            u64 any = 0;
-#pragma unroll
-            for (int j = 0; j < KPT; ++j) any |= mc[j];
-            const int leader = __ffsll((long long)any) - 1;       // a claiming lane is an active one
-            u32 base = 0;
-            if (lane == leader) base = atomicAdd(&ctr[0], nclaim);
-            base = __shfl(base, leader);
-#pragma unroll
-            for (int j = 0; j < KPT; ++j) {
-                const u32 i = base + (u32)__popcll(mc[j] & ((1ull << lane) - 1));
-                if (((mc[j] >> lane) & 1ull) && i < CP_LST) lst[i] = (unsigned short)slot[j];
-                base += (u32)__popcll(mc[j]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) if (live & (1u << j)) slot[j] = (slot[j] + 1) & (CNT_SLOTS - 1);
-        if (round >= CNT_SLOTS) { ctr[2] = 1; break; }           // table full (reported; the host partitions finer)
-    }
-}
-
-template <int NT, int KPT>
-__global__ __launch_bounds__(NT, CP_WPS) void k_count1p(u64* keys, u64* solid_keys, u32* __restrict__ abund, u32* __restrict__ nsolid,
-                                                u64* __restrict__ ghist, u64* __restrict__ gstats,
-                                                u32* __restrict__ overflow, CountParamsP cp) {
-    static_assert(KPT % 2 == 0, "keys are prefetched in pairs");
-    __shared__ __attribute__((aligned(16))) u64 tk[CNT_SLOTS];
-    __shared__ unsigned short lst[CP_LST];
-    __shared__ u32 lh[CP_LH];
-    __shared__ u32 s_ctr[2][4];                 // [parity][ndist, out, ovf]
-    const int tid = threadIdx.x, lane = tid & 63;
-    for (int s = tid; s < CNT_SLOTS; s += NT) tk[s] = DSK_EMPTY;
-    for (int b = tid; b < CP_LH; b += NT) lh[b] = 0;
-    if (tid < 8) s_ctr[tid >> 2][tid & 3] = 0;
-    u32 ones = 0;          // lane 0 of each wave: abundance-1 keys seen (flushed at the end)
-    u64 ndist_acc = 0;
-    u32 q = blockIdx.x;
-    u32 n = 0;
-    u64 pk[KPT];
-    // pairs of keys, 16-byte loads; an index past the sub-partition's keys stays inside its region (cap is a multiple of 8)
-    auto prefetch = [&](u32 qq, u32 nn) {
-        const ulonglong2* base = reinterpret_cast<const ulonglong2*>(keys + (u64)qq * cp.cap);
-        const u32 last = (cp.cap >> 1) - 1;
-        if (nn) {
-#pragma unroll
-            for (int u = 0; u < KPT / 2; ++u) {
-                const u32 i = tid + u * NT;
-                const ulonglong2 v = base[i < last ? i : last];
-                pk[2 * u] = v.x; pk[2 * u + 1] = v.y;
-            }
-        }
-    };
-    if (q < cp.F) { n = cp.subcnt[q]; prefetch(q, n); }
-    lds_barrier();
-    int par = 0;
-    while (q < cp.F) {
-        u32* ctr = s_ctr[par];
-        const u64 lobase = __umul64hi((u64)q << 32, cp.finv) << 32;
-        const u64 begin = (u64)q * cp.cap;
-        {
-            u64 rel[KPT]; u32 live = 0;
-#pragma unroll
-            for (int j = 0; j < KPT; ++j) {
-                const u32 i = 2u * (tid + (j >> 1) * NT) + (j & 1);
-                rel[j] = pk[j] - lobase;
-                live |= (i < n ? 1u : 0u) << j;
-            }
-            table_insert_packed<KPT>(tk, lst, ctr, rel, live);
-        }
-        for (u32 i0 = KPT * NT; i0 < n; i0 += NT) {                    // the rest of an oversized sub-partition
-            const u32 i = i0 + tid;
-            u64 rel[1] = {i < n ? keys[begin + i] - lobase : 0ull};
-            table_insert_packed<1>(tk, lst, ctr, rel, i < n ? 1u : 0u);
-        }
-        // prefetch the block's next sub-partition
-        const u32 qn = q + gridDim.x;
-        u32 nn = 0;
-        if (qn < cp.F) { nn = cp.subcnt[qn]; prefetch(qn, nn); }
-        lds_barrier();
-        const u32 nd = ctr[0];
-        const bool bad = ctr[2] || nd > CNT_MAXLOAD;           // block-uniform
-        if (bad) {
-            for (int s = tid; s < CNT_SLOTS; s += NT) tk[s] = DSK_EMPTY;
-            if (tid == 0) *overflow = 1;
-        } else {
-            for (u32 i0 = 0; i0 < nd; i0 += NT) {
-                const u32 i = i0 + tid;
-                const bool act = i < nd;
-                u64 key = 0; u32 c = 0;
-                if (act) {
-                    const u32 slot = lst[i];
-                    const u64 v = tk[slot];
-                    tk[slot] = DSK_EMPTY;
-                    c = (u32)(v & CP_CMASK); key = (v >> CP_CBITS) + lobase;
-                }
-                const u64 m1 = __ballot(act && c == 1);
-                if (lane == 0) ones += __popcll(m1);
-                if (act && c > 1) {
-                    const u32 bin = c < cp.histo_max ? c : cp.histo_max;
-                    if (bin < CP_LH) atomicAdd(&lh[bin], 1u);
-                    else atomicAdd(&ghist[bin], 1ull);
-                }
-                const bool solid = act && c >= cp.amin && c <= cp.amax;
-                const u64 ms = __ballot(solid);
-                if (ms) {
-                    u32 base = 0;
-                    if (lane == 0) base = atomicAdd(&ctr[1], (u32)__popcll(ms));
-                    base = __shfl(base, 0);
-                    if (solid) {
-                        const u32 pos = base + __popcll(ms & ((1ull << lane) - 1));
-                        solid_keys[begin + pos] = key;
-                        abund[begin + pos] = c;
-                    }
-                }
-            }
-        }
-        lds_barrier();
-        if (tid == 0) {
-            nsolid[q] = bad ? 0u : ctr[1];
-            ndist_acc += bad ? 0u : nd;
-            ctr[0] = 0; ctr[1] = 0; ctr[2] = 0;     // this parity is next used two barriers from now
-        }
-        par ^= 1;
-        q = qn; n = nn;
-    }
-    lds_barrier();
-    if (lane == 0 && ones) atomicAdd(&lh[1], ones);
-    lds_barrier();
-    for (int b = tid; b < CP_LH; b += NT) {
         const u32 v = lh[b];
         if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
     }
@@ -1354,7 +1144,7 @@ __global__ __launch_bounds__(CNT_NT) void k_count_mw(KN<W>* keys, KN<W>* solid_k
         }
         lds_barrier();
         const u32 nd = ctr[0];
-        const bool bad = ctr[2] || nd > C2_MAXLOAD;
+        const bool bad = ctr[2] || nd > cp.maxload;
         if (bad) {
             for (int s = tid; s < C2_SLOTS; s += CNT_NT) { slots[s] = 0; tc[s] = 0; }
             if (tid == 0) *overflow = 1;

@@ -42,22 +42,6 @@ template <int W> struct KN { u64 w[W]; };
 typedef KN<2> K2;
 #define DSK_GOLD 0x9e3779b97f4a7c15ULL
 
-#ifdef DSK_MIXN_CHAIN     // the earlier form: an unbalanced Feistel chain, W + 1 rounds of the 64-bit mixer
-template <int W>
-__host__ __device__ __forceinline__ void kmixN(KN<W>& x) {
-#pragma unroll
-    for (int i = W - 2; i >= 0; --i) x.w[i] ^= kmix(x.w[i + 1] + (u64)(W - 2 - i) * DSK_GOLD);
-    x.w[W - 1] ^= kmix(x.w[0] + DSK_GOLD);
-    x.w[W - 1] = kmix(x.w[W - 1]);             // spread within the digit word
-}
-template <int W>
-__host__ __device__ __forceinline__ void kunmixN(KN<W>& x) {
-    x.w[W - 1] = kunmix(x.w[W - 1]);
-    x.w[W - 1] ^= kmix(x.w[0] + DSK_GOLD);
-#pragma unroll
-    for (int i = 0; i <= W - 2; ++i) x.w[i] ^= kmix(x.w[i + 1] + (u64)(W - 2 - i) * DSK_GOLD);
-}
-#else
 // Only the top word has to be mixed: radix digits, table slot and owner are bit fields of it, the other words are
 // just compared for equality.  top' = kmix(top ^ sum_i w[i] * A_i) with odd multipliers (multilinear hash of the
 // lower words folded into the top one, then the 64-bit finalizer): a bijection on the W words for any fold,
@@ -79,7 +63,6 @@ __host__ __device__ __forceinline__ void kunmixN(KN<W>& x) {
     for (int i = 0; i < W - 1; ++i) t += x.w[i] * kfold_mult(i);
     x.w[W - 1] = kunmix(x.w[W - 1]) ^ t;
 }
-#endif
 template <int W>
 __host__ __device__ __forceinline__ bool key_eq(const KN<W>& a, const KN<W>& b) {
     bool e = true;

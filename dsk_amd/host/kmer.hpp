@@ -68,6 +68,7 @@ struct Kmer {
 
     // {value, abundance}: the row type of the "solid" partition (utils/dsk2ascii.cpp:58,87,104)
     struct Count {
+        static const size_t SPAN = span;      // lets generic code (Group::getPartition<Count>) find the row's HDF5 type
         Type value;
         int32_t abundance;
         Count() : abundance(0) {}

@@ -24,8 +24,9 @@ enum StorageMode_e { STORAGE_HDF5 = 0 };
 
 struct HistoEntry { uint16_t index; uint64_t abundance; };
 
-// HDF5 memory type of a row type (caller H5Tclose's it)
-template <class T> struct H5Row;
+template <size_t span> hid_t count_type();
+// HDF5 memory type of a row type (caller H5Tclose's it): Kmer<span>::Count by default, HistoEntry below
+template <class T> struct H5Row { static hid_t make() { return count_type<T::SPAN>(); } };
 template <> struct H5Row<HistoEntry> {
     static hid_t make() {
         hid_t t = H5Tcreate(H5T_COMPOUND, sizeof(HistoEntry));
@@ -59,6 +60,7 @@ public:
 };
 
 class Storage;
+template <class T> class Partition;
 
 class Group {
 public:
@@ -73,9 +75,14 @@ public:
     uint64_t datasetSize(const std::string& name);
     void readDataset(const std::string& name, hid_t memtype, void* rows, uint64_t offset, uint64_t n);
     bool exists(const std::string& name);
+    // The collection of datasets "0".."P-1" under <this group>/<name> with rows of type T, as read by
+    // `storage->getGroup("dsk").getPartition<Count>("solid")` (utils/dsk2ascii.cpp:61).  nbPartitions = 0: an existing
+    // collection (its "nb_partitions" attribute says how many); > 0: a collection being written.  Owned by the group.
+    template <class T> Partition<T>& getPartition(const std::string& name, size_t nbPartitions = 0);
 private:
     Storage* st_; std::string path_;
     std::map<std::string, std::unique_ptr<Group>> subs_;
+    std::map<std::string, std::shared_ptr<void>> parts_;
 };
 
 // Partition<T>: the datasets "0".."P-1" under <group>/<name>, iterated in index order.
@@ -112,6 +119,14 @@ private:
     };
     Group& grp_; hid_t type_; size_t nb_;
 };
+
+template <class T>
+Partition<T>& Group::getPartition(const std::string& name, size_t nbPartitions) {
+    std::shared_ptr<void>& slot = parts_[name];
+    if (!slot || nbPartitions) slot = std::shared_ptr<void>(new Partition<T>(*this, name, H5Row<T>::make(), nbPartitions),
+                                                            [](void* p) { delete static_cast<Partition<T>*>(p); });
+    return *static_cast<Partition<T>*>(slot.get());
+}
 
 class Storage {
 public:

@@ -218,6 +218,8 @@ private:
 // ---------------------------------------------------------------- Tool
 // Tool::run = parse argv -> getInput() properties -> execute() -> print the
 // info tree when -verbose > 0 (src/main.cpp:34, src/DSK.cpp:57,63-64).
+template <class T> class Iterator;      // storage.hpp
+
 class Tool {
 public:
     explicit Tool(const std::string& name) : name_(name), parser_(new OptionsParser(name)), input_(nullptr), info_(new IProperties()) {
@@ -231,6 +233,14 @@ public:
     OptionsParser* getParser() { return parser_; }
     IProperties* getInput() { return input_; }
     IProperties* getInfo() { return info_; }
+    // `tool.createIterator(collection.iterator(), collection.getNbItems(), "parsing")` (utils/dsk2ascii.cpp:77): gatb-core
+    // wraps the iterator in a progress notifier when -verbose asks for one; here it is handed through unchanged (the
+    // caller owns it, e.g. with LOCAL), and the count and the message are accepted for source compatibility.
+    template <class T>
+    Iterator<T>* createIterator(Iterator<T>* iter, size_t nbIterations = 0, const char* message = nullptr) {
+        (void)nbIterations; (void)message;
+        return iter;
+    }
     virtual std::string getVersion() const { return "dsk_amd 0.1 (MI355X-native count path; CLI surface of DSK 2.3.1)"; }
 
     IProperties* run(int argc, char** argv) {

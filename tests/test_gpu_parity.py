@@ -280,6 +280,45 @@ def test_histogram_free_scatters_and_their_fallback(oracle, dev, monkeypatch):
     assert "hist2" in stages and st["n_retries"] == 0
 
 
+def test_mostly_invalid_stream_with_a_dense_tail(oracle, dev):
+    """The level-1 slices are sized from the MEAN number of valid k-mers per block.  A stream that is mostly N with one
+    block's chunks dense in a single repeated k-mer overflows that block's slice of one bin by far: the kernels must
+    keep every write inside the block's own slices (the overflow is reported and the exact path takes over)."""
+    rng = np.random.default_rng(3)
+    n_junk = 6_000_000
+    junk = np.full(n_junk, ord("N"), dtype=np.uint8)
+    junk[rng.integers(0, n_junk, 40_000)] = ord("A")                # isolated bases: no k-mer
+    tail = np.frombuffer(b"A" * 3_000_000, dtype=np.uint8)          # 3 M copies of one k-mer, all in the last blocks' chunks
+    some = np.frombuffer(("\n".join("".join(rng.choice(list("ACGT"), 150)) for _ in range(20_000))).encode(), dtype=np.uint8)
+    stream = np.concatenate([junk, some, np.frombuffer(b"\n", dtype=np.uint8), tail])
+    st = check_against_oracle(oracle, stream, 31, dev, amin=1)
+    assert st["n_levels"] == 2 and st["n_retries"] >= 1
+
+
+def test_table_overflow_retry_partitions_finer(oracle, dev, monkeypatch):
+    """A count table that would hold more distinct keys than its load limit flags overflow and the host repeats the pass
+    with twice the sub-partitions (dskgpu.hip: extra_bits).  DSKGPU_TABLE_MAXLOAD lowers the limit so that the first
+    plan overflows; the result must be the same and stats.n_retries says how often the plan was refined.  A limit no
+    refinement can meet ends with DSKGPU_E_OVERFLOW after three retries."""
+    from dsk_amd import KmerCounter, synth, DskGpuError
+    reads = synth.make_reads(synth.make_genome(300_000, dev), 60_000, 150).cpu().numpy()
+    for k in (31, 63):
+        with KmerCounter(kmer_size=k) as kc:
+            t = torch.from_numpy(reads).to(dev)
+            kc.set_reads_device(t.data_ptr(), t.numel())
+            kc.count()
+            st0 = kc.stats()
+        per_sub = st0["n_distinct"] / st0["n_final_bins"]
+        monkeypatch.setenv("DSKGPU_TABLE_MAXLOAD", str(max(8, int(per_sub * 0.8))))    # the first plan overflows, a 2-4x finer one fits
+        st = check_against_oracle(oracle, reads, k, dev)
+        assert 1 <= st["n_retries"] <= 3 and st["n_final_bins"] > st0["n_final_bins"]
+        monkeypatch.setenv("DSKGPU_TABLE_MAXLOAD", "1")
+        with pytest.raises(DskGpuError) as e:
+            gpu_count(reads, k, dev)
+        assert e.value.code == -5
+        monkeypatch.delenv("DSKGPU_TABLE_MAXLOAD")
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_randomized_two_level_inputs(oracle, dev, seed):
     """Seeded random inputs big enough for two partition levels (the histogram-free scatters), varying k (all key

@@ -262,6 +262,14 @@ def test_kmer_model_unit(bins):
     assert "ALL OK" in out, out
 
 
+def test_boundary_names_compile_and_run(bins, tmp_path):
+    """A caller written with exactly the names SURVEY.md section 8(b) lists (Group::getPartition<Count>, Tool::createIterator,
+    LOCAL, Integer::apply<Functor,Parameter>, StorageFactory, OptionFailure::displayErrors ...) builds against the host layer
+    and round-trips rows through the HDF5 storage (tests/host/test_boundary_names.cpp)."""
+    out = subprocess.run([os.path.join(ROOT, "tests", "host", "test_boundary_names"), "probe"], cwd=str(tmp_path), stdout=subprocess.PIPE).stdout.decode()
+    assert "ALL OK" in out, out
+
+
 def run_solidity_cases(dsk, dsk2ascii, tmp, oracle):
     """-solidity-kind / -solidity-custom / -histo2D through the CLI (shared by the CPU and GPU variants)."""
     import numpy as np

@@ -7,7 +7,7 @@ for spec in $libs; do
   if [[ $spec == *:* ]]; then envs=${spec%%:*}; lib=${spec#*:}; fi
   [ "$lib" = default ] && lib=dsk_amd/libdskgpu.so
   echo "== $spec"
-  env $envs DSKGPU_LIB=$PWD/$lib python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" 2>&1 | tail -1 | python3 -c "
+  env $envs DSKGPU_LIB=$PWD/$lib python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-e2e "$@" 2>&1 | tail -1 | python3 -c "
 import sys,json
 try:
     d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['stage_ms'].items()})

@@ -59,6 +59,19 @@ for kname in sorted(set(fetch) | set(write)):
     summary[st] = {"hbm_bytes_per_launch": tot, "read_bytes": rd, "write_bytes": wr, "avg_ms": ms}
     lines.append(f"| `{kname[:48]}` | {st} | {ms:.3f} | {fk:.0f} | {wk:.0f} | {rd / 1e9:.2f} | {wr / 1e9:.2f} | {tot / 1e9:.2f} | {tot / 1e9 / (ms / 1e3) if ms else 0:.0f} |")
 open(os.path.join(dst, f"{tag}_pmc.md"), "w").write("\n".join(lines) + "\n")
+# what the numbers belong to: bench.py quotes them (roofline.traffic_from_profiles) only for the same workload and k
+bench_line = [l for l in open(os.path.join(src, "bench_trace.log")) if l.startswith('{"metric"')]
+meta = {"id": f"profiles/{tag}_pmc.md", "workload": "c2_10Mx150", "kmer_size": 31}
+if bench_line:
+    cfg = json.loads(bench_line[-1]).get("config", {})
+    meta["workload"] = cfg.get("workload", "").split(":")[0] or meta["workload"]
+    meta["kmer_size"] = cfg.get("kmer_size", meta["kmer_size"])
+try:
+    import subprocess
+    meta["commit"] = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"]).decode().strip()
+except Exception:
+    meta["commit"] = None
+summary["_meta"] = meta
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 bench = [l for l in open(os.path.join(src, "bench_trace.log")) if l.startswith('{"metric"')]
 if bench:
