@@ -441,21 +441,9 @@ def test_determinism_and_reuse(dev):
         assert (k == outs[0][0]).all() and (a == outs[0][1]).all() and (h == outs[0][2]).all()
 
 
-@pytest.mark.parametrize("workload,k", [("ecoli50x", 31), ("c2_10Mx150", 31), ("c2_10Mx150", 63)])
-def test_full_size_invariants(dev, workload, k, monkeypatch):
-    """Size-independent properties at BASELINE.json's full sizes (configs[1] = c2_10Mx150), too big for
-    the oracle in seconds: sum(abundance * hist) == n_kmers, sum(hist) == n_distinct, sortedness,
-    solid count == hist tail, n_kmers == number of full ACGT windows in the stream."""
-    from dsk_amd import synth, KmerCounter
-    gl, nr, rl = synth.workload(workload)
-    g = synth.make_genome(gl, dev)
-    reads = synth.make_reads(g, nr, rl)
-    def count():
-        with KmerCounter(kmer_size=k, abundance_min=2) as kc:
-            kc.set_reads_device(reads.data_ptr(), reads.numel())
-            kc.count()
-            return kc.stats(), kc.histogram().astype(np.int64), kc.rows()
-    st, h, (kmers, ab) = count()
+def full_size_invariants(st, h, kmers, ab, k, reads, nr, rl, dev):
+    """Size-independent properties of a finished count: sum(abundance * hist) == n_kmers, sum(hist) == n_distinct,
+    strictly ascending rows, solid count == hist tail, hist of the rows == hist tail, n_kmers == number of full ACGT windows."""
     idx = np.arange(len(h), dtype=np.int64)
     assert h[-1] == 0                                   # nothing saturates the last row here
     assert int((h * idx).sum()) == st["n_kmers"]
@@ -466,21 +454,97 @@ def test_full_size_invariants(dev, workload, k, monkeypatch):
     else:
         hi, lo = kmers[:, 1].astype(np.uint64), kmers[:, 0].astype(np.uint64)
         assert ((hi[1:] > hi[:-1]) | ((hi[1:] == hi[:-1]) & (lo[1:] > lo[:-1]))).all()
-    if workload != "ecoli50x":      # the histogram-free scatters and the exact histogram + scan path must agree row for row
+    assert (np.bincount(np.minimum(ab, 10000), minlength=10001)[2:] == h[2:]).all()
+    # every read position with a full ACGT window contributes exactly one k-mer
+    r = reads.view(nr, rl + 1)[:, :rl]
+    n_valid = 0
+    step = 2_000_000
+    for r0 in range(0, nr, step):
+        bad = (r[r0:r0 + step] == 78)
+        run = torch.zeros(bad.shape[0], dtype=torch.int32, device=dev)
+        for j in range(rl):
+            run = torch.where(bad[:, j], torch.zeros_like(run), run + 1)
+            n_valid += int((run >= k).sum())
+    assert n_valid == st["n_kmers"]
+
+
+@pytest.mark.parametrize("workload,k", [("ecoli50x", 31), ("c2_10Mx150", 31), ("c2_10Mx150", 63),
+                                        ("c3_shard_25Mx150", 31), ("c3_shard_25Mx150", 63)])
+def test_full_size_invariants(dev, workload, k, monkeypatch):
+    """Size-independent properties at BASELINE.json's full sizes, too big for the oracle in seconds: configs[1] =
+    c2_10Mx150; c3_shard_25Mx150 = one GPU's share (25 M reads, 3.0e9 k-mers at k = 31) of configs[2] (k = 31) and
+    configs[3] (k = 63, two-word keys) -- the 8-GPU topology itself is the driver's to run."""
+    from dsk_amd import synth, KmerCounter
+    gl, nr, rl = synth.workload(workload)
+    g = synth.make_genome(gl, dev)
+    reads = synth.make_reads(g, nr, rl)
+    del g
+    def count():
+        with KmerCounter(kmer_size=k, abundance_min=2) as kc:
+            kc.set_reads_device(reads.data_ptr(), reads.numel())
+            kc.count()
+            return kc.stats(), kc.histogram().astype(np.int64), kc.rows()
+    st, h, (kmers, ab) = count()
+    torch.cuda.empty_cache()
+    if workload == "c2_10Mx150":      # the histogram-free scatters and the exact histogram + scan path must agree row for row
         monkeypatch.setenv("DSKGPU_NO_OPT2", "1")
         st2, h2, (kmers2, ab2) = count()
         monkeypatch.delenv("DSKGPU_NO_OPT2")
         assert (h2 == h).all() and (kmers2 == kmers).all() and (ab2 == ab).all() and st2["n_distinct"] == st["n_distinct"]
-    assert (np.bincount(np.minimum(ab, 10000), minlength=10001)[2:] == h[2:]).all()
-    # every read position with a full ACGT window contributes exactly one k-mer
-    r = reads.view(nr, rl + 1)[:, :rl]
-    bad = (r == 78)
-    n_valid = 0
-    run = torch.zeros(nr, dtype=torch.int32, device=dev)
-    for j in range(rl):
-        run = torch.where(bad[:, j], torch.zeros_like(run), run + 1)
-        n_valid += int((run >= k).sum())
-    assert n_valid == st["n_kmers"]
+    full_size_invariants(st, h, kmers, ab, k, reads, nr, rl, dev)
+
+
+def test_full_size_multi_pass(dev):
+    """BASELINE.json configs[4] ("multi-pass HBM partitioning"): a full-size input counted in >= 8 passes over the key
+    space (forced with max_pass_mkeys on the 25 M-read shard: 3.0e9 k-mers, <= 400 M per pass) must give row for row
+    what the single pass gives, and keep every size-independent invariant."""
+    from dsk_amd import synth, KmerCounter
+    gl, nr, rl = synth.workload("c3_shard_25Mx150")
+    reads = synth.make_reads(synth.make_genome(gl, dev), nr, rl)
+    res = []
+    for mkeys in (0, 400):
+        with KmerCounter(kmer_size=31, abundance_min=2, max_pass_mkeys=mkeys) as kc:
+            kc.set_reads_device(reads.data_ptr(), reads.numel())
+            kc.count()
+            res.append((kc.stats(), kc.histogram().astype(np.int64), kc.rows()))
+        torch.cuda.empty_cache()
+    (st1, h1, (k1, a1)), (st8, h8, (k8, a8)) = res
+    assert st1["n_passes"] == 1 and st8["n_passes"] >= 8
+    assert (h1 == h8).all() and (k1 == k8).all() and (a1 == a8).all()
+    assert st1["n_kmers"] == st8["n_kmers"] and st1["n_distinct"] == st8["n_distinct"]
+    full_size_invariants(st8, h8, k8, a8, 31, reads, nr, rl, dev)
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_full_size_eight_ranks_on_one_device(dev, k):
+    """configs[2] / configs[3] topology, emulated: the 25 M-read shard split over 8 ranks of one in-process group (all on
+    device 0, exchange by device copies), super-k-mer records routed by minimizer owner.  The union of the ranks' rows
+    must equal the single-GPU count of the same reads row for row; owners stay balanced on uniform data."""
+    from dsk_amd import synth, KmerCounter, KmerGroup
+    gl, nr, rl = synth.workload("c3_shard_25Mx150")
+    reads = synth.make_reads(synth.make_genome(gl, dev), nr, rl)
+    with KmerCounter(kmer_size=k, abundance_min=2) as kc:
+        kc.set_reads_device(reads.data_ptr(), reads.numel())
+        kc.count()
+        st1, h1, (k1, a1) = kc.stats(), kc.histogram().astype(np.int64), kc.rows()
+    torch.cuda.empty_cache()
+    ranks = 8
+    per = nr // ranks
+    with KmerGroup([0] * ranks, kmer_size=k, abundance_min=2, nb_partitions=1) as g:
+        for r in range(ranks):
+            lo, hi = r * per * (rl + 1), (nr if r == ranks - 1 else (r + 1) * per) * (rl + 1)
+            g.rank(r).set_reads_device(reads.data_ptr() + lo, hi - lo)
+        g.count()
+        st = g.stats()
+        assert st["n_kmers"] == st1["n_kmers"] and st["n_distinct"] == st1["n_distinct"] and st["n_solid"] == st1["n_solid"]
+        assert (g.histogram().astype(np.int64) == h1).all()
+        got = [g.rank(r).stats()["n_kmers"] for r in range(ranks)]
+        assert max(got) <= 1.1 * (sum(got) / ranks)                # hash of the minimizer: uniform reads spread evenly
+        assert g.exchanged_words() * 8 < 0.45 * st["n_kmers"] * 8 * (1 if k <= 32 else 2)       # records, not keys: < 45 % of explicit keys' bytes
+        parts = [g.partition(p) for p in range(g.num_partitions())]
+    kk = np.concatenate([p[0] for p in parts]); aa = np.concatenate([p[1] for p in parts])
+    order = np.argsort(kk[:, 0], kind="stable") if k <= 32 else np.lexsort((kk[:, 0], kk[:, 1]))
+    assert (kk[order] == k1).all() and (aa[order] == a1).all()
 
 
 @pytest.mark.parametrize("world,k,explicit", [(2, 31, False), (4, 27, False), (2, 63, False), (8, 20, False), (4, 46, False), (2, 64, False),
@@ -528,6 +592,83 @@ def test_multi_gpu_path_on_one_device(oracle, golden_dir, dev, world, k, explici
     assert sum(c.stats()["n_kmers"] for c in ctxs) == ref.total
     for c in ctxs:
         c.close()
+
+
+def _fmix32(h):
+    h = h.astype(np.uint64)
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x85ebca6b)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13); h = (h * np.uint64(0xc2b2ae35)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    return h
+
+
+@pytest.mark.parametrize("world,k,sliced", [(4, 31, False), (2, 63, False), (8, 27, False), (4, 31, True)])
+def test_super_kmer_record_invariants(oracle, golden_dir, dev, monkeypatch, world, k, sliced):
+    """The wire format of the multi-GPU exchange, decoded on the host (superkmer.h; DSK v2's super-k-mers, CHANGELOG.md:13):
+    every record holds 1..16 k-mers as n + k - 1 packed bases; every k-mer of a record maps to the record's owner under an
+    independent numpy restatement of the owner map (owner = hash of the window's minimizer, m-mers ordered by a 32-bit hash
+    of their canonical value); zero-length records exist only as slice padding; the multiset of the canonical k-mers of all
+    records of all ranks equals the oracle's enumeration of the input."""
+    from dsk_amd import KmerCounter
+    from dsk_amd.multi import scatter_records
+    if sliced:
+        monkeypatch.setenv("DSKGPU_SK_MINSLICE", "1")           # the sampled slice layout on a small input
+    else:
+        monkeypatch.setenv("DSKGPU_SK_EXACT", "1")
+    s, _ = oracle.load_bank(os.path.join(golden_dir, "read50x_ref10K_e001.fasta.gz"))
+    if sliced:                                                   # slices need >= 8 tiles per chunk: a longer stream
+        s = np.concatenate([s] * 12)
+    recs = bytes(s).split(b"\n")
+    m = min(10, 16, k - 15)
+    R = (2 * (k + 15) + 8 + 63) // 64
+    nb = 32 * R
+    got = []
+    for r in range(world):
+        shard = torch.from_numpy(np.frombuffer(b"\n".join(recs[r::world]) + b"\n", dtype=np.uint8).copy()).to(dev)
+        with KmerCounter(kmer_size=k, abundance_min=1, world_size=world, rank=r) as kc:
+            kc.set_reads_device(shard.data_ptr(), shard.numel())
+            torch.cuda.synchronize()
+            send, counts = scatter_records(kc, None, dev)
+            torch.cuda.synchronize()
+            words = send[: sum(counts)].cpu().numpy().view(np.uint64).reshape(-1, R)
+        dest = np.repeat(np.arange(world), [c // R for c in counts])
+        n = (words[:, R - 1] & np.uint64(0xFF)).astype(np.int64)
+        assert n.max() <= 16
+        if not sliced:
+            assert n.min() >= 1                                  # the exact layout has no padding
+        keep = n > 0
+        words, dest, n = words[keep], dest[keep], n[keep]
+        # bases[:, i] = 2-bit code of base i of the record (first base in the top bits of word 0)
+        shifts = np.uint64(62) - np.uint64(2) * np.arange(32, dtype=np.uint64)
+        bases = np.concatenate([((words[:, w:w + 1] >> shifts[None, :]) & np.uint64(3)) for w in range(R)], axis=1).astype(np.int64)
+        # canonical m-mer hash at every position of the record (m-mer starting at base i)
+        npos = nb - m + 1
+        fw = np.zeros((len(n), npos), dtype=np.uint64); rv = np.zeros_like(fw)
+        for i in range(m):
+            fw = (fw << np.uint64(2)) | bases[:, i:i + npos].astype(np.uint64)
+            rv = rv | ((bases[:, i:i + npos].astype(np.uint64) ^ np.uint64(2)) << np.uint64(2 * i))
+        hm = _fmix32(np.minimum(fw, rv))
+        wlen = k - m + 1
+        for j in range(16):                                      # k-mer j of every record that has one
+            rows = np.nonzero(n > j)[0]
+            if len(rows) == 0:
+                break
+            mn = hm[rows, j:j + wlen].min(axis=1)
+            owner = ((mn & np.uint64(0xFFFF)) * np.uint64(world)) >> np.uint64(16)
+            assert (owner.astype(np.int64) == dest[rows]).all(), (r, j)
+            if k <= 32:
+                f = np.zeros(len(rows), dtype=np.uint64); rc = np.zeros(len(rows), dtype=np.uint64)
+                for i in range(k):
+                    b = bases[rows, j + i].astype(np.uint64)
+                    f = (f << np.uint64(2)) | b
+                    rc = rc | ((b ^ np.uint64(2)) << np.uint64(2 * i))
+                got.append(np.minimum(f, rc))
+        # a record is cut where the owner changes, at an invalid base or at a 16-window border: never longer than 16
+    if k <= 32:
+        lo, hi, valid = oracle.enumerate(s, k)
+        want = np.sort(lo[valid.astype(bool)])
+        have = np.sort(np.concatenate(got))
+        assert len(have) == len(want) and (have == want).all()
 
 
 def test_sender_slices_and_their_exact_fallback(oracle, dev, monkeypatch):
