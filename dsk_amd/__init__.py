@@ -12,5 +12,6 @@ from .engine import (  # noqa: F401
     KmerCounter,
     KmerGroup,
     load_library,
+    make_table,
     library_path,
 )

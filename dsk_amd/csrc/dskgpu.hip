@@ -113,7 +113,9 @@ struct dskgpu_ctx {
     bool sk_slices = false;        // the prepared send layout is slices from a sampled estimate (else exact offsets)
     bool sk_exact = false;         // a slice overflowed on these reads: exact counts from now on
     SkParams sk_sp{};
-    DevBuf sk_sums, sk_cbase, sk_keys;
+    DevBuf sk_sums, sk_cbase, sk_keys, sk_table, sk_load;
+    std::vector<uint8_t> h_table;  // the repartition table in use (SK_BUCKETS owners; default: bucket scaled to the world size)
+    bool table_dirty = true;       // h_table not yet copied to sk_table
     std::vector<u32> h_sk_sums; std::vector<u64> h_sk_cbase;
     // records handed to dskgpu_mg_count: the level-1 scatter reads them directly (SRC 2); expanded lazily for the exact path
     const u64* rec_src = nullptr; u64 rec_n = 0; u64 rec_nch = 0, rec_rpc = 0; bool rec_expanded = false;
@@ -917,6 +919,30 @@ int mg_scatter_impl(dskgpu_ctx* ctx, void* d_send, uint64_t* send_words) {
     return DSKGPU_OK;
 }
 
+// ---- repartition table of the super-k-mer owner map (superkmer.h)
+void default_table(uint32_t world, uint8_t* table) { for (u32 b = 0; b < SK_BUCKETS; ++b) table[b] = (uint8_t)((b * world) / SK_BUCKETS); }
+int upload_table(dskgpu_ctx* ctx) {
+    if (ctx->h_table.size() != SK_BUCKETS) { ctx->h_table.resize(SK_BUCKETS); default_table(ctx->cfg.world_size, ctx->h_table.data()); ctx->table_dirty = true; }
+    if (ctx->table_dirty) {
+        CK(ctx->sk_table.ensure(SK_BUCKETS));
+        CK(hipMemcpyAsync(ctx->sk_table.p, ctx->h_table.data(), SK_BUCKETS, hipMemcpyHostToDevice, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        ctx->table_dirty = false;
+    }
+    ctx->sk_sp.table = ctx->sk_table.as<unsigned char>();
+    return DSKGPU_OK;
+}
+// tiles / chunks of the sender kernels over the encoded stream
+void sk_geometry(dskgpu_ctx* ctx, u64 nwords) {
+    SkParams& sp = ctx->sk_sp;
+    sp.ngroups = nwords * 2;
+    sp.ntiles = std::max<u64>(1, (sp.ngroups + SK_GROUPS - 1) / SK_GROUPS);
+    u64 nch = std::min<u64>(std::max<u64>(1, sp.ntiles / 8), (u64)ctx->num_cu * 8);     // >= 8 tiles per chunk when there are that many
+    const u64 tpc = (sp.ntiles + nch - 1) / nch;
+    nch = (sp.ntiles + tpc - 1) / tpc;
+    sp.tiles_per_chunk = (u32)tpc; sp.nchunks = (u32)nch;
+}
+
 // ---- multi-GPU exchange as super-k-mer records (superkmer.h)
 // Sender, step 1: encode + count the records per (owner, chunk) + scan.  Leaves the record range of every
 // owner in h_starts; the exact send size is known before the caller allocates the send buffer.
@@ -930,12 +956,9 @@ int sk_prepare(dskgpu_ctx* ctx) {
     if (rc) return rc;
     ctx->mark("encode");
     SkParams& sp = ctx->sk_sp;
-    sp.ngroups = nwords * 2;
-    sp.ntiles = std::max<u64>(1, (sp.ngroups + SK_GROUPS - 1) / SK_GROUPS);
-    u64 nch = std::min<u64>(std::max<u64>(1, sp.ntiles / 8), (u64)ctx->num_cu * 8);     // >= 8 tiles per chunk when there are that many
-    const u64 tpc = (sp.ntiles + nch - 1) / nch;
-    nch = (sp.ntiles + tpc - 1) / tpc;
-    sp.tiles_per_chunk = (u32)tpc; sp.nchunks = (u32)nch;
+    sk_geometry(ctx, nwords);
+    if ((rc = upload_table(ctx))) return rc;
+    const u64 nch = sp.nchunks, tpc = sp.tiles_per_chunk;
     const u64 M = (u64)sp.G * nch;
     CK(ctx->scalars.ensure(SC_COUNT * 4));
     u32* h_sc = ctx->h_sc;
@@ -1224,7 +1247,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
                       &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
                       &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
                       &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,
-                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys};
+                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i) { ctx->out_w[i].release(); ctx->srt_w[i].release(); ctx->acc_w[i].release(); ctx->u_w[i].release(); ctx->s_w[i].release(); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -1360,6 +1383,71 @@ int dskgpu_mg_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, ui
     if (ctx->sk_mode) return sk_scatter(ctx, d_send, capacity_words, send_words);
     if (capacity_words < dskgpu_mg_send_capacity_words(ctx)) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
     return ctx->W == 1 ? mg_scatter_impl<1>(ctx, d_send, send_words) : ctx->W == 2 ? mg_scatter_impl<2>(ctx, d_send, send_words) : mg_scatter_impl<4>(ctx, d_send, send_words);
+}
+
+int dskgpu_mg_sample(dskgpu_ctx* ctx, uint64_t* loads) {
+    if (!ctx || !loads) return DSKGPU_E_ARG;
+    std::memset(loads, 0, (size_t)SK_BUCKETS * 8);
+    if (!ctx->sk_mode) return DSKGPU_OK;            // explicit keys: the owner is a bit field of the k-mer hash, balanced by construction
+    CK(hipSetDevice(ctx->cfg.device));
+    if (ctx->n_bytes >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "read shard too large for 32-bit record offsets");
+    u64 nwords = 0;
+    int rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords);
+    if (rc) return rc;
+    sk_geometry(ctx, nwords);
+    SkParams sp = ctx->sk_sp;
+    sp.sample_step = sp.tiles_per_chunk >= 16 ? 16u : 1u;        // every 16th tile of a large shard, all tiles of a small one
+    sp.table = nullptr;
+    CK(ctx->sk_load.ensure((size_t)SK_BUCKETS * 8));
+    CK(hipMemsetAsync(ctx->sk_load.p, 0, (size_t)SK_BUCKETS * 8, ctx->stream));
+    hipLaunchKernelGGL(k_sk_sample, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
+                       ctx->sk_load.as<unsigned long long>());
+    CKL("k_sk_sample");
+    CK(hipMemcpyAsync(loads, ctx->sk_load.p, (size_t)SK_BUCKETS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    for (u32 b = 0; b < SK_BUCKETS; ++b) loads[b] *= sp.sample_step;      // an estimate of the whole shard's load
+    ctx->sk_prepared = false;                       // packed / inval were rewritten
+    return DSKGPU_OK;
+}
+
+void dskgpu_mg_make_table(const uint64_t* loads, uint32_t world, uint8_t* table) {
+    if (!table) return;
+    if (world == 0) world = 1;
+    default_table(world, table);
+    if (!loads || world == 1) return;
+    u64 total = 0;
+    for (u32 b = 0; b < SK_BUCKETS; ++b) total += loads[b];
+    if (total == 0) return;
+    // a bucket that alone holds more than a quarter of an owner's fair share is split over all owners by k-mer
+    const u64 heavy = std::max<u64>(1, total / world / 4);
+    std::vector<u64> owner_load(world, 0);
+    std::vector<u32> order;
+    u64 split_load = 0;
+    for (u32 b = 0; b < SK_BUCKETS; ++b) {
+        if (loads[b] > heavy) { table[b] = (uint8_t)SK_SPLIT; split_load += loads[b]; }
+        else if (loads[b]) order.push_back(b);        // (buckets the sample did not see keep their default owner)
+    }
+    for (u32 o = 0; o < world; ++o) owner_load[o] = split_load / world;
+    std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return loads[a] > loads[b]; });    // largest first, ties by index
+    for (u32 b : order) {
+        u32 best = 0;
+        for (u32 o = 1; o < world; ++o) if (owner_load[o] < owner_load[best]) best = o;
+        table[b] = (uint8_t)best;
+        owner_load[best] += loads[b];
+    }
+}
+
+int dskgpu_mg_set_table(dskgpu_ctx* ctx, const uint8_t* table) {
+    if (!ctx) return DSKGPU_E_ARG;
+    ctx->h_table.resize(SK_BUCKETS);
+    if (table) {
+        for (u32 b = 0; b < SK_BUCKETS; ++b)
+            if (table[b] != SK_SPLIT && table[b] >= ctx->cfg.world_size) return fail(ctx, DSKGPU_E_ARG, "repartition table names an owner outside the world");
+        std::memcpy(ctx->h_table.data(), table, SK_BUCKETS);
+    } else default_table(ctx->cfg.world_size, ctx->h_table.data());
+    ctx->table_dirty = true;
+    ctx->sk_prepared = false;
+    return DSKGPU_OK;
 }
 
 int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words) {

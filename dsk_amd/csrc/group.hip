@@ -104,6 +104,9 @@ struct dskgpu_group {
     std::vector<std::string> rank_err;
     std::string err;
     uint32_t histo_max = 10000;
+    bool balance = true;                             // build the repartition table from sampled loads before every count
+    std::vector<std::vector<uint64_t>> loads;        // loads[rank][bucket]
+    std::vector<uint8_t> table;
     uint64_t exchanged_words = 0;                    // words that crossed ranks in the last count (off-diagonal of counts)
     bool have_result = false;
 };
@@ -119,6 +122,23 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
     const uint32_t n = g->n;
     dskgpu_ctx* ctx = g->ctx[r];
     if (hipSetDevice(g->dev[r]) != hipSuccess) fail(DSKGPU_E_DEVICE, "hipSetDevice");
+    // ---- step 0: the minimizer repartition table -- sampled bucket loads of every rank, summed, turned into ONE table
+    if (g->balance) {
+        if (g->rc[r] == DSKGPU_OK) {
+            const int rc = dskgpu_mg_sample(ctx, g->loads[r].data());
+            if (rc != DSKGPU_OK) fail(rc, std::string("mg_sample: ") + dskgpu_last_error(ctx));
+        }
+        bar->wait();
+        if (any_failed()) return;
+        if (r == 0) {
+            std::vector<uint64_t> sum(DSKGPU_MG_BUCKETS, 0);
+            for (uint32_t s = 0; s < n; ++s) for (uint32_t b = 0; b < DSKGPU_MG_BUCKETS; ++b) sum[b] += g->loads[s][b];
+            dskgpu_mg_make_table(sum.data(), n, g->table.data());
+        }
+        bar->wait();
+        const int rc = dskgpu_mg_set_table(ctx, g->table.data());
+        if (rc != DSKGPU_OK) fail(rc, std::string("mg_set_table: ") + dskgpu_last_error(ctx));
+    }
     // ---- step 1: this rank's records, grouped by owner
     if (g->rc[r] == DSKGPU_OK) {
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -197,6 +217,8 @@ int dskgpu_group_create(const dskgpu_config* cfg, const int32_t* devices, uint32
     g->send.resize(n_ranks); g->recv.resize(n_ranks);
     g->counts.assign(n_ranks, std::vector<uint64_t>(n_ranks, 0));
     g->rc.assign(n_ranks, DSKGPU_OK); g->rank_err.assign(n_ranks, "");
+    g->loads.assign(n_ranks, std::vector<uint64_t>(DSKGPU_MG_BUCKETS, 0)); g->table.assign(DSKGPU_MG_BUCKETS, 0);
+    if (const char* e = getenv("DSKGPU_GROUP_BALANCE")) g->balance = std::strcmp(e, "0") != 0;     // "0": keep the default table (tests)
     for (uint32_t r = 0; r < n_ranks; ++r) {
         dskgpu_config c = *cfg;
         c.world_size = n_ranks; c.rank = r; c.device = devices[r];

@@ -10,9 +10,15 @@
 //   receiver : k_sk_count -> prefix -> k_sk_expand    (records -> dense array of mixed keys)
 //
 // Minimizer order: the m-mers of a window are compared by a 32-bit hash of their canonical value
-// (a random order balances the owners better than the lexicographic one, which favours poly-A);
-// owner = low 16 bits of the winning hash scaled to [0, G).  Results never depend on this choice:
-// any function of the window that is the same on every rank is a valid owner map.
+// (a random order balances the owners better than the lexicographic one, which favours poly-A).
+// Owner map = a REPARTITION TABLE over SK_BUCKETS minimizer buckets (bucket = bits 15..4 of the winning hash),
+// gatb-core's minimizer repartition (src/DSK.cpp:63 getConfig; the `minimRepart` table) on the GPU:
+//   table[bucket] = owner in [0, G)   or   SK_SPLIT: the bucket is too heavy for any single owner (poly-A, microsatellites):
+//                                          each of its windows goes to the owner of its own K-MER (hash of the canonical
+//                                          k-mer, as in the explicit-key exchange) and travels as a one-k-mer record.
+// The default table scales the bucket to [0, G); a balanced one is built from sampled bucket loads summed over all ranks
+// (k_sk_sample -> dskgpu_mg_make_table: heavy buckets split, the others placed largest first on the least loaded owner).
+// Results never depend on the table: any function of the window that is the same on every rank is a valid owner map.
 //
 // Record = R 64-bit words (R = 2 for k <= 45, 3 for k <= 64):
 //   bases  : n + k - 1 bases, 2 bits each, first base in bits 63..62 of word 0, continuing MSB first
@@ -26,6 +32,8 @@
 #define SK_HALO 4                         // leading groups of a tile that only contribute m-mer hashes (64 positions >= k - m)
 #define SK_GROUPS (SK_NT - SK_HALO)       // groups (16 window ends each) a tile emits records for
 #define SK_MAX_OWNERS 64
+#define SK_BUCKETS 4096                   // minimizer buckets of the repartition table
+#define SK_SPLIT 255u                     // table entry: route the window by its k-mer, not by its minimizer
 
 struct SkParams {
     u64 ngroups;          // 2 * packed words
@@ -34,6 +42,7 @@ struct SkParams {
     u32 k, m, G, R;
     u32 sample_step;      // k_sk_hist: look at every sample_step-th tile only (1 = exact count)
     u32 slice;            // k_sk_scatter<true>: records per (owner, chunk) slice; owner o starts at o * nchunks * slice
+    const unsigned char* table;   // SK_BUCKETS owners (device memory)
 };
 
 __host__ __device__ __forceinline__ u32 sk_record_words(u32 k) { return (2u * (k + 15u) + 8u + 63u) / 64u; }
@@ -55,9 +64,40 @@ __device__ __forceinline__ u32 sk_owner(const SkThread& s, int i) {
     return (u32)((i < 8 ? s.ow_lo >> (8 * i) : s.ow_hi >> (8 * (i - 8))) & 0xFFu);
 }
 
-// Minimizer phase of one tile.  Thread t handles group gfirst + t.  H = SK_NT * 17 words of LDS.
+__device__ __forceinline__ u64 sk_key1(const u64* r, int j, int k);
+__device__ __forceinline__ K2 sk_key2(const u64* r, int j, int k);
+// bases [bs, bs + nb) of the 96-base frame (w2 : w1 : w0), shifted to the top of o[0..2], the rest cleared
+__device__ __forceinline__ void sk_extract(u64 w2, u64 w1, u64 w0, int bs, int nb, u64 (&o)[3]) {
+    const int sh = 2 * bs, ws = sh >> 6, b = sh & 63;
+    const u64 a = ws == 0 ? w2 : ws == 1 ? w1 : w0;
+    const u64 bb = ws == 0 ? w1 : ws == 1 ? w0 : 0ull;
+    const u64 cc = ws == 0 ? w0 : 0ull;
+    o[0] = b ? (a << b) | (bb >> (64 - b)) : a;
+    o[1] = b ? (bb << b) | (cc >> (64 - b)) : bb;
+    o[2] = b ? (cc << b) : cc;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int keep = 2 * nb - 64 * j;
+        o[j] = keep <= 0 ? 0ull : keep >= 64 ? o[j] : (o[j] & ~(~0ull >> keep));
+    }
+}
+// owner of ONE k-mer (the window ending at base t0 + i of word wi): the same bit field of the mixed canonical k-mer as the
+// explicit-key exchange uses (kernels.h key_digit<0>), so a split bucket spreads over all owners
+__device__ __forceinline__ u32 sk_kmer_owner(const u64* __restrict__ packed, u64 wi, int t0, int i, int k, u32 G) {
+    const u64 w0 = packed[wi];
+    const u64 w1 = wi >= 1 ? packed[wi - 1] : 0ull;
+    const u64 w2 = wi >= 2 ? packed[wi - 2] : 0ull;
+    u64 o[3];
+    sk_extract(w2, w1, w0, 64 + t0 + i - k + 1, k, o);
+    const u64 h = k <= 32 ? sk_key1(o, 0, k) : sk_key2(o, 0, k).w[1];
+    return (((u32)(h >> 12) & 0xFFFFFu) * G) >> 20;
+}
+
+// Minimizer phase of one tile.  Thread t handles group gfirst + t.  H = SK_NT * 17 words of LDS; tab = the repartition
+// table in LDS.  SAMPLE: no records -- every valid window adds 1 to load[bucket] (LDS), for the table builder.
+template <bool SAMPLE = false>
 __device__ __forceinline__ SkThread sk_tile(const u64* __restrict__ packed, const u32* __restrict__ inval,
-                                            const SkParams& sp, long long gfirst, u32* H) {
+                                            const SkParams& sp, long long gfirst, u32* H, const unsigned char* tab, u32* load = nullptr) {
     const int t = threadIdx.x;
     const long long g = gfirst + t;
     const bool live = g >= 0 && (u64)g < sp.ngroups;
@@ -103,24 +143,28 @@ __device__ __forceinline__ SkThread sk_tile(const u64* __restrict__ packed, cons
         const u32 i1 = wi >= 1 ? inval[wi - 1] : 0xFFFFFFFFu;
         const u32 i2 = wi >= 2 ? inval[wi - 2] : 0xFFFFFFFFu;
         const u64 inv_lo = ((u64)i1 << 32) | ic;
-        u32 pr = 0xFFFFFFFFu, prev_owner = 0xFFFFu; bool prev_valid = false;
+        u32 pr = 0xFFFFFFFFu, prev_owner = 0xFFFFu; bool prev_valid = false, prev_split = false;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             if (i > 0) pr = h[i] < pr ? h[i] : pr;
             u32 mn = cm < pr ? cm : pr;
             if (i < 15) mn = sl[i] < mn ? sl[i] : mn;
-            const u32 owner = ((mn & 0xFFFFu) * sp.G) >> 16;
+            const u32 bucket = (mn & 0xFFFFu) >> 4;
+            u32 owner = SAMPLE ? 0u : tab[bucket];
+            const bool split = !SAMPLE && owner == SK_SPLIT;
             const int b0 = 31 - (t0 + i);
             const u64 lo_bits = (k + b0 >= 64) ? (~0ull << b0) : (((1ull << k) - 1ull) << b0);
             const int over = k + b0 - 64;
             const u32 hi_bits = over > 0 ? ((over >= 32) ? 0xFFFFFFFFu : ((1u << over) - 1u)) : 0u;
             const bool valid = ((inv_lo & lo_bits) == 0) && ((i2 & hi_bits) == 0);
+            if (SAMPLE) { if (valid) atomicAdd(&load[bucket], 1u); continue; }
+            if (valid && split) owner = sk_kmer_owner(packed, wi, t0, i, k, sp.G);      // (rare: heavy buckets only)
             if (valid) {
                 r.vm |= 1u << i;
-                if (!prev_valid || owner != prev_owner) r.bm |= 1u << i;
+                if (!prev_valid || owner != prev_owner || split || prev_split) r.bm |= 1u << i;      // a split window is a record of its own
             }
             if (i < 8) r.ow_lo |= (u64)owner << (8 * i); else r.ow_hi |= (u64)owner << (8 * (i - 8));
-            prev_valid = valid; prev_owner = owner;
+            prev_valid = valid; prev_owner = owner; prev_split = split;
         }
     }
     return r;
@@ -137,12 +181,15 @@ __global__ __launch_bounds__(SK_NT) void k_sk_hist(const u64* __restrict__ packe
                                                    SkParams sp, u32* __restrict__ mat) {
     __shared__ u32 H[SK_NT * 17];
     __shared__ u32 cnt[SK_MAX_OWNERS];
+    __shared__ unsigned char tab[SK_BUCKETS];
     const u32 c = blockIdx.x;
     if (threadIdx.x < SK_MAX_OWNERS) cnt[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < SK_BUCKETS / 8; i += SK_NT) reinterpret_cast<u64*>(tab)[i] = reinterpret_cast<const u64*>(sp.table)[i];
+    __syncthreads();
     const u64 tbeg = (u64)c * sp.tiles_per_chunk;
     const u64 tend = tbeg + sp.tiles_per_chunk < sp.ntiles ? tbeg + sp.tiles_per_chunk : sp.ntiles;
     for (u64 tile = tbeg; tile < tend; tile += sp.sample_step) {
-        const SkThread s = sk_tile(packed, inval, sp, (long long)(tile * SK_GROUPS) - SK_HALO, H);
+        const SkThread s = sk_tile(packed, inval, sp, (long long)(tile * SK_GROUPS) - SK_HALO, H, tab);
         u32 bm = s.bm;
         while (bm) {
             const int i = __builtin_ctz(bm); bm &= bm - 1;
@@ -152,6 +199,25 @@ __global__ __launch_bounds__(SK_NT) void k_sk_hist(const u64* __restrict__ packe
     }
     __syncthreads();
     if (threadIdx.x < sp.G) mat[(u64)threadIdx.x * sp.nchunks + c] = cnt[threadIdx.x];
+}
+
+// ---------------------------------------------------------------- repartition: sampled k-mer load per minimizer bucket
+// Every sample_step-th tile; load[] += the number of valid windows whose minimizer falls into the bucket.
+__global__ __launch_bounds__(SK_NT) void k_sk_sample(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                                     SkParams sp, unsigned long long* __restrict__ gload) {
+    __shared__ u32 H[SK_NT * 17];
+    __shared__ u32 load[SK_BUCKETS];
+    for (int i = threadIdx.x; i < SK_BUCKETS; i += SK_NT) load[i] = 0;
+    __syncthreads();
+    const u32 c = blockIdx.x;
+    const u64 tbeg = (u64)c * sp.tiles_per_chunk;
+    const u64 tend = tbeg + sp.tiles_per_chunk < sp.ntiles ? tbeg + sp.tiles_per_chunk : sp.ntiles;
+    for (u64 tile = tbeg; tile < tend; tile += sp.sample_step) {
+        (void)sk_tile<true>(packed, inval, sp, (long long)(tile * SK_GROUPS) - SK_HALO, H, nullptr, load);
+        sk_lds_barrier();
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SK_BUCKETS; i += SK_NT) if (load[i]) atomicAdd(&gload[i], (unsigned long long)load[i]);
 }
 
 // ---------------------------------------------------------------- sender: write the records
@@ -164,7 +230,10 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
                                                       SkParams sp, const u32* __restrict__ mat, u64* __restrict__ send, u32* __restrict__ ovf) {
     __shared__ u32 H[SK_NT * 17];
     __shared__ u32 cur[SK_MAX_OWNERS];
+    __shared__ unsigned char tab[SK_BUCKETS];
     const u32 c = blockIdx.x;
+    for (int i = threadIdx.x; i < SK_BUCKETS / 8; i += SK_NT) reinterpret_cast<u64*>(tab)[i] = reinterpret_cast<const u64*>(sp.table)[i];
+    __syncthreads();
     if (threadIdx.x < sp.G) cur[threadIdx.x] = SLICES ? (threadIdx.x * sp.nchunks + c) * sp.slice : mat[(u64)threadIdx.x * sp.nchunks + c];
     bool over = false;
     const u64 tbeg = (u64)c * sp.tiles_per_chunk;
@@ -173,7 +242,7 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
     const u32 R = sp.R;
     for (u64 tile = tbeg; tile < tend; ++tile) {
         const long long gfirst = (long long)(tile * SK_GROUPS) - SK_HALO;
-        const SkThread s = sk_tile(packed, inval, sp, gfirst, H);
+        const SkThread s = sk_tile(packed, inval, sp, gfirst, H, tab);
         u32 bm = s.bm;
         if (bm) {
             const u64 g = (u64)(gfirst + threadIdx.x);
@@ -188,21 +257,8 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
                 const u32 slot = atomicAdd(&cur[own], 1u);
                 if (SLICES && slot >= (own * sp.nchunks + c + 1) * sp.slice) { over = true; continue; }
                 // bases [bs, bs + nb) of the 96-base frame (w2 : w1 : w0), shifted to the top of the record
-                const int bs = 64 + t0 + i - k + 1;
-                const int nb = (int)n + k - 1;
-                const int sh = 2 * bs, ws = sh >> 6, b = sh & 63;
-                const u64 a = ws == 0 ? w2 : ws == 1 ? w1 : w0;
-                const u64 bb = ws == 0 ? w1 : ws == 1 ? w0 : 0ull;
-                const u64 cc = ws == 0 ? w0 : 0ull;
                 u64 o[3];
-                o[0] = b ? (a << b) | (bb >> (64 - b)) : a;
-                o[1] = b ? (bb << b) | (cc >> (64 - b)) : bb;
-                o[2] = b ? (cc << b) : cc;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int keep = 2 * nb - 64 * j;
-                    o[j] = keep <= 0 ? 0ull : keep >= 64 ? o[j] : (o[j] & ~(~0ull >> keep));
-                }
+                sk_extract(w2, w1, w0, 64 + t0 + i - k + 1, (int)n + k - 1, o);
                 u64* dst = send + (u64)slot * R;
                 if (R == 2) { dst[0] = o[0]; dst[1] = o[1] | n; }
                 else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2] | n; }

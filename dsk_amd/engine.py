@@ -57,6 +57,19 @@ class _Stats(C.Structure):
     ]
 
 
+MG_BUCKETS = 4096      # DSKGPU_MG_BUCKETS
+MG_SPLIT = 255         # DSKGPU_MG_SPLIT
+
+
+def make_table(summed_loads: np.ndarray, world_size: int) -> np.ndarray:
+    """dskgpu_mg_make_table: the (deterministic) repartition table for loads summed over all ranks."""
+    loads = np.ascontiguousarray(summed_loads, dtype=np.uint64)
+    assert loads.size == MG_BUCKETS
+    table = np.zeros(MG_BUCKETS, dtype=np.uint8)
+    load_library().dskgpu_mg_make_table(loads.ctypes.data_as(C.POINTER(C.c_uint64)), world_size, table.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return table
+
+
 F_TIMING = 1
 F_NO_SORT = 2
 F_HISTO2D = 4
@@ -67,7 +80,7 @@ SOLIDITY = {"sum": 0, "min": 1, "max": 2, "one": 3, "all": 4, "custom": 5}
 EXPORTS = [
     "dskgpu_create", "dskgpu_destroy", "dskgpu_last_error", "dskgpu_version", "dskgpu_device_count", "dskgpu_set_stream",
     "dskgpu_push_reads", "dskgpu_reserve_reads", "dskgpu_set_reads_device", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
-    "dskgpu_count", "dskgpu_mg_scatter",
+    "dskgpu_count", "dskgpu_mg_scatter", "dskgpu_mg_sample", "dskgpu_mg_make_table", "dskgpu_mg_set_table",
     "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_get_stats", "dskgpu_histogram",
     "dskgpu_num_partitions", "dskgpu_partition_size", "dskgpu_partition_copy", "dskgpu_result_device",
     "dskgpu_stage_times", "dskgpu_k_encode", "dskgpu_k_enumerate", "dskgpu_k_minimizers",
@@ -112,6 +125,10 @@ def load_library():
     lib.dskgpu_set_banks.argtypes = [vp, C.POINTER(u64), u32]
     lib.dskgpu_histogram2d.argtypes = [vp, C.POINTER(u64), u32]
     lib.dskgpu_mg_scatter.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    lib.dskgpu_mg_sample.argtypes = [vp, C.POINTER(u64)]
+    lib.dskgpu_mg_make_table.argtypes = [C.POINTER(u64), u32, C.POINTER(C.c_uint8)]
+    lib.dskgpu_mg_make_table.restype = None
+    lib.dskgpu_mg_set_table.argtypes = [vp, C.POINTER(C.c_uint8)]
     lib.dskgpu_mg_send_capacity_words.argtypes = [vp]
     lib.dskgpu_mg_send_capacity_words.restype = u64
     lib.dskgpu_mg_count.argtypes = [vp, vp, u64]
@@ -273,6 +290,20 @@ class KmerCounter:
         counts = (C.c_uint64 * self.world_size)()
         self._ck(self._lib.dskgpu_mg_scatter(self._h, C.c_void_p(send_ptr), capacity_words, counts))
         return [int(c) for c in counts]
+
+    def mg_sample(self) -> np.ndarray:
+        """Sampled k-mer load of this rank's reads per minimizer bucket (u64[MG_BUCKETS]); sum over ranks, then make_table."""
+        loads = np.zeros(MG_BUCKETS, dtype=np.uint64)
+        self._ck(self._lib.dskgpu_mg_sample(self._h, loads.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return loads
+
+    def mg_set_table(self, table: Optional[np.ndarray]) -> None:
+        if table is None:
+            self._ck(self._lib.dskgpu_mg_set_table(self._h, None))
+        else:
+            t = np.ascontiguousarray(table, dtype=np.uint8)
+            assert t.size == MG_BUCKETS
+            self._ck(self._lib.dskgpu_mg_set_table(self._h, t.ctypes.data_as(C.POINTER(C.c_uint8))))
 
     def mg_count(self, recv_ptr: int, recv_words: int) -> None:
         self._ck(self._lib.dskgpu_mg_count(self._h, C.c_void_p(recv_ptr), recv_words))

@@ -68,16 +68,30 @@ class ShardedCounter:
     """Drives one rank of the sharded count.  After `count()`, the stage holds
     this rank's share of the result (its owned k-mers)."""
 
-    def __init__(self, stage, device: torch.device, group=None):
+    def __init__(self, stage, device: torch.device, group=None, balance: bool = True):
         self.stage = stage
         self.device = device
         self.group = group
+        self.balance = balance and hasattr(stage, "mg_sample")
+        self.table = None            # the repartition table in use (None = the engine's default)
         self.send: Optional[torch.Tensor] = None
         self.recv: Optional[torch.Tensor] = None
         self.last_send_counts: List[int] = []
         self.last_recv_counts: List[int] = []
 
+    def rebalance(self) -> None:
+        """Minimizer repartition (gatb-core's RepartitorAlgorithm): every rank samples the k-mer load of its reads per
+        minimizer bucket, the loads are summed over the ranks (one 32 KB all-reduce) and every rank derives the same table
+        from the sum -- heavy buckets are split by k-mer, the others placed largest first on the least loaded owner."""
+        from .engine import make_table
+        loads = torch.from_numpy(self.stage.mg_sample().astype("int64")).to(self.device)
+        dist.all_reduce(loads, op=dist.ReduceOp.SUM, group=self.group)
+        self.table = make_table(loads.cpu().numpy().astype("uint64"), dist.get_world_size(self.group))
+        self.stage.mg_set_table(self.table)
+
     def count(self) -> None:
+        if self.balance and self.table is None:      # once per read set (call rebalance() again after new reads)
+            self.rebalance()
         self.send, counts = scatter_records(self.stage, self.send, self.device)
         out, rcounts = exchange(self.send, counts, self.group, self.recv)
         if self.recv is None or self.recv.numel() < out.numel() or out.data_ptr() != self.recv.data_ptr():

@@ -120,6 +120,20 @@ int dskgpu_count(dskgpu_ctx* ctx);
  * dskgpu_mg_send_capacity_words runs the sizing pass over the current reads and returns the words
  * dskgpu_mg_scatter will need (0 on error). */
 int dskgpu_mg_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t* send_words);
+/* Minimizer repartition (gatb-core's RepartitorAlgorithm; the call site that reads its result is src/DSK.cpp:63 getConfig):
+ * the owner of a window = table[bucket of its minimizer], DSKGPU_MG_BUCKETS buckets.  Default: the bucket scaled to
+ * world_size.  A balanced table comes from sampled loads: every rank calls dskgpu_mg_sample on its reads (k-mers per bucket,
+ * estimated from every 16th tile), the loads are summed over the ranks (an all-reduce of 32 KB), dskgpu_mg_make_table turns
+ * the sum into a table -- deterministic, so every rank computes the same one -- and dskgpu_mg_set_table installs it before
+ * dskgpu_mg_scatter.  A bucket holding more than a quarter of a fair share (poly-A, microsatellite minimizers) gets
+ * DSKGPU_MG_SPLIT: its windows go to the owner of their own k-mer as one-k-mer records; the others are placed largest first
+ * on the least loaded owner.  The table must be the same on every rank; results never depend on which table is used.
+ * (dskgpu_group_count does all of this by itself.) */
+#define DSKGPU_MG_BUCKETS 4096
+#define DSKGPU_MG_SPLIT 255
+int dskgpu_mg_sample(dskgpu_ctx* ctx, uint64_t* loads /* [DSKGPU_MG_BUCKETS] */);
+void dskgpu_mg_make_table(const uint64_t* summed_loads, uint32_t world_size, uint8_t* table /* [DSKGPU_MG_BUCKETS] */);
+int dskgpu_mg_set_table(dskgpu_ctx* ctx, const uint8_t* table /* [DSKGPU_MG_BUCKETS], NULL = default */);
 uint64_t dskgpu_mg_send_capacity_words(dskgpu_ctx* ctx);
 int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words);
 

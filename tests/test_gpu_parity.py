@@ -902,6 +902,49 @@ def test_group_count_in_one_process(oracle, golden_dir, dev, monkeypatch, ranks,
                 assert sum(per_rank) == ref.total and min(per_rank) > 0
 
 
+def test_repartition_table_balances_heavy_minimizers(oracle, dev, monkeypatch):
+    """Minimizer repartition (gatb-core's RepartitorAlgorithm, src/DSK.cpp:63): a quarter of the reads are noisy poly-A, so
+    one minimizer (A^10) carries ~ 25 % of all windows.  With the default owner map (hash of the minimizer scaled to the
+    world) one of four ranks receives far more than its share; with the table built from sampled bucket loads (heavy
+    buckets split by k-mer, the rest placed largest first) max / mean of the received k-mers stays <= 1.5.  Same rows,
+    same histogram either way."""
+    from dsk_amd import KmerGroup, synth, make_table, KmerCounter
+    rng = np.random.default_rng(7)
+    normal = synth.make_reads(synth.make_genome(300_000, dev), 60_000, 150).cpu().numpy().reshape(-1, 151)
+    polya = np.full((20_000, 151), ord("A"), dtype=np.uint8); polya[:, 150] = 10
+    noise = rng.random((20_000, 150)) < 0.05
+    polya[:, :150][noise] = rng.choice(np.frombuffer(b"CGT", dtype=np.uint8), int(noise.sum()))
+    reads = np.concatenate([normal, polya]); rng.shuffle(reads)
+    stream = reads.reshape(-1)
+    ref = oracle.count(stream, 31)
+    lo, hi, rab = ref.solid(2)
+    world, per = 4, len(reads) // 4
+    ratios = {}
+    for balance in ("0", "1"):
+        monkeypatch.setenv("DSKGPU_GROUP_BALANCE", balance)
+        with KmerGroup([0] * world, kmer_size=31, abundance_min=2, nb_partitions=1) as g:
+            for r in range(world):
+                g.rank(r).push_reads(reads[r * per: (r + 1) * per if r < world - 1 else len(reads)].reshape(-1))
+            g.count()
+            got = [g.rank(r).stats()["n_kmers"] for r in range(world)]
+            assert sum(got) == ref.total and (g.histogram() == ref.histogram(10000)).all()
+            parts = [g.partition(p) for p in range(g.num_partitions())]
+            kk = np.concatenate([p[0][:, 0] for p in parts]); aa = np.concatenate([p[1] for p in parts])
+            order = np.argsort(kk)
+            assert (kk[order] == lo).all() and (aa[order] == rab).all()
+            ratios[balance] = max(got) / (sum(got) / world)
+    assert ratios["0"] > 1.5, ratios            # the skew is real without the table ...
+    assert ratios["1"] <= 1.5, ratios           # ... and gone with it
+    # the table itself: deterministic, names only owners of the world, splits the heavy bucket
+    with KmerCounter(kmer_size=31, world_size=world, rank=0) as kc:
+        t = torch.from_numpy(stream.copy()).to(dev)
+        kc.set_reads_device(t.data_ptr(), t.numel())
+        loads = kc.mg_sample()
+    table = make_table(loads, world)
+    assert (make_table(loads, world) == table).all() and (table == 255).sum() >= 1 and table[table != 255].max() < world
+    assert loads.sum() > 0.5 * ref.total and loads.sum() < 2.0 * ref.total        # sampled estimate of all windows
+
+
 def test_exchange_over_rccl_single_rank(oracle, golden_dir, dev):
     """The `nccl` branch of dsk_amd.multi.exchange (variable-size all_to_all_single on device tensors) and the whole
     ShardedCounter step under init_process_group("nccl", world_size=1): ragged, empty and repeated exchanges."""

@@ -63,6 +63,17 @@ class CpuStage:
         np.ctypeslib.as_array(buf)[: len(h)] = h
         return counts
 
+    # minimizer repartition (multi.ShardedCounter.rebalance): the stand-in keeps its own owner map, but takes part in the
+    # protocol -- per-rank loads, summed over the ranks, one table derived by every rank from the same sum
+    def mg_sample(self):
+        loads = np.zeros(4096, dtype=np.uint64)
+        loads[: 64] = np.arange(64, dtype=np.uint64) * np.uint64(self.world + 1) + np.uint64(len(self.stream) % 97)
+        loads[777] = 10 ** 9                      # one heavy bucket
+        return loads
+
+    def mg_set_table(self, table):
+        self.table = None if table is None else np.array(table, dtype=np.uint8)
+
     def mg_count(self, ptr, n):
         import ctypes
         if n:
@@ -90,6 +101,10 @@ def _worker(rank, world, port, k, tmpdir):
     stage = CpuStage(oracle, shard, k, world)
     sc = ShardedCounter(stage, torch.device("cpu"))
     sc.count()
+    # the repartition table: same on every rank (built from the all-reduced loads), heavy bucket split, owners inside the world
+    tabs = [torch.zeros(4096, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(tabs, torch.from_numpy(stage.table.copy()))
+    assert all((t == tabs[0]).all() for t in tabs) and int(tabs[0][777]) == 255 and int(tabs[0][tabs[0] != 255].max()) < world
     keys, cnt, h = stage.rows
     assert (owner_of(h, world) == rank).all()            # every received record is owned by this rank
     assert sum(sc.last_recv_counts) == len(h)
