@@ -580,9 +580,9 @@ __global__ __launch_bounds__(256) void k_count_valid(const u32* __restrict__ inv
             // frame of 64 bases (previous word : this word), bit (63 - i) <-> base i.  A window ending at base e is bad if
             // an invalid base lies in [e-k+1, e]: smear every invalid bit over the k-1 following bases (log-step ORs)
             u64 bad = ((u64)(w ? inval[w - 1] : 0xFFFFFFFFu) << 32) | ic;
-            int done = 1;                                   // bases covered by the smear so far
-            while (2 * done <= k) { bad |= bad >> done; done *= 2; }
-            if (k > done) bad |= bad >> (k - done);
+            int rem = k - 1;                                // bases still to cover: steps of 1, 2, 4, 8, 16 (or what is left), as in gen_kmers1
+#pragma unroll
+            for (int st = 1; st <= 16; st <<= 1) { const int sh = rem < st ? rem : st; bad |= bad >> sh; rem -= sh; }
             c += 32u - (u32)__popc((u32)bad);
         } else {
             // longer windows: run = valid bases that end just before this word (walk back over whole valid words), then roll

@@ -97,6 +97,18 @@ __device__ __forceinline__ u32 gen_kmers1(const u64* __restrict__ packed, const 
     u64 rc = (rev_pairs(fwd) >> (64 - 2 * k)) ^ (0xAAAAAAAAAAAAAAAAULL & kmask);
     const int rcs = 2 * k - 2;
     u32 vmask = 0;
+    if (NP == 16) {
+        // validity of all 16 windows at once: smear every invalid bit over the k - 1 following bases (log-step ORs), then the
+        // window ending at base t of `cur` is bad iff bit (31 - t) is set; bit j of the result <-> t = t0 + j (t0 is 0 or 16).
+        // (Straight-line on purpose: the same smear written as `while (2 * done <= k)` with the shift count in a scalar register
+        //  lost a few windows in 10^4, differently from run to run, inside k_hist / k_scatter on gfx950 / ROCm 7.2 -- and not in
+        //  a stand-alone kernel; the five fixed steps below are exact everywhere, see tools/micro/smear_test.hip.)
+        u64 bad = invwin;
+        int rem = k - 1;                                      // bases still to cover: steps of 1, 2, 4, 8, 16 (or what is left)
+#pragma unroll
+        for (int st = 1; st <= 16; st <<= 1) { const int sh = rem < st ? rem : st; bad |= bad >> sh; rem -= sh; }
+        vmask = __brev(~(u32)(bad >> (16 - t0)) & 0xFFFFu) >> 16;
+    }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int t = t0 + j;
@@ -104,7 +116,7 @@ __device__ __forceinline__ u32 gen_kmers1(const u64* __restrict__ packed, const 
         fwd = ((fwd << 2) | c) & kmask;
         rc = (rc >> 2) | ((c ^ 2ull) << rcs);
         canon[j] = fwd < rc ? fwd : rc;
-        if ((invwin & (kbits << (31 - t))) == 0) vmask |= (1u << j);
+        if (NP != 16 && (invwin & (kbits << (31 - t))) == 0) vmask |= (1u << j);
     }
     return vmask;
 }
