@@ -616,7 +616,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             const u64 cpb = (nch1 + grid1 - 1) / grid1;
             u64 slice = ctx->h_nvalid / npass * cpb / ((u64)nch1 * pl.P1) + 1; slice += slice * 3 / 50 + 160; slice = (slice + 7) & ~7ull;   // mean + 6 % + 160
             if (ctx->tune.opt_slice) slice = ctx->tune.opt_slice;                                            // experiments / tests
-            const u64 tail = ctx->h_nvalid / npass / grid1 * 2 + 2 * Tile<W>::KEYS;                                     // worst overrun of one block
+            const u64 tail = 2 * Tile<W>::KEYS;                         // the dump zone behind the last bin (a tile's keys of a bin that outgrew its slice land there)
             if (slice < 8 || cells * slice + tail >= 0xFFFF0000ull) opt1 = false;
             else {
                 o1.slice = (u32)slice; o1.cap1 = (u32)(slice * grid1);

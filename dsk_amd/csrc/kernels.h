@@ -325,8 +325,13 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan_apply(u32* __restrict__ a, con
 //   off[b]   = start of bin b inside the staged tile
 //   delta[b] = cur[b] - off[b]   (HBM index of staged element i of bin b is delta[b] + i)
 //   cur[b]  += cnt[b];  cnt[b] = 0
+// slice != 0 (block-owned slices): bin b may only be written inside [b * cap1 + first, + slice); a bin whose keys of this tile
+// would not fit is redirected, for this tile, to the dump zone [dump, dump + tile) behind the last bin (never read) -- the
+// check costs a few instructions per BIN and tile instead of per key, and nothing is ever written outside the block's own
+// slices or the dump zone.  cur[] keeps advancing, so the overflow shows at the end of the launch.
+struct SliceGuard { u32 slice, cap1, first, dump; };
 template <int NT>
-__device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* cur, int P, u32* wsum, u32* tot) {
+__device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* cur, int P, u32* wsum, u32* tot, SliceGuard sg = SliceGuard{0u, 0u, 0u, 0u}) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ipt = (P + NT - 1) / NT;
     const int base = tid * ipt;
@@ -357,7 +362,8 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
         const int idx = base + j;
         if (j < ipt && idx < P) {
             const u32 c = cur[idx];
-            off[idx] = run; delta[idx] = c - run; cur[idx] = c + v[j]; cnt[idx] = 0;
+            const bool fits = sg.slice == 0u || c + v[j] <= (u32)idx * sg.cap1 + sg.first + sg.slice;
+            off[idx] = run; delta[idx] = fits ? c - run : sg.dump; cur[idx] = c + v[j]; cnt[idx] = 0;
             run += v[j];
         }
     }
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
 #pragma unroll
             for (int j = 0; j < KPT; ++j) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
             lds_barrier();
-            tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot);
+            tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot, OPT ? SliceGuard{o1.slice, o1.cap1, blockIdx.x * o1.slice, P * o1.cap1} : SliceGuard{0u, 0u, 0u, 0u});
             lds_barrier();
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
@@ -517,9 +523,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const u32 i = i0 + u * SC_NT + threadIdx.x;
-                    // OPT: nothing is ever written past the block's own slice of the bin (the overflow is reported at the end of the launch)
-                    const bool fits = !OPT || dd[u] + i < key_digit<MODE>(digit_word(hk[u]), ds) * o1.cap1 + (blockIdx.x + 1) * o1.slice;
-                    if (i < ntile && fits) out[(u64)(dd[u] + i)] = hk[u];
+                    if (i < ntile) out[(u64)(dd[u] + i)] = hk[u];        // (OPT: tile_scan keeps a bin that outgrew its slice out of the other slices)
                 }
             }
             // no barrier here: the next tile's rank phase only touches cnt (zeroed
