@@ -1136,7 +1136,7 @@ int run_banks(dskgpu_ctx* ctx) {
     CK(ctx->s_w[0].ensure((nu + 1) * 8)); CK(ctx->s_val.ensure((nu + 1) * 8));
     const unsigned gb = (unsigned)std::max<u64>(1, (nu + 255) / 256);
     if (nu) {
-        size_t tmp = 0, tmp2 = 0;
+        size_t tmp = 0;
         if (W == 1) {
             const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
             CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->u_w[0].as<u64>(), ctx->s_w[0].as<u64>(), ctx->u_val.as<u64>(), ctx->s_val.as<u64>(), (size_t)nu, 0u, end_bit, ctx->stream));
