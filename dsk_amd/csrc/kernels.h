@@ -493,7 +493,11 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
         if (threadIdx.x == 0) cnt[P] = 0;
         const u64 step = SRC == 0 ? Tile<W>::WORDS : Tile<W>::KEYS;
         Key ha[KPT], hb[KPT]; u32 vma = 0, vmb = 0;
-        auto process = [&](Key (&h)[KPT], u32 vm) {
+        // a tile in two parts, so that the reads-source loop can put the NEXT tile's loads between them: vmcnt counts loads and
+        // stores in issue order, so loads issued after the write-out's stores can only be waited for together with every one
+        // of those stores (a full store round trip per tile); issued before them, they are older and the wait leaves the
+        // stores in flight -- which needs their number to be known: the write-out is a fixed KPT / 4 trips of 4 predicated stores
+        auto rank_and_stage = [&](Key (&h)[KPT], u32 vm) {
             u32 rk[KPT];
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
@@ -513,8 +517,12 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
             }
             if (threadIdx.x == 0) cnt[P] = 0;
             lds_barrier();
+        };
+        auto write_out = [&]() {
             const u32 ntile = *tot;
-            for (u32 i0 = 0; i0 < ntile; i0 += 4 * SC_NT) {
+#pragma unroll
+            for (int it = 0; it < (KPT + 3) / 4; ++it) {
+                const u32 i0 = (u32)it * 4 * SC_NT;
                 Key hk[4]; u32 dd[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { const u32 i = i0 + u * SC_NT + threadIdx.x; hk[u] = stage[i < ntile ? i : 0]; }
@@ -523,13 +531,18 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const u32 i = i0 + u * SC_NT + threadIdx.x;
-                    if (i < ntile) out[(u64)(dd[u] + i)] = hk[u];        // (OPT: tile_scan keeps a bin that outgrew its slice out of the other slices)
+                    // (OPT: tile_scan keeps a bin that outgrew its slice out of the other slices.)  With slices there is a dump zone
+                    // behind the last bin: a lane past the tile's keys stores there instead of being masked off, so that every trip
+                    // issues exactly 4 stores -- the compiler can then count them (see rank_and_stage)
+                    if (OPT) out[i < ntile ? (u64)(dd[u] + i) : (u64)(P * o1.cap1 + i)] = hk[u];
+                    else if (i < ntile) out[(u64)(dd[u] + i)] = hk[u];
                 }
             }
             // no barrier here: the next tile's rank phase only touches cnt (zeroed
             // by tile_scan); its first barrier orders this write-out before the
             // next tile_scan / stage writes.
         };
+        auto process = [&](Key (&h)[KPT], u32 vm) { rank_and_stage(h, vm); write_out(); };
         if (SRC == 1 && d.begin < d.end) vma = tile_keys_array<W>(keys, d.begin, d.end, ha);
         lds_barrier();
         if constexpr (SRC == 2) {              // records: `packed` is the record array, the chunk range is in records
@@ -538,6 +551,34 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                 vma = tile_keys_records<W>(packed, o1.R, r0, d.end, k, ha, smem, wsum, &taken);
                 process(ha, vma);
                 r0 += taken ? taken : 1u;
+            }
+        } else if constexpr (SRC == 0 && W == 1) {
+            // one-word keys from the reads: the four words a thread needs for the NEXT tile are requested before the stores of this one
+            struct Raw { u64 cur, prev; u32 ic, ip; };
+            auto load_raw = [&](u64 t0) {
+                const u64 wi = t0 + (threadIdx.x >> 1);
+                const u64 wc = wi < d.end ? wi : d.end - 1;                   // clamped: the loads stay unconditional (and countable)
+                Raw r; r.cur = packed[wc]; r.prev = packed[wc ? wc - 1 : 0]; r.ic = inval[wc]; r.ip = inval[wc ? wc - 1 : 0];
+                if (wc == 0) { r.prev = 0ull; r.ip = 0xFFFFFFFFu; }
+                return r;
+            };
+            if (d.begin < d.end) {
+                Raw raw = load_raw(d.begin);
+                if (OPT) {          // as many (dump-zone) stores behind the first loads as a tile's write-out issues behind the prefetched ones:
+#pragma unroll                      // the loop is then entered with the same in-flight picture on both edges and the wait at its top is exact
+                    for (int u = 0; u < 4 * ((KPT + 3) / 4); ++u) out[(u64)(P * o1.cap1 + u * SC_NT + threadIdx.x)] = (u64)threadIdx.x;
+                }
+                for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
+                    const bool live = t0 + (threadIdx.x >> 1) < d.end;
+                    vma = gen_kmers1_words<16>(raw.cur, raw.prev, raw.ic, raw.ip, (threadIdx.x & 1) * 16, k, ha);
+                    if (!live) vma = 0u;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) ha[j] = kmix(ha[j]);
+                    rank_and_stage(ha, vma);
+                    const u64 tn = t0 + step < d.end ? t0 + step : t0;      // (the last tile re-reads its own words: same number of loads every trip)
+                    raw = load_raw(tn);
+                    write_out();
+                }
             }
         } else if constexpr (SRC == 0) {
             for (u64 t0 = d.begin; t0 < d.end; t0 += step) {

@@ -81,13 +81,9 @@ __device__ __forceinline__ u64 rev_pairs(u64 x) {
 // Generate the canonical k-mers of the NP windows ending at bases
 // 32*wi + t0 .. 32*wi + t0 + NP-1   (t0 + NP <= 32).
 // canon[j] valid iff bit j of the returned mask is set.
+// (the words of the frame already in registers: cur / prev = packed[wi], packed[wi-1]; ic / ip = their invalid masks)
 template <int NP>
-__device__ __forceinline__ u32 gen_kmers1(const u64* __restrict__ packed, const u32* __restrict__ inval,
-                                          u64 wi, int t0, int k, u64 (&canon)[NP]) {
-    const u64 cur = packed[wi];
-    const u64 prev = wi ? packed[wi - 1] : 0ull;
-    const u32 ic = inval[wi];
-    const u32 ip = wi ? inval[wi - 1] : 0xFFFFFFFFu;
+__device__ __forceinline__ u32 gen_kmers1_words(u64 cur, u64 prev, u32 ic, u32 ip, int t0, int k, u64 (&canon)[NP]) {
     const u64 invwin = ((u64)ip << 32) | ic;                 // bit (63-i) <-> base i of (prev:cur)
     const u64 kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
     const u64 kbits = (1ull << k) - 1;                       // k <= 32
@@ -119,6 +115,12 @@ __device__ __forceinline__ u32 gen_kmers1(const u64* __restrict__ packed, const 
         if (NP != 16 && (invwin & (kbits << (31 - t))) == 0) vmask |= (1u << j);
     }
     return vmask;
+}
+
+template <int NP>
+__device__ __forceinline__ u32 gen_kmers1(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                          u64 wi, int t0, int k, u64 (&canon)[NP]) {
+    return gen_kmers1_words<NP>(packed[wi], wi ? packed[wi - 1] : 0ull, inval[wi], wi ? inval[wi - 1] : 0xFFFFFFFFu, t0, k, canon);
 }
 
 // ---------------------------------------------------------------- two-word k-mers (33 <= k <= 64)
