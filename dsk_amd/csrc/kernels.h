@@ -1010,31 +1010,37 @@ __global__ __launch_bounds__(CNT_NT) void k_count1(u64* keys, u64* solid_keys, c
     auto range_hi = [&](u32 qq) { const u32 c = qq < cp.F ? qq : cp.F - 1; return REG ? 0u : fstart[c + 1]; };
     auto begin_of = [&](u32 qq, u32 lo) { return REG ? (u64)qq * cp.cap : (u64)lo; };
     auto count_of = [&](u32 qq, u32 lo, u32 hi) { return qq < cp.F ? (REG ? lo : hi - lo) : 0u; };
-    u32 q = blockIdx.x;
-    u64 pk[CNT_KPT];
-    auto load_keys = [&](u64 beg, u32 nn) {      // branch-free: an index past the keys re-reads the last one (or key 0 of an empty range)
-        const u32 last = nn ? nn - 1 : 0u;
+    // two register sets of keys, used in turn: the keys of sub-partition q + 2 * grid are requested when q's inserts are done
+    // and consumed two iterations later, so by then neither the loads nor the solid-row stores issued in between (vmcnt counts
+    // both, in issue order) hold the wave up
+    struct Sub { u32 q; u64 begin; u32 n; };
+    auto load_keys = [&](const Sub& sb, u64 (&pk)[CNT_KPT]) {      // branch-free: an index past the keys re-reads the last one (or key 0 of an empty range)
+        const u32 last = sb.n ? sb.n - 1 : 0u;
 #pragma unroll
-        for (int j = 0; j < CNT_KPT; ++j) { const u32 i = tid + j * CNT_NT; pk[j] = keys[beg + (i < nn ? i : last)]; }
+        for (int j = 0; j < CNT_KPT; ++j) { const u32 i = tid + j * CNT_NT; pk[j] = keys[sb.begin + (i < sb.n ? i : last)]; }
     };
-    u32 lo = range_lo(q), hi = range_hi(q);
-    u64 begin = q < cp.F ? begin_of(q, lo) : 0ull; u32 n = count_of(q, lo, hi);
-    u32 nlo = range_lo(q + gridDim.x), nhi = range_hi(q + gridDim.x);
-    load_keys(begin, n);
+    auto sub_of = [&](u32 qq, u32 lo, u32 hi) { Sub sb; sb.q = qq; sb.begin = qq < cp.F ? begin_of(qq, lo) : 0ull; sb.n = count_of(qq, lo, hi); return sb; };
+    const u32 G = gridDim.x;
+    u64 pa[CNT_KPT], pb[CNT_KPT];
+    Sub sa = sub_of(blockIdx.x, range_lo(blockIdx.x), range_hi(blockIdx.x));
+    Sub sb = sub_of(blockIdx.x + G, range_lo(blockIdx.x + G), range_hi(blockIdx.x + G));
+    u32 rq = blockIdx.x + 2 * G, rlo = range_lo(rq), rhi = range_hi(rq);        // range of the sub-partition whose keys are loaded next
+    load_keys(sa, pa);
+    load_keys(sb, pb);
     lds_barrier();
     int par = 0;
-    while (q < cp.F) {
+    // inserts of `cur` from its register set, then the set is refilled with the keys of sub-partition rq; then cur's sweep
+    auto one = [&](Sub& cur, u64 (&pk)[CNT_KPT]) {
         u32* ctr = s_ctr[par];
+        const u32 q = cur.q, n = cur.n; const u64 begin = cur.begin;
 #pragma unroll
         for (int j = 0; j < CNT_KPT; ++j)
             if ((u32)(tid + j * CNT_NT) < n) table_insert1(tk, tc, lst, &ctr[0], &ctr[2], pk[j]);
         for (u32 i = CNT_KPT * CNT_NT + tid; i < n; i += CNT_NT)                 // oversized sub-partition
             table_insert1(tk, tc, lst, &ctr[0], &ctr[2], keys[begin + i]);
-        // the range two sub-partitions ahead, then the keys of the next one (its range arrived an iteration ago)
-        const u32 qn = q + gridDim.x;
-        const u32 flo = range_lo(qn + gridDim.x), fhi = range_hi(qn + gridDim.x);
-        const u64 nbeg = qn < cp.F ? begin_of(qn, nlo) : 0ull; const u32 nn = count_of(qn, nlo, nhi);
-        load_keys(nbeg, nn);
+        cur = sub_of(rq, rlo, rhi);
+        load_keys(cur, pk);
+        rq += G; rlo = range_lo(rq); rhi = range_hi(rq);
         lds_barrier();
         const u32 nd = ctr[0];
         const bool bad = ctr[2] || nd > cp.maxload;            // block-uniform
@@ -1079,7 +1085,11 @@ __global__ __launch_bounds__(CNT_NT) void k_count1(u64* keys, u64* solid_keys, c
             ctr[0] = 0; ctr[1] = 0; ctr[2] = 0;     // this parity is next used two barriers from now
         }
         par ^= 1;
-        q = qn; begin = nbeg; n = nn; nlo = flo; nhi = fhi;
+    };
+    while (sa.q < cp.F) {
+        one(sa, pa);
+        if (sb.q >= cp.F) break;
+        one(sb, pb);
     }
     lds_barrier();
     // flush block-local histogram
