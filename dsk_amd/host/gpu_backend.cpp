@@ -56,7 +56,7 @@ public:
         size_t beg = 0;
         for (uint32_t i = 0; i < N && beg < n; ++i, r = (r + 1) % N) {
             size_t end = i + 1 == N ? n : std::max(beg, n * (i + 1) / N);
-            while (end < n && data[end - 1] != '\n') ++end;          // a piece ends after a separator: k-mers never span pieces
+            while (end < n && (end == 0 || data[end - 1] != '\n')) ++end;          // a piece ends after a separator: k-mers never span pieces
             if (end == beg) continue;
             ckr(r, dskgpu_push_reads(dskgpu_group_ctx(grp_, r), data + beg, end - beg));
             pushed_[r] += end - beg;
