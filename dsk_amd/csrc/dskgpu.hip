@@ -1469,6 +1469,7 @@ int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words) {
     if (ctx->sk_mode)
         return ctx->W == 1 ? sk_count<1>(ctx, static_cast<const u64*>(d_recv), recv_words) : sk_count<2>(ctx, static_cast<const u64*>(d_recv), recv_words);
     if (recv_words % (u64)ctx->W) return fail(ctx, DSKGPU_E_ARG, "recv_words is not a whole number of k-mer records");
+    if (!d_recv) { CK(ctx->sk_keys.ensure(64)); d_recv = ctx->sk_keys.p; }      // nothing received: a null key array would read as "keys come from records"
     if (ctx->W == 1) return run_pipeline<1>(ctx, false, static_cast<const u64*>(d_recv), recv_words);
     if (ctx->W == 2) return run_pipeline<2>(ctx, false, static_cast<const K2*>(d_recv), recv_words / 2);
     return run_pipeline<4>(ctx, false, static_cast<const KN<4>*>(d_recv), recv_words / 4);

@@ -77,6 +77,22 @@ def test_nb_gpus_writes_one_storage(bins, tmp_path, ngpus):
     assert hashlib.md5(b"\n".join(lines) + b"\n").hexdigest() == "5b4da4c690bb00783eb5fdc49fc19466"
 
 
+def test_nb_gpus_with_fewer_reads_than_ranks(bins, tmp_path):
+    """Ranks that get no reads at all (one short read, four ranks) and a k longer than the read: the group still writes the
+    reference's answer (scripts/simple_test.sh T4 / T5 with test/short.parse_results)."""
+    from tests.test_host_cli import G
+    tmp = str(tmp_path)
+    subprocess.check_call([bins["dsk"], "-file", f"{G}/shortread.fasta", "-kmer-size", "15", "-abundance-min", "1", "-out", "s4", "-nb-gpus", "4", "-verbose", "0"], cwd=tmp)
+    subprocess.check_call([bins["dsk2ascii"], "-file", "s4", "-out", "s4.txt", "-verbose", "0"], cwd=tmp)
+    assert sorted(open(os.path.join(tmp, "s4.txt")).read().splitlines()) == sorted(open(f"{G}/short.parse_results").read().splitlines())
+    subprocess.check_call([bins["dsk"], "-file", f"{G}/shortread.fasta", "-kmer-size", "16", "-out", "s16", "-nb-gpus", "2", "-verbose", "0"], cwd=tmp)
+    subprocess.check_call([bins["dsk2ascii"], "-file", "s16", "-out", "s16.txt", "-verbose", "0"], cwd=tmp)
+    assert os.path.getsize(os.path.join(tmp, "s16.txt")) == 0
+    r = subprocess.run([bins["dsk"], "-file", f"{G}/c1.fasta.gz,{G}/c2.fasta.gz", "-kmer-size", "27", "-solidity-kind", "min", "-out", "bad", "-nb-gpus", "2", "-verbose", "0"],
+                       cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"EXCEPTION:" in r.stderr and b"-nb-gpus 1" in r.stderr      # per-bank modes are single-GPU
+
+
 def test_abundance_min_auto_on_gpu(bins, tmp_path, oracle):
     """f2 through the HIP binary: `-abundance-min auto` -> cutoff / nbsolids_auto attributes and the filtered rows."""
     from tests.test_host_cli import run_abundance_min_auto

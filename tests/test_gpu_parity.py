@@ -902,6 +902,26 @@ def test_group_count_in_one_process(oracle, golden_dir, dev, monkeypatch, ranks,
                 assert sum(per_rank) == ref.total and min(per_rank) > 0
 
 
+@pytest.mark.parametrize("k", [15, 27, 63])
+def test_group_with_idle_ranks(oracle, golden_dir, dev, k):
+    """More ranks than reads: ranks that send nothing, receive nothing, or both (records for k >= 20, explicit keys below)."""
+    from dsk_amd import KmerGroup
+    s, _ = oracle.load_bank(os.path.join(golden_dir, "longread.fasta"))
+    recs = [r for r in bytes(s).split(b"\n") if r][:3]                  # three long reads, eight ranks
+    stream = np.frombuffer(b"\n".join(recs) + b"\n", dtype=np.uint8)
+    ref = oracle.count(stream, k)
+    with KmerGroup([0] * 8, kmer_size=k, abundance_min=1, nb_partitions=1) as g:
+        for r, rec in enumerate(recs):
+            g.rank(2 * r + 1).push_reads(rec + b"\n")
+        g.count()
+        assert g.stats()["n_kmers"] == ref.total and g.stats()["n_distinct"] == ref.distinct
+        assert (g.histogram() == ref.histogram(10000)).all()
+        parts = [g.partition(p) for p in range(g.num_partitions())]
+    kk = np.concatenate([p[0] for p in parts]); aa = np.concatenate([p[1] for p in parts])
+    order = np.argsort(kk[:, 0]) if k <= 32 else np.lexsort((kk[:, 0], kk[:, 1]))
+    assert (kk[order, 0] == ref.lo).all() and (aa[order] == ref.ab).all()
+
+
 def test_repartition_table_balances_heavy_minimizers(oracle, dev, monkeypatch):
     """Minimizer repartition (gatb-core's RepartitorAlgorithm, src/DSK.cpp:63): a quarter of the reads are noisy poly-A, so
     one minimizer (A^10) carries ~ 25 % of all windows.  With the default owner map (hash of the minimizer scaled to the
