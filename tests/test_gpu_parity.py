@@ -922,7 +922,8 @@ def test_group_with_idle_ranks(oracle, golden_dir, dev, k):
     assert (kk[order, 0] == ref.lo).all() and (aa[order] == ref.ab).all()
 
 
-def test_repartition_table_balances_heavy_minimizers(oracle, dev, monkeypatch):
+@pytest.mark.parametrize("n_normal,n_polya,sliced", [(60_000, 20_000, False), (450_000, 150_000, True)])
+def test_repartition_table_balances_heavy_minimizers(oracle, dev, monkeypatch, n_normal, n_polya, sliced):
     """Minimizer repartition (gatb-core's RepartitorAlgorithm, src/DSK.cpp:63): a quarter of the reads are noisy poly-A, so
     one minimizer (A^10) carries ~ 25 % of all windows.  With the default owner map (hash of the minimizer scaled to the
     world) one of four ranks receives far more than its share; with the table built from sampled bucket loads (heavy
@@ -930,9 +931,11 @@ def test_repartition_table_balances_heavy_minimizers(oracle, dev, monkeypatch):
     same histogram either way."""
     from dsk_amd import KmerGroup, synth, make_table, KmerCounter
     rng = np.random.default_rng(7)
-    normal = synth.make_reads(synth.make_genome(300_000, dev), 60_000, 150).cpu().numpy().reshape(-1, 151)
-    polya = np.full((20_000, 151), ord("A"), dtype=np.uint8); polya[:, 150] = 10
-    noise = rng.random((20_000, 150)) < 0.05
+    if sliced:                                                    # the sampled slice layout of the sender together with split buckets
+        monkeypatch.setenv("DSKGPU_SK_MINSLICE", "1")
+    normal = synth.make_reads(synth.make_genome(300_000, dev), n_normal, 150).cpu().numpy().reshape(-1, 151)
+    polya = np.full((n_polya, 151), ord("A"), dtype=np.uint8); polya[:, 150] = 10
+    noise = rng.random((n_polya, 150)) < 0.05
     polya[:, :150][noise] = rng.choice(np.frombuffer(b"CGT", dtype=np.uint8), int(noise.sum()))
     reads = np.concatenate([normal, polya]); rng.shuffle(reads)
     stream = reads.reshape(-1)
