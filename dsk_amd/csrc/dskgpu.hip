@@ -12,6 +12,7 @@
 #include "../../include/dskgpu.h"
 #include "kernels.h"
 #include "superkmer.h"
+#include "rowsort.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -49,7 +50,7 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_OVF2, SC_OVF1, SC_COUNT = 12 };
+enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_OVF2, SC_OVF1, SC_RSLEN, SC_RSWORK, SC_RSWORK2, SC_COUNT = 12 };
 #ifndef SORT_TOP_BITS
 #define SORT_TOP_BITS 32u      // 4 radix passes; 40 bits (5 passes) cost 0.3 ms more on 43 M rows, the in-place run fix-up absorbs the extra ties
 #endif
@@ -65,6 +66,8 @@ struct Tuning {
     bool no_aligned = false;                    // DSKGPU_NO_ALIGNED: plain write-out for key-array scatters
     bool balanced_plan = false;                 // DSKGPU_BALANCED_PLAN: P1 ~ P2
     bool fullsort = false;                      // DSKGPU_FULLSORT: full-width row sort
+    bool lib_rowsort = false;                   // DSKGPU_LIB_ROWSORT: one-word rows through the library radix sort on a 32-bit prefix + run fix-up (the path before rowsort.h)
+    u32 rs_block_rows = 0;                      // DSKGPU_RS_BLOCK_ROWS: largest sub-bucket the hand-written row sort orders itself (tests: provoke its fallback)
     bool sk_exact = false, no_recsrc = false;   // DSKGPU_SK_EXACT, DSKGPU_NO_RECSRC (multi-GPU sender layout / receiver source)
     u32 opt_cap = 0;                            // DSKGPU_OPT_CAP: forced level-2 region size (keys)
     u64 opt_slice = 0;                          // DSKGPU_OPT_SLICE: forced level-1 slice size (keys)
@@ -79,6 +82,7 @@ struct Tuning {
         opt_cap = (u32)num("DSKGPU_OPT_CAP", 0) & ~7u; opt_slice = num("DSKGPU_OPT_SLICE", 0) & ~7ull;
         sk_slice = num("DSKGPU_SK_SLICE", 0); sk_minslice = num("DSKGPU_SK_MINSLICE", 2000);
         table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
+        lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0);
     }
 };
 
@@ -120,6 +124,7 @@ struct dskgpu_ctx {
     // records handed to dskgpu_mg_count: the level-1 scatter reads them directly (SRC 2); expanded lazily for the exact path
     const u64* rec_src = nullptr; u64 rec_n = 0; u64 rec_nch = 0, rec_rpc = 0; bool rec_expanded = false;
     u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0; u64 h_nvalid = 0;
+    u32 h_rs[3] = {0, 0, 0};       // host source of the row sort's device scalars (matrix length, list length, work counter)
     bool sentinel_ok = true;       // the all-ones key is not the mixed form of a canonical k-mer of this k (checked at create)
     bool opt1_off = false;         // same for the histogram-free level-1 scatter (block-owned slices)
     bool opt2_off = false;         // the fixed-capacity level-2 scatter overflowed on these reads: use the exact path   // host landing zone of the async size read-back
@@ -462,6 +467,56 @@ int sort_rows_full_multiword(dskgpu_ctx* ctx, u64 n) {
     return DSKGPU_OK;
 }
 
+// ---- one-word rows: hand-written MSD radix sort (rowsort.h).  out_* -> (step A) srt_* -> (steps B, C) out_*; a sub-bucket
+// or cell the kernels do not order themselves raises SC_SORTFLAG and run_pipeline() falls back to the full-width library sort
+// of srt_* (a complete permutation of the rows either way).
+int sort_rows_msd(dskgpu_ctx* ctx, u64 n) {
+    const int total = (int)std::min(64u, 2u * ctx->cfg.kmer_size);
+    const int bA = std::min(10, total), r1 = total - bA, bB = std::min(8, r1), r2 = r1 - bB, bC = std::min(8, r2), r3 = r2 - bC;
+    RsSpec sp{r1, r2, r3, (1u << bA) - 1u, (1u << bB) - 1u, (1u << bC) - 1u};
+    // chunks of step A: about 64 K rows each, a multiple of the CU count of them (whole rounds of blocks), at least one tile each
+    const u64 ncu = (u64)ctx->num_cu;
+    u64 nch = (n + 65535) / 65536;
+    nch = (nch + ncu - 1) / ncu * ncu;
+    nch = std::max<u64>(1, std::min<u64>(nch, (n + RS_TILE - 1) / RS_TILE));
+    const u64 chunk = (n + nch - 1) / nch;
+    nch = (n + chunk - 1) / chunk;
+    const u64 M = (u64)RS_ABINS * nch;
+    const u64 nsubw = (u64)RS_ABINS * (RS_BBINS + 1);                           // sub-bucket starts; behind them the list of large sub-buckets
+    CK(ctx->srt_tmp.ensure((M + 2 + 2 * nsubw + 16) * 4));
+    u32* matrix = static_cast<u32*>(ctx->srt_tmp.p);
+    u32* sub = matrix + M + 2;
+    u32* biglist = sub + nsubw;
+    u32* sc = ctx->scalars.as<u32>();
+    ctx->h_rs[0] = (u32)M; ctx->h_rs[1] = 0; ctx->h_rs[2] = 0;
+    CK(hipMemcpyAsync(sc + SC_RSLEN, ctx->h_rs, 12, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream));
+    const size_t ldsA = RsLds<RS_ABINS, RS_TILE>::bytes, ldsB = RsLds<RS_BBINS, RS_BTILE>::bytes;
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_scatter)); if (e) return e; }
+    if (ldsB > 64 * 1024) { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_split)); if (e) return e; }
+    hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)nch), dim3(RS_NT), 0, ctx->stream, ctx->out_w[0].as<u64>(), n, (u32)chunk, (u32)nch, matrix, sp);
+    CKL("k_rs_hist");
+    { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
+    hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), n,
+                       (u32)chunk, (u32)nch, matrix, ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), sp);
+    CKL("k_rs_scatter");
+    hipLaunchKernelGGL(k_rs_split, dim3((unsigned)std::min<u64>(ncu * (160 * 1024 / (ldsB + 1024)), RS_ABINS)), dim3(RS_BNT), ldsB, ctx->stream,
+                       ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), (u32)nch, matrix, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), sub, sp, sc + SC_RSWORK2);
+    CKL("k_rs_split");
+    const u32 nsub = RS_ABINS * RS_BBINS;
+    hipLaunchKernelGGL(k_rs_cells, dim3(nsub / (RS_CNT / 64)), dim3(RS_CNT), 0, ctx->stream, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), sub, nsub, sp,
+                       biglist, sc + SC_RSWORK, sc + SC_SORTFLAG);
+    CKL("k_rs_cells");
+    const u32 block_rows = ctx->tune.rs_block_rows ? std::min<u32>(ctx->tune.rs_block_rows, RS_BLOCK_ROWS) : RS_BLOCK_ROWS;
+    hipLaunchKernelGGL(k_rs_big, dim3((unsigned)std::min<u64>(ncu, 256)), dim3(RS_NT), 0, ctx->stream, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), sub, sp,
+                       biglist, sc + SC_RSWORK, sc + SC_SORTFLAG, block_rows);
+    CKL("k_rs_big");
+    CK(hipMemcpyAsync(&ctx->h_back[3], sc + SC_SORTFLAG, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sort_partial = true;
+    ctx->res_w[0] = ctx->out_w[0].as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>();
+    return DSKGPU_OK;
+}
+
 // ---- result post-processing: sort rows by k-mer value
 int sort_rows(dskgpu_ctx* ctx, u64 n) {
     const int W = ctx->W;
@@ -472,6 +527,9 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     CK(ctx->srt_w[0].ensure(n * 8));
     CK(ctx->srt_ab.ensure(n * 4));
     size_t tmp = 0;
+    // hand-written MSD sort while its fixed 10 + 8 + 8 bit digits leave sub-buckets a wave can order (mean <= ~370 rows); larger
+    // row sets keep the library sort (a fourth digit level is DESIGN "what comes next")
+    if (W == 1 && !ctx->tune.fullsort && !ctx->tune.lib_rowsort && n <= RS_MAX_ROWS) return sort_rows_msd(ctx, n);
     if (W == 1) {
         const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
         // Sort on the top SORT_TOP_BITS of the value only (4 radix passes instead of 8), then fix the
@@ -681,7 +739,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             if (opt1) {      // segments = the level-1 bin regions (slices + sentinel tails)
                 ctx->h_descs2.resize(pl.P1);
                 for (u32 sgm = 0; sgm < pl.P1; ++sgm) {
-                    ChunkDesc d; d.begin = (u64)sgm * o1.cap1; d.end = d.begin + o1.cap1; d.flat_base = sgm * pl.P2; d.stride = 1;
+                    ChunkDesc d; d.begin = (u64)sgm * o1.slice; d.end = d.begin + o1.slice; d.flat_base = sgm * pl.P2; d.stride = 1;   // slice i of the segment: + i * P1 * slice
                     ctx->h_descs2[sgm] = d;
                 }
                 CK(hipMemcpyAsync(ctx->descs2.p, ctx->h_descs2.data(), (size_t)pl.P1 * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
@@ -691,7 +749,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 CKL("k_plan");
             }
             ctx->mark("plan2");
-            OptSpec os{opt_cap, ctx->mat2.as<u32>(), sc + SC_OVF2, opt1 ? o1.fill : nullptr, o1.slice, grid1};
+            OptSpec os{opt_cap, ctx->mat2.as<u32>(), sc + SC_OVF2, opt1 ? o1.fill : nullptr, o1.slice, grid1, (u64)pl.P1 * o1.slice};
             if (opt1) rc = launch_scatter_al<W, 2, true, true>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
                                                                ctx->bufB.as<Key>(), pl.d2, pl.P2, os);
             else rc = launch_scatter_al<W, 2, true, false>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,

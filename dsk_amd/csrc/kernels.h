@@ -342,18 +342,14 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
         v[j] = (j < ipt && idx < P) ? cnt[idx] : 0u;
         s += v[j];
     }
-    u32 inc = s;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    const u32 inc = wave_incl_scan(s);
     if (lane == 63) wsum[wave] = inc;
     lds_barrier();
     if (wave == 0) {
         const u32 x = lane < NT / 64 ? wsum[lane] : 0u;
-        u32 y = x;
-#pragma unroll
-        for (int d = 1; d < NT / 64; d <<= 1) { const u32 t = __shfl_up(y, d); if (lane >= d) y += t; }
+        const u32 y = wave_incl_scan(x);
         if (lane < NT / 64) wsum[lane] = y - x;
-        if (lane == NT / 64 - 1) *tot = y;
+        if (lane == NT / 64 - 1) { *tot = y; off[P] = y; }        // off[P]: the dummy bin (invalid windows) is staged behind the keys
     }
     lds_barrier();
     u32 run = wsum[wave] + inc - s;
@@ -369,7 +365,7 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
     }
 }
 
-struct OptSpec { u32 cap; u32* subcnt; u32* ovf; const u32* fill; u32 slice, nsl; };   // fill/slice/nsl: SLICED input (below)
+struct OptSpec { u32 cap; u32* subcnt; u32* ovf; const u32* fill; u32 slice, nsl; u64 sstride; };   // fill/slice/nsl/sstride: SLICED input (below)
 __device__ __forceinline__ bool is_empty_key(u64 h) { return h == DSK_EMPTY; }
 template <int W> __device__ __forceinline__ bool is_empty_key(const KN<W>& h) {
     bool e = true;
@@ -419,9 +415,7 @@ __device__ __forceinline__ u32 tile_keys_records(const u64* __restrict__ rec, u3
         }
         s += n[u];
     }
-    u32 inc = s;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    const u32 inc = wave_incl_scan(s);
     if (lane == 63) wsum[wave] = inc;
     lds_barrier();
     u32 off = inc - s;
@@ -460,12 +454,13 @@ __device__ __forceinline__ u32 tile_keys_records(const u64* __restrict__ rec, u3
     return vm;
 }
 
-// OPT (one-word keys, level 1 from reads): "block-owned slices" -- no histogram pass.  Bin b owns the region
-// [b*cap1, (b+1)*cap1) of `out`, cut into one slice of `slice` keys per block (cap1 = gridDim.x * slice); a
-// block appends its keys of bin b to its own slice, the write cursors live in LDS for the whole launch.  The
-// slices are sized from the exact number of valid k-mers (k_count_valid) plus 6 % + 160 keys; how much of
-// each slice holds keys goes to fill[b*grid + block], and the level-2 scatter (SLICED) reads exactly that much.  A slice that would
-// overflow raises *ovf (the host repeats the pass with the exact histogram + scan path).
+// OPT (level 1): "block-owned slices" -- no histogram pass.  Every (block, bin) pair owns one slice of `slice` keys of
+// `out`, block-major: the slice of bin b of block g starts at (g * P + b) * slice, so the P write fronts of a block lie
+// within P * slice keys (44 MB on the bench workload).  A block appends its keys of bin b to its own slice, the write cursors
+// live in LDS for the whole launch.  The slices are sized from the exact number of valid k-mers (k_count_valid) plus 6 % + 160
+// keys; how much of each slice holds keys goes to fill[b*grid + block], and the level-2 scatter (SLICED) gathers the grid
+// slices of its bin (stride P * slice) and reads exactly that much of each.  A slice that would overflow raises *ovf (the host
+// repeats the pass with the exact histogram + scan path).  cap1 = grid * slice (P * cap1 = end of all slices = dump zone).
 struct Opt1Spec { u32 slice, cap1; u32* ovf; u32* fill; u32 R; u64* nkeys; };      // R: words per super-k-mer record (SRC 2)
 
 template <int W, int SRC, int MODE, bool OPT = false>
@@ -479,13 +474,17 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Key* stage = reinterpret_cast<Key*>(smem);                       // Tile<W>::KEYS keys
     u32* cnt = reinterpret_cast<u32*>(smem + sizeof(Key) * Tile<W>::KEYS); // P + 1 (dummy bin P: invalid windows)
-    u32* off = cnt + (P + 1);                                        // P
-    u32* cur = off + P;                                              // P
+    u32* off = cnt + (P + 1);                                        // P + 1 (off[P] = valid keys of the tile = where the dummy bin is staged)
+    u32* cur = off + (P + 1);                                        // P
     u32* delta = cur + P;                                            // P
     u32* wsum = delta + P;                                           // 16 (+1 total)
     u32* tot = wsum + 16;
     const u32 nchunks = *d_nchunks;
-    if (OPT) for (u32 b = threadIdx.x; b < P; b += SC_NT) cur[b] = b * o1.cap1 + blockIdx.x * o1.slice;
+    // OPT: this block's slices are CONTIGUOUS in `out` -- slice of bin b at (blockIdx * P + b) * slice -- so its P write fronts
+    // stay inside a few 2 MB pages (bin-major, the fronts of one block were P regions of grid * slice keys apart: P pages to
+    // cycle through on every tile, far more than the CU's translation cache holds)
+    const u32 first = OPT ? blockIdx.x * P * o1.slice : 0u;
+    if (OPT) for (u32 b = threadIdx.x; b < P; b += SC_NT) cur[b] = first + b * o1.slice;
     for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
         const ChunkDesc d = descs[g];
         lds_barrier();   // previous chunk's write-out reads delta/off/stage
@@ -501,19 +500,26 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
             u32 rk[KPT];
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
-                const u32 dj = ((vm & (1u << j)) && key_in_pass<MODE>(digit_word(h[j]), ds)) ? key_digit<MODE>(digit_word(h[j]), ds) : P;
-                rk[j] = dj << 16;                                    // (digit, rank) packed: rank < 8192, digit <= 2048
+                u32 dj = key_digit<MODE>(digit_word(h[j]), ds);      // for every window, then a select (as a branch around the multiply it cost exec-mask traffic per key)
+                asm volatile("" : "+v"(dj));
+                dj = ((vm & (1u << j)) && key_in_pass<MODE>(digit_word(h[j]), ds)) ? dj : P;
+                rk[j] = dj << 16;                                    // (digit, rank) packed: rank < 16384, digit <= 2048
             }
 #pragma unroll
             for (int j = 0; j < KPT; ++j) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
             lds_barrier();
-            tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot, OPT ? SliceGuard{o1.slice, o1.cap1, blockIdx.x * o1.slice, P * o1.cap1} : SliceGuard{0u, 0u, 0u, 0u});
+            tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot, OPT ? SliceGuard{o1.slice, o1.slice, first, P * o1.cap1} : SliceGuard{0u, 0u, 0u, 0u});
             lds_barrier();
+            // all bin starts first, then all stage writes (no dependent LDS read -> write round trip per key); the keys of invalid
+            // windows (dummy bin P) are staged like any bin, behind the valid ones (off[P] = their number), and never written out
+            constexpr int SB = KPT < 8 ? KPT : 8;                     // (eight at a time: sixteen starts in flight spill registers)
 #pragma unroll
-            for (int j = 0; j < KPT; ++j) {
-                const u32 dj = rk[j] >> 16;
-                const u32 o = off[dj < P ? dj : 0];
-                if (dj < P) stage[o + (rk[j] & 0xFFFFu)] = h[j];
+            for (int j0 = 0; j0 < KPT; j0 += SB) {
+                u32 so[SB];
+#pragma unroll
+                for (int j = 0; j < SB; ++j) so[j] = off[rk[j0 + j] >> 16];
+#pragma unroll
+                for (int j = 0; j < SB; ++j) stage[so[j] + (rk[j0 + j] & 0xFFFFu)] = h[j0 + j];
             }
             if (threadIdx.x == 0) cnt[P] = 0;
             lds_barrier();
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                 const u32 i0 = (u32)it * 4 * SC_NT;
                 Key hk[4]; u32 dd[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const u32 i = i0 + u * SC_NT + threadIdx.x; hk[u] = stage[i < ntile ? i : 0]; }
+                for (int u = 0; u < 4; ++u) hk[u] = stage[i0 + u * SC_NT + threadIdx.x];      // (slots past the tile's keys hold the dummy bin: readable, never stored as keys)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) dd[u] = delta[key_digit<MODE>(digit_word(hk[u]), ds)];
 #pragma unroll
@@ -553,10 +559,15 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                 r0 += taken ? taken : 1u;
             }
         } else if constexpr (SRC == 0 && W == 1) {
-            // one-word keys from the reads: the four words a thread needs for the NEXT tile are requested before the stores of this one
+            // one-word keys from the reads.  Thread -> window mapping: lane l of wave w takes the 16 windows ending in half (w >> 3) of
+            // word (w & 7) * 64 + l of the tile, so which half (t0 = 0 or 16) is wave-uniform and, inside either branch below, a
+            // compile-time constant: every base is one v_bfe_u32 at a fixed offset instead of a 64-bit shift by a per-lane amount.
+            // The four words a thread needs for the NEXT tile are requested before the stores of this one.
             struct Raw { u64 cur, prev; u32 ic, ip; };
+            const u32 wlane = threadIdx.x & (SC_NT / 2 - 1);
+            const bool upper = threadIdx.x >= SC_NT / 2;                      // wave-uniform
             auto load_raw = [&](u64 t0) {
-                const u64 wi = t0 + (threadIdx.x >> 1);
+                const u64 wi = t0 + wlane;
                 const u64 wc = wi < d.end ? wi : d.end - 1;                   // clamped: the loads stay unconditional (and countable)
                 Raw r; r.cur = packed[wc]; r.prev = packed[wc ? wc - 1 : 0]; r.ic = inval[wc]; r.ip = inval[wc ? wc - 1 : 0];
                 if (wc == 0) { r.prev = 0ull; r.ip = 0xFFFFFFFFu; }
@@ -569,8 +580,9 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                     for (int u = 0; u < 4 * ((KPT + 3) / 4); ++u) out[(u64)(P * o1.cap1 + u * SC_NT + threadIdx.x)] = (u64)threadIdx.x;
                 }
                 for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
-                    const bool live = t0 + (threadIdx.x >> 1) < d.end;
-                    vma = gen_kmers1_words<16>(raw.cur, raw.prev, raw.ic, raw.ip, (threadIdx.x & 1) * 16, k, ha);
+                    const bool live = t0 + wlane < d.end;
+                    if (upper) vma = gen_kmers1_words<16>(raw.cur, raw.prev, raw.ic, raw.ip, 16, k, ha);
+                    else vma = gen_kmers1_words<16>(raw.cur, raw.prev, raw.ic, raw.ip, 0, k, ha);
                     if (!live) vma = 0u;
 #pragma unroll
                     for (int j = 0; j < 16; ++j) ha[j] = kmix(ha[j]);
@@ -601,7 +613,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
         bool ovf = false;
         u32 mine = 0;
         for (u32 b = threadIdx.x; b < P; b += SC_NT) {
-            const u32 beg = b * o1.cap1 + blockIdx.x * o1.slice, c = cur[b];
+            const u32 beg = first + b * o1.slice, c = cur[b];
             if (c > beg + o1.slice) ovf = true;
             const u32 f = c > beg + o1.slice ? o1.slice : c - beg;
             o1.fill[(u64)b * gridDim.x + blockIdx.x] = f;
@@ -671,7 +683,7 @@ template <int W> struct ATile {
 #endif
 __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
     const size_t key = 8 * (size_t)W, keys = (size_t)SC_NT * (12 / W), G = 8 / W;
-    return keys * key + (size_t)P * (G - 1) * key + (size_t)(P + 1) * 4 + (size_t)P * 4 + (size_t)P * 12 + (size_t)P * 2 + 20 * 4 + 32
+    return keys * key + (size_t)P * (G - 1) * key + (size_t)(P + 1) * 4 + (size_t)P * 4 + (size_t)(P + 1) * 12 + (size_t)P * 2 + 20 * 4 + 32
            + SLICED_MAX * 4 + 16;     // + prefix sums of the slice fills (SLICED input)
 }
 
@@ -682,8 +694,8 @@ __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
 // (never read: subcnt[q] = number of real keys of the region).  A sub-bin that would
 // outgrow its region raises *ovf (writes wrap to the region start: the result is discarded and the host
 // repeats the level with the exact histogram + scan path).  flat_base of a chunk = s*P.
-// SLICED (with OPT): the input segment is a level-1 bin region written as block-owned slices -- nsl slices of
-// `slice` keys, of which the first fill[s*nsl + i] hold keys.  The loader walks the slices in order and skips their
+// SLICED (with OPT): the input segment is a level-1 bin written as block-owned slices -- nsl slices of `slice` keys,
+// os.sstride keys apart (slice i at keys + d.begin + i * sstride), of which the first fill[s*nsl + i] hold keys.  The loader walks the slices in order and skips their
 // unused tails: a thread's keys of consecutive tiles are monotone in the logical stream, so it only keeps the bounds
 // of its current slice in registers and touches the LDS prefix array when it crosses into the next slice.
 template <int W, int MODE, bool OPT = false, bool SLICED = false>
@@ -702,8 +714,8 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
     u32* pos = cnt + (P + 1);                                         // P   (persistent across tiles)
     // per-bin record of the current tile, read with one LDS access by the write-out:
     //   x = pos before this tile   y = emitted (lo16) | carry fill before (hi16)   z = offset of the bin in the staged tile
-    uint3* rec = reinterpret_cast<uint3*>(pos + P);                   // P
-    u16* rn = reinterpret_cast<u16*>(rec + P);                        // P   carry fill after this tile (persistent)
+    uint3* rec = reinterpret_cast<uint3*>(pos + P);                   // P + 1 (rec[P].z only)
+    u16* rn = reinterpret_cast<u16*>(rec + (P + 1));                  // P   carry fill after this tile (persistent)
     u32* wsum = reinterpret_cast<u32*>(smem + ((reinterpret_cast<char*>(rn + P) - smem + 3) & ~size_t(3)));
     u32* pre = wsum + 20;                                             // SLICED: nsl + 1 prefix sums of the slice fills
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -754,7 +766,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                     const u32 i = (u32)k0 + (ok ? o : n - 1);                 // logical index, monotone over j and over tiles for ok lanes
                     while (i >= shi && sg + 1 < os.nsl) { ++sg; slo = shi; shi = pre[sg + 1]; }
                     const u32 off = i >= slo ? i - slo : 0u;                  // (a clamped, not-ok lane may point below its slice: any valid address will do)
-                    hh[j] = base[(u64)sg * os.slice + off];
+                    hh[j] = base[(u64)sg * os.sstride + off];
                 }
                 m |= (ok ? 1u : 0u) << j;
             }
@@ -765,7 +777,9 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const bool pad = OPT && is_empty_key(h[j]);                 // sentinel of a level-1 slice tail
-                const u32 dj = ((vm & (1u << j)) && !pad && key_in_pass<MODE>(digit_word(h[j]), ds)) ? key_digit<MODE>(digit_word(h[j]), ds) : P;
+                u32 dj = key_digit<MODE>(digit_word(h[j]), ds);             // unconditional + select: no exec-mask traffic around the multiply
+                asm volatile("" : "+v"(dj));
+                dj = ((vm & (1u << j)) && !pad && key_in_pass<MODE>(digit_word(h[j]), ds)) ? dj : P;
                 rk[j] = dj << 16;
             }
 #pragma unroll
@@ -791,17 +805,14 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                     }
                     s += c[j];
                 }
-                u32 inc = s;
-#pragma unroll
-                for (int dd = 1; dd < 64; dd <<= 1) { const u32 t = __shfl_up(inc, dd); if (lane >= dd) inc += t; }
+                const u32 inc = wave_incl_scan(s);
                 if (lane == 63) wsum[wave] = inc;
                 lds_barrier();
                 if (wave == 0) {
                     const u32 x = lane < SC_NT / 64 ? wsum[lane] : 0u;
-                    u32 y = x;
-#pragma unroll
-                    for (int dd = 1; dd < SC_NT / 64; dd <<= 1) { const u32 t = __shfl_up(y, dd); if (lane >= dd) y += t; }
+                    const u32 y = wave_incl_scan(x);
                     if (lane < SC_NT / 64) wsum[lane] = y - x;
+                    if (lane == SC_NT / 64 - 1) rec[P].z = y;              // the dummy bin (masked slots) is staged behind the keys
                 }
                 lds_barrier();
                 u32 run = wsum[wave] + inc - s;
@@ -812,10 +823,13 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                 }
             }
             lds_barrier();
+            {   // all bin offsets first, then all stage writes (no dependent LDS read -> write round trip per key, no branches); masked
+                // slots (dummy bin P) are staged like any bin, behind the keys (rec[P].z = their number), and never written out
+                u32 so[KPT];
 #pragma unroll
-            for (int j = 0; j < KPT; ++j) {
-                const u32 dj = rk[j] >> 16;
-                if (dj < P) stage[rec[dj].z + (rk[j] & 0xFFFFu)] = h[j];
+                for (int j = 0; j < KPT; ++j) so[j] = rec[rk[j] >> 16].z;
+#pragma unroll
+                for (int j = 0; j < KPT; ++j) stage[so[j] + (rk[j] & 0xFFFFu)] = h[j];
             }
             if (tnext < lend) vm = load(tnext, h);        // HBM reads of the next tile fly under the write-out phase
             lds_barrier();

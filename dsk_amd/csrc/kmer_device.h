@@ -18,23 +18,39 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 // Empty-slot sentinel of the one-word LDS table.  Tables hold MIXED keys, so what matters is the
-// pre-image kunmix(~0) = 0x89a5850e63c5f8aa: it has bit 63 set (not a k-mer for k <= 31) and as a
-// 32-mer it is larger than its reverse complement, i.e. never canonical -- no real key collides.
+// pre-image kunmix(~0): it must not be a canonical k-mer of the k being counted (sentinel_is_a_kmer() in dskgpu.hip checks
+// that when a context is created; tests/host/test_kmer.cpp walks every k in 1..128) -- then no real key collides.
 #define DSK_EMPTY 0xFFFFFFFFFFFFFFFFull
 
 // ---------------------------------------------------------------- hashing
-// Bijective 64-bit mixer (murmur3 finalizer).  Partition arrays hold
-// h = kmix(canonical) so radix digits and table slots are plain bit fields of
-// the stored word; kunmix restores the k-mer for the emitted rows only.
+// Bijective 64-bit mixer: fold the high half into the low one, ONE 64-bit multiply by an odd constant, fold again.
+// Partition arrays hold h = kmix(canonical) so radix digits and table slots are plain bit fields of the stored word;
+// kunmix restores the k-mer for the emitted rows only.  The level-1 / level-2 scatters and the count are bound by the
+// number of VALU instructions they issue (rocprofv3: 74-83 % of the SIMD issue cycles busy), and the murmur3 finalizer
+// used before (two multiplies, three folds: 14 instructions, 43 cycles per wave and key) was a fifth of them; this one
+// is 6 instructions / 19 cycles (tools/micro/valu_rates.hip) and partitions the same inputs as evenly: the product's
+// top bits (the radix digits) depend on every input bit, the first fold brings the k-mer's leading bases into the low
+// half before the multiply and the second fold the well-mixed high half into the slot / owner bits.
+#define DSK_MIX_C 0xff51afd7ed558ccdULL
+#define DSK_MIX_CINV 0x4f74430c22a54005ULL        // DSK_MIX_C * DSK_MIX_CINV == 1 (mod 2^64)
 __host__ __device__ __forceinline__ u64 kmix(u64 x) {
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
-    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
-    x ^= x >> 33; return x;
+    x ^= x >> 32; x *= DSK_MIX_C; x ^= x >> 32; return x;
 }
 __host__ __device__ __forceinline__ u64 kunmix(u64 x) {
-    x ^= x >> 33; x *= 0x9cb4b2f8129337dbULL;
-    x ^= x >> 33; x *= 0x4f74430c22a54005ULL;
-    x ^= x >> 33; return x;
+    x ^= x >> 32; x *= DSK_MIX_CINV; x ^= x >> 32; return x;
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave with DPP adds (row shifts inside the rows of 16, then the two row
+// broadcasts): six v_add_u32_dpp, no LDS traffic -- __shfl_up() goes through ds_bpermute_b32 and costs ~5 instructions and an
+// LDS round trip per step.
+__device__ __forceinline__ u32 wave_incl_scan(u32 x) {
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);     // row_shr:4
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);     // row_shr:8
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return x;
 }
 
 // Multi-word keys (k in 33..128): KN<W>, word 0 least significant; digits/slots are taken from the mixed top word.

@@ -1,0 +1,325 @@
+// rowsort.h -- ascending order of the solid rows (one-word k-mers), hand-written for gfx950.
+//
+// The rows leave the count kernels grouped by hash sub-partition; the result contract is "sorted by k-mer value"
+// (Partition<Count> rows as dsk2ascii walks them, utils/dsk2ascii.cpp:77-104; output partitions are slices of that order).
+// 43 M rows of (u64 value, u32 abundance) on the bench workload: an MSD radix sort in three steps, five launches + a scan:
+//
+//   A  k_rs_hist + scan + k_rs_scatter : 1024 buckets on the top 10 value bits.  Exact chunk x bin offsets (the same
+//      one-linear-scan matrix layout as the key scatters), 8192-row tiles staged in LDS, runs of ~8 rows per bucket and tile.
+//   B  k_rs_split, one 256-thread block per bucket (all 1024 in flight): histogram of the next 8 bits in LDS, then the same
+//      LDS-staged scatter inside the bucket (a bucket is ~42 K rows = 500 KB: its second read comes from L2)
+//   C  k_rs_cells, one wave per sub-bucket (~160 rows), in place: the rows are placed by the next 8 bits with LDS atomics
+//      (< 1 row per cell on average) and the few rows that share a cell ordered by insertion on the full value;
+//      sub-buckets of 257..4096 rows are listed and done by whole blocks (k_rs_big).
+//
+// Skew: buckets are exact (any distribution of values works, a heavy bucket just takes its block longer); a sub-bucket
+// above 4096 rows or a cell above the insertion cap raises *flag, and the host orders the rows with the full-width
+// library sort instead (stats.sort_fallback) -- never seen on reads, provoked in tests.
+#pragma once
+#include "kernels.h"
+
+#define RS_NT 1024                        // step A: one 1024-thread block per chunk, 8192-row tiles
+#define RS_RPT 8
+#define RS_TILE (RS_NT * RS_RPT)
+#define RS_ABINS 1024
+#ifndef RS_BNT
+#define RS_BNT 512                        // step B: 512-thread blocks, 4096-row tiles (52 KB of LDS: three blocks per CU hide each
+#endif                                    //   other's memory latency; a heavy bucket is ~20 tiles)
+#define RS_BTILE (RS_BNT * RS_RPT)
+#define RS_BBINS 256
+#define RS_WAVE_ROWS 512                  // step C: a wave orders sub-buckets up to this size alone (8 rows per lane)
+#define RS_MAX_ROWS (96ull << 20)         // most rows this sort takes: 2^18 sub-buckets of ~370 rows on average (the densest twice that)
+#define RS_BLOCK_ROWS 4096                // larger ones: a whole block (k_rs_big); beyond this: flag
+#define RS_WAVE_CELL_CAP 64               // rows sharing all three digits, ordered by insertion (wave path / block path)
+#define RS_BLOCK_CELL_CAP 128
+
+// digit X of value v = (v >> shX) & mX; A = top 10 significant bits, B and C the next 8 + 8 (fewer for very small k)
+struct RsSpec { int shA, shB, shC; u32 mA, mB, mC; };
+__device__ __forceinline__ u32 rs_dig(u64 v, int sh, u32 m) { return (u32)(v >> sh) & m; }
+
+// LDS of a scatter block: TILE rows (value + abundance), P + 1 counters and tile offsets, P cursors and deltas, scan scratch
+template <int P, int TILE>
+struct RsLds {
+    u64* skey; u32* sab; u32* cnt; u32* off; u32* cur; u32* delta; u32* wsum; u32* tot;
+    static constexpr size_t bytes = (size_t)TILE * 12 + (size_t)(P + 1) * 8 + (size_t)P * 8 + 17 * 4 + 16;
+    __device__ __forceinline__ explicit RsLds(char* smem) {
+        skey = reinterpret_cast<u64*>(smem);
+        sab = reinterpret_cast<u32*>(smem + (size_t)TILE * 8);
+        cnt = sab + TILE;                        // bins + 1 (dummy bin: slots past the end of the range)
+        off = cnt + (P + 1);                     // bins + 1
+        cur = off + (P + 1);
+        delta = cur + P;
+        wsum = delta + P;                        // 16
+        tot = wsum + 16;
+    }
+};
+
+// per-chunk histogram of the first digit -> matrix[bin * nch + chunk]
+__global__ __launch_bounds__(RS_NT) void k_rs_hist(const u64* __restrict__ v, u64 n, u32 chunk, u32 nch, u32* __restrict__ matrix, RsSpec sp) {
+    __shared__ u32 lh[RS_ABINS];
+    const u32 c = blockIdx.x;
+    for (u32 b = threadIdx.x; b < RS_ABINS; b += RS_NT) lh[b] = 0;
+    __syncthreads();
+    const u64 beg = (u64)c * chunk;
+    const u64 end = beg + chunk < n ? beg + chunk : n;
+    for (u64 i0 = beg; i0 < end; i0 += 8 * RS_NT) {                   // eight loads in flight per thread
+        u64 x[8]; bool ok[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const u64 i = i0 + threadIdx.x + (u64)j * RS_NT; ok[j] = i < end; x[j] = v[ok[j] ? i : end - 1]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (ok[j]) atomicAdd(&lh[rs_dig(x[j], sp.shA, sp.mA)], 1u);
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < RS_ABINS; b += RS_NT) matrix[(u64)b * nch + c] = lh[b];
+}
+
+// rows [beg, end) -> their bins, through LDS-staged tiles of NT * RS_RPT rows; L.cur[] = next free output index per bin,
+// L.cnt[0..P] zero on entry.  The next tile's rows are loaded before the current tile enters its LDS phases.
+template <int P, int NT>
+__device__ __forceinline__ void rs_scatter_range(const u64* __restrict__ v, const u32* __restrict__ ab, u64 beg, u64 end,
+                                                 u64* __restrict__ ov, u32* __restrict__ oab, int sh, u32 m, const RsLds<P, NT * RS_RPT>& L) {
+    constexpr u32 TILE = NT * RS_RPT;
+    const u32 tid = threadIdx.x;
+    u64 kk[RS_RPT], kn[RS_RPT]; u32 aa[RS_RPT], an[RS_RPT];
+    auto load = [&](u64 t0, u64 (&k)[RS_RPT], u32 (&a)[RS_RPT]) {
+        const u64 left = end - t0;
+        const u32 n = left < (u64)TILE ? (u32)left : TILE;
+#pragma unroll
+        for (int j = 0; j < RS_RPT; ++j) { const u32 i = tid + (u32)j * NT; const u64 src = t0 + (i < n ? i : n - 1); k[j] = v[src]; a[j] = ab[src]; }
+    };
+    if (beg < end) load(beg, kk, aa);
+    for (u64 t0 = beg; t0 < end; t0 += TILE) {
+        const u64 left = end - t0;
+        const u32 n = left < (u64)TILE ? (u32)left : TILE;
+        const bool more = t0 + TILE < end;
+        if (more) load(t0 + TILE, kn, an);
+        u32 rk[RS_RPT];
+#pragma unroll
+        for (int j = 0; j < RS_RPT; ++j) rk[j] = (tid + (u32)j * NT < n ? rs_dig(kk[j], sh, m) : (u32)P) << 16;
+#pragma unroll
+        for (int j = 0; j < RS_RPT; ++j) rk[j] |= atomicAdd(&L.cnt[rk[j] >> 16], 1u);
+        lds_barrier();
+        tile_scan<NT>(L.cnt, L.off, L.delta, L.cur, P, L.wsum, L.tot);
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < RS_RPT; ++j) {
+            const u32 pos = L.off[rk[j] >> 16] + (rk[j] & 0xFFFFu);
+            L.skey[pos] = kk[j]; L.sab[pos] = aa[j];
+        }
+        if (tid == 0) L.cnt[P] = 0;
+        lds_barrier();
+        const u32 ntile = *L.tot;
+#pragma unroll
+        for (int j = 0; j < RS_RPT; ++j) {
+            const u32 i = tid + (u32)j * NT;
+            if (i < ntile) {
+                const u64 k = L.skey[i];
+                const u32 dst = L.delta[rs_dig(k, sh, m)] + i;
+                ov[dst] = k; oab[dst] = L.sab[i];
+            }
+        }
+        // no barrier: the next tile's rank phase only touches cnt; its first barrier orders this write-out before the next stage writes
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < RS_RPT; ++j) { kk[j] = kn[j]; aa[j] = an[j]; }
+        }
+    }
+    lds_barrier();
+}
+
+// step A: chunk c scatters its rows to the 1024 buckets (offsets from the scanned matrix)
+__global__ __launch_bounds__(RS_NT) void k_rs_scatter(const u64* __restrict__ v, const u32* __restrict__ ab, u64 n, u32 chunk, u32 nch,
+                                                      const u32* __restrict__ scanned, u64* __restrict__ ov, u32* __restrict__ oab, RsSpec sp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const RsLds<RS_ABINS, RS_TILE> L(smem);
+    const u32 c = blockIdx.x;
+    for (u32 b = threadIdx.x; b < RS_ABINS; b += RS_NT) { L.cur[b] = scanned[(u64)b * nch + c]; L.cnt[b] = 0; }
+    if (threadIdx.x == 0) L.cnt[RS_ABINS] = 0;
+    lds_barrier();
+    const u64 beg = (u64)c * chunk;
+    const u64 end = beg + chunk < n ? beg + chunk : n;
+    rs_scatter_range<RS_ABINS, RS_NT>(v, ab, beg, end, ov, oab, sp.shA, sp.mA, L);
+}
+
+// step B: a block splits one bucket at a time (rows [scanned[b * nch], scanned[(b + 1) * nch]) of v / ab) into 256 sub-buckets on
+// the second digit and leaves their starts (absolute row indices) in sub[b * 257 ..].  Buckets are handed out by a work
+// counter in ascending order: canonical k-mers are densest at small values (up to twice the mean), so the heavy buckets go first.
+__global__ __launch_bounds__(RS_BNT) void k_rs_split(const u64* __restrict__ v, const u32* __restrict__ ab, u32 nch, const u32* __restrict__ scanned,
+                                                     u64* __restrict__ ov, u32* __restrict__ oab, u32* __restrict__ sub, RsSpec sp, u32* __restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const RsLds<RS_BBINS, RS_BTILE> L(smem);
+    __shared__ u32 s_b;
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_b = atomicAdd(work, 1u);
+        __syncthreads();
+        const u32 b = s_b;
+        if (b >= RS_ABINS) break;
+        const u32 beg = scanned[(u64)b * nch], end = scanned[(u64)(b + 1) * nch];     // (the scan leaves the total behind the last entry)
+        if (tid <= RS_BBINS) L.cnt[tid] = 0;
+        __syncthreads();
+        for (u32 i0 = beg; i0 < end; i0 += 8 * RS_BNT) {
+            u64 x[8]; bool ok[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const u32 i = i0 + tid + (u32)j * RS_BNT; ok[j] = i < end; x[j] = v[ok[j] ? i : end - 1]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (ok[j]) atomicAdd(&L.cnt[rs_dig(x[j], sp.shB, sp.mB)], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {                              // exclusive scan over the 256 counters: four per lane
+            u32 c4[4], s = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c4[q] = L.cnt[4 * lane + q]; s += c4[q]; }
+            u32 run = beg + wave_incl_scan(s) - s;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { L.cur[4 * lane + q] = run; sub[(u64)b * (RS_BBINS + 1) + 4 * lane + q] = run; run += c4[q]; }
+            if (lane == 63) sub[(u64)b * (RS_BBINS + 1) + RS_BBINS] = run;
+        }
+        __syncthreads();
+        if (tid <= RS_BBINS) L.cnt[tid] = 0;
+        __syncthreads();
+        rs_scatter_range<RS_BBINS, RS_BNT>(v, ab, beg, end, ov, oab, sp.shB, sp.mB, L);
+    }
+}
+
+__device__ __forceinline__ void rs_wave_sync() { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// insertion order of rows [o, o + m) of an LDS row area by value (one lane; m is small)
+__device__ __forceinline__ void rs_insertion(u64* rk, u32* ra, u32 o, u32 m) {
+    for (u32 x = o + 1; x < o + m; ++x) {
+        const u64 kv = rk[x]; const u32 av = ra[x];
+        u32 y = x;
+        while (y > o && rk[y - 1] > kv) { rk[y] = rk[y - 1]; ra[y] = ra[y - 1]; --y; }
+        rk[y] = kv; ra[y] = av;
+    }
+}
+
+// step C: one wave per sub-bucket (2 <= nd <= RS_WAVE_ROWS rows at gk / ga, ordered in place).  The rows are placed by the third
+// digit with LDS atomics (rk / ra = the wave's LDS row area, wc = its 256 + 1 cell counters); a row that shares its cell then
+// counts the smaller values of the cell (all rows of the wave at once, one LDS read per step and row) and moves to its final slot.
+__device__ __forceinline__ void rs_wave_sort(u64* gk, u32* ga, u32 nd, u64* rk, u32* ra, u32* wc, int sh, u32 m, u32* flag) {
+    const u32 lane = threadIdx.x & 63;
+    constexpr int RPL = RS_WAVE_ROWS / 64;
+    u64 k[RPL]; u32 a[RPL], r[RPL];
+#pragma unroll
+    for (int t = 0; t < RPL; ++t) { const u32 i = lane + 64 * t; if (i < nd) { k[t] = gk[i]; a[t] = ga[i]; } }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wc[lane + 64 * t] = 0;
+    rs_wave_sync();
+#pragma unroll
+    for (int t = 0; t < RPL; ++t) {
+        const u32 i = lane + 64 * t;
+        if (i < nd) { const u32 d = rs_dig(k[t], sh, m); r[t] = (d << 16) | atomicAdd(&wc[d], 1u); }
+    }
+    rs_wave_sync();
+    {   // exclusive scan of the 256 cell counts (four per lane); wc[256] = nd
+        u32 c4[4], s = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { c4[q] = wc[4 * lane + q]; s += c4[q]; }
+        u32 run = wave_incl_scan(s) - s;
+        rs_wave_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { wc[4 * lane + q] = run; run += c4[q]; }
+        if (lane == 63) wc[RS_BBINS] = run;
+    }
+    rs_wave_sync();
+    u32 o[RPL], c[RPL], fin[RPL], cmax = 0;
+#pragma unroll
+    for (int t = 0; t < RPL; ++t) {
+        const u32 i = lane + 64 * t;
+        o[t] = 0; c[t] = 0; fin[t] = 0;
+        if (i < nd) {
+            const u32 d = r[t] >> 16;
+            o[t] = wc[d]; c[t] = wc[d + 1] - o[t];
+            const u32 pos = o[t] + (r[t] & 0xFFFFu);
+            rk[pos] = k[t]; ra[pos] = a[t];
+            fin[t] = o[t];
+            if (c[t] > 1) cmax = c[t] > cmax ? c[t] : cmax;
+        }
+    }
+    rs_wave_sync();
+    if (cmax > RS_WAVE_CELL_CAP) { *flag = 1u; cmax = 0; }
+    for (u32 j = 0; __ballot(j < cmax); ++j) {
+#pragma unroll
+        for (int t = 0; t < RPL; ++t) if (c[t] > 1 && j < c[t]) fin[t] += rk[o[t] + j] < k[t] ? 1u : 0u;
+    }
+    rs_wave_sync();
+#pragma unroll
+    for (int t = 0; t < RPL; ++t) if (c[t] > 1 && cmax) { rk[fin[t]] = k[t]; ra[fin[t]] = a[t]; }
+    rs_wave_sync();
+#pragma unroll
+    for (int t = 0; t < RPL; ++t) {
+        const u32 i = lane + 64 * t;
+        if (i < nd) { gk[i] = rk[i]; ga[i] = ra[i]; }
+    }
+}
+
+// every sub-bucket of every bucket: wave w of the grid takes sub-bucket w; the large ones go to a list for k_rs_big
+#define RS_CNT 256
+__global__ __launch_bounds__(RS_CNT) void k_rs_cells(u64* kv, u32* av, const u32* __restrict__ sub, u32 nsub, RsSpec sp,
+                                                     u32* __restrict__ biglist, u32* __restrict__ nbig, u32* __restrict__ flag) {
+    __shared__ u64 rk[RS_CNT / 64][RS_WAVE_ROWS];
+    __shared__ u32 ra[RS_CNT / 64][RS_WAVE_ROWS];
+    __shared__ u32 wc[RS_CNT / 64][RS_BBINS + 1];
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 id = blockIdx.x * (RS_CNT / 64) + wave;
+    if (id >= nsub) return;
+    const u32 i = id + id / RS_BBINS;                              // sub[] holds 257 starts per bucket
+    const u32 o = sub[i], nd = sub[i + 1] - o;
+    if (nd < 2) return;
+    if (nd <= RS_WAVE_ROWS) rs_wave_sort(kv + o, av + o, nd, rk[wave], ra[wave], wc[wave], sp.shC, sp.mC, flag);
+    else if (lane == 0) biglist[atomicAdd(nbig, 1u)] = i;
+}
+
+// sub-buckets of 257 .. block_rows rows, one block each (the same placement by the third digit, block-wide)
+__global__ __launch_bounds__(RS_NT) void k_rs_big(u64* kv, u32* av, const u32* __restrict__ sub, RsSpec sp, const u32* __restrict__ biglist,
+                                                  const u32* __restrict__ nbig, u32* __restrict__ flag, u32 block_rows) {
+    __shared__ u64 rk[RS_BLOCK_ROWS];
+    __shared__ u32 ra[RS_BLOCK_ROWS];
+    __shared__ u32 wc[2 * RS_BBINS];
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 nb = *nbig;
+    for (u32 x = blockIdx.x; x < nb; x += gridDim.x) {
+        const u32 i = biglist[x];
+        const u32 o = sub[i], nd = sub[i + 1] - o;
+        if (nd > block_rows) { if (tid == 0) *flag = 1u; continue; }
+        u64* gk = kv + o; u32* ga = av + o;
+        u64 k[4]; u32 a[4], r[4];
+        __syncthreads();
+        if (tid < RS_BBINS) wc[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const u32 j = tid + RS_NT * t;
+            if (j < nd) { k[t] = gk[j]; a[t] = ga[j]; const u32 d = rs_dig(k[t], sp.shC, sp.mC); r[t] = (d << 16) | atomicAdd(&wc[d], 1u); }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            u32 c4[4], s = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c4[q] = wc[4 * lane + q]; s += c4[q]; }
+            u32 run = wave_incl_scan(s) - s;
+            rs_wave_sync();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { wc[RS_BBINS + 4 * lane + q] = c4[q]; wc[4 * lane + q] = run; run += c4[q]; }      // counts kept behind the offsets
+        }
+        __syncthreads();
+        u32 cmine = 0, omine = 0;
+        if (tid < RS_BBINS) { omine = wc[tid]; cmine = wc[RS_BBINS + tid]; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const u32 j = tid + RS_NT * t;
+            if (j < nd) { const u32 pos = wc[r[t] >> 16] + (r[t] & 0xFFFFu); rk[pos] = k[t]; ra[pos] = a[t]; }
+        }
+        __syncthreads();
+        if (cmine > RS_BLOCK_CELL_CAP) *flag = 1u;
+        else if (cmine >= 2) rs_insertion(rk, ra, omine, cmine);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const u32 j = tid + RS_NT * t;
+            if (j < nd) { gk[j] = rk[j]; ga[j] = ra[j]; }
+        }
+    }
+}

@@ -725,8 +725,9 @@ def test_minimizers_match_oracle(oracle, golden_dir, dev, k, m):
 
 
 def test_row_sort_fallback_on_shared_prefixes(oracle, dev):
-    """The row sort orders the top 32 bits with a radix sort and fixes runs of equal prefix in place;
-    more than 32 rows sharing their first 16 bases (here: 20) must take the exact full-width fallback."""
+    """The hand-written row sort (csrc/rowsort.h) places rows by the top 26 value bits (three radix digits) and orders the rows of
+    a cell by comparison; more than 64 rows sharing those 13 bases (here: 300 rows sharing 20) must take the exact full-width
+    fallback, short cells stay on the fast path."""
     from dsk_amd import KmerCounter
     rng = np.random.default_rng(11)
     tails = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(300, 11))
@@ -747,6 +748,32 @@ def test_row_sort_fallback_on_shared_prefixes(oracle, dev):
     s = np.frombuffer(b"\n".join(recs) + b"\n" + noise + b"\n", dtype=np.uint8)
     st = check_against_oracle(oracle, s, 31, dev, amin=1)
     assert st["sort_fallback"] == 0
+
+
+def test_row_sort_paths_agree(oracle, dev, monkeypatch):
+    """One-word rows: the hand-written MSD sort, its large-sub-bucket fallback (forced: no sub-bucket above 512 rows is ordered
+    by a block) and the library prefix sort + run fix-up kept behind DSKGPU_LIB_ROWSORT give the same rows, at k = 31 and at
+    small k (fewer than 26 value bits: the lower digits are empty)."""
+    from dsk_amd import synth
+    g = synth.make_genome(200_000, dev)
+    reads = synth.make_reads(g, 60_000, 150).cpu().numpy()
+    # skewed values: a third of the stream is poly-A with sparse errors -> thousands of distinct k-mers under one 20-bit prefix
+    rng = np.random.default_rng(5)
+    pa = np.full(1_500_000, 65, np.uint8)
+    hit = rng.random(pa.size) < 0.02
+    pa[hit] = rng.choice(np.frombuffer(b"CGT", dtype=np.uint8), size=int(hit.sum()))
+    skew = np.concatenate([pa, np.array([10], np.uint8), reads]).astype(np.uint8)
+    for k, s in ((31, reads), (11, reads), (4, reads)):
+        st = check_against_oracle(oracle, s, k, dev, amin=1)
+        assert st["sort_fallback"] == 0
+    check_against_oracle(oracle, skew, 31, dev, amin=1)                 # (whichever path the skew takes: same rows)
+    monkeypatch.setenv("DSKGPU_RS_BLOCK_ROWS", "512")
+    st = check_against_oracle(oracle, skew, 31, dev, amin=1)
+    assert st["sort_fallback"] == 1
+    monkeypatch.delenv("DSKGPU_RS_BLOCK_ROWS")
+    monkeypatch.setenv("DSKGPU_LIB_ROWSORT", "1")
+    for k, s in ((31, skew), (11, reads)):
+        check_against_oracle(oracle, s, k, dev, amin=1)
 
 
 @pytest.mark.parametrize("k", [40, 63, 70, 100])

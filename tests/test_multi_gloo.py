@@ -17,23 +17,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
-def kmix(x):
+def kmix(x):        # dsk_amd/csrc/kmer_device.h::kmix (fold, one multiply, fold)
     x = x.astype(np.uint64).copy()
-    x ^= x >> np.uint64(33)
+    x ^= x >> np.uint64(32)
     x *= np.uint64(0xff51afd7ed558ccd)
-    x ^= x >> np.uint64(33)
-    x *= np.uint64(0xc4ceb9fe1a85ec53)
-    x ^= x >> np.uint64(33)
+    x ^= x >> np.uint64(32)
     return x
 
 
 def kunmix(x):
     x = x.astype(np.uint64).copy()
-    x ^= x >> np.uint64(33)
-    x *= np.uint64(0x9cb4b2f8129337db)
-    x ^= x >> np.uint64(33)
+    x ^= x >> np.uint64(32)
     x *= np.uint64(0x4f74430c22a54005)
-    x ^= x >> np.uint64(33)
+    x ^= x >> np.uint64(32)
     return x
 
 

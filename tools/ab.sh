@@ -10,6 +10,6 @@ for spec in $libs; do
   env $envs DSKGPU_LIB=$PWD/$lib python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-e2e "$@" 2>&1 | tail -1 | python3 -c "
 import sys,json
 try:
-    d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['stage_ms'].items()})
+    d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['stage_ms'].items()}, int(d['n_distinct']), int(d['n_solid']))
 except Exception as e: print('FAILED', e)"
 done
