@@ -45,10 +45,13 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(stage, n_bytes, n_kmers, W=8):
+def algorithmic_bytes(stage, n_bytes, n_kmers, W=8, n_solid=None):
     """Algorithmic HBM bytes of one launch (DESIGN.md 'roofline'; SURVEY.md §8d terms).
     partition kernels: read the bases that produce the k-mers + write W per k-mer;
-    key-array passes: read W (+ write W); count: read W per k-mer (table lives in LDS)."""
+    key-array passes: read W (+ write W); count: read W per k-mer (table lives in LDS);
+    compact / sort (all their launches together): the solid rows (W + 4 bytes) read once and written once."""
+    if stage in ("compact", "sort"):
+        return None if n_solid is None else 2 * n_solid * (W + 4)
     enc_words = (n_bytes + 31) // 32
     packed = enc_words * 12                      # 8 B packed + 4 B invalid mask per 32 bases
     return {
@@ -341,7 +344,7 @@ def main():
             W = 8 if args.kmer_size <= 32 else 16 if args.kmer_size <= 64 else 32
 
             def price(stage):
-                ab = algorithmic_bytes(stage, n_bytes, local_kmers, W)
+                ab = algorithmic_bytes(stage, n_bytes, local_kmers, W, st["n_solid"])
                 gbs = ab / (stage_ms[stage] * 1e-3) / 1e9
                 return {"algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(stage_ms[stage], 4), "achieved": round(gbs, 1),
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_vs_measured_copy": round(gbs / HBM_COPY_GBS, 4)}
@@ -351,7 +354,7 @@ def main():
                         "peak_measured_copy": HBM_COPY_GBS, "frac_vs_measured_copy": d["frac_vs_measured_copy"],
                         "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "avg_launch_ms": d["avg_launch_ms"],
                         # every partition + hash kernel of the step, priced the same way (HIP events on the launching stream)
-                        "kernels": {st: price(st) for st in ("encode", "scatter1", "scatter2", "count", "mg_scatter") if st in stage_ms}}
+                        "kernels": {st: price(st) for st in ("encode", "scatter1", "scatter2", "count", "compact", "sort", "mg_scatter") if st in stage_ms}}
             pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
             if os.path.exists(pmc):        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an EARLIER run of this command (profiles/)
                 try:

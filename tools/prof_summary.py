@@ -38,7 +38,8 @@ avg_ns = {r["Name"]: float(r["AverageNs"]) for r in rows}
 
 # kernel -> bench stage name.  k_hist/k_scatter: <W, SRC, MODE>; SRC 0 = reads (level 1), 1 = key array (level 2)
 stage_of = [("k_encode", "encode"), ("k_hist<1, 0,", "hist1"), ("k_scatter<1, 0,", "scatter1"), ("k_hist<1, 1,", "hist2"),
-            ("k_scatter<1, 1,", "scatter2"), ("k_scatter_al<1,", "scatter2"), ("k_count1<", "count"), ("k_compact<1>", "compact")]
+            ("k_scatter<1, 1,", "scatter2"), ("k_scatter_al<1,", "scatter2"), ("k_count1<", "count"), ("k_compact<1>", "compact"),
+            ("k_rs_hist", "sort"), ("k_rs_scatter", "sort"), ("k_rs_split", "sort"), ("k_rs_cells", "sort"), ("k_rs_big", "sort")]
 summary = {}
 lines = [f"# PMC summary ({tag})", "",
          "rocprofv3 `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes (TCC slots), values are KiB per dispatch,",
@@ -56,7 +57,9 @@ for kname in sorted(set(fetch) | set(write)):
     rd, wr = 2 * fk * 1024, wk * 1024
     ms = avg_ns.get(kname, 0.0) / 1e6
     tot = rd + wr
-    summary[st] = {"hbm_bytes_per_launch": tot, "read_bytes": rd, "write_bytes": wr, "avg_ms": ms}
+    prev = summary.get(st, {"hbm_bytes_per_launch": 0.0, "read_bytes": 0.0, "write_bytes": 0.0, "avg_ms": 0.0})      # a stage of several kernels: sums
+    summary[st] = {"hbm_bytes_per_launch": prev["hbm_bytes_per_launch"] + tot, "read_bytes": prev["read_bytes"] + rd,
+                   "write_bytes": prev["write_bytes"] + wr, "avg_ms": prev["avg_ms"] + ms}
     lines.append(f"| `{kname[:48]}` | {st} | {ms:.3f} | {fk:.0f} | {wk:.0f} | {rd / 1e9:.2f} | {wr / 1e9:.2f} | {tot / 1e9:.2f} | {tot / 1e9 / (ms / 1e3) if ms else 0:.0f} |")
 open(os.path.join(dst, f"{tag}_pmc.md"), "w").write("\n".join(lines) + "\n")
 # what the numbers belong to: bench.py quotes them (roofline.traffic_from_profiles) only for the same workload and k
