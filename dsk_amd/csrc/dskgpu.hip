@@ -67,6 +67,7 @@ struct Tuning {
     bool balanced_plan = false;                 // DSKGPU_BALANCED_PLAN: P1 ~ P2
     bool fullsort = false;                      // DSKGPU_FULLSORT: full-width row sort
     bool lib_rowsort = false;                   // DSKGPU_LIB_ROWSORT: one-word rows through the library radix sort on a 32-bit prefix + run fix-up (the path before rowsort.h)
+    u32 rs_bbits = 0;                           // DSKGPU_RS_BBITS: forced width of the row sort's second digit (8..10; tests)
     u32 rs_block_rows = 0;                      // DSKGPU_RS_BLOCK_ROWS: largest sub-bucket the hand-written row sort orders itself (tests: provoke its fallback)
     bool sk_exact = false, no_recsrc = false;   // DSKGPU_SK_EXACT, DSKGPU_NO_RECSRC (multi-GPU sender layout / receiver source)
     u32 opt_cap = 0;                            // DSKGPU_OPT_CAP: forced level-2 region size (keys)
@@ -82,7 +83,7 @@ struct Tuning {
         opt_cap = (u32)num("DSKGPU_OPT_CAP", 0) & ~7u; opt_slice = num("DSKGPU_OPT_SLICE", 0) & ~7ull;
         sk_slice = num("DSKGPU_SK_SLICE", 0); sk_minslice = num("DSKGPU_SK_MINSLICE", 2000);
         table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
-        lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0);
+        lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0);
     }
 };
 
@@ -472,7 +473,11 @@ int sort_rows_full_multiword(dskgpu_ctx* ctx, u64 n) {
 // of srt_* (a complete permutation of the rows either way).
 int sort_rows_msd(dskgpu_ctx* ctx, u64 n) {
     const int total = (int)std::min(64u, 2u * ctx->cfg.kmer_size);
-    const int bA = std::min(10, total), r1 = total - bA, bB = std::min(8, r1), r2 = r1 - bB, bC = std::min(8, r2), r3 = r2 - bC;
+    // second digit: 8 bits up to 96 M rows, 9 up to 192 M, 10 beyond (sub-buckets stay near 200 rows: one wave each in step C)
+    int wantB = n <= (96ull << 20) ? 8 : n <= (192ull << 20) ? 9 : 10;
+    if (ctx->tune.rs_bbits >= 8 && ctx->tune.rs_bbits <= 10) wantB = (int)ctx->tune.rs_bbits;      // tests
+    const int bA = std::min(10, total), r1 = total - bA, bB = std::min(wantB, r1), r2 = r1 - bB, bC = std::min(8, r2), r3 = r2 - bC;
+    const u32 BB = 1u << wantB;
     RsSpec sp{r1, r2, r3, (1u << bA) - 1u, (1u << bB) - 1u, (1u << bC) - 1u};
     // chunks of step A: about 64 K rows each, a multiple of the CU count of them (whole rounds of blocks), at least one tile each
     const u64 ncu = (u64)ctx->num_cu;
@@ -482,7 +487,7 @@ int sort_rows_msd(dskgpu_ctx* ctx, u64 n) {
     const u64 chunk = (n + nch - 1) / nch;
     nch = (n + chunk - 1) / chunk;
     const u64 M = (u64)RS_ABINS * nch;
-    const u64 nsubw = (u64)RS_ABINS * (RS_BBINS + 1);                           // sub-bucket starts; behind them the list of large sub-buckets
+    const u64 nsubw = (u64)RS_ABINS * (BB + 1);                           // sub-bucket starts; behind them the list of large sub-buckets
     CK(ctx->srt_tmp.ensure((M + 2 + 2 * nsubw + 16) * 4));
     u32* matrix = static_cast<u32*>(ctx->srt_tmp.p);
     u32* sub = matrix + M + 2;
@@ -491,20 +496,25 @@ int sort_rows_msd(dskgpu_ctx* ctx, u64 n) {
     ctx->h_rs[0] = (u32)M; ctx->h_rs[1] = 0; ctx->h_rs[2] = 0;
     CK(hipMemcpyAsync(sc + SC_RSLEN, ctx->h_rs, 12, hipMemcpyHostToDevice, ctx->stream));
     CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream));
-    const size_t ldsA = RsLds<RS_ABINS, RS_TILE>::bytes, ldsB = RsLds<RS_BBINS, RS_BTILE>::bytes;
+    const size_t ldsA = RsLds<RS_ABINS, RS_TILE>::bytes;
+    const size_t ldsB = BB == 256 ? RsLds<256, RS_BTILE>::bytes : BB == 512 ? RsLds<512, RS_BTILE>::bytes : RsLds<1024, RS_BTILE>::bytes;
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_scatter)); if (e) return e; }
-    if (ldsB > 64 * 1024) { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_split)); if (e) return e; }
     hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)nch), dim3(RS_NT), 0, ctx->stream, ctx->out_w[0].as<u64>(), n, (u32)chunk, (u32)nch, matrix, sp);
     CKL("k_rs_hist");
     { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
     hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), n,
                        (u32)chunk, (u32)nch, matrix, ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), sp);
     CKL("k_rs_scatter");
-    hipLaunchKernelGGL(k_rs_split, dim3((unsigned)std::min<u64>(ncu * (160 * 1024 / (ldsB + 1024)), RS_ABINS)), dim3(RS_BNT), ldsB, ctx->stream,
-                       ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), (u32)nch, matrix, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), sub, sp, sc + SC_RSWORK2);
+    const unsigned gridB = (unsigned)std::min<u64>(ncu * (160 * 1024 / (ldsB + 1024)), RS_ABINS);
+    auto split = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(gridB), dim3(RS_BNT), ldsB, ctx->stream, ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), (u32)nch, matrix,
+                           ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), sub, sp, sc + SC_RSWORK2);
+    };
+    if (BB == 1024 && ldsB > 64 * 1024) { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_split<1024>)); if (e) return e; }
+    if (BB == 256) split(k_rs_split<256>); else if (BB == 512) split(k_rs_split<512>); else split(k_rs_split<1024>);
     CKL("k_rs_split");
-    const u32 nsub = RS_ABINS * RS_BBINS;
-    hipLaunchKernelGGL(k_rs_cells, dim3(nsub / (RS_CNT / 64)), dim3(RS_CNT), 0, ctx->stream, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), sub, nsub, sp,
+    const u32 nsub = RS_ABINS * BB;
+    hipLaunchKernelGGL(k_rs_cells, dim3(nsub / (RS_CNT / 64)), dim3(RS_CNT), 0, ctx->stream, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), sub, nsub, BB, sp,
                        biglist, sc + SC_RSWORK, sc + SC_SORTFLAG);
     CKL("k_rs_cells");
     const u32 block_rows = ctx->tune.rs_block_rows ? std::min<u32>(ctx->tune.rs_block_rows, RS_BLOCK_ROWS) : RS_BLOCK_ROWS;
@@ -527,8 +537,8 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     CK(ctx->srt_w[0].ensure(n * 8));
     CK(ctx->srt_ab.ensure(n * 4));
     size_t tmp = 0;
-    // hand-written MSD sort while its fixed 10 + 8 + 8 bit digits leave sub-buckets a wave can order (mean <= ~370 rows); larger
-    // row sets keep the library sort (a fourth digit level is DESIGN "what comes next")
+    // hand-written MSD sort while its 10 + (8..10) + 8 bit digits leave sub-buckets a wave can order (mean <= ~380 rows); larger
+    // row sets keep the library sort
     if (W == 1 && !ctx->tune.fullsort && !ctx->tune.lib_rowsort && n <= RS_MAX_ROWS) return sort_rows_msd(ctx, n);
     if (W == 1) {
         const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);

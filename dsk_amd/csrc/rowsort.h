@@ -26,9 +26,9 @@
 #define RS_BNT 512                        // step B: 512-thread blocks, 4096-row tiles (52 KB of LDS: three blocks per CU hide each
 #endif                                    //   other's memory latency; a heavy bucket is ~20 tiles)
 #define RS_BTILE (RS_BNT * RS_RPT)
-#define RS_BBINS 256
+#define RS_CELLS 256                      // step C: cells of a sub-bucket (third digit)
 #define RS_WAVE_ROWS 512                  // step C: a wave orders sub-buckets up to this size alone (8 rows per lane)
-#define RS_MAX_ROWS (96ull << 20)         // most rows this sort takes: 2^18 sub-buckets of ~370 rows on average (the densest twice that)
+#define RS_MAX_ROWS (384ull << 20)        // most rows this sort takes: 1024 x 1024 sub-buckets of ~380 rows on average (the densest twice that)
 #define RS_BLOCK_ROWS 4096                // larger ones: a whole block (k_rs_big); beyond this: flag
 #define RS_WAVE_CELL_CAP 64               // rows sharing all three digits, ordered by insertion (wave path / block path)
 #define RS_BLOCK_CELL_CAP 128
@@ -144,12 +144,14 @@ __global__ __launch_bounds__(RS_NT) void k_rs_scatter(const u64* __restrict__ v,
 // step B: a block splits one bucket at a time (rows [scanned[b * nch], scanned[(b + 1) * nch]) of v / ab) into 256 sub-buckets on
 // the second digit and leaves their starts (absolute row indices) in sub[b * 257 ..].  Buckets are handed out by a work
 // counter in ascending order: canonical k-mers are densest at small values (up to twice the mean), so the heavy buckets go first.
+template <int BB>
 __global__ __launch_bounds__(RS_BNT) void k_rs_split(const u64* __restrict__ v, const u32* __restrict__ ab, u32 nch, const u32* __restrict__ scanned,
                                                      u64* __restrict__ ov, u32* __restrict__ oab, u32* __restrict__ sub, RsSpec sp, u32* __restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const RsLds<RS_BBINS, RS_BTILE> L(smem);
-    __shared__ u32 s_b;
+    const RsLds<BB, RS_BTILE> L(smem);
+    u32& s_b = L.tot[1];                                 // (the spare word behind the scan scratch: no static LDS next to the dynamic block)
     const u32 tid = threadIdx.x, lane = tid & 63;
+    constexpr int CPL = BB / 64;                         // counters per lane in the scan of a bucket's histogram
     for (;;) {
         __syncthreads();
         if (tid == 0) s_b = atomicAdd(work, 1u);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(RS_BNT) void k_rs_split(const u64* __restrict__ v, 
         const u32 b = s_b;
         if (b >= RS_ABINS) break;
         const u32 beg = scanned[(u64)b * nch], end = scanned[(u64)(b + 1) * nch];     // (the scan leaves the total behind the last entry)
-        if (tid <= RS_BBINS) L.cnt[tid] = 0;
+        for (u32 d = tid; d <= BB; d += RS_BNT) L.cnt[d] = 0;
         __syncthreads();
         for (u32 i0 = beg; i0 < end; i0 += 8 * RS_BNT) {
             u64 x[8]; bool ok[8];
@@ -167,19 +169,19 @@ __global__ __launch_bounds__(RS_BNT) void k_rs_split(const u64* __restrict__ v, 
             for (int j = 0; j < 8; ++j) if (ok[j]) atomicAdd(&L.cnt[rs_dig(x[j], sp.shB, sp.mB)], 1u);
         }
         __syncthreads();
-        if (tid < 64) {                              // exclusive scan over the 256 counters: four per lane
-            u32 c4[4], s = 0;
+        if (tid < 64) {                              // exclusive scan over the BB counters: CPL per lane
+            u32 c[CPL], s = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { c4[q] = L.cnt[4 * lane + q]; s += c4[q]; }
+            for (int q = 0; q < CPL; ++q) { c[q] = L.cnt[CPL * lane + q]; s += c[q]; }
             u32 run = beg + wave_incl_scan(s) - s;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { L.cur[4 * lane + q] = run; sub[(u64)b * (RS_BBINS + 1) + 4 * lane + q] = run; run += c4[q]; }
-            if (lane == 63) sub[(u64)b * (RS_BBINS + 1) + RS_BBINS] = run;
+            for (int q = 0; q < CPL; ++q) { L.cur[CPL * lane + q] = run; sub[(u64)b * (BB + 1) + CPL * lane + q] = run; run += c[q]; }
+            if (lane == 63) sub[(u64)b * (BB + 1) + BB] = run;
         }
         __syncthreads();
-        if (tid <= RS_BBINS) L.cnt[tid] = 0;
+        for (u32 d = tid; d <= BB; d += RS_BNT) L.cnt[d] = 0;
         __syncthreads();
-        rs_scatter_range<RS_BBINS, RS_BNT>(v, ab, beg, end, ov, oab, sp.shB, sp.mB, L);
+        rs_scatter_range<BB, RS_BNT>(v, ab, beg, end, ov, oab, sp.shB, sp.mB, L);
     }
 }
 
@@ -221,7 +223,7 @@ __device__ __forceinline__ void rs_wave_sort(u64* gk, u32* ga, u32 nd, u64* rk, 
         rs_wave_sync();
 #pragma unroll
         for (int q = 0; q < 4; ++q) { wc[4 * lane + q] = run; run += c4[q]; }
-        if (lane == 63) wc[RS_BBINS] = run;
+        if (lane == 63) wc[RS_CELLS] = run;
     }
     rs_wave_sync();
     u32 o[RPL], c[RPL], fin[RPL], cmax = 0;
@@ -257,15 +259,15 @@ __device__ __forceinline__ void rs_wave_sort(u64* gk, u32* ga, u32 nd, u64* rk, 
 
 // every sub-bucket of every bucket: wave w of the grid takes sub-bucket w; the large ones go to a list for k_rs_big
 #define RS_CNT 256
-__global__ __launch_bounds__(RS_CNT) void k_rs_cells(u64* kv, u32* av, const u32* __restrict__ sub, u32 nsub, RsSpec sp,
+__global__ __launch_bounds__(RS_CNT) void k_rs_cells(u64* kv, u32* av, const u32* __restrict__ sub, u32 nsub, u32 bb, RsSpec sp,
                                                      u32* __restrict__ biglist, u32* __restrict__ nbig, u32* __restrict__ flag) {
     __shared__ u64 rk[RS_CNT / 64][RS_WAVE_ROWS];
     __shared__ u32 ra[RS_CNT / 64][RS_WAVE_ROWS];
-    __shared__ u32 wc[RS_CNT / 64][RS_BBINS + 1];
+    __shared__ u32 wc[RS_CNT / 64][RS_CELLS + 1];
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 id = blockIdx.x * (RS_CNT / 64) + wave;
     if (id >= nsub) return;
-    const u32 i = id + id / RS_BBINS;                              // sub[] holds 257 starts per bucket
+    const u32 i = id + id / bb;                                    // sub[] holds bb + 1 starts per bucket
     const u32 o = sub[i], nd = sub[i + 1] - o;
     if (nd < 2) return;
     if (nd <= RS_WAVE_ROWS) rs_wave_sort(kv + o, av + o, nd, rk[wave], ra[wave], wc[wave], sp.shC, sp.mC, flag);
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(RS_NT) void k_rs_big(u64* kv, u32* av, const u32* _
                                                   const u32* __restrict__ nbig, u32* __restrict__ flag, u32 block_rows) {
     __shared__ u64 rk[RS_BLOCK_ROWS];
     __shared__ u32 ra[RS_BLOCK_ROWS];
-    __shared__ u32 wc[2 * RS_BBINS];
+    __shared__ u32 wc[2 * RS_CELLS];
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 nb = *nbig;
     for (u32 x = blockIdx.x; x < nb; x += gridDim.x) {
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(RS_NT) void k_rs_big(u64* kv, u32* av, const u32* _
         u64* gk = kv + o; u32* ga = av + o;
         u64 k[4]; u32 a[4], r[4];
         __syncthreads();
-        if (tid < RS_BBINS) wc[tid] = 0;
+        if (tid < RS_CELLS) wc[tid] = 0;
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -302,11 +304,11 @@ __global__ __launch_bounds__(RS_NT) void k_rs_big(u64* kv, u32* av, const u32* _
             u32 run = wave_incl_scan(s) - s;
             rs_wave_sync();
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { wc[RS_BBINS + 4 * lane + q] = c4[q]; wc[4 * lane + q] = run; run += c4[q]; }      // counts kept behind the offsets
+            for (int q = 0; q < 4; ++q) { wc[RS_CELLS + 4 * lane + q] = c4[q]; wc[4 * lane + q] = run; run += c4[q]; }      // counts kept behind the offsets
         }
         __syncthreads();
         u32 cmine = 0, omine = 0;
-        if (tid < RS_BBINS) { omine = wc[tid]; cmine = wc[RS_BBINS + tid]; }
+        if (tid < RS_CELLS) { omine = wc[tid]; cmine = wc[RS_CELLS + tid]; }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const u32 j = tid + RS_NT * t;

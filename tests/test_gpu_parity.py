@@ -771,6 +771,11 @@ def test_row_sort_paths_agree(oracle, dev, monkeypatch):
     st = check_against_oracle(oracle, skew, 31, dev, amin=1)
     assert st["sort_fallback"] == 1
     monkeypatch.delenv("DSKGPU_RS_BLOCK_ROWS")
+    for bbits in ("9", "10"):                                           # the wider second digits of row sets above 96 M / 192 M rows
+        monkeypatch.setenv("DSKGPU_RS_BBITS", bbits)
+        for k, s in ((31, reads), (31, skew), (11, reads)):
+            check_against_oracle(oracle, s, k, dev, amin=1)
+    monkeypatch.delenv("DSKGPU_RS_BBITS")
     monkeypatch.setenv("DSKGPU_LIB_ROWSORT", "1")
     for k, s in ((31, skew), (11, reads)):
         check_against_oracle(oracle, s, k, dev, amin=1)
