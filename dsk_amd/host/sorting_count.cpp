@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstdio>
 #include <fstream>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 
@@ -201,18 +202,42 @@ void SortingCountBase::execute() {
     // the engine returns ceil(k/32) words per k-mer; the row type of this span has span/32 (one more
     // when k is a multiple of 32, because span k serves k < span): zero-extend
     const size_t bw = (k + 31) / 32;
-    std::vector<uint64_t> kbuf, wide; std::vector<uint32_t> abuf;
+    // Partition p + 1 is fetched from the engine (device -> host) by a helper thread while partition p is turned into rows
+    // (several threads) and written: two buffer slots, handed back and forth under one mutex.
+    struct Slot { std::vector<uint64_t> k; std::vector<uint32_t> a; uint64_t n = 0; bool ready = false; };
+    Slot slot[2];
+    std::mutex mu; std::condition_variable cv;
+    std::exception_ptr fetch_err;
+    bool stop = false;
+    std::thread fetcher([&]() {
+        try {
+            for (uint32_t p = 0; p < np; ++p) {
+                Slot& sl = slot[p & 1];
+                { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !sl.ready || stop; }); if (stop) return; }
+                sl.n = be->partitionSize(p);
+                sl.k.resize(sl.n * bw + 1); sl.a.resize(sl.n + 1);
+                if (sl.n) be->partitionCopy(p, sl.k.data(), sl.a.data());
+                { std::lock_guard<std::mutex> lk(mu); sl.ready = true; }
+                cv.notify_all();
+            }
+        } catch (...) { std::lock_guard<std::mutex> lk(mu); fetch_err = std::current_exception(); cv.notify_all(); }
+    });
+    struct Joiner { std::thread& t; std::mutex& mu; std::condition_variable& cv; bool& stop;
+                    ~Joiner() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); } } joiner{fetcher, mu, cv, stop};
+    std::vector<uint64_t> wide;
     for (uint32_t p = 0; p < np; ++p) {
-        const uint64_t n = be->partitionSize(p);
-        kbuf.resize(n * bw + 1); abuf.resize(n + 1);
-        if (n) be->partitionCopy(p, kbuf.data(), abuf.data());
-        const uint64_t* rows = kbuf.data();
+        Slot& sl = slot[p & 1];
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return sl.ready || fetch_err; }); if (fetch_err) std::rethrow_exception(fetch_err); }
+        const uint64_t n = sl.n;
+        const uint64_t* rows = sl.k.data();
         if (bw != words_) {
             wide.assign(n * words_ + 1, 0);
-            for (uint64_t i = 0; i < n; ++i) for (size_t w = 0; w < bw; ++w) wide[i * words_ + w] = kbuf[i * bw + w];
+            for (uint64_t i = 0; i < n; ++i) for (size_t w = 0; w < bw; ++w) wide[i * words_ + w] = sl.k[i * bw + w];
             rows = wide.data();
         }
-        writePartition(p, rows, abuf.data(), n, amin, compress);
+        writePartition(p, rows, sl.a.data(), n, amin, compress);
+        { std::lock_guard<std::mutex> lk(mu); sl.ready = false; }
+        cv.notify_all();
     }
     Group& dg = storage_->getGroup("dsk");
     dg.setProperty("kmer_size", std::to_string(k));

@@ -10,6 +10,8 @@
 // plays the CountProcessor chain's outputs into HDF5: histogram -> solidity ->
 // dump (README.md:12,70-78).
 #pragma once
+#include <new>
+#include <thread>
 #include <memory>
 #include <string>
 #include <vector>
@@ -68,16 +70,33 @@ public:
 protected:
     void openPartitions(size_t nb) override { part_.reset(getStorage()->template solidPartition<span>(nb)); }
     void writePartition(size_t p, const uint64_t* kmers, const uint32_t* ab, uint64_t n, unsigned amin, int compress) override {
-        std::vector<Count> rows; rows.reserve(n);
-        for (uint64_t i = 0; i < n; ++i) {
-            if (ab[i] < amin) continue;                      // only when -abundance-min auto raised the bar
-            Count c;
-            for (size_t w = 0; w < Kmer<span>::WORDS; ++w) c.value.w[w] = kmers[i * words_ + w];
-            c.abundance = (int32_t)std::min<uint32_t>(ab[i], 0x7FFFFFFFu);
-            rows.push_back(c);
-        }
-        part_->insert(p, rows.data(), rows.size(), compress);
-        nb_solid_ += rows.size();
+        // rows below amin exist only when -abundance-min auto raised the bar above the engine's: per slice of the partition,
+        // count the keepers, then fill the row array at the slices' offsets (both passes on several threads)
+        const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(8, n >> 16));
+        std::vector<uint64_t> keep(nt + 1, 0);
+        auto slice = [&](unsigned t, uint64_t* b, uint64_t* e) { *b = n * t / nt; *e = n * (t + 1) / nt; };
+        auto run = [&](auto fn) {
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; ++t) th.emplace_back(fn, t);
+            fn(0u);
+            for (auto& x : th) x.join();
+        };
+        run([&](unsigned t) { uint64_t b, e, c = 0; slice(t, &b, &e); for (uint64_t i = b; i < e; ++i) c += ab[i] >= amin; keep[t + 1] = c; });
+        for (unsigned t = 0; t < nt; ++t) keep[t + 1] += keep[t];
+        const uint64_t m = keep[nt];
+        std::unique_ptr<char[]> raw(new char[(m + 1) * sizeof(Count)]);      // (raw storage: the rows are constructed by the filling threads)
+        Count* rows = reinterpret_cast<Count*>(raw.get());
+        run([&](unsigned t) {
+            uint64_t b, e, o = keep[t]; slice(t, &b, &e);
+            for (uint64_t i = b; i < e; ++i) {
+                if (ab[i] < amin) continue;
+                Count* c = new (&rows[o++]) Count();
+                for (size_t w = 0; w < Kmer<span>::WORDS; ++w) c->value.w[w] = kmers[i * words_ + w];
+                c->abundance = (int32_t)std::min<uint32_t>(ab[i], 0x7FFFFFFFu);
+            }
+        });
+        part_->insert(p, rows, m, compress);
+        nb_solid_ += m;
     }
 private:
     std::unique_ptr<Partition<Count>> part_;
