@@ -67,6 +67,7 @@ struct Tuning {
     bool balanced_plan = false;                 // DSKGPU_BALANCED_PLAN: P1 ~ P2
     bool fullsort = false;                      // DSKGPU_FULLSORT: full-width row sort
     bool lib_rowsort = false;                   // DSKGPU_LIB_ROWSORT: one-word rows through the library radix sort on a 32-bit prefix + run fix-up (the path before rowsort.h)
+    u32 rs_heavy = 0;                           // DSKGPU_RS_HEAVY: rows of a first-digit bucket above which the row sort gives up (tests)
     u32 rs_bbits = 0;                           // DSKGPU_RS_BBITS: forced width of the row sort's second digit (8..10; tests)
     u32 rs_block_rows = 0;                      // DSKGPU_RS_BLOCK_ROWS: largest sub-bucket the hand-written row sort orders itself (tests: provoke its fallback)
     bool sk_exact = false, no_recsrc = false;   // DSKGPU_SK_EXACT, DSKGPU_NO_RECSRC (multi-GPU sender layout / receiver source)
@@ -83,7 +84,7 @@ struct Tuning {
         opt_cap = (u32)num("DSKGPU_OPT_CAP", 0) & ~7u; opt_slice = num("DSKGPU_OPT_SLICE", 0) & ~7ull;
         sk_slice = num("DSKGPU_SK_SLICE", 0); sk_minslice = num("DSKGPU_SK_MINSLICE", 2000);
         table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
-        lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0);
+        lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0); rs_heavy = (u32)num("DSKGPU_RS_HEAVY", 0);
     }
 };
 
@@ -505,10 +506,14 @@ int sort_rows_msd(dskgpu_ctx* ctx, u64 n) {
     hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), n,
                        (u32)chunk, (u32)nch, matrix, ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), sp);
     CKL("k_rs_scatter");
+    // a bucket above 16 x the mean (+ 64 K rows) is not a k-mer spectrum any more (canonical k-mers: at most ~2 x): one block would
+    // walk it alone, so it goes to the full-width fallback instead
+    u32 heavy = (u32)std::min<u64>(0xFFFFFFFFull, n / RS_ABINS * 16 + 65536);
+    if (ctx->tune.rs_heavy) heavy = ctx->tune.rs_heavy;
     const unsigned gridB = (unsigned)std::min<u64>(ncu * (160 * 1024 / (ldsB + 1024)), RS_ABINS);
     auto split = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(gridB), dim3(RS_BNT), ldsB, ctx->stream, ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), (u32)nch, matrix,
-                           ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), sub, sp, sc + SC_RSWORK2);
+                           ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), sub, sp, sc + SC_RSWORK2, heavy, sc + SC_SORTFLAG);
     };
     if (BB == 1024 && ldsB > 64 * 1024) { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_split<1024>)); if (e) return e; }
     if (BB == 256) split(k_rs_split<256>); else if (BB == 512) split(k_rs_split<512>); else split(k_rs_split<1024>);

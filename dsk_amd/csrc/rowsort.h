@@ -146,7 +146,8 @@ __global__ __launch_bounds__(RS_NT) void k_rs_scatter(const u64* __restrict__ v,
 // counter in ascending order: canonical k-mers are densest at small values (up to twice the mean), so the heavy buckets go first.
 template <int BB>
 __global__ __launch_bounds__(RS_BNT) void k_rs_split(const u64* __restrict__ v, const u32* __restrict__ ab, u32 nch, const u32* __restrict__ scanned,
-                                                     u64* __restrict__ ov, u32* __restrict__ oab, u32* __restrict__ sub, RsSpec sp, u32* __restrict__ work) {
+                                                     u64* __restrict__ ov, u32* __restrict__ oab, u32* __restrict__ sub, RsSpec sp, u32* __restrict__ work,
+                                                     u32 heavy, u32* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RsLds<BB, RS_BTILE> L(smem);
     u32& s_b = L.tot[1];                                 // (the spare word behind the scan scratch: no static LDS next to the dynamic block)
@@ -159,6 +160,11 @@ __global__ __launch_bounds__(RS_BNT) void k_rs_split(const u64* __restrict__ v, 
         const u32 b = s_b;
         if (b >= RS_ABINS) break;
         const u32 beg = scanned[(u64)b * nch], end = scanned[(u64)(b + 1) * nch];     // (the scan leaves the total behind the last entry)
+        if (end - beg > heavy) {                         // one bucket with a large share of all rows (values far from any k-mer spectrum):
+            if (tid == 0) *flag = 1u;                    // a single block would take it alone -> leave the rows to the full-width fallback
+            for (u32 d = tid; d <= BB; d += RS_BNT) sub[(u64)b * (BB + 1) + d] = d < BB ? beg : end;
+            continue;
+        }
         for (u32 d = tid; d <= BB; d += RS_BNT) L.cnt[d] = 0;
         __syncthreads();
         for (u32 i0 = beg; i0 < end; i0 += 8 * RS_BNT) {

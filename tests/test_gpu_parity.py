@@ -771,6 +771,10 @@ def test_row_sort_paths_agree(oracle, dev, monkeypatch):
     st = check_against_oracle(oracle, skew, 31, dev, amin=1)
     assert st["sort_fallback"] == 1
     monkeypatch.delenv("DSKGPU_RS_BLOCK_ROWS")
+    monkeypatch.setenv("DSKGPU_RS_HEAVY", "1000")                       # a first-digit bucket "too heavy" for one block: fallback, same rows
+    st = check_against_oracle(oracle, reads, 31, dev, amin=1)
+    assert st["sort_fallback"] == 1
+    monkeypatch.delenv("DSKGPU_RS_HEAVY")
     for bbits in ("9", "10"):                                           # the wider second digits of row sets above 96 M / 192 M rows
         monkeypatch.setenv("DSKGPU_RS_BBITS", bbits)
         for k, s in ((31, reads), (31, skew), (11, reads)):
