@@ -6,15 +6,17 @@
 //
 //   A  k_rs_hist + scan + k_rs_scatter : 1024 buckets on the top 10 value bits.  Exact chunk x bin offsets (the same
 //      one-linear-scan matrix layout as the key scatters), 8192-row tiles staged in LDS, runs of ~8 rows per bucket and tile.
-//   B  k_rs_split, one 256-thread block per bucket (all 1024 in flight): histogram of the next 8 bits in LDS, then the same
-//      LDS-staged scatter inside the bucket (a bucket is ~42 K rows = 500 KB: its second read comes from L2)
-//   C  k_rs_cells, one wave per sub-bucket (~160 rows), in place: the rows are placed by the next 8 bits with LDS atomics
-//      (< 1 row per cell on average) and the few rows that share a cell ordered by insertion on the full value;
-//      sub-buckets of 257..4096 rows are listed and done by whole blocks (k_rs_big).
+//   B  k_rs_split, 512-thread blocks taking one bucket at a time from a work counter: histogram of the next 8 bits in LDS
+//      (9 / 10 bits above 96 M / 192 M rows), then the same LDS-staged scatter inside the bucket (a bucket is ~42 K rows =
+//      500 KB: its second read comes from L2); the sub-bucket starts go to `sub`
+//   C  k_rs_cells, one wave per sub-bucket (~160 rows, at most 512), in place: the rows are placed by the next 8 bits with LDS
+//      atomics (< 1 row per cell on average); a row that shares its cell counts the smaller values of the cell and moves to
+//      its final slot.  Sub-buckets of 513..4096 rows are listed and done by whole blocks (k_rs_big).
 //
-// Skew: buckets are exact (any distribution of values works, a heavy bucket just takes its block longer); a sub-bucket
-// above 4096 rows or a cell above the insertion cap raises *flag, and the host orders the rows with the full-width
-// library sort instead (stats.sort_fallback) -- never seen on reads, provoked in tests.
+// Skew: buckets are exact (any distribution of values works); what the kernels do not order themselves -- a first-digit
+// bucket above 16 x the mean (one block would walk it alone), a sub-bucket above 4096 rows, a cell above 64 rows (128 in
+// k_rs_big) -- raises *flag, and the host orders the rows with the full-width library sort instead (stats.sort_fallback):
+// never seen on reads, provoked in tests.
 #pragma once
 #include "kernels.h"
 
@@ -22,15 +24,14 @@
 #define RS_RPT 8
 #define RS_TILE (RS_NT * RS_RPT)
 #define RS_ABINS 1024
-#ifndef RS_BNT
 #define RS_BNT 512                        // step B: 512-thread blocks, 4096-row tiles (52 KB of LDS: three blocks per CU hide each
-#endif                                    //   other's memory latency; a heavy bucket is ~20 tiles)
+                                          //   other's memory latency; a heavy bucket is ~20 tiles)
 #define RS_BTILE (RS_BNT * RS_RPT)
 #define RS_CELLS 256                      // step C: cells of a sub-bucket (third digit)
 #define RS_WAVE_ROWS 512                  // step C: a wave orders sub-buckets up to this size alone (8 rows per lane)
 #define RS_MAX_ROWS (384ull << 20)        // most rows this sort takes: 1024 x 1024 sub-buckets of ~380 rows on average (the densest twice that)
 #define RS_BLOCK_ROWS 4096                // larger ones: a whole block (k_rs_big); beyond this: flag
-#define RS_WAVE_CELL_CAP 64               // rows sharing all three digits, ordered by insertion (wave path / block path)
+#define RS_WAVE_CELL_CAP 64               // rows sharing all three digits that are still ordered here (wave path / block path)
 #define RS_BLOCK_CELL_CAP 128
 
 // digit X of value v = (v >> shX) & mX; A = top 10 significant bits, B and C the next 8 + 8 (fewer for very small k)
