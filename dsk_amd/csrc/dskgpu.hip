@@ -125,7 +125,7 @@ struct dskgpu_ctx {
     std::vector<u32> h_sk_sums; std::vector<u64> h_sk_cbase;
     // records handed to dskgpu_mg_count: the level-1 scatter reads them directly (SRC 2); expanded lazily for the exact path
     const u64* rec_src = nullptr; u64 rec_n = 0; u64 rec_nch = 0, rec_rpc = 0; bool rec_expanded = false;
-    u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0; u64 h_nvalid = 0;
+    u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0; u64 h_nvalid = 0; bool have_nvalid = false;
     u32 h_rs[3] = {0, 0, 0};       // host source of the row sort's device scalars (matrix length, list length, work counter)
     bool sentinel_ok = true;       // the all-ones key is not the mixed form of a canonical k-mer of this k (checked at create)
     bool opt1_off = false;         // same for the histogram-free level-1 scatter (block-owned slices)
@@ -629,7 +629,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
     int extra_bits = 0;
     for (int attempt = 0;; ++attempt) {
         Plan pl;
-        if (!make_plan(cap, extra_bits, W, ctx->tune.balanced_plan, (u32)ctx->num_cu, &pl))
+        const u64 plan_n = (from_reads && npass == 1 && ctx->have_nvalid) ? std::min<u64>(cap, ctx->h_nvalid + 1) : cap;
+        if (!make_plan(plan_n, extra_bits, W, ctx->tune.balanced_plan, (u32)ctx->num_cu, &pl))
             return fail(ctx, DSKGPU_E_OVERFLOW, "cannot partition finer (table overflow persists)");
         pl.d1.world = pl.d2.world = ctx->cfg.world_size; pl.d1.npass = pl.d2.npass = npass; pl.d1.pass = pl.d2.pass = pass;
         // ---------------- level 1
@@ -675,14 +676,6 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         unsigned grid1 = 0;
         if (opt1 && !from_reads) ctx->h_nvalid = nkeys_in;
         if (opt1) {
-            if (from_reads) {
-            CK(hipMemsetAsync(ctx->gstats.p, 0, 4 * 8, ctx->stream));
-            hipLaunchKernelGGL(k_count_valid, dim3((unsigned)std::min<u64>((nwords + 255) / 256, (u64)ctx->num_cu * 8)), dim3(256), 0, ctx->stream,
-                               ctx->inval.as<u32>(), nwords, (int)ctx->cfg.kmer_size, ctx->gstats.as<u64>() + 3);
-            CKL("k_count_valid");
-            CK(hipMemcpyAsync(&ctx->h_nvalid, ctx->gstats.as<u64>() + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
-            CK(hipStreamSynchronize(ctx->stream));
-            }
             grid1 = scatter_grid(ctx, W, pl.P1, nch1);
             const u64 cells = (u64)pl.P1 * grid1;
             // a block's share of the input: it walks chunks blockIdx, blockIdx + grid, .. (equal chunks, the busiest block has ceil(nch/grid))
@@ -878,6 +871,18 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
     CK(ctx->scalars.ensure(SC_COUNT * 4));
     CK(ctx->ghist.ensure(((size_t)ctx->cfg.histo_max + 1) * 8));
     CK(ctx->gstats.ensure(4 * 8));
+    ctx->have_nvalid = false;
+    if (from_reads && nwords) {
+        // the exact number of valid k-mer windows (0.08 ms): the plan is sized from it (the byte count over-states the k-mers of
+        // 150 bp reads by a quarter: 590 K sub-partitions of 2030 keys instead of 469 K of 2560), and so are the level-1 slices
+        CK(hipMemsetAsync(ctx->gstats.p, 0, 4 * 8, ctx->stream));
+        hipLaunchKernelGGL(k_count_valid, dim3((unsigned)std::min<u64>((nwords + 255) / 256, (u64)ctx->num_cu * 8)), dim3(256), 0, ctx->stream,
+                           ctx->inval.as<u32>(), nwords, (int)ctx->cfg.kmer_size, ctx->gstats.as<u64>() + 3);
+        CKL("k_count_valid");
+        CK(hipMemcpyAsync(&ctx->h_nvalid, ctx->gstats.as<u64>() + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        ctx->have_nvalid = true;
+    }
     const u64 max_keys = ctx->max_keys_per_pass ? ctx->max_keys_per_pass : 0xF0000000ull;
     u32 npass = (u32)std::max<u64>(1, (n_upper + max_keys - 1) / max_keys);
     for (;; npass *= 2) {
