@@ -347,7 +347,7 @@ struct Plan {
     DigitSpec d1, d2;
 };
 
-#define TARGET_KEYS 2560      // worst-case mean keys per final sub-partition (table: 4096 slots, 3584 usable)
+#define TARGET_KEYS 2900      // mean keys per final sub-partition (the count kernel prefetches 3072 per sub-partition; table: 4096 slots, 3584 usable)
 #define TARGET_KEYS2 1280     // two-word keys: 2048-slot index table, 1792 usable
 #define MAX_LEVEL_BINS 2048
 #define ONE_LEVEL_BINS 1024
@@ -365,19 +365,17 @@ bool make_plan(u64 n_upper, int extra_bits, int W, bool balanced, u32 num_cu, Pl
     if (F < 2) F = 2;
     if (F <= ONE_LEVEL_BINS) { pl->levels = 1; pl->P1 = (u32)F; pl->P2 = 1; }
     else {
-        u64 p1 = 1; while (p1 * p1 < F) ++p1;
-        // keep level 2 inside the aligned-write-out kernel (its per-bin carry must fit LDS): more level-1 bins
-        // instead -- the level-1 scatter is ALU-bound and does not mind shorter runs
+        // Level 1 costs more per key the more bins it has (3.05 ps + 1.7 fs per bin and key, DESIGN section 6: every tile leaves a
+        // partial line per bin), level 2 costs the same for any number of bins its kernel holds (the per-bin carry must fit LDS:
+        // p2max).  So: the FEWEST level-1 bins that keep level 2 inside that kernel -- but at least one segment per CU, and a
+        // multiple of the CU count: level 2 gives every block whole segments (level-1 bins), one block per CU, and a count that is
+        // not a multiple leaves some blocks one segment more than the rest (770 segments on 256 CUs cost 20 %).
         u64 p2max = MAX_LEVEL_BINS; while (p2max > 64 && ascatter_lds(W, (u32)p2max) > 160 * 1024) --p2max;
-        const u64 p1_al = (F + p2max - 1) / p2max;
-        if (p1_al > p1 && p1_al <= MAX_LEVEL_BINS - 8 && !balanced) p1 = p1_al;
-        // The level-2 kernel gives every block whole segments (level-1 bins), one block per CU: a number of segments that is a
-        // multiple of the CU count leaves no block with an extra one (768 -> 770 segments on 256 CUs cost 20 %).
-        if (!balanced && p1 >= num_cu) {
-            const u64 dn = p1 / num_cu * num_cu, up = dn + num_cu;
-            const bool dn_ok = (F + dn - 1) / dn + 1 <= p2max, up_ok = up <= MAX_LEVEL_BINS - 8 && up <= p1 + p1 / 8;
-            if (dn_ok && (p1 - dn <= up - p1 || !up_ok)) p1 = dn;
-            else if (up_ok) p1 = up;
+        u64 p1 = 1; while (p1 * p1 < F) ++p1;                                  // balanced split: small inputs, DSKGPU_BALANCED_PLAN
+        if (!balanced && F >= (u64)num_cu * 64) {
+            p1 = std::max<u64>((F + p2max - 2) / (p2max - 1), num_cu);         // (p2max - 1: room for the odd-P2 adjustment below)
+            p1 = (p1 + num_cu - 1) / num_cu * num_cu;
+            if (p1 > MAX_LEVEL_BINS - 8) p1 = MAX_LEVEL_BINS - 8;
         }
         u64 p2 = (F + p1 - 1) / p1;
         // An ODD number of level-2 bins: the regions of sub-partition q start q * 545 groups of 64 B into the buffer, and the
