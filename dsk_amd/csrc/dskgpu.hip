@@ -467,11 +467,11 @@ int sort_rows_full_multiword(dskgpu_ctx* ctx, u64 n) {
     return DSKGPU_OK;
 }
 
-// ---- one-word rows: hand-written MSD radix sort (rowsort.h).  out_* -> (step A) srt_* -> (steps B, C) out_*; a sub-bucket
-// or cell the kernels do not order themselves raises SC_SORTFLAG and run_pipeline() falls back to the full-width library sort
-// of srt_* (a complete permutation of the rows either way).
-int sort_rows_msd(dskgpu_ctx* ctx, u64 n) {
-    const int total = (int)std::min(64u, 2u * ctx->cfg.kmer_size);
+// ---- hand-written MSD radix sort (rowsort.h) of n (64-bit key, 32-bit value) pairs on the `total` low bits of the key, in place
+// (tk / tv: scratch of the same size).  One-word rows: (k-mer value, abundance); multi-word rows: (top 63 bits of the value,
+// row index).  Whatever the kernels do not order themselves raises SC_SORTFLAG (zeroed here): the caller falls back to a
+// full-width library sort (k / v and tk / tv each hold a complete permutation of the pairs either way).
+int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int total) {
     // second digit: 8 bits up to 96 M rows, 9 up to 192 M, 10 beyond (sub-buckets stay near 200 rows: one wave each in step C)
     int wantB = n <= (96ull << 20) ? 8 : n <= (192ull << 20) ? 9 : 10;
     if (ctx->tune.rs_bbits >= 8 && ctx->tune.rs_bbits <= 10) wantB = (int)ctx->tune.rs_bbits;      // tests
@@ -498,11 +498,10 @@ int sort_rows_msd(dskgpu_ctx* ctx, u64 n) {
     const size_t ldsA = RsLds<RS_ABINS, RS_TILE>::bytes;
     const size_t ldsB = BB == 256 ? RsLds<256, RS_BTILE>::bytes : BB == 512 ? RsLds<512, RS_BTILE>::bytes : RsLds<1024, RS_BTILE>::bytes;
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_scatter)); if (e) return e; }
-    hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)nch), dim3(RS_NT), 0, ctx->stream, ctx->out_w[0].as<u64>(), n, (u32)chunk, (u32)nch, matrix, sp);
+    hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)nch), dim3(RS_NT), 0, ctx->stream, k, n, (u32)chunk, (u32)nch, matrix, sp);
     CKL("k_rs_hist");
     { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
-    hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), n,
-                       (u32)chunk, (u32)nch, matrix, ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), sp);
+    hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, k, v, n, (u32)chunk, (u32)nch, matrix, tk, tv, sp);
     CKL("k_rs_scatter");
     // a bucket above 16 x the mean (+ 64 K rows) is not a k-mer spectrum any more (canonical k-mers: at most ~2 x): one block would
     // walk it alone, so it goes to the full-width fallback instead
@@ -510,21 +509,26 @@ int sort_rows_msd(dskgpu_ctx* ctx, u64 n) {
     if (ctx->tune.rs_heavy) heavy = ctx->tune.rs_heavy;
     const unsigned gridB = (unsigned)std::min<u64>(ncu * (160 * 1024 / (ldsB + 1024)), RS_ABINS);
     auto split = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(gridB), dim3(RS_BNT), ldsB, ctx->stream, ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), (u32)nch, matrix,
-                           ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), sub, sp, sc + SC_RSWORK2, heavy, sc + SC_SORTFLAG);
+        hipLaunchKernelGGL(kern, dim3(gridB), dim3(RS_BNT), ldsB, ctx->stream, tk, tv, (u32)nch, matrix, k, v, sub, sp, sc + SC_RSWORK2, heavy, sc + SC_SORTFLAG);
     };
     if (BB == 1024 && ldsB > 64 * 1024) { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_split<1024>)); if (e) return e; }
     if (BB == 256) split(k_rs_split<256>); else if (BB == 512) split(k_rs_split<512>); else split(k_rs_split<1024>);
     CKL("k_rs_split");
     const u32 nsub = RS_ABINS * BB;
-    hipLaunchKernelGGL(k_rs_cells, dim3(nsub / (RS_CNT / 64)), dim3(RS_CNT), 0, ctx->stream, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), sub, nsub, BB, sp,
-                       biglist, sc + SC_RSWORK, sc + SC_SORTFLAG);
+    hipLaunchKernelGGL(k_rs_cells, dim3(nsub / (RS_CNT / 64)), dim3(RS_CNT), 0, ctx->stream, k, v, sub, nsub, BB, sp, biglist, sc + SC_RSWORK, sc + SC_SORTFLAG);
     CKL("k_rs_cells");
     const u32 block_rows = ctx->tune.rs_block_rows ? std::min<u32>(ctx->tune.rs_block_rows, RS_BLOCK_ROWS) : RS_BLOCK_ROWS;
-    hipLaunchKernelGGL(k_rs_big, dim3((unsigned)std::min<u64>(ncu, 256)), dim3(RS_NT), 0, ctx->stream, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), sub, sp,
-                       biglist, sc + SC_RSWORK, sc + SC_SORTFLAG, block_rows);
+    hipLaunchKernelGGL(k_rs_big, dim3((unsigned)std::min<u64>(ncu, 256)), dim3(RS_NT), 0, ctx->stream, k, v, sub, sp, biglist, sc + SC_RSWORK, sc + SC_SORTFLAG, block_rows);
     CKL("k_rs_big");
-    CK(hipMemcpyAsync(&ctx->h_back[3], sc + SC_SORTFLAG, 4, hipMemcpyDeviceToHost, ctx->stream));
+    return DSKGPU_OK;
+}
+
+// one-word rows: out_* ordered in place (srt_* = scratch and, for run_pipeline's fallback, a complete permutation of the rows)
+int sort_rows_msd(dskgpu_ctx* ctx, u64 n) {
+    const int e = msd_sort_pairs(ctx, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), n,
+                                 (int)std::min(64u, 2u * ctx->cfg.kmer_size));
+    if (e) return e;
+    CK(hipMemcpyAsync(&ctx->h_back[3], ctx->scalars.as<u32>() + SC_SORTFLAG, 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->sort_partial = true;
     ctx->res_w[0] = ctx->out_w[0].as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>();
     return DSKGPU_OK;
@@ -577,20 +581,29 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
         const int bits = 2 * (int)ctx->cfg.kmer_size;
         if (W == 2) hipLaunchKernelGGL(k_top_key<2>, dim3(gb), dim3(256), 0, ctx->stream, ri, n, bits, ctx->srt_k.as<u64>(), ctx->srt_idx.as<u32>());
         else hipLaunchKernelGGL(k_top_key<4>, dim3(gb), dim3(256), 0, ctx->stream, ri, n, bits, ctx->srt_k.as<u64>(), ctx->srt_idx.as<u32>());
-        const unsigned begin_bit = 63u - SORT_TOP_BITS;
-        CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->srt_k.as<u64>(), ctx->s_val.as<u64>(), ctx->srt_idx.as<u32>(), ctx->srt_idx2.as<u32>(),
-                                     (size_t)n, begin_bit, 63u, ctx->stream));
-        CK(ctx->srt_tmp.ensure(tmp));
-        CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->srt_k.as<u64>(), ctx->s_val.as<u64>(), ctx->srt_idx.as<u32>(), ctx->srt_idx2.as<u32>(),
-                                     (size_t)n, begin_bit, 63u, ctx->stream));
-        const u32* idx = ctx->srt_idx2.as<u32>();
+        u32* flag = ctx->scalars.as<u32>() + SC_SORTFLAG;
+        const u32* idx; const u64* skey; int run_shift;
+        if (!ctx->tune.lib_rowsort && n <= RS_MAX_ROWS) {
+            // the hand-written MSD sort on (top 63 bits, row index): fully ordered by those 63 bits, what is left to k_fix_runs_multi
+            // are the rows that share all of them
+            const int e = msd_sort_pairs(ctx, ctx->srt_k.as<u64>(), ctx->srt_idx.as<u32>(), ctx->s_val.as<u64>(), ctx->srt_idx2.as<u32>(), n, 63);
+            if (e) return e;
+            idx = ctx->srt_idx.as<u32>(); skey = ctx->srt_k.as<u64>(); run_shift = 0;
+        } else {
+            const unsigned begin_bit = 63u - SORT_TOP_BITS;
+            CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->srt_k.as<u64>(), ctx->s_val.as<u64>(), ctx->srt_idx.as<u32>(), ctx->srt_idx2.as<u32>(),
+                                         (size_t)n, begin_bit, 63u, ctx->stream));
+            CK(ctx->srt_tmp.ensure(tmp));
+            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->srt_k.as<u64>(), ctx->s_val.as<u64>(), ctx->srt_idx.as<u32>(), ctx->srt_idx2.as<u32>(),
+                                         (size_t)n, begin_bit, 63u, ctx->stream));
+            CK(hipMemsetAsync(flag, 0, 4, ctx->stream));
+            idx = ctx->srt_idx2.as<u32>(); skey = ctx->s_val.as<u64>(); run_shift = (int)begin_bit;
+        }
         for (int x = 0; x < W; ++x)
             hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_w[x].as<u64>(), ctx->out_w[x].as<u64>(), idx, n);
         hipLaunchKernelGGL(k_gather<u32>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_ab.as<u32>(), ctx->out_ab.as<u32>(), idx, n);
-        u32* flag = ctx->scalars.as<u32>() + SC_SORTFLAG;
-        CK(hipMemsetAsync(flag, 0, 4, ctx->stream));
-        if (W == 2) hipLaunchKernelGGL(k_fix_runs_multi<2>, dim3(gb), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), ctx->s_val.as<u64>(), n, (int)begin_bit, flag);
-        else hipLaunchKernelGGL(k_fix_runs_multi<4>, dim3(gb), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), ctx->s_val.as<u64>(), n, (int)begin_bit, flag);
+        if (W == 2) hipLaunchKernelGGL(k_fix_runs_multi<2>, dim3(gb), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), skey, n, run_shift, flag);
+        else hipLaunchKernelGGL(k_fix_runs_multi<4>, dim3(gb), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), skey, n, run_shift, flag);
         CKL("sort_rows");
         CK(hipMemcpyAsync(&ctx->h_back[3], flag, 4, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sort_partial = true;

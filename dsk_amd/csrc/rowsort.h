@@ -233,25 +233,26 @@ __device__ __forceinline__ void rs_wave_sort(u64* gk, u32* ga, u32 nd, u64* rk, 
         if (lane == 63) wc[RS_CELLS] = run;
     }
     rs_wave_sync();
-    u32 o[RPL], c[RPL], fin[RPL], cmax = 0;
+    u32 o[RPL], c[RPL], fin[RPL], at[RPL], cmax = 0;
 #pragma unroll
     for (int t = 0; t < RPL; ++t) {
         const u32 i = lane + 64 * t;
-        o[t] = 0; c[t] = 0; fin[t] = 0;
+        o[t] = 0; c[t] = 0; fin[t] = 0; at[t] = 0;
         if (i < nd) {
             const u32 d = r[t] >> 16;
             o[t] = wc[d]; c[t] = wc[d + 1] - o[t];
-            const u32 pos = o[t] + (r[t] & 0xFFFFu);
-            rk[pos] = k[t]; ra[pos] = a[t];
+            at[t] = o[t] + (r[t] & 0xFFFFu);
+            rk[at[t]] = k[t]; ra[at[t]] = a[t];
             fin[t] = o[t];
             if (c[t] > 1) cmax = c[t] > cmax ? c[t] : cmax;
         }
     }
     rs_wave_sync();
     if (cmax > RS_WAVE_CELL_CAP) { *flag = 1u; cmax = 0; }
-    for (u32 j = 0; __ballot(j < cmax); ++j) {
+    for (u32 j = 0; __ballot(j < cmax); ++j) {       // (equal keys -- the 63-bit prefixes of multi-word rows can tie -- keep their placement order)
 #pragma unroll
-        for (int t = 0; t < RPL; ++t) if (c[t] > 1 && j < c[t]) fin[t] += rk[o[t] + j] < k[t] ? 1u : 0u;
+        for (int t = 0; t < RPL; ++t)
+            if (c[t] > 1 && j < c[t]) { const u64 kk = rk[o[t] + j]; fin[t] += (kk < k[t] || (kk == k[t] && o[t] + j < at[t])) ? 1u : 0u; }
     }
     rs_wave_sync();
 #pragma unroll
