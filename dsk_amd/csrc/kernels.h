@@ -505,6 +505,20 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                 dj = ((vm & (1u << j)) && key_in_pass<MODE>(digit_word(h[j]), ds)) ? dj : P;
                 rk[j] = dj << 16;                                    // (digit, rank) packed: rank < 16384, digit <= 2048
             }
+            if (MODE == 3) {
+                // one pass of several: most keys belong to other passes.  They are neither ranked nor staged (as members of the
+                // dummy bin they would all add to ONE counter -- 60 of a wave's 64 lanes serialised on it in every rank instruction
+                // -- and fill the stage with keys nobody writes out); masked LDS operations with a few lanes are cheap
+#pragma unroll
+                for (int j = 0; j < KPT; ++j) if ((rk[j] >> 16) < P) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
+                lds_barrier();
+                tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot, OPT ? SliceGuard{o1.slice, o1.slice, first, P * o1.cap1} : SliceGuard{0u, 0u, 0u, 0u});
+                lds_barrier();
+#pragma unroll
+                for (int j = 0; j < KPT; ++j) if ((rk[j] >> 16) < P) stage[off[rk[j] >> 16] + (rk[j] & 0xFFFFu)] = h[j];
+                lds_barrier();
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < KPT; ++j) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
             lds_barrier();
