@@ -505,37 +505,17 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                 dj = ((vm & (1u << j)) && key_in_pass<MODE>(digit_word(h[j]), ds)) ? dj : P;
                 rk[j] = dj << 16;                                    // (digit, rank) packed: rank < 16384, digit <= 2048
             }
-            if (MODE == 3) {
-                // one pass of several: most keys belong to other passes.  They are neither ranked nor staged (as members of the
-                // dummy bin they would all add to ONE counter -- 60 of a wave's 64 lanes serialised on it in every rank instruction
-                // -- and fill the stage with keys nobody writes out); masked LDS operations with a few lanes are cheap
+            // Windows without a key of this launch (read borders, N, keys of other passes) are neither ranked nor staged: as members
+            // of a dummy bin they would all add to ONE counter -- a fifth of a wave's lanes on 150 bp reads, 60 of 64 in a pass of
+            // sixteen, serialised on it in every rank instruction (multi-pass level 1: 137 -> 65 ms per pass) -- and masked LDS
+            // operations cost no more than full ones
 #pragma unroll
-                for (int j = 0; j < KPT; ++j) if ((rk[j] >> 16) < P) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
-                lds_barrier();
-                tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot, OPT ? SliceGuard{o1.slice, o1.slice, first, P * o1.cap1} : SliceGuard{0u, 0u, 0u, 0u});
-                lds_barrier();
-#pragma unroll
-                for (int j = 0; j < KPT; ++j) if ((rk[j] >> 16) < P) stage[off[rk[j] >> 16] + (rk[j] & 0xFFFFu)] = h[j];
-                lds_barrier();
-                return;
-            }
-#pragma unroll
-            for (int j = 0; j < KPT; ++j) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
+            for (int j = 0; j < KPT; ++j) if ((rk[j] >> 16) < P) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
             lds_barrier();
             tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot, OPT ? SliceGuard{o1.slice, o1.slice, first, P * o1.cap1} : SliceGuard{0u, 0u, 0u, 0u});
             lds_barrier();
-            // all bin starts first, then all stage writes (no dependent LDS read -> write round trip per key); the keys of invalid
-            // windows (dummy bin P) are staged like any bin, behind the valid ones (off[P] = their number), and never written out
-            constexpr int SB = KPT < 8 ? KPT : 8;                     // (eight at a time: sixteen starts in flight spill registers)
 #pragma unroll
-            for (int j0 = 0; j0 < KPT; j0 += SB) {
-                u32 so[SB];
-#pragma unroll
-                for (int j = 0; j < SB; ++j) so[j] = off[rk[j0 + j] >> 16];
-#pragma unroll
-                for (int j = 0; j < SB; ++j) stage[so[j] + (rk[j0 + j] & 0xFFFFu)] = h[j0 + j];
-            }
-            if (threadIdx.x == 0) cnt[P] = 0;
+            for (int j = 0; j < KPT; ++j) if ((rk[j] >> 16) < P) stage[off[rk[j] >> 16] + (rk[j] & 0xFFFFu)] = h[j];
             lds_barrier();
         };
         auto write_out = [&]() {
@@ -545,7 +525,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                 const u32 i0 = (u32)it * 4 * SC_NT;
                 Key hk[4]; u32 dd[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) hk[u] = stage[i0 + u * SC_NT + threadIdx.x];      // (slots past the tile's keys hold the dummy bin: readable, never stored as keys)
+                for (int u = 0; u < 4; ++u) hk[u] = stage[i0 + u * SC_NT + threadIdx.x];      // (slots past the tile's keys hold stale keys: readable, never stored as keys)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) dd[u] = delta[key_digit<MODE>(digit_word(hk[u]), ds)];
 #pragma unroll
