@@ -599,9 +599,11 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
             CK(hipMemsetAsync(flag, 0, 4, ctx->stream));
             idx = ctx->srt_idx2.as<u32>(); skey = ctx->s_val.as<u64>(); run_shift = (int)begin_bit;
         }
-        for (int x = 0; x < W; ++x)
-            hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_w[x].as<u64>(), ctx->out_w[x].as<u64>(), idx, n);
-        hipLaunchKernelGGL(k_gather<u32>, dim3(gb), dim3(256), 0, ctx->stream, ctx->srt_ab.as<u32>(), ctx->out_ab.as<u32>(), idx, n);
+        {
+            const unsigned gb4 = (unsigned)((n + 1023) / 1024);
+            if (W == 2) hipLaunchKernelGGL(k_gather_rows<2>, dim3(gb4), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), ri, ctx->out_ab.as<u32>(), idx, n);
+            else hipLaunchKernelGGL(k_gather_rows<4>, dim3(gb4), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), ri, ctx->out_ab.as<u32>(), idx, n);
+        }
         if (W == 2) hipLaunchKernelGGL(k_fix_runs_multi<2>, dim3(gb), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), skey, n, run_shift, flag);
         else hipLaunchKernelGGL(k_fix_runs_multi<4>, dim3(gb), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), skey, n, run_shift, flag);
         CKL("sort_rows");

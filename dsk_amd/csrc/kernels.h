@@ -1325,6 +1325,29 @@ __global__ void k_gather(T* __restrict__ dst, const T* __restrict__ src, const u
     if (i < n) dst[i] = src[idx[i]];
 }
 
+// whole rows in one pass: every thread takes four rows, reads their indices once and has all its W + 1 loads per row in flight
+template <int W>
+__global__ __launch_bounds__(256) void k_gather_rows(RowsOut dst, u32* __restrict__ dab, RowsIn src, const u32* __restrict__ sab,
+                                                     const u32* __restrict__ idx, u64 n) {
+    const u64 b0 = (u64)blockIdx.x * 1024 + threadIdx.x;          // rows b0, b0 + 256, ..: consecutive lanes, consecutive rows
+    u32 id[4]; u64 v[4][W]; u32 a[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) id[r] = b0 + r * 256 < n ? idx[b0 + r * 256] : 0u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int x = 0; x < W; ++x) v[r][x] = src.w[x][id[r]];
+        a[r] = sab[id[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (b0 + r * 256 < n) {
+#pragma unroll
+            for (int x = 0; x < W; ++x) dst.w[x][b0 + r * 256] = v[r][x];
+            dab[b0 + r * 256] = a[r];
+        }
+}
+
 // ------------------------------------------------------------------ test kernels
 // canonical k-mer + validity for the window ending at every byte
 template <int W>
