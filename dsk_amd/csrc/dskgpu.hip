@@ -50,7 +50,7 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_OVF2, SC_OVF1, SC_RSLEN, SC_RSWORK, SC_RSWORK2, SC_COUNT = 12 };
+enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_OVF2, SC_OVF1, SC_RSLEN, SC_RSWORK, SC_RSWORK2, SC_RSTIES, SC_COUNT = 16 };
 #ifndef SORT_TOP_BITS
 #define SORT_TOP_BITS 32u      // 4 radix passes; 40 bits (5 passes) cost 0.3 ms more on 43 M rows, the in-place run fix-up absorbs the extra ties
 #endif
@@ -107,7 +107,7 @@ struct dskgpu_ctx {
     DevBuf bufA, bufB;             // partition ping-pong
     DevBuf mat1, mat2, sums, descs1, descs2, seg, fstart, nsolid, scalars, ghist, gstats;
     DevBuf out_w[4], srt_w[4], acc_w[4];   // rows as struct-of-arrays: word i of every row in [i]
-    DevBuf out_ab, srt_ab, srt_tmp, srt_idx, srt_idx2, srt_k, abund2, acc_ab;
+    DevBuf out_ab, srt_ab, srt_tmp, srt_idx, srt_idx2, srt_k, srt_k2, abund2, acc_ab;   // srt_k2: one record per row for the multi-word gather
     u64 max_keys_per_pass = 0;     // 0 = as many as 32-bit offsets allow
     // multi-bank mode (solidity kinds, 2-D histogram)
     std::vector<u64> bank_ends;    // end offset of every declared bank in the read stream
@@ -126,7 +126,7 @@ struct dskgpu_ctx {
     // records handed to dskgpu_mg_count: the level-1 scatter reads them directly (SRC 2); expanded lazily for the exact path
     const u64* rec_src = nullptr; u64 rec_n = 0; u64 rec_nch = 0, rec_rpc = 0; bool rec_expanded = false;
     u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0; u64 h_nvalid = 0; bool have_nvalid = false;
-    u32 h_rs[3] = {0, 0, 0};       // host source of the row sort's device scalars (matrix length, list length, work counter)
+    u32 h_rs[4] = {0, 0, 0, 0};    // host source of the row sort's device scalars (matrix length, list length, work counter, ties seen)
     bool sentinel_ok = true;       // the all-ones key is not the mixed form of a canonical k-mer of this k (checked at create)
     bool opt1_off = false;         // same for the histogram-free level-1 scatter (block-owned slices)
     bool opt2_off = false;         // the fixed-capacity level-2 scatter overflowed on these reads: use the exact path   // host landing zone of the async size read-back
@@ -492,8 +492,8 @@ int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int
     u32* sub = matrix + M + 2;
     u32* biglist = sub + nsubw;
     u32* sc = ctx->scalars.as<u32>();
-    ctx->h_rs[0] = (u32)M; ctx->h_rs[1] = 0; ctx->h_rs[2] = 0;
-    CK(hipMemcpyAsync(sc + SC_RSLEN, ctx->h_rs, 12, hipMemcpyHostToDevice, ctx->stream));
+    ctx->h_rs[0] = (u32)M; ctx->h_rs[1] = 0; ctx->h_rs[2] = 0; ctx->h_rs[3] = 0;
+    CK(hipMemcpyAsync(sc + SC_RSLEN, ctx->h_rs, 16, hipMemcpyHostToDevice, ctx->stream));
     CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream));
     const size_t ldsA = RsLds<RS_ABINS, RS_TILE>::bytes;
     const size_t ldsB = BB == 256 ? RsLds<256, RS_BTILE>::bytes : BB == 512 ? RsLds<512, RS_BTILE>::bytes : RsLds<1024, RS_BTILE>::bytes;
@@ -515,10 +515,10 @@ int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int
     if (BB == 256) split(k_rs_split<256>); else if (BB == 512) split(k_rs_split<512>); else split(k_rs_split<1024>);
     CKL("k_rs_split");
     const u32 nsub = RS_ABINS * BB;
-    hipLaunchKernelGGL(k_rs_cells, dim3(nsub / (RS_CNT / 64)), dim3(RS_CNT), 0, ctx->stream, k, v, sub, nsub, BB, sp, biglist, sc + SC_RSWORK, sc + SC_SORTFLAG);
+    hipLaunchKernelGGL(k_rs_cells, dim3(nsub / (RS_CNT / 64)), dim3(RS_CNT), 0, ctx->stream, k, v, sub, nsub, BB, sp, biglist, sc + SC_RSWORK, sc + SC_SORTFLAG, sc + SC_RSTIES);
     CKL("k_rs_cells");
     const u32 block_rows = ctx->tune.rs_block_rows ? std::min<u32>(ctx->tune.rs_block_rows, RS_BLOCK_ROWS) : RS_BLOCK_ROWS;
-    hipLaunchKernelGGL(k_rs_big, dim3((unsigned)std::min<u64>(ncu, 256)), dim3(RS_NT), 0, ctx->stream, k, v, sub, sp, biglist, sc + SC_RSWORK, sc + SC_SORTFLAG, block_rows);
+    hipLaunchKernelGGL(k_rs_big, dim3((unsigned)std::min<u64>(ncu, 256)), dim3(RS_NT), 0, ctx->stream, k, v, sub, sp, biglist, sc + SC_RSWORK, sc + SC_SORTFLAG, block_rows, sc + SC_RSTIES);
     CKL("k_rs_big");
     return DSKGPU_OK;
 }
@@ -579,16 +579,24 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
         RowsIn ri{}; RowsOut ro{};
         for (int x = 0; x < W; ++x) { CK(ctx->srt_w[x].ensure(n * 8)); ri.w[x] = ctx->out_w[x].as<u64>(); ro.w[x] = ctx->srt_w[x].as<u64>(); }
         const int bits = 2 * (int)ctx->cfg.kmer_size;
-        if (W == 2) hipLaunchKernelGGL(k_top_key<2>, dim3(gb), dim3(256), 0, ctx->stream, ri, n, bits, ctx->srt_k.as<u64>(), ctx->srt_idx.as<u32>());
+        const bool msd = !ctx->tune.lib_rowsort && n <= RS_MAX_ROWS;
+        u64* aos = nullptr;
+        if (msd) {      // + one record per row for the gather (the full-width fallback buffers are free until then)
+            CK(ctx->srt_k2.ensure(n * 8 * (size_t)(W == 2 ? AosRow<2>::WORDS : AosRow<4>::WORDS)));
+            aos = ctx->srt_k2.as<u64>();
+            if (W == 2) hipLaunchKernelGGL(k_top_key_aos<2>, dim3(gb), dim3(256), 0, ctx->stream, ri, ctx->out_ab.as<u32>(), n, bits, ctx->srt_k.as<u64>(), ctx->srt_idx.as<u32>(), aos);
+            else hipLaunchKernelGGL(k_top_key_aos<4>, dim3(gb), dim3(256), 0, ctx->stream, ri, ctx->out_ab.as<u32>(), n, bits, ctx->srt_k.as<u64>(), ctx->srt_idx.as<u32>(), aos);
+        } else if (W == 2) hipLaunchKernelGGL(k_top_key<2>, dim3(gb), dim3(256), 0, ctx->stream, ri, n, bits, ctx->srt_k.as<u64>(), ctx->srt_idx.as<u32>());
         else hipLaunchKernelGGL(k_top_key<4>, dim3(gb), dim3(256), 0, ctx->stream, ri, n, bits, ctx->srt_k.as<u64>(), ctx->srt_idx.as<u32>());
         u32* flag = ctx->scalars.as<u32>() + SC_SORTFLAG;
+        const u32* ties = nullptr;                     // MSD path: the tie pass returns at once unless the sort met equal keys
         const u32* idx; const u64* skey; int run_shift;
-        if (!ctx->tune.lib_rowsort && n <= RS_MAX_ROWS) {
+        if (msd) {
             // the hand-written MSD sort on (top 63 bits, row index): fully ordered by those 63 bits, what is left to k_fix_runs_multi
             // are the rows that share all of them
             const int e = msd_sort_pairs(ctx, ctx->srt_k.as<u64>(), ctx->srt_idx.as<u32>(), ctx->s_val.as<u64>(), ctx->srt_idx2.as<u32>(), n, 63);
             if (e) return e;
-            idx = ctx->srt_idx.as<u32>(); skey = ctx->srt_k.as<u64>(); run_shift = 0;
+            idx = ctx->srt_idx.as<u32>(); skey = ctx->srt_k.as<u64>(); run_shift = 0; ties = ctx->scalars.as<u32>() + SC_RSTIES;
         } else {
             const unsigned begin_bit = 63u - SORT_TOP_BITS;
             CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->srt_k.as<u64>(), ctx->s_val.as<u64>(), ctx->srt_idx.as<u32>(), ctx->srt_idx2.as<u32>(),
@@ -599,13 +607,17 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
             CK(hipMemsetAsync(flag, 0, 4, ctx->stream));
             idx = ctx->srt_idx2.as<u32>(); skey = ctx->s_val.as<u64>(); run_shift = (int)begin_bit;
         }
-        {
+        if (aos) {
+            if (W == 2) hipLaunchKernelGGL(k_gather_aos<2>, dim3(gb), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), aos, idx, n);
+            else hipLaunchKernelGGL(k_gather_aos<4>, dim3(gb), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), aos, idx, n);
+        } else {
             const unsigned gb4 = (unsigned)((n + 1023) / 1024);
             if (W == 2) hipLaunchKernelGGL(k_gather_rows<2>, dim3(gb4), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), ri, ctx->out_ab.as<u32>(), idx, n);
             else hipLaunchKernelGGL(k_gather_rows<4>, dim3(gb4), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), ri, ctx->out_ab.as<u32>(), idx, n);
         }
-        if (W == 2) hipLaunchKernelGGL(k_fix_runs_multi<2>, dim3(gb), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), skey, n, run_shift, flag);
-        else hipLaunchKernelGGL(k_fix_runs_multi<4>, dim3(gb), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), skey, n, run_shift, flag);
+        const unsigned gfix = (unsigned)std::min<u64>(gb, (u64)ctx->num_cu * 32);      // grid-stride kernel: when there are no ties its blocks leave at once
+        if (W == 2) hipLaunchKernelGGL(k_fix_runs_multi<2>, dim3(gfix), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), skey, n, run_shift, flag, ties);
+        else hipLaunchKernelGGL(k_fix_runs_multi<4>, dim3(gfix), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), skey, n, run_shift, flag, ties);
         CKL("sort_rows");
         CK(hipMemcpyAsync(&ctx->h_back[3], flag, 4, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sort_partial = true;
@@ -1348,7 +1360,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->reads_own, &ctx->packed, &ctx->inval, &ctx->bufA, &ctx->bufB, &ctx->mat1, &ctx->mat2, &ctx->sums,
                       &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats,
                       &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
-                      &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
+                      &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->srt_k2, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
                       &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,
                       &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load};
     for (DevBuf* b : bufs) b->release();

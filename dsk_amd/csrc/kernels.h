@@ -1325,6 +1325,40 @@ __global__ void k_gather(T* __restrict__ dst, const T* __restrict__ src, const u
     if (i < n) dst[i] = src[idx[i]];
 }
 
+// Gathering the rows of a multi-word sort by index costs W + 1 random reads per row from the per-word arrays -- more than
+// the sort itself.  k_top_key_aos therefore also packs every row into ONE record (W value words + the abundance, padded to a
+// multiple of 16 bytes: 32 bytes for two words, 48 for four) while it reads the words anyway, and k_gather_aos fetches a row
+// with one random access of that record.
+template <int W> struct AosRow { static constexpr int WORDS = (W + 1 + 1) & ~1; };      // u64 words per record
+template <int W>
+__global__ __launch_bounds__(256) void k_top_key_aos(RowsIn rows, const u32* __restrict__ ab, u64 n, int bits, u64* __restrict__ key,
+                                                     u32* __restrict__ idx, u64* __restrict__ aos) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int sh = bits - 63, ws = sh >> 6, b = sh & 63;     // bits > 64 for multi-word values
+    u64 w[W], lo = 0, hi = 0;
+#pragma unroll
+    for (int x = 0; x < W; ++x) { w[x] = rows.w[x][i]; if (x == ws) lo = w[x]; if (x == ws + 1) hi = w[x]; }
+    key[i] = b ? (lo >> b) | (hi << (64 - b)) : lo;
+    idx[i] = (u32)i;
+    ulonglong2* rec = reinterpret_cast<ulonglong2*>(aos + i * AosRow<W>::WORDS);
+#pragma unroll
+    for (int x = 0; x < AosRow<W>::WORDS; x += 2)
+        rec[x / 2] = make_ulonglong2(x < W ? w[x] : (x == W ? (u64)ab[i] : 0ull), x + 1 < W ? w[x + 1] : (x + 1 == W ? (u64)ab[i] : 0ull));
+}
+template <int W>
+__global__ __launch_bounds__(256) void k_gather_aos(RowsOut dst, u32* __restrict__ dab, const u64* __restrict__ aos, const u32* __restrict__ idx, u64 n) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ulonglong2* rec = reinterpret_cast<const ulonglong2*>(aos + (u64)idx[i] * AosRow<W>::WORDS);
+    u64 w[AosRow<W>::WORDS];
+#pragma unroll
+    for (int x = 0; x < AosRow<W>::WORDS; x += 2) { const ulonglong2 v = rec[x / 2]; w[x] = v.x; w[x + 1] = v.y; }
+#pragma unroll
+    for (int x = 0; x < W; ++x) dst.w[x][i] = w[x];
+    dab[i] = (u32)w[W];
+}
+
 // whole rows in one pass: every thread takes four rows, reads their indices once and has all its W + 1 loads per row in flight
 template <int W>
 __global__ __launch_bounds__(256) void k_gather_rows(RowsOut dst, u32* __restrict__ dab, RowsIn src, const u32* __restrict__ sab,
@@ -1467,29 +1501,31 @@ __device__ __forceinline__ bool row_less(const u64 (&a)[W], const RowsOut& r, u6
     return false;
 }
 template <int W>
-__global__ __launch_bounds__(256) void k_fix_runs_multi(RowsOut rows, u32* __restrict__ ab, const u64* __restrict__ key, u64 n, int sh, u32* __restrict__ flag) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u64 p = key[i] >> sh;
-    if (i > 0 && (key[i - 1] >> sh) == p) return;           // not a run head
-    u64 e = i + 1;
-    while (e < n && e - i <= FIX_CAP && (key[e] >> sh) == p) ++e;
-    const u64 L = e - i;
-    if (L == 1) return;
-    if (L > FIX_CAP) { *flag = 1; return; }
-    for (u64 a = i + 1; a < e; ++a) {
-        u64 kv[W]; const u32 av = ab[a];
+__global__ __launch_bounds__(256) void k_fix_runs_multi(RowsOut rows, u32* __restrict__ ab, const u64* __restrict__ key, u64 n, int sh, u32* __restrict__ flag,
+                                                        const u32* __restrict__ ties) {
+    if (ties && *ties == 0u) return;                         // the sort saw no two equal keys: nothing to order
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {      // (grid-stride: the launch may be capped)
+        const u64 p = key[i] >> sh;
+        if (i > 0 && (key[i - 1] >> sh) == p) continue;         // not a run head
+        u64 e = i + 1;
+        while (e < n && e - i <= FIX_CAP && (key[e] >> sh) == p) ++e;
+        const u64 L = e - i;
+        if (L == 1) continue;
+        if (L > FIX_CAP) { *flag = 1; continue; }
+        for (u64 a = i + 1; a < e; ++a) {
+            u64 kv[W]; const u32 av = ab[a];
 #pragma unroll
-        for (int x = 0; x < W; ++x) kv[x] = rows.w[x][a];
-        u64 b = a;
-        while (b > i && row_less<W>(kv, rows, b - 1)) {
+            for (int x = 0; x < W; ++x) kv[x] = rows.w[x][a];
+            u64 b = a;
+            while (b > i && row_less<W>(kv, rows, b - 1)) {
 #pragma unroll
-            for (int x = 0; x < W; ++x) rows.w[x][b] = rows.w[x][b - 1];
-            ab[b] = ab[b - 1]; --b;
+                for (int x = 0; x < W; ++x) rows.w[x][b] = rows.w[x][b - 1];
+                ab[b] = ab[b - 1]; --b;
+            }
+#pragma unroll
+            for (int x = 0; x < W; ++x) rows.w[x][b] = kv[x];
+            ab[b] = av;
         }
-#pragma unroll
-        for (int x = 0; x < W; ++x) rows.w[x][b] = kv[x];
-        ab[b] = av;
     }
 }
 

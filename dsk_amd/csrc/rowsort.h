@@ -195,19 +195,22 @@ __global__ __launch_bounds__(RS_BNT) void k_rs_split(const u64* __restrict__ v, 
 __device__ __forceinline__ void rs_wave_sync() { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // insertion order of rows [o, o + m) of an LDS row area by value (one lane; m is small)
-__device__ __forceinline__ void rs_insertion(u64* rk, u32* ra, u32 o, u32 m) {
+__device__ __forceinline__ bool rs_insertion(u64* rk, u32* ra, u32 o, u32 m) {      // -> two equal values met
+    bool tie = false;
     for (u32 x = o + 1; x < o + m; ++x) {
         const u64 kv = rk[x]; const u32 av = ra[x];
         u32 y = x;
         while (y > o && rk[y - 1] > kv) { rk[y] = rk[y - 1]; ra[y] = ra[y - 1]; --y; }
+        if (y > o && rk[y - 1] == kv) tie = true;
         rk[y] = kv; ra[y] = av;
     }
+    return tie;
 }
 
 // step C: one wave per sub-bucket (2 <= nd <= RS_WAVE_ROWS rows at gk / ga, ordered in place).  The rows are placed by the third
 // digit with LDS atomics (rk / ra = the wave's LDS row area, wc = its 256 + 1 cell counters); a row that shares its cell then
 // counts the smaller values of the cell (all rows of the wave at once, one LDS read per step and row) and moves to its final slot.
-__device__ __forceinline__ void rs_wave_sort(u64* gk, u32* ga, u32 nd, u64* rk, u32* ra, u32* wc, int sh, u32 m, u32* flag) {
+__device__ __forceinline__ void rs_wave_sort(u64* gk, u32* ga, u32 nd, u64* rk, u32* ra, u32* wc, int sh, u32 m, u32* flag, u32* ties) {
     const u32 lane = threadIdx.x & 63;
     constexpr int RPL = RS_WAVE_ROWS / 64;
     u64 k[RPL]; u32 a[RPL], r[RPL];
@@ -252,7 +255,11 @@ __device__ __forceinline__ void rs_wave_sort(u64* gk, u32* ga, u32 nd, u64* rk, 
     for (u32 j = 0; __ballot(j < cmax); ++j) {       // (equal keys -- the 63-bit prefixes of multi-word rows can tie -- keep their placement order)
 #pragma unroll
         for (int t = 0; t < RPL; ++t)
-            if (c[t] > 1 && j < c[t]) { const u64 kk = rk[o[t] + j]; fin[t] += (kk < k[t] || (kk == k[t] && o[t] + j < at[t])) ? 1u : 0u; }
+            if (c[t] > 1 && j < c[t]) {
+                const u64 kk = rk[o[t] + j];
+                fin[t] += (kk < k[t] || (kk == k[t] && o[t] + j < at[t])) ? 1u : 0u;
+                if (kk == k[t] && o[t] + j != at[t]) *ties = 1u;          // equal keys exist (63-bit prefixes of multi-word rows): the caller's tie pass has work
+            }
     }
     rs_wave_sync();
 #pragma unroll
@@ -268,7 +275,7 @@ __device__ __forceinline__ void rs_wave_sort(u64* gk, u32* ga, u32 nd, u64* rk, 
 // every sub-bucket of every bucket: wave w of the grid takes sub-bucket w; the large ones go to a list for k_rs_big
 #define RS_CNT 256
 __global__ __launch_bounds__(RS_CNT) void k_rs_cells(u64* kv, u32* av, const u32* __restrict__ sub, u32 nsub, u32 bb, RsSpec sp,
-                                                     u32* __restrict__ biglist, u32* __restrict__ nbig, u32* __restrict__ flag) {
+                                                     u32* __restrict__ biglist, u32* __restrict__ nbig, u32* __restrict__ flag, u32* __restrict__ ties) {
     __shared__ u64 rk[RS_CNT / 64][RS_WAVE_ROWS];
     __shared__ u32 ra[RS_CNT / 64][RS_WAVE_ROWS];
     __shared__ u32 wc[RS_CNT / 64][RS_CELLS + 1];
@@ -278,13 +285,13 @@ __global__ __launch_bounds__(RS_CNT) void k_rs_cells(u64* kv, u32* av, const u32
     const u32 i = id + id / bb;                                    // sub[] holds bb + 1 starts per bucket
     const u32 o = sub[i], nd = sub[i + 1] - o;
     if (nd < 2) return;
-    if (nd <= RS_WAVE_ROWS) rs_wave_sort(kv + o, av + o, nd, rk[wave], ra[wave], wc[wave], sp.shC, sp.mC, flag);
+    if (nd <= RS_WAVE_ROWS) rs_wave_sort(kv + o, av + o, nd, rk[wave], ra[wave], wc[wave], sp.shC, sp.mC, flag, ties);
     else if (lane == 0) biglist[atomicAdd(nbig, 1u)] = i;
 }
 
 // sub-buckets of 257 .. block_rows rows, one block each (the same placement by the third digit, block-wide)
 __global__ __launch_bounds__(RS_NT) void k_rs_big(u64* kv, u32* av, const u32* __restrict__ sub, RsSpec sp, const u32* __restrict__ biglist,
-                                                  const u32* __restrict__ nbig, u32* __restrict__ flag, u32 block_rows) {
+                                                  const u32* __restrict__ nbig, u32* __restrict__ flag, u32 block_rows, u32* __restrict__ ties) {
     __shared__ u64 rk[RS_BLOCK_ROWS];
     __shared__ u32 ra[RS_BLOCK_ROWS];
     __shared__ u32 wc[2 * RS_CELLS];
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(RS_NT) void k_rs_big(u64* kv, u32* av, const u32* _
         }
         __syncthreads();
         if (cmine > RS_BLOCK_CELL_CAP) *flag = 1u;
-        else if (cmine >= 2) rs_insertion(rk, ra, omine, cmine);
+        else if (cmine >= 2) { if (rs_insertion(rk, ra, omine, cmine)) *ties = 1u; }
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 4; ++t) {

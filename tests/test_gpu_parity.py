@@ -798,6 +798,12 @@ def test_multiword_row_sort_prefix_runs_and_fallback(oracle, dev, k):
         s = np.frombuffer(b"\n".join(recs) + b"\n" + noise + b"\n", dtype=np.uint8)
         st = check_against_oracle(oracle, s, k, dev, amin=1)
         assert st["sort_fallback"] == fallback
+    # rows that share MORE than the 63 bits the sort looks at (36 leading bases): equal sort keys, ordered by the tie pass
+    long_head = b"AAAAAAAAAAAAAAAAAAACAAAAAAAAAAAAAAAC"
+    recs = [long_head + t.tobytes()[: k - 36] for t in tails[:25]]
+    s = np.frombuffer(b"\n".join(recs) + b"\n" + noise + b"\n", dtype=np.uint8)
+    st = check_against_oracle(oracle, s, k, dev, amin=1)
+    assert st["sort_fallback"] == 0
 
 
 @pytest.mark.parametrize("k,mkeys,n_reads", [(31, 2, 100_000), (27, 1, 60_000), (63, 1, 60_000)])
