@@ -50,7 +50,7 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_OVF2, SC_OVF1, SC_RSLEN, SC_RSWORK, SC_RSWORK2, SC_RSTIES, SC_COUNT = 16 };
+enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_OVF2, SC_OVF1, SC_RSLEN, SC_RSWORK, SC_RSWORK2, SC_RSTIES, SC_EXT, SC_NCHAINED, SC_COUNT = 16 };
 #ifndef SORT_TOP_BITS
 #define SORT_TOP_BITS 32u      // 4 radix passes; 40 bits (5 passes) cost 0.3 ms more on 43 M rows, the in-place run fix-up absorbs the extra ties
 #endif
@@ -75,6 +75,7 @@ struct Tuning {
     u64 opt_slice = 0;                          // DSKGPU_OPT_SLICE: forced level-1 slice size (keys)
     u64 sk_slice = 0, sk_minslice = 2000;       // DSKGPU_SK_SLICE, DSKGPU_SK_MINSLICE
     u32 table_maxload = 0;                      // DSKGPU_TABLE_MAXLOAD: distinct keys a count table may hold (forces the finer-partition retry)
+    long long max_ext = -1;                     // DSKGPU_MAX_EXT: size of the extension-region pool of the level-2 scatter (tests: 0 = no chains)
     void read() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         auto num = [](const char* n, u64 dflt) { const char* e = getenv(n); return e ? (u64)atoll(e) : dflt; };
@@ -84,6 +85,7 @@ struct Tuning {
         opt_cap = (u32)num("DSKGPU_OPT_CAP", 0) & ~7u; opt_slice = num("DSKGPU_OPT_SLICE", 0) & ~7ull;
         sk_slice = num("DSKGPU_SK_SLICE", 0); sk_minslice = num("DSKGPU_SK_MINSLICE", 2000);
         table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
+        max_ext = getenv("DSKGPU_MAX_EXT") ? atoll(getenv("DSKGPU_MAX_EXT")) : -1;
         lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0); rs_heavy = (u32)num("DSKGPU_RS_HEAVY", 0);
     }
 };
@@ -105,7 +107,7 @@ struct dskgpu_ctx {
 
     DevBuf packed, inval;          // K1 output
     DevBuf bufA, bufB;             // partition ping-pong
-    DevBuf mat1, mat2, sums, descs1, descs2, seg, fstart, nsolid, scalars, ghist, gstats;
+    DevBuf mat1, mat2, sums, descs1, descs2, seg, fstart, nsolid, scalars, ghist, gstats, chain_next;
     DevBuf out_w[4], srt_w[4], acc_w[4];   // rows as struct-of-arrays: word i of every row in [i]
     DevBuf out_ab, srt_ab, srt_tmp, srt_idx, srt_idx2, srt_k, srt_k2, abund2, acc_ab;   // srt_k2: one record per row for the multi-word gather
     u64 max_keys_per_pass = 0;     // 0 = as many as 32-bit offsets allow
@@ -125,7 +127,7 @@ struct dskgpu_ctx {
     std::vector<u32> h_sk_sums; std::vector<u64> h_sk_cbase;
     // records handed to dskgpu_mg_count: the level-1 scatter reads them directly (SRC 2); expanded lazily for the exact path
     const u64* rec_src = nullptr; u64 rec_n = 0; u64 rec_nch = 0, rec_rpc = 0; bool rec_expanded = false;
-    u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0; u64 h_nvalid = 0; bool have_nvalid = false;
+    u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0, h_ext = 0; u64 h_nvalid = 0; bool have_nvalid = false;
     u32 h_rs[4] = {0, 0, 0, 0};    // host source of the row sort's device scalars (matrix length, list length, work counter, ties seen)
     bool sentinel_ok = true;       // the all-ones key is not the mixed form of a canonical k-mer of this k (checked at create)
     bool opt1_off = false;         // same for the histogram-free level-1 scatter (block-owned slices)
@@ -297,7 +299,7 @@ template <> int launch_scatter_rec<4>(dskgpu_ctx*, const ChunkDesc*, const u32*,
 // key-array source with aligned write-out (k_scatter_al) when its LDS footprint fits one CU
 template <int W, int MODE, bool OPT = false, bool SLICED = false>
 int launch_scatter_al(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                      u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, OptSpec os = OptSpec{0u, nullptr, nullptr, nullptr, 0u, 0u}) {
+                      u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, OptSpec os = OptSpec{0u, nullptr, nullptr, nullptr, 0u, 0u, 0ull, 0u, 0u, nullptr, nullptr, nullptr, nullptr}) {
     const size_t lds = ascatter_lds(W, P);
     const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu));
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter_al<W, MODE, OPT, SLICED>)); if (e) return e; }
@@ -688,6 +690,12 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             opt_cap = OPT_GROUPS * (8u / W);                                                    // 545 groups of 64 B whatever the key width
         if (opt_cap && ctx->tune.opt_cap) opt_cap = ctx->tune.opt_cap;                       // experiments / tests
         if (W > 1 && (u64)pl.F * opt_cap >= 0xFFFF0000ull) opt_cap = 0;                       // k_count<W> keeps 32-bit offsets
+        // extension regions behind the home regions (region chains, kernels.h): an eighth of the home regions + 4096, one-word keys
+        // only (the index tables of k_count_mw address one contiguous key range); their offsets inside the pool stay below 2^31
+        u32 max_ext = 0;
+        if (opt_cap && W == 1) max_ext = (u32)std::min<u64>((u64)pl.F / 8 + 4096, 0x7FFFFFFFull / opt_cap - 1);
+        if (opt_cap && ctx->tune.max_ext >= 0) max_ext = W == 1 ? (u32)ctx->tune.max_ext : 0u;        // tests
+        const u64 nregions = (u64)pl.F + max_ext;
         if (opt_cap) {
             // the rows of the solid k-mers land at the region offsets too: abundances (one-word keys: in bufA, the free
             // ping-pong buffer) or keys + abundances (multi-word keys: bufA + abund2).  Size everything BEFORE level 1 writes bufA.
@@ -764,11 +772,12 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         // sub-partition gets a fixed region of OPT_CAP keys; a region that overflows (heavy repeats) sends the
         // level back through the exact histogram + scan path, and the context remembers it for these reads.
         if (pl.levels == 2 && opt_cap) {
-            CK(ctx->bufB.ensure(((u64)pl.F * opt_cap + ATile<W>::KEYS + 16) * sizeof(Key)));
+            CK(ctx->bufB.ensure((nregions * opt_cap + ATile<W>::KEYS + 16) * sizeof(Key)));
             CK(ctx->descs2.ensure(((size_t)pl.P1 * 2 + 1) * sizeof(ChunkDesc)));
             CK(ctx->seg.ensure((size_t)pl.P1 * sizeof(SegInfo)));
-            CK(ctx->mat2.ensure(((size_t)pl.F + 1) * 4));                     // here: keys per sub-partition region
-            CK(hipMemsetAsync(ctx->mat2.p, 0, ((size_t)pl.F + 1) * 4, ctx->stream));
+            CK(ctx->mat2.ensure(((size_t)nregions + 1) * 4));                  // here: keys per region (home regions, then the extension pool)
+            CK(ctx->chain_next.ensure(((size_t)nregions + 1 + max_ext + 1) * 4));   // links (only read where subcnt has its chain bit set), then the list of chained sub-partitions
+            CK(hipMemsetAsync(ctx->mat2.p, 0, ((size_t)nregions + 1) * 4, ctx->stream));
             if (opt1) {      // segments = the level-1 bin regions (slices + sentinel tails)
                 ctx->h_descs2.resize(pl.P1);
                 for (u32 sgm = 0; sgm < pl.P1; ++sgm) {
@@ -782,7 +791,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 CKL("k_plan");
             }
             ctx->mark("plan2");
-            OptSpec os{opt_cap, ctx->mat2.as<u32>(), sc + SC_OVF2, opt1 ? o1.fill : nullptr, o1.slice, grid1, (u64)pl.P1 * o1.slice};
+            OptSpec os{opt_cap, ctx->mat2.as<u32>(), sc + SC_OVF2, opt1 ? o1.fill : nullptr, o1.slice, grid1, (u64)pl.P1 * o1.slice,
+                       pl.F, max_ext, ctx->chain_next.as<u32>(), sc + SC_EXT, ctx->chain_next.as<u32>() + nregions + 1, sc + SC_NCHAINED};
             if (opt1) rc = launch_scatter_al<W, 2, true, true>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
                                                                ctx->bufB.as<Key>(), pl.d2, pl.P2, os);
             else rc = launch_scatter_al<W, 2, true, false>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
@@ -832,6 +842,14 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         u32* solid_ab = W == 1 ? scratch->as<u32>() : ctx->abund2.as<u32>();
         launch_count<W>(ctx, cgrid, fkeys, solid_keys, solid_ab, sc + SC_OVERFLOW, cp);
         CKL("k_count");
+        if constexpr (W == 1) {
+            if (opt_cap && max_ext) {      // the sub-partitions that went on in extension regions (none on repeat-free reads: the blocks leave at once)
+                hipLaunchKernelGGL(k_count_chained, dim3((unsigned)std::min<u64>(max_ext, (u64)ctx->num_cu * 2)), dim3(CNT_NT), 0, ctx->stream, fkeys, solid_keys, solid_ab,
+                                   ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), sc + SC_OVERFLOW, cp, (const u32*)cp.subcnt,
+                                   (const u32*)ctx->chain_next.as<u32>(), (const u32*)(ctx->chain_next.as<u32>() + nregions + 1), (const u32*)(sc + SC_NCHAINED), max_ext);
+                CKL("k_count_chained");
+            }
+        }
         ctx->mark("count");
         if ((rc = run_scan(ctx, ctx->nsolid.as<u32>(), sc + SC_F, pl.F))) return rc;
         ctx->mark("scan_solid");
@@ -842,6 +860,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         if (!opt1) CK(hipMemcpyAsync(&ctx->h_back[2], opt_cap ? ctx->mat1.as<u32>() + M1 : ctx->fstart.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipMemcpyAsync(&ctx->h_ovf2, sc + SC_OVF2, 4, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(&ctx->h_ext, sc + SC_EXT, 4, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipMemcpyAsync(&ctx->h_stats[0], ctx->gstats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
         const u32 h_ovf = ctx->h_back[0], h_nsolid = ctx->h_back[1], h_nk = opt1 ? (u32)ctx->h_stats[2] : ctx->h_back[2];
@@ -871,6 +890,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                            ctx->fstart.as<u32>(), ctx->nsolid.as<u32>(), pl.F, ro, ctx->out_ab.as<u32>(), opt_cap);
         CKL("k_compact");
         ctx->mark("compact");
+        ctx->stats.n_ext_regions += std::min<u32>(ctx->h_ext, max_ext);
         *ns_out = ns; *nk_out = h_nk; *plan_out = pl;
         return DSKGPU_OK;
     }
@@ -1358,7 +1378,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->cfg.device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->reads_own, &ctx->packed, &ctx->inval, &ctx->bufA, &ctx->bufB, &ctx->mat1, &ctx->mat2, &ctx->sums,
-                      &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats,
+                      &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats, &ctx->chain_next,
                       &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
                       &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->srt_k2, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
                       &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,
@@ -1554,10 +1574,11 @@ void dskgpu_mg_make_table(const uint64_t* loads, uint32_t world, uint8_t* table)
 
 int dskgpu_mg_set_table(dskgpu_ctx* ctx, const uint8_t* table) {
     if (!ctx) return DSKGPU_E_ARG;
-    ctx->h_table.resize(SK_BUCKETS);
-    if (table) {
+    if (table)          // validate before the table in use is touched: a rejected table leaves the context as it was
         for (u32 b = 0; b < SK_BUCKETS; ++b)
             if (table[b] != SK_SPLIT && table[b] >= ctx->cfg.world_size) return fail(ctx, DSKGPU_E_ARG, "repartition table names an owner outside the world");
+    ctx->h_table.resize(SK_BUCKETS);
+    if (table) {
         std::memcpy(ctx->h_table.data(), table, SK_BUCKETS);
     } else default_table(ctx->cfg.world_size, ctx->h_table.data());
     ctx->table_dirty = true;

@@ -365,7 +365,16 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
     }
 }
 
-struct OptSpec { u32 cap; u32* subcnt; u32* ovf; const u32* fill; u32 slice, nsl; u64 sstride; };   // fill/slice/nsl/sstride: SLICED input (below)
+struct OptSpec { u32 cap; u32* subcnt; u32* ovf; const u32* fill; u32 slice, nsl; u64 sstride;     // fill/slice/nsl/sstride: SLICED input (below)
+                 u32 F, max_ext; u32* next; u32* ext_cursor; u32* chain_list; u32* chain_cnt; };   // region chains (below)
+// Region chains of the segment-owned level-2 scatter.  Regions 0 .. F-1 are the home regions of the sub-partitions, regions
+// F .. F + max_ext - 1 a pool of extension regions of the same size behind them (region r starts at key r * cap of the output
+// buffer).  A sub-partition that outgrows the region it is writing -- a k-mer with thousands of occurrences: every repeat family
+// of a real genome -- takes the next free extension region(s) (one global atomic per switch) and goes on there; subcnt[r] holds
+// the real keys of region r, its top bit says that the list goes on at region next[r]; a sub-partition that leaves its home region
+// is appended to chain_list (at most max_ext entries: each takes a pool region), and k_count_chained walks those lists.  Only
+// when the pool is used up does *ovf go up (the host then repeats the level with the exact histogram + scan path).
+#define CHAIN_BIT 0x80000000u
 __device__ __forceinline__ bool is_empty_key(u64 h) { return h == DSK_EMPTY; }
 template <int W> __device__ __forceinline__ bool is_empty_key(const KN<W>& h) {
     bool e = true;
@@ -720,6 +729,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
         const ChunkDesc d = descs[g];
         // OPT: positions are relative to the segment's first region (keeps them 32-bit whatever the total)
         Key* out = OPT ? out_all + (u64)d.flat_base * os.cap : out_all;
+        Key* extb = OPT ? out_all + (u64)os.F * os.cap : out_all;         // first extension region
         bool ovf = false;
         lds_barrier();
         for (u32 b = tid; b < P; b += SC_NT) { pos[b] = OPT ? b * os.cap : scanned[d.flat_base + (u64)b * d.stride]; cnt[b] = 0; rn[b] = 0; }
@@ -780,6 +790,8 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
             for (int j = 0; j < KPT; ++j) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
             lds_barrier();
             // ---- scan of the tile histogram fused with the carry bookkeeping
+            if (tid == 0) cnt[P] = 0;     // the dummy bin's ranks are in registers now: its counter starts every tile at 0 (masked slots are
+                                          // staged at rec[P].z + rank, so a rank that grew over the tiles of a chunk would leave the staging area)
             {
                 const int base = tid * ipt;
                 u32 c[4], pe[4], er[4], s = 0;
@@ -790,9 +802,28 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                     if (j < ipt && b < (int)P) {
                         c[j] = cnt[b];
                         const u32 r = rn[b]; u32 p = pos[b];
-                        const u32 bound = (p + r + c[j]) & ~(u32)(G - 1);
-                        const u32 e = bound > p ? bound - p : 0u;
-                        if (OPT && p + e > (u32)(b + 1) * os.cap) { ovf = true; p = (u32)b * os.cap; }   // region full: wrap (result discarded)
+                        // OPT: bit 31 of a position = "inside the extension pool" (offset from its start), clear = offset from the segment's
+                        // first home region.  A position always lies strictly inside its region: a region is left as soon as the next
+                        // groups would reach its end, so the region of a position is its offset / cap.
+                        const u32 pl = OPT ? p & ~CHAIN_BIT : p;
+                        const u32 bound = (pl + r + c[j]) & ~(u32)(G - 1);
+                        const u32 e = bound > pl ? bound - pl : 0u;
+                        if (OPT) {
+                            const bool ext = (p >> 31) != 0u;
+                            const u32 rs = ext ? pl / os.cap * os.cap : (u32)b * os.cap;           // start of the region being written
+                            if (pl + e >= rs + os.cap) {                                            // the groups of this tile would reach its end
+                                const u32 need = e / os.cap + 1u;                                   // regions for e keys, at least one key of room left
+                                const u32 x = atomicAdd(os.ext_cursor, need);
+                                if (x + need > os.max_ext) { ovf = true; p = (u32)b * os.cap; }     // pool used up: wrap (the result is discarded)
+                                else {
+                                    const u32 cur = ext ? os.F + pl / os.cap : d.flat_base + (u32)b;
+                                    os.subcnt[cur] = CHAIN_BIT | (pl - rs); os.next[cur] = os.F + x;
+                                    if (!ext) os.chain_list[atomicAdd(os.chain_cnt, 1u)] = cur;      // (< max_ext entries: every one holds a pool region)
+                                    for (u32 i = 0; i + 1 < need; ++i) { os.subcnt[os.F + x + i] = CHAIN_BIT | os.cap; os.next[os.F + x + i] = os.F + x + i + 1u; }
+                                    p = CHAIN_BIT | (x * os.cap);
+                                }
+                            }
+                        }
                         pe[j] = p; er[j] = e | (r << 16);
                         rn[b] = (u16)(r + c[j] - e);
                         pos[b] = p + e; cnt[b] = 0;
@@ -840,13 +871,15 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                 for (int u = 0; u < 2; ++u) {
                     if (!act[u]) continue;
                     const u32 b = b0 + u * NGRP + gi;
-                    const u32 pold = rb[u].x, e = rb[u].y & 0xFFFFu, r = rb[u].y >> 16, o = rb[u].z;
+                    const u32 e = rb[u].y & 0xFFFFu, r = rb[u].y >> 16, o = rb[u].z;
+                    const u32 pold = OPT ? rb[u].x & ~CHAIN_BIT : rb[u].x;
+                    Key* ob = (OPT && (rb[u].x >> 31)) ? extb : out;                           // home regions of the segment or the extension pool
                     Key* cb = carry + (size_t)b * CARRY;
                     for (u32 a = (pold & ~(u32)(G - 1)) + gl; a < pold + e; a += G) {      // complete groups of this bin
                         if (a >= pold) {
                             const u32 idx = a - pold;
                             const Key kv = idx < r ? cb[idx] : stage[o + idx - r];
-                            out[a] = kv;
+                            ob[a] = kv;
                         }
                     }
                     const u32 c = rnew[u] + e - r;                        // keys this tile gave the bin
@@ -865,10 +898,13 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
             const u32 r = rn[b];
             if (!OPT) { if (gl < r) out[pos[b] + gl] = carry[(size_t)b * CARRY + gl]; }
             else {
-                u32 p = pos[b];
-                if (r && p + G > (u32)(b + 1) * os.cap) { ovf = true; p = (u32)b * os.cap; }
-                if (r) out[p + gl] = gl < r ? carry[(size_t)b * CARRY + gl] : empty_key<W>();       // pad the last group
-                if (gl == 0) { const u32 n = p - (u32)b * os.cap + r; os.subcnt[d.flat_base + b] = n < os.cap ? n : os.cap; }   // real keys: the pads are never read
+                // (a position lies strictly inside its region and is a multiple of G: the last partial group always has room)
+                const u32 p = pos[b], pl = p & ~CHAIN_BIT;
+                const bool ext = (p >> 31) != 0u;
+                const u32 rs = ext ? pl / os.cap * os.cap : b * os.cap;
+                Key* ob = ext ? extb : out;
+                if (r) ob[pl + gl] = gl < r ? carry[(size_t)b * CARRY + gl] : empty_key<W>();       // pad the last group
+                if (gl == 0) os.subcnt[ext ? os.F + pl / os.cap : d.flat_base + b] = pl - rs + r;    // real keys of the list's last region: the pads are never read
             }
         }
         if (OPT && ovf) *os.ovf = 1u;
@@ -976,7 +1012,7 @@ __device__ __forceinline__ void sub_range(const CountParams& cp, const u32* __re
 // solid_keys: where the solid rows' (still mixed) keys go, at index begin+pos.
 //             one-word keys: == keys (in place); two-word keys: the free ping-pong buffer
 // abund     : abundance of the solid rows at the same index
-__device__ __forceinline__ void table_insert1(u64* tk, u32* tc, unsigned short* lst, u32* ndist, u32* ovf, u64 h) {
+__device__ __forceinline__ void table_insert1(u64* tk, u32* tc, unsigned short* lst, u32* ndist, u32* ovf, u64 h, u32 inc = 1u) {
     u32 slot = (u32)h & (CNT_SLOTS - 1);
     int probe = 0;
     for (; probe < CNT_SLOTS; ++probe) {
@@ -985,7 +1021,7 @@ __device__ __forceinline__ void table_insert1(u64* tk, u32* tc, unsigned short* 
             old = atomicCAS(&tk[slot], DSK_EMPTY, h);
             if (old == DSK_EMPTY) { lst[atomicAdd(ndist, 1u)] = (unsigned short)slot; old = h; }
         }
-        if (old == h) { atomicAdd(&tc[slot], 1u); return; }
+        if (old == h) { atomicAdd(&tc[slot], inc); return; }
         slot = (slot + 1) & (CNT_SLOTS - 1);
     }
     *ovf = 1;
@@ -1017,7 +1053,9 @@ __global__ __launch_bounds__(CNT_NT) void k_count1(u64* keys, u64* solid_keys, c
     auto range_lo = [&](u32 qq) { const u32 c = qq < cp.F ? qq : cp.F - 1; return REG ? subcnt[c] : fstart[c]; };
     auto range_hi = [&](u32 qq) { const u32 c = qq < cp.F ? qq : cp.F - 1; return REG ? 0u : fstart[c + 1]; };
     auto begin_of = [&](u32 qq, u32 lo) { return REG ? (u64)qq * cp.cap : (u64)lo; };
-    auto count_of = [&](u32 qq, u32 lo, u32 hi) { return qq < cp.F ? (REG ? lo : hi - lo) : 0u; };
+    // (REG: the top bit of subcnt says "this sub-partition goes on in extension regions": it reads as empty here and is counted by
+    //  k_count_chained -- a branch for it inside this loop cost 1.6 of 4.0 ms: the kernel's speed follows its instruction schedule)
+    auto count_of = [&](u32 qq, u32 lo, u32 hi) { return qq < cp.F ? (REG ? ((int)lo < 0 ? 0u : lo) : hi - lo) : 0u; };
     // two register sets of keys, used in turn: the keys of sub-partition q + 2 * grid are requested when q's inserts are done
     // and consumed two iterations later, so by then neither the loads nor the solid-row stores issued in between (vmcnt counts
     // both, in issue order) hold the wave up
@@ -1106,6 +1144,87 @@ __global__ __launch_bounds__(CNT_NT) void k_count1(u64* keys, u64* solid_keys, c
     for (int b = tid; b < CNT_LH; b += CNT_NT) {
         const u32 v = lh[b];
         if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
+    }
+    if (tid == 0 && ndist_acc) atomicAdd(&gstats[0], ndist_acc);
+}
+
+// Sub-partitions that go on in extension regions (k_scatter_al, "region chains"; listed in chain_list by the scatter): the same
+// table, sweep and in-place solid rows as k_count1, one block per listed sub-partition in turn, keys read region by region along
+// the chain.  Such keys arrive in runs (a k-mer with thousands of occurrences), so a wave first adds up the lanes that hold the
+// same key as its first lane -- one insert for all of them instead of a 64-way same-address atomic -- and the other lanes insert
+// their own.  Rare by construction (no sub-partition of repeat-free reads is chained): written for clarity, not for speed.
+__global__ __launch_bounds__(CNT_NT) void k_count_chained(u64* keys, u64* solid_keys, u32* __restrict__ abund, u32* __restrict__ nsolid,
+                                                          u64* __restrict__ ghist, u64* __restrict__ gstats, u32* __restrict__ overflow,
+                                                          CountParams cp, const u32* __restrict__ subcnt, const u32* __restrict__ chain_next,
+                                                          const u32* __restrict__ chain_list, const u32* __restrict__ d_nchained, u32 list_cap) {
+    __shared__ u64 tk[CNT_SLOTS];
+    __shared__ u32 tc[CNT_SLOTS];
+    __shared__ unsigned short lst[CNT_SLOTS];
+    __shared__ u32 ctr[4];                      // ndist, out, ovf
+    const int tid = threadIdx.x, lane = tid & 63;
+    const u32 nchained = *d_nchained < list_cap ? *d_nchained : list_cap;
+    if (blockIdx.x >= nchained) return;
+    for (int s = tid; s < CNT_SLOTS; s += CNT_NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
+    if (tid < 4) ctr[tid] = 0;
+    u64 ndist_acc = 0;
+    __syncthreads();
+    for (u32 li = blockIdx.x; li < nchained; li += gridDim.x) {
+        const u32 q = chain_list[li];
+        const u64 begin = (u64)q * cp.cap;
+        u32 rg = q;
+        while (true) {
+            const u32 f = subcnt[rg], nn = f & ~CHAIN_BIT;
+            const u64 rb = (u64)rg * cp.cap;
+            for (u32 i0 = 0; i0 < nn; i0 += CNT_NT) {
+                const bool act = i0 + tid < nn;
+                const u64 kv = keys[rb + (act ? i0 + tid : 0u)];
+                const u64 first = ((u64)__builtin_amdgcn_readfirstlane((u32)(kv >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)kv);
+                const bool same = act && kv == first;
+                const u64 m = __ballot(same);
+                if (same && lane == __ffsll((unsigned long long)m) - 1) table_insert1(tk, tc, lst, &ctr[0], &ctr[2], first, (u32)__popcll(m));
+                if (act && !same) table_insert1(tk, tc, lst, &ctr[0], &ctr[2], kv);
+            }
+            if (!(f >> 31)) break;
+            rg = chain_next[rg];
+        }
+        __syncthreads();
+        const u32 nd = ctr[0];
+        const bool bad = ctr[2] || nd > cp.maxload;            // block-uniform
+        if (bad) {
+            for (int s = tid; s < CNT_SLOTS; s += CNT_NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
+            if (tid == 0) *overflow = 1;
+        } else {
+            for (u32 i0 = 0; i0 < nd; i0 += CNT_NT) {
+                const u32 i = i0 + tid;
+                const bool act = i < nd;
+                u64 key = 0; u32 c = 0;
+                if (act) {
+                    const u32 slot = lst[i];
+                    key = tk[slot]; c = tc[slot];
+                    tk[slot] = DSK_EMPTY; tc[slot] = 0;
+                    atomicAdd(&ghist[c < cp.histo_max ? c : cp.histo_max], 1ull);
+                }
+                const bool solid = act && c >= cp.amin && c <= cp.amax;
+                const u64 ms = __ballot(solid);
+                if (ms) {
+                    u32 base = 0;
+                    if (lane == 0) base = atomicAdd(&ctr[1], (u32)__popcll(ms));
+                    base = __shfl(base, 0);
+                    if (solid) {
+                        const u32 pos = base + __popcll(ms & ((1ull << lane) - 1));
+                        solid_keys[begin + pos] = key;      // (distinct keys <= maxload < cap: the rows fit the home region)
+                        abund[begin + pos] = c;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            nsolid[q] = bad ? 0u : ctr[1];
+            ndist_acc += bad ? 0u : nd;
+            ctr[0] = 0; ctr[1] = 0; ctr[2] = 0;
+        }
+        __syncthreads();
     }
     if (tid == 0 && ndist_acc) atomicAdd(&gstats[0], ndist_acc);
 }

@@ -53,7 +53,8 @@ class _Stats(C.Structure):
         ("n_retries", C.c_uint32),
         ("sort_fallback", C.c_uint64),
         ("n_passes", C.c_uint64),
-        ("reserved", C.c_uint64 * 2),
+        ("n_ext_regions", C.c_uint64),
+        ("n_heavy", C.c_uint64),
     ]
 
 

@@ -103,6 +103,8 @@ public:
         info.add(d, "partition_levels", "%u", s.n_levels);
         info.add(d, "hash_sub_partitions", "%u", s.n_final_bins);
         info.add(d, "overflow_retries", "%u", s.n_retries);
+        info.add(d, "extension_regions", "%llu", (unsigned long long)s.n_ext_regions);
+        info.add(d, "heavy_kmers", "%llu", (unsigned long long)s.n_heavy);
         const char* names[64]; float ms[64];
         int n = dskgpu_stage_times(grp_ ? dskgpu_group_ctx(grp_, 0) : ctx_, names, ms, 64);
         if (n > 0) {

@@ -150,7 +150,9 @@ typedef struct dskgpu_stats {
     uint32_t n_retries;      /* table-overflow retries                   */
     uint64_t sort_fallback;  /* 1 if the row sort needed its full-width fallback */
     uint64_t n_passes;       /* passes over the key space (1 unless the input exceeds a pass) */
-    uint64_t reserved[2];
+    uint64_t n_ext_regions;  /* extension regions taken by sub-partitions that outgrew their home region (repeat-rich
+                                inputs: heavy k-mers stay on the histogram-free path; 0 on repeat-free reads)   */
+    uint64_t n_heavy;        /* k-mers counted apart from the partitions (found heavy in the sample pass)       */
 } dskgpu_stats;
 int dskgpu_get_stats(const dskgpu_ctx* ctx, dskgpu_stats* out);
 

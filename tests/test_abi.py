@@ -53,7 +53,7 @@ def test_bad_config_rejected():
     from dsk_amd import engine
     if not os.path.exists(engine.library_path()):
         pytest.skip("library not built")
-    for kw in (dict(kmer_size=0), dict(kmer_size=65), dict(world_size=3), dict(world_size=2, rank=2)):
+    for kw in (dict(kmer_size=0), dict(kmer_size=129), dict(world_size=3), dict(world_size=2, rank=2)):      # (k = 1..128 is valid: four-word keys)
         with pytest.raises(engine.DskGpuError):
             engine.KmerCounter(**kw)
 

@@ -280,6 +280,59 @@ def test_histogram_free_scatters_and_their_fallback(oracle, dev, monkeypatch):
     assert "hist2" in stages and st["n_retries"] == 0
 
 
+def _reads_with_planted_kmers(rng, n_reads, rl, k, planted):
+    """Error-free reads of a random genome (20x) with `planted` = [(copies, seed)] fixed k-mers written over a random
+    window of `copies` distinct reads each: k-mers with that many occurrences, spread evenly over the stream."""
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=max(rl + 1, n_reads * rl // 20))      # 20x coverage
+    reads = genome[rng.integers(0, len(genome) - rl, size=n_reads)[:, None] + np.arange(rl)[None, :]]
+    free = rng.permutation(n_reads)
+    at = 0
+    for copies, seed in planted:
+        kmer = np.random.default_rng(seed).choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=k)
+        rows = free[at: at + copies]; at += copies
+        pos = rng.integers(0, rl - k + 1, size=copies)
+        reads[rows[:, None], pos[:, None] + np.arange(k)[None, :]] = kmer[None, :]
+    return np.concatenate([reads, np.full((n_reads, 1), ord("\n"), np.uint8)], axis=1).reshape(-1)
+
+
+def test_region_chains_keep_heavy_kmers_on_the_histogram_free_path(oracle, dev, monkeypatch):
+    """k-mers with thousands of occurrences outgrow the fixed-capacity region of their sub-partition (4360 keys, mean fill
+    2900).  The level-2 scatter then chains extension regions to it and the count kernel walks the chain: no retry, no
+    histogram pass, rows and histogram equal the oracle's.  With the pool switched off (DSKGPU_MAX_EXT=0) the same input
+    takes the exact path after one retry -- the behaviour before the chains."""
+    from dsk_amd import KmerCounter
+    rng = np.random.default_rng(42)
+    stream = _reads_with_planted_kmers(rng, 50_000, 150, 31, [(200, 1), (1500, 2), (2500, 3), (5000, 4), (9000, 5), (14000, 6)])
+    ref = oracle.count(stream, 31)
+    t = torch.from_numpy(stream).to(dev)
+
+    def run():
+        with KmerCounter(kmer_size=31, abundance_min=2, timing=True) as kc:
+            kc.set_reads_device(t.data_ptr(), t.numel())
+            kc.count()
+            rows, ab = kc.rows()
+            return rows, ab, kc.histogram(), kc.stats(), dict(kc.stage_times())
+
+    def check(rows, ab, hist, st):
+        keep = ref.ab >= 2
+        assert st["n_levels"] == 2 and st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct
+        assert (rows[:, 0] == ref.lo[keep]).all() and (ab == ref.ab[keep]).all() and (hist == ref.histogram(10000)).all()
+
+    assert ref.ab.max() >= 14000
+    rows, ab, hist, st, stages = run()
+    check(rows, ab, hist, st)
+    assert st["n_retries"] == 0 and "hist1" not in stages and "hist2" not in stages
+    assert st["n_ext_regions"] >= 2 + 3 + 1                 # 14000, 9000 and 5000 occurrences need at least 3, 2 and 1 regions more
+    monkeypatch.setenv("DSKGPU_MAX_EXT", "2")              # a pool that runs dry: the exact path takes over
+    rows, ab, hist, st, stages = run()
+    check(rows, ab, hist, st)
+    assert st["n_retries"] == 1 and "hist2" in stages
+    monkeypatch.setenv("DSKGPU_MAX_EXT", "0")
+    rows, ab, hist, st, stages = run()
+    check(rows, ab, hist, st)
+    assert st["n_retries"] == 1 and "hist2" in stages and st["n_ext_regions"] == 0
+
+
 def test_mostly_invalid_stream_with_a_dense_tail(oracle, dev):
     """The level-1 slices are sized from the MEAN number of valid k-mers per block.  A stream that is mostly N with one
     block's chunks dense in a single repeated k-mer overflows that block's slice of one bin by far: the kernels must
@@ -545,6 +598,43 @@ def test_full_size_eight_ranks_on_one_device(dev, k):
     kk = np.concatenate([p[0] for p in parts]); aa = np.concatenate([p[1] for p in parts])
     order = np.argsort(kk[:, 0], kind="stable") if k <= 32 else np.lexsort((kk[:, 0], kk[:, 1]))
     assert (kk[order] == k1).all() and (aa[order] == a1).all()
+
+
+@pytest.mark.parametrize("k,explicit", [(31, False), (31, True), (63, False), (27, True)])
+def test_multi_pass_on_the_receive_side(oracle, dev, k, explicit):
+    """Several passes over the key space with the keys coming from an ARRAY or from super-k-mer RECORDS (multi-GPU receive side
+    with max_pass_mkeys forcing npass > 1): level 1 is then the aligned scatter with the pass filter (k_scatter_al, MODE 3), where
+    every tile has the keys of the other passes as masked slots (their ranks once accumulated over the tiles of a chunk)."""
+    from dsk_amd import KmerCounter, synth
+    world = 2
+    reads = synth.make_reads(synth.make_genome(300_000, dev), 60_000, 150).cpu().numpy()
+    recs = bytes(reads).split(b"\n")
+    ctxs, sends, counts, shards = [], [], [], []
+    for r in range(world):
+        shard = torch.from_numpy(np.frombuffer(b"\n".join(recs[r::world]) + b"\n", dtype=np.uint8).copy()).to(dev)
+        kc = KmerCounter(kmer_size=k, abundance_min=2, world_size=world, rank=r, mg_explicit=explicit, max_pass_mkeys=1)
+        kc.set_reads_device(shard.data_ptr(), shard.numel())
+        send = torch.zeros(kc.mg_send_capacity_words(), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        counts.append(kc.mg_scatter(send.data_ptr(), send.numel()))
+        ctxs.append(kc); sends.append(send); shards.append(shard)
+    rows_k, rows_a, hist = [], [], np.zeros(10001, np.uint64)
+    for d in range(world):
+        recv = torch.cat([sends[src][sum(counts[src][:d]): sum(counts[src][:d]) + counts[src][d]] for src in range(world)])
+        torch.cuda.synchronize()
+        ctxs[d].mg_count(recv.data_ptr(), recv.numel())
+        assert ctxs[d].stats()["n_passes"] >= 2
+        kk, aa = ctxs[d].rows()
+        rows_k.append(kk); rows_a.append(aa); hist += ctxs[d].histogram()
+    kk = np.concatenate(rows_k); aa = np.concatenate(rows_a)
+    ref = oracle.count(reads, k)
+    assert (hist == ref.histogram(10000)).all()
+    keep = ref.ab >= 2
+    order = np.argsort(kk[:, 0]) if k <= 32 else np.lexsort((kk[:, 0], kk[:, 1]))
+    assert (kk[order] == ref.words()[keep]).all() and (aa[order] == ref.ab[keep]).all()
+    assert sum(c.stats()["n_kmers"] for c in ctxs) == ref.total
+    for c in ctxs:
+        c.close()
 
 
 @pytest.mark.parametrize("world,k,explicit", [(2, 31, False), (4, 27, False), (2, 63, False), (8, 20, False), (4, 46, False), (2, 64, False),
