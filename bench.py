@@ -277,11 +277,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    gl, nr, rl = synth.workload(args.workload)
     # weak scaling: same per-GPU shard size, genome grows with the node so coverage stays 50x
-    genome = synth.make_genome(gl * world, dev)
-    reads = synth.make_reads(genome, nr, rl, seed=synth.SEED + 1 + rank)
-    del genome
+    reads, gl, nr, rl = synth.make_workload(args.workload, dev, world, rank)
     torch.cuda.synchronize()
     n_bytes = reads.numel()
 
@@ -391,6 +388,7 @@ def main():
             "bases_per_s": tot_bytes / per_step,
             "n_distinct": n_distinct, "n_kmers": n_kmers, "n_solid": n_solid,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "engine_stats": {k: st[k] for k in ("n_passes", "n_retries", "sort_fallback", "n_ext_regions", "n_heavy", "n_final_bins")},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -50,7 +51,7 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_OVF2, SC_OVF1, SC_RSLEN, SC_RSWORK, SC_RSWORK2, SC_RSTIES, SC_EXT, SC_NCHAINED, SC_COUNT = 16 };
+enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_OVF2, SC_OVF1, SC_RSLEN, SC_RSWORK, SC_RSWORK2, SC_RSTIES, SC_EXT, SC_NCHAINED, SC_NCH_S, SC_MLEN_S, SC_WORK2, SC_COUNT = 24 };
 #ifndef SORT_TOP_BITS
 #define SORT_TOP_BITS 32u      // 4 radix passes; 40 bits (5 passes) cost 0.3 ms more on 43 M rows, the in-place run fix-up absorbs the extra ties
 #endif
@@ -76,6 +77,10 @@ struct Tuning {
     u64 sk_slice = 0, sk_minslice = 2000;       // DSKGPU_SK_SLICE, DSKGPU_SK_MINSLICE
     u32 table_maxload = 0;                      // DSKGPU_TABLE_MAXLOAD: distinct keys a count table may hold (forces the finer-partition retry)
     long long max_ext = -1;                     // DSKGPU_MAX_EXT: size of the extension-region pool of the level-2 scatter (tests: 0 = no chains)
+    bool no_sample = false;                     // DSKGPU_NO_SAMPLE: level-1 slices from the mean load instead of the sampled per-bin loads
+    bool no_heavy = false;                      // DSKGPU_NO_HEAVY: no k-mer is counted apart by the level-2 scatter
+    bool verbose = false;                       // DSKGPU_VERBOSE: trace of the plan decisions on stderr
+    bool l2_static = false;                     // DSKGPU_L2_STATIC: segments of the level-2 scatter round-robin over the blocks instead of by work counter
     void read() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         auto num = [](const char* n, u64 dflt) { const char* e = getenv(n); return e ? (u64)atoll(e) : dflt; };
@@ -86,6 +91,7 @@ struct Tuning {
         sk_slice = num("DSKGPU_SK_SLICE", 0); sk_minslice = num("DSKGPU_SK_MINSLICE", 2000);
         table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
         max_ext = getenv("DSKGPU_MAX_EXT") ? atoll(getenv("DSKGPU_MAX_EXT")) : -1;
+        no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); l2_static = on("DSKGPU_L2_STATIC");
         lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0); rs_heavy = (u32)num("DSKGPU_RS_HEAVY", 0);
     }
 };
@@ -108,6 +114,10 @@ struct dskgpu_ctx {
     DevBuf packed, inval;          // K1 output
     DevBuf bufA, bufB;             // partition ping-pong
     DevBuf mat1, mat2, sums, descs1, descs2, seg, fstart, nsolid, scalars, ghist, gstats, chain_next;
+    DevBuf smp_mat, smp_descs, boff;   // sampled level-1 loads: chunk x bin matrix of the sample tiles, their descriptors; per-bin slice offsets
+    DevBuf hv_lut, hv_collect, hv_buf; // heavy k-mers: bin -> collect slot, collected sample keys; [keys | counts | rows] of the k-mers counted apart
+    std::vector<unsigned char> h_hv_lut; std::vector<u32> h_hv_cnt, h_hv_step; std::vector<u64> h_hv_coll, h_hv_keys;
+    std::vector<ChunkDesc> h_descs_s; std::vector<u32> h_boff; std::vector<u64> h_mom; std::vector<double> h_load, h_spread, h_seg_work;
     DevBuf out_w[4], srt_w[4], acc_w[4];   // rows as struct-of-arrays: word i of every row in [i]
     DevBuf out_ab, srt_ab, srt_tmp, srt_idx, srt_idx2, srt_k, srt_k2, abund2, acc_ab;   // srt_k2: one record per row for the multi-word gather
     u64 max_keys_per_pass = 0;     // 0 = as many as 32-bit offsets allow
@@ -243,7 +253,7 @@ int allow_big_lds(dskgpu_ctx* ctx, const void* fn) {
     return DSKGPU_OK;
 }
 
-size_t scatter_lds(int W, u32 P) { return (size_t)SC_NT * (16 / W) * 8 * W + (size_t)P * 16 + 4 + 17 * 4 + 16; }
+size_t scatter_lds(int W, u32 P, bool opt = false) { return (size_t)SC_NT * (16 / W) * 8 * W + (size_t)P * (opt ? 20 : 16) + 4 + 17 * 4 + 16; }   // opt: + the slice ends
 
 template <int W, int SRC, int MODE>
 int launch_hist_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
@@ -267,16 +277,16 @@ int launch_hist(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDes
                         : launch_hist_m<W, 1, 1>(ctx, keys, descs, d_nch, max_chunks, matrix, ds, P);
 }
 
-unsigned scatter_grid(const dskgpu_ctx* ctx, int W, u32 P, u64 max_chunks) {
-    const size_t lds = scatter_lds(W, P);
+unsigned scatter_grid(const dskgpu_ctx* ctx, int W, u32 P, u64 max_chunks, bool opt = false) {
+    const size_t lds = scatter_lds(W, P, opt);
     const u64 per_cu = std::max<u64>(1, std::min<u64>(2048 / SC_NT, (160 * 1024) / lds));   // resident blocks per CU
     return (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * per_cu));
 }
 template <int W, int SRC, int MODE, bool OPT = false>
 int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1 = Opt1Spec{0u, 0u, nullptr}) {
-    const size_t lds = scatter_lds(W, P);
-    const unsigned grid = scatter_grid(ctx, W, P, max_chunks);
+                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1 = Opt1Spec{nullptr, 0u, 0u, nullptr, nullptr, 0u, nullptr}) {
+    const size_t lds = scatter_lds(W, P, OPT);
+    const unsigned grid = scatter_grid(ctx, W, P, max_chunks, OPT);
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, SRC, MODE, OPT>)); if (e) return e; }
     hipLaunchKernelGGL((k_scatter<W, SRC, MODE, OPT>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->packed.as<u64>(),
                        ctx->inval.as<u32>(), keys, descs, d_nch, scanned, out, (int)ctx->cfg.kmer_size, ds, P, o1);
@@ -286,8 +296,8 @@ int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chu
 // super-k-mer records as the source of the histogram-free level-1 scatter (one- and two-word keys)
 template <int W>
 int launch_scatter_rec(dskgpu_ctx* ctx, const ChunkDesc* descs, const u32* d_nch, u64 max_chunks, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1) {
-    const size_t lds = scatter_lds(W, P);
-    const unsigned grid = scatter_grid(ctx, W, P, max_chunks);
+    const size_t lds = scatter_lds(W, P, true);
+    const unsigned grid = scatter_grid(ctx, W, P, max_chunks, true);
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, 2, 1, true>)); if (e) return e; }
     hipLaunchKernelGGL((k_scatter<W, 2, 1, true>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->rec_src, (const u32*)nullptr,
                        (const typename KeyT<W>::T*)nullptr, descs, d_nch, (const u32*)nullptr, out, (int)ctx->cfg.kmer_size, ds, P, o1);
@@ -297,13 +307,13 @@ int launch_scatter_rec(dskgpu_ctx* ctx, const ChunkDesc* descs, const u32* d_nch
 template <> int launch_scatter_rec<4>(dskgpu_ctx*, const ChunkDesc*, const u32*, u64, KN<4>*, DigitSpec, u32, Opt1Spec) { return DSKGPU_E_STATE; }
 
 // key-array source with aligned write-out (k_scatter_al) when its LDS footprint fits one CU
-template <int W, int MODE, bool OPT = false, bool SLICED = false>
+template <int W, int MODE, bool OPT = false, bool SLICED = false, bool HEAVY = false>
 int launch_scatter_al(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                      u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, OptSpec os = OptSpec{0u, nullptr, nullptr, nullptr, 0u, 0u, 0ull, 0u, 0u, nullptr, nullptr, nullptr, nullptr}) {
+                      u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, OptSpec os = OptSpec{0u, nullptr, nullptr, nullptr, 0u, 0u, 0ull, 0u, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
     const size_t lds = ascatter_lds(W, P);
     const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu));
-    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter_al<W, MODE, OPT, SLICED>)); if (e) return e; }
-    hipLaunchKernelGGL((k_scatter_al<W, MODE, OPT, SLICED>), dim3(grid), dim3(SC_NT), lds, ctx->stream, keys, descs, d_nch, scanned, out, ds, P, os);
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter_al<W, MODE, OPT, SLICED, HEAVY>)); if (e) return e; }
+    hipLaunchKernelGGL((k_scatter_al<W, MODE, OPT, SLICED, HEAVY>), dim3(grid), dim3(SC_NT), lds, ctx->stream, keys, descs, d_nch, scanned, out, ds, P, os);
     CKL("k_scatter_al");
     return DSKGPU_OK;
 }
@@ -645,6 +655,96 @@ int expand_records(dskgpu_ctx* ctx, u64 total) {
 }
 template <> int expand_records<4>(dskgpu_ctx*, u64) { return DSKGPU_E_STATE; }      // records carry k <= 64 only
 
+// Heavy k-mers of a pass (one-word keys): level-1 bins whose sampled load stands 20 % above the median hold a k-mer that alone is a
+// large share of a bin.  k_collect_heavy gathers up to HV_COLLECT sampled keys of up to HV_SLOTS such bins; a k-mer that makes up
+// >= 5 % of a bin's collected keys is heavy: the (at most HV_PER_SEG per bin) heavy keys go to hv_buf = [keys | counts | rows],
+// where the level-2 scatter counts them.  ctx->h_load is reduced by what they take away (the order of the level-2 segments).
+int find_heavy(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u32 nts, const Plan& pl, u32* nheavy_out) {
+    *nheavy_out = 0;
+    const u32 P1 = pl.P1;
+    std::vector<double> sorted(ctx->h_load);
+    std::nth_element(sorted.begin(), sorted.begin() + P1 / 2, sorted.end());
+    const double median = sorted[P1 / 2];
+    std::vector<u32> flagged;
+    for (u32 b = 0; b < P1; ++b) if (ctx->h_load[b] > 1.2 * median + 4096.0) flagged.push_back(b);
+    if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] find_heavy: median load %.0f, %zu bins above 1.2 x\n", median, flagged.size());
+    if (flagged.empty()) return DSKGPU_OK;
+    std::sort(flagged.begin(), flagged.end(), [&](u32 a, u32 b) { return ctx->h_load[a] > ctx->h_load[b]; });
+    if (flagged.size() > HV_SLOTS) flagged.resize(HV_SLOTS);
+    ctx->h_hv_lut.assign(P1, 0xFF);
+    for (size_t f = 0; f < flagged.size(); ++f) ctx->h_hv_lut[flagged[f]] = (unsigned char)f;
+    const size_t nf = flagged.size();
+    CK(ctx->hv_lut.ensure(P1));
+    const unsigned grid = (unsigned)std::min<u64>(nts, (u64)ctx->num_cu * 2);
+    const size_t per_slot = (size_t)grid * HV_BLOCK_KEYS;
+    CK(ctx->hv_collect.ensure((size_t)HV_SLOTS * per_slot * 8 + (size_t)HV_SLOTS * grid * 4 + HV_SLOTS * 4));
+    u32* d_kept = reinterpret_cast<u32*>(ctx->hv_collect.as<u64>() + (size_t)HV_SLOTS * per_slot);
+    u32* d_step = d_kept + (size_t)HV_SLOTS * grid;
+    // keep every step-th sampled key of a bin, so that about HV_COLLECT are collected (h_mom: the bin's keys in the sample)
+    ctx->h_hv_step.assign(HV_SLOTS, 1);
+    for (size_t f = 0; f < flagged.size(); ++f) ctx->h_hv_step[f] = (u32)std::max<u64>(1, ctx->h_mom[2 * (size_t)flagged[f]] / HV_COLLECT);
+    CK(hipMemcpyAsync(ctx->hv_lut.p, ctx->h_hv_lut.data(), P1, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemcpyAsync(d_step, ctx->h_hv_step.data(), HV_SLOTS * 4, hipMemcpyHostToDevice, ctx->stream));
+    u32* sc = ctx->scalars.as<u32>();
+    const bool mp = pl.d1.npass > 1;
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SC_NT), 0, ctx->stream, (const u64*)ctx->packed.as<u64>(), (const u32*)ctx->inval.as<u32>(), d_keys_in,
+                           (const ChunkDesc*)ctx->smp_descs.as<ChunkDesc>(), (const u32*)(sc + SC_NCH_S), (int)ctx->cfg.kmer_size, pl.d1, P1,
+                           (const unsigned char*)ctx->hv_lut.as<unsigned char>(), d_kept, ctx->hv_collect.as<u64>(), (const u32*)d_step);
+    };
+    if (from_reads) { if (mp) launch(k_collect_heavy<0, 3>); else launch(k_collect_heavy<0, 1>); }
+    else { if (mp) launch(k_collect_heavy<1, 3>); else launch(k_collect_heavy<1, 1>); }
+    CKL("k_collect_heavy");
+    ctx->h_hv_cnt.resize(nf * grid);
+    ctx->h_hv_coll.resize(nf * per_slot);
+    CK(hipMemcpyAsync(ctx->h_hv_cnt.data(), d_kept, nf * grid * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(ctx->h_hv_coll.data(), ctx->hv_collect.p, nf * per_slot * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->h_hv_keys.assign((size_t)P1 * HV_PER_SEG, DSK_EMPTY);
+    u32 nheavy = 0;
+    for (size_t f = 0; f < nf; ++f) {
+        u64* kk = ctx->h_hv_coll.data() + f * per_slot;       // the blocks' kept keys, made dense in place
+        u32 n = 0;
+        for (unsigned g = 0; g < grid; ++g) {
+            const u32 c = std::min<u32>(ctx->h_hv_cnt[f * grid + g], HV_BLOCK_KEYS);
+            for (u32 i = 0; i < c; ++i) kk[n++] = kk[(size_t)g * HV_BLOCK_KEYS + i];
+        }
+        if (n < 256) continue;
+        std::sort(kk, kk + n);
+        std::vector<std::pair<u32, u64>> runs;               // (length, key) of the runs of >= 5 % of the collected keys
+        for (u32 i = 0; i < n;) {
+            u32 j = i + 1;
+            while (j < n && kk[j] == kk[i]) ++j;
+            if ((u64)(j - i) * 20 >= n) runs.push_back({j - i, kk[i]});
+            i = j;
+        }
+        std::sort(runs.begin(), runs.end(), [](const std::pair<u32, u64>& a, const std::pair<u32, u64>& b) { return a.first > b.first; });
+        if (ctx->tune.verbose) {
+            u32 best = 0; u64 bk = 0;
+            for (u32 i = 0; i < n;) { u32 j = i + 1; while (j < n && kk[j] == kk[i]) ++j; if (j - i > best) { best = j - i; bk = kk[i]; } i = j; }
+            fprintf(stderr, "[dskgpu]   longest run %u of %u (key %016llx), first keys %016llx %016llx %016llx\n", best, n, (unsigned long long)bk,
+                    (unsigned long long)kk[0], (unsigned long long)kk[1], (unsigned long long)kk[n - 1]);
+        }
+        const u32 bin = flagged[f];
+        if (ctx->tune.verbose) fprintf(stderr, "[dskgpu]   bin %u load %.0f: %u keys collected, %zu dominant\n", bin, ctx->h_load[bin], n, runs.size());
+        double taken = 0.0;
+        for (size_t x = 0; x < runs.size() && x < HV_PER_SEG; ++x) {
+            ctx->h_hv_keys[(size_t)bin * HV_PER_SEG + x] = runs[x].second;
+            taken += ctx->h_load[bin] * (double)runs[x].first / (double)n;
+            ++nheavy;
+        }
+        ctx->h_seg_work[bin] -= taken * 0.5;                  // (a key counted apart still is read and compared: about half the work of a partitioned one)
+    }
+    if (nheavy) {
+        const size_t slots = (size_t)P1 * HV_PER_SEG;
+        CK(ctx->hv_buf.ensure(slots * (8 + 8 + 8 + 4)));
+        CK(hipMemcpyAsync(ctx->hv_buf.p, ctx->h_hv_keys.data(), slots * 8, hipMemcpyHostToDevice, ctx->stream));
+        CK(hipMemsetAsync(ctx->hv_buf.as<u64>() + slots, 0, slots * 8, ctx->stream));
+    }
+    *nheavy_out = nheavy;
+    return DSKGPU_OK;
+}
+
 // One pass: partition + count the keys of pass `pass` (of `npass`) and leave its solid rows
 // (unsorted) in out_w[0]/out_w[1]/out_ab.  Returns PASS_TOO_BIG when the pass holds more keys than `cap`.
 #define PASS_TOO_BIG 1000
@@ -705,24 +805,104 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         }
         bool opt1 = opt_cap && !ctx->opt1_off && !ctx->tune.no_opt1 && (npass == 1 || from_reads);   // several passes: reads only (MODE 3)
         if (from_rec && (!opt1 || W > 2 || ctx->tune.no_recsrc)) { int e = records_to_keys(); if (e) return e; }
-        Opt1Spec o1{0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2};
+        Opt1Spec o1{nullptr, 0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2};
         unsigned grid1 = 0;
+        u32 nheavy = 0;                  // k-mers the level-2 scatter counts apart (find_heavy)
+        if (opt1 && scatter_lds(W, pl.P1, true) > 160 * 1024) opt1 = false;       // (the slice ends need 4 more bytes of LDS per bin)
         if (opt1 && !from_reads) ctx->h_nvalid = nkeys_in;
         if (opt1) {
-            grid1 = scatter_grid(ctx, W, pl.P1, nch1);
-            const u64 cells = (u64)pl.P1 * grid1;
+            grid1 = scatter_grid(ctx, W, pl.P1, nch1, true);
             // a block's share of the input: it walks chunks blockIdx, blockIdx + grid, .. (equal chunks, the busiest block has ceil(nch/grid))
             const u64 cpb = (nch1 + grid1 - 1) / grid1;
-            u64 slice = ctx->h_nvalid / npass * cpb / ((u64)nch1 * pl.P1) + 1; slice += slice * 3 / 50 + 160; slice = (slice + 7) & ~7ull;   // mean + 6 % + 160
-            if (ctx->tune.opt_slice) slice = ctx->tune.opt_slice;                                            // experiments / tests
-            const u64 tail = 2 * Tile<W>::KEYS;                         // the dump zone behind the last bin (a tile's keys of a bin that outgrew its slice land there)
-            if (slice < 8 || cells * slice + tail >= 0xFFFF0000ull) opt1 = false;
+            const double share = (double)cpb / (double)nch1;
+            // ---- level-1 loads of this pass, per bin ("PartiInfo" before the spill): a positional sample -- the level-1 digit
+            // histogram of <= 1024 tiles spread over the source -- scaled to the pass.  Every bin's slices are sized from ITS load,
+            // so a bin that holds a repeat family (or poly-A) gets longer slices instead of overflowing the mean-sized ones.
+            // Records (multi-GPU receive side) have no histogram kernel: uniform loads.
+            const double pass_keys = (double)(ctx->h_nvalid / npass);
+            std::vector<double>& load = ctx->h_load;
+            load.assign(pl.P1, pass_keys / pl.P1);
+            ctx->h_seg_work = load;
+            std::vector<double>& spread = ctx->h_spread;
+            spread.assign(pl.P1, 0.0);
+            bool sampled = false;
+            if (!from_rec && !ctx->tune.no_sample) {
+                const u64 units = from_reads ? nwords : nkeys_in, tile = from_reads ? Tile<W>::WORDS : Tile<W>::KEYS;
+                const u64 ntiles = std::max<u64>(1, (units + tile - 1) / tile);
+                const u64 nts = std::min<u64>(ntiles, 1024);
+                ctx->h_descs_s.resize(nts);
+                for (u64 i = 0; i < nts; ++i) {
+                    const u64 t = i * ntiles / nts;
+                    ChunkDesc d; d.begin = t * tile; d.end = std::min<u64>(units, (t + 1) * tile); d.flat_base = (u32)i; d.stride = (u32)nts;
+                    ctx->h_descs_s[i] = d;
+                }
+                const u64 Ms = (u64)pl.P1 * nts;
+                CK(ctx->smp_descs.ensure(nts * sizeof(ChunkDesc)));
+                CK(ctx->smp_mat.ensure((Ms + 1) * 4 + (size_t)pl.P1 * 16));
+                CK(hipMemcpyAsync(ctx->smp_descs.p, ctx->h_descs_s.data(), nts * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
+                ctx->h_sc[SC_NCH_S] = (u32)nts;
+                CK(hipMemcpyAsync(sc + SC_NCH_S, &ctx->h_sc[SC_NCH_S], 4, hipMemcpyHostToDevice, ctx->stream));
+                int e;
+                if (from_reads) e = launch_hist<W, 0>(ctx, nullptr, ctx->smp_descs.as<ChunkDesc>(), sc + SC_NCH_S, nts, ctx->smp_mat.as<u32>(), pl.d1, pl.P1);
+                else e = launch_hist<W, 1>(ctx, d_keys_in, ctx->smp_descs.as<ChunkDesc>(), sc + SC_NCH_S, nts, ctx->smp_mat.as<u32>(), pl.d1, pl.P1);
+                if (e) return e;
+                u64* mom = reinterpret_cast<u64*>(ctx->smp_mat.as<u32>() + ((Ms + 2) & ~(u64)1));
+                hipLaunchKernelGGL(k_bin_moments, dim3((pl.P1 + 3) / 4), dim3(256), 0, ctx->stream, (const u32*)ctx->smp_mat.as<u32>(), (u32)nts, pl.P1, mom);
+                CKL("k_bin_moments");
+                ctx->h_mom.resize((size_t)pl.P1 * 2);
+                CK(hipMemcpyAsync(ctx->h_mom.data(), mom, (size_t)pl.P1 * 16, hipMemcpyDeviceToHost, ctx->stream));
+                CK(hipStreamSynchronize(ctx->stream));
+                u64 stot = 0;
+                for (u32 b = 0; b < pl.P1; ++b) stot += ctx->h_mom[2 * b];
+                if (stot >= (u64)pl.P1 * 64) {        // enough sampled keys to say something per bin
+                    // one pass from the reads: scaled so that the loads add up to the exact number of valid k-mers; otherwise by position
+                    const double scale = (from_reads && npass > 1) ? (double)ntiles / (double)nts : pass_keys / (double)stot;
+                    // tiles a block walks (the busiest one), and how far a bin's keys on those tiles may be from share * load:
+                    //   the block's own spread: 5 sigma of the sum over its tiles of the per-tile count (variance measured on the sample),
+                    //   the estimate's error  : 4 sigma of the sampled sum, scaled to the block's share
+                    const double tiles_per_block = (double)ntiles * share;
+                    for (u32 b = 0; b < pl.P1; ++b) {
+                        const double sum = (double)ctx->h_mom[2 * b], sq = (double)ctx->h_mom[2 * b + 1];
+                        const double mean = sum / (double)nts, var = std::max(mean, sq / (double)nts - mean * mean);      // (at least Poisson)
+                        load[b] = sum * scale;
+                        spread[b] = 5.0 * std::sqrt(tiles_per_block * var) + 4.0 * std::sqrt((double)nts * var) * scale * share;
+                    }
+                    ctx->h_seg_work = load;
+                    sampled = true;
+                }
+                // ---- a k-mer that alone is a large share of a level-1 bin (poly-A reads, a satellite: millions of occurrences):
+                // its bin stands far above the others.  Collect sampled keys of those bins, find the dominant k-mer(s) on the host
+                // and let the level-2 scatter count them apart (k_scatter_al<.., HEAVY>) -- everything lighter is what the region
+                // chains are for.
+                if constexpr (W == 1) {
+                    if (sampled && opt_cap && !ctx->tune.no_heavy) { const int e2 = find_heavy(ctx, from_reads, d_keys_in, (u32)nts, pl, &nheavy); if (e2) return e2; }
+                }
+                ctx->mark("sample1");
+            }
+            // slice of bin b = the busiest block's share of its load + the spread above + 1 % + 64 keys; without a sample: + 6 % + 160
+            // (what uniform reads need), in whole groups of 8 keys
+            ctx->h_boff.resize(pl.P1 + 1);
+            u64 area = 0;
+            for (u32 b = 0; b < pl.P1; ++b) {
+                double sl = load[b] * share;
+                sl += sampled ? spread[b] + sl * 0.01 + 64.0 : sl * 0.06 + 160.0;
+                u64 slice = ((u64)sl + 8) & ~7ull;
+                if (ctx->tune.opt_slice) slice = ctx->tune.opt_slice;                                        // experiments / tests
+                ctx->h_boff[b] = (u32)std::min<u64>(area, 0xFFFFFFFFull); area += slice;
+            }
+            ctx->h_boff[pl.P1] = (u32)std::min<u64>(area, 0xFFFFFFFFull);
+            const u64 tail = 2 * Tile<W>::KEYS;                         // the dump zone behind the last slice (a tile's keys of a bin that outgrew its slice land there)
+            const u64 cells = (u64)pl.P1 * grid1;
+            if (area < 8 || area * grid1 + tail >= 0xFFFF0000ull) opt1 = false;
             else {
-                o1.slice = (u32)slice; o1.cap1 = (u32)(slice * grid1);
+                o1.area = (u32)area; o1.dump = (u32)(area * grid1);
+                CK(ctx->boff.ensure(((size_t)pl.P1 + 1) * 4));
+                CK(hipMemcpyAsync(ctx->boff.p, ctx->h_boff.data(), ((size_t)pl.P1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+                o1.boff = ctx->boff.as<u32>();
                 CK(ctx->mat1.ensure((cells + 1) * 4));                      // here: keys per (bin, block) slice
                 o1.fill = ctx->mat1.as<u32>();
                 if (grid1 + 1 > SLICED_MAX) opt1 = false;                   // the level-2 loader keeps the slice bounds in LDS
-                CK(ctx->bufA.ensure((cells * slice + tail + 1) * sizeof(Key)));
+                CK(ctx->bufA.ensure((area * grid1 + tail + 1) * sizeof(Key)));
             }
         }
         if (from_rec && !opt1) { int e = records_to_keys(); if (e) return e; }
@@ -731,6 +911,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         std::memset(h_sc, 0, sizeof(ctx->h_sc));
         h_sc[SC_NCH1] = nch1; h_sc[SC_MLEN1] = (u32)M1; h_sc[SC_F] = pl.F;
         if (opt1) h_sc[SC_NCH2] = pl.P1;                       // level-2 chunks = the level-1 bin regions
+        h_sc[SC_WORK2] = (u32)std::min<u64>(pl.P1, (u64)ctx->num_cu);   // work counter of the segment-owned level-2 scatter: first segment not taken in the first round
         CK(hipMemcpyAsync(sc, h_sc, sizeof(ctx->h_sc), hipMemcpyHostToDevice, ctx->stream));
         // histogram / distinct counters of THIS pass attempt (a table-overflow retry must not double count)
         CK(hipMemsetAsync(ctx->ghist.p, 0, ((size_t)ctx->cfg.histo_max + 1) * 8, ctx->stream));
@@ -780,9 +961,18 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             CK(hipMemsetAsync(ctx->mat2.p, 0, ((size_t)nregions + 1) * 4, ctx->stream));
             if (opt1) {      // segments = the level-1 bin regions (slices + sentinel tails)
                 ctx->h_descs2.resize(pl.P1);
-                for (u32 sgm = 0; sgm < pl.P1; ++sgm) {
-                    ChunkDesc d; d.begin = (u64)sgm * o1.slice; d.end = d.begin + o1.slice; d.flat_base = sgm * pl.P2; d.stride = 1;   // slice i of the segment: + i * P1 * slice
-                    ctx->h_descs2[sgm] = d;
+                // heaviest segments first (the kernel hands them out by a work counter): a segment that holds a repeat family takes a
+                // block longer than the others, so it must not be the last thing a block starts
+                std::vector<u32> order(pl.P1);
+                for (u32 sgm = 0; sgm < pl.P1; ++sgm) order[sgm] = sgm;
+                // (in steps of 5 % of the mean, stable: the segments of uniform reads keep their natural order, neighbours in memory run together)
+                double mean_work = 0.0; for (double w : ctx->h_seg_work) mean_work += w; mean_work = std::max(1.0, mean_work / pl.P1);
+                auto wclass = [&](u32 a) { return (long long)(ctx->h_seg_work[a] / (0.05 * mean_work)); };
+                std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return wclass(a) > wclass(b); });
+                for (u32 i = 0; i < pl.P1; ++i) {
+                    const u32 sgm = order[i];
+                    ChunkDesc d; d.begin = ctx->h_boff[sgm]; d.end = ctx->h_boff[sgm + 1]; d.flat_base = sgm * pl.P2; d.stride = 1;   // slice i of the segment: + i * area
+                    ctx->h_descs2[i] = d;
                 }
                 CK(hipMemcpyAsync(ctx->descs2.p, ctx->h_descs2.data(), (size_t)pl.P1 * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
             } else {
@@ -791,9 +981,16 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 CKL("k_plan");
             }
             ctx->mark("plan2");
-            OptSpec os{opt_cap, ctx->mat2.as<u32>(), sc + SC_OVF2, opt1 ? o1.fill : nullptr, o1.slice, grid1, (u64)pl.P1 * o1.slice,
-                       pl.F, max_ext, ctx->chain_next.as<u32>(), sc + SC_EXT, ctx->chain_next.as<u32>() + nregions + 1, sc + SC_NCHAINED};
-            if (opt1) rc = launch_scatter_al<W, 2, true, true>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
+            OptSpec os{opt_cap, ctx->mat2.as<u32>(), sc + SC_OVF2, opt1 ? o1.fill : nullptr, 0u, grid1, (u64)o1.area,
+                       pl.F, max_ext, ctx->chain_next.as<u32>(), sc + SC_EXT, ctx->chain_next.as<u32>() + nregions + 1, sc + SC_NCHAINED,
+                       nheavy ? ctx->hv_buf.as<u64>() : nullptr, nheavy ? reinterpret_cast<unsigned long long*>(ctx->hv_buf.as<u64>() + (size_t)pl.P1 * HV_PER_SEG) : nullptr,
+                       ctx->tune.l2_static ? nullptr : sc + SC_WORK2};
+            if (opt1 && nheavy) {
+                if constexpr (W == 1) rc = launch_scatter_al<1, 2, true, true, true>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
+                                                                                       ctx->bufB.as<Key>(), pl.d2, pl.P2, os);
+                else rc = DSKGPU_E_STATE;
+            }
+            else if (opt1) rc = launch_scatter_al<W, 2, true, true>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
                                                                ctx->bufB.as<Key>(), pl.d2, pl.P2, os);
             else rc = launch_scatter_al<W, 2, true, false>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
                                                            ctx->bufB.as<Key>(), pl.d2, pl.P2, os);
@@ -850,6 +1047,13 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 CKL("k_count_chained");
             }
         }
+        if (nheavy) {      // the k-mers the level-2 scatter counted apart: histogram, distinct count, rows (appended behind the compacted ones below)
+            const u32 slots = pl.P1 * HV_PER_SEG;
+            u64* hvb = ctx->hv_buf.as<u64>();
+            hipLaunchKernelGGL(k_heavy_rows, dim3((slots + 255) / 256), dim3(256), 0, ctx->stream, (const u64*)hvb, (const unsigned long long*)(hvb + slots), slots,
+                               cp.amin, cp.amax, cp.histo_max, ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), hvb + 2 * (size_t)slots, reinterpret_cast<u32*>(hvb + 3 * (size_t)slots));
+            CKL("k_heavy_rows");
+        }
         ctx->mark("count");
         if ((rc = run_scan(ctx, ctx->nsolid.as<u32>(), sc + SC_F, pl.F))) return rc;
         ctx->mark("scan_solid");
@@ -882,10 +1086,17 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             continue;
         }
         // ---------------- dense rows of this pass
-        const u64 ns = h_nsolid;
+        const u64 nhs = nheavy ? ctx->h_stats[1] : 0;                    // solid rows of the k-mers counted apart
+        const u64 ns = h_nsolid + nhs;
         CK(ctx->out_ab.ensure((ns + 1) * 4));
         RowsOut ro{};
         for (int x = 0; x < W; ++x) { CK(ctx->out_w[x].ensure((ns + 1) * 8)); ro.w[x] = ctx->out_w[x].as<u64>(); }
+        if (nhs) {
+            const size_t slots = (size_t)pl.P1 * HV_PER_SEG;
+            CK(hipMemcpyAsync(ctx->out_w[0].as<u64>() + h_nsolid, ctx->hv_buf.as<u64>() + 2 * slots, nhs * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            CK(hipMemcpyAsync(ctx->out_ab.as<u32>() + h_nsolid, ctx->hv_buf.as<u64>() + 3 * slots, nhs * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        ctx->stats.n_heavy += nheavy;
         hipLaunchKernelGGL(k_compact<W>, dim3((pl.F + 3) / 4), dim3(256), 0, ctx->stream, (const Key*)solid_keys, (const u32*)solid_ab,
                            ctx->fstart.as<u32>(), ctx->nsolid.as<u32>(), pl.F, ro, ctx->out_ab.as<u32>(), opt_cap);
         CKL("k_compact");
@@ -1378,7 +1589,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->cfg.device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->reads_own, &ctx->packed, &ctx->inval, &ctx->bufA, &ctx->bufB, &ctx->mat1, &ctx->mat2, &ctx->sums,
-                      &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats, &ctx->chain_next,
+                      &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats, &ctx->chain_next, &ctx->smp_mat, &ctx->smp_descs, &ctx->boff, &ctx->hv_lut, &ctx->hv_collect, &ctx->hv_buf,
                       &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
                       &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->srt_k2, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
                       &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,

@@ -325,13 +325,13 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan_apply(u32* __restrict__ a, con
 //   off[b]   = start of bin b inside the staged tile
 //   delta[b] = cur[b] - off[b]   (HBM index of staged element i of bin b is delta[b] + i)
 //   cur[b]  += cnt[b];  cnt[b] = 0
-// slice != 0 (block-owned slices): bin b may only be written inside [b * cap1 + first, + slice); a bin whose keys of this tile
-// would not fit is redirected, for this tile, to the dump zone [dump, dump + tile) behind the last bin (never read) -- the
+// sg.lim (block-owned slices): bin b may only be written below lim[b], the end of the block's slice of that bin; a bin whose keys
+// of this tile would not fit is redirected, for this tile, to the dump zone [dump, dump + tile) behind the last slice (never read) -- the
 // check costs a few instructions per BIN and tile instead of per key, and nothing is ever written outside the block's own
 // slices or the dump zone.  cur[] keeps advancing, so the overflow shows at the end of the launch.
-struct SliceGuard { u32 slice, cap1, first, dump; };
+struct SliceGuard { const u32* lim; u32 dump; };      // lim[b] (LDS): end of the block's slice of bin b; nullptr = no guard
 template <int NT>
-__device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* cur, int P, u32* wsum, u32* tot, SliceGuard sg = SliceGuard{0u, 0u, 0u, 0u}) {
+__device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* cur, int P, u32* wsum, u32* tot, SliceGuard sg = SliceGuard{nullptr, 0u}) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ipt = (P + NT - 1) / NT;
     const int base = tid * ipt;
@@ -358,7 +358,7 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
         const int idx = base + j;
         if (j < ipt && idx < P) {
             const u32 c = cur[idx];
-            const bool fits = sg.slice == 0u || c + v[j] <= (u32)idx * sg.cap1 + sg.first + sg.slice;
+            const bool fits = sg.lim == nullptr || c + v[j] <= sg.lim[idx];
             off[idx] = run; delta[idx] = fits ? c - run : sg.dump; cur[idx] = c + v[j]; cnt[idx] = 0;
             run += v[j];
         }
@@ -366,7 +366,8 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
 }
 
 struct OptSpec { u32 cap; u32* subcnt; u32* ovf; const u32* fill; u32 slice, nsl; u64 sstride;     // fill/slice/nsl/sstride: SLICED input (below)
-                 u32 F, max_ext; u32* next; u32* ext_cursor; u32* chain_list; u32* chain_cnt; };   // region chains (below)
+                 u32 F, max_ext; u32* next; u32* ext_cursor; u32* chain_list; u32* chain_cnt;     // region chains (below)
+                 const u64* hv_keys; unsigned long long* hv_cnt; u32* work; };                                 // HEAVY: [segment][HV_PER_SEG] k-mers counted apart (DSK_EMPTY = none) and their counts
 // Region chains of the segment-owned level-2 scatter.  Regions 0 .. F-1 are the home regions of the sub-partitions, regions
 // F .. F + max_ext - 1 a pool of extension regions of the same size behind them (region r starts at key r * cap of the output
 // buffer).  A sub-partition that outgrows the region it is writing -- a k-mer with thousands of occurrences: every repeat family
@@ -375,6 +376,7 @@ struct OptSpec { u32 cap; u32* subcnt; u32* ovf; const u32* fill; u32 slice, nsl
 // is appended to chain_list (at most max_ext entries: each takes a pool region), and k_count_chained walks those lists.  Only
 // when the pool is used up does *ovf go up (the host then repeats the level with the exact histogram + scan path).
 #define CHAIN_BIT 0x80000000u
+#define HV_PER_SEG 2               // heavy k-mers a level-2 segment can count apart
 __device__ __forceinline__ bool is_empty_key(u64 h) { return h == DSK_EMPTY; }
 template <int W> __device__ __forceinline__ bool is_empty_key(const KN<W>& h) {
     bool e = true;
@@ -463,14 +465,16 @@ __device__ __forceinline__ u32 tile_keys_records(const u64* __restrict__ rec, u3
     return vm;
 }
 
-// OPT (level 1): "block-owned slices" -- no histogram pass.  Every (block, bin) pair owns one slice of `slice` keys of
-// `out`, block-major: the slice of bin b of block g starts at (g * P + b) * slice, so the P write fronts of a block lie
-// within P * slice keys (44 MB on the bench workload).  A block appends its keys of bin b to its own slice, the write cursors
-// live in LDS for the whole launch.  The slices are sized from the exact number of valid k-mers (k_count_valid) plus 6 % + 160
-// keys; how much of each slice holds keys goes to fill[b*grid + block], and the level-2 scatter (SLICED) gathers the grid
-// slices of its bin (stride P * slice) and reads exactly that much of each.  A slice that would overflow raises *ovf (the host
-// repeats the pass with the exact histogram + scan path).  cap1 = grid * slice (P * cap1 = end of all slices = dump zone).
-struct Opt1Spec { u32 slice, cap1; u32* ovf; u32* fill; u32 R; u64* nkeys; };      // R: words per super-k-mer record (SRC 2)
+// OPT (level 1): "block-owned slices" -- no histogram pass.  Every (block, bin) pair owns one slice of `out`, block-major: the
+// slice of bin b of block g is [g * area + boff[b], g * area + boff[b + 1]), so the P write fronts of a block lie within `area`
+// keys (44 MB on the bench workload).  A block appends its keys of bin b to its own slice, the write cursors live in LDS for the
+// whole launch.  The slices are sized per bin from a positional sample of the level-1 loads scaled to the exact number of valid
+// k-mers (k_count_valid), plus 6 % + 160 keys; how much of each slice holds keys goes to fill[b*grid + block], and the level-2
+// scatter (SLICED) gathers the grid slices of its bin (stride `area`) and reads exactly that much of each.  A slice that would
+// overflow raises *ovf (the host repeats the pass with the exact histogram + scan path).  dump = grid * area = the dump zone.
+// boff[b] .. boff[b + 1]: the slice of bin b inside a block's area (P + 1 offsets, sized per bin from the sampled level-1 loads:
+// a bin that holds a repeat family simply gets longer slices); area = boff[P] keys per block; dump = grid * area.
+struct Opt1Spec { const u32* boff; u32 area, dump; u32* ovf; u32* fill; u32 R; u64* nkeys; };      // R: words per super-k-mer record (SRC 2)
 
 template <int W, int SRC, int MODE, bool OPT = false>
 __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
@@ -488,12 +492,13 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
     u32* delta = cur + P;                                            // P
     u32* wsum = delta + P;                                           // 16 (+1 total)
     u32* tot = wsum + 16;
+    u32* lim = tot + 1;                                              // P (OPT): end of this block's slice of every bin
     const u32 nchunks = *d_nchunks;
-    // OPT: this block's slices are CONTIGUOUS in `out` -- slice of bin b at (blockIdx * P + b) * slice -- so its P write fronts
+    // OPT: this block's slices are CONTIGUOUS in `out` -- slice of bin b at blockIdx * area + boff[b] -- so its P write fronts
     // stay inside a few 2 MB pages (bin-major, the fronts of one block were P regions of grid * slice keys apart: P pages to
     // cycle through on every tile, far more than the CU's translation cache holds)
-    const u32 first = OPT ? blockIdx.x * P * o1.slice : 0u;
-    if (OPT) for (u32 b = threadIdx.x; b < P; b += SC_NT) cur[b] = first + b * o1.slice;
+    const u32 first = OPT ? blockIdx.x * o1.area : 0u;
+    if (OPT) for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] = first + o1.boff[b]; lim[b] = first + o1.boff[b + 1]; }
     for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
         const ChunkDesc d = descs[g];
         lds_barrier();   // previous chunk's write-out reads delta/off/stage
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
 #pragma unroll
             for (int j = 0; j < KPT; ++j) if ((rk[j] >> 16) < P) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
             lds_barrier();
-            tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot, OPT ? SliceGuard{o1.slice, o1.slice, first, P * o1.cap1} : SliceGuard{0u, 0u, 0u, 0u});
+            tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot, OPT ? SliceGuard{lim, o1.dump} : SliceGuard{nullptr, 0u});
             lds_barrier();
 #pragma unroll
             for (int j = 0; j < KPT; ++j) if ((rk[j] >> 16) < P) stage[off[rk[j] >> 16] + (rk[j] & 0xFFFFu)] = h[j];
@@ -543,7 +548,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                     // (OPT: tile_scan keeps a bin that outgrew its slice out of the other slices.)  With slices there is a dump zone
                     // behind the last bin: a lane past the tile's keys stores there instead of being masked off, so that every trip
                     // issues exactly 4 stores -- the compiler can then count them (see rank_and_stage)
-                    if (OPT) out[i < ntile ? (u64)(dd[u] + i) : (u64)(P * o1.cap1 + i)] = hk[u];
+                    if (OPT) out[i < ntile ? (u64)(dd[u] + i) : (u64)(o1.dump + i)] = hk[u];
                     else if (i < ntile) out[(u64)(dd[u] + i)] = hk[u];
                 }
             }
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                 Raw raw = load_raw(d.begin);
                 if (OPT) {          // as many (dump-zone) stores behind the first loads as a tile's write-out issues behind the prefetched ones:
 #pragma unroll                      // the loop is then entered with the same in-flight picture on both edges and the wait at its top is exact
-                    for (int u = 0; u < 4 * ((KPT + 3) / 4); ++u) out[(u64)(P * o1.cap1 + u * SC_NT + threadIdx.x)] = (u64)threadIdx.x;
+                    for (int u = 0; u < 4 * ((KPT + 3) / 4); ++u) out[(u64)(o1.dump + u * SC_NT + threadIdx.x)] = (u64)threadIdx.x;
                 }
                 for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
                     const bool live = t0 + wlane < d.end;
@@ -616,9 +621,9 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
         bool ovf = false;
         u32 mine = 0;
         for (u32 b = threadIdx.x; b < P; b += SC_NT) {
-            const u32 beg = first + b * o1.slice, c = cur[b];
-            if (c > beg + o1.slice) ovf = true;
-            const u32 f = c > beg + o1.slice ? o1.slice : c - beg;
+            const u32 beg = first + o1.boff[b], c = cur[b], end = lim[b];
+            if (c > end) ovf = true;
+            const u32 f = c > end ? end - beg : c - beg;
             o1.fill[(u64)b * gridDim.x + blockIdx.x] = f;
             mine += f;
         }
@@ -701,7 +706,11 @@ __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
 // os.sstride keys apart (slice i at keys + d.begin + i * sstride), of which the first fill[s*nsl + i] hold keys.  The loader walks the slices in order and skips their
 // unused tails: a thread's keys of consecutive tiles are monotone in the logical stream, so it only keeps the bounds
 // of its current slice in registers and touches the LDS prefix array when it crosses into the next slice.
-template <int W, int MODE, bool OPT = false, bool SLICED = false>
+// HEAVY (with OPT): up to HV_PER_SEG k-mers per segment are counted apart instead of being partitioned (os.hv_keys / os.hv_cnt): a
+// k-mer that alone is a large share of a level-1 bin -- poly-A reads: millions of occurrences -- would otherwise put a third of
+// every wave's keys on ONE rank counter and one sub-partition.  Its keys are compared out before the rank phase (masked slots),
+// a segment without such a k-mer skips the comparisons.  A separate instantiation: the plain one keeps its instruction schedule.
+template <int W, int MODE, bool OPT = false, bool SLICED = false, bool HEAVY = false>
 __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>::T* __restrict__ keys,
                                                          const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
                                                          const u32* __restrict__ scanned,
@@ -725,7 +734,12 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
     const u32 gi = tid / G, gl = tid % G;
     const u32 nchunks = *d_nchunks;
     const int ipt = (int)((P + SC_NT - 1) / SC_NT);
-    for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
+    // OPT: the segments are handed out by a work counter, in the order of the descriptors (the host lists the heaviest first): a
+    // segment that holds a repeat family takes its block longer, and the block then simply takes fewer -- a static round-robin left
+    // the block of a poly-A segment 0.7 ms behind the rest.  The first round needs no atomic (block b takes descriptor b).
+    u32 g = blockIdx.x;
+    for (;; ) {
+        if (g >= nchunks) break;
         const ChunkDesc d = descs[g];
         // OPT: positions are relative to the segment's first region (keeps them 32-bit whatever the total)
         Key* out = OPT ? out_all + (u64)d.flat_base * os.cap : out_all;
@@ -754,6 +768,11 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
             lds_barrier();
             lbeg = 0; lend = pre[os.nsl];
             shi = pre[1];
+        }
+        u64 hk[HV_PER_SEG]; u32 hc[HV_PER_SEG]; bool any_heavy = false;
+        if constexpr (HEAVY) {
+#pragma unroll
+            for (int x = 0; x < HV_PER_SEG; ++x) { hk[x] = os.hv_keys[(u64)(d.flat_base / P) * HV_PER_SEG + x]; hc[x] = 0; any_heavy = any_heavy || hk[x] != DSK_EMPTY; }
         }
         Key h[KPT]; u32 vm = 0;       // one register set: the next tile is loaded as soon as the stage writes have consumed this one
         auto load = [&](u64 k0, Key (&hh)[KPT]) -> u32 {
@@ -786,8 +805,25 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                 dj = ((vm & (1u << j)) && !pad && key_in_pass<MODE>(digit_word(h[j]), ds)) ? dj : P;
                 rk[j] = dj << 16;
             }
+            u32 hm = 0;                          // HEAVY: keys of this thread that are counted apart
+            if constexpr (HEAVY && W == 1) {
+                if (any_heavy) {                 // (block-uniform)
 #pragma unroll
-            for (int j = 0; j < KPT; ++j) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
+                    for (int j = 0; j < KPT; ++j) {
+                        const bool live = (rk[j] >> 16) < P;
+#pragma unroll
+                        for (int x = 0; x < HV_PER_SEG; ++x) {
+                            const bool hit = live && h[j] == hk[x];
+                            hc[x] += hit ? 1u : 0u;
+                            if (hit) { rk[j] = P << 16; hm |= 1u << j; }
+                        }
+                    }
+                }
+            }
+            // (a key counted apart is a masked slot WITHOUT a rank: ranked, a third of every wave's lanes would add to the dummy bin's one
+            //  counter; unranked they all stage at the first masked slot, rec[P].z < TKEYS, which nobody reads)
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) if (!HEAVY || !(hm & (1u << j))) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
             lds_barrier();
             // ---- scan of the tile histogram fused with the carry bookkeeping
             if (tid == 0) cnt[P] = 0;     // the dummy bin's ranks are in registers now: its counter starts every tile at 0 (masked slots are
@@ -908,6 +944,23 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
             }
         }
         if (OPT && ovf) *os.ovf = 1u;
+        if constexpr (HEAVY) {
+            if (any_heavy) {
+#pragma unroll
+                for (int x = 0; x < HV_PER_SEG; ++x) {
+                    u32 v = hc[x];
+#pragma unroll
+                    for (int dd = 32; dd >= 1; dd >>= 1) v += __shfl_down(v, dd);
+                    if (lane == 0 && v) atomicAdd(&os.hv_cnt[(u64)(d.flat_base / P) * HV_PER_SEG + x], (unsigned long long)v);
+                }
+            }
+        }
+        if (OPT && os.work) {          // next segment: from the work counter (starts at the grid size)
+            lds_barrier();
+            if (tid == 0) wsum[19] = atomicAdd(os.work, 1u);
+            lds_barrier();
+            g = wsum[19];
+        } else g += gridDim.x;
     }
 }
 
@@ -1160,12 +1213,15 @@ __global__ __launch_bounds__(CNT_NT) void k_count_chained(u64* keys, u64* solid_
     __shared__ u64 tk[CNT_SLOTS];
     __shared__ u32 tc[CNT_SLOTS];
     __shared__ unsigned short lst[CNT_SLOTS];
+    __shared__ u32 lh[CNT_LH];
     __shared__ u32 ctr[4];                      // ndist, out, ovf
     const int tid = threadIdx.x, lane = tid & 63;
     const u32 nchained = *d_nchained < list_cap ? *d_nchained : list_cap;
     if (blockIdx.x >= nchained) return;
     for (int s = tid; s < CNT_SLOTS; s += CNT_NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
+    for (int b = tid; b < CNT_LH; b += CNT_NT) lh[b] = 0;
     if (tid < 4) ctr[tid] = 0;
+    u32 ones = 0;          // lane 0 of each wave: abundance-1 keys seen (flushed at the end)
     u64 ndist_acc = 0;
     __syncthreads();
     for (u32 li = blockIdx.x; li < nchained; li += gridDim.x) {
@@ -1202,7 +1258,13 @@ __global__ __launch_bounds__(CNT_NT) void k_count_chained(u64* keys, u64* solid_
                     const u32 slot = lst[i];
                     key = tk[slot]; c = tc[slot];
                     tk[slot] = DSK_EMPTY; tc[slot] = 0;
-                    atomicAdd(&ghist[c < cp.histo_max ? c : cp.histo_max], 1ull);
+                }
+                const u64 m1 = __ballot(act && c == 1);
+                if (lane == 0) ones += __popcll(m1);
+                if (act && c > 1) {
+                    const u32 bin = c < cp.histo_max ? c : cp.histo_max;
+                    if (bin < CNT_LH) atomicAdd(&lh[bin], 1u);
+                    else atomicAdd(&ghist[bin], 1ull);
                 }
                 const bool solid = act && c >= cp.amin && c <= cp.amax;
                 const u64 ms = __ballot(solid);
@@ -1225,6 +1287,12 @@ __global__ __launch_bounds__(CNT_NT) void k_count_chained(u64* keys, u64* solid_
             ctr[0] = 0; ctr[1] = 0; ctr[2] = 0;
         }
         __syncthreads();
+    }
+    if (lane == 0 && ones) atomicAdd(&lh[1], ones);
+    __syncthreads();
+    for (int b = tid; b < CNT_LH; b += CNT_NT) {
+        const u32 v = lh[b];
+        if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
     }
     if (tid == 0 && ndist_acc) atomicAdd(&gstats[0], ndist_acc);
 }
@@ -1738,6 +1806,92 @@ __global__ __launch_bounds__(256) void k_pick_rows(RowsIn rows, const u32* __res
 __global__ void k_pack_bank(u64* __restrict__ dst, const u32* __restrict__ ab, u64 n, u32 bank) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = ((u64)bank << 32) | ab[i];
+}
+// Sum and sum of squares over the `nch` chunks of every bin of a (bin-major) chunk x bin matrix: one wave per bin.  The level-1
+// loads of a positional sample of tiles: mom[2 b] = keys of bin b in the sample, mom[2 b + 1] = sum of the squared per-tile
+// counts -- the spread tells how clumped a bin's keys arrive (a poly-A read is 120 keys of one bin in a row).
+__global__ __launch_bounds__(256) void k_bin_moments(const u32* __restrict__ matrix, u32 nch, u32 P, u64* __restrict__ mom) {
+    const u32 b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= P) return;
+    u64 s = 0, q = 0;
+    for (u32 c = lane; c < nch; c += 64) { const u64 x = matrix[(u64)b * nch + c]; s += x; q += x * x; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { s += __shfl_down(s, d); q += __shfl_down(q, d); }
+    if (lane == 0) { mom[2 * b] = s; mom[2 * b + 1] = q; }
+}
+// Keys of a few level-1 bins, from the sample tiles: the bins whose sampled load stands far above the others hold a k-mer that
+// alone is a large share of a whole level-1 bin (poly-A reads, a satellite).  lut[d] = slot of bin d (0xFF: not wanted).  Every
+// block keeps every keep_step[slot]-th key of a slot that it meets -- a systematic sample of the arrival sequence, so a key's
+// share of the kept keys is its share of the bin (the FIRST arrivals are not: a thread delivers a poly-A read's keys one by
+// one) -- in its own HV_BLOCK_KEYS entries of out[slot][block][..], arrival numbers from LDS counters (a single global
+// counter per slot took 1 ms: 40 K returning atomics on one address); kept[slot][block] = entries written.  The host then finds
+// the dominant key(s) of every slot (dskgpu.hip: find_heavy) and the level-2 scatter counts them apart (k_scatter_al<.., HEAVY>).
+#define HV_SLOTS 16
+#define HV_COLLECT 2048            // keys aimed at per slot, over all blocks
+#define HV_BLOCK_KEYS 32           // entries of a block per slot
+template <int SRC, int MODE>
+__global__ __launch_bounds__(SC_NT) void k_collect_heavy(const u64* __restrict__ packed, const u32* __restrict__ inval, const u64* __restrict__ keys,
+                                                         const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks, int k, DigitSpec ds, u32 P,
+                                                         const unsigned char* __restrict__ lut, u32* __restrict__ kept, u64* __restrict__ out, const u32* __restrict__ keep_step) {
+    __shared__ unsigned char slut[MAX_BINS + 8];
+    __shared__ u32 lcnt[HV_SLOTS], lstep[HV_SLOTS];
+    const int lane = threadIdx.x & 63;
+    for (u32 b = threadIdx.x; b < P; b += SC_NT) slut[b] = lut[b];
+    // (arrival numbers start at a per-block phase: starting every block at 0 would keep every block's FIRST key -- a quarter of all kept keys)
+    if (threadIdx.x < HV_SLOTS) { const u32 st = keep_step[threadIdx.x]; lstep[threadIdx.x] = st; lcnt[threadIdx.x] = (blockIdx.x * 7919u) % st; }
+    __syncthreads();
+    const u32 nchunks = *d_nchunks;
+    for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
+        const ChunkDesc d = descs[g];
+        const u64 step = SRC == 0 ? Tile<1>::WORDS : Tile<1>::KEYS;
+        for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
+            u64 h[16];
+            const u32 vm = SRC == 0 ? tile_keys_reads(packed, inval, t0, d.end, k, h) : tile_keys_array<1>(keys, t0, d.end, h);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                u32 f = 0xFFu;
+                if ((vm & (1u << j)) && key_in_pass<MODE>(h[j], ds)) f = slut[key_digit<MODE>(h[j], ds)];
+                u64 todo = __ballot(f != 0xFFu);
+                while (todo) {                   // one LDS atomic per wave and slot: the lanes of a slot take consecutive arrival numbers
+                    const int lead = __ffsll((unsigned long long)todo) - 1;
+                    const u32 fl = (u32)__shfl((int)f, lead);
+                    const u64 grp = __ballot(f == fl);
+                    u32 base = 0;
+                    if (lane == lead) base = atomicAdd(&lcnt[fl], (u32)__popcll(grp));
+                    base = (u32)__shfl((int)base, lead);
+                    if (f == fl) {
+                        const u32 idx = base + (u32)__popcll(grp & ((1ull << lane) - 1)), st = lstep[fl];
+                        const u32 p0 = ((blockIdx.x * 7919u) % st + st - 1) / st;        // kept entries "before" the phase
+                        if (idx % st == 0u && idx / st - p0 < HV_BLOCK_KEYS) out[((u64)fl * gridDim.x + blockIdx.x) * HV_BLOCK_KEYS + idx / st - p0] = h[j];
+                    }
+                    todo &= ~grp;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < HV_SLOTS) {
+        const u32 st = lstep[threadIdx.x];
+        const u32 n = (lcnt[threadIdx.x] + st - 1) / st - ((blockIdx.x * 7919u) % st + st - 1) / st;
+        kept[threadIdx.x * gridDim.x + blockIdx.x] = n < HV_BLOCK_KEYS ? n : HV_BLOCK_KEYS;
+    }
+}
+// The k-mers counted apart by the level-2 scatter (HEAVY) join the result here: histogram, distinct count and, when solid, a row
+// (value restored from the mixed key) in rows_k / rows_ab; gstats[1] = rows written.  One thread per slot.
+__global__ void k_heavy_rows(const u64* __restrict__ hv_keys, const unsigned long long* __restrict__ hv_cnt, u32 nslots, u32 amin, u32 amax, u32 histo_max,
+                             u64* __restrict__ ghist, u64* __restrict__ gstats, u64* __restrict__ rows_k, u32* __restrict__ rows_ab) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nslots) return;
+    const u64 key = hv_keys[i];
+    const unsigned long long c64 = hv_cnt[i];
+    if (key == DSK_EMPTY || c64 == 0ull) return;
+    const u32 c = c64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)c64;
+    atomicAdd(&ghist[c < histo_max ? c : histo_max], 1ull);
+    atomicAdd(&gstats[0], 1ull);
+    if (c >= amin && c <= amax) {
+        const u64 at = atomicAdd(&gstats[1], 1ull);
+        rows_k[at] = kunmix(key); rows_ab[at] = c;
+    }
 }
 __global__ void k_copy_u32(u32* __restrict__ dst, const u32* __restrict__ src, u64 n) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -14,9 +14,10 @@
 //      its final slot.  Sub-buckets of 513..4096 rows are listed and done by whole blocks (k_rs_big).
 //
 // Skew: buckets are exact (any distribution of values works); what the kernels do not order themselves -- a first-digit
-// bucket above 16 x the mean (one block would walk it alone), a sub-bucket above 4096 rows, a cell above 64 rows (128 in
-// k_rs_big) -- raises *flag, and the host orders the rows with the full-width library sort instead (stats.sort_fallback):
-// never seen on reads, provoked in tests.
+// bucket above 16 x the mean (one block would walk it alone) or a sub-bucket above 4096 rows -- raises *flag, and the host orders
+// the rows with the full-width library sort instead (stats.sort_fallback): never seen on reads, provoked in tests.  Cells of any
+// size are ordered here: above 64 rows by a block (k_rs_big), there above 16 with a bitonic network over the sub-bucket (the error
+// variants of a poly-A k-mer share 13 and more leading bases).
 #pragma once
 #include "kernels.h"
 
@@ -32,7 +33,7 @@
 #define RS_MAX_ROWS (384ull << 20)        // most rows this sort takes: 1024 x 1024 sub-buckets of ~380 rows on average (the densest twice that)
 #define RS_BLOCK_ROWS 4096                // larger ones: a whole block (k_rs_big); beyond this: flag
 #define RS_WAVE_CELL_CAP 64               // rows sharing all three digits that are still ordered here (wave path / block path)
-#define RS_BLOCK_CELL_CAP 128
+#define RS_BLOCK_CELL_CAP 16              // block path: cells up to here are ordered by one thread each (insertion), a sub-bucket with a larger one by the bitonic network
 
 // digit X of value v = (v >> shX) & mX; A = top 10 significant bits, B and C the next 8 + 8 (fewer for very small k)
 struct RsSpec { int shA, shB, shC; u32 mA, mB, mC; };
@@ -210,7 +211,8 @@ __device__ __forceinline__ bool rs_insertion(u64* rk, u32* ra, u32 o, u32 m) {  
 // step C: one wave per sub-bucket (2 <= nd <= RS_WAVE_ROWS rows at gk / ga, ordered in place).  The rows are placed by the third
 // digit with LDS atomics (rk / ra = the wave's LDS row area, wc = its 256 + 1 cell counters); a row that shares its cell then
 // counts the smaller values of the cell (all rows of the wave at once, one LDS read per step and row) and moves to its final slot.
-__device__ __forceinline__ void rs_wave_sort(u64* gk, u32* ga, u32 nd, u64* rk, u32* ra, u32* wc, int sh, u32 m, u32* flag, u32* ties) {
+// -> false (rows untouched) when a cell holds more than RS_WAVE_CELL_CAP rows: the caller hands the sub-bucket to k_rs_big
+__device__ __forceinline__ bool rs_wave_sort(u64* gk, u32* ga, u32 nd, u64* rk, u32* ra, u32* wc, int sh, u32 m, u32* ties) {
     const u32 lane = threadIdx.x & 63;
     constexpr int RPL = RS_WAVE_ROWS / 64;
     u64 k[RPL]; u32 a[RPL], r[RPL];
@@ -251,7 +253,7 @@ __device__ __forceinline__ void rs_wave_sort(u64* gk, u32* ga, u32 nd, u64* rk, 
         }
     }
     rs_wave_sync();
-    if (cmax > RS_WAVE_CELL_CAP) { *flag = 1u; cmax = 0; }
+    if (__ballot(cmax > RS_WAVE_CELL_CAP)) return false;      // (wave-uniform) k-mers sharing all three digits -- low-complexity sequence: a block orders them
     for (u32 j = 0; __ballot(j < cmax); ++j) {       // (equal keys -- the 63-bit prefixes of multi-word rows can tie -- keep their placement order)
 #pragma unroll
         for (int t = 0; t < RPL; ++t)
@@ -270,6 +272,7 @@ __device__ __forceinline__ void rs_wave_sort(u64* gk, u32* ga, u32 nd, u64* rk, 
         const u32 i = lane + 64 * t;
         if (i < nd) { gk[i] = rk[i]; ga[i] = ra[i]; }
     }
+    return true;
 }
 
 // every sub-bucket of every bucket: wave w of the grid takes sub-bucket w; the large ones go to a list for k_rs_big
@@ -285,8 +288,9 @@ __global__ __launch_bounds__(RS_CNT) void k_rs_cells(u64* kv, u32* av, const u32
     const u32 i = id + id / bb;                                    // sub[] holds bb + 1 starts per bucket
     const u32 o = sub[i], nd = sub[i + 1] - o;
     if (nd < 2) return;
-    if (nd <= RS_WAVE_ROWS) rs_wave_sort(kv + o, av + o, nd, rk[wave], ra[wave], wc[wave], sp.shC, sp.mC, flag, ties);
-    else if (lane == 0) biglist[atomicAdd(nbig, 1u)] = i;
+    bool done = false;
+    if (nd <= RS_WAVE_ROWS) done = rs_wave_sort(kv + o, av + o, nd, rk[wave], ra[wave], wc[wave], sp.shC, sp.mC, ties);
+    if (!done && lane == 0) biglist[atomicAdd(nbig, 1u)] = i;
 }
 
 // sub-buckets of 257 .. block_rows rows, one block each (the same placement by the third digit, block-wide)
@@ -329,9 +333,30 @@ __global__ __launch_bounds__(RS_NT) void k_rs_big(u64* kv, u32* av, const u32* _
             const u32 j = tid + RS_NT * t;
             if (j < nd) { const u32 pos = wc[r[t] >> 16] + (r[t] & 0xFFFFu); rk[pos] = k[t]; ra[pos] = a[t]; }
         }
-        __syncthreads();
-        if (cmine > RS_BLOCK_CELL_CAP) *flag = 1u;
-        else if (cmine >= 2) { if (rs_insertion(rk, ra, omine, cmine)) *ties = 1u; }
+        // cells of a few rows: one thread orders each by insertion.  A cell above RS_BLOCK_CELL_CAP rows (k-mers that share all three
+        // digits: low-complexity sequence, e.g. the error variants of poly-A) would take one thread quadratic time (100 rows: 0.1 ms): then the whole
+        // sub-bucket is ordered by a bitonic network over the LDS area instead (any distribution, <= 4096 rows padded with all-ones
+        // keys, which no value equals: 78 compare-exchange phases)
+        if (__syncthreads_or(cmine > RS_BLOCK_CELL_CAP)) {
+            u32 np2 = 2; while (np2 < nd) np2 <<= 1;
+            for (u32 j = nd + tid; j < np2; j += RS_NT) { rk[j] = ~0ull; ra[j] = 0u; }
+            __syncthreads();
+            for (u32 kk = 2; kk <= np2; kk <<= 1)
+                for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+                    for (u32 x = tid; x < np2; x += RS_NT) {
+                        const u32 y = x ^ jj;
+                        if (y > x) {
+                            const u64 a0 = rk[x], a1 = rk[y];
+                            const bool up = (x & kk) == 0;
+                            if ((a0 > a1) == up) { rk[x] = a1; rk[y] = a0; const u32 t0 = ra[x]; ra[x] = ra[y]; ra[y] = t0; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            bool tie = false;
+            for (u32 j = tid; j + 1 < nd; j += RS_NT) tie = tie || rk[j] == rk[j + 1];
+            if (tie) *ties = 1u;
+        } else if (cmine >= 2) { if (rs_insertion(rk, ra, omine, cmine)) *ties = 1u; }
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 4; ++t) {

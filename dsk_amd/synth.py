@@ -21,9 +21,41 @@ def make_genome(genome_len: int, device, seed: int = SEED) -> torch.Tensor:
     return torch.randint(0, 4, (genome_len,), generator=g, device=device, dtype=torch.uint8)
 
 
+def make_genome_repeats(genome_len: int, device, seed: int = SEED, family_frac: float = 0.01, unit_len: int = 300,
+                        divergence: float = 0.02, tandem_unit: int = 37, tandem_copies: int = 2000, tandem_loci: int = 4) -> torch.Tensor:
+    """A repeat-rich genome (what the uniform one of SURVEY.md section 8(d) lacks, and every real genome has):
+    * a high-copy interspersed family: `family_frac` of the genome is copies of ONE `unit_len`-bp element, every copy with
+      `divergence` substitutions per base, dropped at random positions (an Alu-like family: its k-mers occur in hundreds of copies);
+    * `tandem_loci` tandem arrays of `tandem_copies` x a `tandem_unit`-bp unit (satellite-like: `tandem_unit` distinct k-mers
+      per locus, each `tandem_copies` times in the genome);
+    the rest i.i.d. uniform.  Seeded, runs on `device`."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed ^ 0x5EED)
+    genome = make_genome(genome_len, device, seed)
+    n_copies = int(genome_len * family_frac) // unit_len
+    if n_copies:
+        unit = torch.randint(0, 4, (unit_len,), generator=g, device=device, dtype=torch.uint8)
+        copies = unit.repeat(n_copies, 1)
+        mut = torch.rand((n_copies, unit_len), generator=g, device=device) < divergence
+        delta = torch.randint(1, 4, (n_copies, unit_len), generator=g, device=device, dtype=torch.uint8)
+        copies = torch.where(mut, (copies + delta) & 3, copies)
+        # the copies sit in distinct slots of unit_len bases (no two overlap: the scatter below is deterministic)
+        slots = torch.randperm(genome_len // unit_len, generator=g, device=device)[:n_copies].to(torch.int64).reshape(-1, 1)
+        genome[(slots * unit_len + torch.arange(unit_len, device=device)).reshape(-1)] = copies.reshape(-1)
+    for locus in range(tandem_loci):
+        span = tandem_unit * tandem_copies
+        if span * (tandem_loci + 1) >= genome_len:
+            break
+        unit = torch.randint(0, 4, (tandem_unit,), generator=g, device=device, dtype=torch.uint8)
+        at = (locus + 1) * (genome_len // (tandem_loci + 1))
+        genome[at: at + span] = unit.repeat(tandem_copies)
+    return genome
+
+
 def make_reads(genome: torch.Tensor, n_reads: int, read_len: int = 150, error_rate: float = 0.01,
-               n_rate: float = 0.001, seed: int = SEED + 1, chunk: int = 1 << 20) -> torch.Tensor:
-    """-> uint8 tensor of n_reads * (read_len + 1) bytes on genome.device."""
+               n_rate: float = 0.001, seed: int = SEED + 1, chunk: int = 1 << 20, polya_rate: float = 0.0) -> torch.Tensor:
+    """-> uint8 tensor of n_reads * (read_len + 1) bytes on genome.device.
+    polya_rate: fraction of the reads that are poly-A (before strand flip and errors): ONE k-mer with millions of occurrences."""
     dev = genome.device
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -35,6 +67,9 @@ def make_reads(genome: torch.Tensor, n_reads: int, read_len: int = 150, error_ra
         r = min(chunk, n_reads - r0)
         starts = torch.randint(0, G - read_len + 1, (r, 1), generator=g, device=dev, dtype=torch.int64)
         codes = genome[starts + ar]                                   # r x L
+        if polya_rate > 0.0:
+            pa = torch.rand((r, 1), generator=g, device=dev) < polya_rate
+            codes = torch.where(pa, torch.zeros_like(codes), codes)
         flip = torch.rand((r, 1), generator=g, device=dev) < 0.5
         rc = (3 - codes).flip(1)
         codes = torch.where(flip, rc, codes)
@@ -50,6 +85,29 @@ def make_reads(genome: torch.Tensor, n_reads: int, read_len: int = 150, error_ra
         out[r0:r0 + r, read_len] = 10                                  # '\n'
         del starts, codes, rc, err, delta, ascii_
     return out.view(-1)
+
+
+REPEAT_WORKLOADS = {
+    # name: (plain workload it mirrors, poly-A read fraction)
+    "c2_repeats_10Mx150": ("c2_10Mx150", 0.002),
+    "small_repeats": ("small", 0.002),
+}
+
+
+def make_workload(name: str, device, world: int = 1, rank: int = 0):
+    """The read stream of a named workload on `device` -> (reads, genome_len, n_reads, read_len).  `*_repeats*` workloads use
+    make_genome_repeats and a fraction of poly-A reads; the others are the uniform genome of SURVEY.md section 8(d)."""
+    if name in REPEAT_WORKLOADS:
+        base, polya = REPEAT_WORKLOADS[name]
+        gl, nr, rl = workload(base)
+        genome = make_genome_repeats(gl * world, device)
+        reads = make_reads(genome, nr, rl, seed=SEED + 1 + rank, polya_rate=polya)
+    else:
+        gl, nr, rl = workload(name)
+        genome = make_genome(gl * world, device)
+        reads = make_reads(genome, nr, rl, seed=SEED + 1 + rank)
+    del genome
+    return reads, gl, nr, rl
 
 
 def workload(name: str):

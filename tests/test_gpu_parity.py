@@ -333,10 +333,44 @@ def test_region_chains_keep_heavy_kmers_on_the_histogram_free_path(oracle, dev, 
     assert st["n_retries"] == 1 and "hist2" in stages and st["n_ext_regions"] == 0
 
 
-def test_mostly_invalid_stream_with_a_dense_tail(oracle, dev):
-    """The level-1 slices are sized from the MEAN number of valid k-mers per block.  A stream that is mostly N with one
-    block's chunks dense in a single repeated k-mer overflows that block's slice of one bin by far: the kernels must
-    keep every write inside the block's own slices (the overflow is reported and the exact path takes over)."""
+def test_repeat_rich_reads_stay_on_the_histogram_free_path(oracle, dev, monkeypatch):
+    """A repeat-rich genome (a high-copy family, tandem arrays) plus poly-A reads -- dsk_amd.synth `small_repeats`, the small
+    brother of the bench's `c2_repeats_10Mx150`: k-mers with 10^4 .. 10^5 occurrences.  The level-1 slices are sized per bin
+    from the sampled loads and the level-2 regions chain extensions, so the count needs no retry and no histogram pass; with
+    the sample switched off (slices from the mean load) the same input overflows level 1 and takes the exact path."""
+    from dsk_amd import KmerCounter, synth
+    reads, gl, nr, rl = synth.make_workload("small_repeats", dev)
+    ref = oracle.count(reads.cpu().numpy(), 31)
+    assert ref.ab.max() > 50_000
+
+    def run():
+        with KmerCounter(kmer_size=31, abundance_min=2, timing=True) as kc:
+            kc.set_reads_device(reads.data_ptr(), reads.numel())
+            kc.count()
+            rows, ab = kc.rows()
+            return rows, ab, kc.histogram(), kc.stats(), dict(kc.stage_times())
+
+    def check(rows, ab, hist, st):
+        keep = ref.ab >= 2
+        assert st["n_levels"] == 2 and st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct
+        assert (rows[:, 0] == ref.lo[keep]).all() and (ab == ref.ab[keep]).all() and (hist == ref.histogram(10000)).all()
+
+    rows, ab, hist, st, stages = run()
+    check(rows, ab, hist, st)
+    assert st["n_retries"] == 0 and st["sort_fallback"] == 0 and "hist1" not in stages and "hist2" not in stages
+    assert st["n_ext_regions"] > 0
+    monkeypatch.setenv("DSKGPU_NO_SAMPLE", "1")
+    rows, ab, hist, st, stages = run()
+    check(rows, ab, hist, st)
+    assert st["n_retries"] >= 1 and "hist1" in stages and "hist2" not in stages      # level 1 exact, level 2 still chains
+
+
+def test_mostly_invalid_stream_with_a_dense_tail(oracle, dev, monkeypatch):
+    """A stream that is mostly N with the last blocks' chunks dense in a single repeated k-mer.  The level-1 slices are sized per
+    bin from the sampled loads AND their measured spread over the tiles, and the k-mer that is nearly all of its bin is counted
+    apart by the level-2 scatter: no retry.  With the sample switched off the slices come from the MEAN number of valid k-mers
+    per block and that block's slice of one bin overflows by far: the kernels must keep every write inside the block's own
+    slices (the overflow is reported and the exact path takes over)."""
     rng = np.random.default_rng(3)
     n_junk = 6_000_000
     junk = np.full(n_junk, ord("N"), dtype=np.uint8)
@@ -345,7 +379,10 @@ def test_mostly_invalid_stream_with_a_dense_tail(oracle, dev):
     some = np.frombuffer(("\n".join("".join(rng.choice(list("ACGT"), 150)) for _ in range(20_000))).encode(), dtype=np.uint8)
     stream = np.concatenate([junk, some, np.frombuffer(b"\n", dtype=np.uint8), tail])
     st = check_against_oracle(oracle, stream, 31, dev, amin=1)
-    assert st["n_levels"] == 2 and st["n_retries"] >= 1
+    assert st["n_levels"] == 2 and st["n_retries"] == 0 and st["n_heavy"] == 1
+    monkeypatch.setenv("DSKGPU_NO_SAMPLE", "1")
+    st = check_against_oracle(oracle, stream, 31, dev, amin=1)
+    assert st["n_levels"] == 2 and st["n_retries"] >= 1 and st["n_heavy"] == 0
 
 
 def test_table_overflow_retry_partitions_finer(oracle, dev, monkeypatch):
@@ -816,8 +853,8 @@ def test_minimizers_match_oracle(oracle, golden_dir, dev, k, m):
 
 def test_row_sort_fallback_on_shared_prefixes(oracle, dev):
     """The hand-written row sort (csrc/rowsort.h) places rows by the top 26 value bits (three radix digits) and orders the rows of
-    a cell by comparison; more than 64 rows sharing those 13 bases (here: 300 rows sharing 20) must take the exact full-width
-    fallback, short cells stay on the fast path."""
+    a cell by comparison; more than 64 rows sharing those 13 bases (here: 300 rows sharing 20) go to a block, which orders a
+    sub-bucket with such a cell by a bitonic network in LDS -- no full-width fallback; short cells stay on the wave path."""
     from dsk_amd import KmerCounter
     rng = np.random.default_rng(11)
     tails = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(300, 11))
@@ -831,7 +868,7 @@ def test_row_sort_fallback_on_shared_prefixes(oracle, dev):
         kmers, ab = kc.rows()
         st = kc.stats()
     lo, hi, rab = oracle.count(s, 31).solid(1)
-    assert st["sort_fallback"] == 1
+    assert st["sort_fallback"] == 0
     assert (kmers[:, 0] == lo).all() and (ab == rab).all()
     # short runs (<= 32 rows per prefix) are fixed in place, no fallback
     recs = [b"AAAAAAAAAAAAAAAAAAAC" + t.tobytes() for t in tails[:20]] + [b"CCCCCCCCCCCCCCCCCCCA" + t.tobytes() for t in tails[:25]]
@@ -877,13 +914,14 @@ def test_row_sort_paths_agree(oracle, dev, monkeypatch):
 
 @pytest.mark.parametrize("k", [40, 63, 70, 100])
 def test_multiword_row_sort_prefix_runs_and_fallback(oracle, dev, k):
-    """Multi-word rows use the same two-step order (radix sort on the top 32 bits of the value, runs fixed in place by
-    full comparison): short runs of a shared 20-base prefix stay on that path, long ones take the full-width fallback."""
+    """Multi-word rows are ordered as (top 63 value bits, row index) pairs by the hand-written sort, rows that share all 63 bits
+    by a tie pass with full comparison: 25 or 300 rows sharing a 20-base prefix stay on that path (the 300 in one cell are
+    ordered by the block path's bitonic network); more than 32 rows that share ALL 63 bits take the full-width fallback."""
     rng = np.random.default_rng(12)
     tails = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(300, k - 20))
     noise = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=60_000).tobytes()
     head = b"AAAAAAAAAAAAAAAAAAAC"
-    for nshare, fallback in ((25, 0), (300, 1)):
+    for nshare, fallback in ((25, 0), (300, 0)):
         recs = [head + t.tobytes() for t in tails[:nshare]]
         s = np.frombuffer(b"\n".join(recs) + b"\n" + noise + b"\n", dtype=np.uint8)
         st = check_against_oracle(oracle, s, k, dev, amin=1)
@@ -894,6 +932,11 @@ def test_multiword_row_sort_prefix_runs_and_fallback(oracle, dev, k):
     s = np.frombuffer(b"\n".join(recs) + b"\n" + noise + b"\n", dtype=np.uint8)
     st = check_against_oracle(oracle, s, k, dev, amin=1)
     assert st["sort_fallback"] == 0
+    if k >= 63:      # 60 rows with equal sort keys: beyond what the tie pass orders in place
+        recs = [long_head + t.tobytes()[: k - 36] for t in tails[:60]]
+        s = np.frombuffer(b"\n".join(recs) + b"\n" + noise + b"\n", dtype=np.uint8)
+        st = check_against_oracle(oracle, s, k, dev, amin=1)
+        assert st["sort_fallback"] == 1
 
 
 @pytest.mark.parametrize("k,mkeys,n_reads", [(31, 2, 100_000), (27, 1, 60_000), (63, 1, 60_000)])
