@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file -> .h5 wall-clock block (dsk binary)")
+    ap.add_argument("--no-repeat-rich", action="store_true", help="skip the repeat-rich twin of the workload (extra block, headline unchanged)")
     return ap.parse_args()
 
 
@@ -391,6 +392,32 @@ def main():
             "engine_stats": {k: st[k] for k in ("n_passes", "n_retries", "sort_fallback", "n_ext_regions", "n_heavy", "n_final_bins")},
             "roofline": roofline,
         }
+        # the same shape with what real genomes have and the uniform one lacks: a high-copy family, tandem arrays, poly-A reads
+        # (dsk_amd/synth.py: make_genome_repeats).  An extra block: the headline above stays the BASELINE.json workload.
+        twin = args.workload.replace("_10Mx150", "_repeats_10Mx150")
+        if world == 1 and not args.no_repeat_rich and twin in synth.REPEAT_WORKLOADS and twin != args.workload:
+            rr, _, _, _ = synth.make_workload(twin, dev)
+            torch.cuda.synchronize()
+            kc.set_reads_device(rr.data_ptr(), rr.numel())
+            for _ in range(args.warmup):
+                kc.count()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                kc.count()
+            torch.cuda.synchronize()
+            rr_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            rst = kc.stats()
+            out["repeat_rich"] = {"workload": twin + ": 1 % of the genome one 300 bp family (2 % divergence), 4 tandem arrays of 2000 x 37 bp, 0.2 % poly-A reads",
+                                  "ms_per_step": round(rr_ms, 3), "vs_uniform": round(rr_ms / (per_step * 1e3), 4),
+                                  "n_kmers": rst["n_kmers"], "n_distinct": rst["n_distinct"], "n_solid": rst["n_solid"],
+                                  "stage_ms": {k: round(v, 4) for k, v in kc.stage_times()},
+                                  **{k: rst[k] for k in ("n_retries", "sort_fallback", "n_ext_regions", "n_heavy")}}
+            kc.set_reads_device(reads.data_ptr(), n_bytes)
+            del rr
+        out["configs_not_run"] = {"configs[4]": "not run: 30x human (90 Gbp) exists on neither box; its mechanisms run under -m gpu "
+                                                "(multi-pass: test_full_size_multi_pass; repeat content: repeat_rich block above, "
+                                                "test_full_size_repeat_rich)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(reads, rl, args.cpu_sample_reads, args.kmer_size)
         elif not args.no_cpu_baseline:

@@ -686,13 +686,19 @@ template <int W> struct ATile {
     static constexpr int KPT = 12 / W;           // 12288 one-word / 6144 two-word keys per tile = 96 KB
     static constexpr int KEYS = SC_NT * KPT;
 };
+// A bin that receives more than AL_BIG_KEYS keys in ONE tile (a k-mer with tens of thousands of occurrences: 2 % of a tile) is
+// written out by the whole block instead of by its lane group alone -- 300 keys are 38 trips of one group of 8 lanes while the
+// other 1016 threads wait at the next barrier (0.7 ms of 4.4 on a repeat-rich genome; with poly-A reads, 20 ms).
+#define AL_BIG 64                   // most such bins per tile (a tile holds 12288 keys: at most 191 could exist, the rest stay with their groups)
+#define AL_BIG_KEYS 64u
 #ifndef SLICED_MAX
 #define SLICED_MAX 320      // most level-1 slices per bin (= blocks of the level-1 launch: 256 CUs x 1) the level-2 loader can walk
 #endif
 __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
     const size_t key = 8 * (size_t)W, keys = (size_t)SC_NT * (12 / W), G = 8 / W;
     return keys * key + (size_t)P * (G - 1) * key + (size_t)(P + 1) * 4 + (size_t)P * 4 + (size_t)(P + 1) * 12 + (size_t)P * 2 + 20 * 4 + 32
-           + SLICED_MAX * 4 + 16;     // + prefix sums of the slice fills (SLICED input)
+           + SLICED_MAX * 4 + 16      // + prefix sums of the slice fills (SLICED input)
+           + 2 * AL_BIG * 2 + 16;     // + the lists (one per tile parity) of bins with a long run in the tile (written by the whole block)
 }
 
 // OPT (one-word keys, level 2): "segment-owned" variant that needs NO histogram pass.  A chunk is a whole
@@ -730,6 +736,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
     u16* rn = reinterpret_cast<u16*>(rec + (P + 1));                  // P   carry fill after this tile (persistent)
     u32* wsum = reinterpret_cast<u32*>(smem + ((reinterpret_cast<char*>(rn + P) - smem + 3) & ~size_t(3)));
     u32* pre = wsum + 20;                                             // SLICED: nsl + 1 prefix sums of the slice fills
+    u16* big = reinterpret_cast<u16*>(pre + SLICED_MAX + 4);          // bins with a long run in this tile; nbig[parity] = how many (wsum[17], wsum[18])
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 gi = tid / G, gl = tid % G;
     const u32 nchunks = *d_nchunks;
@@ -747,7 +754,8 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
         bool ovf = false;
         lds_barrier();
         for (u32 b = tid; b < P; b += SC_NT) { pos[b] = OPT ? b * os.cap : scanned[d.flat_base + (u64)b * d.stride]; cnt[b] = 0; rn[b] = 0; }
-        if (tid == 0) cnt[P] = 0;
+        if (tid == 0) { cnt[P] = 0; wsum[17] = 0; wsum[18] = 0; }
+        u32 par = 0;                                                  // tile parity: which of the two list counters this tile fills
         u64 lbeg = d.begin, lend = d.end;                             // range of the (logical) key stream of this chunk
         u32 sg = 0, slo = 0, shi = 0;                                 // SLICED: this thread's current slice and its logical bounds
         if (SLICED) {
@@ -820,14 +828,17 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                     }
                 }
             }
-            // (a key counted apart is a masked slot WITHOUT a rank: ranked, a third of every wave's lanes would add to the dummy bin's one
-            //  counter; unranked they all stage at the first masked slot, rec[P].z < TKEYS, which nobody reads)
+            // (a key counted apart is a masked slot WITHOUT a rank -- ranked, a third of every wave's lanes would add to the dummy bin's one
+            //  counter -- and is not staged either)
 #pragma unroll
             for (int j = 0; j < KPT; ++j) if (!HEAVY || !(hm & (1u << j))) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
             lds_barrier();
             // ---- scan of the tile histogram fused with the carry bookkeeping
-            if (tid == 0) cnt[P] = 0;     // the dummy bin's ranks are in registers now: its counter starts every tile at 0 (masked slots are
+            if (tid == 0) {
+                cnt[P] = 0;               // the dummy bin's ranks are in registers now: its counter starts every tile at 0 (masked slots are
                                           // staged at rec[P].z + rank, so a rank that grew over the tiles of a chunk would leave the staging area)
+                wsum[17 + (par ^ 1u)] = 0;  // the previous tile's list of long runs has been read by everyone (they are past this tile's first barrier)
+            }
             {
                 const int base = tid * ipt;
                 u32 c[4], pe[4], er[4], s = 0;
@@ -863,6 +874,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                         pe[j] = p; er[j] = e | (r << 16);
                         rn[b] = (u16)(r + c[j] - e);
                         pos[b] = p + e; cnt[b] = 0;
+                        if (e > AL_BIG_KEYS) { const u32 x = atomicAdd(&wsum[17 + par], 1u); if (x < AL_BIG) big[par * AL_BIG + x] = (u16)b; else er[j] |= 0x8000u; }   // (list full: bit 15 of e = "the group writes it all")
                     }
                     s += c[j];
                 }
@@ -889,11 +901,24 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                 u32 so[KPT];
 #pragma unroll
                 for (int j = 0; j < KPT; ++j) so[j] = rec[rk[j] >> 16].z;
+                // (HEAVY: a key counted apart is not staged: a third of a wave's lanes storing to ONE masked slot is a 20-way write conflict)
 #pragma unroll
-                for (int j = 0; j < KPT; ++j) stage[so[j] + (rk[j] & 0xFFFFu)] = h[j];
+                for (int j = 0; j < KPT; ++j) if (!HEAVY || !(hm & (1u << j))) stage[so[j] + (rk[j] & 0xFFFFu)] = h[j];
             }
             if (tnext < lend) vm = load(tnext, h);        // HBM reads of the next tile fly under the write-out phase
             lds_barrier();
+            // ---- long runs first, by the whole block: consecutive threads, consecutive keys (the first group of such a bin -- it holds
+            // the carried keys -- and the carry refresh stay with the bin's lane group below)
+            {
+                const u32 nb = wsum[17 + par] < (u32)AL_BIG ? wsum[17 + par] : (u32)AL_BIG;
+                for (u32 x = 0; x < nb; ++x) {
+                    const uint3 rbig = rec[big[par * AL_BIG + x]];
+                    const u32 e = rbig.y & 0x7FFFu, r = rbig.y >> 16, o = rbig.z;
+                    const u32 pl = OPT ? rbig.x & ~CHAIN_BIT : rbig.x;
+                    Key* ob = (OPT && (rbig.x >> 31)) ? extb : out;
+                    for (u32 idx = G + tid; idx < e; idx += SC_NT) ob[pl + idx] = stage[o + idx - r];
+                }
+            }
             // ---- write-out + carry refresh, one lane group per bin
             for (u32 b0 = 0; b0 < P; b0 += 2 * NGRP) {
                 uint3 rb[2]; u32 rnew[2]; bool act[2];
@@ -907,11 +932,12 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                 for (int u = 0; u < 2; ++u) {
                     if (!act[u]) continue;
                     const u32 b = b0 + u * NGRP + gi;
-                    const u32 e = rb[u].y & 0xFFFFu, r = rb[u].y >> 16, o = rb[u].z;
+                    const u32 e = rb[u].y & 0x7FFFu, r = rb[u].y >> 16, o = rb[u].z;
+                    const u32 mine = (e > AL_BIG_KEYS && !(rb[u].y & 0x8000u)) ? (u32)G : e;   // a listed long run: only its first group (the block wrote the rest)
                     const u32 pold = OPT ? rb[u].x & ~CHAIN_BIT : rb[u].x;
                     Key* ob = (OPT && (rb[u].x >> 31)) ? extb : out;                           // home regions of the segment or the extension pool
                     Key* cb = carry + (size_t)b * CARRY;
-                    for (u32 a = (pold & ~(u32)(G - 1)) + gl; a < pold + e; a += G) {      // complete groups of this bin
+                    for (u32 a = (pold & ~(u32)(G - 1)) + gl; a < pold + mine; a += G) {   // complete groups of this bin
                         if (a >= pold) {
                             const u32 idx = a - pold;
                             const Key kv = idx < r ? cb[idx] : stage[o + idx - r];
@@ -924,6 +950,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                 }
             }
             // no barrier: the next tile's rank phase only touches cnt; its barriers order the rest
+            par ^= 1u;
         };
         if (lbeg < lend) vm = load(lbeg, h);
         lds_barrier();

@@ -91,6 +91,7 @@ REPEAT_WORKLOADS = {
     # name: (plain workload it mirrors, poly-A read fraction)
     "c2_repeats_10Mx150": ("c2_10Mx150", 0.002),
     "small_repeats": ("small", 0.002),
+    "c2_repeats_nopolya_10Mx150": ("c2_10Mx150", 0.0),      # (experiments: the repeat-rich genome without the poly-A reads)
 }
 
 

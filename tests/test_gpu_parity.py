@@ -584,6 +584,39 @@ def test_full_size_invariants(dev, workload, k, monkeypatch):
     full_size_invariants(st, h, kmers, ab, k, reads, nr, rl, dev)
 
 
+def test_full_size_repeat_rich(oracle, dev, monkeypatch):
+    """The bench workload's repeat-rich twin (10 M x 150 bp; a 1 % high-copy family, tandem arrays, 0.2 % poly-A reads: k-mers
+    with 10^4 .. 1.8 * 10^6 occurrences) at full size: no retry, no sort fallback, one k-mer counted apart, thousands of
+    extension regions -- and the rows and the histogram equal both the exact histogram + scan path's (DSKGPU_NO_OPT2) and the
+    CPU oracle's."""
+    from dsk_amd import KmerCounter, synth
+    reads, gl, nr, rl = synth.make_workload("c2_repeats_10Mx150", dev)
+
+    def run():
+        with KmerCounter(kmer_size=31, abundance_min=2, timing=True) as kc:
+            kc.set_reads_device(reads.data_ptr(), reads.numel())
+            kc.count()
+            torch.cuda.synchronize()
+            rows, ab = kc.rows()
+            return rows, ab, kc.histogram(), kc.stats(), dict(kc.stage_times())
+
+    rows, ab, hist, st, stages = run()
+    assert st["n_retries"] == 0 and st["sort_fallback"] == 0 and "hist1" not in stages and "hist2" not in stages
+    assert st["n_heavy"] == 1 and st["n_ext_regions"] > 1000
+    assert (np.diff(rows[:, 0].astype(np.uint64)) > 0).all() and int(hist.sum()) == st["n_distinct"] and hist[10000] > 50     # (the last row saturates here)
+    monkeypatch.setenv("DSKGPU_NO_OPT2", "1")
+    rows2, ab2, hist2, st2, stages2 = run()
+    monkeypatch.delenv("DSKGPU_NO_OPT2")
+    assert "hist1" in stages2 and "hist2" in stages2 and st2["n_ext_regions"] == 0 and st2["n_heavy"] == 0
+    assert (rows == rows2).all() and (ab == ab2).all() and (hist == hist2).all()
+    assert st["n_kmers"] == st2["n_kmers"] and st["n_distinct"] == st2["n_distinct"]
+    del rows2, ab2
+    ref = oracle.count(reads.cpu().numpy(), 31, threads=os.cpu_count())
+    keep = ref.ab >= 2
+    assert st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct and int(ref.ab.max()) > 1_000_000
+    assert (hist == ref.histogram(10000)).all() and (rows[:, 0] == ref.lo[keep]).all() and (ab == ref.ab[keep]).all()
+
+
 def test_full_size_multi_pass(dev):
     """BASELINE.json configs[4] ("multi-pass HBM partitioning"): a full-size input counted in >= 8 passes over the key
     space (forced with max_pass_mkeys on the 25 M-read shard: 3.0e9 k-mers, <= 400 M per pass) must give row for row
