@@ -78,10 +78,10 @@ struct Tuning {
     u32 table_maxload = 0;                      // DSKGPU_TABLE_MAXLOAD: distinct keys a count table may hold (forces the finer-partition retry)
     long long max_ext = -1;                     // DSKGPU_MAX_EXT: size of the extension-region pool of the level-2 scatter (tests: 0 = no chains)
     bool no_sample = false;                     // DSKGPU_NO_SAMPLE: level-1 slices from the mean load instead of the sampled per-bin loads
-    bool no_heavy = false;                      // DSKGPU_NO_HEAVY: no k-mer is counted apart by the level-2 scatter
+    bool no_heavy = false;                      // DSKGPU_NO_HEAVY: no k-mer is counted apart by the level-1 scatter
     bool verbose = false;                       // DSKGPU_VERBOSE: trace of the plan decisions on stderr
     bool l2_static = false;                     // DSKGPU_L2_STATIC: segments of the level-2 scatter round-robin over the blocks instead of by work counter
-    bool force_heavy = false;                   // DSKGPU_FORCE_HEAVY: the HEAVY instantiation of the level-2 scatter even when no k-mer is counted apart (timing)
+    bool force_heavy = false;                   // DSKGPU_FORCE_HEAVY: the HEAVY instantiation of the level-1 scatter even when no k-mer is counted apart (timing)
     void read() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         auto num = [](const char* n, u64 dflt) { const char* e = getenv(n); return e ? (u64)atoll(e) : dflt; };
@@ -116,7 +116,7 @@ struct dskgpu_ctx {
     DevBuf bufA, bufB;             // partition ping-pong
     DevBuf mat1, mat2, sums, descs1, descs2, seg, fstart, nsolid, scalars, ghist, gstats, chain_next;
     DevBuf smp_mat, smp_descs, boff;   // sampled level-1 loads: chunk x bin matrix of the sample tiles, their descriptors; per-bin slice offsets
-    DevBuf hv_lut, hv_collect, hv_buf; // heavy k-mers: bin -> collect slot, collected sample keys; [keys | counts | rows] of the k-mers counted apart
+    DevBuf dbg; DevBuf hv_lut, hv_collect, hv_buf; // heavy k-mers: bin -> collect slot, collected sample keys; [keys | counts | rows] of the k-mers counted apart
     std::vector<unsigned char> h_hv_lut; std::vector<u32> h_hv_cnt, h_hv_step; std::vector<u64> h_hv_coll, h_hv_keys;
     std::vector<ChunkDesc> h_descs_s; std::vector<u32> h_boff; std::vector<u64> h_mom; std::vector<double> h_load, h_spread, h_seg_work;
     DevBuf out_w[4], srt_w[4], acc_w[4];   // rows as struct-of-arrays: word i of every row in [i]
@@ -283,13 +283,13 @@ unsigned scatter_grid(const dskgpu_ctx* ctx, int W, u32 P, u64 max_chunks, bool 
     const u64 per_cu = std::max<u64>(1, std::min<u64>(2048 / SC_NT, (160 * 1024) / lds));   // resident blocks per CU
     return (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * per_cu));
 }
-template <int W, int SRC, int MODE, bool OPT = false>
+template <int W, int SRC, int MODE, bool OPT = false, bool HEAVY = false>
 int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1 = Opt1Spec{nullptr, 0u, 0u, nullptr, nullptr, 0u, nullptr}) {
+                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1 = Opt1Spec{nullptr, 0u, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr}) {
     const size_t lds = scatter_lds(W, P, OPT);
     const unsigned grid = scatter_grid(ctx, W, P, max_chunks, OPT);
-    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, SRC, MODE, OPT>)); if (e) return e; }
-    hipLaunchKernelGGL((k_scatter<W, SRC, MODE, OPT>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->packed.as<u64>(),
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, SRC, MODE, OPT, HEAVY>)); if (e) return e; }
+    hipLaunchKernelGGL((k_scatter<W, SRC, MODE, OPT, HEAVY>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->packed.as<u64>(),
                        ctx->inval.as<u32>(), keys, descs, d_nch, scanned, out, (int)ctx->cfg.kmer_size, ds, P, o1);
     CKL("k_scatter");
     return DSKGPU_OK;
@@ -308,13 +308,13 @@ int launch_scatter_rec(dskgpu_ctx* ctx, const ChunkDesc* descs, const u32* d_nch
 template <> int launch_scatter_rec<4>(dskgpu_ctx*, const ChunkDesc*, const u32*, u64, KN<4>*, DigitSpec, u32, Opt1Spec) { return DSKGPU_E_STATE; }
 
 // key-array source with aligned write-out (k_scatter_al) when its LDS footprint fits one CU
-template <int W, int MODE, bool OPT = false, bool SLICED = false, bool HEAVY = false>
+template <int W, int MODE, bool OPT = false, bool SLICED = false>
 int launch_scatter_al(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                      u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, OptSpec os = OptSpec{0u, nullptr, nullptr, nullptr, 0u, 0u, 0ull, 0u, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
+                      u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, OptSpec os = OptSpec{0u, nullptr, nullptr, nullptr, 0u, 0u, 0ull, 0u, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
     const size_t lds = ascatter_lds(W, P);
     const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu));
-    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter_al<W, MODE, OPT, SLICED, HEAVY>)); if (e) return e; }
-    hipLaunchKernelGGL((k_scatter_al<W, MODE, OPT, SLICED, HEAVY>), dim3(grid), dim3(SC_NT), lds, ctx->stream, keys, descs, d_nch, scanned, out, ds, P, os);
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter_al<W, MODE, OPT, SLICED>)); if (e) return e; }
+    hipLaunchKernelGGL((k_scatter_al<W, MODE, OPT, SLICED>), dim3(grid), dim3(SC_NT), lds, ctx->stream, keys, descs, d_nch, scanned, out, ds, P, os);
     CKL("k_scatter_al");
     return DSKGPU_OK;
 }
@@ -657,9 +657,9 @@ int expand_records(dskgpu_ctx* ctx, u64 total) {
 template <> int expand_records<4>(dskgpu_ctx*, u64) { return DSKGPU_E_STATE; }      // records carry k <= 64 only
 
 // Heavy k-mers of a pass (one-word keys): level-1 bins whose sampled load stands 20 % above the median hold a k-mer that alone is a
-// large share of a bin.  k_collect_heavy gathers up to HV_COLLECT sampled keys of up to HV_SLOTS such bins; a k-mer that makes up
-// >= 5 % of a bin's collected keys is heavy: the (at most HV_PER_SEG per bin) heavy keys go to hv_buf = [keys | counts | rows],
-// where the level-2 scatter counts them.  ctx->h_load is reduced by what they take away (the order of the level-2 segments).
+// large share of a bin.  k_collect_heavy gathers about HV_COLLECT sampled keys of up to HV_SLOTS such bins; a k-mer that makes up
+// >= 5 % of a bin's collected keys is heavy: the HV_KEYS heaviest go to hv_buf = [keys | counts | rows], and the level-1
+// scatter counts them apart.  ctx->h_load is reduced by what they take away (slice sizes, order of the level-2 segments).
 int find_heavy(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u32 nts, const Plan& pl, u32* nheavy_out) {
     *nheavy_out = 0;
     const u32 P1 = pl.P1;
@@ -670,10 +670,9 @@ int find_heavy(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u32 nts, 
     for (u32 b = 0; b < P1; ++b) if (ctx->h_load[b] > 1.2 * median + 4096.0) flagged.push_back(b);
     if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] find_heavy: median load %.0f, %zu bins above 1.2 x\n", median, flagged.size());
     if (flagged.empty() && ctx->tune.force_heavy) {
-        const size_t slots = (size_t)P1 * HV_PER_SEG;
-        CK(ctx->hv_buf.ensure(slots * (8 + 8 + 8 + 4)));
-        CK(hipMemsetAsync(ctx->hv_buf.p, 0xFF, slots * 8, ctx->stream));
-        CK(hipMemsetAsync(ctx->hv_buf.as<u64>() + slots, 0, slots * 8, ctx->stream));
+        CK(ctx->hv_buf.ensure((size_t)HV_KEYS * (8 + 8 + 8 + 4)));
+        CK(hipMemsetAsync(ctx->hv_buf.p, 0xFF, HV_KEYS * 8, ctx->stream));
+        CK(hipMemsetAsync(ctx->hv_buf.as<u64>() + HV_KEYS, 0, HV_KEYS * 8, ctx->stream));
         *nheavy_out = 1;
     }
     if (flagged.empty()) return DSKGPU_OK;
@@ -708,8 +707,9 @@ int find_heavy(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u32 nts, 
     CK(hipMemcpyAsync(ctx->h_hv_cnt.data(), d_kept, nf * grid * 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipMemcpyAsync(ctx->h_hv_coll.data(), ctx->hv_collect.p, nf * per_slot * 8, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
-    ctx->h_hv_keys.assign((size_t)P1 * HV_PER_SEG, DSK_EMPTY);
-    u32 nheavy = 0;
+    // candidates over all flagged bins: (estimated occurrences, key, bin); the HV_KEYS largest are counted apart
+    struct Cand { double est; u64 key; u32 bin; };
+    std::vector<Cand> cands;
     for (size_t f = 0; f < nf; ++f) {
         u64* kk = ctx->h_hv_coll.data() + f * per_slot;       // the blocks' kept keys, made dense in place
         u32 n = 0;
@@ -719,42 +719,30 @@ int find_heavy(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u32 nts, 
         }
         if (n < 256) continue;
         std::sort(kk, kk + n);
-        std::vector<std::pair<u32, u64>> runs;               // (length, key) of the runs of >= 5 % of the collected keys
+        const u32 bin = flagged[f];
+        u32 found = 0;
         for (u32 i = 0; i < n;) {
             u32 j = i + 1;
             while (j < n && kk[j] == kk[i]) ++j;
-            if ((u64)(j - i) * 20 >= n) runs.push_back({j - i, kk[i]});
+            if ((u64)(j - i) * 20 >= n) { cands.push_back({ctx->h_load[bin] * (double)(j - i) / (double)n, kk[i], bin}); ++found; }     // >= 5 % of the bin's collected keys
             i = j;
         }
-        std::sort(runs.begin(), runs.end(), [](const std::pair<u32, u64>& a, const std::pair<u32, u64>& b) { return a.first > b.first; });
-        if (ctx->tune.verbose) {
-            u32 best = 0; u64 bk = 0;
-            for (u32 i = 0; i < n;) { u32 j = i + 1; while (j < n && kk[j] == kk[i]) ++j; if (j - i > best) { best = j - i; bk = kk[i]; } i = j; }
-            fprintf(stderr, "[dskgpu]   longest run %u of %u (key %016llx), first keys %016llx %016llx %016llx\n", best, n, (unsigned long long)bk,
-                    (unsigned long long)kk[0], (unsigned long long)kk[1], (unsigned long long)kk[n - 1]);
-        }
-        const u32 bin = flagged[f];
-        if (ctx->tune.verbose) fprintf(stderr, "[dskgpu]   bin %u load %.0f: %u keys collected, %zu dominant\n", bin, ctx->h_load[bin], n, runs.size());
-        double taken = 0.0;
-        for (size_t x = 0; x < runs.size() && x < HV_PER_SEG; ++x) {
-            ctx->h_hv_keys[(size_t)bin * HV_PER_SEG + x] = runs[x].second;
-            taken += ctx->h_load[bin] * (double)runs[x].first / (double)n;
-            ++nheavy;
-        }
-        ctx->h_seg_work[bin] -= taken * 0.5;                  // (a key counted apart still is read and compared: about half the work of a partitioned one)
+        if (ctx->tune.verbose) fprintf(stderr, "[dskgpu]   bin %u load %.0f: %u keys collected, %u dominant\n", bin, ctx->h_load[bin], n, found);
     }
+    std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.est > b.est; });
+    if (cands.size() > HV_KEYS) cands.resize(HV_KEYS);
+    ctx->h_hv_keys.assign(HV_KEYS, DSK_EMPTY);
+    for (size_t x = 0; x < cands.size(); ++x) {
+        ctx->h_hv_keys[x] = cands[x].key;
+        ctx->h_load[cands[x].bin] -= cands[x].est;            // they never reach the bin: slices and the order of the level-2 segments follow
+        ctx->h_seg_work[cands[x].bin] -= cands[x].est;
+    }
+    u32 nheavy = (u32)cands.size();
+    if (!nheavy && ctx->tune.force_heavy) nheavy = 1;         // (timing experiments: the HEAVY kernel with no heavy key)
     if (nheavy) {
-        const size_t slots = (size_t)P1 * HV_PER_SEG;
-        CK(ctx->hv_buf.ensure(slots * (8 + 8 + 8 + 4)));
-        CK(hipMemcpyAsync(ctx->hv_buf.p, ctx->h_hv_keys.data(), slots * 8, hipMemcpyHostToDevice, ctx->stream));
-        CK(hipMemsetAsync(ctx->hv_buf.as<u64>() + slots, 0, slots * 8, ctx->stream));
-    }
-    if (!nheavy && ctx->tune.force_heavy) {      // (timing experiments: the HEAVY kernel with no heavy key)
-        const size_t slots = (size_t)P1 * HV_PER_SEG;
-        CK(ctx->hv_buf.ensure(slots * (8 + 8 + 8 + 4)));
-        CK(hipMemsetAsync(ctx->hv_buf.p, 0xFF, slots * 8, ctx->stream));
-        CK(hipMemsetAsync(ctx->hv_buf.as<u64>() + slots, 0, slots * 8, ctx->stream));
-        nheavy = 1;
+        CK(ctx->hv_buf.ensure((size_t)HV_KEYS * (8 + 8 + 8 + 4)));
+        CK(hipMemcpyAsync(ctx->hv_buf.p, ctx->h_hv_keys.data(), HV_KEYS * 8, hipMemcpyHostToDevice, ctx->stream));
+        CK(hipMemsetAsync(ctx->hv_buf.as<u64>() + HV_KEYS, 0, HV_KEYS * 8, ctx->stream));
     }
     *nheavy_out = nheavy;
     return DSKGPU_OK;
@@ -820,7 +808,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         }
         bool opt1 = opt_cap && !ctx->opt1_off && !ctx->tune.no_opt1 && (npass == 1 || from_reads);   // several passes: reads only (MODE 3)
         if (from_rec && (!opt1 || W > 2 || ctx->tune.no_recsrc)) { int e = records_to_keys(); if (e) return e; }
-        Opt1Spec o1{nullptr, 0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2};
+        Opt1Spec o1{nullptr, 0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2, nullptr, nullptr};
         unsigned grid1 = 0;
         u32 nheavy = 0;                  // k-mers the level-2 scatter counts apart (find_heavy)
         if (opt1 && scatter_lds(W, pl.P1, true) > 160 * 1024) opt1 = false;       // (the slice ends need 4 more bytes of LDS per bin)
@@ -887,7 +875,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 }
                 // ---- a k-mer that alone is a large share of a level-1 bin (poly-A reads, a satellite: millions of occurrences):
                 // its bin stands far above the others.  Collect sampled keys of those bins, find the dominant k-mer(s) on the host
-                // and let the level-2 scatter count them apart (k_scatter_al<.., HEAVY>) -- everything lighter is what the region
+                // and let the level-1 scatter count them apart (k_scatter<.., HEAVY>) -- everything lighter is what the region
                 // chains are for.
                 if constexpr (W == 1) {
                     if (sampled && opt_cap && !ctx->tune.no_heavy) { const int e2 = find_heavy(ctx, from_reads, d_keys_in, (u32)nts, pl, &nheavy); if (e2) return e2; }
@@ -935,7 +923,16 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         int rc;
         const ChunkDesc* dd1 = ctx->descs1.as<ChunkDesc>();
         if (opt1) {
-            if (from_reads && npass > 1) rc = launch_scatter_m<W, 0, 3, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+            if (nheavy) { o1.hv_keys = ctx->hv_buf.as<u64>(); o1.hv_cnt = reinterpret_cast<unsigned long long*>(ctx->hv_buf.as<u64>() + HV_KEYS); }
+            if (nheavy && from_reads) {
+                if constexpr (W == 1) rc = npass > 1 ? launch_scatter_m<1, 0, 3, true, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1)
+                                                     : launch_scatter_m<1, 0, 1, true, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+                else rc = DSKGPU_E_STATE;
+            } else if (nheavy) {
+                if constexpr (W == 1) rc = launch_scatter_m<1, 1, 1, true, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+                else rc = DSKGPU_E_STATE;
+            }
+            else if (from_reads && npass > 1) rc = launch_scatter_m<W, 0, 3, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
             else if (from_reads) rc = launch_scatter_m<W, 0, 1, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
             else if (from_rec) rc = launch_scatter_rec<W>(ctx, dd1, sc + SC_NCH1, nch1, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
             else rc = launch_scatter_m<W, 1, 1, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
@@ -998,19 +995,25 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             ctx->mark("plan2");
             OptSpec os{opt_cap, ctx->mat2.as<u32>(), sc + SC_OVF2, opt1 ? o1.fill : nullptr, 0u, grid1, (u64)o1.area,
                        pl.F, max_ext, ctx->chain_next.as<u32>(), sc + SC_EXT, ctx->chain_next.as<u32>() + nregions + 1, sc + SC_NCHAINED,
-                       nheavy ? ctx->hv_buf.as<u64>() : nullptr, nheavy ? reinterpret_cast<unsigned long long*>(ctx->hv_buf.as<u64>() + (size_t)pl.P1 * HV_PER_SEG) : nullptr,
-                       ctx->tune.l2_static ? nullptr : sc + SC_WORK2};
-            if (opt1 && nheavy) {
-                if constexpr (W == 1) rc = launch_scatter_al<1, 2, true, true, true>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
-                                                                                       ctx->bufB.as<Key>(), pl.d2, pl.P2, os);
-                else rc = DSKGPU_E_STATE;
-            }
-            else if (opt1) rc = launch_scatter_al<W, 2, true, true>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
+                       ctx->tune.l2_static ? nullptr : sc + SC_WORK2, nullptr};
+            if (ctx->tune.verbose && opt1) { CK(ctx->dbg.ensure((size_t)pl.P1 * 24)); os.dbg = ctx->dbg.as<unsigned long long>(); }
+            if (opt1) rc = launch_scatter_al<W, 2, true, true>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
                                                                ctx->bufB.as<Key>(), pl.d2, pl.P2, os);
             else rc = launch_scatter_al<W, 2, true, false>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
                                                            ctx->bufB.as<Key>(), pl.d2, pl.P2, os);
             if (rc) return rc;
             ctx->mark("scatter2");
+            if (ctx->tune.verbose && opt1) {      // per-segment times of the level-2 scatter, in hand-out order
+                std::vector<unsigned long long> t((size_t)pl.P1 * 3);
+                CK(hipMemcpyAsync(t.data(), ctx->dbg.p, t.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+                CK(hipStreamSynchronize(ctx->stream));
+                unsigned long long t0 = ~0ull, t1 = 0; for (u32 i = 0; i < pl.P1; ++i) { t0 = std::min(t0, t[3 * i]); t1 = std::max(t1, t[3 * i + 1]); }
+                fprintf(stderr, "[dskgpu] level 2: %u segments, %.3f ms first start -> last end\n", pl.P1, (t1 - t0) * 1e-5);
+                for (u32 i = 0; i < pl.P1; ++i)
+                    if (i < 6 || i + 3 >= pl.P1 || t[3 * i + 1] + 20000 > t1)
+                        fprintf(stderr, "[dskgpu]   desc %u (segment %u, load %.0f) block %llu: %.3f .. %.3f ms\n", i, (u32)(ctx->h_descs2[i].flat_base / pl.P2),
+                                ctx->h_load[ctx->h_descs2[i].flat_base / pl.P2], t[3 * i + 2], (t[3 * i] - t0) * 1e-5, (t[3 * i + 1] - t0) * 1e-5);
+            }
             fkeys = ctx->bufB.as<Key>();
             scratch = &ctx->bufA;
         } else if (pl.levels == 2) {
@@ -1062,8 +1065,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 CKL("k_count_chained");
             }
         }
-        if (nheavy) {      // the k-mers the level-2 scatter counted apart: histogram, distinct count, rows (appended behind the compacted ones below)
-            const u32 slots = pl.P1 * HV_PER_SEG;
+        if (nheavy) {      // the k-mers the level-1 scatter counted apart: histogram, distinct count, rows (appended behind the compacted ones below)
+            const u32 slots = HV_KEYS;
             u64* hvb = ctx->hv_buf.as<u64>();
             hipLaunchKernelGGL(k_heavy_rows, dim3((slots + 255) / 256), dim3(256), 0, ctx->stream, (const u64*)hvb, (const unsigned long long*)(hvb + slots), slots,
                                cp.amin, cp.amax, cp.histo_max, ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), hvb + 2 * (size_t)slots, reinterpret_cast<u32*>(hvb + 3 * (size_t)slots));
@@ -1107,7 +1110,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         RowsOut ro{};
         for (int x = 0; x < W; ++x) { CK(ctx->out_w[x].ensure((ns + 1) * 8)); ro.w[x] = ctx->out_w[x].as<u64>(); }
         if (nhs) {
-            const size_t slots = (size_t)pl.P1 * HV_PER_SEG;
+            const size_t slots = HV_KEYS;
             CK(hipMemcpyAsync(ctx->out_w[0].as<u64>() + h_nsolid, ctx->hv_buf.as<u64>() + 2 * slots, nhs * 8, hipMemcpyDeviceToDevice, ctx->stream));
             CK(hipMemcpyAsync(ctx->out_ab.as<u32>() + h_nsolid, ctx->hv_buf.as<u64>() + 3 * slots, nhs * 4, hipMemcpyDeviceToDevice, ctx->stream));
         }
@@ -1604,7 +1607,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->cfg.device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->reads_own, &ctx->packed, &ctx->inval, &ctx->bufA, &ctx->bufB, &ctx->mat1, &ctx->mat2, &ctx->sums,
-                      &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats, &ctx->chain_next, &ctx->smp_mat, &ctx->smp_descs, &ctx->boff, &ctx->hv_lut, &ctx->hv_collect, &ctx->hv_buf,
+                      &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats, &ctx->chain_next, &ctx->smp_mat, &ctx->smp_descs, &ctx->boff, &ctx->hv_lut, &ctx->hv_collect, &ctx->hv_buf, &ctx->dbg,
                       &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
                       &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->srt_k2, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
                       &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,

@@ -367,7 +367,8 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
 
 struct OptSpec { u32 cap; u32* subcnt; u32* ovf; const u32* fill; u32 slice, nsl; u64 sstride;     // fill/slice/nsl/sstride: SLICED input (below)
                  u32 F, max_ext; u32* next; u32* ext_cursor; u32* chain_list; u32* chain_cnt;     // region chains (below)
-                 const u64* hv_keys; unsigned long long* hv_cnt; u32* work; };                                 // HEAVY: [segment][HV_PER_SEG] k-mers counted apart (DSK_EMPTY = none) and their counts
+                 u32* work;                                                                         // work counter of the segment hand-out
+                 unsigned long long* dbg; };                                                       // DSKGPU_VERBOSE: per-segment (start, end) clock, 100 MHz
 // Region chains of the segment-owned level-2 scatter.  Regions 0 .. F-1 are the home regions of the sub-partitions, regions
 // F .. F + max_ext - 1 a pool of extension regions of the same size behind them (region r starts at key r * cap of the output
 // buffer).  A sub-partition that outgrows the region it is writing -- a k-mer with thousands of occurrences: every repeat family
@@ -376,7 +377,7 @@ struct OptSpec { u32 cap; u32* subcnt; u32* ovf; const u32* fill; u32 slice, nsl
 // is appended to chain_list (at most max_ext entries: each takes a pool region), and k_count_chained walks those lists.  Only
 // when the pool is used up does *ovf go up (the host then repeats the level with the exact histogram + scan path).
 #define CHAIN_BIT 0x80000000u
-#define HV_PER_SEG 2               // heavy k-mers a level-2 segment can count apart
+#define HV_KEYS 4                  // k-mers the level-1 scatter can count apart (HEAVY)
 __device__ __forceinline__ bool is_empty_key(u64 h) { return h == DSK_EMPTY; }
 template <int W> __device__ __forceinline__ bool is_empty_key(const KN<W>& h) {
     bool e = true;
@@ -474,9 +475,15 @@ __device__ __forceinline__ u32 tile_keys_records(const u64* __restrict__ rec, u3
 // overflow raises *ovf (the host repeats the pass with the exact histogram + scan path).  dump = grid * area = the dump zone.
 // boff[b] .. boff[b + 1]: the slice of bin b inside a block's area (P + 1 offsets, sized per bin from the sampled level-1 loads:
 // a bin that holds a repeat family simply gets longer slices); area = boff[P] keys per block; dump = grid * area.
-struct Opt1Spec { const u32* boff; u32 area, dump; u32* ovf; u32* fill; u32 R; u64* nkeys; };      // R: words per super-k-mer record (SRC 2)
+// HEAVY: hv_keys[HV_KEYS] (DSK_EMPTY = unused) are counted apart (hv_cnt) instead of being partitioned: a k-mer that alone is a large
+// share of a level-1 bin -- poly-A reads: millions of occurrences -- would make its bin's level-2 segment twice the work of the others
+// and put a third of that segment's keys on one rank counter and one sub-partition.  A window that holds such a k-mer simply loses
+// its validity bit (windows without a key are neither ranked nor staged); the compares are VALU work, which this kernel has to spare.
+// A separate instantiation: the plain one keeps its instruction schedule.
+struct Opt1Spec { const u32* boff; u32 area, dump; u32* ovf; u32* fill; u32 R; u64* nkeys;      // R: words per super-k-mer record (SRC 2)
+                  const u64* hv_keys; unsigned long long* hv_cnt; };
 
-template <int W, int SRC, int MODE, bool OPT = false>
+template <int W, int SRC, int MODE, bool OPT = false, bool HEAVY = false>
 __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
                                                    const typename KeyT<W>::T* __restrict__ keys,
                                                    const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
@@ -499,6 +506,11 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
     // cycle through on every tile, far more than the CU's translation cache holds)
     const u32 first = OPT ? blockIdx.x * o1.area : 0u;
     if (OPT) for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] = first + o1.boff[b]; lim[b] = first + o1.boff[b + 1]; }
+    u64 hk[HV_KEYS]; u32 hc[HV_KEYS]; int nhk = 0;       // (nhk: how many are in use -- the list is dense, a wave-uniform count)
+    if constexpr (HEAVY) {
+#pragma unroll
+        for (int x = 0; x < HV_KEYS; ++x) { hk[x] = o1.hv_keys[x]; hc[x] = 0; if (hk[x] != DSK_EMPTY) nhk = x + 1; }
+    }
     for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
         const ChunkDesc d = descs[g];
         lds_barrier();   // previous chunk's write-out reads delta/off/stage
@@ -511,6 +523,19 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
         // of those stores (a full store round trip per tile); issued before them, they are older and the wait leaves the
         // stores in flight -- which needs their number to be known: the write-out is a fixed KPT / 4 trips of 4 predicated stores
         auto rank_and_stage = [&](Key (&h)[KPT], u32 vm) {
+            if constexpr (HEAVY && W == 1) {      // the k-mers counted apart leave the tile here (one-word keys)
+#pragma unroll
+                for (int x = 0; x < HV_KEYS; ++x) {
+                    if (x < nhk) {                   // (uniform: one k-mer counted apart costs one compare per key, not HV_KEYS)
+#pragma unroll
+                        for (int j = 0; j < KPT; ++j) {
+                            const bool hit = (vm & (1u << j)) && h[j] == hk[x];
+                            hc[x] += hit ? 1u : 0u;
+                            if (hit) vm &= ~(1u << j);
+                        }
+                    }
+                }
+            }
             u32 rk[KPT];
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
@@ -628,6 +653,15 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
             mine += f;
         }
         if (ovf) *o1.ovf = 1u;
+        if constexpr (HEAVY) {
+#pragma unroll
+            for (int x = 0; x < HV_KEYS; ++x) {
+                u32 v = hc[x];
+#pragma unroll
+                for (int dd = 32; dd >= 1; dd >>= 1) v += __shfl_down(v, dd);
+                if ((threadIdx.x & 63) == 0 && v) { atomicAdd(&o1.hv_cnt[x], (unsigned long long)v); mine += v; }      // (they count as keys of the launch)
+            }
+        }
 #pragma unroll
         for (int dd = 32; dd >= 1; dd >>= 1) mine += __shfl_down(mine, dd);
         if ((threadIdx.x & 63) == 0 && mine) atomicAdd(o1.nkeys, (u64)mine);      // keys this launch placed (all of them unless a slice overflowed)
@@ -712,11 +746,7 @@ __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
 // os.sstride keys apart (slice i at keys + d.begin + i * sstride), of which the first fill[s*nsl + i] hold keys.  The loader walks the slices in order and skips their
 // unused tails: a thread's keys of consecutive tiles are monotone in the logical stream, so it only keeps the bounds
 // of its current slice in registers and touches the LDS prefix array when it crosses into the next slice.
-// HEAVY (with OPT): up to HV_PER_SEG k-mers per segment are counted apart instead of being partitioned (os.hv_keys / os.hv_cnt): a
-// k-mer that alone is a large share of a level-1 bin -- poly-A reads: millions of occurrences -- would otherwise put a third of
-// every wave's keys on ONE rank counter and one sub-partition.  Its keys are compared out before the rank phase (masked slots),
-// a segment without such a k-mer skips the comparisons.  A separate instantiation: the plain one keeps its instruction schedule.
-template <int W, int MODE, bool OPT = false, bool SLICED = false, bool HEAVY = false>
+template <int W, int MODE, bool OPT = false, bool SLICED = false>
 __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>::T* __restrict__ keys,
                                                          const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
                                                          const u32* __restrict__ scanned,
@@ -748,6 +778,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
     for (;; ) {
         if (g >= nchunks) break;
         const ChunkDesc d = descs[g];
+        if (OPT && os.dbg && tid == 0) { os.dbg[3 * g] = wall_clock64(); os.dbg[3 * g + 2] = blockIdx.x; }
         // OPT: positions are relative to the segment's first region (keeps them 32-bit whatever the total)
         Key* out = OPT ? out_all + (u64)d.flat_base * os.cap : out_all;
         Key* extb = OPT ? out_all + (u64)os.F * os.cap : out_all;         // first extension region
@@ -776,11 +807,6 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
             lds_barrier();
             lbeg = 0; lend = pre[os.nsl];
             shi = pre[1];
-        }
-        u64 hk[HV_PER_SEG]; u32 hc[HV_PER_SEG]; bool any_heavy = false;
-        if constexpr (HEAVY) {
-#pragma unroll
-            for (int x = 0; x < HV_PER_SEG; ++x) { hk[x] = os.hv_keys[(u64)(d.flat_base / P) * HV_PER_SEG + x]; hc[x] = 0; any_heavy = any_heavy || hk[x] != DSK_EMPTY; }
         }
         Key h[KPT]; u32 vm = 0;       // one register set: the next tile is loaded as soon as the stage writes have consumed this one
         auto load = [&](u64 k0, Key (&hh)[KPT]) -> u32 {
@@ -813,25 +839,8 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                 dj = ((vm & (1u << j)) && !pad && key_in_pass<MODE>(digit_word(h[j]), ds)) ? dj : P;
                 rk[j] = dj << 16;
             }
-            u32 hm = 0;                          // HEAVY: keys of this thread that are counted apart
-            if constexpr (HEAVY && W == 1) {
-                if (any_heavy) {                 // (block-uniform)
 #pragma unroll
-                    for (int j = 0; j < KPT; ++j) {
-                        const bool live = (rk[j] >> 16) < P;
-#pragma unroll
-                        for (int x = 0; x < HV_PER_SEG; ++x) {
-                            const bool hit = live && h[j] == hk[x];
-                            hc[x] += hit ? 1u : 0u;
-                            if (hit) { rk[j] = P << 16; hm |= 1u << j; }
-                        }
-                    }
-                }
-            }
-            // (a key counted apart is a masked slot WITHOUT a rank -- ranked, a third of every wave's lanes would add to the dummy bin's one
-            //  counter -- and is not staged either)
-#pragma unroll
-            for (int j = 0; j < KPT; ++j) if (!HEAVY || !(hm & (1u << j))) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
+            for (int j = 0; j < KPT; ++j) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
             lds_barrier();
             // ---- scan of the tile histogram fused with the carry bookkeeping
             if (tid == 0) {
@@ -901,9 +910,8 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
                 u32 so[KPT];
 #pragma unroll
                 for (int j = 0; j < KPT; ++j) so[j] = rec[rk[j] >> 16].z;
-                // (HEAVY: a key counted apart is not staged: a third of a wave's lanes storing to ONE masked slot is a 20-way write conflict)
 #pragma unroll
-                for (int j = 0; j < KPT; ++j) if (!HEAVY || !(hm & (1u << j))) stage[so[j] + (rk[j] & 0xFFFFu)] = h[j];
+                for (int j = 0; j < KPT; ++j) stage[so[j] + (rk[j] & 0xFFFFu)] = h[j];
             }
             if (tnext < lend) vm = load(tnext, h);        // HBM reads of the next tile fly under the write-out phase
             lds_barrier();
@@ -971,17 +979,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
             }
         }
         if (OPT && ovf) *os.ovf = 1u;
-        if constexpr (HEAVY) {
-            if (any_heavy) {
-#pragma unroll
-                for (int x = 0; x < HV_PER_SEG; ++x) {
-                    u32 v = hc[x];
-#pragma unroll
-                    for (int dd = 32; dd >= 1; dd >>= 1) v += __shfl_down(v, dd);
-                    if (lane == 0 && v) atomicAdd(&os.hv_cnt[(u64)(d.flat_base / P) * HV_PER_SEG + x], (unsigned long long)v);
-                }
-            }
-        }
+        if (OPT && os.dbg && tid == 0) os.dbg[3 * g + 1] = wall_clock64();
         if (OPT && os.work) {          // next segment: from the work counter (starts at the grid size)
             lds_barrier();
             if (tid == 0) wsum[19] = atomicAdd(os.work, 1u);
@@ -1852,7 +1850,7 @@ __global__ __launch_bounds__(256) void k_bin_moments(const u32* __restrict__ mat
 // share of the kept keys is its share of the bin (the FIRST arrivals are not: a thread delivers a poly-A read's keys one by
 // one) -- in its own HV_BLOCK_KEYS entries of out[slot][block][..], arrival numbers from LDS counters (a single global
 // counter per slot took 1 ms: 40 K returning atomics on one address); kept[slot][block] = entries written.  The host then finds
-// the dominant key(s) of every slot (dskgpu.hip: find_heavy) and the level-2 scatter counts them apart (k_scatter_al<.., HEAVY>).
+// the dominant key(s) of every slot (dskgpu.hip: find_heavy) and the level-1 scatter counts them apart (k_scatter<.., HEAVY>).
 #define HV_SLOTS 16
 #define HV_COLLECT 2048            // keys aimed at per slot, over all blocks
 #define HV_BLOCK_KEYS 32           // entries of a block per slot
@@ -1903,7 +1901,7 @@ __global__ __launch_bounds__(SC_NT) void k_collect_heavy(const u64* __restrict__
         kept[threadIdx.x * gridDim.x + blockIdx.x] = n < HV_BLOCK_KEYS ? n : HV_BLOCK_KEYS;
     }
 }
-// The k-mers counted apart by the level-2 scatter (HEAVY) join the result here: histogram, distinct count and, when solid, a row
+// The k-mers counted apart by the level-1 scatter (HEAVY) join the result here: histogram, distinct count and, when solid, a row
 // (value restored from the mixed key) in rows_k / rows_ab; gstats[1] = rows written.  One thread per slot.
 __global__ void k_heavy_rows(const u64* __restrict__ hv_keys, const unsigned long long* __restrict__ hv_cnt, u32 nslots, u32 amin, u32 amax, u32 histo_max,
                              u64* __restrict__ ghist, u64* __restrict__ gstats, u64* __restrict__ rows_k, u32* __restrict__ rows_ab) {
