@@ -1226,6 +1226,149 @@ __global__ __launch_bounds__(CNT_NT) void k_count1(u64* keys, u64* solid_keys, c
     if (tid == 0 && ndist_acc) atomicAdd(&gstats[0], ndist_acc);
 }
 
+// ---- k_count1v3 (fixed-capacity regions only: the kernel of the histogram-free path): the same table WITHOUT the slot list.  The
+// lane whose CAS claims a slot remembers the slot in a register and sweeps it itself after the barrier: the insert chain loses the
+// list index (a returning LDS add and its wait) and the list write, the sweep loses the list read (by itself: 4.01 -> 3.98 ms --
+// the kernel is bound by dependent LDS round trips and its barriers at 44 % LDS busy, not by the LDS instruction count).  A region
+// holds at most cap <= CNT_V3_KEYS * CNT_NT keys, so a lane has at most CNT_V3_KEYS claims.  (Tried on the way, same results, both
+// slower: a round that handles a lane's three keys together -- three reads, then three CASes in flight, a wave-private slot list,
+// every step behind a wave-uniform ballot -- 6.2 ms; the same round one key at a time 5.0 ms.)
+#define CNT_V3_KEYS 5
+#define CNT_NONE 0xFFFFFFFFu
+// The probe loop is written for the WAVE -- one exit test per round (a ballot), no per-lane loop state: ~30 instructions per round
+// against ~65 of the per-lane loop of table_insert1 (3.98 -> 3.8 ms).  Called under the lanes' own condition: the ballot sees
+// the active ones.  -> the slot if this lane claimed it, else CNT_NONE
+__device__ __forceinline__ u32 table_insert3(u64* tk, u32* tc, u32* ovf, u64 h) {
+    u32 slot = (u32)h & (CNT_SLOTS - 1), res = CNT_NONE;
+    bool pend = true;
+    for (int probe = 0; probe < CNT_SLOTS; ++probe) {
+        u64 old = 0ull;
+        if (pend) old = tk[slot];
+        const bool e = pend && old == DSK_EMPTY;
+        if (e) { old = atomicCAS(&tk[slot], DSK_EMPTY, h); if (old == DSK_EMPTY) { res = slot; old = h; } }
+        const bool m = pend && old == h;
+        if (m) atomicAdd(&tc[slot], 1u);
+        pend = pend && !m;
+        slot = (slot + 1) & (CNT_SLOTS - 1);
+        if (!__ballot(pend)) return res;
+    }
+    *ovf = 1;
+    return res;
+}
+
+__global__ __launch_bounds__(CNT_NT) void k_count1v3(u64* keys, u64* solid_keys, u32* __restrict__ abund, u32* __restrict__ nsolid,
+                                                      u64* __restrict__ ghist, u64* __restrict__ gstats,
+                                                      u32* __restrict__ overflow, CountParams cp, const u32* __restrict__ subcnt) {
+    __shared__ u64 tk[CNT_SLOTS];
+    __shared__ u32 tc[CNT_SLOTS];
+    __shared__ u32 lh[CNT_LH];
+    __shared__ u32 s_ctr[2][4];                 // [parity][ndist, out, ovf]
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int s = tid; s < CNT_SLOTS; s += CNT_NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
+    for (int b = tid; b < CNT_LH; b += CNT_NT) lh[b] = 0;
+    if (tid < 8) s_ctr[tid >> 2][tid & 3] = 0;
+    u32 ones = 0;          // lane 0 of each wave: abundance-1 keys seen (flushed at the end)
+    u64 ndist_acc = 0;
+    auto range_lo = [&](u32 qq) { const u32 c = qq < cp.F ? qq : cp.F - 1; return subcnt[c]; };
+    auto count_of = [&](u32 qq, u32 lo) { return qq < cp.F ? ((int)lo < 0 ? 0u : lo) : 0u; };      // (chained: counted by k_count_chained)
+    struct Sub { u32 q; u64 begin; u32 n; };
+    auto load_keys = [&](const Sub& sb, u64 (&pk)[CNT_KPT]) {
+        const u32 last = sb.n ? sb.n - 1 : 0u;
+#pragma unroll
+        for (int j = 0; j < CNT_KPT; ++j) { const u32 i = tid + j * CNT_NT; pk[j] = keys[sb.begin + (i < sb.n ? i : last)]; }
+    };
+    auto sub_of = [&](u32 qq, u32 lo) { Sub sb; sb.q = qq; sb.begin = qq < cp.F ? (u64)qq * cp.cap : 0ull; sb.n = count_of(qq, lo); return sb; };
+    const u32 G = gridDim.x;
+    u64 pa[CNT_KPT], pb[CNT_KPT];
+    Sub sa = sub_of(blockIdx.x, range_lo(blockIdx.x));
+    Sub sb = sub_of(blockIdx.x + G, range_lo(blockIdx.x + G));
+    u32 rq = blockIdx.x + 2 * G, rlo = range_lo(rq);
+    load_keys(sa, pa);
+    load_keys(sb, pb);
+    lds_barrier();
+    int par = 0;
+    auto one = [&](Sub& cur, u64 (&pk)[CNT_KPT]) {
+        u32* ctr = s_ctr[par];
+        const u32 q = cur.q, n = cur.n; const u64 begin = cur.begin;
+        u32 cl[CNT_V3_KEYS];                                       // slots this lane claimed
+#pragma unroll
+        for (int j = 0; j < CNT_V3_KEYS; ++j) cl[j] = CNT_NONE;
+#pragma unroll
+        for (int j = 0; j < CNT_KPT; ++j)
+            if ((u32)(tid + j * CNT_NT) < n) cl[j] = table_insert3(tk, tc, &ctr[2], pk[j]);
+#pragma unroll
+        for (int j = CNT_KPT; j < CNT_V3_KEYS; ++j)                // keys past the prefetched ones (n <= cap <= CNT_V3_KEYS * CNT_NT)
+            if ((u32)(tid + j * CNT_NT) < n) cl[j] = table_insert3(tk, tc, &ctr[2], keys[begin + tid + j * CNT_NT]);
+        {
+            u32 mine = 0;
+#pragma unroll
+            for (int j = 0; j < CNT_V3_KEYS; ++j) mine += (u32)__popcll(__ballot(cl[j] != CNT_NONE));
+            if (lane == 0 && mine) atomicAdd(&ctr[0], mine);
+        }
+        cur = sub_of(rq, rlo);
+        load_keys(cur, pk);
+        rq += G; rlo = range_lo(rq);
+        lds_barrier();
+        const u32 nd = ctr[0];
+        const bool bad = ctr[2] || nd > cp.maxload;            // block-uniform
+        if (bad) {
+            for (int s = tid; s < CNT_SLOTS; s += CNT_NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
+            if (tid == 0) *overflow = 1;
+        } else {
+#pragma unroll
+            for (int j = 0; j < CNT_V3_KEYS; ++j) {
+                const bool act = cl[j] != CNT_NONE;
+                if (!__ballot(act)) continue;                      // (wave-uniform)
+                u64 key = 0; u32 c = 0;
+                if (act) {
+                    const u32 slot = cl[j];
+                    key = tk[slot]; c = tc[slot];
+                    tk[slot] = DSK_EMPTY; tc[slot] = 0;
+                }
+                const u64 m1 = __ballot(act && c == 1);
+                if (lane == 0) ones += __popcll(m1);
+                if (act && c > 1) {
+                    const u32 bin = c < cp.histo_max ? c : cp.histo_max;
+                    if (bin < CNT_LH) atomicAdd(&lh[bin], 1u);
+                    else atomicAdd(&ghist[bin], 1ull);
+                }
+                const bool solid = act && c >= cp.amin && c <= cp.amax;
+                const u64 ms = __ballot(solid);
+                if (ms) {
+                    u32 base = 0;
+                    if (lane == 0) base = atomicAdd(&ctr[1], (u32)__popcll(ms));
+                    base = __shfl(base, 0);
+                    if (solid) {
+                        const u32 pos = base + __popcll(ms & ((1ull << lane) - 1));
+                        solid_keys[begin + pos] = key;
+                        abund[begin + pos] = c;
+                    }
+                }
+            }
+        }
+        lds_barrier();
+        if (tid == 0) {
+            nsolid[q] = bad ? 0u : ctr[1];
+            ndist_acc += bad ? 0u : nd;
+            ctr[0] = 0; ctr[1] = 0; ctr[2] = 0;     // this parity is next used two barriers from now
+        }
+        par ^= 1;
+    };
+    while (sa.q < cp.F) {
+        one(sa, pa);
+        if (sb.q >= cp.F) break;
+        one(sb, pb);
+    }
+    lds_barrier();
+    if (lane == 0 && ones) atomicAdd(&lh[1], ones);
+    lds_barrier();
+    for (int b = tid; b < CNT_LH; b += CNT_NT) {
+        const u32 v = lh[b];
+        if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
+    }
+    if (tid == 0 && ndist_acc) atomicAdd(&gstats[0], ndist_acc);
+}
+
 // Sub-partitions that go on in extension regions (k_scatter_al, "region chains"; listed in chain_list by the scatter): the same
 // table, sweep and in-place solid rows as k_count1, one block per listed sub-partition in turn, keys read region by region along
 // the chain.  Such keys arrive in runs (a k-mer with thousands of occurrences), so a wave first adds up the lanes that hold the
