@@ -339,7 +339,7 @@ int launch_scatter(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chunk
 // fixed-capacity regions or exact offsets: a compile-time switch of the count kernels (k_count1 / k_count_mw)
 inline void launch_count_impl(dskgpu_ctx* ctx, unsigned grid, u64* keys, u64* solid_keys, u32* solid_ab, u32* ovf, const CountParams& cp) {
     if (!ctx->tune.count_v1 && cp.cap && cp.cap <= CNT_V3_KEYS * CNT_NT) {      // regions: the list-free kernel
-        hipLaunchKernelGGL(k_count1v3, dim3(grid), dim3(CNT_NT), 0, ctx->stream, keys, solid_keys, solid_ab,
+        hipLaunchKernelGGL((k_count1v3<CNT_NT, CNT_KPT, CNT_V3_KEYS>), dim3(grid), dim3(CNT_NT), 0, ctx->stream, keys, solid_keys, solid_ab,
                            ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, cp, cp.subcnt);
         return;
     }
@@ -1163,7 +1163,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         CK(hipStreamSynchronize(ctx->stream));
         ctx->have_nvalid = true;
     }
-    const u64 max_keys = ctx->max_keys_per_pass ? ctx->max_keys_per_pass : 0xF0000000ull;
+    const u64 max_keys = ctx->max_keys_per_pass ? ctx->max_keys_per_pass : 0xD0000000ull;      // (3.49 G: level 1 then needs <= 1536 bins, what its LDS holds with the slice ends)
     u32 npass = (u32)std::max<u64>(1, (n_upper + max_keys - 1) / max_keys);
     for (;; npass *= 2) {
         if (npass > 4096) return fail(ctx, DSKGPU_E_OVERFLOW, "too many passes (one k-mer alone exceeds a pass)");
@@ -1691,6 +1691,26 @@ int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes) {
     ctx->reads_own.release();
     ctx->reads_own = nb;
     if (ctx->reads_len) ctx->d_reads = nb.as<uint8_t>();
+    return DSKGPU_OK;
+}
+
+int dskgpu_reserve_work(dskgpu_ctx* ctx, uint64_t nbytes) {
+    if (!ctx) return DSKGPU_E_ARG;
+    CK(hipSetDevice(ctx->cfg.device));
+    // upper bounds from the byte count (every byte could end a k-mer): the encoded stream, the level-1 slices / the keys of a pass
+    // (bufA), the level-2 regions + extension pool (bufB); DevBuf only ever grows, so dskgpu_count finds them in place
+    const u64 max_keys = ctx->max_keys_per_pass ? ctx->max_keys_per_pass : 0xD0000000ull;
+    const u64 n = std::min<u64>(nbytes + 1, max_keys + max_keys / 4);
+    const u64 key = 8ull * (u64)ctx->W;
+    const u64 nwords = (nbytes + 31) / 32;
+    CK(ctx->packed.ensure((nwords + 1) * 8));
+    CK(ctx->inval.ensure((nwords + 1) * 4));
+    const u64 target = ctx->W == 1 ? TARGET_KEYS : ctx->W == 2 ? TARGET_KEYS2 : TARGET_KEYS2 / 2;
+    const u64 F = n / target + 2, cap = OPT_GROUPS * (8u / (u64)ctx->W);
+    const u64 regions = F + (ctx->W == 1 ? F / 8 + 4096 : 0);
+    CK(ctx->bufA.ensure(std::max<u64>((n + n / 8 + (1u << 20)) * key, ctx->W == 1 ? F * cap * 4 : 0)));
+    CK(ctx->bufB.ensure((regions * cap + (1u << 16)) * key));
+    if (ctx->W > 1) CK(ctx->abund2.ensure((F * cap + (1u << 16)) * 4));
     return DSKGPU_OK;
 }
 

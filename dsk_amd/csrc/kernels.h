@@ -1232,7 +1232,8 @@ __global__ __launch_bounds__(CNT_NT) void k_count1(u64* keys, u64* solid_keys, c
 // the kernel is bound by dependent LDS round trips and its barriers at 44 % LDS busy, not by the LDS instruction count).  A region
 // holds at most cap <= CNT_V3_KEYS * CNT_NT keys, so a lane has at most CNT_V3_KEYS claims.  (Tried on the way, same results, both
 // slower: a round that handles a lane's three keys together -- three reads, then three CASes in flight, a wave-private slot list,
-// every step behind a wave-uniform ballot -- 6.2 ms; the same round one key at a time 5.0 ms.)
+// every step behind a wave-uniform ballot -- 6.2 ms; the same round one key at a time 5.0 ms; three blocks of 640 threads per CU
+// -- this kernel needs 50 KB of LDS -- 4.9 ms: 64 VGPRs are not enough for five keys per lane in two register sets.)
 #define CNT_V3_KEYS 5
 #define CNT_NONE 0xFFFFFFFFu
 // The probe loop is written for the WAVE -- one exit test per round (a ballot), no per-lane loop state: ~30 instructions per round
@@ -1256,7 +1257,8 @@ __device__ __forceinline__ u32 table_insert3(u64* tk, u32* tc, u32* ovf, u64 h) 
     return res;
 }
 
-__global__ __launch_bounds__(CNT_NT) void k_count1v3(u64* keys, u64* solid_keys, u32* __restrict__ abund, u32* __restrict__ nsolid,
+template <int NT, int KPT, int NKEYS>
+__global__ __launch_bounds__(NT) void k_count1v3(u64* keys, u64* solid_keys, u32* __restrict__ abund, u32* __restrict__ nsolid,
                                                       u64* __restrict__ ghist, u64* __restrict__ gstats,
                                                       u32* __restrict__ overflow, CountParams cp, const u32* __restrict__ subcnt) {
     __shared__ u64 tk[CNT_SLOTS];
@@ -1264,22 +1266,22 @@ __global__ __launch_bounds__(CNT_NT) void k_count1v3(u64* keys, u64* solid_keys,
     __shared__ u32 lh[CNT_LH];
     __shared__ u32 s_ctr[2][4];                 // [parity][ndist, out, ovf]
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int s = tid; s < CNT_SLOTS; s += CNT_NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
-    for (int b = tid; b < CNT_LH; b += CNT_NT) lh[b] = 0;
+    for (int s = tid; s < CNT_SLOTS; s += NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
+    for (int b = tid; b < CNT_LH; b += NT) lh[b] = 0;
     if (tid < 8) s_ctr[tid >> 2][tid & 3] = 0;
     u32 ones = 0;          // lane 0 of each wave: abundance-1 keys seen (flushed at the end)
     u64 ndist_acc = 0;
     auto range_lo = [&](u32 qq) { const u32 c = qq < cp.F ? qq : cp.F - 1; return subcnt[c]; };
     auto count_of = [&](u32 qq, u32 lo) { return qq < cp.F ? ((int)lo < 0 ? 0u : lo) : 0u; };      // (chained: counted by k_count_chained)
     struct Sub { u32 q; u64 begin; u32 n; };
-    auto load_keys = [&](const Sub& sb, u64 (&pk)[CNT_KPT]) {
+    auto load_keys = [&](const Sub& sb, u64 (&pk)[KPT]) {
         const u32 last = sb.n ? sb.n - 1 : 0u;
 #pragma unroll
-        for (int j = 0; j < CNT_KPT; ++j) { const u32 i = tid + j * CNT_NT; pk[j] = keys[sb.begin + (i < sb.n ? i : last)]; }
+        for (int j = 0; j < KPT; ++j) { const u32 i = tid + j * NT; pk[j] = keys[sb.begin + (i < sb.n ? i : last)]; }
     };
     auto sub_of = [&](u32 qq, u32 lo) { Sub sb; sb.q = qq; sb.begin = qq < cp.F ? (u64)qq * cp.cap : 0ull; sb.n = count_of(qq, lo); return sb; };
     const u32 G = gridDim.x;
-    u64 pa[CNT_KPT], pb[CNT_KPT];
+    u64 pa[KPT], pb[KPT];
     Sub sa = sub_of(blockIdx.x, range_lo(blockIdx.x));
     Sub sb = sub_of(blockIdx.x + G, range_lo(blockIdx.x + G));
     u32 rq = blockIdx.x + 2 * G, rlo = range_lo(rq);
@@ -1287,22 +1289,22 @@ __global__ __launch_bounds__(CNT_NT) void k_count1v3(u64* keys, u64* solid_keys,
     load_keys(sb, pb);
     lds_barrier();
     int par = 0;
-    auto one = [&](Sub& cur, u64 (&pk)[CNT_KPT]) {
+    auto one = [&](Sub& cur, u64 (&pk)[KPT]) {
         u32* ctr = s_ctr[par];
         const u32 q = cur.q, n = cur.n; const u64 begin = cur.begin;
-        u32 cl[CNT_V3_KEYS];                                       // slots this lane claimed
+        u32 cl[NKEYS];                                       // slots this lane claimed
 #pragma unroll
-        for (int j = 0; j < CNT_V3_KEYS; ++j) cl[j] = CNT_NONE;
+        for (int j = 0; j < NKEYS; ++j) cl[j] = CNT_NONE;
 #pragma unroll
-        for (int j = 0; j < CNT_KPT; ++j)
-            if ((u32)(tid + j * CNT_NT) < n) cl[j] = table_insert3(tk, tc, &ctr[2], pk[j]);
+        for (int j = 0; j < KPT; ++j)
+            if ((u32)(tid + j * NT) < n) cl[j] = table_insert3(tk, tc, &ctr[2], pk[j]);
 #pragma unroll
-        for (int j = CNT_KPT; j < CNT_V3_KEYS; ++j)                // keys past the prefetched ones (n <= cap <= CNT_V3_KEYS * CNT_NT)
-            if ((u32)(tid + j * CNT_NT) < n) cl[j] = table_insert3(tk, tc, &ctr[2], keys[begin + tid + j * CNT_NT]);
+        for (int j = KPT; j < NKEYS; ++j)                // keys past the prefetched ones (n <= cap <= NKEYS * NT)
+            if ((u32)(tid + j * NT) < n) cl[j] = table_insert3(tk, tc, &ctr[2], keys[begin + tid + j * NT]);
         {
             u32 mine = 0;
 #pragma unroll
-            for (int j = 0; j < CNT_V3_KEYS; ++j) mine += (u32)__popcll(__ballot(cl[j] != CNT_NONE));
+            for (int j = 0; j < NKEYS; ++j) mine += (u32)__popcll(__ballot(cl[j] != CNT_NONE));
             if (lane == 0 && mine) atomicAdd(&ctr[0], mine);
         }
         cur = sub_of(rq, rlo);
@@ -1312,11 +1314,11 @@ __global__ __launch_bounds__(CNT_NT) void k_count1v3(u64* keys, u64* solid_keys,
         const u32 nd = ctr[0];
         const bool bad = ctr[2] || nd > cp.maxload;            // block-uniform
         if (bad) {
-            for (int s = tid; s < CNT_SLOTS; s += CNT_NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
+            for (int s = tid; s < CNT_SLOTS; s += NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
             if (tid == 0) *overflow = 1;
         } else {
 #pragma unroll
-            for (int j = 0; j < CNT_V3_KEYS; ++j) {
+            for (int j = 0; j < NKEYS; ++j) {
                 const bool act = cl[j] != CNT_NONE;
                 if (!__ballot(act)) continue;                      // (wave-uniform)
                 u64 key = 0; u32 c = 0;
@@ -1362,7 +1364,7 @@ __global__ __launch_bounds__(CNT_NT) void k_count1v3(u64* keys, u64* solid_keys,
     lds_barrier();
     if (lane == 0 && ones) atomicAdd(&lh[1], ones);
     lds_barrier();
-    for (int b = tid; b < CNT_LH; b += CNT_NT) {
+    for (int b = tid; b < CNT_LH; b += NT) {
         const u32 v = lh[b];
         if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
     }

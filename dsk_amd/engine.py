@@ -80,7 +80,7 @@ SOLIDITY = {"sum": 0, "min": 1, "max": 2, "one": 3, "all": 4, "custom": 5}
 # every symbol include/dskgpu.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "dskgpu_create", "dskgpu_destroy", "dskgpu_last_error", "dskgpu_version", "dskgpu_device_count", "dskgpu_set_stream",
-    "dskgpu_push_reads", "dskgpu_reserve_reads", "dskgpu_set_reads_device", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
+    "dskgpu_push_reads", "dskgpu_reserve_reads", "dskgpu_reserve_work", "dskgpu_set_reads_device", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
     "dskgpu_count", "dskgpu_mg_scatter", "dskgpu_mg_sample", "dskgpu_mg_make_table", "dskgpu_mg_set_table",
     "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_get_stats", "dskgpu_histogram",
     "dskgpu_num_partitions", "dskgpu_partition_size", "dskgpu_partition_copy", "dskgpu_result_device",
@@ -120,6 +120,7 @@ def load_library():
     lib.dskgpu_set_stream.argtypes = [vp, vp]
     lib.dskgpu_push_reads.argtypes = [vp, vp, u64]
     lib.dskgpu_reserve_reads.argtypes = [vp, u64]
+    lib.dskgpu_reserve_work.argtypes = [vp, u64]
     lib.dskgpu_set_reads_device.argtypes = [vp, vp, u64]
     lib.dskgpu_count.argtypes = [vp]
     lib.dskgpu_next_bank.argtypes = [vp]
@@ -261,6 +262,9 @@ class KmerCounter:
 
     def reserve_reads(self, nbytes: int) -> None:
         self._ck(self._lib.dskgpu_reserve_reads(self._h, nbytes))
+
+    def reserve_work(self, nbytes: int) -> None:
+        self._ck(self._lib.dskgpu_reserve_work(self._h, nbytes))
 
     def set_reads_device(self, ptr: int, nbytes: int) -> None:
         self._ck(self._lib.dskgpu_set_reads_device(self._h, C.c_void_p(ptr), nbytes))

@@ -32,6 +32,8 @@ public:
     virtual std::string name() const = 0;
     virtual void configure(const CountConfig& cfg) = 0;
     virtual void reserve(uint64_t nbytes) {}                  // optional hint: total read-stream bytes to come
+    virtual void prepare(uint64_t nbytes) {}                  // optional: set up the work buffers of a count over that many bytes now (may run
+                                                              // on another thread while push() is called; done before finish())
     virtual void push(const char* data, size_t nbytes) = 0;   // read-stream chunk, whole records
     virtual void nextBank() = 0;                              // what was pushed so far is one bank (comma-separated input)
     virtual void finish() = 0;                                // run the count; results valid afterwards

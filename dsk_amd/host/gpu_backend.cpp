@@ -47,6 +47,11 @@ public:
         const uint32_t N = dskgpu_group_size(grp_);
         for (uint32_t r = 0; r < N; ++r) ckr(r, dskgpu_reserve_reads(dskgpu_group_ctx(grp_, r), n / N + n / (8 * N) + 4096));
     }
+    void prepare(uint64_t n) override {
+        if (!grp_) { ck(dskgpu_reserve_work(ctx_, n)); return; }
+        const uint32_t N = dskgpu_group_size(grp_);
+        for (uint32_t r = 0; r < N; ++r) ckr(r, dskgpu_reserve_work(dskgpu_group_ctx(grp_, r), n / N + n / (8 * N) + 4096));
+    }
     void push(const char* data, size_t n) override {
         if (!grp_) { ck(dskgpu_push_reads(ctx_, data, n)); return; }
         // N pieces cut at record separators; the rank that has received least so far gets the first (largest) one

@@ -131,24 +131,47 @@ void SortingCountBase::execute() {
 
     if (input_.has(STR_NB_CORES)) Bank::setParseThreads((unsigned)std::max<long long>(0, input_.getInt(STR_NB_CORES)));
     std::unique_ptr<ICountBackend> be(createBackend());
-    be->configure(cfg);
     uint64_t nbytes = 0;
     const double t1 = now_s();
-    {   // size the device read buffer once: plain files hold at most their size in sequence bytes, gzip ~4x
-        uint64_t hint = 0;
-        for (const std::string& f : bank_->files()) {
-            const bool gz = f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0;
-            std::unique_ptr<IBank> one(Bank::open(f));
-            hint += one->getSize() * (gz ? 4 : 1);
-        }
-        be->reserve(hint + 4096);
+    // The engine comes up on a helper thread while this one already parses the input: device runtime start-up (0.2 s), the device
+    // read buffer sized once (plain files hold at most their size in sequence bytes, gzip ~4x; fasta/fastq headers and quality
+    // lines make the real stream half of that), then the partition buffers of the count (tens of GB of HBM).  The first chunk
+    // handed to push() waits for the read buffer; finish() waits for all of it.
+    uint64_t hint = 0, seq_hint = 0;                     // file bytes (inflated); sequence bytes among them (FASTQ: half is quality)
+    for (const std::string& f : bank_->files()) {
+        const bool gz = f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0;
+        const std::string stem = gz ? f.substr(0, f.size() - 3) : f;
+        const bool fq = (stem.size() > 6 && stem.compare(stem.size() - 6, 6, ".fastq") == 0) || (stem.size() > 3 && stem.compare(stem.size() - 3, 3, ".fq") == 0);
+        std::unique_ptr<IBank> one(Bank::open(f));
+        const uint64_t b = one->getSize() * (gz ? 4 : 1);
+        hint += b; seq_hint += fq ? b / 2 : b;
     }
+    struct Startup {
+        std::mutex mu; std::condition_variable cv; bool can_push = false, done = false; std::exception_ptr err; std::thread th;
+        void wait_push() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return can_push || err; }); if (err) std::rethrow_exception(err); }
+        void wait_done() { if (th.joinable()) th.join(); if (err) std::rethrow_exception(err); }
+        ~Startup() { if (th.joinable()) th.join(); }
+    } startup;
+    startup.th = std::thread([&]() {
+        try {
+            be->configure(cfg);
+            be->reserve(hint + 4096);
+            { std::lock_guard<std::mutex> lk(startup.mu); startup.can_push = true; }
+            startup.cv.notify_all();
+            be->prepare(seq_hint + 4096);
+        } catch (...) { std::lock_guard<std::mutex> lk(startup.mu); startup.err = std::current_exception(); }
+        { std::lock_guard<std::mutex> lk(startup.mu); startup.done = true; }
+        startup.cv.notify_all();
+    });
+    bool pushing = false;
+    auto push = [&](const char* d, size_t n) { if (!pushing) { startup.wait_push(); pushing = true; } be->push(d, n); nbytes += n; };      // (callers serialise the sink)
     uint64_t nseq = 0;
     std::vector<IBank*> subs = bank_->banks();   // one bank per comma-separated input (README.md:52-58)
     const bool per_bank = cfg.solidity_kind != 0 || cfg.histo2d;
     if (per_bank || subs.size() < 2) {           // bank boundaries matter: stream the banks in order
         for (IBank* sub : subs) {
-            nseq += sub->stream((size_t)64 << 20, [&](const char* d, size_t n) { be->push(d, n); nbytes += n; });
+            nseq += sub->stream((size_t)64 << 20, push);
+            if (!pushing) { startup.wait_push(); pushing = true; }
             be->nextBank();
         }
     } else {                                     // plain sum: inflate / parse the files concurrently (host thread pool)
@@ -159,7 +182,7 @@ void SortingCountBase::execute() {
                 const size_t i = next.fetch_add(1);
                 if (i >= subs.size()) return;
                 try {
-                    seqs += subs[i]->stream((size_t)32 << 20, [&](const char* d, size_t n) { std::lock_guard<std::mutex> g(mu); be->push(d, n); nbytes += n; });
+                    seqs += subs[i]->stream((size_t)32 << 20, [&](const char* d, size_t n) { std::lock_guard<std::mutex> g(mu); push(d, n); });
                 } catch (Exception& e) { std::lock_guard<std::mutex> g(mu); if (err.empty()) err = e.getMessage(); next = subs.size(); }
                 catch (std::exception& e) { std::lock_guard<std::mutex> g(mu); if (err.empty()) err = e.what(); next = subs.size(); }
                 catch (...) { std::lock_guard<std::mutex> g(mu); if (err.empty()) err = "unknown failure while reading the input"; next = subs.size(); }
@@ -172,6 +195,7 @@ void SortingCountBase::execute() {
         if (!err.empty()) throw Exception(err);
         nseq = seqs;
     }
+    startup.wait_done();
     const double t2 = now_s();
     be->finish();
     const double t3 = now_s();

@@ -1,7 +1,9 @@
 // storage.cpp -- see storage.hpp.
 #include "storage.hpp"
 
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstring>
@@ -58,7 +60,7 @@ Storage* StorageFactory::load(const std::string& uri) {
     return st.release();
 }
 
-Storage::~Storage() { root_.reset(); if (fid_ >= 0) H5Fclose(fid_); }
+Storage::~Storage() { root_.reset(); if (raw_fd_ >= 0) ::close(raw_fd_); if (fid_ >= 0) H5Fclose(fid_); }
 
 Group& Storage::getGroup(const std::string& name) { return root_->getGroup(name); }
 
@@ -135,6 +137,44 @@ void Group::writeDataset(const std::string& name, hid_t memtype, const void* row
         H5Dclose(ds); H5Pclose(pl); H5Sclose(sp); throw Exception("unable to write dataset '%s'", p.c_str());
     }
     H5Dclose(ds); H5Pclose(pl); H5Sclose(sp);
+}
+
+long long Group::reserveDataset(const std::string& name, hid_t memtype, uint64_t n) {
+    if (n == 0) return -1;
+    std::string p = path_.empty() ? name : path_ + "/" + name;
+    if (link_exists(st_->file(), p)) H5Ldelete(st_->file(), p.c_str(), H5P_DEFAULT);
+    hsize_t dims[1] = {n};
+    hid_t sp = H5Screate_simple(1, dims, nullptr);
+    hid_t pl = H5Pcreate(H5P_DATASET_CREATE);
+    H5Pset_layout(pl, H5D_CONTIGUOUS);
+    H5Pset_alloc_time(pl, H5D_ALLOC_TIME_EARLY);       // the rows get their place in the file now ...
+    H5Pset_fill_time(pl, H5D_FILL_TIME_NEVER);         // ... and the library writes nothing there
+    hid_t ds = H5Dcreate2(st_->file(), p.c_str(), memtype, sp, H5P_DEFAULT, pl, H5P_DEFAULT);
+    long long off = -1;
+    if (ds >= 0) {
+        const haddr_t a = H5Dget_offset(ds);
+        if (a != HADDR_UNDEF) off = (long long)a;
+        H5Dclose(ds);
+        if (off < 0) H5Ldelete(st_->file(), p.c_str(), H5P_DEFAULT);
+    }
+    H5Pclose(pl); H5Sclose(sp);
+    return off;
+}
+
+void Storage::rawWrite(long long offset, const void* data, size_t bytes) {
+    {
+        std::lock_guard<std::mutex> g(raw_mu_);
+        if (raw_fd_ < 0) {
+            raw_fd_ = ::open(filename_.c_str(), O_WRONLY);
+            if (raw_fd_ < 0) throw Exception("unable to open '%s' for the partition rows", filename_.c_str());
+        }
+    }
+    const char* p = static_cast<const char*>(data);
+    while (bytes) {
+        const ssize_t w = ::pwrite(raw_fd_, p, bytes, (off_t)offset);
+        if (w <= 0) throw Exception("write error in '%s'", filename_.c_str());
+        p += w; offset += w; bytes -= (size_t)w;
+    }
 }
 
 uint64_t Group::datasetSize(const std::string& name) {

@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -72,6 +73,10 @@ public:
     Storage* storage() const { return st_; }
     // raw dataset helpers (1-D arrays of a compound/atomic memory type)
     void writeDataset(const std::string& name, hid_t memtype, const void* rows, uint64_t n, int compress = 0);
+    // A dataset of n rows with its space in the file allocated at once (contiguous, never filled) -> the file offset of row 0:
+    // the caller writes the rows itself (Storage::rawWrite, from several threads), which is what a big partition needs --
+    // H5Dwrite copies the rows into the page cache from one thread.  -1 when the library gives no offset.
+    long long reserveDataset(const std::string& name, hid_t memtype, uint64_t n);
     uint64_t datasetSize(const std::string& name);
     void readDataset(const std::string& name, hid_t memtype, void* rows, uint64_t offset, uint64_t n);
     bool exists(const std::string& name);
@@ -97,6 +102,9 @@ public:
     ~Partition() { H5Tclose(type_); }
     size_t size() const { return nb_; }
     void insert(size_t p, const T* rows, uint64_t n, int compress = 0) { grp_.writeDataset(std::to_string(p), type_, rows, n, compress); }
+    // partition p as n rows the caller writes itself with Storage::rawWrite at the returned file offset (-1: use insert)
+    long long reserve(size_t p, uint64_t n) { return grp_.reserveDataset(std::to_string(p), type_, n); }
+    Storage* storage() const { return grp_.storage(); }
     uint64_t partitionSize(size_t p) { return grp_.datasetSize(std::to_string(p)); }
     uint64_t getNbItems() { uint64_t t = 0; for (size_t p = 0; p < nb_; ++p) t += partitionSize(p); return t; }
     void read(size_t p, std::vector<T>& out) {
@@ -136,6 +144,8 @@ public:
     hid_t file() const { return fid_; }
     bool writable() const { return writable_; }
     const std::string& filename() const { return filename_; }
+    // bytes of a reserved dataset, straight into the file (thread-safe: positional writes on a descriptor of its own)
+    void rawWrite(long long offset, const void* data, size_t bytes);
     template <size_t span>
     Partition<typename Kmer<span>::Count>* solidPartition(size_t nbPartitions = 0) {
         return new Partition<typename Kmer<span>::Count>(getGroup("dsk"), "solid", count_type<span>(), nbPartitions);
@@ -144,6 +154,7 @@ private:
     friend class StorageFactory;
     Storage() : fid_(-1), writable_(false) {}
     hid_t fid_; bool writable_; std::string filename_;
+    int raw_fd_ = -1; std::mutex raw_mu_;
     std::unique_ptr<Group> root_;
 };
 

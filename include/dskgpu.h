@@ -94,6 +94,11 @@ int dskgpu_set_stream(dskgpu_ctx* ctx, void* hip_stream);
 int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes);
 /* Optional: size the device-side read buffer once (e.g. from Bank::getSize) instead of growing it push by push. */
 int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes);
+/* Optional: allocate the partition buffers of a count over up to `nbytes` read-stream bytes now (tens of GB of HBM: 0.2 s of
+ * hipMalloc on a 10 M-read input) instead of inside the first dskgpu_count.  May run on another host thread WHILE the reads
+ * are pushed -- it touches nothing dskgpu_push_reads / dskgpu_reserve_reads use -- but must have returned before dskgpu_count.
+ * Stands where SortingCountAlgorithm's configure step sizes its passes and partitions before execute() fills them. */
+int dskgpu_reserve_work(dskgpu_ctx* ctx, uint64_t nbytes);
 /* Use a read stream already resident in HBM (caller keeps ownership and must
  * keep it alive until dskgpu_count returns).  Replaces any pushed reads. */
 int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes);

@@ -101,6 +101,29 @@ def test_span_borders_and_large_k(bins, tmp_path, oracle, k):
     assert ('H5T_STD_U64LE "value"' in hdr) if words == 1 else (f"H5T_ARRAY {{ [{words}] H5T_STD_U64LE }}" in hdr)
 
 
+def test_big_partitions_written_in_place(bins, tmp_path, oracle):
+    """Partitions of >= 16 K rows are not handed to H5Dwrite: their dataset is allocated at once (contiguous) and several threads
+    write the rows they build straight into the file.  The file must read back -- through this repo's reader (dsk2ascii) AND
+    through stock h5dump -- exactly as the rows of the oracle; a compressed output (-out-compress) keeps the library path."""
+    import numpy as np
+    fa = f"{G}/read50x_ref10K_e001.fasta.gz"
+    stream, _ = oracle.load_bank(fa)
+    ref = oracle.count(stream, 27)
+    want = "".join(f"{''.join('ACTG'[(int(v) >> (2 * (26 - i))) & 3] for i in range(27))} {int(a)}\n" for v, a in zip(ref.lo, ref.ab))
+    for extra in ((), ("-out-compress", "3")):
+        r = subprocess.run([bins["dsk"], "-file", fa, "-kmer-size", "27", "-abundance-min", "1", "-out", "big", "-verbose", "0", *extra],
+                           cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr
+        r = subprocess.run([bins["dsk2ascii"], "-file", "big.h5", "-out", "big.txt", "-verbose", "0"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stdout
+        got = open(os.path.join(tmp_path, "big.txt")).read()
+        assert sorted(got.splitlines()) == sorted(want.splitlines()) and len(got.splitlines()) == 93948
+        layout = subprocess.check_output([H5DUMP, "-p", "-H", "-d", "dsk/solid/0", "big.h5"], cwd=tmp_path).decode()
+        assert ("CONTIGUOUS" in layout) == (not extra) and "93948" not in layout      # 4 partitions of ~23 K rows
+        first = subprocess.check_output(f"{H5DUMP} -d dsk/solid/0 -s 0 -c 1 big.h5 | grep -c abundance", shell=True, cwd=tmp_path).decode()
+        assert int(first) >= 1
+
+
 def test_layout_and_attributes(bins, tmp_path):
     tmp = str(tmp_path)
     subprocess.check_call([bins["dsk"], "-file", f"{G}/longread.fasta", "-kmer-size", "31", "-out", "lay", "-verbose", "0",

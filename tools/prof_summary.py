@@ -37,8 +37,9 @@ write = pmc(os.path.join(src, "write", "w_counter_collection.csv"), "WRITE_SIZE"
 avg_ns = {r["Name"]: float(r["AverageNs"]) for r in rows}
 
 # kernel -> bench stage name.  k_hist/k_scatter: <W, SRC, MODE>; SRC 0 = reads (level 1), 1 = key array (level 2)
-stage_of = [("k_encode", "encode"), ("k_hist<1, 0,", "hist1"), ("k_scatter<1, 0,", "scatter1"), ("k_hist<1, 1,", "hist2"),
-            ("k_scatter<1, 1,", "scatter2"), ("k_scatter_al<1,", "scatter2"), ("k_count1<", "count"), ("k_compact<1>", "compact"),
+stage_of = [("k_encode", "encode"), ("k_hist<1, 0,", "sample1"), ("k_bin_moments", "sample1"), ("k_scatter<1, 0,", "scatter1"), ("k_hist<1, 1,", "hist2"),
+            ("k_scatter<1, 1,", "scatter2"), ("k_scatter_al<1,", "scatter2"), ("k_count1<", "count"), ("k_count1v3<", "count"), ("k_count_chained", "count"),
+            ("k_compact<1>", "compact"),
             ("k_rs_hist", "sort"), ("k_rs_scatter", "sort"), ("k_rs_split", "sort"), ("k_rs_cells", "sort"), ("k_rs_big", "sort")]
 summary = {}
 lines = [f"# PMC summary ({tag})", "",
