@@ -3,7 +3,10 @@
 // does its work in the reference (src/DSK.cpp:60).  C error codes become
 // dsk::Exception (src/main.cpp:42-46 prints "EXCEPTION: <msg>").
 #include "../../include/dskgpu.h"
+#include <sys/time.h>
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "count_backend.hpp"
 
@@ -39,6 +42,15 @@ public:
             pushed_.assign(c.nb_gpus, 0);
             return;
         }
+        // One GPU of a node with several: let the device runtime bring up only that one (its start-up is most of a small run and
+        // grows with the devices it enumerates).  Only before the runtime is initialised, and only if the user did not choose.
+        static bool runtime_up = false;
+        if (!getenv("ROCR_VISIBLE_DEVICES") && !getenv("HIP_VISIBLE_DEVICES") && !getenv("CUDA_VISIBLE_DEVICES") && !runtime_up && c.device >= 0) {
+            char dev[16]; snprintf(dev, sizeof dev, "%d", c.device);
+            setenv("ROCR_VISIBLE_DEVICES", dev, 1);
+            g.device = 0;
+        }
+        runtime_up = true;
         int rc = dskgpu_create(&g, &ctx_);
         if (rc != DSKGPU_OK) { std::string m = dskgpu_last_error(nullptr); ctx_ = nullptr; throw Exception("GPU engine: %s (code %d)", m.c_str(), rc); }
     }
@@ -118,7 +130,15 @@ public:
         }
     }
 private:
-    void drop() { if (ctx_) dskgpu_destroy(ctx_); if (grp_) dskgpu_group_destroy(grp_); ctx_ = nullptr; grp_ = nullptr; }
+    void drop() {
+        const bool trace = getenv("DSK_PHASE_TIMES") != nullptr && (ctx_ || grp_);
+        struct timeval a, b; gettimeofday(&a, nullptr);
+        if (ctx_) dskgpu_destroy(ctx_);
+        if (grp_) dskgpu_group_destroy(grp_);
+        ctx_ = nullptr; grp_ = nullptr;
+        gettimeofday(&b, nullptr);
+        if (trace) fprintf(stderr, "[dsk] engine teardown %.3f s\n", (b.tv_sec - a.tv_sec) + 1e-6 * (b.tv_usec - a.tv_usec));
+    }
     void ck(int rc) { if (rc != DSKGPU_OK) throw Exception("GPU engine: %s (code %d)", dskgpu_last_error(ctx_), rc); }
     void ckr(uint32_t r, int rc) { if (rc != DSKGPU_OK) throw Exception("GPU engine, rank %u: %s (code %d)", r, dskgpu_last_error(dskgpu_group_ctx(grp_, r)), rc); }
     dskgpu_ctx* ctx_; dskgpu_group* grp_; CountConfig cfg_; std::vector<uint64_t> pushed_;
