@@ -28,8 +28,10 @@ struct DevBuf {
     size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
+        // growing a buffer that exists: 6 % on top, so that a size that wobbles by a few per cent from pass to pass (slices from
+        // sampled loads) does not free and allocate tens of GB again -- near a full HBM that took a second
+        size_t want = ((p ? bytes + bytes / 16 : bytes) + 255) & ~size_t(255);
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = (bytes + 255) & ~size_t(255);
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want; else p = nullptr;
         return e;
@@ -81,6 +83,7 @@ struct Tuning {
     bool no_heavy = false;                      // DSKGPU_NO_HEAVY: no k-mer is counted apart by the level-1 scatter
     bool verbose = false;                       // DSKGPU_VERBOSE: trace of the plan decisions on stderr
     bool l2_static = false;                     // DSKGPU_L2_STATIC: segments of the level-2 scatter round-robin over the blocks instead of by work counter
+    bool no_level0 = false; u32 l0_passes = 0;  // DSKGPU_NO_LEVEL0: every pass of a multi-pass count re-generates its keys; DSKGPU_L0_PASSES=n: passes per level-0 sweep (tests)
     bool count_v1 = false;                      // DSKGPU_COUNT_V1: k_count1<true> (slot list) instead of the list-free k_count1v3 on regions
     bool force_heavy = false;                   // DSKGPU_FORCE_HEAVY: the HEAVY instantiation of the level-1 scatter even when no k-mer is counted apart (timing)
     void read() {
@@ -93,7 +96,7 @@ struct Tuning {
         sk_slice = num("DSKGPU_SK_SLICE", 0); sk_minslice = num("DSKGPU_SK_MINSLICE", 2000);
         table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
         max_ext = getenv("DSKGPU_MAX_EXT") ? atoll(getenv("DSKGPU_MAX_EXT")) : -1;
-        no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); l2_static = on("DSKGPU_L2_STATIC"); force_heavy = on("DSKGPU_FORCE_HEAVY"); count_v1 = on("DSKGPU_COUNT_V1");
+        no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); l2_static = on("DSKGPU_L2_STATIC"); force_heavy = on("DSKGPU_FORCE_HEAVY"); count_v1 = on("DSKGPU_COUNT_V1"); no_level0 = on("DSKGPU_NO_LEVEL0"); l0_passes = (u32)num("DSKGPU_L0_PASSES", 0);
         lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0); rs_heavy = (u32)num("DSKGPU_RS_HEAVY", 0);
     }
 };
@@ -117,7 +120,7 @@ struct dskgpu_ctx {
     DevBuf bufA, bufB;             // partition ping-pong
     DevBuf mat1, mat2, sums, descs1, descs2, seg, fstart, nsolid, scalars, ghist, gstats, chain_next;
     DevBuf smp_mat, smp_descs, boff;   // sampled level-1 loads: chunk x bin matrix of the sample tiles, their descriptors; per-bin slice offsets
-    DevBuf dbg; DevBuf hv_lut, hv_collect, hv_buf; // heavy k-mers: bin -> collect slot, collected sample keys; [keys | counts | rows] of the k-mers counted apart
+    DevBuf dbg, l0buf; DevBuf hv_lut, hv_collect, hv_buf; // heavy k-mers: bin -> collect slot, collected sample keys; [keys | counts | rows] of the k-mers counted apart
     std::vector<unsigned char> h_hv_lut; std::vector<u32> h_hv_cnt, h_hv_step; std::vector<u64> h_hv_coll, h_hv_keys;
     std::vector<ChunkDesc> h_descs_s; std::vector<u32> h_boff; std::vector<u64> h_mom; std::vector<double> h_load, h_spread, h_seg_work;
     DevBuf out_w[4], srt_w[4], acc_w[4];   // rows as struct-of-arrays: word i of every row in [i]
@@ -286,7 +289,7 @@ unsigned scatter_grid(const dskgpu_ctx* ctx, int W, u32 P, u64 max_chunks, bool 
 }
 template <int W, int SRC, int MODE, bool OPT = false, bool HEAVY = false>
 int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1 = Opt1Spec{nullptr, 0u, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr}) {
+                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1 = Opt1Spec{nullptr, 0u, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 0u, {0ull, 0ull, 0ull, 0ull}}) {
     const size_t lds = scatter_lds(W, P, OPT);
     const unsigned grid = scatter_grid(ctx, W, P, max_chunks, OPT);
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, SRC, MODE, OPT, HEAVY>)); if (e) return e; }
@@ -765,7 +768,10 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
     int extra_bits = 0;
     for (int attempt = 0;; ++attempt) {
         Plan pl;
-        const u64 plan_n = (from_reads && npass == 1 && ctx->have_nvalid) ? std::min<u64>(cap, ctx->h_nvalid + 1) : cap;
+        // keys the plan is sized for: the exact number of valid windows of a single pass from the reads; of several passes its share
+        // + 2 % (cap holds 6 % head-room: sized for it, 7 passes of 200 M reads needed 1792 level-1 bins, more than the LDS of the
+        // histogram-free level 1 holds)
+        const u64 plan_n = (from_reads && ctx->have_nvalid) ? std::min<u64>(cap, npass == 1 ? ctx->h_nvalid + 1 : ctx->h_nvalid / npass + ctx->h_nvalid / npass / 50 + 4096) : cap;
         if (!make_plan(plan_n, extra_bits, W, ctx->tune.balanced_plan, (u32)ctx->num_cu, &pl))
             return fail(ctx, DSKGPU_E_OVERFLOW, "cannot partition finer (table overflow persists)");
         pl.d1.world = pl.d2.world = ctx->cfg.world_size; pl.d1.npass = pl.d2.npass = npass; pl.d1.pass = pl.d2.pass = pass;
@@ -805,6 +811,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         if (opt_cap && W == 1) max_ext = (u32)std::min<u64>((u64)pl.F / 8 + 4096, 0x7FFFFFFFull / opt_cap - 1);
         if (opt_cap && ctx->tune.max_ext >= 0) max_ext = W == 1 ? (u32)ctx->tune.max_ext : 0u;        // tests
         const u64 nregions = (u64)pl.F + max_ext;
+        if (!opt_cap) { CK(ctx->bufA.ensure((cap + 1) * sizeof(Key))); CK(ctx->bufB.ensure((cap + 1) * sizeof(Key))); }      // exact offsets: the keys of the pass, twice
         if (opt_cap) {
             // the rows of the solid k-mers land at the region offsets too: abundances (one-word keys: in bufA, the free
             // ping-pong buffer) or keys + abundances (multi-word keys: bufA + abund2).  Size everything BEFORE level 1 writes bufA.
@@ -814,7 +821,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         }
         bool opt1 = opt_cap && !ctx->opt1_off && !ctx->tune.no_opt1 && (npass == 1 || from_reads);   // several passes: reads only (MODE 3)
         if (from_rec && (!opt1 || W > 2 || ctx->tune.no_recsrc)) { int e = records_to_keys(); if (e) return e; }
-        Opt1Spec o1{nullptr, 0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2, nullptr, nullptr};
+        Opt1Spec o1{nullptr, 0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2, nullptr, nullptr, 0u, {0ull, 0ull, 0ull, 0ull}};
         unsigned grid1 = 0;
         u32 nheavy = 0;                  // k-mers the level-2 scatter counts apart (find_heavy)
         if (opt1 && scatter_lds(W, pl.P1, true) > 160 * 1024) opt1 = false;       // (the slice ends need 4 more bytes of LDS per bin)
@@ -902,6 +909,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             ctx->h_boff[pl.P1] = (u32)std::min<u64>(area, 0xFFFFFFFFull);
             const u64 tail = 2 * Tile<W>::KEYS;                         // the dump zone behind the last slice (a tile's keys of a bin that outgrew its slice land there)
             const u64 cells = (u64)pl.P1 * grid1;
+            if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] pass %u/%u: P1 %u P2 %u, %u level-1 blocks, area %llu keys per block (%.2f GB of slices), sampled %d\n", pass, npass, pl.P1, pl.P2, grid1,
+                                           (unsigned long long)area, (double)area * grid1 * sizeof(Key) * 1e-9, (int)sampled);
             if (area < 8 || area * grid1 + tail >= 0xFFFF0000ull) opt1 = false;
             else {
                 o1.area = (u32)area; o1.dump = (u32)(area * grid1);
@@ -1094,6 +1103,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         const u32 h_ovf = ctx->h_back[0], h_nsolid = ctx->h_back[1], h_nk = opt1 ? (u32)ctx->h_stats[2] : ctx->h_back[2];
         if ((opt_cap && ctx->h_ovf2) || (opt1 && ctx->h_ovf1)) {       // a slice / region overflowed: repeat this attempt with exact offsets
             ctx->resolve_marks();
+            if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] pass %u/%u: %s overflowed: the exact path takes over\n", pass, npass, (opt1 && ctx->h_ovf1) ? "a level-1 slice" : "the level-2 extension pool");
             if (opt1 && ctx->h_ovf1) ctx->opt1_off = true;
             else { ctx->opt2_off = true; ctx->opt1_off = true; }     // the exact level 2 cannot read sentinel-padded slices
             ctx->stats.n_retries += 1;
@@ -1131,6 +1141,61 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
     }
 }
 
+// "Level 0" of a multi-pass count from reads (one-word keys): ONE sweep over the encoded reads writes the mixed keys of passes
+// [lo, lo + G) of npass into ctx->l0buf, grouped by pass -- the histogram-free scatter with the pass as its digit (MODE 4): every
+// (block, pass) pair owns a slice of `slice` keys inside the pass's region, the unused tails are padded with the sentinel, so a
+// region is one key array.  The passes of the group then run from those arrays (run_one_pass with a key source) instead of
+// re-generating every k-mer once per pass -- the in-HBM counterpart of DSK writing every k-mer to its partition file ONCE
+// (doc/paper.tex:65-67; README.md:126-130 asks for few passes because each one re-reads the input).
+// -> *region_keys: keys (pads included) of a pass's array; obase[i]: its offset in l0buf.  DSKGPU_OK with *G_out = 0: no room.
+int level0_materialise(dskgpu_ctx* ctx, u64 nwords, u32 lo, u32 npass, u32* G_out, u64* region_keys, u64 (&obase)[L0_MAX_PASSES]) {
+    *G_out = 0;
+    const u64 nper = ctx->h_nvalid / npass + 1;
+    u32 nch1 = 0;
+    build_descs1(ctx, nwords, Tile<1>::WORDS, (u64)ctx->num_cu * 8, &nch1);
+    const unsigned grid = scatter_grid(ctx, 1, L0_MAX_PASSES, nch1, true);
+    const u64 cpb = (nch1 + grid - 1) / grid;
+    u64 slice = (u64)((double)nper * (double)cpb / (double)nch1 * 1.02) + 4096;      // hash-uniform passes: 2 % + 4096 over the busiest block's share
+    slice = (slice + 7) & ~7ull;
+    const u64 tail = 2 * Tile<1>::KEYS;
+    const u64 region = slice * grid + tail;                                         // keys; + the dump zone
+    if (region >= 0xFFFF0000ull) return DSKGPU_OK;
+    // how many passes fit beside what a pass itself needs (slices, regions + pool, rows): about 30 bytes per key of a pass
+    size_t free_b = 0, total_b = 0;
+    CK(hipMemGetInfo(&free_b, &total_b));
+    const u64 have = ctx->bufA.cap + ctx->bufB.cap + ctx->l0buf.cap;
+    const u64 need = nper * 30ull + (4ull << 30);
+    const u64 room = free_b + have > need ? free_b + have - need : 0;
+    u32 G = (u32)std::min<u64>(std::min<u64>(L0_MAX_PASSES, npass - lo), room / (region * 8));
+    if (ctx->tune.l0_passes) G = std::min<u32>(std::min<u32>(ctx->tune.l0_passes, L0_MAX_PASSES), npass - lo);      // tests
+    if (G < 2 && !(ctx->tune.l0_passes)) return DSKGPU_OK;                          // one pass at a time gains nothing over reading the reads
+    if (G == 0) return DSKGPU_OK;
+    CK(ctx->l0buf.ensure(region * G * 8 + 64));
+    CK(ctx->descs1.ensure(ctx->h_descs1.size() * sizeof(ChunkDesc)));
+    CK(hipMemcpyAsync(ctx->descs1.p, ctx->h_descs1.data(), ctx->h_descs1.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
+    u32* sc = ctx->scalars.as<u32>();
+    ctx->h_sc[SC_NCH1] = nch1; ctx->h_sc[SC_OVF1] = 0;
+    CK(hipMemcpyAsync(sc + SC_NCH1, &ctx->h_sc[SC_NCH1], 4, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemsetAsync(sc + SC_OVF1, 0, 4, ctx->stream));
+    ctx->h_boff.assign(L0_MAX_PASSES + 1, 0);
+    CK(ctx->boff.ensure((L0_MAX_PASSES + 1) * 4));
+    CK(hipMemsetAsync(ctx->boff.p, 0, (L0_MAX_PASSES + 1) * 4, ctx->stream));
+    CK(ctx->mat1.ensure(((size_t)L0_MAX_PASSES * grid + 1) * 4));
+    CK(hipMemsetAsync(ctx->gstats.as<u64>() + 2, 0, 8, ctx->stream));
+    Opt1Spec o1{ctx->boff.as<u32>(), (u32)slice, (u32)(slice * grid), sc + SC_OVF1, ctx->mat1.as<u32>(), 0u, ctx->gstats.as<u64>() + 2, nullptr, nullptr, (u32)slice, {0ull, 0ull, 0ull, 0ull}};
+    for (u32 i = 0; i < L0_MAX_PASSES; ++i) { obase[i] = (u64)std::min(i, G - 1) * region; o1.obase[i] = obase[i]; }
+    const DigitSpec ds{4u, G, 0u, ctx->cfg.world_size, npass, lo};
+    const int rc = launch_scatter_m<1, 0, 4, true>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, nullptr, ctx->l0buf.as<u64>(), ds, G, o1);
+    if (rc) return rc;
+    ctx->mark("level0");
+    CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] level 0: passes %u..%u of %u materialised, %.2f GB each%s\n", lo, lo + G - 1, npass, (double)region * 8e-9, ctx->h_ovf1 ? " -- a slice overflowed: these passes read the reads" : "");
+    if (ctx->h_ovf1) return DSKGPU_OK;                                             // (a skewed key space: the passes of this group re-generate their keys)
+    *G_out = G; *region_keys = slice * grid;
+    return DSKGPU_OK;
+}
+
 // The pipeline behind dskgpu_count / dskgpu_mg_count: encode once, then one or several passes over
 // the key space (several when the input holds more k-mers than a pass may: < 2^32 offsets, and the
 // ping-pong buffers must fit HBM -- the in-memory counterpart of DSK's disk passes), then the row sort.
@@ -1164,24 +1229,42 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         ctx->have_nvalid = true;
     }
     const u64 max_keys = ctx->max_keys_per_pass ? ctx->max_keys_per_pass : 0xD0000000ull;      // (3.49 G: level 1 then needs <= 1536 bins, what its LDS holds with the slice ends)
-    u32 npass = (u32)std::max<u64>(1, (n_upper + max_keys - 1) / max_keys);
-    for (;; npass *= 2) {
+    // Passes over the key space: as few as hold the keys -- any number, not a power of two (key_in_pass maps a bit field of the
+    // mixed key onto [0, npass)) -- counted from the EXACT number of valid k-mer windows when the keys come from reads: the byte
+    // count over-states the k-mers of 150 bp reads by a quarter, which together with the doubling below once made 16 passes of
+    // what 7 hold (200 M x 150 bp on one GPU: every pass re-generates all k-mers).  A pass that turns out too big (a skewed
+    // key space) doubles the count.
+    const u64 n_keys = (from_reads && ctx->have_nvalid) ? std::max<u64>(1, ctx->h_nvalid) : n_upper;
+    u32 npass = (u32)std::max<u64>(1, (n_keys + max_keys - 1) / max_keys);
+    u64 cap_floor = 0;       // keys the largest pass seen so far really holds (a k-mer with millions of occurrences sits in ONE pass whatever their number)
+    for (;;) {
         if (npass > 4096) return fail(ctx, DSKGPU_E_OVERFLOW, "too many passes (one k-mer alone exceeds a pass)");
-        // buffers of one pass: every position could yield a key when there is a single pass; with
-        // several, the hash spreads keys evenly and 25 % + 1 M head-room is checked after the histogram
-        const u64 cap = npass == 1 ? n_upper : std::min<u64>(n_upper, n_upper / npass + n_upper / npass / 4 + (1u << 20));
-        if (cap >= 0xFFFF0000ull) continue;
-        CK(ctx->bufA.ensure((cap + 1) * sizeof(Key)));
-        CK(ctx->bufB.ensure((cap + 1) * sizeof(Key)));
+        // buffers of one pass: every position could yield a key when there is a single pass; with several, the hash spreads
+        // the keys evenly: 6 % + 1 M head-room, checked after the level-1 histogram (exact path) or by the slices (sampled path)
+        const u64 cap = npass == 1 ? n_upper : std::min<u64>(n_upper, std::max<u64>(cap_floor, n_keys / npass + n_keys / npass / 16 + (1u << 20)));
+        if (cap >= 0xFFFF0000ull) { npass *= 2; cap_floor = 0; continue; }
+        // (bufA / bufB are sized by the pass itself: the histogram-free path wants slices and regions, not `cap` keys)
         if (W > 1) CK(ctx->abund2.ensure((cap + 1) * 4));
         ctx->hist.assign((size_t)ctx->cfg.histo_max + 1, 0);
         std::vector<u64> pass_hist(ctx->hist.size());
         u64 tot_rows = 0, tot_kmers = 0, tot_distinct = 0;
         Plan pl{};
         bool too_big = false;
+        u32 l0_lo = 0, l0_n = 0; u64 l0_keys = 0; u64 l0_base[L0_MAX_PASSES] = {0, 0, 0, 0};       // passes materialised by the last level-0 sweep
+        bool l0_try = W == 1 && from_reads && npass > 1 && ctx->have_nvalid && !ctx->tune.no_level0;
         for (u32 p = 0; p < npass; ++p) {
             u64 ns = 0, nk = 0;
-            int rc = run_one_pass<W>(ctx, from_reads, d_keys_in, nkeys_in, nwords, p, npass, cap, &ns, &nk, &pl);
+            int rc;
+            if (l0_try && p >= l0_lo + l0_n) {       // the next group of passes: one sweep over the reads writes their keys
+                if constexpr (W == 1) { if ((rc = level0_materialise(ctx, nwords, p, npass, &l0_n, &l0_keys, l0_base))) return rc; }
+                l0_lo = p;
+                if (l0_n == 0) l0_try = false;       // no room (or a skewed key space): every pass reads the reads
+            }
+            if (l0_try && p < l0_lo + l0_n) {
+                const u64 nvalid = ctx->h_nvalid;    // (a pass from a key array sizes itself from its own key count)
+                rc = run_one_pass<W>(ctx, false, reinterpret_cast<const Key*>(ctx->l0buf.as<u64>() + l0_base[p - l0_lo]), l0_keys, 0, 0u, 1u, l0_keys, &ns, &nk, &pl);
+                ctx->h_nvalid = nvalid;
+            } else rc = run_one_pass<W>(ctx, from_reads, d_keys_in, nkeys_in, nwords, p, npass, cap, &ns, &nk, &pl);
             if (rc == PASS_TOO_BIG) { too_big = true; break; }
             if (rc) return rc;
             tot_kmers += nk; tot_distinct += ctx->h_stats[0];
@@ -1204,7 +1287,13 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             }
             tot_rows += ns;
         }
-        if (too_big) continue;
+        if (too_big) {
+            // the pass holds more keys than its buffers: give the passes that capacity (more passes would not make THAT pass
+            // smaller); only when it exceeds what 32-bit offsets address, more passes
+            const u64 seen = (u64)ctx->h_back[2];
+            if (seen + (1u << 20) < 0xFFFF0000ull && seen > cap_floor) cap_floor = seen + (1u << 20); else { npass *= 2; cap_floor = 0; }
+            continue;
+        }
         // ---------------- row sort over all passes
         if (npass > 1) {      // make the accumulated rows the sort input
             std::swap(ctx->out_ab, ctx->acc_ab);
@@ -1242,6 +1331,10 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         ctx->stats.n_levels = (u32)pl.levels;
         ctx->stats.n_final_bins = pl.F;
         ctx->stats.n_passes = npass;
+        if (npass > 1) {      // the names go back: acc_* stays the job-sized buffer (it holds the result now), out_* the pass-sized one --
+            std::swap(ctx->out_ab, ctx->acc_ab);      // left swapped, the next count grew the small one to job size again (10 GB of hipMalloc + hipFree per call)
+            for (int x = 0; x < W; ++x) std::swap(ctx->out_w[x], ctx->acc_w[x]);
+        }
         u32 np = ctx->cfg.nb_partitions ? ctx->cfg.nb_partitions : 4u;
         ctx->stats.n_partitions = np;
         ctx->have_result = true;
@@ -1613,7 +1706,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->cfg.device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->reads_own, &ctx->packed, &ctx->inval, &ctx->bufA, &ctx->bufB, &ctx->mat1, &ctx->mat2, &ctx->sums,
-                      &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats, &ctx->chain_next, &ctx->smp_mat, &ctx->smp_descs, &ctx->boff, &ctx->hv_lut, &ctx->hv_collect, &ctx->hv_buf, &ctx->dbg,
+                      &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats, &ctx->chain_next, &ctx->smp_mat, &ctx->smp_descs, &ctx->boff, &ctx->hv_lut, &ctx->hv_collect, &ctx->hv_buf, &ctx->dbg, &ctx->l0buf,
                       &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
                       &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->srt_k2, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
                       &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,

@@ -117,18 +117,27 @@ template <int W> __device__ __forceinline__ u64 digit_word(const KN<W>& h) { ret
 struct DigitSpec { u32 mode, pa, pb, world, npass, pass; };   // mode 0: owner(pa=G)  1: level1(pa=P1)  2: level2(pa=P1,pb=P2)
 // MODE (compile time): 0 owner, 1 level 1, 2 level 2, 3 level 1 of a multi-pass count (adds the pass filter;
 // a separate instantiation so that the single-pass tile body stays branch-free)
+// pass of a key (of ds.npass): the fraction left over by the owner in h[31:12]
+__device__ __forceinline__ u32 key_pass(u64 w, const DigitSpec& ds) {
+    const u32 frac = (((u32)(w >> 12) & 0xFFFFFu) * ds.world) & 0xFFFFFu;
+    return (frac * ds.npass) >> 20;
+}
+// MODE 4 ("level 0" of a multi-pass count): the digit is the PASS of the key, counted from ds.pass, for the ds.pa passes
+// materialised together -- one sweep over the reads writes the keys of a group of passes grouped by pass, and the passes then
+// run from key arrays instead of re-generating every k-mer once per pass.
 template <int MODE>
 __device__ __forceinline__ u32 key_digit(u64 w, const DigitSpec& ds) {
     if (MODE == 1 || MODE == 3) return __umulhi((u32)(w >> 32), ds.pa);
     if (MODE == 2) return __umulhi((u32)(w >> 32) * ds.pa, ds.pb);
+    if (MODE == 4) return key_pass(w, ds) - ds.pass;
     return (((u32)(w >> 12) & 0xFFFFFu) * ds.pa) >> 20;
 }
-// does this key belong to the pass being counted?
+// does this key belong to the pass (MODE 3) / the group of passes (MODE 4) being handled?
 template <int MODE>
 __device__ __forceinline__ bool key_in_pass(u64 w, const DigitSpec& ds) {
-    if (MODE != 3) return true;
-    const u32 frac = (((u32)(w >> 12) & 0xFFFFFu) * ds.world) & 0xFFFFFu;
-    return ((frac * ds.npass) >> 20) == ds.pass;
+    if (MODE == 3) return key_pass(w, ds) == ds.pass;
+    if (MODE == 4) return key_pass(w, ds) - ds.pass < ds.pa;
+    return true;
 }
 
 // multi-word windows: the tuned two-word generator for W = 2, the general one otherwise
@@ -162,6 +171,8 @@ __device__ __forceinline__ u32 tile_keys_reads(const u64* __restrict__ packed, c
     return vm;
 }
 
+__device__ __forceinline__ bool is_pad_key(u64 h) { return h == DSK_EMPTY; }
+template <int W> __device__ __forceinline__ bool is_pad_key(const KN<W>&) { return false; }
 // KEYS: chunk range is in keys; tile t covers keys [begin + t*Tile<W>::KEYS, ...);
 // thread loads keys tid + j*SC_NT (coalesced).
 template <int W>
@@ -178,7 +189,7 @@ __device__ __forceinline__ u32 tile_keys_array(const typename KeyT<W>::T* __rest
         const u32 o = threadIdx.x + (u32)j * SC_NT;
         const bool ok = o < n;
         h[j] = base[ok ? o : n - 1];
-        vm |= (ok ? 1u : 0u) << j;
+        vm |= ((ok && !is_pad_key(h[j])) ? 1u : 0u) << j;      // (the all-ones sentinel pads the slices a level-0 scatter leaves: never a key)
     }
     return vm;
 }
@@ -480,8 +491,14 @@ __device__ __forceinline__ u32 tile_keys_records(const u64* __restrict__ rec, u3
 // and put a third of that segment's keys on one rank counter and one sub-partition.  A window that holds such a k-mer simply loses
 // its validity bit (windows without a key are neither ranked nor staged); the compares are VALU work, which this kernel has to spare.
 // A separate instantiation: the plain one keeps its instruction schedule.
+// slice_len != 0 (level 0, MODE 4): BIN-major slices of that length -- bin b owns the region of `out` that starts at key obase[b]
+// (64-bit: a group of passes holds more than 2^32 keys; positions inside a region stay 32-bit), slice (block g, bin b) at g *
+// slice_len in it (area = slice_len, boff[b] = 0), the dump zone behind the last slice -- whose unused tails the block fills
+// with the all-ones sentinel at the end: a bin's region is then ONE key array (with pads that tile_keys_array masks), which
+// the pass reads as its input.
 struct Opt1Spec { const u32* boff; u32 area, dump; u32* ovf; u32* fill; u32 R; u64* nkeys;      // R: words per super-k-mer record (SRC 2)
-                  const u64* hv_keys; unsigned long long* hv_cnt; };
+                  const u64* hv_keys; unsigned long long* hv_cnt; u32 slice_len; u64 obase[4]; };      // obase: MODE 4, key offset of every bin's region in `out`
+#define L0_MAX_PASSES 4            // passes a level-0 sweep materialises together (bins of the MODE 4 scatter)
 
 template <int W, int SRC, int MODE, bool OPT = false, bool HEAVY = false>
 __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
@@ -505,7 +522,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
     // stay inside a few 2 MB pages (bin-major, the fronts of one block were P regions of grid * slice keys apart: P pages to
     // cycle through on every tile, far more than the CU's translation cache holds)
     const u32 first = OPT ? blockIdx.x * o1.area : 0u;
-    if (OPT) for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] = first + o1.boff[b]; lim[b] = first + o1.boff[b + 1]; }
+    if (OPT) for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] = first + o1.boff[b]; lim[b] = o1.slice_len ? cur[b] + o1.slice_len : first + o1.boff[b + 1]; }
     u64 hk[HV_KEYS]; u32 hc[HV_KEYS]; int nhk = 0;       // (nhk: how many are in use -- the list is dense, a wave-uniform count)
     if constexpr (HEAVY) {
 #pragma unroll
@@ -566,14 +583,18 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
 #pragma unroll
                 for (int u = 0; u < 4; ++u) hk[u] = stage[i0 + u * SC_NT + threadIdx.x];      // (slots past the tile's keys hold stale keys: readable, never stored as keys)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) dd[u] = delta[key_digit<MODE>(digit_word(hk[u]), ds)];
+                for (int u = 0; u < 4; ++u) {
+                    const u32 dg = key_digit<MODE>(digit_word(hk[u]), ds);
+                    dd[u] = delta[MODE == 4 ? (dg < P ? dg : 0u) : dg];      // (MODE 4: the stale keys past the tile's keys may carry any pass)
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const u32 i = i0 + u * SC_NT + threadIdx.x;
                     // (OPT: tile_scan keeps a bin that outgrew its slice out of the other slices.)  With slices there is a dump zone
                     // behind the last bin: a lane past the tile's keys stores there instead of being masked off, so that every trip
                     // issues exactly 4 stores -- the compiler can then count them (see rank_and_stage)
-                    if (OPT) out[i < ntile ? (u64)(dd[u] + i) : (u64)(o1.dump + i)] = hk[u];
+                    if (OPT && MODE == 4) out[i < ntile ? o1.obase[key_digit<MODE>(digit_word(hk[u]), ds) & (L0_MAX_PASSES - 1)] + (u64)(dd[u] + i) : o1.obase[0] + (u64)(o1.dump + i)] = hk[u];
+                    else if (OPT) out[i < ntile ? (u64)(dd[u] + i) : (u64)(o1.dump + i)] = hk[u];
                     else if (i < ntile) out[(u64)(dd[u] + i)] = hk[u];
                 }
             }
@@ -610,7 +631,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                 Raw raw = load_raw(d.begin);
                 if (OPT) {          // as many (dump-zone) stores behind the first loads as a tile's write-out issues behind the prefetched ones:
 #pragma unroll                      // the loop is then entered with the same in-flight picture on both edges and the wait at its top is exact
-                    for (int u = 0; u < 4 * ((KPT + 3) / 4); ++u) out[(u64)(o1.dump + u * SC_NT + threadIdx.x)] = (u64)threadIdx.x;
+                    for (int u = 0; u < 4 * ((KPT + 3) / 4); ++u) out[(MODE == 4 ? o1.obase[0] : 0ull) + (u64)(o1.dump + u * SC_NT + threadIdx.x)] = (u64)threadIdx.x;
                 }
                 for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
                     const bool live = t0 + wlane < d.end;
@@ -651,6 +672,15 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
             const u32 f = c > end ? end - beg : c - beg;
             o1.fill[(u64)b * gridDim.x + blockIdx.x] = f;
             mine += f;
+        }
+        if constexpr (W == 1) {
+            if (o1.slice_len) {                  // level 0: the unused tail of every slice of this block becomes sentinel keys
+                lds_barrier();
+                for (u32 b = 0; b < P; ++b) {
+                    const u32 c = cur[b] < lim[b] ? cur[b] : lim[b];
+                    for (u32 i = c + threadIdx.x; i < lim[b]; i += SC_NT) out[o1.obase[b & (L0_MAX_PASSES - 1)] + i] = DSK_EMPTY;
+                }
+            }
         }
         if (ovf) *o1.ovf = 1u;
         if constexpr (HEAVY) {
@@ -833,7 +863,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter_al(const typename KeyT<W>:
             u32 rk[KPT];
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
-                const bool pad = OPT && is_empty_key(h[j]);                 // sentinel of a level-1 slice tail
+                const bool pad = (OPT && is_empty_key(h[j])) || is_pad_key(h[j]);      // sentinel of a level-1 slice tail / of a level-0 key array
                 u32 dj = key_digit<MODE>(digit_word(h[j]), ds);             // unconditional + select: no exec-mask traffic around the multiply
                 asm volatile("" : "+v"(dj));
                 dj = ((vm & (1u << j)) && !pad && key_in_pass<MODE>(digit_word(h[j]), ds)) ? dj : P;

@@ -980,26 +980,29 @@ def test_multi_pass_over_key_space(oracle, dev, k, mkeys, n_reads):
     g = synth.make_genome(300_000, dev)
     reads = synth.make_reads(g, n_reads, 150).cpu().numpy()
     st = check_against_oracle(oracle, reads, k, dev, max_pass_mkeys=mkeys)
-    assert st["n_passes"] >= len(reads) // (mkeys * 1_000_000)
+    assert st["n_passes"] >= st["n_kmers"] // (mkeys * 1_000_000)          # (sized from the valid k-mer windows, not from the bytes)
     assert st["n_passes"] > 1
     st1 = check_against_oracle(oracle, reads, k, dev)
     assert st1["n_passes"] == 1
 
 
-def test_multi_pass_skew_doubles_passes(oracle, dev):
-    # 600k copies of one k-mer land in ONE pass whatever the pass count: the pass-capacity check must
-    # grow the pass count until that pass fits (or fail loudly), never write out of bounds
-    from dsk_amd import synth, KmerCounter, DskGpuError
+def test_multi_pass_skewed_key_space(oracle, dev, monkeypatch):
+    """Millions of copies of one k-mer land in ONE pass whatever the pass count.  On the sampled path that pass just gets longer
+    slices (and the k-mer is counted apart); on the exact path (DSKGPU_NO_OPT2) the pass-capacity check must give the passes the
+    capacity that pass needs -- more passes would not make it smaller -- and never write out of bounds."""
+    from dsk_amd import synth
     g = synth.make_genome(200_000, dev)
     noise = synth.make_reads(g, 40_000, 150).cpu().numpy()
-    s = np.concatenate([np.full(600_000, 65, np.uint8), np.array([10], np.uint8), noise]).astype(np.uint8)
-    st = check_against_oracle(oracle, s, 31, dev, amin=1, max_pass_mkeys=2)      # 6.6 M positions / 2 M per pass
-    assert st["n_passes"] >= 4
-    t = torch.from_numpy(np.full(3_000_000, 65, np.uint8)).to(dev)             # one k-mer x 3 M can never fit a 1 M pass
-    with KmerCounter(kmer_size=31, max_pass_mkeys=1) as kc:
-        kc.set_reads_device(t.data_ptr(), t.numel())
-        with pytest.raises(DskGpuError):
-            kc.count()
+    s = np.concatenate([np.full(3_000_000, 65, np.uint8), np.array([10], np.uint8), noise]).astype(np.uint8)
+    for exact in (False, True):
+        if exact:
+            monkeypatch.setenv("DSKGPU_NO_OPT2", "1")
+        st = check_against_oracle(oracle, s, 31, dev, amin=1, max_pass_mkeys=2)      # 7.8 M k-mers / 2 M per pass, one pass holds 3 M + its share
+        assert st["n_passes"] == 4
+    monkeypatch.delenv("DSKGPU_NO_OPT2")
+    t = np.full(3_000_000, 65, np.uint8)                                             # one k-mer x 3 M, 1 M per pass: three passes, two of them empty
+    st = check_against_oracle(oracle, t, 31, dev, amin=1, max_pass_mkeys=1)
+    assert st["n_passes"] == 3 and st["n_distinct"] == 1
 
 
 def _bank_reference(oracle, streams, k, kind, amin, amax, mask, hmax=10000):
