@@ -289,9 +289,9 @@ unsigned scatter_grid(const dskgpu_ctx* ctx, int W, u32 P, u64 max_chunks, bool 
 }
 template <int W, int SRC, int MODE, bool OPT = false, bool HEAVY = false>
 int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1 = Opt1Spec{nullptr, 0u, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 0u, {0ull, 0ull, 0ull, 0ull}}) {
-    const size_t lds = scatter_lds(W, P, OPT);
-    const unsigned grid = scatter_grid(ctx, W, P, max_chunks, OPT);
+                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1 = Opt1Spec{nullptr, 0u, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 0u, {0ull, 0ull, 0ull, 0ull}, 0u}) {
+    const size_t lds = scatter_lds(W, P, OPT && !o1.uslice);
+    const unsigned grid = scatter_grid(ctx, W, P, max_chunks, OPT && !o1.uslice);
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, SRC, MODE, OPT, HEAVY>)); if (e) return e; }
     hipLaunchKernelGGL((k_scatter<W, SRC, MODE, OPT, HEAVY>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->packed.as<u64>(),
                        ctx->inval.as<u32>(), keys, descs, d_nch, scanned, out, (int)ctx->cfg.kmer_size, ds, P, o1);
@@ -301,8 +301,8 @@ int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chu
 // super-k-mer records as the source of the histogram-free level-1 scatter (one- and two-word keys)
 template <int W>
 int launch_scatter_rec(dskgpu_ctx* ctx, const ChunkDesc* descs, const u32* d_nch, u64 max_chunks, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1) {
-    const size_t lds = scatter_lds(W, P, true);
-    const unsigned grid = scatter_grid(ctx, W, P, max_chunks, true);
+    const size_t lds = scatter_lds(W, P, !o1.uslice);
+    const unsigned grid = scatter_grid(ctx, W, P, max_chunks, !o1.uslice);
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, 2, 1, true>)); if (e) return e; }
     hipLaunchKernelGGL((k_scatter<W, 2, 1, true>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->rec_src, (const u32*)nullptr,
                        (const typename KeyT<W>::T*)nullptr, descs, d_nch, (const u32*)nullptr, out, (int)ctx->cfg.kmer_size, ds, P, o1);
@@ -821,13 +821,15 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         }
         bool opt1 = opt_cap && !ctx->opt1_off && !ctx->tune.no_opt1 && (npass == 1 || from_reads);   // several passes: reads only (MODE 3)
         if (from_rec && (!opt1 || W > 2 || ctx->tune.no_recsrc)) { int e = records_to_keys(); if (e) return e; }
-        Opt1Spec o1{nullptr, 0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2, nullptr, nullptr, 0u, {0ull, 0ull, 0ull, 0ull}};
+        Opt1Spec o1{nullptr, 0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2, nullptr, nullptr, 0u, {0ull, 0ull, 0ull, 0ull}, 0u};
         unsigned grid1 = 0;
         u32 nheavy = 0;                  // k-mers the level-2 scatter counts apart (find_heavy)
-        if (opt1 && scatter_lds(W, pl.P1, true) > 160 * 1024) opt1 = false;       // (the slice ends need 4 more bytes of LDS per bin)
+        // (the per-bin slice ends need 4 more bytes of LDS per bin: plans above 1634 level-1 bins keep UNIFORM slices, mean-sized, no sample)
+        const bool uniform1 = scatter_lds(W, pl.P1, true) > 160 * 1024;
+        if (opt1 && scatter_lds(W, pl.P1, false) > 160 * 1024) opt1 = false;
         if (opt1 && !from_reads) ctx->h_nvalid = nkeys_in;
         if (opt1) {
-            grid1 = scatter_grid(ctx, W, pl.P1, nch1, true);
+            grid1 = scatter_grid(ctx, W, pl.P1, nch1, !uniform1);
             // a block's share of the input: it walks chunks blockIdx, blockIdx + grid, .. (equal chunks, the busiest block has ceil(nch/grid))
             const u64 cpb = (nch1 + grid1 - 1) / grid1;
             const double share = (double)cpb / (double)nch1;
@@ -842,7 +844,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             std::vector<double>& spread = ctx->h_spread;
             spread.assign(pl.P1, 0.0);
             bool sampled = false;
-            if (!from_rec && !ctx->tune.no_sample) {
+            if (!from_rec && !ctx->tune.no_sample && !uniform1) {
                 const u64 units = from_reads ? nwords : nkeys_in, tile = from_reads ? Tile<W>::WORDS : Tile<W>::KEYS;
                 const u64 ntiles = std::max<u64>(1, (units + tile - 1) / tile);
                 const u64 nts = std::min<u64>(ntiles, 1024);
@@ -899,10 +901,12 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             // (what uniform reads need), in whole groups of 8 keys
             ctx->h_boff.resize(pl.P1 + 1);
             u64 area = 0;
+            if (uniform1) o1.uslice = 1u;          // (set below)
             for (u32 b = 0; b < pl.P1; ++b) {
                 double sl = load[b] * share;
                 sl += sampled ? spread[b] + sl * 0.01 + 64.0 : sl * 0.06 + 160.0;
                 u64 slice = ((u64)sl + 8) & ~7ull;
+                if (uniform1) o1.uslice = (u32)slice;
                 if (ctx->tune.opt_slice) slice = ctx->tune.opt_slice;                                        // experiments / tests
                 ctx->h_boff[b] = (u32)std::min<u64>(area, 0xFFFFFFFFull); area += slice;
             }
@@ -1182,7 +1186,7 @@ int level0_materialise(dskgpu_ctx* ctx, u64 nwords, u32 lo, u32 npass, u32* G_ou
     CK(hipMemsetAsync(ctx->boff.p, 0, (L0_MAX_PASSES + 1) * 4, ctx->stream));
     CK(ctx->mat1.ensure(((size_t)L0_MAX_PASSES * grid + 1) * 4));
     CK(hipMemsetAsync(ctx->gstats.as<u64>() + 2, 0, 8, ctx->stream));
-    Opt1Spec o1{ctx->boff.as<u32>(), (u32)slice, (u32)(slice * grid), sc + SC_OVF1, ctx->mat1.as<u32>(), 0u, ctx->gstats.as<u64>() + 2, nullptr, nullptr, (u32)slice, {0ull, 0ull, 0ull, 0ull}};
+    Opt1Spec o1{ctx->boff.as<u32>(), (u32)slice, (u32)(slice * grid), sc + SC_OVF1, ctx->mat1.as<u32>(), 0u, ctx->gstats.as<u64>() + 2, nullptr, nullptr, (u32)slice, {0ull, 0ull, 0ull, 0ull}, 0u};
     for (u32 i = 0; i < L0_MAX_PASSES; ++i) { obase[i] = (u64)std::min(i, G - 1) * region; o1.obase[i] = obase[i]; }
     const DigitSpec ds{4u, G, 0u, ctx->cfg.world_size, npass, lo};
     const int rc = launch_scatter_m<1, 0, 4, true>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, nullptr, ctx->l0buf.as<u64>(), ds, G, o1);

@@ -340,9 +340,9 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan_apply(u32* __restrict__ a, con
 // of this tile would not fit is redirected, for this tile, to the dump zone [dump, dump + tile) behind the last slice (never read) -- the
 // check costs a few instructions per BIN and tile instead of per key, and nothing is ever written outside the block's own
 // slices or the dump zone.  cur[] keeps advancing, so the overflow shows at the end of the launch.
-struct SliceGuard { const u32* lim; u32 dump; };      // lim[b] (LDS): end of the block's slice of bin b; nullptr = no guard
+struct SliceGuard { const u32* lim; u32 dump; u32 uslice, first; };      // lim[b] (LDS): end of the block's slice of bin b; or uniform slices of uslice keys from `first` (no array); neither = no guard
 template <int NT>
-__device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* cur, int P, u32* wsum, u32* tot, SliceGuard sg = SliceGuard{nullptr, 0u}) {
+__device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* cur, int P, u32* wsum, u32* tot, SliceGuard sg = SliceGuard{nullptr, 0u, 0u, 0u}) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ipt = (P + NT - 1) / NT;
     const int base = tid * ipt;
@@ -369,7 +369,7 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
         const int idx = base + j;
         if (j < ipt && idx < P) {
             const u32 c = cur[idx];
-            const bool fits = sg.lim == nullptr || c + v[j] <= sg.lim[idx];
+            const bool fits = sg.lim ? c + v[j] <= sg.lim[idx] : sg.uslice ? c + v[j] <= sg.first + (u32)(idx + 1) * sg.uslice : true;
             off[idx] = run; delta[idx] = fits ? c - run : sg.dump; cur[idx] = c + v[j]; cnt[idx] = 0;
             run += v[j];
         }
@@ -497,7 +497,8 @@ __device__ __forceinline__ u32 tile_keys_records(const u64* __restrict__ rec, u3
 // with the all-ones sentinel at the end: a bin's region is then ONE key array (with pads that tile_keys_array masks), which
 // the pass reads as its input.
 struct Opt1Spec { const u32* boff; u32 area, dump; u32* ovf; u32* fill; u32 R; u64* nkeys;      // R: words per super-k-mer record (SRC 2)
-                  const u64* hv_keys; unsigned long long* hv_cnt; u32 slice_len; u64 obase[4]; };      // obase: MODE 4, key offset of every bin's region in `out`
+                  const u64* hv_keys; unsigned long long* hv_cnt; u32 slice_len; u64 obase[4];      // obase: MODE 4, key offset of every bin's region in `out`
+                  u32 uslice; };      // != 0: UNIFORM slices of that many keys (bin b at b * uslice, boff unused) -- no slice-end array in LDS: plans above 1634 bins
 #define L0_MAX_PASSES 4            // passes a level-0 sweep materialises together (bins of the MODE 4 scatter)
 
 template <int W, int SRC, int MODE, bool OPT = false, bool HEAVY = false>
@@ -522,7 +523,8 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
     // stay inside a few 2 MB pages (bin-major, the fronts of one block were P regions of grid * slice keys apart: P pages to
     // cycle through on every tile, far more than the CU's translation cache holds)
     const u32 first = OPT ? blockIdx.x * o1.area : 0u;
-    if (OPT) for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] = first + o1.boff[b]; lim[b] = o1.slice_len ? cur[b] + o1.slice_len : first + o1.boff[b + 1]; }
+    if (OPT && o1.uslice) for (u32 b = threadIdx.x; b < P; b += SC_NT) cur[b] = first + b * o1.uslice;
+    else if (OPT) for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] = first + o1.boff[b]; lim[b] = o1.slice_len ? cur[b] + o1.slice_len : first + o1.boff[b + 1]; }
     u64 hk[HV_KEYS]; u32 hc[HV_KEYS]; int nhk = 0;       // (nhk: how many are in use -- the list is dense, a wave-uniform count)
     if constexpr (HEAVY) {
 #pragma unroll
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
 #pragma unroll
             for (int j = 0; j < KPT; ++j) if ((rk[j] >> 16) < P) rk[j] |= atomicAdd(&cnt[rk[j] >> 16], 1u);
             lds_barrier();
-            tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot, OPT ? SliceGuard{lim, o1.dump} : SliceGuard{nullptr, 0u});
+            tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot, OPT ? SliceGuard{o1.uslice ? nullptr : lim, o1.dump, o1.uslice, first} : SliceGuard{nullptr, 0u, 0u, 0u});
             lds_barrier();
 #pragma unroll
             for (int j = 0; j < KPT; ++j) if ((rk[j] >> 16) < P) stage[off[rk[j] >> 16] + (rk[j] & 0xFFFFu)] = h[j];
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
         bool ovf = false;
         u32 mine = 0;
         for (u32 b = threadIdx.x; b < P; b += SC_NT) {
-            const u32 beg = first + o1.boff[b], c = cur[b], end = lim[b];
+            const u32 beg = first + (o1.uslice ? b * o1.uslice : o1.boff[b]), c = cur[b], end = o1.uslice ? beg + o1.uslice : lim[b];
             if (c > end) ovf = true;
             const u32 f = c > end ? end - beg : c - beg;
             o1.fill[(u64)b * gridDim.x + blockIdx.x] = f;

@@ -559,11 +559,14 @@ def full_size_invariants(st, h, kmers, ab, k, reads, nr, rl, dev):
 
 
 @pytest.mark.parametrize("workload,k", [("ecoli50x", 31), ("c2_10Mx150", 31), ("c2_10Mx150", 63),
-                                        ("c3_shard_25Mx150", 31), ("c3_shard_25Mx150", 63)])
+                                        ("c3_shard_25Mx150", 31), ("c3_shard_25Mx150", 63),
+                                        ("c3_200Mx150", 31), ("c3_200Mx150", 63)])
 def test_full_size_invariants(dev, workload, k, monkeypatch):
     """Size-independent properties at BASELINE.json's full sizes, too big for the oracle in seconds: configs[1] =
     c2_10Mx150; c3_shard_25Mx150 = one GPU's share (25 M reads, 3.0e9 k-mers at k = 31) of configs[2] (k = 31) and
-    configs[3] (k = 63, two-word keys) -- the 8-GPU topology itself is the driver's to run."""
+    configs[3] (k = 63, two-word keys); c3_200Mx150 = the WHOLE volume of configs[2] / configs[3] (200 M reads, 30 GB of reads,
+    2.4e10 / 1.76e10 k-mers) on this one GPU, as several passes over the key space -- the 8-GPU topology itself is the driver's
+    to run."""
     from dsk_amd import synth, KmerCounter
     gl, nr, rl = synth.workload(workload)
     g = synth.make_genome(gl, dev)
