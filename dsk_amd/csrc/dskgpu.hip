@@ -132,6 +132,7 @@ struct dskgpu_ctx {
     std::vector<u64> hist2d;
     std::vector<u32> h_starts;
     // multi-GPU exchange as super-k-mer records (superkmer.h)
+    bool enc_fresh = false;        // packed / inval hold the encoding of the current reads, left by dskgpu_mg_sample for the sender's sizing pass of the same step
     bool sk_mode = false, sk_prepared = false;
     bool sk_slices = false;        // the prepared send layout is slices from a sampled estimate (else exact offsets)
     bool sk_exact = false;         // a slice overflowed on these reads: exact counts from now on
@@ -221,6 +222,7 @@ bool sentinel_is_a_kmer(int W, unsigned k) {
 // ---- K1 launcher
 int run_encode(dskgpu_ctx* ctx, const uint8_t* d_bytes, u64 n, u64* nwords_out) {
     const u64 nwords = (n + 31) / 32;
+    ctx->enc_fresh = false;
     CK(ctx->packed.ensure((nwords + 1) * 8));
     CK(ctx->inval.ensure((nwords + 1) * 4));
     if (nwords) {
@@ -1419,8 +1421,9 @@ int sk_prepare(dskgpu_ctx* ctx) {
     if (ctx->n_bytes >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "read shard too large for 32-bit record offsets");
     ctx->mark("start");
     u64 nwords = 0;
-    int rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords);
-    if (rc) return rc;
+    int rc = DSKGPU_OK;
+    if (ctx->enc_fresh) { nwords = (ctx->n_bytes + 31) / 32; ctx->enc_fresh = false; }      // (the repartition sample of this step just encoded these reads)
+    else if ((rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords))) return rc;
     ctx->mark("encode");
     SkParams& sp = ctx->sk_sp;
     sk_geometry(ctx, nwords);
@@ -1773,7 +1776,7 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
     CK(hipMemsetAsync(dst + ctx->reads_len + nbytes, '\n', 1, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     ctx->reads_len += nbytes + 1;
-    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false;
+    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false;
     return DSKGPU_OK;
 }
 
@@ -1813,7 +1816,7 @@ int dskgpu_reserve_work(dskgpu_ctx* ctx, uint64_t nbytes) {
 
 int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes) {
     if (!ctx || (!d_bytes && nbytes)) return DSKGPU_E_ARG;
-    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false;
+    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false;
     ctx->n_bytes = nbytes;
     ctx->reads_len = 0;
     ctx->bank_ends.clear();
@@ -1894,6 +1897,7 @@ int dskgpu_mg_sample(dskgpu_ctx* ctx, uint64_t* loads) {
     CK(hipStreamSynchronize(ctx->stream));
     for (u32 b = 0; b < SK_BUCKETS; ++b) loads[b] *= sp.sample_step;      // an estimate of the whole shard's load
     ctx->sk_prepared = false;                       // packed / inval were rewritten
+    ctx->enc_fresh = true;                          // ... with the encoding of the current reads: the sender's sizing pass reuses it
     return DSKGPU_OK;
 }
 

@@ -59,18 +59,22 @@ struct RcclApi {
 RcclApi g_rccl;
 std::mutex g_rccl_mu;
 
-// all ranks meet here; reusable
+// All ranks meet here; reusable.  wait(failed) returns the OR of what the ranks brought to THIS meeting, the same value to every
+// rank: whether to go on is decided collectively -- a rank that looked at the others' result codes on its own could see a failure
+// that a faster rank missed, leave, and let the rest wait forever at the next meeting (or inside an RCCL send).
 class Barrier {
 public:
     explicit Barrier(unsigned n) : n_(n) {}
-    void wait() {
+    bool wait(bool failed) {
         std::unique_lock<std::mutex> lk(mu_);
         const unsigned gen = gen_;
-        if (++count_ == n_) { count_ = 0; ++gen_; cv_.notify_all(); }
+        pending_ = pending_ || failed;
+        if (++count_ == n_) { count_ = 0; result_ = pending_; pending_ = false; ++gen_; cv_.notify_all(); }
         else cv_.wait(lk, [&] { return gen_ != gen; });
+        return result_;          // (cannot change before every rank of this meeting has left: the next one needs all of them)
     }
 private:
-    std::mutex mu_; std::condition_variable cv_; unsigned n_, count_ = 0, gen_ = 0;
+    std::mutex mu_; std::condition_variable cv_; unsigned n_, count_ = 0, gen_ = 0; bool pending_ = false, result_ = false;
 };
 
 struct DevMem {
@@ -117,8 +121,8 @@ int group_fail(dskgpu_group* g, int code, const std::string& msg) { g->err = msg
 
 // one rank of one sharded count
 void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
-    auto fail = [&](int code, const std::string& msg) { g->rc[r] = code; g->rank_err[r] = msg; };
-    auto any_failed = [&]() { for (int c : g->rc) if (c != DSKGPU_OK) return true; return false; };
+    auto fail = [&](int code, const std::string& msg) { g->rc[r] = code; g->rank_err[r] = msg; };      // (a rank writes its own slot only; the slots are read after the join)
+    auto failed = [&]() { return g->rc[r] != DSKGPU_OK; };
     const uint32_t n = g->n;
     dskgpu_ctx* ctx = g->ctx[r];
     if (hipSetDevice(g->dev[r]) != hipSuccess) fail(DSKGPU_E_DEVICE, "hipSetDevice");
@@ -128,14 +132,13 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
             const int rc = dskgpu_mg_sample(ctx, g->loads[r].data());
             if (rc != DSKGPU_OK) fail(rc, std::string("mg_sample: ") + dskgpu_last_error(ctx));
         }
-        bar->wait();
-        if (any_failed()) return;
+        if (bar->wait(failed())) return;
         if (r == 0) {
             std::vector<uint64_t> sum(DSKGPU_MG_BUCKETS, 0);
             for (uint32_t s = 0; s < n; ++s) for (uint32_t b = 0; b < DSKGPU_MG_BUCKETS; ++b) sum[b] += g->loads[s][b];
             dskgpu_mg_make_table(sum.data(), n, g->table.data());
         }
-        bar->wait();
+        (void)bar->wait(false);
         const int rc = dskgpu_mg_set_table(ctx, g->table.data());
         if (rc != DSKGPU_OK) fail(rc, std::string("mg_set_table: ") + dskgpu_last_error(ctx));
     }
@@ -153,16 +156,14 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
             break;
         }
     }
-    bar->wait();                                     // every rank's counts row is final, every send buffer complete
-    if (any_failed()) return;
+    if (bar->wait(failed())) return;                 // every rank's counts row is final, every send buffer complete
     // ---- step 2: the exchange (all-to-all-v)
     uint64_t recv_words = 0;
     std::vector<uint64_t> roff(n + 1, 0), soff(n + 1, 0);
     for (uint32_t s = 0; s < n; ++s) { roff[s + 1] = roff[s] + g->counts[s][r]; soff[s + 1] = soff[s] + g->counts[r][s]; }
     recv_words = roff[n];
     if (!g->recv[r].ensure(std::max<uint64_t>(recv_words, 1) * 8)) fail(DSKGPU_E_NOMEM, "receive buffer");
-    bar->wait();                                     // (a failed allocation must stop everybody before RCCL would hang)
-    if (any_failed()) return;
+    if (bar->wait(failed())) return;                 // (a failed allocation must stop everybody before RCCL would hang)
     uint64_t* sb = static_cast<uint64_t*>(g->send[r].p);
     uint64_t* rb = static_cast<uint64_t*>(g->recv[r].p);
     if (g->use_rccl) {
@@ -186,8 +187,7 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
         }
     }
     if (g->rc[r] == DSKGPU_OK && hipStreamSynchronize(g->stream[r]) != hipSuccess) fail(DSKGPU_E_DEVICE, "exchange: stream synchronize");
-    bar->wait();                                     // nobody overwrites a send buffer a peer still reads
-    if (any_failed()) return;
+    if (bar->wait(failed())) return;                 // nobody overwrites a send buffer a peer still reads
     // ---- step 3: count what this rank owns
     const int rc = dskgpu_mg_count(ctx, recv_words ? g->recv[r].p : nullptr, recv_words);
     if (rc != DSKGPU_OK) fail(rc, std::string("mg_count: ") + dskgpu_last_error(ctx));
@@ -276,7 +276,10 @@ int dskgpu_group_count(dskgpu_group* g) {
     Barrier bar(g->n);
     std::vector<std::thread> th;
     for (uint32_t r = 1; r < g->n; ++r) th.emplace_back(rank_body, g, r, &bar);
+    int caller_dev = -1;
+    (void)hipGetDevice(&caller_dev);                 // rank 0 runs on the caller's thread: its current device is put back
     rank_body(g, 0, &bar);
+    if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
     for (auto& t : th) t.join();
     for (uint32_t r = 0; r < g->n; ++r)
         if (g->rc[r] != DSKGPU_OK) return group_fail(g, g->rc[r], "rank " + std::to_string(r) + ": " + g->rank_err[r]);

@@ -5,6 +5,8 @@
 #include "../../include/dskgpu.h"
 #include <sys/time.h>
 #include <algorithm>
+#include <thread>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 
@@ -70,15 +72,25 @@ public:
         const uint32_t N = dskgpu_group_size(grp_);
         uint32_t r = 0;
         for (uint32_t i = 1; i < N; ++i) if (pushed_[i] < pushed_[r]) r = i;
+        // one feeder thread per rank: the pieces go to their GPUs at the same time (every rank has its own pinned staging
+        // buffers, stream and PCIe link); fed in turn from one thread, N GPUs took N times one GPU's push
+        struct Piece { uint32_t rank; size_t beg, end; int rc; };
+        std::vector<Piece> pieces;
         size_t beg = 0;
         for (uint32_t i = 0; i < N && beg < n; ++i, r = (r + 1) % N) {
             size_t end = i + 1 == N ? n : std::max(beg, n * (i + 1) / N);
             while (end < n && (end == 0 || data[end - 1] != '\n')) ++end;          // a piece ends after a separator: k-mers never span pieces
             if (end == beg) continue;
-            ckr(r, dskgpu_push_reads(dskgpu_group_ctx(grp_, r), data + beg, end - beg));
+            pieces.push_back({r, beg, end, DSKGPU_OK});
             pushed_[r] += end - beg;
             beg = end;
         }
+        std::vector<std::thread> th;
+        auto feed = [&](Piece& pc) { pc.rc = dskgpu_push_reads(dskgpu_group_ctx(grp_, pc.rank), data + pc.beg, pc.end - pc.beg); };
+        for (size_t i = 1; i < pieces.size(); ++i) th.emplace_back(feed, std::ref(pieces[i]));
+        if (!pieces.empty()) feed(pieces[0]);
+        for (auto& t : th) t.join();
+        for (Piece& pc : pieces) ckr(pc.rank, pc.rc);
     }
     void nextBank() override { if (!grp_) ck(dskgpu_next_bank(ctx_)); }      // (banks only matter to the per-bank modes: one GPU)
     void finish() override {

@@ -90,7 +90,7 @@ class ShardedCounter:
         self.stage.mg_set_table(self.table)
 
     def count(self) -> None:
-        if self.balance and self.table is None:      # once per read set (call rebalance() again after new reads)
+        if self.balance:                             # part of every count, like the reference's repartition step inside execute()
             self.rebalance()
         self.send, counts = scatter_records(self.stage, self.send, self.device)
         out, rcounts = exchange(self.send, counts, self.group, self.recv)
