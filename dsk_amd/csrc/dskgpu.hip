@@ -101,8 +101,12 @@ struct Tuning {
     }
 };
 
+// state of a per-bank count in steps (banks_begin .. banks_finish below)
+struct BankJob { dskgpu_config cfg; const uint8_t* base; u64 total; std::vector<u64> ends; u64 nu, tot_kmers; u32 passes, retries; bool active = false; };
+
 struct dskgpu_ctx {
     dskgpu_config cfg{};
+    BankJob bank_job{};
     Tuning tune;
     int W = 1;
     int words_out = 1;
@@ -1549,46 +1553,65 @@ int sk_count(dskgpu_ctx* ctx, const u64* d_rec, u64 recv_words) {
 namespace {
 
 // Multi-bank count: every bank is counted on its own (all distinct k-mers kept), the per-bank rows are
-// united and sorted by k-mer, and k_merge_banks applies the solidity kind / builds the histograms.
-template <int W>
-int run_banks(dskgpu_ctx* ctx) {
+// united and sorted by k-mer, and k_merge_banks applies the solidity kind / builds the histograms.  In steps, so that the
+// in-process group (group.hip) can put its own count -- scatter, exchange, mg_count -- between them:
+//   banks_begin   the per-bank counts keep every k-mer (abundance window 1 .. max, rows unsorted); the union is empty
+//   banks_select  the context's read stream = bank b of the stream it was given (or all of it again: b = ~0u)
+//   banks_add     the rows of the count just finished join the union as bank b
+//   banks_finish  configuration and read stream restored; union sorted by k-mer, merged -> the result of the context
+
+u32 banks_of(dskgpu_ctx* ctx) {
     std::vector<u64> ends = ctx->bank_ends;
     if (ends.empty() || ends.back() < ctx->n_bytes) ends.push_back(ctx->n_bytes);
-    const u32 B = (u32)ends.size();
-    if (B > 32) return fail(ctx, DSKGPU_E_ARG, "at most 32 banks are supported by the solidity kinds");
-    const dskgpu_config saved = ctx->cfg;
-    const uint8_t* base = ctx->d_reads; const u64 total = ctx->n_bytes;
-    // the per-bank counts run with their own thresholds and read range: whatever way this function is left
-    // (also the early returns of CK), the context gets its configuration and its read stream back
-    struct Restore {
-        dskgpu_ctx* c; dskgpu_config cfg; const uint8_t* reads; u64 n; bool armed = true;
-        void now() { if (armed) { c->cfg = cfg; c->d_reads = reads; c->n_bytes = n; armed = false; } }
-        ~Restore() { now(); }
-    } restore{ctx, saved, base, total};
+    return (u32)ends.size();
+}
+int banks_begin(dskgpu_ctx* ctx) {
+    BankJob& j = ctx->bank_job;
+    j.ends = ctx->bank_ends;
+    if (j.ends.empty() || j.ends.back() < ctx->n_bytes) j.ends.push_back(ctx->n_bytes);
+    if (j.ends.size() > 32) return fail(ctx, DSKGPU_E_ARG, "at most 32 banks are supported by the solidity kinds");
+    j.cfg = ctx->cfg; j.base = ctx->d_reads; j.total = ctx->n_bytes;
+    j.nu = 0; j.tot_kmers = 0; j.passes = 1; j.retries = 0; j.active = true;
     ctx->cfg.abundance_min = 1; ctx->cfg.abundance_max = 0xFFFFFFFFu; ctx->cfg.flags |= DSKGPU_F_NO_SORT;
-    u64 nu = 0, tot_kmers = 0; u32 passes = 1, retries = 0;
-    int rc = DSKGPU_OK;
-    for (u32 b = 0; b < B && rc == DSKGPU_OK; ++b) {
-        const u64 beg = b ? ends[b - 1] : 0;
-        ctx->d_reads = base + beg; ctx->n_bytes = ends[b] - beg;
-        rc = run_pipeline<W>(ctx, true, nullptr, 0);
-        if (rc) break;
-        const u64 n = ctx->n_rows;
-        tot_kmers += ctx->stats.n_kmers; passes = std::max<u32>(passes, (u32)ctx->stats.n_passes); retries += ctx->stats.n_retries;
-        bool nomem = ctx->u_val.ensure_keep((nu + n + 1) * 8, nu * 8, ctx->stream) != 0;
-        for (int x = 0; x < W; ++x) nomem = nomem || ctx->u_w[x].ensure_keep((nu + n + 1) * 8, nu * 8, ctx->stream) != 0;
-        if (nomem) { rc = fail(ctx, DSKGPU_E_NOMEM, "bank rows"); break; }
-        if (n) {
-            for (int x = 0; x < W; ++x)
-                CK(hipMemcpyAsync(ctx->u_w[x].as<u64>() + nu, ctx->res_w[x], n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-            hipLaunchKernelGGL(k_pack_bank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->u_val.as<u64>() + nu, ctx->res_ab, n, b);
-            CK(hipStreamSynchronize(ctx->stream));
-        }
-        nu += n;
+    return DSKGPU_OK;
+}
+void banks_select(dskgpu_ctx* ctx, u32 b) {
+    BankJob& j = ctx->bank_job;
+    if (!j.active) return;
+    if (b >= j.ends.size()) { ctx->d_reads = j.base; ctx->n_bytes = j.total; }
+    else { const u64 beg = b ? j.ends[b - 1] : 0; ctx->d_reads = j.base + beg; ctx->n_bytes = j.ends[b] - beg; }
+    ctx->enc_fresh = false; ctx->sk_prepared = false;
+}
+void banks_abort(dskgpu_ctx* ctx) {      // (an error inside a per-bank count: the context gets its configuration and its read stream back)
+    BankJob& j = ctx->bank_job;
+    if (!j.active) return;
+    ctx->cfg = j.cfg; ctx->d_reads = j.base; ctx->n_bytes = j.total; j.active = false;
+}
+template <int W>
+int banks_add(dskgpu_ctx* ctx, u32 b) {
+    BankJob& j = ctx->bank_job;
+    const u64 n = ctx->n_rows, nu = j.nu;
+    j.tot_kmers += ctx->stats.n_kmers; j.passes = std::max<u32>(j.passes, (u32)ctx->stats.n_passes); j.retries += ctx->stats.n_retries;
+    bool nomem = ctx->u_val.ensure_keep((nu + n + 1) * 8, nu * 8, ctx->stream) != 0;
+    for (int x = 0; x < W; ++x) nomem = nomem || ctx->u_w[x].ensure_keep((nu + n + 1) * 8, nu * 8, ctx->stream) != 0;
+    if (nomem) return fail(ctx, DSKGPU_E_NOMEM, "bank rows");
+    if (n) {
+        for (int x = 0; x < W; ++x)
+            CK(hipMemcpyAsync(ctx->u_w[x].as<u64>() + nu, ctx->res_w[x], n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_pack_bank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->u_val.as<u64>() + nu, ctx->res_ab, n, b);
+        CK(hipStreamSynchronize(ctx->stream));
     }
-    restore.now();
-    if (rc) return rc;
+    j.nu += n;
+    return DSKGPU_OK;
+}
+template <int W>
+int banks_finish(dskgpu_ctx* ctx) {
+    BankJob& j = ctx->bank_job;
+    const u32 B = (u32)j.ends.size();
+    const u64 nu = j.nu, total = j.total, tot_kmers = j.tot_kmers; const u32 passes = j.passes, retries = j.retries;
+    banks_abort(ctx);                          // configuration and read stream back
     ctx->have_result = false;
+    int rc = DSKGPU_OK;
     if (nu >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "too many distinct k-mers over the banks for the merge");
     // ---- sort the union by k-mer
     CK(ctx->s_w[0].ensure((nu + 1) * 8)); CK(ctx->s_val.ensure((nu + 1) * 8));
@@ -1655,8 +1678,35 @@ int run_banks(dskgpu_ctx* ctx) {
     ctx->have_result = true;
     return DSKGPU_OK;
 }
+template <int W>
+int run_banks(dskgpu_ctx* ctx) {
+    int rc = banks_begin(ctx);
+    if (rc) return rc;
+    const u32 B = (u32)ctx->bank_job.ends.size();
+    for (u32 b = 0; b < B; ++b) {
+        banks_select(ctx, b);
+        if ((rc = run_pipeline<W>(ctx, true, nullptr, 0)) || (rc = banks_add<W>(ctx, b))) { banks_abort(ctx); return rc; }
+    }
+    return banks_finish<W>(ctx);
+}
 
 }  // namespace
+
+// ---- the same steps for group.hip (one library, not part of the C-ABI)
+__attribute__((visibility("hidden"))) bool dskgpu_i_per_bank(dskgpu_ctx* ctx) {
+    const bool banks = ctx->bank_ends.size() > 1 || (!ctx->bank_ends.empty() && ctx->bank_ends.back() < ctx->n_bytes);
+    return banks && (ctx->cfg.solidity_kind != DSKGPU_SOLIDITY_SUM || (ctx->cfg.flags & DSKGPU_F_HISTO2D));
+}
+__attribute__((visibility("hidden"))) uint32_t dskgpu_i_banks(dskgpu_ctx* ctx) { return banks_of(ctx); }
+__attribute__((visibility("hidden"))) int dskgpu_i_banks_begin(dskgpu_ctx* ctx) { return banks_begin(ctx); }
+__attribute__((visibility("hidden"))) void dskgpu_i_banks_select(dskgpu_ctx* ctx, uint32_t b) { banks_select(ctx, b); }
+__attribute__((visibility("hidden"))) void dskgpu_i_banks_abort(dskgpu_ctx* ctx) { banks_abort(ctx); }
+__attribute__((visibility("hidden"))) int dskgpu_i_banks_add(dskgpu_ctx* ctx, uint32_t b) {
+    return ctx->W == 1 ? banks_add<1>(ctx, b) : ctx->W == 2 ? banks_add<2>(ctx, b) : banks_add<4>(ctx, b);
+}
+__attribute__((visibility("hidden"))) int dskgpu_i_banks_finish(dskgpu_ctx* ctx) {
+    return ctx->W == 1 ? banks_finish<1>(ctx) : ctx->W == 2 ? banks_finish<2>(ctx) : banks_finish<4>(ctx);
+}
 
 // =============================================================== C-ABI
 extern "C" {

@@ -26,6 +26,15 @@
 
 #include "../../include/dskgpu.h"
 
+// the per-bank steps of dskgpu.hip (same library, not part of the C-ABI): see "Multi-bank count" there
+bool dskgpu_i_per_bank(dskgpu_ctx* ctx);
+uint32_t dskgpu_i_banks(dskgpu_ctx* ctx);
+int dskgpu_i_banks_begin(dskgpu_ctx* ctx);
+void dskgpu_i_banks_select(dskgpu_ctx* ctx, uint32_t b);
+void dskgpu_i_banks_abort(dskgpu_ctx* ctx);
+int dskgpu_i_banks_add(dskgpu_ctx* ctx, uint32_t b);
+int dskgpu_i_banks_finish(dskgpu_ctx* ctx);
+
 namespace {
 
 struct RcclApi {
@@ -142,6 +151,15 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
         const int rc = dskgpu_mg_set_table(ctx, g->table.data());
         if (rc != DSKGPU_OK) fail(rc, std::string("mg_set_table: ") + dskgpu_last_error(ctx));
     }
+    // ---- per-bank modes (-solidity-kind other than sum, -histo2D): every bank goes through steps 1-3 on its own -- with the ONE
+    // repartition table built above from all the reads, so a k-mer has the same owner in every bank -- and joins the rank's union
+    // of per-bank rows; the rank then applies the solidity kind to the k-mers it owns (banks_finish), exactly as one GPU does.
+    const bool per_bank = dskgpu_i_per_bank(ctx);
+    const uint32_t nbanks = per_bank ? dskgpu_i_banks(ctx) : 1u;
+    if (per_bank && g->rc[r] == DSKGPU_OK) { const int rc = dskgpu_i_banks_begin(ctx); if (rc != DSKGPU_OK) fail(rc, std::string("banks: ") + dskgpu_last_error(ctx)); }
+    struct Unwind { dskgpu_ctx* c; bool on; ~Unwind() { if (on) dskgpu_i_banks_abort(c); } } unwind{ctx, per_bank};      // (whatever way the body is left)
+  for (uint32_t bank = 0; bank < nbanks; ++bank) {
+    if (per_bank) { dskgpu_i_banks_select(ctx, bank); for (auto& c : g->counts[r]) c = 0; }
     // ---- step 1: this rank's records, grouped by owner
     if (g->rc[r] == DSKGPU_OK) {
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -189,8 +207,18 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
     if (g->rc[r] == DSKGPU_OK && hipStreamSynchronize(g->stream[r]) != hipSuccess) fail(DSKGPU_E_DEVICE, "exchange: stream synchronize");
     if (bar->wait(failed())) return;                 // nobody overwrites a send buffer a peer still reads
     // ---- step 3: count what this rank owns
-    const int rc = dskgpu_mg_count(ctx, recv_words ? g->recv[r].p : nullptr, recv_words);
+    int rc = dskgpu_mg_count(ctx, recv_words ? g->recv[r].p : nullptr, recv_words);
     if (rc != DSKGPU_OK) fail(rc, std::string("mg_count: ") + dskgpu_last_error(ctx));
+    if (per_bank) {
+        if (g->rc[r] == DSKGPU_OK && (rc = dskgpu_i_banks_add(ctx, bank)) != DSKGPU_OK) fail(rc, std::string("banks: ") + dskgpu_last_error(ctx));
+        if (bar->wait(failed())) return;             // (the next bank re-uses the send buffers and the counts matrix)
+    }
+  }
+    if (per_bank) {
+        unwind.on = false;
+        const int rc = dskgpu_i_banks_finish(ctx);
+        if (rc != DSKGPU_OK) fail(rc, std::string("banks: ") + dskgpu_last_error(ctx));
+    }
 }
 
 }  // namespace
@@ -299,6 +327,20 @@ int dskgpu_group_histogram(const dskgpu_group* g, uint64_t* out, uint32_t nbins)
         const int rc = dskgpu_histogram(g->ctx[r], one.data(), nbins);
         if (rc != DSKGPU_OK) return rc;
         for (uint32_t i = 0; i < nbins; ++i) out[i] += one[i];
+    }
+    return DSKGPU_OK;
+}
+
+int dskgpu_group_histogram2d(const dskgpu_group* g, uint64_t* out, uint32_t nrows) {
+    if (!g || !out) return DSKGPU_E_ARG;
+    if (!g->have_result) return DSKGPU_E_STATE;
+    if (nrows != g->histo_max + 1) return DSKGPU_E_ARG;
+    std::vector<uint64_t> one((size_t)nrows * 11);
+    std::memset(out, 0, (size_t)nrows * 11 * 8);
+    for (uint32_t r = 0; r < g->n; ++r) {
+        const int rc = dskgpu_histogram2d(g->ctx[r], one.data(), nrows);
+        if (rc != DSKGPU_OK) return rc;
+        for (size_t i = 0; i < one.size(); ++i) out[i] += one[i];
     }
     return DSKGPU_OK;
 }

@@ -86,7 +86,7 @@ EXPORTS = [
     "dskgpu_num_partitions", "dskgpu_partition_size", "dskgpu_partition_copy", "dskgpu_result_device",
     "dskgpu_stage_times", "dskgpu_k_encode", "dskgpu_k_enumerate", "dskgpu_k_minimizers",
     "dskgpu_group_create", "dskgpu_group_destroy", "dskgpu_group_last_error", "dskgpu_group_size", "dskgpu_group_ctx",
-    "dskgpu_group_transport", "dskgpu_group_count", "dskgpu_group_exchanged_words", "dskgpu_group_histogram",
+    "dskgpu_group_transport", "dskgpu_group_count", "dskgpu_group_exchanged_words", "dskgpu_group_histogram", "dskgpu_group_histogram2d",
     "dskgpu_group_get_stats", "dskgpu_group_num_partitions", "dskgpu_group_partition_size", "dskgpu_group_partition_copy",
 ]
 
@@ -161,6 +161,7 @@ def load_library():
     lib.dskgpu_group_exchanged_words.argtypes = [vp]
     lib.dskgpu_group_exchanged_words.restype = u64
     lib.dskgpu_group_histogram.argtypes = [vp, C.POINTER(u64), u32]
+    lib.dskgpu_group_histogram2d.argtypes = [vp, C.POINTER(u64), u32]
     lib.dskgpu_group_get_stats.argtypes = [vp, C.POINTER(_Stats)]
     lib.dskgpu_group_num_partitions.argtypes = [vp]
     lib.dskgpu_group_num_partitions.restype = u32

@@ -33,8 +33,6 @@ public:
         g.solidity_kind = c.solidity_kind; g.solidity_custom = c.solidity_custom; g.minimizer_size = c.minimizer_size;
         cfg_ = c;
         if (c.nb_gpus > 1) {
-            if (c.solidity_kind != DSKGPU_SOLIDITY_SUM || c.histo2d)
-                throw Exception("-solidity-kind other than sum and -histo2D count the banks one by one: use -nb-gpus 1");
             const int ndev = dskgpu_device_count();
             if (ndev < 1) throw Exception("GPU engine: no HIP device");
             std::vector<int32_t> devs(c.nb_gpus);
@@ -92,7 +90,10 @@ public:
         for (auto& t : th) t.join();
         for (Piece& pc : pieces) ckr(pc.rank, pc.rc);
     }
-    void nextBank() override { if (!grp_) ck(dskgpu_next_bank(ctx_)); }      // (banks only matter to the per-bank modes: one GPU)
+    void nextBank() override {
+        if (!grp_) { ck(dskgpu_next_bank(ctx_)); return; }
+        for (uint32_t r = 0; r < dskgpu_group_size(grp_); ++r) ckr(r, dskgpu_next_bank(dskgpu_group_ctx(grp_, r)));      // every rank's share of the bank ends here
+    }
     void finish() override {
         if (!grp_) { ck(dskgpu_count(ctx_)); return; }
         const int rc = dskgpu_group_count(grp_);
@@ -105,9 +106,10 @@ public:
     }
     void histogram2d(std::vector<uint64_t>& h) override {
         h.clear();
-        if (!cfg_.histo2d || grp_) return;
+        if (!cfg_.histo2d) return;
         h.assign((size_t)(cfg_.histo_max + 1) * 11, 0);
-        if (dskgpu_histogram2d(ctx_, h.data(), cfg_.histo_max + 1) != DSKGPU_OK) h.clear();   // single bank: nothing to cross
+        const int rc = grp_ ? dskgpu_group_histogram2d(grp_, h.data(), cfg_.histo_max + 1) : dskgpu_histogram2d(ctx_, h.data(), cfg_.histo_max + 1);
+        if (rc != DSKGPU_OK) h.clear();   // single bank: nothing to cross
     }
     uint32_t numPartitions() override { return grp_ ? dskgpu_group_num_partitions(grp_) : dskgpu_num_partitions(ctx_); }
     uint64_t partitionSize(uint32_t p) override { return grp_ ? dskgpu_group_partition_size(grp_, p) : dskgpu_partition_size(ctx_, p); }

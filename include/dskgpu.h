@@ -208,6 +208,10 @@ const char* dskgpu_group_transport(const dskgpu_group* g);     /* "rccl" or "cop
 int dskgpu_group_count(dskgpu_group* g);
 uint64_t dskgpu_group_exchanged_words(const dskgpu_group* g);  /* 8-byte words that changed rank in the last count */
 int dskgpu_group_histogram(const dskgpu_group* g, uint64_t* out, uint32_t nbins);
+/* Per-bank modes (solidity_kind != sum, DSKGPU_F_HISTO2D; banks = dskgpu_next_bank on EVERY rank's context at the same
+ * points of the stream): dskgpu_group_count counts the banks one by one with one repartition table, every rank applies the
+ * solidity kind to the k-mers it owns; the 2-D histogram is the element-wise sum (README.md:98-102). */
+int dskgpu_group_histogram2d(const dskgpu_group* g, uint64_t* out, uint32_t nrows);
 int dskgpu_group_get_stats(const dskgpu_group* g, dskgpu_stats* out);   /* sums over the ranks */
 uint32_t dskgpu_group_num_partitions(const dskgpu_group* g);
 uint64_t dskgpu_group_partition_size(const dskgpu_group* g, uint32_t P);

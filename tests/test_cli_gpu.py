@@ -88,9 +88,30 @@ def test_nb_gpus_with_fewer_reads_than_ranks(bins, tmp_path):
     subprocess.check_call([bins["dsk"], "-file", f"{G}/shortread.fasta", "-kmer-size", "16", "-out", "s16", "-nb-gpus", "2", "-verbose", "0"], cwd=tmp)
     subprocess.check_call([bins["dsk2ascii"], "-file", "s16", "-out", "s16.txt", "-verbose", "0"], cwd=tmp)
     assert os.path.getsize(os.path.join(tmp, "s16.txt")) == 0
-    r = subprocess.run([bins["dsk"], "-file", f"{G}/c1.fasta.gz,{G}/c2.fasta.gz", "-kmer-size", "27", "-solidity-kind", "min", "-out", "bad", "-nb-gpus", "2", "-verbose", "0"],
-                       cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode == 1 and b"EXCEPTION:" in r.stderr and b"-nb-gpus 1" in r.stderr      # per-bank modes are single-GPU
+
+
+@pytest.mark.parametrize("ngpus", [2, 4])
+def test_nb_gpus_per_bank_modes(bins, tmp_path, ngpus):
+    """-solidity-kind / -solidity-custom / -histo2D over the comma-separated banks (CHANGELOG.md:22, README.md:98-102) with the
+    k-mer space sharded over N ranks: every bank is exchanged and counted on its own with ONE repartition table, every rank
+    applies the solidity kind to the k-mers it owns.  The rows (put in k-mer order: the partitions interleave), the histogram
+    and the 2-D histogram must equal the one-GPU run's."""
+    from tests.test_host_cli import G, h5_histo
+    tmp = str(tmp_path)
+    files = ",".join(f"{G}/c{i}.fasta.gz" for i in (1, 2, 3))
+    val = lambda l: int(l.split()[0].translate(bytes.maketrans(b"ACTG", b"0123")), 4)
+    for tag, extra in (("min", ["-solidity-kind", "min"]), ("custom", ["-solidity-kind", "custom", "-solidity-custom", "101"]), ("h2d", ["-histo2D", "1", "-histo", "1"])):
+        got = {}
+        for n in (1, ngpus):
+            name = f"{tag}_{n}"
+            r = subprocess.run([bins["dsk"], "-file", files, "-kmer-size", "27", "-abundance-min", "2", *extra, "-out", name, "-nb-gpus", str(n), "-verbose", "0"],
+                               cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0, r.stderr
+            subprocess.check_call([bins["dsk2ascii"], "-file", name, "-out", name + ".txt", "-verbose", "0"], cwd=tmp)
+            lines = open(os.path.join(tmp, name + ".txt"), "rb").read().splitlines()
+            lines.sort(key=val)
+            got[n] = (lines, h5_histo(name + ".h5", tmp), open(os.path.join(tmp, name + ".histo2D")).read() if tag == "h2d" else "")
+        assert len(got[1][0]) > 10 and got[1] == got[ngpus]
 
 
 def test_abundance_min_auto_on_gpu(bins, tmp_path, oracle):
