@@ -21,6 +21,10 @@ def bins():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "dsk_amd", "host"), "bin/dsk2ascii", "bin/libdskhost.a"],
                           stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "host")], stdout=subprocess.DEVNULL)
+    if os.environ.get("DSK_TEST_ASAN"):      # the same suite on the AddressSanitizer + UBSan build of the host layer and the oracle (make -C tests/host asan)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "host"), "asan"], stdout=subprocess.DEVNULL)
+        return {"dsk": os.path.join(ROOT, "tests", "host", "asan", "dsk_cpu_check"),
+                "dsk2ascii": os.path.join(ROOT, "tests", "host", "asan", "dsk2ascii")}
     return {"dsk": os.path.join(ROOT, "tests", "host", "dsk_cpu_check"),
             "dsk2ascii": os.path.join(ROOT, "dsk_amd", "host", "bin", "dsk2ascii")}
 
