@@ -77,26 +77,35 @@ def cpu_baseline(reads_u8, read_len, n_sample_reads, k, target_s=15.0):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libdsk_oracle.so"])
     oracle = Oracle(so)
     total_reads = reads_u8.numel() // (read_len + 1)
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
     probe_reads = min(n_sample_reads, total_reads)
     sample = reads_u8[: probe_reads * (read_len + 1)].cpu().numpy()
-    t0 = time.perf_counter()
-    r = oracle.count(sample, k, threads=cores)
-    dt = time.perf_counter() - t0
+    # the restatement does not scale to every core of a 256-thread host (its scatter and sort are memory-bound): the thread count
+    # with the best rate on the probe is the one used and reported
+    cores, dt = ncpu, None
+    for t in sorted({ncpu, min(ncpu, 64), min(ncpu, 32)}, reverse=True):
+        t0 = time.perf_counter()
+        oracle.count_only(sample, k, threads=t)
+        d = time.perf_counter() - t0
+        if dt is None or d < dt:
+            cores, dt = t, d
+
+    class _R:      # (total, distinct) of a count_only call
+        def __init__(self, td): self.total, self.distinct = td
     n_reads = probe_reads
     # grow the sample towards target_s (bounded by the workload and by 16 GiB of k-mer keys)
     want = int(min(total_reads, probe_reads * max(1.0, target_s / max(dt, 1e-3)), 16 * 2**30 // (8 * (read_len - k + 1))))
     if want > probe_reads * 2:
         n_reads = want
         sample = reads_u8[: n_reads * (read_len + 1)].cpu().numpy()
-        t0 = time.perf_counter()
-        r = oracle.count(sample, k, threads=cores)
-        dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    r = _R(oracle.count_only(sample, k, threads=cores))
+    dt = time.perf_counter() - t0
     # the same code on ONE thread, on a sample sized for a few seconds (DSK v1's published rates are 1-thread)
     n1 = max(1000, min(n_reads, int(n_reads * 6.0 / max(dt, 1e-3) / max(cores, 1)) * 4))
     s1 = reads_u8[: n1 * (read_len + 1)].cpu().numpy()
     t0 = time.perf_counter()
-    r1 = oracle.count(s1, k, threads=1)
+    r1 = _R(oracle.count_only(s1, k, threads=1))
     dt1 = time.perf_counter() - t0
     return {
         "value": r.distinct / dt,

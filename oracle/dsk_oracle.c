@@ -12,7 +12,9 @@
 #include <string.h>
 #include <zlib.h>
 
-#define PART_BITS 8
+/* 4096 value-prefix partitions: canonical k-mers are densest at small values (up to twice the mean), so partitions far
+ * outnumber the threads and are handed out by a ticket -- with 256 partitions on 256 threads the slowest one set the pace */
+#define PART_BITS 12
 #define NPART (1 << PART_BITS)
 
 struct dsko_result {
@@ -33,6 +35,9 @@ static void init_code(void) {
     g_code['T'] = g_code['t'] = 2;
     g_code['G'] = g_code['g'] = 3;
 }
+
+#include <time.h>
+static double dsko_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 #define KT uint64_t
 #define SFX 64

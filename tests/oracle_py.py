@@ -107,6 +107,17 @@ class Oracle:
 
         return OracleResult(k, total, lo, hi, ab, hist, w2, w3)
 
+    def count_only(self, stream: np.ndarray, k: int, threads: int = 4):
+        """The count alone -> (total k-mers, distinct k-mers): what bench.py's cpu_baseline times (no copy of the rows to numpy)."""
+        stream = np.ascontiguousarray(stream, dtype=np.uint8)
+        h = self.lib.dsko_count(stream.ctypes.data, len(stream), k, threads)
+        if not h:
+            raise ValueError("bad k")
+        try:
+            return int(self.lib.dsko_total_kmers(h)), int(self.lib.dsko_num_distinct(h))
+        finally:
+            self.lib.dsko_free(h)
+
     def enumerate(self, stream: np.ndarray, k: int):
         stream = np.ascontiguousarray(stream, dtype=np.uint8)
         n = len(stream)
