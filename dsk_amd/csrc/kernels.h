@@ -414,64 +414,91 @@ __device__ __forceinline__ void sk_key(const u64* r, int j, int k, K2& out) { ou
 template <int W> __device__ __forceinline__ void sk_key(const u64*, int, int, KN<W>&) {}      // (records carry k <= 64 only)
 
 // candidate records per tile: 3072 for 16384 one-word key slots (more than fit on average -- the tile takes the prefix that
-// fits and is ~100 % full; 2048 candidates: 7.4 -> 6.5 ms), 1024 for 8192 two-word slots
-template <int W> struct RecTile { static constexpr int NR = W == 1 ? 3 * SC_NT : SC_NT; };
+// fits and is ~100 % full; 2048 candidates: 7.4 -> 6.5 ms), 1024 for 8192 two-word slots.
+// Thread t looks at candidates t * RPT .. t * RPT + RPT - 1 (requested from HBM a tile ahead: RecPre) and builds the keys of the
+// KPT CONSECUTIVE slots t * KPT ..: the candidates that fit are staged densely (zero-length pad records dropped), every record
+// that covers a slot q * KPT notes (record, k-mer index) in first[q], and thread q walks on from there -- no per-slot map.
+template <int W> struct RecTile { static constexpr int NR = W == 1 ? 3 * SC_NT : SC_NT; static constexpr int RPT = NR / SC_NT;
+                                  static constexpr int RS = W == 1 ? 2 : 3; };          // staged words per record (W = 1: k <= 32, two words)
+template <int W> struct RecPre { u64 w[RecTile<W>::RPT * RecTile<W>::RS]; };
 template <int W>
-__device__ __forceinline__ u32 tile_keys_records(const u64* __restrict__ rec, u32 R, u64 r0, u64 rend, int k,
+__device__ __forceinline__ void rec_prefetch(RecPre<W>& pre, const u64* __restrict__ rec, u32 R, u64 r0, u64 rend) {
+    constexpr int RPT = RecTile<W>::RPT, RS = RecTile<W>::RS;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const u64 r = r0 + (u64)threadIdx.x * RPT + u;
+        const u64* p = rec + (r < rend ? r : r0) * R;                          // (clamped: unconditional loads; candidates past the end are ignored)
+        pre.w[u * RS] = p[0]; pre.w[u * RS + 1] = p[1];
+        if (RS == 3) pre.w[u * RS + 2] = (R == 3) ? p[2] : 0ull;
+    }
+}
+template <int W>
+__device__ __forceinline__ u32 tile_keys_records(const RecPre<W>& pre, u32 R, u64 r0, u64 rend, int k,
                                                  typename KeyT<W>::T (&h)[Tile<W>::KPT], char* scratch, u32* wsum, u32* taken) {
-    constexpr int KPT = Tile<W>::KPT, KEYS = Tile<W>::KEYS, NR = RecTile<W>::NR, RPT = NR / SC_NT;
-    u64* srec = reinterpret_cast<u64*>(scratch);                             // NR * 3 words
-    unsigned short* smap = reinterpret_cast<unsigned short*>(srec + (size_t)NR * 3);   // KEYS entries
+    constexpr int KPT = Tile<W>::KPT, KEYS = Tile<W>::KEYS, NR = RecTile<W>::NR, RPT = RecTile<W>::RPT, RS = RecTile<W>::RS;
+    u64* srec = reinterpret_cast<u64*>(scratch);                             // NR * RS words
+    unsigned short* first = reinterpret_cast<unsigned short*>(srec + (size_t)NR * RS);   // KEYS / KPT = SC_NT entries
+    u32* info = reinterpret_cast<u32*>(first + SC_NT);                       // (records taken << 16) | keys of the tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    lds_barrier();                                                           // the previous tile's write-out is done with the staging area
-    u32 n[RPT], s = 0;
+    const u64 left = rend - r0;                                              // candidates that exist
+    u32 n[RPT], s = 0;                                                       // s = (records with keys << 16) | keys, over this thread's candidates
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
         const u32 l = (u32)tid * RPT + u;
-        const u64 r = r0 + l;
-        n[u] = 0;
-        if (r < rend) {
-            const u64* p = rec + r * R;
-            const u64 a = p[0], b = p[1], c = (R == 3) ? p[2] : 0ull;
-            srec[l * 3] = a; srec[l * 3 + 1] = b; srec[l * 3 + 2] = c;
-            n[u] = (u32)((R == 3 ? c : b) & 0xFFu);
-        }
-        s += n[u];
+        n[u] = l < left ? (u32)(pre.w[u * RS + ((RS == 3 && R == 3) ? 2 : 1)] & 0xFFu) : 0u;
+        s += n[u] + (n[u] ? 0x10000u : 0u);
     }
+    // (sums: keys <= 16 * NR = 49152 < 2^16, records <= NR)
     const u32 inc = wave_incl_scan(s);
     if (lane == 63) wsum[wave] = inc;
-    lds_barrier();
-    u32 off = inc - s;
+    lds_barrier();                                                           // ... and the previous tile's write-out is done with the staging area
+    u32 run = inc - s;
 #pragma unroll
-    for (int x = 0; x < SC_NT / 64; ++x) { const u32 v = wsum[x]; if (x < wave) off += v; }
-    // records are taken in order while their keys still fit the tile; (taken << 16 | keys) summed over the block
-    u32 mine = 0, run = off;
-    bool fit[RPT];
+    for (int x = 0; x < SC_NT / 64; ++x) { const u32 v = wsum[x]; if (x < wave) run += v; }
+    // records are taken in order while their keys still fit the tile.  Exactly one candidate position is "the first that is not
+    // taken" (or none: all NR are), and its thread publishes (taken, keys)
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
-        const u64 r = r0 + (u64)tid * RPT + u;
-        fit[u] = r < rend && run + n[u] <= (u32)KEYS;
-        if (fit[u]) { mine += (1u << 16) | n[u]; for (u32 j = 0; j < n[u]; ++j) smap[run + j] = (unsigned short)((((u32)tid * RPT + u) << 4) | j); }
-        run += n[u];
+        const u32 l = (u32)tid * RPT + u;
+        const u32 start = run & 0xFFFFu, dense = run >> 16;
+        const bool exists = l < left;
+        const bool fit = exists && start + n[u] <= (u32)KEYS;
+        if (!fit && start <= (u32)KEYS && (exists || l == left)) *info = (l << 16) | start;
+        if (fit && n[u]) {
+#pragma unroll
+            for (int x = 0; x < RS; ++x) srec[dense * RS + x] = pre.w[u * RS + x];
+            const u32 bnd = (start + KPT - 1) & ~(u32)(KPT - 1);              // slot groups that begin inside this record
+            for (u32 q = bnd; q < start + n[u]; q += KPT) first[q / KPT] = (unsigned short)((dense << 4) | (q - start));
+        }
+        run += n[u] + (n[u] ? 0x10000u : 0u);
+        if (u == RPT - 1 && tid == SC_NT - 1 && fit) *info = ((u32)NR << 16) | (run & 0xFFFFu);
     }
-    lds_barrier();                                                           // everyone has read wsum: reuse it for the second sum
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d);
-    if (lane == 0) wsum[wave] = mine;
     lds_barrier();
-    u32 tot = 0;
-#pragma unroll
-    for (int x = 0; x < SC_NT / 64; ++x) tot += wsum[x];
-    *taken = tot >> 16;
-    const u32 nkeys = tot & 0xFFFFu;
+    const u32 inf = *info;
+    *taken = inf >> 16;
+    const u32 nkeys = inf & 0xFFFFu;
     u32 vm = 0;
+    const u32 slot0 = (u32)tid * KPT;
+    if (slot0 < nkeys) {
+        const u32 e = first[tid];
+        u32 rl = e >> 4, jj = e & 15u;
+        u64 r[3]; r[2] = 0ull;
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-        const u32 slot = (u32)tid + (u32)j * SC_NT;
-        if (slot < nkeys) {
-            const u32 e = smap[slot];
-            sk_key(srec + (e >> 4) * 3, (int)(e & 15u), k, h[j]);
-            vm |= 1u << j;
+        for (int x = 0; x < RS; ++x) r[x] = srec[rl * RS + x];
+        u32 nn = (u32)(r[(RS == 3 && R == 3) ? 2 : 1] & 0xFFu);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            if (slot0 + j < nkeys) {
+                if (jj == nn) {
+                    ++rl; jj = 0;
+#pragma unroll
+                    for (int x = 0; x < RS; ++x) r[x] = srec[rl * RS + x];
+                    nn = (u32)(r[(RS == 3 && R == 3) ? 2 : 1] & 0xFFu);
+                }
+                sk_key(r, (int)jj, k, h[j]);
+                ++jj;
+                vm |= 1u << j;
+            }
         }
     }
     return vm;
@@ -608,11 +635,17 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
         if (SRC == 1 && d.begin < d.end) vma = tile_keys_array<W>(keys, d.begin, d.end, ha);
         lds_barrier();
         if constexpr (SRC == 2) {              // records: `packed` is the record array, the chunk range is in records
-            for (u64 r0 = d.begin; r0 < d.end;) {
-                u32 taken = 0;
-                vma = tile_keys_records<W>(packed, o1.R, r0, d.end, k, ha, smem, wsum, &taken);
-                process(ha, vma);
-                r0 += taken ? taken : 1u;
+            if constexpr (W <= 2) {
+                RecPre<W> pre;
+                if (d.begin < d.end) rec_prefetch<W>(pre, packed, o1.R, d.begin, d.end);
+                for (u64 r0 = d.begin; r0 < d.end;) {
+                    u32 taken = 0;
+                    vma = tile_keys_records<W>(pre, o1.R, r0, d.end, k, ha, smem, wsum, &taken);
+                    rank_and_stage(ha, vma);
+                    r0 += taken ? taken : 1u;
+                    if (r0 < d.end) rec_prefetch<W>(pre, packed, o1.R, r0, d.end);      // the next tile's candidates, requested before this tile's stores
+                    write_out();
+                }
             }
         } else if constexpr (SRC == 0 && W == 1) {
             // one-word keys from the reads.  Thread -> window mapping: lane l of wave w takes the 16 windows ending in half (w >> 3) of
