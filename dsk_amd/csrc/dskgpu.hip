@@ -141,7 +141,10 @@ struct dskgpu_ctx {
     bool sk_slices = false;        // the prepared send layout is slices from a sampled estimate (else exact offsets)
     bool sk_exact = false;         // a slice overflowed on these reads: exact counts from now on
     SkParams sk_sp{};
-    DevBuf sk_sums, sk_cbase, sk_keys, sk_table, sk_load;
+    DevBuf sk_sums, sk_cbase, sk_keys, sk_table, sk_load, sk_sent;
+    u64 h_sk_sent[SK_MAX_OWNERS] = {0};      // k-mers inside the records the last mg_scatter wrote for every owner
+    u64 rec_hint = 0;                        // dskgpu_mg_count_sized: the caller's k-mer total of the records (0 = none)
+    bool rec_sized = false;                  // per-chunk k-mer sums of the records are on the device (k_sk_count ran)
     std::vector<uint8_t> h_table;  // the repartition table in use (SK_BUCKETS owners; default: bucket scaled to the world size)
     bool table_dirty = true;       // h_table not yet copied to sk_table
     std::vector<u32> h_sk_sums; std::vector<u64> h_sk_cbase;
@@ -656,11 +659,40 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     return sort_rows_full_multiword(ctx, n);
 }
 
+// k-mers per chunk of received records (k_sk_count) -> chunk bases for the expansion, and the total.  Needed up front only when
+// the caller did not pass the total (dskgpu_mg_count); otherwise only by paths that expand the records.
+int sk_sizes(dskgpu_ctx* ctx, u64* total_out) {
+    const u64 nrec = ctx->rec_n; const u32 R = ctx->sk_sp.R;
+    u64 nch = std::min<u64>((nrec + SKX_NT - 1) / SKX_NT, (u64)ctx->num_cu * 16);
+    u64 rpc = (nrec + nch - 1) / nch;
+    rpc = (rpc + SKX_NT - 1) / SKX_NT * SKX_NT;
+    nch = (nrec + rpc - 1) / rpc;
+    if (rpc * 16 >= 0xFFFFFFFFull) return fail(ctx, DSKGPU_E_ARG, "too many records per chunk");
+    CK(ctx->sk_sums.ensure(nch * 4)); CK(ctx->sk_cbase.ensure(nch * 8));
+    ctx->h_sk_sums.assign(nch, 0); ctx->h_sk_cbase.assign(nch, 0);
+    hipLaunchKernelGGL(k_sk_count, dim3((unsigned)nch), dim3(SKX_NT), 0, ctx->stream, ctx->rec_src, nrec, R, (u32)rpc, ctx->sk_sums.as<u32>());
+    CKL("k_sk_count");
+    CK(hipMemcpyAsync(ctx->h_sk_sums.data(), ctx->sk_sums.p, nch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    u64 total = 0;
+    for (u64 c = 0; c < nch; ++c) { ctx->h_sk_cbase[c] = total; total += ctx->h_sk_sums[c]; }
+    CK(hipMemcpyAsync(ctx->sk_cbase.p, ctx->h_sk_cbase.data(), nch * 8, hipMemcpyHostToDevice, ctx->stream));
+    ctx->rec_nch = nch; ctx->rec_rpc = rpc; ctx->rec_sized = true;
+    *total_out = total;
+    return DSKGPU_OK;
+}
+
 // records -> dense key array (only when the level-1 scatter cannot read the records itself: exact / multi-pass path)
 template <int W>
 int expand_records(dskgpu_ctx* ctx, u64 total) {
     typedef typename KeyT<W>::T Key;
     if (ctx->rec_expanded) return DSKGPU_OK;
+    if (!ctx->rec_sized) {
+        u64 real = 0;
+        const int e = sk_sizes(ctx, &real);
+        if (e) return e;
+        if (real != total) return fail(ctx, DSKGPU_E_ARG, "dskgpu_mg_count_sized: n_kmers does not match the k-mers inside the records");
+    }
     CK(ctx->sk_keys.ensure((total + 1) * sizeof(Key)));
     hipLaunchKernelGGL(k_sk_expand<W>, dim3((unsigned)ctx->rec_nch), dim3(SKX_NT), 0, ctx->stream, ctx->rec_src, ctx->rec_n, ctx->sk_sp.R,
                        (int)ctx->cfg.kmer_size, (u32)ctx->rec_rpc, ctx->sk_cbase.as<u64>(), ctx->sk_keys.as<Key>());
@@ -1487,15 +1519,18 @@ int sk_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t*
     ctx->marks.clear(); ctx->ev_used = 0;
     ctx->mark("start");
     u32* sc = ctx->scalars.as<u32>();
+    CK(ctx->sk_sent.ensure(SK_MAX_OWNERS * 8));
+    CK(hipMemsetAsync(ctx->sk_sent.p, 0, SK_MAX_OWNERS * 8, ctx->stream));
     if (ctx->sk_slices)
         hipLaunchKernelGGL(k_sk_scatter<true>, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
-                           ctx->mat1.as<u32>(), static_cast<u64*>(d_send), sc + SC_OVF1);
+                           ctx->mat1.as<u32>(), static_cast<u64*>(d_send), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>());
     else
         hipLaunchKernelGGL(k_sk_scatter<false>, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
-                           ctx->mat1.as<u32>(), static_cast<u64*>(d_send), sc + SC_OVF1);
+                           ctx->mat1.as<u32>(), static_cast<u64*>(d_send), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>());
     CKL("k_sk_scatter");
     ctx->mark("mg_scatter");
     if (ctx->sk_slices) CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(ctx->h_sk_sent, ctx->sk_sent.p, SK_MAX_OWNERS * 8, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     ctx->resolve_marks();
     if (ctx->sk_slices && ctx->h_ovf1) {      // a slice overflowed: exact counts for these reads from now on (and right away)
@@ -1510,7 +1545,7 @@ int sk_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t*
 
 // Receiver: records -> dense mixed keys -> the ordinary partition + count over a key array.
 template <int W>
-int sk_count(dskgpu_ctx* ctx, const u64* d_rec, u64 recv_words) {
+int sk_count(dskgpu_ctx* ctx, const u64* d_rec, u64 recv_words, u64 n_kmers_hint) {
     typedef typename KeyT<W>::T Key;
     const u32 R = ctx->sk_sp.R;
     if (recv_words % R) return fail(ctx, DSKGPU_E_ARG, "recv_words is not a whole number of super-k-mer records");
@@ -1518,21 +1553,11 @@ int sk_count(dskgpu_ctx* ctx, const u64* d_rec, u64 recv_words) {
     ctx->marks.clear(); ctx->ev_used = 0;
     ctx->mark("start");
     u64 total = 0;
+    ctx->rec_hint = 0; ctx->rec_sized = false;
     if (nrec) {
-        u64 nch = std::min<u64>((nrec + SKX_NT - 1) / SKX_NT, (u64)ctx->num_cu * 16);
-        u64 rpc = (nrec + nch - 1) / nch;
-        rpc = (rpc + SKX_NT - 1) / SKX_NT * SKX_NT;
-        nch = (nrec + rpc - 1) / rpc;
-        if (rpc * 16 >= 0xFFFFFFFFull) return fail(ctx, DSKGPU_E_ARG, "too many records per chunk");
-        CK(ctx->sk_sums.ensure(nch * 4)); CK(ctx->sk_cbase.ensure(nch * 8));
-        ctx->h_sk_sums.assign(nch, 0); ctx->h_sk_cbase.assign(nch, 0);
-        hipLaunchKernelGGL(k_sk_count, dim3((unsigned)nch), dim3(SKX_NT), 0, ctx->stream, d_rec, nrec, R, (u32)rpc, ctx->sk_sums.as<u32>());
-        CKL("k_sk_count");
-        CK(hipMemcpyAsync(ctx->h_sk_sums.data(), ctx->sk_sums.p, nch * 4, hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipStreamSynchronize(ctx->stream));
-        for (u64 c = 0; c < nch; ++c) { ctx->h_sk_cbase[c] = total; total += ctx->h_sk_sums[c]; }
-        CK(hipMemcpyAsync(ctx->sk_cbase.p, ctx->h_sk_cbase.data(), nch * 8, hipMemcpyHostToDevice, ctx->stream));
-        ctx->rec_src = d_rec; ctx->rec_n = nrec; ctx->rec_nch = nch; ctx->rec_rpc = rpc; ctx->rec_expanded = false;
+        ctx->rec_src = d_rec; ctx->rec_n = nrec; ctx->rec_expanded = false;
+        if (n_kmers_hint) { total = n_kmers_hint; ctx->rec_hint = n_kmers_hint; }      // the senders counted while they wrote the records
+        else { const int e = sk_sizes(ctx, &total); if (e) return e; }
     } else {
         ctx->rec_src = nullptr; ctx->rec_n = 0;
         CK(ctx->sk_keys.ensure(sizeof(Key)));
@@ -1543,6 +1568,10 @@ int sk_count(dskgpu_ctx* ctx, const u64* d_rec, u64 recv_words) {
     if (!ctx->rec_src) return run_pipeline<W>(ctx, false, ctx->sk_keys.as<Key>(), 0);
     const int rc = run_pipeline<W>(ctx, false, nullptr, total);      // nullptr: keys come from ctx->rec_src
     ctx->rec_src = nullptr;
+    if (rc == DSKGPU_OK && ctx->rec_hint && ctx->stats.n_kmers != ctx->rec_hint) {
+        ctx->have_result = false;
+        return fail(ctx, DSKGPU_E_ARG, "dskgpu_mg_count_sized: n_kmers does not match the k-mers inside the records");
+    }
     return rc;
 }
 
@@ -1767,7 +1796,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
                       &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
                       &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->srt_k2, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
                       &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,
-                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load};
+                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i) { ctx->out_w[i].release(); ctx->srt_w[i].release(); ctx->acc_w[i].release(); ctx->u_w[i].release(); ctx->s_w[i].release(); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -1922,7 +1951,9 @@ int dskgpu_mg_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, ui
     CK(hipSetDevice(ctx->cfg.device));
     if (ctx->sk_mode) return sk_scatter(ctx, d_send, capacity_words, send_words);
     if (capacity_words < dskgpu_mg_send_capacity_words(ctx)) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
-    return ctx->W == 1 ? mg_scatter_impl<1>(ctx, d_send, send_words) : ctx->W == 2 ? mg_scatter_impl<2>(ctx, d_send, send_words) : mg_scatter_impl<4>(ctx, d_send, send_words);
+    const int rc = ctx->W == 1 ? mg_scatter_impl<1>(ctx, d_send, send_words) : ctx->W == 2 ? mg_scatter_impl<2>(ctx, d_send, send_words) : mg_scatter_impl<4>(ctx, d_send, send_words);
+    if (rc == DSKGPU_OK) for (u32 o = 0; o < ctx->cfg.world_size; ++o) ctx->h_sk_sent[o] = send_words[o] / (u64)ctx->W;
+    return rc;
 }
 
 int dskgpu_mg_sample(dskgpu_ctx* ctx, uint64_t* loads) {
@@ -1992,12 +2023,21 @@ int dskgpu_mg_set_table(dskgpu_ctx* ctx, const uint8_t* table) {
     return DSKGPU_OK;
 }
 
-int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words) {
+int dskgpu_mg_sent_kmers(dskgpu_ctx* ctx, uint64_t* kmers) {
+    if (!ctx || !kmers) return DSKGPU_E_ARG;
+    for (u32 o = 0; o < ctx->cfg.world_size; ++o) kmers[o] = ctx->h_sk_sent[o];
+    return DSKGPU_OK;
+}
+
+int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words) { return dskgpu_mg_count_sized(ctx, d_recv, recv_words, 0); }
+
+int dskgpu_mg_count_sized(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words, uint64_t n_kmers) {
     if (!ctx || (!d_recv && recv_words)) return DSKGPU_E_ARG;
     CK(hipSetDevice(ctx->cfg.device));
     ctx->stats = dskgpu_stats{};
     if (ctx->sk_mode)
-        return ctx->W == 1 ? sk_count<1>(ctx, static_cast<const u64*>(d_recv), recv_words) : sk_count<2>(ctx, static_cast<const u64*>(d_recv), recv_words);
+        return ctx->W == 1 ? sk_count<1>(ctx, static_cast<const u64*>(d_recv), recv_words, n_kmers) : sk_count<2>(ctx, static_cast<const u64*>(d_recv), recv_words, n_kmers);
+    if (n_kmers && n_kmers != recv_words / (u64)ctx->W) return fail(ctx, DSKGPU_E_ARG, "dskgpu_mg_count_sized: n_kmers does not match the k-mers received");
     if (recv_words % (u64)ctx->W) return fail(ctx, DSKGPU_E_ARG, "recv_words is not a whole number of k-mer records");
     if (!d_recv) { CK(ctx->sk_keys.ensure(64)); d_recv = ctx->sk_keys.p; }      // nothing received: a null key array would read as "keys come from records"
     if (ctx->W == 1) return run_pipeline<1>(ctx, false, static_cast<const u64*>(d_recv), recv_words);

@@ -113,6 +113,7 @@ struct dskgpu_group {
     std::vector<ncclComm_t> comm;
     std::vector<DevMem> send, recv;
     std::vector<std::vector<uint64_t>> counts;      // counts[src][dst], 8-byte words
+    std::vector<std::vector<uint64_t>> kmers;       // kmers[src][dst], k-mers inside those words (the receiver's sizing)
     std::vector<int> rc;
     std::vector<std::string> rank_err;
     std::string err;
@@ -160,6 +161,7 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
     struct Unwind { dskgpu_ctx* c; bool on; ~Unwind() { if (on) dskgpu_i_banks_abort(c); } } unwind{ctx, per_bank};      // (whatever way the body is left)
   for (uint32_t bank = 0; bank < nbanks; ++bank) {
     if (per_bank) { dskgpu_i_banks_select(ctx, bank); for (auto& c : g->counts[r]) c = 0; }
+    for (auto& c : g->kmers[r]) c = 0;
     // ---- step 1: this rank's records, grouped by owner
     if (g->rc[r] == DSKGPU_OK) {
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -167,7 +169,7 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
             if (cap == 0) { fail(DSKGPU_E_DEVICE, std::string("send capacity: ") + dskgpu_last_error(ctx)); break; }
             if (!g->send[r].ensure(cap * 8)) { fail(DSKGPU_E_NOMEM, "send buffer"); break; }
             const int rc = dskgpu_mg_scatter(ctx, g->send[r].p, g->send[r].cap / 8, g->counts[r].data());
-            if (rc == DSKGPU_OK) break;
+            if (rc == DSKGPU_OK) { (void)dskgpu_mg_sent_kmers(ctx, g->kmers[r].data()); break; }
             // a slice of the sampled send layout overflowed and the exact layout needs more room: ask again, once
             if (attempt == 0 && rc == DSKGPU_E_ARG && std::strstr(dskgpu_last_error(ctx), "send buffer too small")) continue;
             fail(rc, std::string("mg_scatter: ") + dskgpu_last_error(ctx));
@@ -207,7 +209,9 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
     if (g->rc[r] == DSKGPU_OK && hipStreamSynchronize(g->stream[r]) != hipSuccess) fail(DSKGPU_E_DEVICE, "exchange: stream synchronize");
     if (bar->wait(failed())) return;                 // nobody overwrites a send buffer a peer still reads
     // ---- step 3: count what this rank owns
-    int rc = dskgpu_mg_count(ctx, recv_words ? g->recv[r].p : nullptr, recv_words);
+    uint64_t recv_kmers = 0;
+    for (uint32_t s = 0; s < n; ++s) recv_kmers += g->kmers[s][r];
+    int rc = dskgpu_mg_count_sized(ctx, recv_words ? g->recv[r].p : nullptr, recv_words, recv_kmers);
     if (rc != DSKGPU_OK) fail(rc, std::string("mg_count: ") + dskgpu_last_error(ctx));
     if (per_bank) {
         if (g->rc[r] == DSKGPU_OK && (rc = dskgpu_i_banks_add(ctx, bank)) != DSKGPU_OK) fail(rc, std::string("banks: ") + dskgpu_last_error(ctx));
@@ -244,6 +248,7 @@ int dskgpu_group_create(const dskgpu_config* cfg, const int32_t* devices, uint32
     g->ctx.assign(n_ranks, nullptr); g->stream.assign(n_ranks, nullptr); g->comm.assign(n_ranks, nullptr);
     g->send.resize(n_ranks); g->recv.resize(n_ranks);
     g->counts.assign(n_ranks, std::vector<uint64_t>(n_ranks, 0));
+    g->kmers.assign(n_ranks, std::vector<uint64_t>(n_ranks, 0));
     g->rc.assign(n_ranks, DSKGPU_OK); g->rank_err.assign(n_ranks, "");
     g->loads.assign(n_ranks, std::vector<uint64_t>(DSKGPU_MG_BUCKETS, 0)); g->table.assign(DSKGPU_MG_BUCKETS, 0);
     if (const char* e = getenv("DSKGPU_GROUP_BALANCE")) g->balance = std::strcmp(e, "0") != 0;     // "0": keep the default table (tests)

@@ -142,7 +142,19 @@ __device__ __forceinline__ SkThread sk_tile(const u64* __restrict__ packed, cons
         const u32 ic = inval[wi];
         const u32 i1 = wi >= 1 ? inval[wi - 1] : 0xFFFFFFFFu;
         const u32 i2 = wi >= 2 ? inval[wi - 2] : 0xFFFFFFFFu;
-        const u64 inv_lo = ((u64)i1 << 32) | ic;
+        // a window is invalid if an invalid base lies among its k: smear every invalid bit of the frame (i2 : i1 : ic, bit 31 - p
+        // of ic <-> base p of word wi) over the k - 1 following bases in log steps, then window i is bit 31 - (t0 + i)
+        u64 bad_lo = ((u64)i1 << 32) | ic, bad_hi = i2;
+        {
+            int rem = k - 1;
+#pragma unroll
+            for (int st = 1; st <= 32; st <<= 1) {
+                const int sh = rem < st ? rem : st;
+                if (sh) { bad_lo |= (bad_lo >> sh) | (bad_hi << (64 - sh)); bad_hi |= bad_hi >> sh; }
+                rem -= sh;
+            }
+        }
+        const u32 bad16 = (u32)(bad_lo >> (16 - t0)) & 0xFFFFu;              // bit 15 - i: window i holds an invalid base
         u32 pr = 0xFFFFFFFFu, prev_owner = 0xFFFFu; bool prev_valid = false, prev_split = false;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -152,11 +164,7 @@ __device__ __forceinline__ SkThread sk_tile(const u64* __restrict__ packed, cons
             const u32 bucket = (mn & 0xFFFFu) >> 4;
             u32 owner = SAMPLE ? 0u : tab[bucket];
             const bool split = !SAMPLE && owner == SK_SPLIT;
-            const int b0 = 31 - (t0 + i);
-            const u64 lo_bits = (k + b0 >= 64) ? (~0ull << b0) : (((1ull << k) - 1ull) << b0);
-            const int over = k + b0 - 64;
-            const u32 hi_bits = over > 0 ? ((over >= 32) ? 0xFFFFFFFFu : ((1u << over) - 1u)) : 0u;
-            const bool valid = ((inv_lo & lo_bits) == 0) && ((i2 & hi_bits) == 0);
+            const bool valid = !((bad16 >> (15 - i)) & 1u);
             if (SAMPLE) { if (valid) atomicAdd(&load[bucket], 1u); continue; }
             if (valid && split) owner = sk_kmer_owner(packed, wi, t0, i, k, sp.G);      // (rare: heavy buckets only)
             if (valid) {
@@ -227,14 +235,16 @@ __global__ __launch_bounds__(SK_NT) void k_sk_sample(const u64* __restrict__ pac
 // that would overflow raises *ovf (nothing is written past a slice) and the host repeats with exact counts.
 template <bool SLICES>
 __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
-                                                      SkParams sp, const u32* __restrict__ mat, u64* __restrict__ send, u32* __restrict__ ovf) {
+                                                      SkParams sp, const u32* __restrict__ mat, u64* __restrict__ send, u32* __restrict__ ovf,
+                                                      unsigned long long* __restrict__ kmers) {      // kmers[o] += k-mers inside the records written for owner o
     __shared__ u32 H[SK_NT * 17];
     __shared__ u32 cur[SK_MAX_OWNERS];
+    __shared__ u32 kc[SK_MAX_OWNERS];
     __shared__ unsigned char tab[SK_BUCKETS];
     const u32 c = blockIdx.x;
     for (int i = threadIdx.x; i < SK_BUCKETS / 8; i += SK_NT) reinterpret_cast<u64*>(tab)[i] = reinterpret_cast<const u64*>(sp.table)[i];
     __syncthreads();
-    if (threadIdx.x < sp.G) cur[threadIdx.x] = SLICES ? (threadIdx.x * sp.nchunks + c) * sp.slice : mat[(u64)threadIdx.x * sp.nchunks + c];
+    if (threadIdx.x < sp.G) { cur[threadIdx.x] = SLICES ? (threadIdx.x * sp.nchunks + c) * sp.slice : mat[(u64)threadIdx.x * sp.nchunks + c]; kc[threadIdx.x] = 0; }
     bool over = false;
     const u64 tbeg = (u64)c * sp.tiles_per_chunk;
     const u64 tend = tbeg + sp.tiles_per_chunk < sp.ntiles ? tbeg + sp.tiles_per_chunk : sp.ntiles;
@@ -256,6 +266,7 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
                 const u32 own = sk_owner(s, i);
                 const u32 slot = atomicAdd(&cur[own], 1u);
                 if (SLICES && slot >= (own * sp.nchunks + c + 1) * sp.slice) { over = true; continue; }
+                atomicAdd(&kc[own], n);
                 // bases [bs, bs + nb) of the 96-base frame (w2 : w1 : w0), shifted to the top of the record
                 u64 o[3];
                 sk_extract(w2, w1, w0, 64 + t0 + i - k + 1, (int)n + k - 1, o);
@@ -266,9 +277,10 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
         }
         sk_lds_barrier();
     }
+    __syncthreads();
+    if (threadIdx.x < sp.G && kc[threadIdx.x]) atomicAdd(&kmers[threadIdx.x], (unsigned long long)kc[threadIdx.x]);
     if (SLICES) {
         if (over) *ovf = 1u;
-        __syncthreads();
         for (u32 o = 0; o < sp.G; ++o) {                      // zero-length records up to the end of each of this block's slices
             const u64 end = (u64)(o * sp.nchunks + c + 1) * sp.slice * R;
             for (u64 w = (u64)cur[o] * R + threadIdx.x; w < end; w += SK_NT) send[w] = 0ull;

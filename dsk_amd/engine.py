@@ -82,7 +82,7 @@ EXPORTS = [
     "dskgpu_create", "dskgpu_destroy", "dskgpu_last_error", "dskgpu_version", "dskgpu_device_count", "dskgpu_set_stream",
     "dskgpu_push_reads", "dskgpu_reserve_reads", "dskgpu_reserve_work", "dskgpu_set_reads_device", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
     "dskgpu_count", "dskgpu_mg_scatter", "dskgpu_mg_sample", "dskgpu_mg_make_table", "dskgpu_mg_set_table",
-    "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_get_stats", "dskgpu_histogram",
+    "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_mg_sent_kmers", "dskgpu_mg_count_sized", "dskgpu_get_stats", "dskgpu_histogram",
     "dskgpu_num_partitions", "dskgpu_partition_size", "dskgpu_partition_copy", "dskgpu_result_device",
     "dskgpu_stage_times", "dskgpu_k_encode", "dskgpu_k_enumerate", "dskgpu_k_minimizers",
     "dskgpu_group_create", "dskgpu_group_destroy", "dskgpu_group_last_error", "dskgpu_group_size", "dskgpu_group_ctx",
@@ -134,6 +134,8 @@ def load_library():
     lib.dskgpu_mg_send_capacity_words.argtypes = [vp]
     lib.dskgpu_mg_send_capacity_words.restype = u64
     lib.dskgpu_mg_count.argtypes = [vp, vp, u64]
+    lib.dskgpu_mg_sent_kmers.argtypes = [vp, C.POINTER(u64)]
+    lib.dskgpu_mg_count_sized.argtypes = [vp, vp, u64, u64]
     lib.dskgpu_get_stats.argtypes = [vp, C.POINTER(_Stats)]
     lib.dskgpu_histogram.argtypes = [vp, C.POINTER(u64), u32]
     lib.dskgpu_num_partitions.argtypes = [vp]
@@ -311,8 +313,15 @@ class KmerCounter:
             assert t.size == MG_BUCKETS
             self._ck(self._lib.dskgpu_mg_set_table(self._h, t.ctypes.data_as(C.POINTER(C.c_uint8))))
 
-    def mg_count(self, recv_ptr: int, recv_words: int) -> None:
-        self._ck(self._lib.dskgpu_mg_count(self._h, C.c_void_p(recv_ptr), recv_words))
+    def mg_sent_kmers(self) -> List[int]:
+        """k-mers inside the records the last mg_scatter wrote for every owner (the receivers' sizing: see mg_count)."""
+        k = (C.c_uint64 * self.world_size)()
+        self._ck(self._lib.dskgpu_mg_sent_kmers(self._h, k))
+        return [int(c) for c in k]
+
+    def mg_count(self, recv_ptr: int, recv_words: int, n_kmers: int = 0) -> None:
+        """n_kmers = the senders' k-mer total for this rank (sum over sources of mg_sent_kmers()[rank]); 0 = count them here."""
+        self._ck(self._lib.dskgpu_mg_count_sized(self._h, C.c_void_p(recv_ptr), recv_words, n_kmers))
 
     # -- results
     def stats(self) -> dict:

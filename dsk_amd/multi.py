@@ -21,24 +21,30 @@ import torch.distributed as dist
 
 
 def exchange(send: torch.Tensor, send_counts: Sequence[int], group=None,
-             recv: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, List[int]]:
+             recv: Optional[torch.Tensor] = None, send_kmers: Optional[Sequence[int]] = None,
+             recv_kmers: Optional[List[int]] = None) -> Tuple[torch.Tensor, List[int]]:
     """Variable-size all-to-all of 8-byte words.  send[: sum(send_counts)] is grouped by
-    destination rank.  Returns (recv buffer view, per-source counts)."""
+    destination rank.  Returns (recv buffer view, per-source counts).  send_kmers (k-mers inside the
+    words for every destination) rides along with the counts; the per-source figures are appended to recv_kmers."""
     world = dist.get_world_size(group)
     assert len(send_counts) == world
     if send.is_cuda and dist.get_backend(group) == "gloo":
         # development path (several ranks sharing one GPU, no RCCL): stage the exchange through host memory
-        out_cpu, rcounts = exchange(send[: sum(send_counts)].cpu(), send_counts, group)
+        out_cpu, rcounts = exchange(send[: sum(send_counts)].cpu(), send_counts, group, None, send_kmers, recv_kmers)
         n = out_cpu.numel()
         if recv is None or recv.numel() < n:
             recv = torch.empty(max(n, 1), dtype=send.dtype, device=send.device)
         recv[:n].copy_(out_cpu)
         return recv[:n], rcounts
     dev = send.device
-    sc = torch.tensor(list(send_counts), dtype=torch.int64, device=dev)
+    km = list(send_kmers) if send_kmers is not None else [0] * world
+    sc = torch.tensor([[int(c), int(k)] for c, k in zip(send_counts, km)], dtype=torch.int64, device=dev)
     rc = torch.empty_like(sc)
-    dist.all_to_all_single(rc, sc, group=group)
-    recv_counts = [int(x) for x in rc.tolist()]
+    dist.all_to_all_single(rc, sc, group=group)          # one round: (words, k-mers) per peer
+    pairs = rc.tolist()
+    recv_counts = [int(x[0]) for x in pairs]
+    if recv_kmers is not None:
+        recv_kmers.extend(int(x[1]) for x in pairs)
     n_recv = sum(recv_counts)
     if recv is None or recv.numel() < n_recv:
         recv = torch.empty(int(n_recv * 1.1) + 1024, dtype=send.dtype, device=dev)   # head-room: sizes wobble step to step
@@ -93,13 +99,18 @@ class ShardedCounter:
         if self.balance:                             # part of every count, like the reference's repartition step inside execute()
             self.rebalance()
         self.send, counts = scatter_records(self.stage, self.send, self.device)
-        out, rcounts = exchange(self.send, counts, self.group, self.recv)
+        sized = hasattr(self.stage, "mg_sent_kmers")      # the senders counted the k-mers they packed: the receiver need not
+        rk: List[int] = []
+        out, rcounts = exchange(self.send, counts, self.group, self.recv, self.stage.mg_sent_kmers() if sized else None, rk)
         if self.recv is None or self.recv.numel() < out.numel() or out.data_ptr() != self.recv.data_ptr():
             self.recv = out._base if out._base is not None else out        # keep the (larger) backing buffer for the next step
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
         self.last_send_counts, self.last_recv_counts = list(counts), rcounts
-        self.stage.mg_count(out.data_ptr() if out.numel() else 0, int(out.numel()))
+        if sized:
+            self.stage.mg_count(out.data_ptr() if out.numel() else 0, int(out.numel()), sum(rk))
+        else:
+            self.stage.mg_count(out.data_ptr() if out.numel() else 0, int(out.numel()))
 
 
 def gather_histogram(hist: torch.Tensor, group=None) -> torch.Tensor:

@@ -141,6 +141,13 @@ void dskgpu_mg_make_table(const uint64_t* summed_loads, uint32_t world_size, uin
 int dskgpu_mg_set_table(dskgpu_ctx* ctx, const uint8_t* table /* [DSKGPU_MG_BUCKETS], NULL = default */);
 uint64_t dskgpu_mg_send_capacity_words(dskgpu_ctx* ctx);
 int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words);
+/* The senders know how many k-mers they packed for every owner (counted while the records are written):
+ * dskgpu_mg_sent_kmers returns that row after dskgpu_mg_scatter (host array of world_size entries), the caller sends it
+ * along with the word counts, and the receiver passes the column sum to dskgpu_mg_count_sized -- which then skips its own
+ * pass over the received records (0.6 ms of a 20 ms step).  n_kmers = 0 behaves as dskgpu_mg_count; a figure that does not
+ * match the records is reported as DSKGPU_E_ARG, never as a wrong result. */
+int dskgpu_mg_sent_kmers(dskgpu_ctx* ctx, uint64_t* kmers /* [world_size] */);
+int dskgpu_mg_count_sized(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words, uint64_t n_kmers);
 
 /* ---- results: replace the CountProcessor outputs read back through
  * Storage (src/DSK.cpp:68; utils/dsk2ascii.cpp:61-104; simple_test.sh:37) */

@@ -715,11 +715,11 @@ def test_multi_pass_on_the_receive_side(oracle, dev, k, explicit):
 def test_multi_gpu_path_on_one_device(oracle, golden_dir, dev, world, k, explicit):
     """dskgpu_mg_scatter / dskgpu_mg_count with the exchange done by hand: `world` contexts on the
     same GPU, each fed its shard of the reads; the union of their results must equal the oracle."""
-    from dsk_amd import KmerCounter
+    from dsk_amd import KmerCounter, DskGpuError
     s, _ = oracle.load_bank(os.path.join(golden_dir, "read50x_ref10K_e001.fasta.gz"))
     recs = bytes(s).split(b"\n")
     W = 1 if k <= 32 else 2
-    ctxs, sends, counts, shards = [], [], [], []
+    ctxs, sends, counts, shards, kmers = [], [], [], [], []
     for r in range(world):
         shard = torch.from_numpy(np.frombuffer(b"\n".join(recs[r::world]) + b"\n", dtype=np.uint8).copy()).to(dev)
         kc = KmerCounter(kmer_size=k, abundance_min=1, world_size=world, rank=r, mg_explicit=explicit)
@@ -731,7 +731,7 @@ def test_multi_gpu_path_on_one_device(oracle, golden_dir, dev, world, k, explici
         assert all(x % ((2 if k <= 45 else 3) if records else W) == 0 for x in c)
         if records:   # a record carries up to 16 k-mers: far fewer words than one key per k-mer
             assert sum(c) < 0.6 * W * (shard.numel() - len(recs[r::world]) * k)
-        ctxs.append(kc); sends.append(send); counts.append(c); shards.append(shard)
+        ctxs.append(kc); sends.append(send); counts.append(c); shards.append(shard); kmers.append(kc.mg_sent_kmers())
     rows_k, rows_a, hist = [], [], np.zeros(10001, np.uint64)
     for d in range(world):
         parts = []
@@ -740,7 +740,14 @@ def test_multi_gpu_path_on_one_device(oracle, golden_dir, dev, world, k, explici
             parts.append(sends[src][off: off + counts[src][d]])
         recv = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
-        ctxs[d].mg_count(recv.data_ptr(), recv.numel())
+        # the senders' k-mer totals size the receiver (dskgpu_mg_count_sized); a figure that does not match the records is an
+        # error, never a wrong result -- one too many (found at the end), half (found when the sized slices overflow)
+        hint = sum(kmers[src][d] for src in range(world))
+        assert hint > 0
+        for wrong in ((hint + 1,) if d == 0 else (hint // 2,) if d == 1 else ()):
+            with pytest.raises(DskGpuError):
+                ctxs[d].mg_count(recv.data_ptr(), recv.numel(), wrong)
+        ctxs[d].mg_count(recv.data_ptr(), recv.numel(), hint if d % 2 == 0 else 0)
         kk, aa = ctxs[d].rows()
         rows_k.append(kk); rows_a.append(aa); hist += ctxs[d].histogram()
     kk = np.concatenate(rows_k); aa = np.concatenate(rows_a)

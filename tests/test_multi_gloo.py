@@ -57,7 +57,11 @@ class CpuStage:
         import ctypes
         buf = (ctypes.c_uint64 * max(1, len(h))).from_address(ptr)
         np.ctypeslib.as_array(buf)[: len(h)] = h
+        self.sent = list(counts)                  # explicit keys: one k-mer per word
         return counts
+
+    def mg_sent_kmers(self):
+        return self.sent
 
     # minimizer repartition (multi.ShardedCounter.rebalance): the stand-in keeps its own owner map, but takes part in the
     # protocol -- per-rank loads, summed over the ranks, one table derived by every rank from the same sum
@@ -70,8 +74,9 @@ class CpuStage:
     def mg_set_table(self, table):
         self.table = None if table is None else np.array(table, dtype=np.uint8)
 
-    def mg_count(self, ptr, n):
+    def mg_count(self, ptr, n, n_kmers=0):
         import ctypes
+        assert n_kmers == n                       # the senders' k-mer totals arrived with the word counts
         if n:
             h = np.ctypeslib.as_array((ctypes.c_uint64 * n).from_address(ptr)).copy()
         else:

@@ -27,7 +27,7 @@ for it in range(4):
         send = torch.empty(cap, dtype=torch.int64, device=dev)
     counts = kc.mg_scatter(send.data_ptr(), send.numel())
     torch.cuda.synchronize(); t1 = time.perf_counter()
-    kc.mg_count(send.data_ptr(), sum(counts))
+    kc.mg_count(send.data_ptr(), sum(counts), sum(kc.mg_sent_kmers()))
     torch.cuda.synchronize(); t2 = time.perf_counter()
 st = kc.stats()
 print(f"world={world} k={k} explicit={explicit}: scatter side {1e3*(t1-t0):.2f} ms, count side {1e3*(t2-t1):.2f} ms, total {1e3*(t2-t0):.2f} ms")
