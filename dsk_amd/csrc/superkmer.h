@@ -33,6 +33,7 @@
 #define SK_GROUPS (SK_NT - SK_HALO)       // groups (16 window ends each) a tile emits records for
 #define SK_MAX_OWNERS 64
 #define SK_BUCKETS 4096                   // minimizer buckets of the repartition table
+#define SK_DESC 256                       // records a wave deals out per round (k_sk_scatter)
 #define SK_SPLIT 255u                     // table entry: route the window by its k-mer, not by its minimizer
 
 struct SkParams {
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
     __shared__ u32 H[SK_NT * 17];
     __shared__ u32 cur[SK_MAX_OWNERS];
     __shared__ u32 kc[SK_MAX_OWNERS];
+    __shared__ u32 desc[SK_NT / 64][SK_DESC];
     __shared__ unsigned char tab[SK_BUCKETS];
     const u32 c = blockIdx.x;
     for (int i = threadIdx.x; i < SK_BUCKETS / 8; i += SK_NT) reinterpret_cast<u64*>(tab)[i] = reinterpret_cast<const u64*>(sp.table)[i];
@@ -250,20 +252,35 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
     const u64 tend = tbeg + sp.tiles_per_chunk < sp.ntiles ? tbeg + sp.tiles_per_chunk : sp.ntiles;
     const int k = (int)sp.k;
     const u32 R = sp.R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (u64 tile = tbeg; tile < tend; ++tile) {
         const long long gfirst = (long long)(tile * SK_GROUPS) - SK_HALO;
         const SkThread s = sk_tile(packed, inval, sp, gfirst, H, tab);
-        u32 bm = s.bm;
-        if (bm) {
-            const u64 g = (u64)(gfirst + threadIdx.x);
-            const u64 wi = g >> 1; const int t0 = (int)(g & 1) << 4;
-            const u64 w0 = packed[wi];
-            const u64 w1 = wi >= 1 ? packed[wi - 1] : 0ull;
-            const u64 w2 = wi >= 2 ? packed[wi - 2] : 0ull;
+        // The records of a WAVE are dealt out to its lanes, one record per lane and trip: a thread holds 0..16 records (2.3 on
+        // average), and a loop over a thread's own records runs as often as the busiest of 64 lanes needs (5-6 trips of the
+        // ~80-instruction body).  Every thread notes its records -- (lane, first window, k-mers, owner) -- in the wave's
+        // list (a light loop), then lane e builds record e, e + 64, ..: it fetches the frame of the noting lane's group itself.
+        const u32 cnt = (u32)__popc(s.bm);
+        const u32 inc = wave_incl_scan(cnt);
+        const u32 total = (u32)__shfl((int)inc, 63);
+        for (u32 B = 0; B < total; B += SK_DESC) {                          // (wave-uniform; more than SK_DESC records in a wave: several rounds)
+            u32 bm = s.bm, id = inc - cnt - B;
             while (bm) {
                 const int i = __builtin_ctz(bm); bm &= bm - 1;
-                const u32 n = sk_run_length(s, i);
-                const u32 own = sk_owner(s, i);
+                if (id < SK_DESC) desc[wave][id] = (u32)lane | ((u32)i << 6) | ((sk_run_length(s, i) - 1u) << 10) | (sk_owner(s, i) << 14);
+                ++id;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const u32 m = total - B < SK_DESC ? total - B : SK_DESC;
+            for (u32 e = (u32)lane; e < m; e += 64) {
+                const u32 dsc = desc[wave][e];
+                const int i = (int)((dsc >> 6) & 15u);
+                const u32 n = ((dsc >> 10) & 15u) + 1u, own = dsc >> 14;
+                const u64 g = (u64)(gfirst + (long long)((wave << 6) + (int)(dsc & 63u)));
+                const u64 wi = g >> 1; const int t0 = (int)(g & 1) << 4;
+                const u64 w0 = packed[wi];
+                const u64 w1 = wi >= 1 ? packed[wi - 1] : 0ull;
+                const u64 w2 = wi >= 2 ? packed[wi - 2] : 0ull;
                 const u32 slot = atomicAdd(&cur[own], 1u);
                 if (SLICES && slot >= (own * sp.nchunks + c + 1) * sp.slice) { over = true; continue; }
                 atomicAdd(&kc[own], n);
@@ -274,6 +291,7 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
                 if (R == 2) { dst[0] = o[0]; dst[1] = o[1] | n; }
                 else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2] | n; }
             }
+            __builtin_amdgcn_wave_barrier();
         }
         sk_lds_barrier();
     }
