@@ -143,7 +143,14 @@ struct dskgpu_ctx {
     SkParams sk_sp{};
     DevBuf sk_sums, sk_cbase, sk_keys, sk_table, sk_load, sk_sent;
     u64 h_sk_sent[SK_MAX_OWNERS] = {0};      // k-mers inside the records the last mg_scatter wrote for every owner
+    u64 h_sk_est[SK_MAX_OWNERS] = {0};       // sampled layout: estimated k-mers per owner (k_sk_hist on every 16th tile, scaled)
+    u32 sk_nslices = 0;                      // dskgpu_mg_slices_prepare: slices of the prepared step (0 = none prepared)
     u64 rec_hint = 0;                        // dskgpu_mg_count_sized: the caller's k-mer total of the records (0 = none)
+    bool rec_hint_est = false;               // ... an estimate (sliced step): sizes the fast path only, never checked against the result
+    std::vector<u64> rec_slice_end;          // dskgpu_mg_count_sliced: record index where every slice ends; empty = one piece
+    dskgpu_slice_gate rec_gate = nullptr; void* rec_gate_user = nullptr; u32 rec_gated = 0;      // slices whose arrival the stream already waits for
+    std::vector<u32> h_slice_chunk;          // first level-1 chunk of every slice (+ the end)
+    DevBuf cur_state;                        // parked write cursors of the level-1 blocks between the launches of a sliced receive
     bool rec_sized = false;                  // per-chunk k-mer sums of the records are on the device (k_sk_count ran)
     std::vector<uint8_t> h_table;  // the repartition table in use (SK_BUCKETS owners; default: bucket scaled to the world size)
     bool table_dirty = true;       // h_table not yet copied to sk_table
@@ -442,6 +449,35 @@ void build_descs1(dskgpu_ctx* ctx, u64 n_units_total, u64 tile, u64 max_chunks, 
     *nch_out = (u32)nch;
 }
 
+// the same for records that arrive in slices (ctx->rec_slice_end): every slice gets its own chunks (a launch per slice walks
+// them); h_slice_chunk[s] = first chunk of slice s
+void build_descs1_slices(dskgpu_ctx* ctx, u64 tile, u64 max_chunks, u32* nch_out) {
+    const size_t S = ctx->rec_slice_end.size();
+    ctx->h_descs1.clear(); ctx->h_slice_chunk.assign(S + 1, 0);
+    const u64 per_slice = std::max<u64>(1, max_chunks / S);
+    u64 rb = 0;
+    for (size_t sl = 0; sl < S; ++sl) {
+        const u64 re = ctx->rec_slice_end[sl];
+        ctx->h_slice_chunk[sl] = (u32)ctx->h_descs1.size();
+        if (re > rb) {
+            const u64 ntiles = (re - rb + tile - 1) / tile;
+            u64 nch = std::min<u64>(ntiles, per_slice);
+            const u64 tpc = (ntiles + nch - 1) / nch;
+            nch = (ntiles + tpc - 1) / tpc;
+            for (u64 c = 0; c < nch; ++c) {
+                ChunkDesc d;
+                d.begin = rb + c * tpc * tile; d.end = std::min<u64>(re, rb + (c + 1) * tpc * tile);
+                d.flat_base = 0; d.stride = 0;                      // (only the histogram-free scatter reads these chunks)
+                ctx->h_descs1.push_back(d);
+            }
+        }
+        rb = re;
+    }
+    ctx->h_slice_chunk[S] = (u32)ctx->h_descs1.size();
+    for (auto& d : ctx->h_descs1) d.stride = (u32)ctx->h_descs1.size();
+    *nch_out = (u32)ctx->h_descs1.size();
+}
+
 }  // namespace
 
 namespace {
@@ -661,8 +697,18 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
 
 // k-mers per chunk of received records (k_sk_count) -> chunk bases for the expansion, and the total.  Needed up front only when
 // the caller did not pass the total (dskgpu_mg_count); otherwise only by paths that expand the records.
+#define REC_RESIZE 1001            // expand_records: the k-mer total the pipeline was sized with was an estimate and is off -- ctx->rec_hint holds the real one
+// the stream waits for the arrival of the slices up to `upto` (exclusive) -- in order, each once
+void rec_gate_upto(dskgpu_ctx* ctx, u32 upto) {
+    if (!ctx->rec_gate) return;
+    const u32 n = (u32)ctx->rec_slice_end.size();
+    for (; ctx->rec_gated < std::min(upto, n); ++ctx->rec_gated) ctx->rec_gate(ctx->rec_gate_user, ctx->rec_gated);
+}
+void rec_gate_all(dskgpu_ctx* ctx) { rec_gate_upto(ctx, 0xFFFFFFFFu); }
+
 int sk_sizes(dskgpu_ctx* ctx, u64* total_out) {
     const u64 nrec = ctx->rec_n; const u32 R = ctx->sk_sp.R;
+    rec_gate_all(ctx);                                          // (a sliced receive: every record has to be there)
     u64 nch = std::min<u64>((nrec + SKX_NT - 1) / SKX_NT, (u64)ctx->num_cu * 16);
     u64 rpc = (nrec + nch - 1) / nch;
     rpc = (rpc + SKX_NT - 1) / SKX_NT * SKX_NT;
@@ -691,8 +737,10 @@ int expand_records(dskgpu_ctx* ctx, u64 total) {
         u64 real = 0;
         const int e = sk_sizes(ctx, &real);
         if (e) return e;
+        if (real != total && ctx->rec_hint_est) { ctx->rec_hint = real; return REC_RESIZE; }      // the estimate sized the fast path only: once more with the real figure
         if (real != total) return fail(ctx, DSKGPU_E_ARG, "dskgpu_mg_count_sized: n_kmers does not match the k-mers inside the records");
     }
+    rec_gate_all(ctx);
     CK(ctx->sk_keys.ensure((total + 1) * sizeof(Key)));
     hipLaunchKernelGGL(k_sk_expand<W>, dim3((unsigned)ctx->rec_nch), dim3(SKX_NT), 0, ctx->stream, ctx->rec_src, ctx->rec_n, ctx->sk_sp.R,
                        (int)ctx->cfg.kmer_size, (u32)ctx->rec_rpc, ctx->sk_cbase.as<u64>(), ctx->sk_keys.as<Key>());
@@ -821,6 +869,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         bool from_rec = !from_reads && d_keys_in == nullptr;
         auto upload_descs1 = [&]() -> int {
             if (from_reads) build_descs1(ctx, nwords, Tile<W>::WORDS, max_chunks1, &nch1);
+            else if (from_rec && ctx->rec_slice_end.size() > 1) build_descs1_slices(ctx, RecTile<W>::NR, max_chunks1, &nch1);
             else if (from_rec) build_descs1(ctx, ctx->rec_n, RecTile<W>::NR, max_chunks1, &nch1);
             else build_descs1(ctx, nkeys_in, Tile<W>::KEYS, max_chunks1, &nch1);
             CK(ctx->descs1.ensure(ctx->h_descs1.size() * sizeof(ChunkDesc)));
@@ -870,7 +919,16 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             grid1 = scatter_grid(ctx, W, pl.P1, nch1, !uniform1);
             // a block's share of the input: it walks chunks blockIdx, blockIdx + grid, .. (equal chunks, the busiest block has ceil(nch/grid))
             const u64 cpb = (nch1 + grid1 - 1) / grid1;
-            const double share = (double)cpb / (double)nch1;
+            double share = (double)cpb / (double)nch1;
+            if (from_rec && ctx->rec_slice_end.size() > 1) {      // a launch per slice: the busiest block's chunks of every slice add up
+                share = 0.0;
+                u64 rb = 0;
+                for (size_t sl = 0; sl < ctx->rec_slice_end.size(); ++sl) {
+                    const u64 re = ctx->rec_slice_end[sl], nc = ctx->h_slice_chunk[sl + 1] - ctx->h_slice_chunk[sl];
+                    if (nc) share += (double)((nc + grid1 - 1) / grid1) / (double)nc * (double)(re - rb) / (double)ctx->rec_n;
+                    rb = re;
+                }
+            }
             // ---- level-1 loads of this pass, per bin ("PartiInfo" before the spill): a positional sample -- the level-1 digit
             // histogram of <= 1024 tiles spread over the source -- scaled to the pass.  Every bin's slices are sized from ITS load,
             // so a bin that holds a repeat family (or poly-A) gets longer slices instead of overflowing the mean-sized ones.
@@ -991,7 +1049,21 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             }
             else if (from_reads && npass > 1) rc = launch_scatter_m<W, 0, 3, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
             else if (from_reads) rc = launch_scatter_m<W, 0, 1, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
-            else if (from_rec) rc = launch_scatter_rec<W>(ctx, dd1, sc + SC_NCH1, nch1, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+            else if (from_rec && ctx->rec_slice_end.size() > 1) {
+                // the records arrive in slices: one launch per slice, each behind the arrival of its slice (rec_gate), the blocks'
+                // write cursors parked in between
+                const size_t S = ctx->rec_slice_end.size();
+                CK(ctx->cur_state.ensure((size_t)grid1 * pl.P1 * 4));
+                o1.cur_state = ctx->cur_state.as<u32>();
+                rc = DSKGPU_OK;
+                for (size_t sl = 0; sl < S && rc == DSKGPU_OK; ++sl) {
+                    rec_gate_upto(ctx, (u32)sl + 1);
+                    o1.g0 = ctx->h_slice_chunk[sl]; o1.gn = ctx->h_slice_chunk[sl + 1] - ctx->h_slice_chunk[sl];
+                    o1.resume = sl > 0 ? 1u : 0u; o1.last = sl + 1 == S ? 1u : 0u;
+                    rc = launch_scatter_rec<W>(ctx, dd1, sc + SC_NCH1, nch1, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+                }
+            }
+            else if (from_rec) { rec_gate_all(ctx); rc = launch_scatter_rec<W>(ctx, dd1, sc + SC_NCH1, nch1, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1); }
             else rc = launch_scatter_m<W, 1, 1, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
             if (rc) return rc;
             ctx->mark("scatter1");
@@ -1446,6 +1518,7 @@ void sk_geometry(dskgpu_ctx* ctx, u64 nwords) {
     const u64 tpc = (sp.ntiles + nch - 1) / nch;
     nch = (sp.ntiles + tpc - 1) / tpc;
     sp.tiles_per_chunk = (u32)tpc; sp.nchunks = (u32)nch;
+    sp.c0 = 0; sp.c0g = 0; sp.clen = (u32)nch; sp.rbase = 0;      // one layout group: the whole step
 }
 
 // ---- multi-GPU exchange as super-k-mer records (superkmer.h)
@@ -1478,8 +1551,12 @@ int sk_prepare(dskgpu_ctx* ctx) {
     // pads the slices with zero-length records.  Saves the full counting pass (1.95 of 5 ms); ~8 % more words to send.
     const bool slices = !ctx->sk_exact && !ctx->tune.sk_exact && tpc >= 8;
     sp.sample_step = slices ? 16u : 1u;
-    hipLaunchKernelGGL(k_sk_hist, dim3((unsigned)nch), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, ctx->mat1.as<u32>());
+    CK(ctx->sk_sent.ensure(2 * SK_MAX_OWNERS * 8));            // [k-mers sent per owner | sampled k-mers per owner]
+    CK(hipMemsetAsync(ctx->sk_sent.as<u64>() + SK_MAX_OWNERS, 0, SK_MAX_OWNERS * 8, ctx->stream));
+    hipLaunchKernelGGL(k_sk_hist, dim3((unsigned)nch), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, ctx->mat1.as<u32>(),
+                       ctx->sk_sent.as<unsigned long long>() + SK_MAX_OWNERS);
     CKL("k_sk_hist");
+    CK(hipMemcpyAsync(ctx->h_sk_est, ctx->sk_sent.as<u64>() + SK_MAX_OWNERS, SK_MAX_OWNERS * 8, hipMemcpyDeviceToHost, ctx->stream));
     ctx->mark("mg_hist");
     if ((rc = run_scan(ctx, ctx->mat1.as<u32>(), sc + SC_MLEN1, M))) return rc;
     ctx->h_starts.assign(sp.G + 1, 0);
@@ -1498,6 +1575,7 @@ int sk_prepare(dskgpu_ctx* ctx) {
         if (ctx->tune.sk_slice) slice = ctx->tune.sk_slice;                               // tests
         if (!small && slice * nch * sp.G < 0xFFFF0000ull) {
             sp.slice = (u32)slice;
+            for (u32 o = 0; o < sp.G; ++o) ctx->h_sk_est[o] = ctx->h_sk_est[o] * tpc / sampled_tiles;      // sampled tiles -> all tiles
             for (u32 o = 0; o <= sp.G; ++o) ctx->h_starts[o] = (u32)(o * nch * slice);
             ctx->sk_slices = true;
         } else {                                             // small input, or too many records to index: count exactly after all
@@ -1519,7 +1597,6 @@ int sk_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t*
     ctx->marks.clear(); ctx->ev_used = 0;
     ctx->mark("start");
     u32* sc = ctx->scalars.as<u32>();
-    CK(ctx->sk_sent.ensure(SK_MAX_OWNERS * 8));
     CK(hipMemsetAsync(ctx->sk_sent.p, 0, SK_MAX_OWNERS * 8, ctx->stream));
     if (ctx->sk_slices)
         hipLaunchKernelGGL(k_sk_scatter<true>, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
@@ -1543,9 +1620,66 @@ int sk_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t*
     return DSKGPU_OK;
 }
 
+// ---- a step in slices (the exchange of slice i overlaps the sender's slice i + 1 and the receiver's level 1 of slice i - 1).
+// Only with the sampled send layout (its sizes are known before a record exists): slice s = the chunks [s * nch / S, (s + 1) * nch / S),
+// a layout group of its own in the send buffer (SkParams::c0g, clen, rbase), owner-major inside.
+void sk_slice_range(const SkParams& sp, u32 S, u32 s, u32* cb, u32* ce) { *cb = (u32)((u64)s * sp.nchunks / S); *ce = (u32)((u64)(s + 1) * sp.nchunks / S); }
+
+int sk_slices_prepare(dskgpu_ctx* ctx, u32 want, u32* nslices, uint64_t* send_words, uint64_t* kmers_est) {
+    int rc;
+    *nslices = 0; ctx->sk_nslices = 0;
+    if (!ctx->sk_prepared && (rc = sk_prepare(ctx))) return rc;
+    const SkParams& sp = ctx->sk_sp;
+    if (!ctx->sk_slices || want < 2) return DSKGPU_OK;          // exact layout (small input, or a slice overflowed before): one piece
+    const u32 S = std::min<u32>(want, sp.nchunks);
+    if (S < 2) return DSKGPU_OK;
+    for (u32 sl = 0; sl < S; ++sl) {
+        u32 cb, ce; sk_slice_range(sp, S, sl, &cb, &ce);
+        for (u32 o = 0; o < sp.G; ++o) send_words[(size_t)sl * sp.G + o] = (u64)(ce - cb) * sp.slice * sp.R;
+    }
+    for (u32 o = 0; o < sp.G; ++o) kmers_est[o] = ctx->h_sk_est[o];
+    *nslices = S; ctx->sk_nslices = S;
+    return DSKGPU_OK;
+}
+
+// launch the scatter of slice s (asynchronous on the context's stream: the caller records an event behind it and starts the exchange)
+int sk_scatter_slice(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, u32 sl) {
+    if (!ctx->sk_prepared || !ctx->sk_slices || sl >= ctx->sk_nslices) return fail(ctx, DSKGPU_E_STATE, "dskgpu_mg_scatter_slice without dskgpu_mg_slices_prepare");
+    SkParams sp = ctx->sk_sp;
+    if (capacity_words < (u64)ctx->h_starts[sp.G] * sp.R) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
+    u32* sc = ctx->scalars.as<u32>();
+    if (sl == 0) {
+        ctx->marks.clear(); ctx->ev_used = 0;
+        ctx->mark("start");
+        CK(hipMemsetAsync(ctx->sk_sent.p, 0, SK_MAX_OWNERS * 8, ctx->stream));
+    }
+    u32 cb, ce; sk_slice_range(sp, ctx->sk_nslices, sl, &cb, &ce);
+    sp.c0 = cb; sp.c0g = cb; sp.clen = ce - cb; sp.rbase = cb * sp.G * sp.slice;
+    if (ce > cb)
+        hipLaunchKernelGGL(k_sk_scatter<true>, dim3(ce - cb), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
+                           ctx->mat1.as<u32>(), static_cast<u64*>(d_send), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>());
+    CKL("k_sk_scatter");
+    if (sl + 1 == ctx->sk_nslices) ctx->mark("mg_scatter");
+    return DSKGPU_OK;
+}
+
+// end of the sender's part: did a slice of the send layout overflow (then the records of this step are incomplete -- every rank
+// repeats the step in one piece; this context will use exact counts), and the k-mers that were packed
+int sk_slices_finish(dskgpu_ctx* ctx, int* overflowed) {
+    if (!ctx->sk_nslices) return fail(ctx, DSKGPU_E_STATE, "dskgpu_mg_slices_finish without dskgpu_mg_slices_prepare");
+    u32* sc = ctx->scalars.as<u32>();
+    CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(ctx->h_sk_sent, ctx->sk_sent.p, SK_MAX_OWNERS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    *overflowed = ctx->h_ovf1 ? 1 : 0;
+    if (ctx->h_ovf1) ctx->sk_exact = true;
+    ctx->sk_prepared = false; ctx->sk_nslices = 0;
+    return DSKGPU_OK;
+}
+
 // Receiver: records -> dense mixed keys -> the ordinary partition + count over a key array.
 template <int W>
-int sk_count(dskgpu_ctx* ctx, const u64* d_rec, u64 recv_words, u64 n_kmers_hint) {
+int sk_count(dskgpu_ctx* ctx, const u64* d_rec, u64 recv_words, u64 n_kmers_hint, bool hint_is_estimate = false) {
     typedef typename KeyT<W>::T Key;
     const u32 R = ctx->sk_sp.R;
     if (recv_words % R) return fail(ctx, DSKGPU_E_ARG, "recv_words is not a whole number of super-k-mer records");
@@ -1553,7 +1687,7 @@ int sk_count(dskgpu_ctx* ctx, const u64* d_rec, u64 recv_words, u64 n_kmers_hint
     ctx->marks.clear(); ctx->ev_used = 0;
     ctx->mark("start");
     u64 total = 0;
-    ctx->rec_hint = 0; ctx->rec_sized = false;
+    ctx->rec_hint = 0; ctx->rec_sized = false; ctx->rec_hint_est = hint_is_estimate;
     if (nrec) {
         ctx->rec_src = d_rec; ctx->rec_n = nrec; ctx->rec_expanded = false;
         if (n_kmers_hint) { total = n_kmers_hint; ctx->rec_hint = n_kmers_hint; }      // the senders counted while they wrote the records
@@ -1565,10 +1699,11 @@ int sk_count(dskgpu_ctx* ctx, const u64* d_rec, u64 recv_words, u64 n_kmers_hint
     ctx->mark("mg_sizes");
     CK(hipStreamSynchronize(ctx->stream));
     ctx->resolve_marks();
-    if (!ctx->rec_src) return run_pipeline<W>(ctx, false, ctx->sk_keys.as<Key>(), 0);
-    const int rc = run_pipeline<W>(ctx, false, nullptr, total);      // nullptr: keys come from ctx->rec_src
+    if (!ctx->rec_src) { rec_gate_all(ctx); return run_pipeline<W>(ctx, false, ctx->sk_keys.as<Key>(), 0); }
+    int rc = run_pipeline<W>(ctx, false, nullptr, total);      // nullptr: keys come from ctx->rec_src
+    if (rc == REC_RESIZE) { ctx->rec_hint_est = false; rc = run_pipeline<W>(ctx, false, nullptr, ctx->rec_hint); ctx->rec_hint = 0; }
     ctx->rec_src = nullptr;
-    if (rc == DSKGPU_OK && ctx->rec_hint && ctx->stats.n_kmers != ctx->rec_hint) {
+    if (rc == DSKGPU_OK && ctx->rec_hint && !ctx->rec_hint_est && ctx->stats.n_kmers != ctx->rec_hint) {
         ctx->have_result = false;
         return fail(ctx, DSKGPU_E_ARG, "dskgpu_mg_count_sized: n_kmers does not match the k-mers inside the records");
     }
@@ -1796,7 +1931,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
                       &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
                       &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->srt_k2, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
                       &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,
-                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent};
+                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent, &ctx->cur_state};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i) { ctx->out_w[i].release(); ctx->srt_w[i].release(); ctx->acc_w[i].release(); ctx->u_w[i].release(); ctx->s_w[i].release(); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -2030,6 +2165,46 @@ int dskgpu_mg_sent_kmers(dskgpu_ctx* ctx, uint64_t* kmers) {
 }
 
 int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words) { return dskgpu_mg_count_sized(ctx, d_recv, recv_words, 0); }
+
+int dskgpu_mg_slices_prepare(dskgpu_ctx* ctx, uint32_t want_slices, uint32_t* nslices, uint64_t* send_words, uint64_t* kmers_est) {
+    if (!ctx || !nslices || !send_words || !kmers_est) return DSKGPU_E_ARG;
+    *nslices = 0;
+    if (!ctx->sk_mode) return DSKGPU_OK;                 // explicit keys: one piece
+    CK(hipSetDevice(ctx->cfg.device));
+    return sk_slices_prepare(ctx, want_slices, nslices, send_words, kmers_est);
+}
+int dskgpu_mg_scatter_slice(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint32_t slice) {
+    if (!ctx || !d_send) return DSKGPU_E_ARG;
+    CK(hipSetDevice(ctx->cfg.device));
+    return sk_scatter_slice(ctx, d_send, capacity_words, slice);
+}
+int dskgpu_mg_slices_finish(dskgpu_ctx* ctx, int* overflowed) {
+    if (!ctx || !overflowed) return DSKGPU_E_ARG;
+    CK(hipSetDevice(ctx->cfg.device));
+    return sk_slices_finish(ctx, overflowed);
+}
+int dskgpu_mg_count_sliced(dskgpu_ctx* ctx, const void* d_recv, uint32_t nslices, const uint64_t* slice_words, uint64_t n_kmers_est,
+                           dskgpu_slice_gate gate, void* user) {
+    if (!ctx || !nslices || !slice_words || !gate) return DSKGPU_E_ARG;
+    if (!ctx->sk_mode) return fail(ctx, DSKGPU_E_STATE, "dskgpu_mg_count_sliced needs super-k-mer records (20 <= k <= 64, no DSKGPU_F_MG_EXPLICIT)");
+    CK(hipSetDevice(ctx->cfg.device));
+    ctx->stats = dskgpu_stats{};
+    const u32 R = ctx->sk_sp.R;
+    u64 words = 0;
+    ctx->rec_slice_end.clear();
+    for (u32 sl = 0; sl < nslices; ++sl) {
+        if (slice_words[sl] % R) { ctx->rec_slice_end.clear(); return fail(ctx, DSKGPU_E_ARG, "a slice is not a whole number of super-k-mer records"); }
+        words += slice_words[sl];
+        ctx->rec_slice_end.push_back(words / R);
+    }
+    if (!d_recv && words) { ctx->rec_slice_end.clear(); return DSKGPU_E_ARG; }
+    ctx->rec_gate = gate; ctx->rec_gate_user = user; ctx->rec_gated = 0;
+    const int rc = ctx->W == 1 ? sk_count<1>(ctx, static_cast<const u64*>(d_recv), words, n_kmers_est, true)
+                               : sk_count<2>(ctx, static_cast<const u64*>(d_recv), words, n_kmers_est, true);
+    rec_gate_all(ctx);                                   // (an error path may have left early: the caller's gates are all passed when this returns)
+    ctx->rec_gate = nullptr; ctx->rec_gate_user = nullptr; ctx->rec_slice_end.clear();
+    return rc;
+}
 
 int dskgpu_mg_count_sized(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words, uint64_t n_kmers) {
     if (!ctx || (!d_recv && recv_words)) return DSKGPU_E_ARG;

@@ -525,7 +525,11 @@ __device__ __forceinline__ u32 tile_keys_records(const RecPre<W>& pre, u32 R, u6
 // the pass reads as its input.
 struct Opt1Spec { const u32* boff; u32 area, dump; u32* ovf; u32* fill; u32 R; u64* nkeys;      // R: words per super-k-mer record (SRC 2)
                   const u64* hv_keys; unsigned long long* hv_cnt; u32 slice_len; u64 obase[4];      // obase: MODE 4, key offset of every bin's region in `out`
-                  u32 uslice; };      // != 0: UNIFORM slices of that many keys (bin b at b * uslice, boff unused) -- no slice-end array in LDS: plans above 1634 bins
+                  u32 uslice;         // != 0: UNIFORM slices of that many keys (bin b at b * uslice, boff unused) -- no slice-end array in LDS: plans above 1634 bins
+                  // records (SRC 2) arriving in slices (a multi-GPU step whose exchange overlaps this kernel): one launch per slice over
+                  // the chunks [g0, g0 + gn) (cur_state == nullptr: one launch over all chunks), the blocks' write cursors parked in cur_state[block * P + bin] in between;
+                  // `resume` picks them up, only the `last` launch reports fill / overflow / keys placed
+                  u32* cur_state; u32 g0, gn, resume, last; };
 #define L0_MAX_PASSES 4            // passes a level-0 sweep materialises together (bins of the MODE 4 scatter)
 
 template <int W, int SRC, int MODE, bool OPT = false, bool HEAVY = false>
@@ -552,12 +556,17 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
     const u32 first = OPT ? blockIdx.x * o1.area : 0u;
     if (OPT && o1.uslice) for (u32 b = threadIdx.x; b < P; b += SC_NT) cur[b] = first + b * o1.uslice;
     else if (OPT) for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] = first + o1.boff[b]; lim[b] = o1.slice_len ? cur[b] + o1.slice_len : first + o1.boff[b + 1]; }
+    u32 gbeg = blockIdx.x, gend = nchunks;
+    if constexpr (SRC == 2 && OPT) {
+        if (o1.cur_state) { gbeg += o1.g0; gend = o1.g0 + o1.gn; }
+        if (o1.resume) for (u32 b = threadIdx.x; b < P; b += SC_NT) cur[b] = o1.cur_state[(u64)blockIdx.x * P + b];
+    }
     u64 hk[HV_KEYS]; u32 hc[HV_KEYS]; int nhk = 0;       // (nhk: how many are in use -- the list is dense, a wave-uniform count)
     if constexpr (HEAVY) {
 #pragma unroll
         for (int x = 0; x < HV_KEYS; ++x) { hk[x] = o1.hv_keys[x]; hc[x] = 0; if (hk[x] != DSK_EMPTY) nhk = x + 1; }
     }
-    for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
+    for (u32 g = gbeg; g < gend; g += gridDim.x) {
         const ChunkDesc d = descs[g];
         lds_barrier();   // previous chunk's write-out reads delta/off/stage
         for (u32 b = threadIdx.x; b < P; b += SC_NT) { if (!OPT) cur[b] = scanned[d.flat_base + (u64)b * d.stride]; cnt[b] = 0; }
@@ -699,6 +708,12 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
     }
     if (OPT) {      // how much of each of its slices this block filled; report a slice that was outgrown
         lds_barrier();
+        if constexpr (SRC == 2) {
+            if (o1.cur_state) {
+                for (u32 b = threadIdx.x; b < P; b += SC_NT) o1.cur_state[(u64)blockIdx.x * P + b] = cur[b];
+                if (!o1.last) return;
+            }
+        }
         bool ovf = false;
         u32 mine = 0;
         for (u32 b = threadIdx.x; b < P; b += SC_NT) {

@@ -42,7 +42,12 @@ struct SkParams {
     u32 tiles_per_chunk, nchunks;
     u32 k, m, G, R;
     u32 sample_step;      // k_sk_hist: look at every sample_step-th tile only (1 = exact count)
-    u32 slice;            // k_sk_scatter<true>: records per (owner, chunk) slice; owner o starts at o * nchunks * slice
+    u32 slice;            // k_sk_scatter<true>: records per (owner, chunk) slice
+    // k_sk_scatter<true> writes the chunks [c0, c0 + gridDim) of a layout GROUP of clen chunks that starts at chunk c0g and at record
+    // rbase of the send buffer: owner o of the group starts at rbase + o * clen * slice, its chunk c at + (c - c0g) * slice.
+    // One group = all chunks (c0 = c0g = 0, clen = nchunks, rbase = 0): the layout of a whole step; S groups: a step sent in S
+    // slices, each complete -- and on its way -- before the next is written (dskgpu_mg_scatter_slice).
+    u32 c0, c0g, clen, rbase;
     const unsigned char* table;   // SK_BUCKETS owners (device memory)
 };
 
@@ -186,13 +191,16 @@ __device__ __forceinline__ u32 sk_run_length(const SkThread& s, int i) {
 }
 
 // ---------------------------------------------------------------- sender: records per (owner, chunk)
+// kmers[o] += k-mers inside the records counted for owner o (with sample_step > 1: of the sampled tiles -- the estimate that
+// sizes the receivers of a sliced step before any record exists)
 __global__ __launch_bounds__(SK_NT) void k_sk_hist(const u64* __restrict__ packed, const u32* __restrict__ inval,
-                                                   SkParams sp, u32* __restrict__ mat) {
+                                                   SkParams sp, u32* __restrict__ mat, unsigned long long* __restrict__ kmers) {
     __shared__ u32 H[SK_NT * 17];
     __shared__ u32 cnt[SK_MAX_OWNERS];
+    __shared__ u32 kcn[SK_MAX_OWNERS];
     __shared__ unsigned char tab[SK_BUCKETS];
     const u32 c = blockIdx.x;
-    if (threadIdx.x < SK_MAX_OWNERS) cnt[threadIdx.x] = 0;
+    if (threadIdx.x < SK_MAX_OWNERS) { cnt[threadIdx.x] = 0; kcn[threadIdx.x] = 0; }
     for (int i = threadIdx.x; i < SK_BUCKETS / 8; i += SK_NT) reinterpret_cast<u64*>(tab)[i] = reinterpret_cast<const u64*>(sp.table)[i];
     __syncthreads();
     const u64 tbeg = (u64)c * sp.tiles_per_chunk;
@@ -203,11 +211,15 @@ __global__ __launch_bounds__(SK_NT) void k_sk_hist(const u64* __restrict__ packe
         while (bm) {
             const int i = __builtin_ctz(bm); bm &= bm - 1;
             atomicAdd(&cnt[sk_owner(s, i)], 1u);
+            atomicAdd(&kcn[sk_owner(s, i)], sk_run_length(s, i));
         }
         sk_lds_barrier();
     }
     __syncthreads();
-    if (threadIdx.x < sp.G) mat[(u64)threadIdx.x * sp.nchunks + c] = cnt[threadIdx.x];
+    if (threadIdx.x < sp.G) {
+        mat[(u64)threadIdx.x * sp.nchunks + c] = cnt[threadIdx.x];
+        if (kcn[threadIdx.x]) atomicAdd(&kmers[threadIdx.x], (unsigned long long)kcn[threadIdx.x]);
+    }
 }
 
 // ---------------------------------------------------------------- repartition: sampled k-mer load per minimizer bucket
@@ -243,10 +255,10 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
     __shared__ u32 kc[SK_MAX_OWNERS];
     __shared__ u32 desc[SK_NT / 64][SK_DESC];
     __shared__ unsigned char tab[SK_BUCKETS];
-    const u32 c = blockIdx.x;
+    const u32 c = blockIdx.x + (SLICES ? sp.c0 : 0u);
     for (int i = threadIdx.x; i < SK_BUCKETS / 8; i += SK_NT) reinterpret_cast<u64*>(tab)[i] = reinterpret_cast<const u64*>(sp.table)[i];
     __syncthreads();
-    if (threadIdx.x < sp.G) { cur[threadIdx.x] = SLICES ? (threadIdx.x * sp.nchunks + c) * sp.slice : mat[(u64)threadIdx.x * sp.nchunks + c]; kc[threadIdx.x] = 0; }
+    if (threadIdx.x < sp.G) { cur[threadIdx.x] = SLICES ? sp.rbase + (threadIdx.x * sp.clen + (c - sp.c0g)) * sp.slice : mat[(u64)threadIdx.x * sp.nchunks + c]; kc[threadIdx.x] = 0; }
     bool over = false;
     const u64 tbeg = (u64)c * sp.tiles_per_chunk;
     const u64 tend = tbeg + sp.tiles_per_chunk < sp.ntiles ? tbeg + sp.tiles_per_chunk : sp.ntiles;
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
                 const u64 w1 = wi >= 1 ? packed[wi - 1] : 0ull;
                 const u64 w2 = wi >= 2 ? packed[wi - 2] : 0ull;
                 const u32 slot = atomicAdd(&cur[own], 1u);
-                if (SLICES && slot >= (own * sp.nchunks + c + 1) * sp.slice) { over = true; continue; }
+                if (SLICES && slot >= sp.rbase + (own * sp.clen + (c - sp.c0g) + 1) * sp.slice) { over = true; continue; }
                 atomicAdd(&kc[own], n);
                 // bases [bs, bs + nb) of the 96-base frame (w2 : w1 : w0), shifted to the top of the record
                 u64 o[3];
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
     if (SLICES) {
         if (over) *ovf = 1u;
         for (u32 o = 0; o < sp.G; ++o) {                      // zero-length records up to the end of each of this block's slices
-            const u64 end = (u64)(o * sp.nchunks + c + 1) * sp.slice * R;
+            const u64 end = (u64)(sp.rbase + (o * sp.clen + (c - sp.c0g) + 1) * sp.slice) * R;
             for (u64 w = (u64)cur[o] * R + threadIdx.x; w < end; w += SK_NT) send[w] = 0ull;
         }
     }

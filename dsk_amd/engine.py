@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import List, Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -82,7 +82,8 @@ EXPORTS = [
     "dskgpu_create", "dskgpu_destroy", "dskgpu_last_error", "dskgpu_version", "dskgpu_device_count", "dskgpu_set_stream",
     "dskgpu_push_reads", "dskgpu_reserve_reads", "dskgpu_reserve_work", "dskgpu_set_reads_device", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
     "dskgpu_count", "dskgpu_mg_scatter", "dskgpu_mg_sample", "dskgpu_mg_make_table", "dskgpu_mg_set_table",
-    "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_mg_sent_kmers", "dskgpu_mg_count_sized", "dskgpu_get_stats", "dskgpu_histogram",
+    "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_mg_sent_kmers", "dskgpu_mg_count_sized",
+    "dskgpu_mg_slices_prepare", "dskgpu_mg_scatter_slice", "dskgpu_mg_slices_finish", "dskgpu_mg_count_sliced", "dskgpu_get_stats", "dskgpu_histogram",
     "dskgpu_num_partitions", "dskgpu_partition_size", "dskgpu_partition_copy", "dskgpu_result_device",
     "dskgpu_stage_times", "dskgpu_k_encode", "dskgpu_k_enumerate", "dskgpu_k_minimizers",
     "dskgpu_group_create", "dskgpu_group_destroy", "dskgpu_group_last_error", "dskgpu_group_size", "dskgpu_group_ctx",
@@ -91,6 +92,9 @@ EXPORTS = [
 ]
 
 _lib = None
+
+
+SLICE_GATE = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32)      # dskgpu_slice_gate
 
 
 def library_path() -> str:
@@ -136,6 +140,10 @@ def load_library():
     lib.dskgpu_mg_count.argtypes = [vp, vp, u64]
     lib.dskgpu_mg_sent_kmers.argtypes = [vp, C.POINTER(u64)]
     lib.dskgpu_mg_count_sized.argtypes = [vp, vp, u64, u64]
+    lib.dskgpu_mg_slices_prepare.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
+    lib.dskgpu_mg_scatter_slice.argtypes = [vp, vp, u64, u32]
+    lib.dskgpu_mg_slices_finish.argtypes = [vp, C.POINTER(C.c_int)]
+    lib.dskgpu_mg_count_sliced.argtypes = [vp, vp, u32, C.POINTER(u64), u64, SLICE_GATE, vp]
     lib.dskgpu_get_stats.argtypes = [vp, C.POINTER(_Stats)]
     lib.dskgpu_histogram.argtypes = [vp, C.POINTER(u64), u32]
     lib.dskgpu_num_partitions.argtypes = [vp]
@@ -318,6 +326,32 @@ class KmerCounter:
         k = (C.c_uint64 * self.world_size)()
         self._ck(self._lib.dskgpu_mg_sent_kmers(self._h, k))
         return [int(c) for c in k]
+
+    # -- a step in slices (the exchange of slice i overlaps the sender of slice i + 1 and the receiver's level 1 of slice i - 1)
+    def mg_slices_prepare(self, want_slices: int):
+        """-> (nslices, send_words[nslices][world], kmers_est[world]); nslices == 0: this input takes the one-piece path."""
+        n = C.c_uint32(0)
+        words = (C.c_uint64 * (want_slices * self.world_size))()
+        est = (C.c_uint64 * self.world_size)()
+        self._ck(self._lib.dskgpu_mg_slices_prepare(self._h, want_slices, C.byref(n), words, est))
+        ns = int(n.value)
+        return ns, [[int(words[s * self.world_size + o]) for o in range(self.world_size)] for s in range(ns)], [int(x) for x in est]
+
+    def mg_scatter_slice(self, send_ptr: int, capacity_words: int, s: int) -> None:
+        """Launches the sender of slice s on the context's stream; returns without synchronising."""
+        self._ck(self._lib.dskgpu_mg_scatter_slice(self._h, C.c_void_p(send_ptr), capacity_words, s))
+
+    def mg_slices_finish(self) -> bool:
+        """True when a slice of the send layout overflowed: every rank then repeats the step in one piece."""
+        o = C.c_int(0)
+        self._ck(self._lib.dskgpu_mg_slices_finish(self._h, C.byref(o)))
+        return bool(o.value)
+
+    def mg_count_sliced(self, recv_ptr: int, slice_words: Sequence[int], n_kmers_est: int, gate) -> None:
+        """gate(s) is called right before the first device work that reads slice s is enqueued: make the stream wait for it."""
+        arr = (C.c_uint64 * len(slice_words))(*[int(w) for w in slice_words])
+        cb = SLICE_GATE(lambda _user, s: gate(int(s)))
+        self._ck(self._lib.dskgpu_mg_count_sliced(self._h, C.c_void_p(recv_ptr), len(slice_words), arr, n_kmers_est, cb, None))
 
     def mg_count(self, recv_ptr: int, recv_words: int, n_kmers: int = 0) -> None:
         """n_kmers = the senders' k-mer total for this rank (sum over sources of mg_sent_kmers()[rank]); 0 = count them here."""

@@ -148,6 +148,31 @@ int dskgpu_mg_count(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words);
  * match the records is reported as DSKGPU_E_ARG, never as a wrong result. */
 int dskgpu_mg_sent_kmers(dskgpu_ctx* ctx, uint64_t* kmers /* [world_size] */);
 int dskgpu_mg_count_sized(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_words, uint64_t n_kmers);
+/* ---- the same step in SLICES, so that the exchange overlaps both of its neighbours: the exchange of slice i runs while the
+ * sender writes slice i + 1 and while the receiver partitions slice i - 1.  Needs the sampled send layout (its sizes are known
+ * before a record exists: the word counts of ALL slices go round once, up front):
+ *   dskgpu_mg_slices_prepare  sizing pass; *nslices = 0 when this input takes the one-piece path (small input, explicit keys, a
+ *                             send slice overflowed before) -- then use dskgpu_mg_scatter / dskgpu_mg_count.  Otherwise
+ *                             send_words[s * world_size + o] = words slice s holds for owner o (slice-major, owner-major inside: the
+ *                             send buffer is the concatenation, dskgpu_mg_send_capacity_words in all), kmers_est[o] = estimated
+ *                             k-mers for owner o over all slices (sizes the receiver; an estimate, never a correctness input).
+ *   dskgpu_mg_scatter_slice   launches the sender of slice s on the context's stream and returns (no synchronisation): the caller
+ *                             records an event behind it and starts that slice's exchange on another stream.
+ *   dskgpu_mg_count_sliced    the receiver: d_recv holds the slices one after the other (slice_words[s] words each, whatever the
+ *                             order of the sources inside a slice); gate(user, s) is called on the host right before the first
+ *                             device work that reads slice s is enqueued -- the callee makes the context's stream wait for the
+ *                             arrival of slice s (hipStreamWaitEvent / a torch work handle's wait()).  Slices are gated in order,
+ *                             each once; a path that needs all records at once gates all of them first.
+ *   dskgpu_mg_slices_finish   after the exchange: *overflowed != 0 when a slice of the SEND layout overflowed -- the records of this
+ *                             step are then incomplete on some receivers, and every rank must repeat the step in one piece (the
+ *                             decision is the caller's collective: OR the flags); the context will use exact counts from then on. */
+typedef void (*dskgpu_slice_gate)(void* user, uint32_t slice);
+int dskgpu_mg_slices_prepare(dskgpu_ctx* ctx, uint32_t want_slices, uint32_t* nslices, uint64_t* send_words /* [want_slices * world_size] */,
+                             uint64_t* kmers_est /* [world_size] */);
+int dskgpu_mg_scatter_slice(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint32_t slice);
+int dskgpu_mg_slices_finish(dskgpu_ctx* ctx, int* overflowed);
+int dskgpu_mg_count_sliced(dskgpu_ctx* ctx, const void* d_recv, uint32_t nslices, const uint64_t* slice_words, uint64_t n_kmers_est,
+                           dskgpu_slice_gate gate, void* user);
 
 /* ---- results: replace the CountProcessor outputs read back through
  * Storage (src/DSK.cpp:68; utils/dsk2ascii.cpp:61-104; simple_test.sh:37) */

@@ -764,6 +764,72 @@ def test_multi_gpu_path_on_one_device(oracle, golden_dir, dev, world, k, explici
         c.close()
 
 
+@pytest.mark.parametrize("world,k,est_scale", [(4, 31, 1.0), (2, 63, 1.0), (4, 31, 0.5), (2, 31, 3.0)])
+def test_step_in_slices_on_one_device(oracle, dev, monkeypatch, world, k, est_scale):
+    """The sliced step (dskgpu_mg_slices_prepare / _scatter_slice / _count_sliced / _slices_finish) with the exchange done by hand:
+    every sender writes its records in 4 slices (slice-major, owner-major inside), every receiver gets the slices one after the
+    other and partitions them with one level-1 launch per slice behind its gate -- gates called in order, each once.  The k-mer
+    total that sizes the receiver is an ESTIMATE: halved (the sized slices overflow: the receiver re-plans with the real figure)
+    or tripled it must not change the result.  Same rows and histogram as the oracle, and as the one-piece step."""
+    from dsk_amd import KmerCounter, synth
+    monkeypatch.setenv("DSKGPU_SK_MINSLICE", "1")              # the sampled send layout on a test-sized input
+    S = 4
+    reads = synth.make_reads(synth.make_genome(2_000_000, dev), 600_000, 150)
+    n_reads = 600_000
+    per = n_reads // world
+    ctxs, sends, words, ests = [], [], [], []
+    for r in range(world):
+        shard = reads[r * per * 151: (r + 1) * per * 151].clone()
+        kc = KmerCounter(kmer_size=k, abundance_min=2, world_size=world, rank=r)
+        kc.set_reads_device(shard.data_ptr(), shard.numel())
+        ns, w, est = kc.mg_slices_prepare(S)
+        assert ns == S and len(w) == S and all(len(x) == world for x in w)
+        cap = kc.mg_send_capacity_words()
+        assert sum(sum(x) for x in w) + 1 == cap              # the slices tile the send buffer
+        send = torch.zeros(cap, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        for sl in range(S):
+            kc.mg_scatter_slice(send.data_ptr(), send.numel(), sl)
+        ctxs.append((kc, shard)); sends.append(send); words.append(w); ests.append(est)
+    torch.cuda.synchronize()
+    rows_k, rows_a, hist, nk = [], [], np.zeros(10001, np.uint64), 0
+    for d in range(world):
+        parts, slice_words = [], []
+        for sl in range(S):
+            tot = 0
+            for src in range(world):
+                off = sum(sum(words[src][x]) for x in range(sl)) + sum(words[src][sl][:d])
+                parts.append(sends[src][off: off + words[src][sl][d]])
+                tot += words[src][sl][d]
+            slice_words.append(tot)
+        recv = torch.cat(parts)
+        torch.cuda.synchronize()
+        gates = []
+        est = int(sum(ests[src][d] for src in range(world)) * est_scale)
+        ctxs[d][0].mg_count_sliced(recv.data_ptr(), slice_words, est, gates.append)
+        assert gates == list(range(S))
+        kk, aa = ctxs[d][0].rows()
+        rows_k.append(kk); rows_a.append(aa); hist += ctxs[d][0].histogram(); nk += ctxs[d][0].stats()["n_kmers"]
+        if est_scale == 1.0:                                   # the estimate is good to a few per cent, and the fast path was taken
+            real = ctxs[d][0].stats()["n_kmers"]
+            assert abs(est - real) < 0.03 * real and ctxs[d][0].stats()["n_retries"] == 0
+            assert ctxs[d][0].stats()["n_levels"] == 2          # (two levels: the level-1 scatter ran once per slice, from the records)
+    for kc, _ in ctxs:
+        assert kc.mg_slices_finish() is False
+    ref = oracle.count(reads.cpu().numpy(), k)
+    assert nk == ref.total and (hist == ref.histogram(10000)).all()
+    kk = np.concatenate(rows_k); aa = np.concatenate(rows_a)
+    keep = ref.ab >= 2
+    if k <= 32:
+        order = np.argsort(kk[:, 0])
+        assert (kk[order, 0] == ref.lo[keep]).all() and (aa[order] == ref.ab[keep]).all()
+    else:
+        order = np.lexsort((kk[:, 0], kk[:, 1]))
+        assert (kk[order, 0] == ref.lo[keep]).all() and (kk[order, 1] == ref.hi[keep]).all() and (aa[order] == ref.ab[keep]).all()
+    for kc, _ in ctxs:
+        kc.close()
+
+
 def _fmix32(h):
     h = h.astype(np.uint64)
     h ^= h >> np.uint64(16); h = (h * np.uint64(0x85ebca6b)) & np.uint64(0xFFFFFFFF)
