@@ -1551,7 +1551,7 @@ int sk_prepare(dskgpu_ctx* ctx) {
     // pads the slices with zero-length records.  Saves the full counting pass (1.95 of 5 ms); ~8 % more words to send.
     const bool slices = !ctx->sk_exact && !ctx->tune.sk_exact && tpc >= 8;
     sp.sample_step = slices ? 16u : 1u;
-    CK(ctx->sk_sent.ensure(2 * SK_MAX_OWNERS * 8));            // [k-mers sent per owner | sampled k-mers per owner]
+    CK(ctx->sk_sent.ensure(3 * SK_MAX_OWNERS * 8));            // [k-mers sent per owner | sampled k-mers per owner | overflow flag of a sliced step]
     CK(hipMemsetAsync(ctx->sk_sent.as<u64>() + SK_MAX_OWNERS, 0, SK_MAX_OWNERS * 8, ctx->stream));
     hipLaunchKernelGGL(k_sk_hist, dim3((unsigned)nch), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, ctx->mat1.as<u32>(),
                        ctx->sk_sent.as<unsigned long long>() + SK_MAX_OWNERS);
@@ -1647,17 +1647,20 @@ int sk_scatter_slice(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, u32
     if (!ctx->sk_prepared || !ctx->sk_slices || sl >= ctx->sk_nslices) return fail(ctx, DSKGPU_E_STATE, "dskgpu_mg_scatter_slice without dskgpu_mg_slices_prepare");
     SkParams sp = ctx->sk_sp;
     if (capacity_words < (u64)ctx->h_starts[sp.G] * sp.R) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
-    u32* sc = ctx->scalars.as<u32>();
     if (sl == 0) {
         ctx->marks.clear(); ctx->ev_used = 0;
         ctx->mark("start");
         CK(hipMemsetAsync(ctx->sk_sent.p, 0, SK_MAX_OWNERS * 8, ctx->stream));
+        CK(hipMemsetAsync(ctx->sk_sent.as<u64>() + 2 * SK_MAX_OWNERS, 0, 8, ctx->stream));
     }
     u32 cb, ce; sk_slice_range(sp, ctx->sk_nslices, sl, &cb, &ce);
     sp.c0 = cb; sp.c0g = cb; sp.clen = ce - cb; sp.rbase = cb * sp.G * sp.slice;
+    // (the overflow flag of a sliced step lives apart from the scalars: the receiver's pipeline, which runs before the flag is
+    //  read, resets those)
     if (ce > cb)
         hipLaunchKernelGGL(k_sk_scatter<true>, dim3(ce - cb), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
-                           ctx->mat1.as<u32>(), static_cast<u64*>(d_send), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>());
+                           ctx->mat1.as<u32>(), static_cast<u64*>(d_send), reinterpret_cast<u32*>(ctx->sk_sent.as<u64>() + 2 * SK_MAX_OWNERS),
+                           ctx->sk_sent.as<unsigned long long>());
     CKL("k_sk_scatter");
     if (sl + 1 == ctx->sk_nslices) ctx->mark("mg_scatter");
     return DSKGPU_OK;
@@ -1667,8 +1670,7 @@ int sk_scatter_slice(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, u32
 // repeats the step in one piece; this context will use exact counts), and the k-mers that were packed
 int sk_slices_finish(dskgpu_ctx* ctx, int* overflowed) {
     if (!ctx->sk_nslices) return fail(ctx, DSKGPU_E_STATE, "dskgpu_mg_slices_finish without dskgpu_mg_slices_prepare");
-    u32* sc = ctx->scalars.as<u32>();
-    CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(&ctx->h_ovf1, ctx->sk_sent.as<u64>() + 2 * SK_MAX_OWNERS, 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipMemcpyAsync(ctx->h_sk_sent, ctx->sk_sent.p, SK_MAX_OWNERS * 8, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     *overflowed = ctx->h_ovf1 ? 1 : 0;

@@ -74,16 +74,18 @@ std::mutex g_rccl_mu;
 class Barrier {
 public:
     explicit Barrier(unsigned n) : n_(n) {}
-    bool wait(bool failed) {
+    bool wait(bool failed) { return (wait_bits(failed ? 1u : 0u) & 1u) != 0; }
+    // the same with a few flags: bit 0 = "this rank failed", the others as the meeting defines them
+    unsigned wait_bits(unsigned bits) {
         std::unique_lock<std::mutex> lk(mu_);
         const unsigned gen = gen_;
-        pending_ = pending_ || failed;
-        if (++count_ == n_) { count_ = 0; result_ = pending_; pending_ = false; ++gen_; cv_.notify_all(); }
+        pending_ |= bits;
+        if (++count_ == n_) { count_ = 0; result_ = pending_; pending_ = 0; ++gen_; cv_.notify_all(); }
         else cv_.wait(lk, [&] { return gen_ != gen; });
         return result_;          // (cannot change before every rank of this meeting has left: the next one needs all of them)
     }
 private:
-    std::mutex mu_; std::condition_variable cv_; unsigned n_, count_ = 0, gen_ = 0; bool pending_ = false, result_ = false;
+    std::mutex mu_; std::condition_variable cv_; unsigned n_, count_ = 0, gen_ = 0; unsigned pending_ = 0, result_ = 0;
 };
 
 struct DevMem {
@@ -114,6 +116,14 @@ struct dskgpu_group {
     std::vector<DevMem> send, recv;
     std::vector<std::vector<uint64_t>> counts;      // counts[src][dst], 8-byte words
     std::vector<std::vector<uint64_t>> kmers;       // kmers[src][dst], k-mers inside those words (the receiver's sizing)
+    // a step in slices (dskgpu_mg_slices_*): the exchange of slice i runs on the rank's second stream while its first writes
+    // slice i + 1 and, later, partitions slice i - 1
+    uint32_t nslices = 4;                            // DSKGPU_GROUP_SLICES (< 2: every step in one piece)
+    std::vector<hipStream_t> cstream;                // the exchange stream of every rank
+    std::vector<std::vector<hipEvent_t>> ev_sent, ev_recv;      // [rank][slice]: slice written by the sender / arrived at the receiver
+    std::vector<std::vector<uint64_t>> swords;       // swords[src][slice * n + dst], 8-byte words
+    std::vector<std::vector<uint64_t>> kest;         // kest[src][dst]: estimated k-mers over all slices
+    uint32_t sliced_steps = 0;                       // steps of the last count that ran in slices
     std::vector<int> rc;
     std::vector<std::string> rank_err;
     std::string err;
@@ -162,6 +172,97 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
   for (uint32_t bank = 0; bank < nbanks; ++bank) {
     if (per_bank) { dskgpu_i_banks_select(ctx, bank); for (auto& c : g->counts[r]) c = 0; }
     for (auto& c : g->kmers[r]) c = 0;
+    // ---- the step in slices when every rank's input allows it (sampled send layout); else, or when a send slice overflowed,
+    // the step in one piece below
+    bool done_in_slices = false;
+    if (g->nslices >= 2) {
+        const uint32_t S = g->nslices;
+        uint32_t ns = 0;
+        if (g->rc[r] == DSKGPU_OK) {
+            const int rc = dskgpu_mg_slices_prepare(ctx, S, &ns, g->swords[r].data(), g->kest[r].data());
+            if (rc != DSKGPU_OK) fail(rc, std::string("mg_slices_prepare: ") + dskgpu_last_error(ctx));
+        }
+        unsigned bits = bar->wait_bits((failed() ? 1u : 0u) | (ns != S ? 2u : 0u));
+        if (bits & 1u) return;
+        if (!(bits & 2u)) {
+            const std::vector<uint64_t>& mine = g->swords[r];
+            std::vector<uint64_t> rw(S, 0), rbase(S + 1, 0), sbase(S + 1, 0);
+            for (uint32_t sl = 0; sl < S; ++sl) {
+                uint64_t sw = 0;
+                for (uint32_t p = 0; p < n; ++p) { rw[sl] += g->swords[p][(size_t)sl * n + r]; sw += mine[(size_t)sl * n + p]; }
+                rbase[sl + 1] = rbase[sl] + rw[sl]; sbase[sl + 1] = sbase[sl] + sw;
+            }
+            const uint64_t cap = dskgpu_mg_send_capacity_words(ctx);
+            if (cap == 0) fail(DSKGPU_E_DEVICE, std::string("send capacity: ") + dskgpu_last_error(ctx));
+            else if (!g->send[r].ensure(cap * 8)) fail(DSKGPU_E_NOMEM, "send buffer");
+            if (!g->recv[r].ensure(std::max<uint64_t>(rbase[S], 1) * 8)) fail(DSKGPU_E_NOMEM, "receive buffer");
+            if (bar->wait(failed())) return;
+            uint64_t* sb = static_cast<uint64_t*>(g->send[r].p);
+            uint64_t* rb = static_cast<uint64_t*>(g->recv[r].p);
+            hipStream_t cs = g->cstream[r];
+            for (uint32_t sl = 0; sl < S; ++sl) {
+                if (g->rc[r] == DSKGPU_OK) {
+                    const int rc = dskgpu_mg_scatter_slice(ctx, sb, g->send[r].cap / 8, sl);
+                    if (rc != DSKGPU_OK) fail(rc, std::string("mg_scatter_slice: ") + dskgpu_last_error(ctx));
+                    else if (hipEventRecord(g->ev_sent[r][sl], g->stream[r]) != hipSuccess) fail(DSKGPU_E_DEVICE, "hipEventRecord");
+                }
+                if (g->use_rccl) {
+                    if (g->rc[r] != DSKGPU_OK) continue;             // (its peers will hang in RCCL, as in the one-piece exchange: a device error)
+                    RcclApi& a = g_rccl;
+                    (void)hipStreamWaitEvent(cs, g->ev_sent[r][sl], 0);
+                    ncclResult_t e = a.GroupStart();
+                    uint64_t so = sbase[sl], ro = rbase[sl];
+                    for (uint32_t p = 0; p < n && e == ncclSuccess; ++p) {
+                        const uint64_t ws = mine[(size_t)sl * n + p], wr = g->swords[p][(size_t)sl * n + r];
+                        if (ws) e = a.Send(sb + so, ws, ncclUint64, (int)p, g->comm[r], cs);
+                        if (e == ncclSuccess && wr) e = a.Recv(rb + ro, wr, ncclUint64, (int)p, g->comm[r], cs);
+                        so += ws; ro += wr;
+                    }
+                    const ncclResult_t e2 = a.GroupEnd();
+                    if (e == ncclSuccess) e = e2;
+                    if (e != ncclSuccess) fail(DSKGPU_E_DEVICE, std::string("RCCL exchange: ") + a.GetErrorString(e));
+                } else {
+                    if (bar->wait(failed())) return;               // every rank's event of this slice is recorded
+                    uint64_t ro = rbase[sl];
+                    for (uint32_t p = 0; p < n; ++p) {
+                        const uint64_t wr = g->swords[p][(size_t)sl * n + r];
+                        if (!wr) continue;
+                        uint64_t so = 0;                              // where slice sl, owner r starts in p's send buffer
+                        for (uint32_t x = 0; x < sl; ++x) for (uint32_t o = 0; o < n; ++o) so += g->swords[p][(size_t)x * n + o];
+                        for (uint32_t o = 0; o < r; ++o) so += g->swords[p][(size_t)sl * n + o];
+                        hipError_t e = hipStreamWaitEvent(cs, g->ev_sent[p][sl], 0);
+                        if (e == hipSuccess) e = hipMemcpyAsync(rb + ro, static_cast<const uint64_t*>(g->send[p].p) + so, wr * 8, hipMemcpyDefault, cs);
+                        if (e != hipSuccess) { fail(DSKGPU_E_DEVICE, std::string("exchange copy: ") + hipGetErrorString(e)); break; }
+                        ro += wr;
+                    }
+                }
+                if (hipEventRecord(g->ev_recv[r][sl], cs) != hipSuccess) fail(DSKGPU_E_DEVICE, "hipEventRecord");
+            }
+            // the receiver: one level-1 launch per slice, each behind the arrival of its slice
+            uint64_t est = 0;
+            for (uint32_t p = 0; p < n; ++p) est += g->kest[p][r];
+            struct Gate { hipStream_t st; hipEvent_t* ev; } gs{g->stream[r], g->ev_recv[r].data()};
+            auto gate = [](void* u, uint32_t sl) { Gate* x = static_cast<Gate*>(u); (void)hipStreamWaitEvent(x->st, x->ev[sl], 0); };
+            if (g->rc[r] == DSKGPU_OK) {
+                const int rc = dskgpu_mg_count_sliced(ctx, rbase[S] ? rb : nullptr, S, rw.data(), est, gate, &gs);
+                if (rc != DSKGPU_OK) fail(rc, std::string("mg_count_sliced: ") + dskgpu_last_error(ctx));
+            }
+            int ovf = 0;
+            if (g->rc[r] == DSKGPU_OK) {
+                const int rc = dskgpu_mg_slices_finish(ctx, &ovf);
+                if (rc != DSKGPU_OK) fail(rc, std::string("mg_slices_finish: ") + dskgpu_last_error(ctx));
+            }
+            if (hipStreamSynchronize(cs) != hipSuccess) fail(DSKGPU_E_DEVICE, "exchange: stream synchronize");
+            bits = bar->wait_bits((failed() ? 1u : 0u) | (ovf ? 2u : 0u));      // (also: nobody overwrites a send buffer a peer still reads)
+            if (bits & 1u) return;
+            if (!(bits & 2u)) {
+                done_in_slices = true;
+                for (uint32_t p = 0; p < n; ++p) { g->counts[r][p] = 0; for (uint32_t sl = 0; sl < S; ++sl) g->counts[r][p] += mine[(size_t)sl * n + p]; }
+                if (r == 0) ++g->sliced_steps;
+            }
+        }
+    }
+  if (!done_in_slices) {
     // ---- step 1: this rank's records, grouped by owner
     if (g->rc[r] == DSKGPU_OK) {
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -213,7 +314,9 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
     for (uint32_t s = 0; s < n; ++s) recv_kmers += g->kmers[s][r];
     int rc = dskgpu_mg_count_sized(ctx, recv_words ? g->recv[r].p : nullptr, recv_words, recv_kmers);
     if (rc != DSKGPU_OK) fail(rc, std::string("mg_count: ") + dskgpu_last_error(ctx));
+  }
     if (per_bank) {
+        int rc;
         if (g->rc[r] == DSKGPU_OK && (rc = dskgpu_i_banks_add(ctx, bank)) != DSKGPU_OK) fail(rc, std::string("banks: ") + dskgpu_last_error(ctx));
         if (bar->wait(failed())) return;             // (the next bank re-uses the send buffers and the counts matrix)
     }
@@ -250,6 +353,11 @@ int dskgpu_group_create(const dskgpu_config* cfg, const int32_t* devices, uint32
     g->counts.assign(n_ranks, std::vector<uint64_t>(n_ranks, 0));
     g->kmers.assign(n_ranks, std::vector<uint64_t>(n_ranks, 0));
     g->rc.assign(n_ranks, DSKGPU_OK); g->rank_err.assign(n_ranks, "");
+    if (const char* e = getenv("DSKGPU_GROUP_SLICES")) g->nslices = (uint32_t)std::min<long>(64, std::max<long>(0, std::atol(e)));
+    g->cstream.assign(n_ranks, nullptr);
+    g->ev_sent.assign(n_ranks, std::vector<hipEvent_t>(g->nslices, nullptr)); g->ev_recv = g->ev_sent;
+    g->swords.assign(n_ranks, std::vector<uint64_t>((size_t)std::max<uint32_t>(g->nslices, 1) * n_ranks, 0));
+    g->kest.assign(n_ranks, std::vector<uint64_t>(n_ranks, 0));
     g->loads.assign(n_ranks, std::vector<uint64_t>(DSKGPU_MG_BUCKETS, 0)); g->table.assign(DSKGPU_MG_BUCKETS, 0);
     if (const char* e = getenv("DSKGPU_GROUP_BALANCE")) g->balance = std::strcmp(e, "0") != 0;     // "0": keep the default table (tests)
     for (uint32_t r = 0; r < n_ranks; ++r) {
@@ -260,6 +368,12 @@ int dskgpu_group_create(const dskgpu_config* cfg, const int32_t* devices, uint32
         if (hipSetDevice(devices[r]) != hipSuccess || hipStreamCreateWithFlags(&g->stream[r], hipStreamNonBlocking) != hipSuccess)
             return bail(DSKGPU_E_DEVICE, "stream of rank " + std::to_string(r));
         if (dskgpu_set_stream(g->ctx[r], g->stream[r]) != DSKGPU_OK) return bail(DSKGPU_E_DEVICE, "set_stream");
+        if (g->nslices >= 2) {
+            if (hipStreamCreateWithFlags(&g->cstream[r], hipStreamNonBlocking) != hipSuccess) return bail(DSKGPU_E_DEVICE, "exchange stream of rank " + std::to_string(r));
+            for (uint32_t sl = 0; sl < g->nslices; ++sl)
+                if (hipEventCreateWithFlags(&g->ev_sent[r][sl], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&g->ev_recv[r][sl], hipEventDisableTiming) != hipSuccess) return bail(DSKGPU_E_DEVICE, "events of rank " + std::to_string(r));
+        }
     }
     if (!g->use_rccl) {                                  // the copy transport reads the peers' send buffers directly
         for (uint32_t a = 0; a < n_ranks; ++a)
@@ -292,6 +406,9 @@ void dskgpu_group_destroy(dskgpu_group* g) {
         if (g->ctx[r]) { (void)dskgpu_set_stream(g->ctx[r], nullptr); dskgpu_destroy(g->ctx[r]); }
         if (r < g->send.size()) { g->send[r].release(); g->recv[r].release(); }
         if (r < g->stream.size() && g->stream[r]) (void)hipStreamDestroy(g->stream[r]);
+        if (r < g->cstream.size() && g->cstream[r]) { (void)hipStreamSynchronize(g->cstream[r]); (void)hipStreamDestroy(g->cstream[r]); }
+        if (r < g->ev_sent.size()) for (hipEvent_t e : g->ev_sent[r]) if (e) (void)hipEventDestroy(e);
+        if (r < g->ev_recv.size()) for (hipEvent_t e : g->ev_recv[r]) if (e) (void)hipEventDestroy(e);
     }
     delete g;
 }
@@ -300,10 +417,11 @@ uint32_t dskgpu_group_size(const dskgpu_group* g) { return g ? g->n : 0; }
 dskgpu_ctx* dskgpu_group_ctx(dskgpu_group* g, uint32_t rank) { return (g && rank < g->n) ? g->ctx[rank] : nullptr; }
 const char* dskgpu_group_transport(const dskgpu_group* g) { return !g ? "" : g->use_rccl ? "rccl" : "copy"; }
 uint64_t dskgpu_group_exchanged_words(const dskgpu_group* g) { return g ? g->exchanged_words : 0; }
+uint32_t dskgpu_group_sliced_steps(const dskgpu_group* g) { return g ? g->sliced_steps : 0; }
 
 int dskgpu_group_count(dskgpu_group* g) {
     if (!g) return DSKGPU_E_ARG;
-    g->have_result = false;
+    g->have_result = false; g->sliced_steps = 0;
     std::fill(g->rc.begin(), g->rc.end(), DSKGPU_OK);
     for (auto& row : g->counts) std::fill(row.begin(), row.end(), 0);
     Barrier bar(g->n);

@@ -87,7 +87,7 @@ EXPORTS = [
     "dskgpu_num_partitions", "dskgpu_partition_size", "dskgpu_partition_copy", "dskgpu_result_device",
     "dskgpu_stage_times", "dskgpu_k_encode", "dskgpu_k_enumerate", "dskgpu_k_minimizers",
     "dskgpu_group_create", "dskgpu_group_destroy", "dskgpu_group_last_error", "dskgpu_group_size", "dskgpu_group_ctx",
-    "dskgpu_group_transport", "dskgpu_group_count", "dskgpu_group_exchanged_words", "dskgpu_group_histogram", "dskgpu_group_histogram2d",
+    "dskgpu_group_transport", "dskgpu_group_count", "dskgpu_group_exchanged_words", "dskgpu_group_sliced_steps", "dskgpu_group_histogram", "dskgpu_group_histogram2d",
     "dskgpu_group_get_stats", "dskgpu_group_num_partitions", "dskgpu_group_partition_size", "dskgpu_group_partition_copy",
 ]
 
@@ -170,6 +170,8 @@ def load_library():
     lib.dskgpu_group_count.argtypes = [vp]
     lib.dskgpu_group_exchanged_words.argtypes = [vp]
     lib.dskgpu_group_exchanged_words.restype = u64
+    lib.dskgpu_group_sliced_steps.argtypes = [vp]
+    lib.dskgpu_group_sliced_steps.restype = u32
     lib.dskgpu_group_histogram.argtypes = [vp, C.POINTER(u64), u32]
     lib.dskgpu_group_histogram2d.argtypes = [vp, C.POINTER(u64), u32]
     lib.dskgpu_group_get_stats.argtypes = [vp, C.POINTER(_Stats)]
@@ -469,6 +471,10 @@ class KmerGroup:
 
     def exchanged_words(self) -> int:
         return int(self._lib.dskgpu_group_exchanged_words(self._h))
+
+    def sliced_steps(self) -> int:
+        """Steps of the last count whose exchange ran in slices (overlapped with the sender and the receiver's level 1)."""
+        return int(self._lib.dskgpu_group_sliced_steps(self._h))
 
     def histogram(self) -> np.ndarray:
         out = np.zeros(self.histo_max + 1, dtype=np.uint64)

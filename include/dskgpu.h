@@ -239,6 +239,9 @@ dskgpu_ctx* dskgpu_group_ctx(dskgpu_group* g, uint32_t rank);
 const char* dskgpu_group_transport(const dskgpu_group* g);     /* "rccl" or "copy" */
 int dskgpu_group_count(dskgpu_group* g);
 uint64_t dskgpu_group_exchanged_words(const dskgpu_group* g);  /* 8-byte words that changed rank in the last count */
+/* steps of the last count that ran in slices -- exchange overlapped with the sender and the receiver's level 1 (dskgpu_mg_slices_*;
+ * DSKGPU_GROUP_SLICES = slices per step, default 4, < 2 = every step in one piece); 0 when the input took the one-piece path */
+uint32_t dskgpu_group_sliced_steps(const dskgpu_group* g);
 int dskgpu_group_histogram(const dskgpu_group* g, uint64_t* out, uint32_t nbins);
 /* Per-bank modes (solidity_kind != sum, DSKGPU_F_HISTO2D; banks = dskgpu_next_bank on EVERY rank's context at the same
  * points of the stream): dskgpu_group_count counts the banks one by one with one repartition table, every rank applies the

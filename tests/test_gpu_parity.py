@@ -1189,6 +1189,48 @@ def test_group_count_in_one_process(oracle, golden_dir, dev, monkeypatch, ranks,
                 assert sum(per_rank) == ref.total and min(per_rank) > 0
 
 
+@pytest.mark.parametrize("ranks,k,mode", [(4, 31, "slices"), (2, 63, "slices"), (4, 31, "one_piece"), (4, 31, "one_rank_small"),
+                                          (4, 31, "send_overflow")])
+def test_group_step_in_slices(oracle, dev, monkeypatch, ranks, k, mode):
+    """dskgpu_group_count with the exchange in slices (second stream + events per rank; the level-1 scatter of slice i - 1 and the
+    sender of slice i + 1 run beside the exchange of slice i).  Collective fall-backs to the step in one piece: a rank whose input
+    is too small for the sampled send layout, and a send slice that overflows (the sliced attempt is discarded and repeated)."""
+    from dsk_amd import KmerGroup, synth
+    monkeypatch.setenv("DSKGPU_SK_MINSLICE", "1")
+    if mode == "one_piece":
+        monkeypatch.setenv("DSKGPU_GROUP_SLICES", "1")
+    if mode == "send_overflow":
+        monkeypatch.setenv("DSKGPU_SK_SLICE", "300")            # records per (owner, chunk) slice: far too few
+    n_reads = 600_000
+    reads = synth.make_reads(synth.make_genome(2_000_000, dev), n_reads, 150).cpu().numpy()
+    per = n_reads // ranks
+    shards = [reads[r * per * 151: (r + 1) * per * 151] for r in range(ranks)]
+    if mode == "one_rank_small":
+        shards[1] = shards[1][: 2000 * 151]
+        reads = np.concatenate(shards)
+    ref = oracle.count(reads, k)
+    with KmerGroup([0] * ranks, kmer_size=k, abundance_min=2, nb_partitions=2) as g:
+        for r in range(ranks):
+            g.rank(r).push_reads(shards[r].tobytes())
+        for rep in range(2):
+            g.count()
+            assert g.sliced_steps() == (1 if mode == "slices" else 0)
+            st = g.stats()
+            assert st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct
+            assert (g.histogram() == ref.histogram(10000)).all()
+            ks, abs_ = [], []
+            for p in range(g.num_partitions()):
+                kk, aa = g.partition(p)
+                ks.append(kk); abs_.append(aa)
+            kk = np.concatenate(ks); aa = np.concatenate(abs_)
+            order = np.argsort(kk[:, 0]) if k <= 32 else np.lexsort((kk[:, 0], kk[:, 1]))
+            lo, hi, rab = ref.solid(2)
+            assert (kk[order, 0] == lo).all() and (aa[order] == rab).all()
+            if k > 32:
+                assert (kk[order, 1] == hi).all()
+            assert g.exchanged_words() > 0
+
+
 @pytest.mark.parametrize("k", [15, 27, 63])
 def test_group_with_idle_ranks(oracle, golden_dir, dev, k):
     """More ranks than reads: ranks that send nothing, receive nothing, or both (records for k >= 20, explicit keys below)."""
