@@ -14,6 +14,7 @@ methods to exercise this driver under gloo.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -74,11 +75,18 @@ class ShardedCounter:
     """Drives one rank of the sharded count.  After `count()`, the stage holds
     this rank's share of the result (its owned k-mers)."""
 
-    def __init__(self, stage, device: torch.device, group=None, balance: bool = True):
+    def __init__(self, stage, device: torch.device, group=None, balance: bool = True, slices: Optional[int] = None):
         self.stage = stage
         self.device = device
         self.group = group
         self.balance = balance and hasattr(stage, "mg_sample")
+        # a step in slices: the exchange of slice i (async all-to-all on the process group's stream) runs beside the sender of
+        # slice i + 1 and the receiver's level 1 of slice i - 1.  The stage's stream must be torch's current stream (the
+        # collectives order themselves against it).  DSK_MG_SLICES = slices per step (default 4; < 2: every step in one piece)
+        if slices is None:
+            slices = int(os.environ.get("DSK_MG_SLICES", "4"))
+        self.slices = slices if hasattr(stage, "mg_slices_prepare") else 0
+        self.last_step_sliced = False
         self.table = None            # the repartition table in use (None = the engine's default)
         self.send: Optional[torch.Tensor] = None
         self.recv: Optional[torch.Tensor] = None
@@ -95,9 +103,54 @@ class ShardedCounter:
         self.table = make_table(loads.cpu().numpy().astype("uint64"), dist.get_world_size(self.group))
         self.stage.mg_set_table(self.table)
 
+    def _count_in_slices(self) -> bool:
+        """One step with the exchange in slices; False when the step has to run in one piece -- some rank's input does not take the
+        sampled send layout, or a send slice overflowed (the attempt is then discarded): decided by all ranks together."""
+        world, S = dist.get_world_size(self.group), self.slices
+        if self.device.type == "cuda" and dist.get_backend(self.group) == "gloo":
+            return False                              # (development path: the exchange is staged through host memory)
+        ns, words, est = self.stage.mg_slices_prepare(S)
+        ok = ns == S
+        # one host round: per peer, the words of every slice, the estimated k-mers, and whether this rank can run in slices
+        sc = torch.tensor([[words[s][p] if ok else 0 for s in range(S)] + [est[p] if ok else 0, 1 if ok else 0] for p in range(world)],
+                          dtype=torch.int64, device=self.device)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        rows = rc.tolist()
+        if not all(int(row[S + 1]) for row in rows):
+            return False
+        rw = [sum(int(rows[p][s]) for p in range(world)) for s in range(S)]
+        sw = [sum(words[s]) for s in range(S)]
+        cap = int(self.stage.mg_send_capacity_words())
+        if self.send is None or self.send.numel() < cap:
+            self.send = torch.empty(max(cap, 1), dtype=torch.int64, device=self.device)
+        n_recv = sum(rw)
+        if self.recv is None or self.recv.numel() < n_recv:
+            self.recv = torch.empty(int(n_recv * 1.1) + 1024, dtype=torch.int64, device=self.device)
+        works, so, ro = [], 0, 0
+        for s in range(S):
+            self.stage.mg_scatter_slice(self.send.data_ptr(), self.send.numel(), s)
+            works.append(dist.all_to_all_single(self.recv[ro: ro + rw[s]], self.send[so: so + sw[s]],
+                                                [int(rows[p][s]) for p in range(world)], list(words[s]), group=self.group, async_op=True))
+            so += sw[s]; ro += rw[s]
+        self.stage.mg_count_sliced(self.recv.data_ptr() if n_recv else 0, rw, sum(int(rows[p][S]) for p in range(world)),
+                                   lambda s: works[s].wait())
+        for w in works:
+            w.wait()
+        flag = torch.tensor([1 if self.stage.mg_slices_finish() else 0], dtype=torch.int64, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if int(flag.item()):
+            return False
+        self.last_send_counts = [sum(words[s][p] for s in range(S)) for p in range(world)]
+        self.last_recv_counts = [sum(int(rows[p][s]) for s in range(S)) for p in range(world)]
+        return True
+
     def count(self) -> None:
         if self.balance:                             # part of every count, like the reference's repartition step inside execute()
             self.rebalance()
+        self.last_step_sliced = self.slices >= 2 and self._count_in_slices()
+        if self.last_step_sliced:
+            return
         self.send, counts = scatter_records(self.stage, self.send, self.device)
         sized = hasattr(self.stage, "mg_sent_kmers")      # the senders counted the k-mers they packed: the receiver need not
         rk: List[int] = []

@@ -1330,5 +1330,26 @@ def test_exchange_over_rccl_single_rank(oracle, golden_dir, dev):
                     h = gather_histogram(torch.from_numpy(kc.histogram().astype(np.int64)).to(dev))
                     assert (h.cpu().numpy().astype(np.uint64) == ref.histogram(10000)).all()
                     assert sc.last_send_counts == sc.last_recv_counts and sum(sc.last_send_counts) > 0
+                    assert not sc.last_step_sliced                  # (this input is too small for the sampled send layout)
+        # a step in slices over RCCL: asynchronous all_to_all_single per slice on the process group's stream, the sender of
+        # the next slice and the level-1 scatter of the previous one on the context's (= torch's current) stream
+        from dsk_amd import synth
+        os.environ["DSKGPU_SK_MINSLICE"] = "1"
+        try:
+            reads = synth.make_reads(synth.make_genome(1_000_000, dev), 300_000, 150)
+            for k in (31, 63):
+                ref = oracle.count(reads.cpu().numpy(), k)
+                with KmerCounter(kmer_size=k, abundance_min=2, world_size=1, rank=0, stream=torch.cuda.current_stream().cuda_stream) as kc:
+                    kc.set_reads_device(reads.data_ptr(), reads.numel())
+                    sc = ShardedCounter(kc, dev, slices=4)
+                    for _ in range(2):
+                        sc.count()
+                        assert sc.last_step_sliced
+                        kk, aa = kc.rows()
+                        lo, hi, rab = ref.solid(2)
+                        assert (kk[:, 0] == lo).all() and (aa == rab).all() and kc.stats()["n_kmers"] == ref.total
+                        assert (kc.histogram() == ref.histogram(10000)).all()
+        finally:
+            del os.environ["DSKGPU_SK_MINSLICE"]
     finally:
         dist.destroy_process_group()

@@ -40,12 +40,59 @@ def owner_of(h, G):
 class CpuStage:
     """Stand-in for KmerCounter's multi-GPU entry points (test only)."""
 
-    def __init__(self, oracle, stream, k, world):
+    def __init__(self, oracle, stream, k, world, can_slice=True):
         self.oracle, self.stream, self.k, self.world = oracle, stream, k, world
         self.rows = None
+        self.can_slice = can_slice
+        self.gated = []
+
+    # a step in slices (multi.ShardedCounter._count_in_slices): the stand-in cuts its k-mers into S runs by position
+    def _owned(self):
+        lo, hi, valid = self.oracle.enumerate(self.stream, self.k)
+        h = kmix(lo[valid.astype(bool)])
+        return h, owner_of(h, self.world)
+
+    def mg_slices_prepare(self, want):
+        if not self.can_slice:
+            return 0, [], [0] * self.world
+        h, own = self._owned()
+        cuts = [len(h) * s // want for s in range(want + 1)]
+        self.parts = []
+        for s in range(want):
+            hs, os_ = h[cuts[s]: cuts[s + 1]], own[cuts[s]: cuts[s + 1]]
+            order = np.argsort(os_, kind="stable")
+            self.parts.append((hs[order], np.bincount(os_, minlength=self.world).tolist()))
+        self.sent = np.bincount(own, minlength=self.world).tolist()
+        return want, [p[1] for p in self.parts], [int(0.98 * x) for x in self.sent]      # (the k-mer figure is an estimate)
+
+    def mg_scatter_slice(self, ptr, cap, s):
+        import ctypes
+        off = sum(len(p[0]) for p in self.parts[:s])
+        hs = self.parts[s][0]
+        if len(hs):
+            np.ctypeslib.as_array((ctypes.c_uint64 * (off + len(hs))).from_address(ptr))[off:] = hs
+
+    def mg_slices_finish(self):
+        return False
+
+    def mg_count_sliced(self, ptr, slice_words, est, gate):
+        import ctypes
+        n, got = sum(slice_words), []
+        off = 0
+        for s, w in enumerate(slice_words):
+            gate(s); self.gated.append(s)                # a slice is read only behind its gate
+            if w:
+                got.append(np.ctypeslib.as_array((ctypes.c_uint64 * (off + w)).from_address(ptr))[off:].copy())
+            off += w
+        h = np.concatenate(got) if got else np.zeros(0, np.uint64)
+        assert abs(est - n) <= 0.05 * max(n, 1)
+        keys, cnt = np.unique(kunmix(h), return_counts=True)
+        self.rows = (keys, cnt.astype(np.uint32), h)
 
     def mg_send_capacity_words(self):
         return len(self.stream) + 1
+
+    one_piece = False
 
     def mg_scatter(self, ptr, cap):
         lo, hi, valid = self.oracle.enumerate(self.stream, self.k)
@@ -58,6 +105,7 @@ class CpuStage:
         buf = (ctypes.c_uint64 * max(1, len(h))).from_address(ptr)
         np.ctypeslib.as_array(buf)[: len(h)] = h
         self.sent = list(counts)                  # explicit keys: one k-mer per word
+        self.one_piece = True
         return counts
 
     def mg_sent_kmers(self):
@@ -85,7 +133,7 @@ class CpuStage:
         self.rows = (keys, cnt.astype(np.uint32), h)
 
 
-def _worker(rank, world, port, k, tmpdir):
+def _worker(rank, world, port, k, tmpdir, mode="slices"):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -99,9 +147,12 @@ def _worker(rank, world, port, k, tmpdir):
     recs = bytes(stream).split(b"\n")
     mine = b"\n".join(recs[rank::world]) + b"\n"
     shard = np.frombuffer(mine, dtype=np.uint8)
-    stage = CpuStage(oracle, shard, k, world)
-    sc = ShardedCounter(stage, torch.device("cpu"))
+    stage = CpuStage(oracle, shard, k, world, can_slice=not (mode == "one_rank_cannot" and rank == 1))
+    sc = ShardedCounter(stage, torch.device("cpu"), slices=1 if mode == "one_piece" else 4)
     sc.count()
+    # the step ran in slices (every slice read behind its gate, in order) -- or, decided by all ranks together, in one piece
+    assert sc.last_step_sliced == (mode == "slices") and stage.one_piece == (mode != "slices")
+    assert stage.gated == (list(range(4)) if mode == "slices" else [])
     # the repartition table: same on every rank (built from the all-reduced loads), heavy bucket split, owners inside the world
     tabs = [torch.zeros(4096, dtype=torch.uint8) for _ in range(world)]
     dist.all_gather(tabs, torch.from_numpy(stage.table.copy()))
@@ -127,10 +178,10 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_count_equals_single_process(oracle, golden_dir, tmp_path, world):
+@pytest.mark.parametrize("world,mode", [(2, "slices"), (4, "slices"), (2, "one_piece"), (4, "one_rank_cannot")])
+def test_sharded_count_equals_single_process(oracle, golden_dir, tmp_path, world, mode):
     k = 31
-    mp.spawn(_worker, args=(world, _free_port(), k, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), k, str(tmp_path), mode), nprocs=world, join=True)
     keys = np.concatenate([np.load(tmp_path / f"keys{r}.npy") for r in range(world)])
     cnt = np.concatenate([np.load(tmp_path / f"cnt{r}.npy") for r in range(world)])
     order = np.argsort(keys)
