@@ -303,12 +303,14 @@ def main():
         sharded = ShardedCounter(kc, dev)
 
     stage_acc = {}
+    sliced_steps = [0]
 
     def step():
         if world == 1:
             kc.count()
         else:
-            sharded.count()      # mg_scatter -> RCCL all-to-all -> mg_count
+            sharded.count()      # records -> RCCL all-to-all -> count; in slices, the exchange beside the sender and the receiver's level 1
+            sliced_steps[0] += int(sharded.last_step_sliced)
         for name, ms in kc.stage_times():
             stage_acc.setdefault(name, []).append(ms)
 
@@ -393,7 +395,9 @@ def main():
             "config": {"workload": f"{args.workload}: {nr} reads x {rl} bp per GPU, k={args.kmer_size}, "
                                    f"abundance-min={args.abundance_min}, genome {gl * world} bp, HBM-resident",
                        "reads_per_gpu": nr, "read_len": rl, "kmer_size": args.kmer_size,
-                       "parallelism": f"kmer-space sharded over {world} GPU(s)" + (", RCCL all-to-all" if world > 1 else "")},
+                       "parallelism": f"kmer-space sharded over {world} GPU(s)" + (
+                           f", RCCL all-to-all in {sharded.slices} slices overlapped with the sender and the receiver's level 1"
+                           f" ({sliced_steps[0]} of {args.steps + args.warmup} steps ran in slices)" if world > 1 else "")},
             "kmer_occurrences_per_s": n_kmers / per_step,
             "bases_per_s": tot_bytes / per_step,
             "n_distinct": n_distinct, "n_kmers": n_kmers, "n_solid": n_solid,
