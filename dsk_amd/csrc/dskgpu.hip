@@ -1000,7 +1000,10 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             if (uniform1) o1.uslice = 1u;          // (set below)
             for (u32 b = 0; b < pl.P1; ++b) {
                 double sl = load[b] * share;
-                sl += sampled ? spread[b] + sl * 0.01 + 64.0 : sl * 0.06 + 160.0;
+                // (records: the senders' zero-length pad records sit at the ends of their slices, so a level-1 chunk holds anything from
+                //  no pads to ~10 % -- a block that walks only a few chunks does not average that out: more room there)
+                const double few = (from_rec && share * (double)nch1 < 16.0) ? 0.08 : 0.0;
+                sl += sampled ? spread[b] + sl * 0.01 + 64.0 : sl * (0.06 + few) + 160.0;
                 u64 slice = ((u64)sl + 8) & ~7ull;
                 if (uniform1) o1.uslice = (u32)slice;
                 if (ctx->tune.opt_slice) slice = ctx->tune.opt_slice;                                        // experiments / tests
@@ -1009,8 +1012,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             ctx->h_boff[pl.P1] = (u32)std::min<u64>(area, 0xFFFFFFFFull);
             const u64 tail = 2 * Tile<W>::KEYS;                         // the dump zone behind the last slice (a tile's keys of a bin that outgrew its slice land there)
             const u64 cells = (u64)pl.P1 * grid1;
-            if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] pass %u/%u: P1 %u P2 %u, %u level-1 blocks, area %llu keys per block (%.2f GB of slices), sampled %d\n", pass, npass, pl.P1, pl.P2, grid1,
-                                           (unsigned long long)area, (double)area * grid1 * sizeof(Key) * 1e-9, (int)sampled);
+            if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] pass %u/%u: P1 %u P2 %u, %u level-1 blocks, area %llu keys per block (%.2f GB of slices), sampled %d, keys %llu, %u chunks, share %.6f, %zu slices\n", pass, npass, pl.P1, pl.P2, grid1,
+                                           (unsigned long long)area, (double)area * grid1 * sizeof(Key) * 1e-9, (int)sampled, (unsigned long long)ctx->h_nvalid, nch1, share, ctx->rec_slice_end.size());
             if (area < 8 || area * grid1 + tail >= 0xFFFF0000ull) opt1 = false;
             else {
                 o1.area = (u32)area; o1.dump = (u32)(area * grid1);

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan_apply(u32* __restrict__ a, con
 // sg.lim (block-owned slices): bin b may only be written below lim[b], the end of the block's slice of that bin; a bin whose keys
 // of this tile would not fit is redirected, for this tile, to the dump zone [dump, dump + tile) behind the last slice (never read) -- the
 // check costs a few instructions per BIN and tile instead of per key, and nothing is ever written outside the block's own
-// slices or the dump zone.  cur[] keeps advancing, so the overflow shows at the end of the launch.
+// slices or the dump zone.  The cursor of such a bin is parked at end + 1, so the overflow shows at the end of the launch.
 struct SliceGuard { const u32* lim; u32 dump; u32 uslice, first; };      // lim[b] (LDS): end of the block's slice of bin b; or uniform slices of uslice keys from `first` (no array); neither = no guard
 template <int NT>
 __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* cur, int P, u32* wsum, u32* tot, SliceGuard sg = SliceGuard{nullptr, 0u, 0u, 0u}) {
@@ -369,8 +369,11 @@ __device__ __forceinline__ void tile_scan(u32* cnt, u32* off, u32* delta, u32* c
         const int idx = base + j;
         if (j < ipt && idx < P) {
             const u32 c = cur[idx];
-            const bool fits = sg.lim ? c + v[j] <= sg.lim[idx] : sg.uslice ? c + v[j] <= sg.first + (u32)(idx + 1) * sg.uslice : true;
-            off[idx] = run; delta[idx] = fits ? c - run : sg.dump; cur[idx] = c + v[j]; cnt[idx] = 0;
+            // (a cursor that left its slice stays at end + 1: it marks the overflow for the end of the launch and cannot wrap 2^32
+            //  however many keys the bin still receives; below the end, c + v <= 0xFFFF0000 + a tile)
+            const u32 end = sg.lim ? sg.lim[idx] : sg.uslice ? sg.first + (u32)(idx + 1) * sg.uslice : 0xFFFFFFFFu;
+            const bool fits = (sg.lim || sg.uslice) ? c + v[j] <= end : true;
+            off[idx] = run; delta[idx] = fits ? c - run : sg.dump; cur[idx] = fits ? c + v[j] : end + 1u; cnt[idx] = 0;
             run += v[j];
         }
     }

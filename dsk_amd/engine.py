@@ -294,6 +294,11 @@ class KmerCounter:
         self._ck(self._lib.dskgpu_histogram2d(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), self.histo_max + 1))
         return out
 
+    def set_stream(self, stream: Optional[int]) -> None:
+        """All device work of this context on the given hipStream_t handle.  None or 0 = a stream owned by the context -- NOT the
+        legacy default stream (whose handle is 0): to order the context against torch work, hand it a torch.cuda.Stream()."""
+        self._ck(self._lib.dskgpu_set_stream(self._h, C.c_void_p(stream) if stream else None))
+
     # -- hot path
     def count(self) -> None:
         self._ck(self._lib.dskgpu_count(self._h))

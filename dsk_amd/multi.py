@@ -81,12 +81,20 @@ class ShardedCounter:
         self.group = group
         self.balance = balance and hasattr(stage, "mg_sample")
         # a step in slices: the exchange of slice i (async all-to-all on the process group's stream) runs beside the sender of
-        # slice i + 1 and the receiver's level 1 of slice i - 1.  The stage's stream must be torch's current stream (the
-        # collectives order themselves against it).  DSK_MG_SLICES = slices per step (default 4; < 2: every step in one piece)
+        # slice i + 1 and the receiver's level 1 of slice i - 1 (the collectives order themselves against torch's current stream:
+        # self.stream below, which is also the stage's).  DSK_MG_SLICES = slices per step (default 4; < 2: every step in one piece)
         if slices is None:
             slices = int(os.environ.get("DSK_MG_SLICES", "4"))
         self.slices = slices if hasattr(stage, "mg_slices_prepare") else 0
         self.last_step_sliced = False
+        # One stream for the stage's kernels and for what torch.distributed orders its collectives against: a torch side stream
+        # handed to the stage.  (A stage created on "torch's current stream" got handle 0 when that was the default stream -- which
+        # the C-ABI reads as "a stream of your own", invisible to torch: fine for the one-piece step, whose calls end with host
+        # synchronisation, not for slices.)
+        self.stream = None
+        if device.type == "cuda" and hasattr(stage, "set_stream"):
+            self.stream = torch.cuda.Stream(device)
+            stage.set_stream(self.stream.cuda_stream)
         self.table = None            # the repartition table in use (None = the engine's default)
         self.send: Optional[torch.Tensor] = None
         self.recv: Optional[torch.Tensor] = None
@@ -146,6 +154,14 @@ class ShardedCounter:
         return True
 
     def count(self) -> None:
+        if self.stream is None:
+            return self._count()
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))       # (the reads, the buffers of the last step)
+        with torch.cuda.stream(self.stream):
+            self._count()
+            self.stream.synchronize()
+
+    def _count(self) -> None:
         if self.balance:                             # part of every count, like the reference's repartition step inside execute()
             self.rebalance()
         self.last_step_sliced = self.slices >= 2 and self._count_in_slices()

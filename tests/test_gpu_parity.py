@@ -1342,12 +1342,16 @@ def test_exchange_over_rccl_single_rank(oracle, golden_dir, dev):
                 with KmerCounter(kmer_size=k, abundance_min=2, world_size=1, rank=0, stream=torch.cuda.current_stream().cuda_stream) as kc:
                     kc.set_reads_device(reads.data_ptr(), reads.numel())
                     sc = ShardedCounter(kc, dev, slices=4)
-                    for _ in range(2):
+                    for it in range(2):
                         sc.count()
                         assert sc.last_step_sliced
+                        st = kc.stats()
+                        assert (st["n_kmers"], st["n_distinct"]) == (ref.total, ref.distinct), (k, it, st)
+                        assert st["n_retries"] == 0                      # the level-1 launches per slice took everything
                         kk, aa = kc.rows()
                         lo, hi, rab = ref.solid(2)
-                        assert (kk[:, 0] == lo).all() and (aa == rab).all() and kc.stats()["n_kmers"] == ref.total
+                        assert len(kk) == len(lo), (k, it, st)
+                        assert (kk[:, 0] == lo).all() and (aa == rab).all()
                         assert (kc.histogram() == ref.histogram(10000)).all()
         finally:
             del os.environ["DSKGPU_SK_MINSLICE"]
