@@ -23,6 +23,60 @@ namespace {
 
 thread_local std::string g_create_err;
 
+// Where a big buffer lies in HBM decides how fast scattered stores into it go: of several 9.6 GB allocations of one process some take
+// the store pattern of the level-1 scatter (256 blocks x 512 streams x 256-byte runs) in 3.14 ms and others in 3.41 (a streaming
+// fill: 1.70 / 1.79), the same virtual address changes class after a free + malloc, and the kernels' "two speeds" (level 1: 3.8 /
+// 4.5 ms) follow (tools/micro/write_place.hip).  With DSKGPU_PLACE = K > 1 every allocation of >= 256 MB is the best of up to K
+// candidates, each timed with that store pattern (one-off: ~0.1 s per candidate of 10 GB); the others are freed.
+__global__ __launch_bounds__(1024) void k_place_probe(unsigned long long* __restrict__ out, unsigned long long n) {
+    const unsigned long long per_block = n / gridDim.x, per_stream = per_block / 512;
+    unsigned long long* base = out + (unsigned long long)blockIdx.x * per_block;
+    const int r = threadIdx.x >> 5, l = threadIdx.x & 31;
+    for (unsigned long long off = 0; off + 32 <= per_stream; off += 32)
+        for (int p = r; p < 512; p += 32) base[(unsigned long long)p * per_stream + off + l] = off;
+}
+int g_place_k = -1;          // DSKGPU_PLACE (read once)
+float place_probe_ms(void* p, size_t bytes) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0.f;
+    float best = 1e30f;
+    for (int i = 0; i < 3; ++i) {
+        (void)hipEventRecord(a, 0);
+        hipLaunchKernelGGL(k_place_probe, dim3(256), dim3(1024), 0, 0, static_cast<unsigned long long*>(p), (unsigned long long)(bytes / 8));
+        (void)hipEventRecord(b, 0);
+        (void)hipEventSynchronize(b);
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, a, b);
+        if (i && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return best;
+}
+hipError_t placed_malloc(void** out, size_t bytes) {
+    if (g_place_k < 0) { const char* e = getenv("DSKGPU_PLACE"); g_place_k = e ? atoi(e) : 0; }      // (dskgpu_create with DSKGPU_F_PLACE sets 8)
+    size_t free_b = 0, total_b = 0;
+    if (g_place_k < 2 || bytes < (size_t(1) << 28) || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return hipMalloc(out, bytes);
+    const int K = (int)std::min<size_t>((size_t)g_place_k, free_b / 2 / bytes);      // candidates held at once: at most half of what is free
+    if (K < 2) return hipMalloc(out, bytes);
+    std::vector<void*> cand; std::vector<float> ms;
+    for (int i = 0; i < K; ++i) {
+        void* q = nullptr;
+        if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        static const size_t probe_max = getenv("DSKGPU_PLACE_GB") ? (size_t)(atof(getenv("DSKGPU_PLACE_GB")) * (1ull << 30)) : ~size_t(0);
+        cand.push_back(q); ms.push_back(place_probe_ms(q, std::min(bytes, probe_max)));
+    }
+    if (cand.empty()) return hipErrorOutOfMemory;
+    size_t best = 0;
+    for (size_t i = 1; i < cand.size(); ++i) if (ms[i] < ms[best]) best = i;
+    for (size_t i = 0; i < cand.size(); ++i) if (i != best) (void)hipFree(cand[i]);
+    if (getenv("DSKGPU_VERBOSE")) {
+        fprintf(stderr, "[dskgpu] placement of %.2f GB: probe ms", bytes * 1e-9);
+        for (size_t i = 0; i < cand.size(); ++i) fprintf(stderr, " %.3f%s", ms[i], i == best ? "*" : "");
+        fprintf(stderr, "\n");
+    }
+    *out = cand[best];
+    return hipSuccess;
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -32,7 +86,7 @@ struct DevBuf {
         // sampled loads) does not free and allocate tens of GB again -- near a full HBM that took a second
         size_t want = ((p ? bytes + bytes / 16 : bytes) + 255) & ~size_t(255);
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        hipError_t e = hipMalloc(&p, want);
+        hipError_t e = placed_malloc(&p, want);
         if (e == hipSuccess) cap = want; else p = nullptr;
         return e;
     }
@@ -1891,6 +1945,8 @@ int dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out) {
     *out = nullptr;
     if (cfg->kmer_size < 1 || cfg->kmer_size > 128) { g_create_err = "kmer_size must be in 1..128"; return DSKGPU_E_ARG; }
     if (cfg->solidity_kind > DSKGPU_SOLIDITY_CUSTOM) { g_create_err = "unknown solidity_kind"; return DSKGPU_E_ARG; }
+    if (g_place_k < 0) { const char* e = getenv("DSKGPU_PLACE"); g_place_k = e ? atoi(e) : 0; }
+    if ((cfg->flags & DSKGPU_F_PLACE) && g_place_k < 2) g_place_k = 8;
     const u32 ws = cfg->world_size ? cfg->world_size : 1;
     if ((ws & (ws - 1)) != 0 || ws > 64 || cfg->rank >= ws) { g_create_err = "world_size must be a power of two <= 64 and rank < world_size"; return DSKGPU_E_ARG; }
     int ndev = 0;

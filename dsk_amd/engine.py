@@ -75,6 +75,7 @@ F_TIMING = 1
 F_NO_SORT = 2
 F_HISTO2D = 4
 F_MG_EXPLICIT = 8
+F_PLACE = 16
 SOLIDITY = {"sum": 0, "min": 1, "max": 2, "one": 3, "all": 4, "custom": 5}
 
 # every symbol include/dskgpu.h declares (checked by tests/test_abi.py)
@@ -187,7 +188,7 @@ def load_library():
 
 
 def _make_config(kmer_size, abundance_min, abundance_max, histo_max, device, nb_partitions, timing, sort, world_size, rank,
-                 minimizer_size, max_pass_mkeys, solidity_kind, solidity_custom, histo2d, mg_explicit) -> "_Config":
+                 minimizer_size, max_pass_mkeys, solidity_kind, solidity_custom, histo2d, mg_explicit, place=False) -> "_Config":
     cfg = _Config()
     cfg.kmer_size = kmer_size
     cfg.abundance_min = abundance_min
@@ -197,7 +198,7 @@ def _make_config(kmer_size, abundance_min, abundance_max, histo_max, device, nb_
     cfg.nb_partitions = nb_partitions
     cfg.minimizer_size = minimizer_size
     cfg.max_pass_mkeys = max_pass_mkeys
-    cfg.flags = (F_TIMING if timing else 0) | (0 if sort else F_NO_SORT) | (F_HISTO2D if histo2d else 0) | (F_MG_EXPLICIT if mg_explicit else 0)
+    cfg.flags = (F_TIMING if timing else 0) | (0 if sort else F_NO_SORT) | (F_HISTO2D if histo2d else 0) | (F_MG_EXPLICIT if mg_explicit else 0) | (F_PLACE if place else 0)
     cfg.solidity_kind = SOLIDITY[solidity_kind]
     cfg.solidity_custom = solidity_custom
     cfg.world_size = world_size
@@ -223,11 +224,13 @@ class KmerCounter:
                  histo_max: int = 10000, device: int = 0, nb_partitions: int = 0, timing: bool = False,
                  sort: bool = True, world_size: int = 1, rank: int = 0, stream: Optional[int] = None,
                  minimizer_size: int = 0, max_pass_mkeys: int = 0, solidity_kind: str = "sum", solidity_custom: int = 0,
-                 histo2d: bool = False, mg_explicit: bool = False):
+                 histo2d: bool = False, mg_explicit: bool = False, place: bool = False):
+        """place: DSKGPU_F_PLACE -- every big device buffer becomes the best-placed of 8 candidate allocations (one-off cost of a
+        few seconds at the first count, steps ~6 % faster and no longer box- and process-dependent): for contexts that count often."""
         self._lib = load_library()
         self._owned = True
         cfg = _make_config(kmer_size, abundance_min, abundance_max, histo_max, device, nb_partitions, timing, sort, world_size, rank,
-                           minimizer_size, max_pass_mkeys, solidity_kind, solidity_custom, histo2d, mg_explicit)
+                           minimizer_size, max_pass_mkeys, solidity_kind, solidity_custom, histo2d, mg_explicit, place)
         self.kmer_size = kmer_size
         self.histo_max = histo_max
         self.words = (kmer_size + 31) // 32          # 64-bit words of a k-mer at the ABI (1..4)

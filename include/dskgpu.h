@@ -66,6 +66,12 @@ typedef struct dskgpu_config {
 #define DSKGPU_F_NO_SORT 2u       /* leave solid rows unsorted (bench ablation) */
 #define DSKGPU_F_MG_EXPLICIT 8u   /* multi-GPU: exchange one explicit key per k-mer instead of super-k-mer records */
 #define DSKGPU_F_HISTO2D 4u       /* also build the 2-D histogram: bank 0 (genome) x the other banks (reads), -histo2D */
+#define DSKGPU_F_PLACE 16u        /* pick the place of every big device buffer: where a buffer lies in HBM changes the rate of
+                                   * scattered stores into it by up to 40 % (tools/micro/write_place.hip; the "two speeds" of the
+                                   * partition kernels).  Each allocation >= 256 MB becomes the best of up to 8 candidates, timed
+                                   * with the store pattern of the level-1 scatter; the others are freed.  One-off cost at the
+                                   * first count (~3-6 s for 30 GB of buffers): for contexts that count many times.  Process-wide
+                                   * once a context asked for it; DSKGPU_PLACE=<candidates> in the environment does the same. */
 
 /* -solidity-kind (gatb-core option; only `sum` is exercised by the reference's tests, README.md:12).
  * Banks = the inputs separated with dskgpu_next_bank / dskgpu_set_banks; one bank => plain counting. */
