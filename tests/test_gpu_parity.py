@@ -1357,3 +1357,22 @@ def test_exchange_over_rccl_single_rank(oracle, golden_dir, dev):
             del os.environ["DSKGPU_SK_MINSLICE"]
     finally:
         dist.destroy_process_group()
+
+
+def test_buffer_placement_keeps_results(dev):
+    """DSKGPU_F_PLACE (best-placed of 8 candidate allocations for every big device buffer) is a matter of speed only: same rows and
+    histogram as a context on plain hipMalloc buffers.  Last in the file: the flag is process-wide once a context asked for it."""
+    from dsk_amd import synth, KmerCounter
+    reads = synth.make_reads(synth.make_genome(6_000_000, dev), 2_000_000, 150)
+    with KmerCounter(kmer_size=31) as kc:
+        kc.set_reads_device(reads.data_ptr(), reads.numel())
+        kc.count()
+        k0, a0 = kc.rows()
+        h0, st0 = kc.histogram(), kc.stats()
+    with KmerCounter(kmer_size=31, place=True) as kc:
+        kc.set_reads_device(reads.data_ptr(), reads.numel())
+        for _ in range(2):
+            kc.count()
+            k1, a1 = kc.rows()
+            assert (k1 == k0).all() and (a1 == a0).all() and (kc.histogram() == h0).all()
+            assert kc.stats()["n_kmers"] == st0["n_kmers"] and kc.stats()["n_retries"] == 0
