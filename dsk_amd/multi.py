@@ -115,13 +115,15 @@ class ShardedCounter:
         """One step with the exchange in slices; False when the step has to run in one piece -- some rank's input does not take the
         sampled send layout, or a send slice overflowed (the attempt is then discarded): decided by all ranks together."""
         world, S = dist.get_world_size(self.group), self.slices
-        if self.device.type == "cuda" and dist.get_backend(self.group) == "gloo":
-            return False                              # (development path: the exchange is staged through host memory)
+        # development path (several ranks sharing one GPU, no RCCL): every slice is staged through host memory -- the same
+        # protocol and device work, no overlap
+        staged = self.device.type == "cuda" and dist.get_backend(self.group) == "gloo"
+        cdev = torch.device("cpu") if staged else self.device
         ns, words, est = self.stage.mg_slices_prepare(S)
         ok = ns == S
         # one host round: per peer, the words of every slice, the estimated k-mers, and whether this rank can run in slices
         sc = torch.tensor([[words[s][p] if ok else 0 for s in range(S)] + [est[p] if ok else 0, 1 if ok else 0] for p in range(world)],
-                          dtype=torch.int64, device=self.device)
+                          dtype=torch.int64, device=cdev)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.group)
         rows = rc.tolist()
@@ -135,17 +137,27 @@ class ShardedCounter:
         n_recv = sum(rw)
         if self.recv is None or self.recv.numel() < n_recv:
             self.recv = torch.empty(int(n_recv * 1.1) + 1024, dtype=torch.int64, device=self.device)
-        works, so, ro = [], 0, 0
+        works, landed, so, ro = [], [], 0, 0
         for s in range(S):
             self.stage.mg_scatter_slice(self.send.data_ptr(), self.send.numel(), s)
-            works.append(dist.all_to_all_single(self.recv[ro: ro + rw[s]], self.send[so: so + sw[s]],
-                                                [int(rows[p][s]) for p in range(world)], list(words[s]), group=self.group, async_op=True))
+            src, dst = self.send[so: so + sw[s]], self.recv[ro: ro + rw[s]]
+            if staged:
+                torch.cuda.current_stream(self.device).synchronize()
+                src = src.cpu()
+                landed.append((dst, torch.empty(rw[s], dtype=torch.int64)))
+                dst = landed[-1][1]
+            works.append(dist.all_to_all_single(dst, src, [int(rows[p][s]) for p in range(world)], list(words[s]),
+                                                group=self.group, async_op=True))
             so += sw[s]; ro += rw[s]
-        self.stage.mg_count_sliced(self.recv.data_ptr() if n_recv else 0, rw, sum(int(rows[p][S]) for p in range(world)),
-                                   lambda s: works[s].wait())
+
+        def gate(s: int) -> None:                     # the stage's stream waits for slice s (RCCL: an event wait, the host goes on)
+            works[s].wait()
+            if staged:
+                landed[s][0].copy_(landed[s][1])
+        self.stage.mg_count_sliced(self.recv.data_ptr() if n_recv else 0, rw, sum(int(rows[p][S]) for p in range(world)), gate)
         for w in works:
             w.wait()
-        flag = torch.tensor([1 if self.stage.mg_slices_finish() else 0], dtype=torch.int64, device=self.device)
+        flag = torch.tensor([1 if self.stage.mg_slices_finish() else 0], dtype=torch.int64, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
         if int(flag.item()):
             return False

@@ -1359,6 +1359,22 @@ def test_exchange_over_rccl_single_rank(oracle, golden_dir, dev):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world,k", [(2, 31), (4, 63)])
+def test_sliced_step_with_real_processes(dev, world, k):
+    """tools/check_multi.py: `world` processes under torch.distributed.run sharing cuda:0, the exchange over gloo (every slice staged
+    through host memory): the whole protocol of ShardedCounter -- counts round, slice layouts of several real senders, gates,
+    collective flags -- with the real engine; the sum over the ranks equals a single-context count of all the reads."""
+    import socket, subprocess, sys
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSKGPU_SK_MINSLICE="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tools", "check_multi.py"), str(k), "400000"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and f"multi ok: world={world} k={k} sliced=True" in out, out[-3000:]
+
+
 def test_buffer_placement_keeps_results(dev):
     """DSKGPU_F_PLACE (best-placed of 8 candidate allocations for every big device buffer) is a matter of speed only: same rows and
     histogram as a context on plain hipMalloc buffers.  Last in the file: the flag is process-wide once a context asked for it."""

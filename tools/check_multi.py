@@ -12,13 +12,15 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 dev = torch.device("cuda:0")
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 31
-genome = synth.make_genome(300_000 * world, dev)
-shards = [synth.make_reads(genome, 100_000, 150, seed=synth.SEED + 1 + r) for r in range(world)]
+nreads = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000         # >= ~300 000 per rank with DSKGPU_SK_MINSLICE=1: the step runs in slices
+genome = synth.make_genome(3 * nreads * world, dev)
+shards = [synth.make_reads(genome, nreads, 150, seed=synth.SEED + 1 + r) for r in range(world)]
 kc = KmerCounter(kmer_size=k, abundance_min=2, world_size=world, rank=rank)
 kc.set_reads_device(shards[rank].data_ptr(), shards[rank].numel())
 sc = ShardedCounter(kc, dev)
 sc.count(); sc.count()
 st = kc.stats()
+sliced = sc.last_step_sliced
 hist = gather_histogram(torch.from_numpy(kc.histogram().astype(np.int64)))
 tot = torch.tensor([st["n_kmers"], st["n_distinct"], st["n_solid"]], dtype=torch.int64)
 dist.all_reduce(tot)
@@ -30,6 +32,6 @@ if rank == 0:
         s1 = one.stats(); h1 = one.histogram().astype(np.int64)
     assert tot.tolist() == [s1["n_kmers"], s1["n_distinct"], s1["n_solid"]], (tot.tolist(), s1)
     assert (hist.numpy() == h1).all()
-    print(f"multi ok: world={world} k={k} kmers={s1['n_kmers']} distinct={s1['n_distinct']} solid={s1['n_solid']}")
+    print(f"multi ok: world={world} k={k} sliced={sliced} kmers={s1['n_kmers']} distinct={s1['n_distinct']} solid={s1['n_solid']}")
 dist.barrier()
 dist.destroy_process_group()
