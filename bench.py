@@ -283,10 +283,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the count path has no CPU fallback")
+    # DSK_BENCH_SHARE_GPU=1 (development, never a measurement): all ranks on device 0, the exchange over gloo staged through the
+    # host -- runs the N-rank code path of this file on a 1-GPU box
+    share_gpu = world > 1 and os.environ.get("DSK_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rdev = torch.device("cpu") if share_gpu else dev          # where the few reduction scalars live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # weak scaling: same per-GPU shard size, genome grows with the node so coverage stays 50x
     reads, gl, nr, rl = synth.make_workload(args.workload, dev, world, rank)
@@ -340,8 +349,8 @@ def main():
     st = kc.stats()
 
     # whole-job aggregates (MAX time over ranks, SUM of units)
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    units = torch.tensor([st["n_distinct"], st["n_kmers"], st["n_solid"], n_bytes], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
+    units = torch.tensor([st["n_distinct"], st["n_kmers"], st["n_solid"], n_bytes], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(units, op=dist.ReduceOp.SUM)
@@ -399,7 +408,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u64",
-            "data": "synthetic",
+            "data": "synthetic" + (" -- DEVELOPMENT RUN: all ranks share one GPU, exchange over gloo (not a measurement)" if share_gpu else ""),
             "config": {"workload": f"{args.workload}: {nr} reads x {rl} bp per GPU, k={args.kmer_size}, "
                                    f"abundance-min={args.abundance_min}, genome {gl * world} bp, HBM-resident",
                        "reads_per_gpu": nr, "read_len": rl, "kmer_size": args.kmer_size,

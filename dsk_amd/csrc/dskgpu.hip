@@ -1751,6 +1751,10 @@ int sk_count(dskgpu_ctx* ctx, const u64* d_rec, u64 recv_words, u64 n_kmers_hint
     const u32 R = ctx->sk_sp.R;
     if (recv_words % R) return fail(ctx, DSKGPU_E_ARG, "recv_words is not a whole number of super-k-mer records");
     const u64 nrec = recv_words / R;
+    if (hint_is_estimate && ctx->marks.size() > 1) {      // a sliced step: the sender's marks are still open (its launches returned at once)
+        CK(hipStreamSynchronize(ctx->stream));
+        ctx->resolve_marks();
+    }
     ctx->marks.clear(); ctx->ev_used = 0;
     ctx->mark("start");
     u64 total = 0;
