@@ -1364,14 +1364,26 @@ def test_sliced_step_with_real_processes(dev, world, k):
     """tools/check_multi.py: `world` processes under torch.distributed.run sharing cuda:0, the exchange over gloo (every slice staged
     through host memory): the whole protocol of ShardedCounter -- counts round, slice layouts of several real senders, gates,
     collective flags -- with the real engine; the sum over the ranks equals a single-context count of all the reads."""
-    import socket, subprocess, sys
+    import gc, socket, subprocess, sys
+    gc.collect(); torch.cuda.empty_cache()          # the child processes share this GPU: give back what earlier tests left in torch's cache
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DSKGPU_SK_MINSLICE="1")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(root, "tools", "check_multi.py"), str(k), "400000"],
-                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
-    out = p.stdout.decode()
+    for attempt in range(2):
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(root, "tools", "check_multi.py"), str(k), "400000"],
+                           cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        out = p.stdout.decode()
+        if p.returncode == 0 or "AssertionError" in out:
+            break                                   # done -- or a wrong result, which is never retried
+        # the launcher or a rank failed before it compared anything (seen on fresh boxes: rendezvous / start-up): once more, and
+        # keep what it said
+        dbg = os.path.join(root, "gpurun_out")
+        if os.path.isdir(dbg):
+            with open(os.path.join(dbg, f"sliced_real_{world}_{k}_attempt{attempt}.log"), "w") as f:
+                f.write(out)
+        print(out[-3000:], file=sys.stderr)
     assert p.returncode == 0 and f"multi ok: world={world} k={k} sliced=True" in out, out[-3000:]
 
 
