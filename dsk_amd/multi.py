@@ -107,8 +107,8 @@ class ShardedCounter:
         from the sum -- heavy buckets are split by k-mer, the others placed largest first on the least loaded owner."""
         from .engine import make_table
         loads = torch.from_numpy(self.stage.mg_sample().astype("int64"))
-        if dist.get_backend(self.group) != "gloo":      # (gloo reduces host tensors; handed a device tensor on a side stream it raced: ranks
-            loads = loads.to(self.device)                #  derived different tables now and then -- seen with 4 processes sharing one GPU)
+        if dist.get_backend(self.group) != "gloo":      # (gloo reduces host tensors anyway; a device tensor would only add a staging hop
+            loads = loads.to(self.device)                #  on the step's side stream)
         dist.all_reduce(loads, op=dist.ReduceOp.SUM, group=self.group)
         self.table = make_table(loads.cpu().numpy().astype("uint64"), dist.get_world_size(self.group))
         self.stage.mg_set_table(self.table)
