@@ -161,24 +161,49 @@ __device__ __forceinline__ SkThread sk_tile(const u64* __restrict__ packed, cons
             }
         }
         const u32 bad16 = (u32)(bad_lo >> (16 - t0)) & 0xFFFFu;              // bit 15 - i: window i holds an invalid base
-        u32 pr = 0xFFFFFFFFu, prev_owner = 0xFFFFu; bool prev_valid = false, prev_split = false;
+        u32 pr = 0xFFFFFFFFu;
+        if constexpr (SAMPLE) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (i > 0) pr = h[i] < pr ? h[i] : pr;
-            u32 mn = cm < pr ? cm : pr;
-            if (i < 15) mn = sl[i] < mn ? sl[i] : mn;
-            const u32 bucket = (mn & 0xFFFFu) >> 4;
-            u32 owner = SAMPLE ? 0u : tab[bucket];
-            const bool split = !SAMPLE && owner == SK_SPLIT;
-            const bool valid = !((bad16 >> (15 - i)) & 1u);
-            if (SAMPLE) { if (valid) atomicAdd(&load[bucket], 1u); continue; }
-            if (valid && split) owner = sk_kmer_owner(packed, wi, t0, i, k, sp.G);      // (rare: heavy buckets only)
-            if (valid) {
-                r.vm |= 1u << i;
-                if (!prev_valid || owner != prev_owner || split || prev_split) r.bm |= 1u << i;      // a split window is a record of its own
+            for (int i = 0; i < 16; ++i) {
+                if (i > 0) pr = h[i] < pr ? h[i] : pr;
+                u32 mn = cm < pr ? cm : pr;
+                if (i < 15) mn = sl[i] < mn ? sl[i] : mn;
+                if (!((bad16 >> (15 - i)) & 1u)) atomicAdd(&load[(mn & 0xFFFFu) >> 4], 1u);
             }
-            if (i < 8) r.ow_lo |= (u64)owner << (8 * i); else r.ow_hi |= (u64)owner << (8 * (i - 8));
-            prev_valid = valid; prev_owner = owner; prev_split = split;
+        } else {
+            // The loop only looks the owners up and packs them, four to a word; validity, "this window is routed by its own k-mer" and
+            // "the owner changes here" then come from a few word-wide operations instead of a chain of conditions per window (the
+            // kernel is bound by its instruction count: 73 % VALU busy).
+            u32 ow[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i > 0) pr = h[i] < pr ? h[i] : pr;
+                u32 mn = cm < pr ? cm : pr;
+                if (i < 15) mn = sl[i] < mn ? sl[i] : mn;
+                ow[i >> 2] |= (u32)tab[(mn & 0xFFFFu) >> 4] << (8 * (i & 3));
+            }
+            r.vm = __brev(~bad16 & 0xFFFFu) >> 16;                             // bit i: window i is a valid k-mer (bad16 runs the other way)
+            // bit j of nib(w) = byte j of w has its low bit set (bytes hold 0 or 1): one multiply gathers the four bits
+            auto nib = [](u32 w) { return (w * 0x10204080u) >> 28; };
+            u32 splitm = 0;                                                    // table entry SK_SPLIT (255): the only bytes with bit 7 set
+#pragma unroll
+            for (int q = 0; q < 4; ++q) splitm |= nib((ow[q] >> 7) & 0x01010101u) << (4 * q);
+            splitm &= r.vm;
+            u64 lo = ((u64)ow[1] << 32) | ow[0], hi = ((u64)ow[3] << 32) | ow[2];
+            for (u32 sm = splitm; sm; sm &= sm - 1) {                          // (rare: heavy buckets only) the owner of the window's own k-mer
+                const int i = __builtin_ctz(sm);
+                const u64 o = sk_kmer_owner(packed, wi, t0, i, k, sp.G);
+                if (i < 8) lo = (lo & ~(0xFFull << (8 * i))) | (o << (8 * i));
+                else hi = (hi & ~(0xFFull << (8 * (i - 8)))) | (o << (8 * (i - 8)));
+            }
+            lo &= 0x3F3F3F3F3F3F3F3Full; hi &= 0x3F3F3F3F3F3F3F3Full;         // owners are < 64; what is left of a 255 belongs to a window without a k-mer
+            r.ow_lo = lo; r.ow_hi = hi;
+            // d bit i (i >= 1): owner of window i differs from the owner of window i - 1
+            const u32 w0 = (u32)lo, w1 = (u32)(lo >> 32), w2 = (u32)hi, w3 = (u32)(hi >> 32);
+            auto diff = [&](u32 w, u32 prev_top) { const u32 x = w ^ ((w << 8) | prev_top); return nib(((x + 0x3F3F3F3Fu) >> 6) & 0x01010101u); };
+            const u32 d = diff(w0, 0u) | (diff(w1, w0 >> 24) << 4) | (diff(w2, w1 >> 24) << 8) | (diff(w3, w2 >> 24) << 12);
+            // a record starts at a valid window whose predecessor is not valid, has another owner, or when either is routed by its k-mer
+            r.bm = r.vm & (~(r.vm << 1) | d | splitm | (splitm << 1)) & 0xFFFFu;
         }
     }
     return r;
