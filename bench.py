@@ -18,6 +18,7 @@ times the CPU oracle (a restatement of DSK's method, NOT GATB/dsk itself, which
 cannot be built here: its gatb-core submodule is absent) on a bounded sample.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -26,6 +27,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+COLLECTIVE_TIMEOUT_S = 180.0   # longest any rank waits inside one collective of the N > 1 bench before it fails loudly
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0   # MI355X_MICROARCH.md: measured float4 copy (79 % of spec)
 
@@ -35,7 +37,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2_10Mx150")
+    ap.add_argument("--workload", default=None,
+                    help="default: c2_10Mx150 (BASELINE.json configs[1]) at --gpus 1; c3_shard_25Mx150 per GPU at --gpus N > 1 "
+                         "(N = 8 is exactly configs[2]: 200 M x 150 bp on a 600 Mbp genome; --kmer-size 63 makes it configs[3])")
     ap.add_argument("--kmer-size", type=int, default=31)
     ap.add_argument("--abundance-min", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -47,24 +51,27 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(stage, n_bytes, n_kmers, W=8, n_solid=None):
+def algorithmic_bytes(stage, n_bytes, n_kmers, W=8, n_solid=None, sent_words=None, recv_words=None):
     """Algorithmic HBM bytes of one launch (DESIGN.md 'roofline'; SURVEY.md §8d terms).
     partition kernels: read the bases that produce the k-mers + write W per k-mer;
     key-array passes: read W (+ write W); count: read W per k-mer (table lives in LDS);
-    compact / sort (all their launches together): the solid rows (W + 4 bytes) read once and written once."""
+    compact / sort (all their launches together): the solid rows (W + 4 bytes) read once and written once.
+    N > 1 (sent_words / recv_words = 8-byte words of super-k-mer records this rank sends / receives per step): the sender reads the
+    2-bit stream and writes its records; the receiver's level 1 reads the received records and writes W per k-mer it owns."""
     if stage in ("compact", "sort"):
         return None if n_solid is None else 2 * n_solid * (W + 4)
     enc_words = (n_bytes + 31) // 32
     packed = enc_words * 12                      # 8 B packed + 4 B invalid mask per 32 bases
+    multi = sent_words is not None
     return {
         "encode": n_bytes + packed,
         "hist1": packed,
-        "scatter1": packed + n_kmers * W,
+        "scatter1": (recv_words * 8 if multi else packed) + n_kmers * W,
         "hist2": n_kmers * W,
         "scatter2": 2 * n_kmers * W,
         "count": n_kmers * W,
         "mg_hist": packed,
-        "mg_scatter": packed + n_kmers * W,
+        "mg_scatter": packed + (sent_words * 8 if multi else n_kmers * W),
     }.get(stage)
 
 
@@ -256,9 +263,21 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: needed by RCCL between processes on this pool
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    # watchdog: a rank that dies or hangs inside a collective must not turn into the driver's 30-minute timeout with no message --
+    # the children run in their own process group, and past DSK_BENCH_TIMEOUT_S (default 1200 s) all of them are killed
+    limit = float(os.environ.get("DSK_BENCH_TIMEOUT_S", "1200"))
+    import signal
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        stdout, _ = proc.communicate()
+        print(f"bench.py: the {args.gpus} ranks did not finish within {limit:.0f} s (a rank hung in a collective?): killed", file=sys.stderr)
+        sys.stderr.write(stdout.decode(errors="replace")[-4000:])
+        sys.exit(124)
     line = None
-    for ln in proc.stdout.decode(errors="replace").splitlines():
+    for ln in stdout.decode(errors="replace").splitlines():
         if ln.startswith('{"metric"'):
             line = ln
         else:
@@ -270,6 +289,8 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.workload is None:
+        args.workload = "c2_10Mx150" if args.gpus <= 1 else "c3_shard_25Mx150"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     import torch
@@ -293,9 +314,10 @@ def main():
     rdev = torch.device("cpu") if share_gpu else dev          # where the few reduction scalars live
     if world > 1:
         if share_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            # (RCCL: the process group's watchdog aborts the communicator and ends the rank when a collective exceeds the timeout)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))
 
     # weak scaling: same per-GPU shard size, genome grows with the node so coverage stays 50x
     reads, gl, nr, rl = synth.make_workload(args.workload, dev, world, rank)
@@ -303,6 +325,20 @@ def main():
     n_bytes = reads.numel()
 
     stream = torch.cuda.current_stream().cuda_stream
+    # the same steps on plain hipMalloc buffers first (3 warm-up + 10 timed, same process, before any context asks for placement --
+    # the flag is process-wide): reported next to the headline as ms_per_step_no_place
+    no_place_ms = None
+    if world == 1 and not args.no_place:
+        with KmerCounter(kmer_size=args.kmer_size, abundance_min=args.abundance_min, device=local_rank, sort=not args.no_sort, stream=stream) as kp:
+            kp.set_reads_device(reads.data_ptr(), n_bytes)
+            for _ in range(3):
+                kp.count()
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for _ in range(10):
+                kp.count()
+            torch.cuda.synchronize()
+            no_place_ms = (time.perf_counter() - tp) / 10 * 1e3
     kc = KmerCounter(kmer_size=args.kmer_size, abundance_min=args.abundance_min, device=local_rank, timing=True,
                      sort=not args.no_sort, world_size=world, rank=rank, stream=stream, place=not args.no_place)
     kc.set_reads_device(reads.data_ptr(), n_bytes)
@@ -310,7 +346,7 @@ def main():
     sharded = None
     if world > 1:
         from dsk_amd.multi import ShardedCounter
-        sharded = ShardedCounter(kc, dev)
+        sharded = ShardedCounter(kc, dev, wait_timeout_s=COLLECTIVE_TIMEOUT_S)
 
     stage_acc = {}
     sliced_steps = [0]
@@ -363,14 +399,16 @@ def main():
         stage_ms = {k: sum(v) / len(v) for k, v in stage_acc.items()}
         # dominant kernel = the longest stage that has an algorithmic byte count
         local_kmers = st["n_kmers"]
-        cand = {k: v for k, v in stage_ms.items() if algorithmic_bytes(k, n_bytes, local_kmers) is not None}
+        sent_w = sum(sharded.last_send_counts) if world > 1 else None
+        recv_w = sum(sharded.last_recv_counts) if world > 1 else None
+        cand = {k: v for k, v in stage_ms.items() if algorithmic_bytes(k, n_bytes, local_kmers, sent_words=sent_w, recv_words=recv_w) is not None}
         dom = max(cand, key=cand.get) if cand else None
         roofline = None
         if dom:
             W = 8 if args.kmer_size <= 32 else 16 if args.kmer_size <= 64 else 32
 
             def price(stage):
-                ab = algorithmic_bytes(stage, n_bytes, local_kmers, W, st["n_solid"])
+                ab = algorithmic_bytes(stage, n_bytes, local_kmers, W, st["n_solid"], sent_w, recv_w)
                 gbs = ab / (stage_ms[stage] * 1e-3) / 1e9
                 return {"algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(stage_ms[stage], 4), "achieved": round(gbs, 1),
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_vs_measured_copy": round(gbs / HBM_COPY_GBS, 4)}
@@ -425,8 +463,22 @@ def main():
                                           "the level-1 store pattern (where a buffer lies in HBM moves the scatter kernels by up to 18 %)",
                                   "candidates": 8}),
             "first_step_s": round(first_step_s, 3),
+            "ms_per_step_no_place": None if no_place_ms is None else round(no_place_ms, 3),
             "roofline": roofline,
         }
+        if world > 1:
+            # rank 0's view of the exchange (every rank sends and receives about the same: owners are balanced by the repartition table)
+            out["exchange_bytes"] = {"sent_per_rank": int(sent_w) * 8, "received_per_rank": int(recv_w) * 8,
+                                     "per_kmer_on_the_wire": round(int(sent_w) * 8 / max(1.0, n_kmers / world), 3),
+                                     "format": "super-k-mer records (2-3 words per <= 16 k-mers)" if 20 <= args.kmer_size <= 64 else "explicit keys"}
+            out["sliced_steps"] = sliced_steps[0]
+            if roofline:
+                roofline["per_rank"] = ("rank 0's kernels: mg_scatter = the sender (2-bit stream -> records), scatter1 = level 1 straight from the received "
+                                        "records -- in a sliced step its stage time includes the wait for the slices' arrival")
+            which = {31: "configs[2]", 63: "configs[3]"}.get(args.kmer_size)
+            if args.workload == "c3_shard_25Mx150" and which:
+                out["config"]["baseline_config"] = (f"{which} of BASELINE.json when N = 8 (200 M x 150 bp on a 600 Mbp genome); "
+                                                    f"this run: {world} x 25 M reads on a {gl * world} bp genome")
         # the same shape with what real genomes have and the uniform one lacks: a high-copy family, tandem arrays, poly-A reads
         # (dsk_amd/synth.py: make_genome_repeats).  An extra block: the headline above stays the BASELINE.json workload.
         twin = args.workload.replace("_10Mx150", "_repeats_10Mx150")

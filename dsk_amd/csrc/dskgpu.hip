@@ -203,6 +203,7 @@ struct dskgpu_ctx {
     bool rec_hint_est = false;               // ... an estimate (sliced step): sizes the fast path only, never checked against the result
     std::vector<u64> rec_slice_end;          // dskgpu_mg_count_sliced: record index where every slice ends; empty = one piece
     dskgpu_slice_gate rec_gate = nullptr; void* rec_gate_user = nullptr; u32 rec_gated = 0;      // slices whose arrival the stream already waits for
+    bool rec_gate_failed = false;            // a gate said its slice will never arrive: the count stops (DSKGPU_E_STATE)
     std::vector<u32> h_slice_chunk;          // first level-1 chunk of every slice (+ the end)
     DevBuf cur_state;                        // parked write cursors of the level-1 blocks between the launches of a sliced receive
     bool rec_sized = false;                  // per-chunk k-mer sums of the records are on the device (k_sk_count ran)
@@ -753,16 +754,19 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
 // the caller did not pass the total (dskgpu_mg_count); otherwise only by paths that expand the records.
 #define REC_RESIZE 1001            // expand_records: the k-mer total the pipeline was sized with was an estimate and is off -- ctx->rec_hint holds the real one
 // the stream waits for the arrival of the slices up to `upto` (exclusive) -- in order, each once
-void rec_gate_upto(dskgpu_ctx* ctx, u32 upto) {
-    if (!ctx->rec_gate) return;
+// -> DSKGPU_OK, or DSKGPU_E_STATE once a gate has failed (the caller enqueues nothing that reads the records)
+int rec_gate_upto(dskgpu_ctx* ctx, u32 upto) {
+    if (!ctx->rec_gate) return DSKGPU_OK;
     const u32 n = (u32)ctx->rec_slice_end.size();
-    for (; ctx->rec_gated < std::min(upto, n); ++ctx->rec_gated) ctx->rec_gate(ctx->rec_gate_user, ctx->rec_gated);
+    for (; ctx->rec_gated < std::min(upto, n); ++ctx->rec_gated)
+        if (ctx->rec_gate(ctx->rec_gate_user, ctx->rec_gated) != 0) ctx->rec_gate_failed = true;
+    return ctx->rec_gate_failed ? fail(ctx, DSKGPU_E_STATE, "a slice of the exchange did not arrive (the caller's gate failed)") : DSKGPU_OK;
 }
-void rec_gate_all(dskgpu_ctx* ctx) { rec_gate_upto(ctx, 0xFFFFFFFFu); }
+int rec_gate_all(dskgpu_ctx* ctx) { return rec_gate_upto(ctx, 0xFFFFFFFFu); }
 
 int sk_sizes(dskgpu_ctx* ctx, u64* total_out) {
     const u64 nrec = ctx->rec_n; const u32 R = ctx->sk_sp.R;
-    rec_gate_all(ctx);                                          // (a sliced receive: every record has to be there)
+    { const int e = rec_gate_all(ctx); if (e) return e; }      // (a sliced receive: every record has to be there)
     u64 nch = std::min<u64>((nrec + SKX_NT - 1) / SKX_NT, (u64)ctx->num_cu * 16);
     u64 rpc = (nrec + nch - 1) / nch;
     rpc = (rpc + SKX_NT - 1) / SKX_NT * SKX_NT;
@@ -794,7 +798,7 @@ int expand_records(dskgpu_ctx* ctx, u64 total) {
         if (real != total && ctx->rec_hint_est) { ctx->rec_hint = real; return REC_RESIZE; }      // the estimate sized the fast path only: once more with the real figure
         if (real != total) return fail(ctx, DSKGPU_E_ARG, "dskgpu_mg_count_sized: n_kmers does not match the k-mers inside the records");
     }
-    rec_gate_all(ctx);
+    { const int e = rec_gate_all(ctx); if (e) return e; }
     CK(ctx->sk_keys.ensure((total + 1) * sizeof(Key)));
     hipLaunchKernelGGL(k_sk_expand<W>, dim3((unsigned)ctx->rec_nch), dim3(SKX_NT), 0, ctx->stream, ctx->rec_src, ctx->rec_n, ctx->sk_sp.R,
                        (int)ctx->cfg.kmer_size, (u32)ctx->rec_rpc, ctx->sk_cbase.as<u64>(), ctx->sk_keys.as<Key>());
@@ -1122,13 +1126,13 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 o1.cur_state = ctx->cur_state.as<u32>();
                 rc = DSKGPU_OK;
                 for (size_t sl = 0; sl < S && rc == DSKGPU_OK; ++sl) {
-                    rec_gate_upto(ctx, (u32)sl + 1);
+                    if ((rc = rec_gate_upto(ctx, (u32)sl + 1))) break;
                     o1.g0 = ctx->h_slice_chunk[sl]; o1.gn = ctx->h_slice_chunk[sl + 1] - ctx->h_slice_chunk[sl];
                     o1.resume = sl > 0 ? 1u : 0u; o1.last = sl + 1 == S ? 1u : 0u;
                     rc = launch_scatter_rec<W>(ctx, dd1, sc + SC_NCH1, nch1, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
                 }
             }
-            else if (from_rec) { rec_gate_all(ctx); rc = launch_scatter_rec<W>(ctx, dd1, sc + SC_NCH1, nch1, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1); }
+            else if (from_rec) { if (!(rc = rec_gate_all(ctx))) rc = launch_scatter_rec<W>(ctx, dd1, sc + SC_NCH1, nch1, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1); }
             else rc = launch_scatter_m<W, 1, 1, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
             if (rc) return rc;
             ctx->mark("scatter1");
@@ -1770,7 +1774,7 @@ int sk_count(dskgpu_ctx* ctx, const u64* d_rec, u64 recv_words, u64 n_kmers_hint
     ctx->mark("mg_sizes");
     CK(hipStreamSynchronize(ctx->stream));
     ctx->resolve_marks();
-    if (!ctx->rec_src) { rec_gate_all(ctx); return run_pipeline<W>(ctx, false, ctx->sk_keys.as<Key>(), 0); }
+    if (!ctx->rec_src) { const int e = rec_gate_all(ctx); if (e) return e; return run_pipeline<W>(ctx, false, ctx->sk_keys.as<Key>(), 0); }
     int rc = run_pipeline<W>(ctx, false, nullptr, total);      // nullptr: keys come from ctx->rec_src
     if (rc == REC_RESIZE) { ctx->rec_hint_est = false; rc = run_pipeline<W>(ctx, false, nullptr, ctx->rec_hint); ctx->rec_hint = 0; }
     ctx->rec_src = nullptr;
@@ -2095,6 +2099,15 @@ int dskgpu_reserve_work(dskgpu_ctx* ctx, uint64_t nbytes) {
     const u64 target = ctx->W == 1 ? TARGET_KEYS : ctx->W == 2 ? TARGET_KEYS2 : TARGET_KEYS2 / 2;
     const u64 F = n / target + 2, cap = OPT_GROUPS * (8u / (u64)ctx->W);
     const u64 regions = F + (ctx->W == 1 ? F / 8 + 4096 : 0);
+    {   // a reservation is a convenience: never more than 60 % of what is free (the sizes are upper bounds from a byte count; ranks that
+        // share a device and DSKGPU_PLACE's candidates need room too) -- beyond that dskgpu_count sizes the buffers itself
+        size_t free_b = 0, total_b = 0;
+        const u64 want = (nwords + 1) * 12 + std::max<u64>((n + n / 8 + (1u << 20)) * key, ctx->W == 1 ? F * cap * 4 : 0) + (regions * cap + (1u << 16)) * key;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const u64 have = ctx->packed.cap + ctx->inval.cap + ctx->bufA.cap + ctx->bufB.cap;
+            if (want > have && want - have > (u64)free_b * 6 / 10) return fail(ctx, DSKGPU_E_NOMEM, "dskgpu_reserve_work: the reservation exceeds 60 % of the free device memory (not reserved; dskgpu_count sizes its own buffers)");
+        }
+    }
     CK(ctx->bufA.ensure(std::max<u64>((n + n / 8 + (1u << 20)) * key, ctx->W == 1 ? F * cap * 4 : 0)));
     CK(ctx->bufB.ensure((regions * cap + (1u << 16)) * key));
     if (ctx->W > 1) CK(ctx->abund2.ensure((F * cap + (1u << 16)) * 4));
@@ -2103,6 +2116,11 @@ int dskgpu_reserve_work(dskgpu_ctx* ctx, uint64_t nbytes) {
 
 int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes) {
     if (!ctx || (!d_bytes && nbytes)) return DSKGPU_E_ARG;
+    // The caller usually just PRODUCED these bytes on a stream of its own (torch's), and the context's stream is non-blocking: nothing
+    // orders the two.  Wait for the device once, here, so that a count can never read reads that are still being written (the r03
+    // intermittent failure of the multi-process test was exactly that, in the test's reference count).  Once per read set, not per count.
+    CK(hipSetDevice(ctx->cfg.device));
+    CK(hipDeviceSynchronize());
     ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false;
     ctx->n_bytes = nbytes;
     ctx->reads_len = 0;
@@ -2271,10 +2289,12 @@ int dskgpu_mg_count_sliced(dskgpu_ctx* ctx, const void* d_recv, uint32_t nslices
         ctx->rec_slice_end.push_back(words / R);
     }
     if (!d_recv && words) { ctx->rec_slice_end.clear(); return DSKGPU_E_ARG; }
-    ctx->rec_gate = gate; ctx->rec_gate_user = user; ctx->rec_gated = 0;
-    const int rc = ctx->W == 1 ? sk_count<1>(ctx, static_cast<const u64*>(d_recv), words, n_kmers_est, true)
-                               : sk_count<2>(ctx, static_cast<const u64*>(d_recv), words, n_kmers_est, true);
-    rec_gate_all(ctx);                                   // (an error path may have left early: the caller's gates are all passed when this returns)
+    ctx->rec_gate = gate; ctx->rec_gate_user = user; ctx->rec_gated = 0; ctx->rec_gate_failed = false;
+    int rc = ctx->W == 1 ? sk_count<1>(ctx, static_cast<const u64*>(d_recv), words, n_kmers_est, true)
+                         : sk_count<2>(ctx, static_cast<const u64*>(d_recv), words, n_kmers_est, true);
+    const std::string err = ctx->err;
+    (void)rec_gate_all(ctx);                             // (an error path may have left early: the caller's gates are all passed when this returns)
+    if (ctx->rec_gate_failed) { ctx->have_result = false; if (rc == DSKGPU_OK) rc = DSKGPU_E_STATE; else ctx->err = err; }
     ctx->rec_gate = nullptr; ctx->rec_gate_user = nullptr; ctx->rec_slice_end.clear();
     return rc;
 }

@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +42,7 @@ struct RcclApi {
     void* handle = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -57,12 +59,13 @@ struct RcclApi {
         auto sym = [&](const char* n) { void* p = dlsym(handle, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        CommAbort = reinterpret_cast<decltype(CommAbort)>(sym("ncclCommAbort"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
         Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
         Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
-        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString;
+        return CommInitAll && CommDestroy && CommAbort && GroupStart && GroupEnd && Send && Recv && GetErrorString;
     }
 };
 RcclApi g_rccl;
@@ -133,11 +136,22 @@ struct dskgpu_group {
     std::vector<uint8_t> table;
     uint64_t exchanged_words = 0;                    // words that crossed ranks in the last count (off-diagonal of counts)
     bool have_result = false;
+    // A rank that fails between the meetings of an RCCL exchange (device error, a failed ncclSend) cannot just leave: its peers have
+    // already posted the matching ncclRecv and would wait in it forever.  It ABORTS every communicator of the group instead
+    // (ncclCommAbort is the call RCCL offers for exactly this, from any thread): the peers' pending transfers end with an error,
+    // their stream synchronisation returns, the step fails on every rank with a message -- and the group, whose communicators
+    // are gone, refuses further counts (create a new one).
+    std::atomic<int> comms_aborted{0};
 };
 
 namespace {
 
 int group_fail(dskgpu_group* g, int code, const std::string& msg) { g->err = msg; return code; }
+
+void abort_comms(dskgpu_group* g) {
+    if (!g->use_rccl || g->comms_aborted.exchange(1)) return;
+    for (auto& c : g->comm) if (c) { (void)g_rccl.CommAbort(c); c = nullptr; }
+}
 
 // one rank of one sharded count
 void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
@@ -207,7 +221,7 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
                     else if (hipEventRecord(g->ev_sent[r][sl], g->stream[r]) != hipSuccess) fail(DSKGPU_E_DEVICE, "hipEventRecord");
                 }
                 if (g->use_rccl) {
-                    if (g->rc[r] != DSKGPU_OK) continue;             // (its peers will hang in RCCL, as in the one-piece exchange: a device error)
+                    if (g->rc[r] != DSKGPU_OK || g->comms_aborted.load()) { abort_comms(g); break; }      // (the peers' posted receives end with an error instead of waiting for this rank)
                     RcclApi& a = g_rccl;
                     (void)hipStreamWaitEvent(cs, g->ev_sent[r][sl], 0);
                     ncclResult_t e = a.GroupStart();
@@ -220,7 +234,7 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
                     }
                     const ncclResult_t e2 = a.GroupEnd();
                     if (e == ncclSuccess) e = e2;
-                    if (e != ncclSuccess) fail(DSKGPU_E_DEVICE, std::string("RCCL exchange: ") + a.GetErrorString(e));
+                    if (e != ncclSuccess) { fail(DSKGPU_E_DEVICE, std::string("RCCL exchange: ") + a.GetErrorString(e)); abort_comms(g); break; }
                 } else {
                     if (bar->wait(failed())) return;               // every rank's event of this slice is recorded
                     uint64_t ro = rbase[sl];
@@ -242,11 +256,12 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
             uint64_t est = 0;
             for (uint32_t p = 0; p < n; ++p) est += g->kest[p][r];
             struct Gate { hipStream_t st; hipEvent_t* ev; } gs{g->stream[r], g->ev_recv[r].data()};
-            auto gate = [](void* u, uint32_t sl) { Gate* x = static_cast<Gate*>(u); (void)hipStreamWaitEvent(x->st, x->ev[sl], 0); };
-            if (g->rc[r] == DSKGPU_OK) {
+            auto gate = [](void* u, uint32_t sl) -> int { Gate* x = static_cast<Gate*>(u); return hipStreamWaitEvent(x->st, x->ev[sl], 0) == hipSuccess ? 0 : 1; };
+            if (g->rc[r] == DSKGPU_OK && !g->comms_aborted.load()) {
                 const int rc = dskgpu_mg_count_sliced(ctx, rbase[S] ? rb : nullptr, S, rw.data(), est, gate, &gs);
-                if (rc != DSKGPU_OK) fail(rc, std::string("mg_count_sliced: ") + dskgpu_last_error(ctx));
+                if (rc != DSKGPU_OK) { fail(rc, std::string("mg_count_sliced: ") + dskgpu_last_error(ctx)); abort_comms(g); }      // (a peer may still wait for a slice this rank was to send)
             }
+            if (g->comms_aborted.load() && g->rc[r] == DSKGPU_OK) fail(DSKGPU_E_DEVICE, "the exchange was aborted: another rank failed");
             int ovf = 0;
             if (g->rc[r] == DSKGPU_OK) {
                 const int rc = dskgpu_mg_slices_finish(ctx, &ovf);
@@ -296,7 +311,7 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
         }
         const ncclResult_t e2 = a.GroupEnd();
         if (e == ncclSuccess) e = e2;
-        if (e != ncclSuccess) fail(DSKGPU_E_DEVICE, std::string("RCCL exchange: ") + a.GetErrorString(e));
+        if (e != ncclSuccess) { fail(DSKGPU_E_DEVICE, std::string("RCCL exchange: ") + a.GetErrorString(e)); abort_comms(g); }
     } else {
         for (uint32_t s = 0; s < n; ++s) {
             const uint64_t w = g->counts[s][r];
@@ -421,6 +436,7 @@ uint32_t dskgpu_group_sliced_steps(const dskgpu_group* g) { return g ? g->sliced
 
 int dskgpu_group_count(dskgpu_group* g) {
     if (!g) return DSKGPU_E_ARG;
+    if (g->comms_aborted.load()) return group_fail(g, DSKGPU_E_STATE, "the group's RCCL communicators were aborted by a failed step: create a new group");
     g->have_result = false; g->sliced_steps = 0;
     std::fill(g->rc.begin(), g->rc.end(), DSKGPU_OK);
     for (auto& row : g->counts) std::fill(row.begin(), row.end(), 0);

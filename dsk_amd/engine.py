@@ -95,7 +95,7 @@ EXPORTS = [
 _lib = None
 
 
-SLICE_GATE = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32)      # dskgpu_slice_gate
+SLICE_GATE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32)      # dskgpu_slice_gate: 0 = the stream waits for the slice, else the count stops
 
 
 def library_path() -> str:
@@ -360,8 +360,20 @@ class KmerCounter:
     def mg_count_sliced(self, recv_ptr: int, slice_words: Sequence[int], n_kmers_est: int, gate) -> None:
         """gate(s) is called right before the first device work that reads slice s is enqueued: make the stream wait for it."""
         arr = (C.c_uint64 * len(slice_words))(*[int(w) for w in slice_words])
-        cb = SLICE_GATE(lambda _user, s: gate(int(s)))
-        self._ck(self._lib.dskgpu_mg_count_sliced(self._h, C.c_void_p(recv_ptr), len(slice_words), arr, n_kmers_est, cb, None))
+        failed: list = []
+
+        def _gate(_user, s):      # ctypes would print and swallow an exception raised in here: keep it, tell the C side, re-raise below
+            try:
+                gate(int(s))
+                return 0
+            except BaseException as e:      # noqa: BLE001 -- a failed wait (collective timeout / abort) must stop the count, whatever it is
+                failed.append(e)
+                return 1
+        cb = SLICE_GATE(_gate)
+        rc = self._lib.dskgpu_mg_count_sliced(self._h, C.c_void_p(recv_ptr), len(slice_words), arr, n_kmers_est, cb, None)
+        if failed:
+            raise failed[0]
+        self._ck(rc)
 
     def mg_count(self, recv_ptr: int, recv_words: int, n_kmers: int = 0) -> None:
         """n_kmers = the senders' k-mer total for this rank (sum over sources of mg_sent_kmers()[rank]); 0 = count them here."""

@@ -2,7 +2,9 @@
 // OptionFailure -> usage on stdout, its code; Exception -> "EXCEPTION: msg" on stderr, EXIT_FAILURE.
 #include "dsk.hpp"
 
+#include <hdf5.h>
 #include <sys/time.h>
+#include <cstring>
 #include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
@@ -10,6 +12,21 @@ static double wall_s() { struct timeval tv; gettimeofday(&tv, nullptr); return t
 
 int main(int argc, char* argv[]) {
     const double t0 = wall_s();
+    // One GPU of a node with several: let the device runtime bring up only that one (its start-up is most of a small run and grows
+    // with the devices it enumerates).  Decided HERE, before any thread exists (setenv next to the parser threads' getenv was a data
+    // race: ADVICE r03), for the command line only -- a host that embeds the backend selects its device with -device / hipSetDevice.
+    {
+        int device = 0; bool multi = false;
+        for (int i = 1; i + 1 < argc; ++i) {
+            if (!std::strcmp(argv[i], "-device")) device = atoi(argv[i + 1]);
+            if (!std::strcmp(argv[i], "-nb-gpus") && atoi(argv[i + 1]) > 1) multi = true;
+        }
+        if (!multi && device >= 0 && !getenv("ROCR_VISIBLE_DEVICES") && !getenv("HIP_VISIBLE_DEVICES") && !getenv("CUDA_VISIBLE_DEVICES")) {
+            char dev[16]; snprintf(dev, sizeof dev, "%d", device);
+            setenv("ROCR_VISIBLE_DEVICES", dev, 1);
+            setenv("DSK_DEVICE_REMAPPED", dev, 1);          // the backend maps `-device <dev>` to ordinal 0 of what is visible now
+        }
+    }
     dsk::setBackendFactory(dsk::createGpuBackend);   // the only backend this binary knows: the HIP engine
     try {
         dsk::DSK().run(argc, argv);
@@ -21,6 +38,9 @@ int main(int argc, char* argv[]) {
     }
     // The output file is closed and everything printed: leave without the device runtime's exit handlers (0.1 s of a 0.4 s run
     // on the E. coli-sized input: they unload code objects and unmap the device for a process that is gone a moment later).
+    // (HDF5 first: H5close flushes and closes whatever the library still holds -- with the default weak close degree a leaked
+    //  handle would otherwise leave the .h5 unflushed behind an exit code of 0)
+    H5close();
     std::cout.flush(); std::cerr.flush(); fflush(nullptr);
     if (getenv("DSK_PHASE_TIMES")) fprintf(stderr, "[dsk] main() took %.3f s\n", wall_s() - t0);
     _exit(EXIT_SUCCESS);

@@ -42,15 +42,9 @@ public:
             pushed_.assign(c.nb_gpus, 0);
             return;
         }
-        // One GPU of a node with several: let the device runtime bring up only that one (its start-up is most of a small run and
-        // grows with the devices it enumerates).  Only before the runtime is initialised, and only if the user did not choose.
-        static bool runtime_up = false;
-        if (!getenv("ROCR_VISIBLE_DEVICES") && !getenv("HIP_VISIBLE_DEVICES") && !getenv("CUDA_VISIBLE_DEVICES") && !runtime_up && c.device >= 0) {
-            char dev[16]; snprintf(dev, sizeof dev, "%d", c.device);
-            setenv("ROCR_VISIBLE_DEVICES", dev, 1);
-            g.device = 0;
-        }
-        runtime_up = true;
+        // (`dsk -device N` on a node with several GPUs: main() made only that device visible before any thread started, so it is
+        //  ordinal 0 here; an embedding host keeps its own device numbering and nothing is remapped)
+        if (const char* m = getenv("DSK_DEVICE_REMAPPED")) { if (atoi(m) == c.device) g.device = 0; }
         int rc = dskgpu_create(&g, &ctx_);
         if (rc != DSKGPU_OK) { std::string m = dskgpu_last_error(nullptr); ctx_ = nullptr; throw Exception("GPU engine: %s (code %d)", m.c_str(), rc); }
     }
@@ -60,9 +54,12 @@ public:
         for (uint32_t r = 0; r < N; ++r) ckr(r, dskgpu_reserve_reads(dskgpu_group_ctx(grp_, r), n / N + n / (8 * N) + 4096));
     }
     void prepare(uint64_t n) override {
-        if (!grp_) { ck(dskgpu_reserve_work(ctx_, n)); return; }
+        // optional by contract: a reservation that does not fit (its sizes are upper bounds from file-size hints) is not an error --
+        // dskgpu_count sizes its buffers from the real k-mer count, in several passes if need be
+        auto soft = [&](int rc) { return rc == DSKGPU_E_NOMEM ? DSKGPU_OK : rc; };
+        if (!grp_) { ck(soft(dskgpu_reserve_work(ctx_, n))); return; }
         const uint32_t N = dskgpu_group_size(grp_);
-        for (uint32_t r = 0; r < N; ++r) ckr(r, dskgpu_reserve_work(dskgpu_group_ctx(grp_, r), n / N + n / (8 * N) + 4096));
+        for (uint32_t r = 0; r < N; ++r) ckr(r, soft(dskgpu_reserve_work(dskgpu_group_ctx(grp_, r), n / N + n / (8 * N) + 4096)));
     }
     void push(const char* data, size_t n) override {
         if (!grp_) { ck(dskgpu_push_reads(ctx_, data, n)); return; }

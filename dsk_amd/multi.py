@@ -14,6 +14,7 @@ methods to exercise this driver under gloo.
 """
 from __future__ import annotations
 
+import datetime
 import os
 from typing import List, Optional, Sequence, Tuple
 
@@ -75,7 +76,13 @@ class ShardedCounter:
     """Drives one rank of the sharded count.  After `count()`, the stage holds
     this rank's share of the result (its owned k-mers)."""
 
-    def __init__(self, stage, device: torch.device, group=None, balance: bool = True, slices: Optional[int] = None):
+    def __init__(self, stage, device: torch.device, group=None, balance: bool = True, slices: Optional[int] = None,
+                 wait_timeout_s: float = 120.0):
+        """wait_timeout_s: longest a rank waits for one slice of the exchange (gloo: the work handle's own timeout; RCCL: the
+        process group's watchdog enforces the timeout given to init_process_group -- bench.py passes the same figure there).  A
+        wait that fails raises here AND stops the count inside the engine (the gate returns non-zero): no level-1 launch ever
+        reads a slice that did not arrive."""
+        self.wait_timeout = datetime.timedelta(seconds=wait_timeout_s)
         self.stage = stage
         self.device = device
         self.group = group
@@ -152,8 +159,14 @@ class ShardedCounter:
                                                 group=self.group, async_op=True))
             so += sw[s]; ro += rw[s]
 
+        gloo = dist.get_backend(self.group) == "gloo"
+
         def gate(s: int) -> None:                     # the stage's stream waits for slice s (RCCL: an event wait, the host goes on)
-            works[s].wait()
+            if gloo:
+                if works[s].wait(self.wait_timeout) is False:
+                    raise RuntimeError(f"slice {s} of the exchange did not arrive within {self.wait_timeout}")
+            else:
+                works[s].wait()
             if staged:
                 landed[s][0].copy_(landed[s][1])
         self.stage.mg_count_sliced(self.recv.data_ptr() if n_recv else 0, rw, sum(int(rows[p][S]) for p in range(world)), gate)

@@ -106,7 +106,10 @@ int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes);
  * Stands where SortingCountAlgorithm's configure step sizes its passes and partitions before execute() fills them. */
 int dskgpu_reserve_work(dskgpu_ctx* ctx, uint64_t nbytes);
 /* Use a read stream already resident in HBM (caller keeps ownership and must
- * keep it alive until dskgpu_count returns).  Replaces any pushed reads. */
+ * keep it alive until dskgpu_count returns).  Replaces any pushed reads.  The call waits for all device work this
+ * process has submitted so far (hipDeviceSynchronize): bytes that another stream is still writing when it is made
+ * are complete when it returns.  Bytes written AFTER the call must be ordered by the caller (same stream as
+ * dskgpu_set_stream, or a synchronisation of its own) before dskgpu_count. */
 int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes);
 
 /* Banks: the comma-separated inputs of `-file` are separate banks (README.md:52-58).  Call
@@ -168,11 +171,14 @@ int dskgpu_mg_count_sized(dskgpu_ctx* ctx, const void* d_recv, uint64_t recv_wor
  *                             order of the sources inside a slice); gate(user, s) is called on the host right before the first
  *                             device work that reads slice s is enqueued -- the callee makes the context's stream wait for the
  *                             arrival of slice s (hipStreamWaitEvent / a torch work handle's wait()).  Slices are gated in order,
- *                             each once; a path that needs all records at once gates all of them first.
+ *                             each once; a path that needs all records at once gates all of them first.  A gate that returns
+ *                             non-zero (the wait failed: a collective timed out or was aborted) stops the count: no further device
+ *                             work is enqueued, the remaining gates are still called (their result ignored), the call returns
+ *                             DSKGPU_E_STATE and the context holds no result.
  *   dskgpu_mg_slices_finish   after the exchange: *overflowed != 0 when a slice of the SEND layout overflowed -- the records of this
  *                             step are then incomplete on some receivers, and every rank must repeat the step in one piece (the
  *                             decision is the caller's collective: OR the flags); the context will use exact counts from then on. */
-typedef void (*dskgpu_slice_gate)(void* user, uint32_t slice);
+typedef int (*dskgpu_slice_gate)(void* user, uint32_t slice);   /* 0 = the stream now waits for the slice; non-zero = it will never arrive */
 int dskgpu_mg_slices_prepare(dskgpu_ctx* ctx, uint32_t want_slices, uint32_t* nslices, uint64_t* send_words /* [want_slices * world_size] */,
                              uint64_t* kmers_est /* [world_size] */);
 int dskgpu_mg_scatter_slice(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint32_t slice);

@@ -26,6 +26,11 @@ tot = torch.tensor([st["n_kmers"], st["n_distinct"], st["n_solid"]], dtype=torch
 dist.all_reduce(tot)
 if rank == 0:
     allreads = torch.cat(shards)
+    # torch builds `allreads` on ITS stream; the context below runs on its own non-blocking stream.  Without this wait the reference
+    # count could read the buffer before torch.cat had written it -- the intermittent r03 failure of
+    # test_sliced_step_with_real_processes (tools/stress_multi.py with STRESS_RACE=1 reproduces it at will; profiles/r04_stress/).
+    # (dskgpu_set_reads_device now waits for the device itself; the explicit wait documents the contract.)
+    torch.cuda.synchronize()
     with KmerCounter(kmer_size=k, abundance_min=2) as one:
         one.set_reads_device(allreads.data_ptr(), allreads.numel())
         one.count()
