@@ -139,6 +139,9 @@ struct Tuning {
     bool l2_static = false;                     // DSKGPU_L2_STATIC: segments of the level-2 scatter round-robin over the blocks instead of by work counter
     bool no_level0 = false; u32 l0_passes = 0;  // DSKGPU_NO_LEVEL0: every pass of a multi-pass count re-generates its keys; DSKGPU_L0_PASSES=n: passes per level-0 sweep (tests)
     bool count_v1 = false;                      // DSKGPU_COUNT_V1: k_count1<true> (slot list) instead of the list-free k_count1v3 on regions
+    u64 rs_max_rows = 0;                        // DSKGPU_RS_MAX_ROWS: most rows the MSD row sort takes in one piece (tests: the group-wise path of huge row sets on a small input)
+    bool l0_staged = false;                     // DSKGPU_L0_STAGED: level 0 through the LDS-staged scatter (k_scatter<1, 0, 4>) instead of k_level0 (experiments)
+    u32 mp_pass_mkeys = 0;                      // DSKGPU_MP_PASS_MKEYS: keys (millions) per pass of an input that needs several passes (default 1000)
     bool force_heavy = false;                   // DSKGPU_FORCE_HEAVY: the HEAVY instantiation of the level-1 scatter even when no k-mer is counted apart (timing)
     void read() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
@@ -150,7 +153,7 @@ struct Tuning {
         sk_slice = num("DSKGPU_SK_SLICE", 0); sk_minslice = num("DSKGPU_SK_MINSLICE", 2000);
         table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
         max_ext = getenv("DSKGPU_MAX_EXT") ? atoll(getenv("DSKGPU_MAX_EXT")) : -1;
-        no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); l2_static = on("DSKGPU_L2_STATIC"); force_heavy = on("DSKGPU_FORCE_HEAVY"); count_v1 = on("DSKGPU_COUNT_V1"); no_level0 = on("DSKGPU_NO_LEVEL0"); l0_passes = (u32)num("DSKGPU_L0_PASSES", 0);
+        no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); l2_static = on("DSKGPU_L2_STATIC"); force_heavy = on("DSKGPU_FORCE_HEAVY"); count_v1 = on("DSKGPU_COUNT_V1"); no_level0 = on("DSKGPU_NO_LEVEL0"); l0_passes = (u32)num("DSKGPU_L0_PASSES", 0); mp_pass_mkeys = (u32)num("DSKGPU_MP_PASS_MKEYS", 0); rs_max_rows = num("DSKGPU_RS_MAX_ROWS", 0); l0_staged = on("DSKGPU_L0_STAGED");
         lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0); rs_heavy = (u32)num("DSKGPU_RS_HEAVY", 0);
     }
 };
@@ -177,6 +180,11 @@ struct dskgpu_ctx {
     DevBuf packed, inval;          // K1 output
     DevBuf bufA, bufB;             // partition ping-pong
     DevBuf mat1, mat2, sums, descs1, descs2, seg, fstart, nsolid, scalars, ghist, gstats, chain_next;
+    DevBuf rs_g[4];                // row sort: the gathered rows of the listed sub-buckets, one buffer per round (sort_oversize)
+    DevBuf rs_ovs;                 // row sort: [count | (offset, rows, bits left) x RS_OVS_CAP] of the sub-buckets listed for another round
+    std::vector<u32> h_ovs;
+    u64* rs_res_k = nullptr; u32* rs_res_v = nullptr; u64* rs_tmp_k = nullptr; u32* rs_tmp_v = nullptr;   // the partially sorted rows and their scratch twin (sort_oversize)
+    DevBuf smp_keys;               // records: the sample expanded to a key array (16 slots per candidate record, sentinel pads)
     DevBuf smp_mat, smp_descs, boff;   // sampled level-1 loads: chunk x bin matrix of the sample tiles, their descriptors; per-bin slice offsets
     DevBuf dbg, l0buf; DevBuf hv_lut, hv_collect, hv_buf; // heavy k-mers: bin -> collect slot, collected sample keys; [keys | counts | rows] of the k-mers counted apart
     std::vector<unsigned char> h_hv_lut; std::vector<u32> h_hv_cnt, h_hv_step; std::vector<u64> h_hv_coll, h_hv_keys;
@@ -214,6 +222,7 @@ struct dskgpu_ctx {
     const u64* rec_src = nullptr; u64 rec_n = 0; u64 rec_nch = 0, rec_rpc = 0; bool rec_expanded = false;
     u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0, h_ext = 0; u64 h_nvalid = 0; bool have_nvalid = false;
     u32 h_rs[4] = {0, 0, 0, 0};    // host source of the row sort's device scalars (matrix length, list length, work counter, ties seen)
+    u64* fb_src_k = nullptr; u32* fb_src_v = nullptr; u64* fb_dst_k = nullptr; u32* fb_dst_v = nullptr;   // one-word row sort: where the full-width fallback finds a permutation of the rows / leaves them sorted
     bool sentinel_ok = true;       // the all-ones key is not the mixed form of a canonical k-mer of this k (checked at create)
     bool opt1_off = false;         // same for the histogram-free level-1 scatter (block-owned slices)
     bool opt2_off = false;         // the fixed-capacity level-2 scatter overflowed on these reads: use the exact path   // host landing zone of the async size read-back
@@ -244,7 +253,10 @@ struct dskgpu_ctx {
     void resolve_marks() {   // after a stream sync; appends to st_names/st_ms
         for (size_t i = 0; i + 1 < marks.size(); ++i) {
             float ms = 0; (void)hipEventElapsedTime(&ms, marks[i].ev, marks[i + 1].ev);
-            st_names.push_back(marks[i + 1].name); st_ms.push_back(ms);
+            // one entry per stage name: the passes of a multi-pass count (and the retries of a pass) add up
+            size_t at = 0;
+            while (at < st_names.size() && std::strcmp(st_names[at], marks[i + 1].name) != 0) ++at;
+            if (at == st_names.size()) { st_names.push_back(marks[i + 1].name); st_ms.push_back(ms); } else st_ms[at] += ms;
         }
         marks.clear(); ev_used = 0;
     }
@@ -329,12 +341,12 @@ int allow_big_lds(dskgpu_ctx* ctx, const void* fn) {
     return DSKGPU_OK;
 }
 
-size_t scatter_lds(int W, u32 P, bool opt = false) { return (size_t)SC_NT * (16 / W) * 8 * W + (size_t)P * (opt ? 20 : 16) + 4 + 17 * 4 + 16; }   // opt: + the slice ends
+size_t scatter_lds(int W, u32 P, bool opt = false) { return (size_t)SC_NT * (16 / W) * 8 * W + (size_t)P * (opt ? 20 : 16) + 4 + 17 * 4 + 16 + (opt ? 8 + L0_MAX_PASSES * 8 : 0); }   // opt: + the slice ends (+ the region bases of a level-0 sweep)
 
 template <int W, int SRC, int MODE>
 int launch_hist_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
                   u64 max_chunks, u32* matrix, DigitSpec ds, u32 P) {
-    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu * 2));
+    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(max_chunks, (u64)ctx->num_cu));
     hipLaunchKernelGGL((k_hist<W, SRC, MODE>), dim3(grid), dim3(SC_NT), 0, ctx->stream, ctx->packed.as<u64>(),
                        ctx->inval.as<u32>(), keys, descs, d_nch, matrix, (int)ctx->cfg.kmer_size, ds, P);
     CKL("k_hist");
@@ -360,7 +372,7 @@ unsigned scatter_grid(const dskgpu_ctx* ctx, int W, u32 P, u64 max_chunks, bool 
 }
 template <int W, int SRC, int MODE, bool OPT = false, bool HEAVY = false>
 int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1 = Opt1Spec{nullptr, 0u, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 0u, {0ull, 0ull, 0ull, 0ull}, 0u}) {
+                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1 = Opt1Spec{nullptr, 0u, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 0u, nullptr, 0ull, 0u}) {
     const size_t lds = scatter_lds(W, P, OPT && !o1.uslice);
     const unsigned grid = scatter_grid(ctx, W, P, max_chunks, OPT && !o1.uslice);
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, SRC, MODE, OPT, HEAVY>)); if (e) return e; }
@@ -369,18 +381,23 @@ int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chu
     CKL("k_scatter");
     return DSKGPU_OK;
 }
-// super-k-mer records as the source of the histogram-free level-1 scatter (one- and two-word keys)
-template <int W>
+// super-k-mer records as the source of the histogram-free level-1 scatter (one- and two-word keys); HEAVY: with k-mers counted apart (one-word keys)
+template <int W, bool HEAVY = false>
 int launch_scatter_rec(dskgpu_ctx* ctx, const ChunkDesc* descs, const u32* d_nch, u64 max_chunks, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1) {
     const size_t lds = scatter_lds(W, P, !o1.uslice);
     const unsigned grid = scatter_grid(ctx, W, P, max_chunks, !o1.uslice);
-    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, 2, 1, true>)); if (e) return e; }
-    hipLaunchKernelGGL((k_scatter<W, 2, 1, true>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->rec_src, (const u32*)nullptr,
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, 2, 1, true, HEAVY>)); if (e) return e; }
+    hipLaunchKernelGGL((k_scatter<W, 2, 1, true, HEAVY>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->rec_src, (const u32*)nullptr,
                        (const typename KeyT<W>::T*)nullptr, descs, d_nch, (const u32*)nullptr, out, (int)ctx->cfg.kmer_size, ds, P, o1);
     CKL("k_scatter(records)");
     return DSKGPU_OK;
 }
-template <> int launch_scatter_rec<4>(dskgpu_ctx*, const ChunkDesc*, const u32*, u64, KN<4>*, DigitSpec, u32, Opt1Spec) { return DSKGPU_E_STATE; }
+template <> int launch_scatter_rec<4, false>(dskgpu_ctx*, const ChunkDesc*, const u32*, u64, KN<4>*, DigitSpec, u32, Opt1Spec) { return DSKGPU_E_STATE; }
+template <int W>
+int launch_scatter_rec_h(dskgpu_ctx* ctx, bool heavy, const ChunkDesc* descs, const u32* d_nch, u64 max_chunks, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1) {
+    if constexpr (W == 1) { if (heavy) return launch_scatter_rec<1, true>(ctx, descs, d_nch, max_chunks, out, ds, P, o1); }
+    return launch_scatter_rec<W, false>(ctx, descs, d_nch, max_chunks, out, ds, P, o1);
+}
 
 // key-array source with aligned write-out (k_scatter_al) when its LDS footprint fits one CU
 template <int W, int MODE, bool OPT = false, bool SLICED = false>
@@ -593,7 +610,7 @@ int sort_rows_full_multiword(dskgpu_ctx* ctx, u64 n) {
 // (tk / tv: scratch of the same size).  One-word rows: (k-mer value, abundance); multi-word rows: (top 63 bits of the value,
 // row index).  Whatever the kernels do not order themselves raises SC_SORTFLAG (zeroed here): the caller falls back to a
 // full-width library sort (k / v and tk / tv each hold a complete permutation of the pairs either way).
-int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int total) {
+int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int total, bool reset_flags = true, u32 base = 0) {
     // second digit: 8 bits up to 96 M rows, 9 up to 192 M, 10 beyond (sub-buckets stay near 200 rows: one wave each in step C)
     int wantB = n <= (96ull << 20) ? 8 : n <= (192ull << 20) ? 9 : 10;
     if (ctx->tune.rs_bbits >= 8 && ctx->tune.rs_bbits <= 10) wantB = (int)ctx->tune.rs_bbits;      // tests
@@ -615,8 +632,9 @@ int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int
     u32* biglist = sub + nsubw;
     u32* sc = ctx->scalars.as<u32>();
     ctx->h_rs[0] = (u32)M; ctx->h_rs[1] = 0; ctx->h_rs[2] = 0; ctx->h_rs[3] = 0;
-    CK(hipMemcpyAsync(sc + SC_RSLEN, ctx->h_rs, 16, hipMemcpyHostToDevice, ctx->stream));
-    CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream));
+    CK(hipMemcpyAsync(sc + SC_RSLEN, ctx->h_rs, reset_flags ? 16 : 12, hipMemcpyHostToDevice, ctx->stream));      // (length, two work counters [, ties seen])
+    CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
+    if (reset_flags) { CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream)); CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream)); }
     const size_t ldsA = RsLds<RS_ABINS, RS_TILE>::bytes;
     const size_t ldsB = BB == 256 ? RsLds<256, RS_BTILE>::bytes : BB == 512 ? RsLds<512, RS_BTILE>::bytes : RsLds<1024, RS_BTILE>::bytes;
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_scatter)); if (e) return e; }
@@ -640,7 +658,7 @@ int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int
     hipLaunchKernelGGL(k_rs_cells, dim3(nsub / (RS_CNT / 64)), dim3(RS_CNT), 0, ctx->stream, k, v, sub, nsub, BB, sp, biglist, sc + SC_RSWORK, sc + SC_SORTFLAG, sc + SC_RSTIES);
     CKL("k_rs_cells");
     const u32 block_rows = ctx->tune.rs_block_rows ? std::min<u32>(ctx->tune.rs_block_rows, RS_BLOCK_ROWS) : RS_BLOCK_ROWS;
-    hipLaunchKernelGGL(k_rs_big, dim3((unsigned)std::min<u64>(ncu, 256)), dim3(RS_NT), 0, ctx->stream, k, v, sub, sp, biglist, sc + SC_RSWORK, sc + SC_SORTFLAG, block_rows, sc + SC_RSTIES);
+    hipLaunchKernelGGL(k_rs_big, dim3((unsigned)std::min<u64>(ncu, 256)), dim3(RS_NT), 0, ctx->stream, k, v, sub, sp, biglist, sc + SC_RSWORK, sc + SC_SORTFLAG, block_rows, sc + SC_RSTIES, base, ctx->rs_ovs.as<u32>());
     CKL("k_rs_big");
     return DSKGPU_OK;
 }
@@ -651,8 +669,139 @@ int sort_rows_msd(dskgpu_ctx* ctx, u64 n) {
                                  (int)std::min(64u, 2u * ctx->cfg.kmer_size));
     if (e) return e;
     CK(hipMemcpyAsync(&ctx->h_back[3], ctx->scalars.as<u32>() + SC_SORTFLAG, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->h_ovs.assign(1, 0);
+    CK(hipMemcpyAsync(ctx->h_ovs.data(), ctx->rs_ovs.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->sort_partial = true;
     ctx->res_w[0] = ctx->out_w[0].as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>();
+    ctx->rs_res_k = ctx->out_w[0].as<u64>(); ctx->rs_res_v = ctx->out_ab.as<u32>(); ctx->rs_tmp_k = ctx->srt_w[0].as<u64>(); ctx->rs_tmp_v = ctx->srt_ab.as<u32>();
+    return DSKGPU_OK;
+}
+
+// The sub-buckets a row sort listed instead of ordering them (k_rs_big: more than RS_BLOCK_ROWS rows share two digits -- the error
+// variants of a k-mer with 10^8 occurrences share 13 and more leading bases): the rows of all listed ranges are gathered under
+// the composite key (range number, value bits the range has not used yet), ordered by ONE more MSD sort and put back
+// (k_ovs_gather / k_ovs_scatter) -- which may list ranges of the gathered array again: a few rounds at most, the rows of a range
+// share ever longer prefixes.  Called after the host has seen a non-zero count (ctx->h_ovs[0]); synchronous.  Leaves
+// ctx->h_back[3] != 0 when rounds or list run out: the caller's full-width fallback.
+int sort_oversize_round(dskgpu_ctx* ctx, u64* res_k, u32* res_v, int depth) {
+    u32* sc = ctx->scalars.as<u32>();
+    const u32 cnt = ctx->h_ovs[0];
+    if (cnt == 0) return DSKGPU_OK;
+    if (cnt > RS_OVS_CAP || depth >= 4) { ctx->h_back[3] = 1; return DSKGPU_OK; }
+    std::vector<u32> list(3 * (size_t)cnt), starts(cnt + 1, 0);
+    CK(hipMemcpyAsync(list.data(), ctx->rs_ovs.as<u32>() + 1, list.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    u64 tot = 0; u32 maxbits = 1;
+    for (u32 i = 0; i < cnt; ++i) { starts[i] = (u32)tot; tot += list[3 * i + 1]; maxbits = std::max(maxbits, list[3 * i + 2]); }
+    if (tot >= 0xFFFF0000ull || maxbits > RS_OVS_SHIFT) { ctx->h_back[3] = 1; return DSKGPU_OK; }
+    if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] row sort: %u sub-bucket(s) above %u rows (%llu rows in all, up to %u bits left) go round again\n", cnt, (u32)RS_BLOCK_ROWS, (unsigned long long)tot, maxbits);
+    DevBuf& g = ctx->rs_g[depth];
+    const size_t n_al = (size_t)((tot + 31) & ~(u64)31);
+    const size_t meta = ((size_t)cnt * 4 * 4 + (size_t)cnt * 8 + 255) & ~size_t(255);      // list (3 words) + starts, then the prefixes
+    CK(g.ensure(2 * n_al * 12 + meta + 256));
+    u64* gk = g.as<u64>(); u64* tk = gk + n_al; u32* gv = reinterpret_cast<u32*>(tk + n_al); u32* tv = gv + n_al;
+    u32* d_list = tv + n_al; u32* d_starts = d_list + 3 * (size_t)cnt;
+    u64* d_prefix = reinterpret_cast<u64*>(reinterpret_cast<char*>(d_list) + (((size_t)cnt * 16 + 7) & ~size_t(7)));
+    CK(hipMemcpyAsync(d_list, list.data(), list.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemcpyAsync(d_starts, starts.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned gridr = (unsigned)std::min<u64>(cnt, (u64)ctx->num_cu * 8);
+    hipLaunchKernelGGL(k_ovs_gather, dim3(gridr), dim3(256), 0, ctx->stream, (const u64*)res_k, (const u32*)res_v, (const u32*)d_list, (const u32*)d_starts, cnt, gk, gv, d_prefix, maxbits);
+    CKL("k_ovs_gather");
+    CK(hipStreamSynchronize(ctx->stream));          // (list / starts were read from host vectors)
+    CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream));
+    int idbits = 1; while ((1u << idbits) < cnt) ++idbits;
+    { const int rc = msd_sort_pairs(ctx, gk, gv, tk, tv, tot, (int)maxbits + idbits, false, 0u); if (rc) return rc; }
+    ctx->h_ovs.assign(1, 0);
+    CK(hipMemcpyAsync(ctx->h_ovs.data(), ctx->rs_ovs.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(&ctx->h_back[3], sc + SC_SORTFLAG, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (!ctx->h_back[3] && ctx->h_ovs[0]) { const int rc = sort_oversize_round(ctx, gk, gv, depth + 1); if (rc) return rc; }
+    if (ctx->h_back[3]) return DSKGPU_OK;
+    hipLaunchKernelGGL(k_ovs_scatter, dim3(gridr), dim3(256), 0, ctx->stream, res_k, res_v, (const u32*)d_list, (const u32*)d_starts, cnt, (const u64*)gk, (const u32*)gv, (const u64*)d_prefix, maxbits);
+    CKL("k_ovs_scatter");
+    return DSKGPU_OK;
+}
+int sort_oversize(dskgpu_ctx* ctx) { return sort_oversize_round(ctx, ctx->rs_res_k, ctx->rs_res_v, 0); }
+
+// Row sets above RS_MAX_ROWS (one-word rows; the 3 * 10^9 solid k-mers of a 30x human run, the 6 * 10^8 of 200 M reads): step A of
+// the MSD sort ONCE over all rows -- 1024 buckets on the top 10 value bits, exact offsets (rows < 2^32) -- then the rows that
+// share their top `sb` bits (sb = the fewest bits for which every such group holds <= RS_MAX_ROWS rows: 3-5 for those inputs)
+// are ordered group by group with the MSD sort on the remaining bits.  No library kernel; what the MSD kernels do not order
+// themselves raises the same flag as for small row sets (full-width fallback in run_pipeline).  Scratch for the second copy of
+// the rows: the level-0 buffer of a multi-pass count when it is large enough (its key arrays are dead by now), else srt_* --
+// after giving back the partition buffers when HBM is short (the next count allocates them again).
+// In: rows in out_w[0] / out_ab.  Out: ctx->res_* (the scratch copy), ctx->fb_*: where the fallback finds a permutation of the rows.
+int sort_rows_big(dskgpu_ctx* ctx, u64 n) {
+    u64* k = ctx->out_w[0].as<u64>(); u32* v = ctx->out_ab.as<u32>();
+    const size_t n_al = (size_t)((n + 31) & ~(u64)31), need = n_al * 12 + 256;
+    u64* tk; u32* tv;
+    if (ctx->l0buf.cap >= need) { tk = ctx->l0buf.as<u64>(); tv = reinterpret_cast<u32*>(tk + n_al); }
+    else {
+        size_t free_b = 0, total_b = 0;
+        CK(hipMemGetInfo(&free_b, &total_b));
+        if (ctx->srt_w[0].cap + ctx->srt_ab.cap + free_b < need + ((size_t)2 << 30)) { ctx->l0buf.release(); ctx->bufA.release(); ctx->bufB.release(); }
+        CK(ctx->srt_w[0].ensure(n * 8)); CK(ctx->srt_ab.ensure(n * 4));
+        tk = ctx->srt_w[0].as<u64>(); tv = ctx->srt_ab.as<u32>();
+    }
+    const int total = (int)std::min(64u, 2u * ctx->cfg.kmer_size);
+    const int bA = std::min(10, total);
+    RsSpec sp{total - bA, 0, 0, (1u << bA) - 1u, 0u, 0u};
+    const u64 ncu = (u64)ctx->num_cu;
+    u64 nch = (n + 65535) / 65536;
+    nch = (nch + ncu - 1) / ncu * ncu;
+    const u64 chunk = (n + nch - 1) / nch;
+    nch = (n + chunk - 1) / chunk;
+    const u64 M = (u64)RS_ABINS * nch;
+    if (M >= 0xFFFFFFF0ull) return fail(ctx, DSKGPU_E_ARG, "row sort: too many rows");
+    CK(ctx->mat2.ensure((M + 2) * 4));
+    u32* matrix = ctx->mat2.as<u32>();
+    u32* sc = ctx->scalars.as<u32>();
+    ctx->h_rs[0] = (u32)M; ctx->h_rs[1] = 0; ctx->h_rs[2] = 0; ctx->h_rs[3] = 0;
+    CK(hipMemcpyAsync(sc + SC_RSLEN, ctx->h_rs, 16, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream));
+    CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
+    CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream));
+    ctx->h_ovs.assign(1, 0);
+    ctx->rs_res_k = tk; ctx->rs_res_v = tv; ctx->rs_tmp_k = k; ctx->rs_tmp_v = v;
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_scatter)); if (e) return e; }
+    hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)nch), dim3(RS_NT), 0, ctx->stream, k, n, (u32)chunk, (u32)nch, matrix, sp);
+    CKL("k_rs_hist");
+    { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
+    const size_t ldsA = RsLds<RS_ABINS, RS_TILE>::bytes;
+    hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, k, v, n, (u32)chunk, (u32)nch, matrix, tk, tv, sp);
+    CKL("k_rs_scatter");
+    // bucket starts -> host (entry b * nch of the scanned matrix; the scan leaves the total behind the last entry)
+    std::vector<u32> start(RS_ABINS + 1);
+    CK(hipMemcpy2DAsync(start.data(), 4, matrix, nch * 4, 4, RS_ABINS + 1, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    start[RS_ABINS] = (u32)n;
+    const u64 rs_max = ctx->tune.rs_max_rows ? std::min<u64>(ctx->tune.rs_max_rows, RS_MAX_ROWS) : RS_MAX_ROWS;
+    int sb = -1;
+    for (int bits = 0; bits <= bA && sb < 0; ++bits) {
+        const u32 per = (1u << bA) >> bits;               // 10-bit buckets per group
+        bool ok = true;
+        for (u32 g0 = 0; g0 < (1u << bA) && ok; g0 += per) ok = (u64)start[g0 + per] - start[g0] <= rs_max;
+        if (ok) sb = bits;
+    }
+    ctx->fb_src_k = tk; ctx->fb_src_v = tv; ctx->fb_dst_k = k; ctx->fb_dst_v = v;
+    ctx->res_w[0] = tk; ctx->res_ab = tv; ctx->sort_partial = true;
+    if (sb < 0) {                                          // one 10-bit bucket alone exceeds the MSD sort: not a k-mer spectrum -> full-width fallback
+        ctx->h_back[3] = 1;
+        return DSKGPU_OK;
+    }
+    const u32 per = (1u << bA) >> sb;
+    bool first = true;
+    for (u32 g0 = 0; g0 < (1u << bA); g0 += per) {
+        const u64 b = start[g0], e = start[g0 + per];
+        if (e - b < 2 || total - sb < 1) continue;
+        const int rc = msd_sort_pairs(ctx, tk + b, tv + b, k + b, v + b, e - b, total - sb, false, (u32)b);      // (in place in tk / tv; k / v = its scratch)
+        if (rc) return rc;
+        first = false;
+    }
+    (void)first;
+    CK(hipMemcpyAsync(&ctx->h_back[3], sc + SC_SORTFLAG, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(ctx->h_ovs.data(), ctx->rs_ovs.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] row sort: %llu rows in %u groups on their top %d bits, MSD sort per group\n", (unsigned long long)n, 1u << sb, sb);
     return DSKGPU_OK;
 }
 
@@ -662,9 +811,13 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     for (int x = 0; x < 4; ++x) ctx->res_w[x] = x < W ? ctx->out_w[x].as<u64>() : nullptr;
     ctx->res_ab = ctx->out_ab.as<u32>();
     ctx->sort_partial = false;
+    ctx->h_ovs.assign(1, 0);
     if (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT)) return DSKGPU_OK;
+    const u64 rs_max = ctx->tune.rs_max_rows ? std::min<u64>(ctx->tune.rs_max_rows, RS_MAX_ROWS) : RS_MAX_ROWS;
+    if (W == 1 && !ctx->tune.fullsort && !ctx->tune.lib_rowsort && n > rs_max && n < 0xFFFF0000ull) return sort_rows_big(ctx, n);
     CK(ctx->srt_w[0].ensure(n * 8));
     CK(ctx->srt_ab.ensure(n * 4));
+    ctx->fb_src_k = ctx->srt_w[0].as<u64>(); ctx->fb_src_v = ctx->srt_ab.as<u32>(); ctx->fb_dst_k = ctx->out_w[0].as<u64>(); ctx->fb_dst_v = ctx->out_ab.as<u32>();
     size_t tmp = 0;
     // hand-written MSD sort while its 10 + (8..10) + 8 bit digits leave sub-buckets a wave can order (mean <= ~380 rows); larger
     // row sets keep the library sort
@@ -742,6 +895,7 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
         else hipLaunchKernelGGL(k_fix_runs_multi<4>, dim3(gfix), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), skey, n, run_shift, flag, ties);
         CKL("sort_rows");
         CK(hipMemcpyAsync(&ctx->h_back[3], flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (msd) CK(hipMemcpyAsync(ctx->h_ovs.data(), ctx->rs_ovs.p, 4, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sort_partial = true;
         for (int x = 0; x < W; ++x) ctx->res_w[x] = ctx->srt_w[x].as<u64>();
         ctx->res_ab = ctx->srt_ab.as<u32>();
@@ -950,11 +1104,16 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             opt_cap = OPT_GROUPS * (8u / W);                                                    // 545 groups of 64 B whatever the key width
         if (opt_cap && ctx->tune.opt_cap) opt_cap = ctx->tune.opt_cap;                       // experiments / tests
         if (W > 1 && (u64)pl.F * opt_cap >= 0xFFFF0000ull) opt_cap = 0;                       // k_count<W> keeps 32-bit offsets
-        // extension regions behind the home regions (region chains, kernels.h): an eighth of the home regions + 4096, one-word keys
-        // only (the index tables of k_count_mw address one contiguous key range); their offsets inside the pool stay below 2^31
+        // extension regions behind the home regions (region chains, kernels.h): an eighth of the home regions + 4096; their offsets
+        // inside the pool stay below 2^31.  Two-word keys (k_count_mw / k_count_chained_mw index keys with 32 bits): home regions
+        // and pool together below 2^32 keys.  Four-word keys: none (tiles of 4096 keys: the scan over the bins dominates anyway).
         u32 max_ext = 0;
-        if (opt_cap && W == 1) max_ext = (u32)std::min<u64>((u64)pl.F / 8 + 4096, 0x7FFFFFFFull / opt_cap - 1);
-        if (opt_cap && ctx->tune.max_ext >= 0) max_ext = W == 1 ? (u32)ctx->tune.max_ext : 0u;        // tests
+        if (opt_cap && W <= 2) {
+            u64 want = std::min<u64>((u64)pl.F / 8 + 4096, 0x7FFFFFFFull / opt_cap - 1);
+            if (ctx->tune.max_ext >= 0) want = (u64)ctx->tune.max_ext;                                 // tests
+            if (W > 1) { const u64 room = 0xFFFF0000ull / opt_cap; want = room > (u64)pl.F + 1 ? std::min<u64>(want, room - pl.F - 1) : 0; }
+            max_ext = (u32)want;
+        }
         const u64 nregions = (u64)pl.F + max_ext;
         if (!opt_cap) { CK(ctx->bufA.ensure((cap + 1) * sizeof(Key))); CK(ctx->bufB.ensure((cap + 1) * sizeof(Key))); }      // exact offsets: the keys of the pass, twice
         if (opt_cap) {
@@ -966,7 +1125,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         }
         bool opt1 = opt_cap && !ctx->opt1_off && !ctx->tune.no_opt1 && (npass == 1 || from_reads);   // several passes: reads only (MODE 3)
         if (from_rec && (!opt1 || W > 2 || ctx->tune.no_recsrc)) { int e = records_to_keys(); if (e) return e; }
-        Opt1Spec o1{nullptr, 0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2, nullptr, nullptr, 0u, {0ull, 0ull, 0ull, 0ull}, 0u};
+        Opt1Spec o1{nullptr, 0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2, nullptr, nullptr, 0u, nullptr, 0ull, 0u};
         unsigned grid1 = 0;
         u32 nheavy = 0;                  // k-mers the level-2 scatter counts apart (find_heavy)
         // (the per-bin slice ends need 4 more bytes of LDS per bin: plans above 1634 level-1 bins keep UNIFORM slices, mean-sized, no sample)
@@ -998,8 +1157,40 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             std::vector<double>& spread = ctx->h_spread;
             spread.assign(pl.P1, 0.0);
             bool sampled = false;
-            if (!from_rec && !ctx->tune.no_sample && !uniform1) {
-                const u64 units = from_reads ? nwords : nkeys_in, tile = from_reads ? Tile<W>::WORDS : Tile<W>::KEYS;
+            // records (the multi-GPU receive side, the passes of a record-based multi-pass count): a positional sample of the records is
+            // expanded into a key array with pads (k_sk_sample_keys: 16 slots per candidate record) and sampled like any key array.
+            // Records that arrive in slices: the sample comes from the first slice (the slices are positional cuts of every sender's
+            // reads: alike), so only that slice has to have arrived.
+            const Key* d_keys_s = d_keys_in;             // the key array the sample kernels read
+            double smp_density = 1.0;                    // records: real keys per slot of the sample array (a level-1 tile is full, a sample tile is not)
+            bool rec_sample_ok = true;
+            u64 rec_units = 0;
+            if constexpr (W <= 2) {
+              if (from_rec && !ctx->tune.no_sample && !uniform1) {
+                const u64 nrec_s = ctx->rec_slice_end.size() > 1 ? ctx->rec_slice_end[0] : ctx->rec_n;
+                const u64 NR = RecTile<W>::NR;
+                const u64 nchk_all = (nrec_s + NR - 1) / NR;
+                const u64 nchk = std::min<u64>(nchk_all, 256);
+                if (nchk == 0) rec_sample_ok = false;
+                else {
+                    { const int e = rec_gate_upto(ctx, 1); if (e) return e; }
+                    std::vector<u64> cbeg(nchk);
+                    for (u64 i = 0; i < nchk; ++i) cbeg[i] = (i * nchk_all / nchk) * NR;
+                    rec_units = nchk * NR * 16;
+                    CK(ctx->smp_keys.ensure(rec_units * sizeof(Key) + nchk * 8 + 64));
+                    u64* d_cbeg = reinterpret_cast<u64*>(ctx->smp_keys.as<char>() + rec_units * sizeof(Key));
+                    CK(hipMemcpyAsync(d_cbeg, cbeg.data(), nchk * 8, hipMemcpyHostToDevice, ctx->stream));
+                    hipLaunchKernelGGL(k_sk_sample_keys<W>, dim3((unsigned)nchk), dim3(SKX_NT), 0, ctx->stream, ctx->rec_src, ctx->rec_n, ctx->sk_sp.R, (int)ctx->cfg.kmer_size,
+                                       (const u64*)d_cbeg, (u32)NR, ctx->smp_keys.as<Key>());
+                    CKL("k_sk_sample_keys");
+                    CK(hipStreamSynchronize(ctx->stream));      // (cbeg is a local)
+                    d_keys_s = ctx->smp_keys.as<Key>();
+                }
+              }
+            }
+            const bool smp_rec = from_rec && rec_units != 0;
+            if ((!from_rec || smp_rec) && rec_sample_ok && !ctx->tune.no_sample && !uniform1) {
+                const u64 units = from_reads ? nwords : smp_rec ? rec_units : nkeys_in, tile = from_reads ? Tile<W>::WORDS : Tile<W>::KEYS;
                 const u64 ntiles = std::max<u64>(1, (units + tile - 1) / tile);
                 const u64 nts = std::min<u64>(ntiles, 1024);
                 ctx->h_descs_s.resize(nts);
@@ -1016,7 +1207,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 CK(hipMemcpyAsync(sc + SC_NCH_S, &ctx->h_sc[SC_NCH_S], 4, hipMemcpyHostToDevice, ctx->stream));
                 int e;
                 if (from_reads) e = launch_hist<W, 0>(ctx, nullptr, ctx->smp_descs.as<ChunkDesc>(), sc + SC_NCH_S, nts, ctx->smp_mat.as<u32>(), pl.d1, pl.P1);
-                else e = launch_hist<W, 1>(ctx, d_keys_in, ctx->smp_descs.as<ChunkDesc>(), sc + SC_NCH_S, nts, ctx->smp_mat.as<u32>(), pl.d1, pl.P1);
+                else e = launch_hist<W, 1>(ctx, d_keys_s, ctx->smp_descs.as<ChunkDesc>(), sc + SC_NCH_S, nts, ctx->smp_mat.as<u32>(), pl.d1, pl.P1);
                 if (e) return e;
                 u64* mom = reinterpret_cast<u64*>(ctx->smp_mat.as<u32>() + ((Ms + 2) & ~(u64)1));
                 hipLaunchKernelGGL(k_bin_moments, dim3((pl.P1 + 3) / 4), dim3(256), 0, ctx->stream, (const u32*)ctx->smp_mat.as<u32>(), (u32)nts, pl.P1, mom);
@@ -1032,12 +1223,15 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                     // tiles a block walks (the busiest one), and how far a bin's keys on those tiles may be from share * load:
                     //   the block's own spread: 5 sigma of the sum over its tiles of the per-tile count (variance measured on the sample),
                     //   the estimate's error  : 4 sigma of the sampled sum, scaled to the block's share
-                    const double tiles_per_block = (double)ntiles * share;
+                    // (records: a level-1 tile is full, a tile of the sample array holds smp_density of its slots: the block walks
+                    //  pass_keys * share / KEYS full tiles, each with 1 / density times the variance of a sample tile)
+                    if (smp_rec) smp_density = std::max(0.05, (double)stot / ((double)nts * (double)Tile<W>::KEYS));
+                    const double tiles_per_block = smp_rec ? pass_keys * share / (double)Tile<W>::KEYS : (double)ntiles * share;
                     for (u32 b = 0; b < pl.P1; ++b) {
                         const double sum = (double)ctx->h_mom[2 * b], sq = (double)ctx->h_mom[2 * b + 1];
                         const double mean = sum / (double)nts, var = std::max(mean, sq / (double)nts - mean * mean);      // (at least Poisson)
                         load[b] = sum * scale;
-                        spread[b] = 5.0 * std::sqrt(tiles_per_block * var) + 4.0 * std::sqrt((double)nts * var) * scale * share;
+                        spread[b] = 5.0 * std::sqrt(tiles_per_block * var / smp_density) + 4.0 * std::sqrt((double)nts * var) * scale * share;
                     }
                     ctx->h_seg_work = load;
                     sampled = true;
@@ -1047,7 +1241,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 // and let the level-1 scatter count them apart (k_scatter<.., HEAVY>) -- everything lighter is what the region
                 // chains are for.
                 if constexpr (W == 1) {
-                    if (sampled && opt_cap && !ctx->tune.no_heavy) { const int e2 = find_heavy(ctx, from_reads, d_keys_in, (u32)nts, pl, &nheavy); if (e2) return e2; }
+                    if (sampled && opt_cap && !ctx->tune.no_heavy) { const int e2 = find_heavy(ctx, from_reads, d_keys_s, (u32)nts, pl, &nheavy); if (e2) return e2; }
                 }
                 ctx->mark("sample1");
             }
@@ -1100,7 +1294,22 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         const ChunkDesc* dd1 = ctx->descs1.as<ChunkDesc>();
         if (opt1) {
             if (nheavy) { o1.hv_keys = ctx->hv_buf.as<u64>(); o1.hv_cnt = reinterpret_cast<unsigned long long*>(ctx->hv_buf.as<u64>() + HV_KEYS); }
-            if (nheavy && from_reads) {
+            if (from_rec && ctx->rec_slice_end.size() > 1) {
+                // the records arrive in slices: one launch per slice, each behind the arrival of its slice (rec_gate), the blocks'
+                // write cursors parked in between
+                const size_t S = ctx->rec_slice_end.size();
+                CK(ctx->cur_state.ensure((size_t)grid1 * pl.P1 * 4));
+                o1.cur_state = ctx->cur_state.as<u32>();
+                rc = DSKGPU_OK;
+                for (size_t sl = 0; sl < S && rc == DSKGPU_OK; ++sl) {
+                    if ((rc = rec_gate_upto(ctx, (u32)sl + 1))) break;
+                    o1.g0 = ctx->h_slice_chunk[sl]; o1.gn = ctx->h_slice_chunk[sl + 1] - ctx->h_slice_chunk[sl];
+                    o1.resume = sl > 0 ? 1u : 0u; o1.last = sl + 1 == S ? 1u : 0u;
+                    rc = launch_scatter_rec_h<W>(ctx, nheavy != 0, dd1, sc + SC_NCH1, nch1, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+                }
+            }
+            else if (from_rec) { if (!(rc = rec_gate_all(ctx))) rc = launch_scatter_rec_h<W>(ctx, nheavy != 0, dd1, sc + SC_NCH1, nch1, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1); }
+            else if (nheavy && from_reads) {
                 if constexpr (W == 1) rc = npass > 1 ? launch_scatter_m<1, 0, 3, true, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1)
                                                      : launch_scatter_m<1, 0, 1, true, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
                 else rc = DSKGPU_E_STATE;
@@ -1118,21 +1327,6 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             }
 #endif
             else if (from_reads) rc = launch_scatter_m<W, 0, 1, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
-            else if (from_rec && ctx->rec_slice_end.size() > 1) {
-                // the records arrive in slices: one launch per slice, each behind the arrival of its slice (rec_gate), the blocks'
-                // write cursors parked in between
-                const size_t S = ctx->rec_slice_end.size();
-                CK(ctx->cur_state.ensure((size_t)grid1 * pl.P1 * 4));
-                o1.cur_state = ctx->cur_state.as<u32>();
-                rc = DSKGPU_OK;
-                for (size_t sl = 0; sl < S && rc == DSKGPU_OK; ++sl) {
-                    if ((rc = rec_gate_upto(ctx, (u32)sl + 1))) break;
-                    o1.g0 = ctx->h_slice_chunk[sl]; o1.gn = ctx->h_slice_chunk[sl + 1] - ctx->h_slice_chunk[sl];
-                    o1.resume = sl > 0 ? 1u : 0u; o1.last = sl + 1 == S ? 1u : 0u;
-                    rc = launch_scatter_rec<W>(ctx, dd1, sc + SC_NCH1, nch1, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
-                }
-            }
-            else if (from_rec) { if (!(rc = rec_gate_all(ctx))) rc = launch_scatter_rec<W>(ctx, dd1, sc + SC_NCH1, nch1, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1); }
             else rc = launch_scatter_m<W, 1, 1, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
             if (rc) return rc;
             ctx->mark("scatter1");
@@ -1255,6 +1449,14 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         u32* solid_ab = W == 1 ? scratch->as<u32>() : ctx->abund2.as<u32>();
         launch_count<W>(ctx, cgrid, fkeys, solid_keys, solid_ab, sc + SC_OVERFLOW, cp);
         CKL("k_count");
+        if constexpr (W == 2) {
+            if (opt_cap && max_ext) {
+                hipLaunchKernelGGL(k_count_chained_mw<2>, dim3((unsigned)std::min<u64>(max_ext, (u64)ctx->num_cu * 2)), dim3(CNT_NT), 0, ctx->stream, (const Key*)fkeys, solid_keys, solid_ab,
+                                   ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), sc + SC_OVERFLOW, cp, (const u32*)cp.subcnt,
+                                   (const u32*)ctx->chain_next.as<u32>(), (const u32*)(ctx->chain_next.as<u32>() + nregions + 1), (const u32*)(sc + SC_NCHAINED), max_ext);
+                CKL("k_count_chained_mw");
+            }
+        }
         if constexpr (W == 1) {
             if (opt_cap && max_ext) {      // the sub-partitions that went on in extension regions (none on repeat-free reads: the blocks leave at once)
                 hipLaunchKernelGGL(k_count_chained, dim3((unsigned)std::min<u64>(max_ext, (u64)ctx->num_cu * 2)), dim3(CNT_NT), 0, ctx->stream, fkeys, solid_keys, solid_ab,
@@ -1326,56 +1528,120 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
 
 // "Level 0" of a multi-pass count from reads (one-word keys): ONE sweep over the encoded reads writes the mixed keys of passes
 // [lo, lo + G) of npass into ctx->l0buf, grouped by pass -- the histogram-free scatter with the pass as its digit (MODE 4): every
-// (block, pass) pair owns a slice of `slice` keys inside the pass's region, the unused tails are padded with the sentinel, so a
-// region is one key array.  The passes of the group then run from those arrays (run_one_pass with a key source) instead of
-// re-generating every k-mer once per pass -- the in-HBM counterpart of DSK writing every k-mer to its partition file ONCE
-// (doc/paper.tex:65-67; README.md:126-130 asks for few passes because each one re-reads the input).
-// -> *region_keys: keys (pads included) of a pass's array; obase[i]: its offset in l0buf.  DSKGPU_OK with *G_out = 0: no room.
-int level0_materialise(dskgpu_ctx* ctx, u64 nwords, u32 lo, u32 npass, u32* G_out, u64* region_keys, u64 (&obase)[L0_MAX_PASSES]) {
+// (block, pass) pair owns a slice inside the pass's region, the unused tails are padded with the sentinel, so a region is one key
+// array.  The passes of the group then run from those arrays (run_one_pass with a key source) instead of re-generating every k-mer
+// once per pass -- the in-HBM counterpart of DSK writing every k-mer to its partition file ONCE (doc/paper.tex:65-67;
+// README.md:126-130 asks for few passes because each one re-reads the input: a sweep here is what a pass is there).
+// G = as many passes as the free HBM holds next to what a pass itself needs and `reserve_bytes` (rows still to come), at most
+// L0_MAX_PASSES.  The slices of pass i are sized from ITS sampled load and its measured spread (a positional sample of <= 1024
+// tiles, as at level 1): the pass that holds a k-mer with 10^8 occurrences (poly-A reads of a 30x human run) gets longer slices
+// instead of sending its whole group back to the reads.
+// -> region_keys[i]: keys (pads included) of pass lo + i's array; obase[i]: its offset in l0buf.  DSKGPU_OK with *G_out = 0: no room.
+int level0_materialise(dskgpu_ctx* ctx, u64 nwords, u32 lo, u32 npass, u64 reserve_bytes, u32* G_out, u64 (&region_keys)[L0_MAX_PASSES], u64 (&obase)[L0_MAX_PASSES]) {
     *G_out = 0;
     const u64 nper = ctx->h_nvalid / npass + 1;
     u32 nch1 = 0;
     build_descs1(ctx, nwords, Tile<1>::WORDS, (u64)ctx->num_cu * 8, &nch1);
-    const unsigned grid = scatter_grid(ctx, 1, L0_MAX_PASSES, nch1, true);
+    // (k_level0 keeps nothing but its cursors in LDS: two blocks per CU, 32 waves, hide each other's atomics and stores)
+    const unsigned grid = ctx->tune.l0_staged ? scatter_grid(ctx, 1, L0_MAX_PASSES, nch1, true) : (unsigned)std::max<u64>(1, std::min<u64>(nch1, (u64)ctx->num_cu));
     const u64 cpb = (nch1 + grid - 1) / grid;
-    u64 slice = (u64)((double)nper * (double)cpb / (double)nch1 * 1.02) + 4096;      // hash-uniform passes: 2 % + 4096 over the busiest block's share
-    slice = (slice + 7) & ~7ull;
+    const double share = (double)cpb / (double)nch1;                                // the busiest block's share of the chunks
     const u64 tail = 2 * Tile<1>::KEYS;
-    const u64 region = slice * grid + tail;                                         // keys; + the dump zone
-    if (region >= 0xFFFF0000ull) return DSKGPU_OK;
+    const u64 uslice = (((u64)((double)nper * share * 1.02) + 4096) + 7) & ~7ull;   // hash-uniform passes: 2 % + 4096 over the busiest block's share
+    const u64 uregion = uslice * grid + tail;                                       // keys; + the dump zone
+    if (uregion >= 0xFFFF0000ull) return DSKGPU_OK;
     // how many passes fit beside what a pass itself needs (slices, regions + pool, rows): about 30 bytes per key of a pass
     size_t free_b = 0, total_b = 0;
     CK(hipMemGetInfo(&free_b, &total_b));
     const u64 have = ctx->bufA.cap + ctx->bufB.cap + ctx->l0buf.cap;
-    const u64 need = nper * 30ull + (4ull << 30);
+    const u64 need = nper * 30ull + (4ull << 30) + reserve_bytes;
     const u64 room = free_b + have > need ? free_b + have - need : 0;
-    u32 G = (u32)std::min<u64>(std::min<u64>(L0_MAX_PASSES, npass - lo), room / (region * 8));
+    u32 G = (u32)std::min<u64>(std::min<u64>(L0_MAX_PASSES, npass - lo), room / (uregion * 8));
     if (ctx->tune.l0_passes) G = std::min<u32>(std::min<u32>(ctx->tune.l0_passes, L0_MAX_PASSES), npass - lo);      // tests
     if (G < 2 && !(ctx->tune.l0_passes)) return DSKGPU_OK;                          // one pass at a time gains nothing over reading the reads
     if (G == 0) return DSKGPU_OK;
-    CK(ctx->l0buf.ensure(region * G * 8 + 64));
     CK(ctx->descs1.ensure(ctx->h_descs1.size() * sizeof(ChunkDesc)));
     CK(hipMemcpyAsync(ctx->descs1.p, ctx->h_descs1.data(), ctx->h_descs1.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
     u32* sc = ctx->scalars.as<u32>();
+    DigitSpec ds{4u, G, 0u, ctx->cfg.world_size, npass, lo};
+    // ---- the passes' loads in this sweep, sampled
+    std::vector<u64> slice(G, uslice);
+    if (!ctx->tune.no_sample) {
+        const u64 ntiles = std::max<u64>(1, (nwords + Tile<1>::WORDS - 1) / Tile<1>::WORDS);
+        const u64 nts = std::min<u64>(ntiles, 1024);
+        ctx->h_descs_s.resize(nts);
+        for (u64 i = 0; i < nts; ++i) {
+            const u64 t = i * ntiles / nts;
+            ChunkDesc d; d.begin = t * Tile<1>::WORDS; d.end = std::min<u64>(nwords, (t + 1) * Tile<1>::WORDS); d.flat_base = (u32)i; d.stride = (u32)nts;
+            ctx->h_descs_s[i] = d;
+        }
+        const u64 Ms = (u64)G * nts;
+        CK(ctx->smp_descs.ensure(nts * sizeof(ChunkDesc)));
+        CK(ctx->smp_mat.ensure((Ms + 4) * 4 + (size_t)G * 16));
+        CK(hipMemcpyAsync(ctx->smp_descs.p, ctx->h_descs_s.data(), nts * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
+        ctx->h_sc[SC_NCH_S] = (u32)nts;
+        CK(hipMemcpyAsync(sc + SC_NCH_S, &ctx->h_sc[SC_NCH_S], 4, hipMemcpyHostToDevice, ctx->stream));
+        { const int e = launch_hist_m<1, 0, 4>(ctx, nullptr, ctx->smp_descs.as<ChunkDesc>(), sc + SC_NCH_S, nts, ctx->smp_mat.as<u32>(), ds, G); if (e) return e; }
+        u64* mom = reinterpret_cast<u64*>(ctx->smp_mat.as<u32>() + ((Ms + 2) & ~(u64)1));
+        hipLaunchKernelGGL(k_bin_moments, dim3((G + 3) / 4), dim3(256), 0, ctx->stream, (const u32*)ctx->smp_mat.as<u32>(), (u32)nts, G, mom);
+        CKL("k_bin_moments");
+        ctx->h_mom.resize((size_t)G * 2);
+        CK(hipMemcpyAsync(ctx->h_mom.data(), mom, (size_t)G * 16, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        u64 stot = 0;
+        for (u32 b = 0; b < G; ++b) stot += ctx->h_mom[2 * b];
+        if (stot >= (u64)G * 4096) {
+            const double scale = (double)ntiles / (double)nts, tiles_per_block = (double)ntiles * share;
+            for (u32 b = 0; b < G; ++b) {
+                const double sum = (double)ctx->h_mom[2 * b], sq = (double)ctx->h_mom[2 * b + 1];
+                const double mean = sum / (double)nts, var = std::max(mean, sq / (double)nts - mean * mean);
+                const double sl = sum * scale * share * 1.01 + 5.0 * std::sqrt(tiles_per_block * var) + 4.0 * std::sqrt((double)nts * var) * scale * share + 64.0;
+                slice[b] = ((u64)sl + 8) & ~7ull;
+            }
+        }
+        ctx->mark("sample0");
+    }
+    // regions, largest G whose regions fit the room
+    for (;;) {
+        u64 tot = 0; bool ok = true;
+        for (u32 b = 0; b < G; ++b) { const u64 region = slice[b] * grid + tail; if (region >= 0xFFFF0000ull) ok = false; obase[b] = tot; region_keys[b] = slice[b] * grid; tot += region; }
+        if (ok && (tot * 8 <= room || ctx->tune.l0_passes)) { CK(ctx->l0buf.ensure(tot * 8 + 64)); break; }
+        if (--G < 2) return DSKGPU_OK;
+    }
+    ds.pa = G;
     ctx->h_sc[SC_NCH1] = nch1; ctx->h_sc[SC_OVF1] = 0;
     CK(hipMemcpyAsync(sc + SC_NCH1, &ctx->h_sc[SC_NCH1], 4, hipMemcpyHostToDevice, ctx->stream));
     CK(hipMemsetAsync(sc + SC_OVF1, 0, 4, ctx->stream));
-    ctx->h_boff.assign(L0_MAX_PASSES + 1, 0);
-    CK(ctx->boff.ensure((L0_MAX_PASSES + 1) * 4));
-    CK(hipMemsetAsync(ctx->boff.p, 0, (L0_MAX_PASSES + 1) * 4, ctx->stream));
-    CK(ctx->mat1.ensure(((size_t)L0_MAX_PASSES * grid + 1) * 4));
-    CK(hipMemsetAsync(ctx->gstats.as<u64>() + 2, 0, 8, ctx->stream));
-    Opt1Spec o1{ctx->boff.as<u32>(), (u32)slice, (u32)(slice * grid), sc + SC_OVF1, ctx->mat1.as<u32>(), 0u, ctx->gstats.as<u64>() + 2, nullptr, nullptr, (u32)slice, {0ull, 0ull, 0ull, 0ull}, 0u};
-    for (u32 i = 0; i < L0_MAX_PASSES; ++i) { obase[i] = (u64)std::min(i, G - 1) * region; o1.obase[i] = obase[i]; }
-    const DigitSpec ds{4u, G, 0u, ctx->cfg.world_size, npass, lo};
-    const int rc = launch_scatter_m<1, 0, 4, true>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, nullptr, ctx->l0buf.as<u64>(), ds, G, o1);
-    if (rc) return rc;
+    // device arrays of the sweep: [slice length per bin: u32 x (L0_MAX_PASSES + 1)] [region base per bin: u64 x L0_MAX_PASSES]
+    ctx->h_boff.assign(L0_MAX_PASSES + 1 + 3 + 2 * L0_MAX_PASSES, 0);
+    u64 hob[L0_MAX_PASSES];
+    for (u32 i = 0; i < L0_MAX_PASSES; ++i) { ctx->h_boff[i] = (u32)slice[std::min(i, G - 1)]; hob[i] = obase[std::min(i, G - 1)]; }
+    std::memcpy(&ctx->h_boff[L0_MAX_PASSES + 4], hob, sizeof hob);          // (at byte 80: 8-byte aligned)
+    CK(ctx->boff.ensure(ctx->h_boff.size() * 4));
+    CK(hipMemcpyAsync(ctx->boff.p, ctx->h_boff.data(), ctx->h_boff.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    const u32* d_slen = ctx->boff.as<u32>();
+    const u64* d_obase = reinterpret_cast<const u64*>(ctx->boff.as<u32>() + L0_MAX_PASSES + 4);
+    if (ctx->tune.l0_staged) {      // (experiments: the first version -- the histogram-free scatter with the pass as its digit, staged through LDS tiles)
+        CK(ctx->mat1.ensure(((size_t)L0_MAX_PASSES * grid + 1) * 4));
+        CK(hipMemsetAsync(ctx->gstats.as<u64>() + 2, 0, 8, ctx->stream));
+        Opt1Spec o1{d_slen, (u32)slice[0], (u32)(slice[0] * grid), sc + SC_OVF1, ctx->mat1.as<u32>(), 0u, ctx->gstats.as<u64>() + 2, nullptr, nullptr, (u32)slice[0], d_obase, obase[0], 0u};
+        const int rc = launch_scatter_m<1, 0, 4, true>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, nullptr, ctx->l0buf.as<u64>(), ds, G, o1);
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(k_level0, dim3(grid), dim3(SC_NT), 0, ctx->stream, (const u64*)ctx->packed.as<u64>(), (const u32*)ctx->inval.as<u32>(), (const ChunkDesc*)ctx->descs1.as<ChunkDesc>(),
+                           (const u32*)(sc + SC_NCH1), ctx->l0buf.as<u64>(), (int)ctx->cfg.kmer_size, ds, G, d_slen, d_obase, sc + SC_OVF1);
+        CKL("k_level0");
+    }
     ctx->mark("level0");
     CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
-    if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] level 0: passes %u..%u of %u materialised, %.2f GB each%s\n", lo, lo + G - 1, npass, (double)region * 8e-9, ctx->h_ovf1 ? " -- a slice overflowed: these passes read the reads" : "");
-    if (ctx->h_ovf1) return DSKGPU_OK;                                             // (a skewed key space: the passes of this group re-generate their keys)
-    *G_out = G; *region_keys = slice * grid;
+    if (ctx->tune.verbose) {
+        u64 tot = 0; for (u32 b = 0; b < G; ++b) tot += region_keys[b];
+        fprintf(stderr, "[dskgpu] level 0: passes %u..%u of %u materialised, %.2f GB in all (%.2f GB free before)%s\n", lo, lo + G - 1, npass, (double)tot * 8e-9, (double)free_b * 1e-9,
+                ctx->h_ovf1 ? " -- a slice overflowed: these passes read the reads" : "");
+    }
+    if (ctx->h_ovf1) return DSKGPU_OK;                                             // (a skewed key space beyond the sampled spread: the passes of this group re-generate their keys)
+    *G_out = G;
     return DSKGPU_OK;
 }
 
@@ -1418,7 +1684,14 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
     // what 7 hold (200 M x 150 bp on one GPU: every pass re-generates all k-mers).  A pass that turns out too big (a skewed
     // key space) doubles the count.
     const u64 n_keys = (from_reads && ctx->have_nvalid) ? std::max<u64>(1, ctx->h_nvalid) : n_upper;
-    u32 npass = (u32)std::max<u64>(1, (n_keys + max_keys - 1) / max_keys);
+    // An input that needs several passes anyway (one-word keys from reads) takes SMALL ones -- 10^9 keys, the size of the bench
+    // workload: a level-0 sweep then materialises up to 16 of them (what the free HBM holds: a pass of 10^9 keys works in 22 GB,
+    // one of 3.5 * 10^9 in 75 GB, which left room for one or two key arrays beside it on a 90 Gbp input), and level 1 of a pass
+    // has 512 bins instead of 1536 (its cost per key grows with the bin count: 3.8 against 5.9 ps).
+    u64 pass_keys = max_keys;
+    if (W == 1 && from_reads && ctx->have_nvalid && n_keys > max_keys && !ctx->max_keys_per_pass && !ctx->tune.no_level0)
+        pass_keys = ctx->tune.mp_pass_mkeys ? (u64)ctx->tune.mp_pass_mkeys * 1000000ull : 1000000000ull;
+    u32 npass = (u32)std::max<u64>(1, (n_keys + pass_keys - 1) / pass_keys);
     u64 cap_floor = 0;       // keys the largest pass seen so far really holds (a k-mer with millions of occurrences sits in ONE pass whatever their number)
     for (;;) {
         if (npass > 4096) return fail(ctx, DSKGPU_E_OVERFLOW, "too many passes (one k-mer alone exceeds a pass)");
@@ -1433,21 +1706,29 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         u64 tot_rows = 0, tot_kmers = 0, tot_distinct = 0;
         Plan pl{};
         bool too_big = false;
-        u32 l0_lo = 0, l0_n = 0; u64 l0_keys = 0; u64 l0_base[L0_MAX_PASSES] = {0, 0, 0, 0};       // passes materialised by the last level-0 sweep
+        u32 l0_lo = 0, l0_n = 0; u64 l0_keys[L0_MAX_PASSES] = {0}; u64 l0_base[L0_MAX_PASSES] = {0};       // passes materialised by the last level-0 sweep
         bool l0_try = W == 1 && from_reads && npass > 1 && ctx->have_nvalid && !ctx->tune.no_level0;
+        u64 sweeps = 0;          // times the encoded reads were walked to generate k-mers (DSK's notion of a pass: README.md:126-130)
+        bool rows_sized = false; // the row accumulators are sized for all passes (known after the first one)
         for (u32 p = 0; p < npass; ++p) {
             u64 ns = 0, nk = 0;
             int rc;
+            if (npass > 1) { ctx->opt1_off = false; ctx->opt2_off = false; }      // an overflow is a property of ONE pass (the one that holds a k-mer with 10^8 occurrences): the others keep the fast path
             if (l0_try && p >= l0_lo + l0_n) {       // the next group of passes: one sweep over the reads writes their keys
-                if constexpr (W == 1) { if ((rc = level0_materialise(ctx, nwords, p, npass, &l0_n, &l0_keys, l0_base))) return rc; }
+                // (until the first pass has told how many rows a pass leaves, room is kept for one solid row per sixteen k-mers -- what
+                //  20x coverage leaves; should the rows need more, the group's remaining key arrays give way: below)
+                const u64 reserve = rows_sized ? 0 : n_keys / 16 * 12;
+                if constexpr (W == 1) { if ((rc = level0_materialise(ctx, nwords, p, npass, reserve, &l0_n, l0_keys, l0_base))) return rc; }
                 l0_lo = p;
                 if (l0_n == 0) l0_try = false;       // no room (or a skewed key space): every pass reads the reads
+                else ++sweeps;
             }
             if (l0_try && p < l0_lo + l0_n) {
                 const u64 nvalid = ctx->h_nvalid;    // (a pass from a key array sizes itself from its own key count)
-                rc = run_one_pass<W>(ctx, false, reinterpret_cast<const Key*>(ctx->l0buf.as<u64>() + l0_base[p - l0_lo]), l0_keys, 0, 0u, 1u, l0_keys, &ns, &nk, &pl);
+                const u64 nk_in = l0_keys[p - l0_lo];
+                rc = run_one_pass<W>(ctx, false, reinterpret_cast<const Key*>(ctx->l0buf.as<u64>() + l0_base[p - l0_lo]), nk_in, 0, 0u, 1u, nk_in, &ns, &nk, &pl);
                 ctx->h_nvalid = nvalid;
-            } else rc = run_one_pass<W>(ctx, from_reads, d_keys_in, nkeys_in, nwords, p, npass, cap, &ns, &nk, &pl);
+            } else { rc = run_one_pass<W>(ctx, from_reads, d_keys_in, nkeys_in, nwords, p, npass, cap, &ns, &nk, &pl); if (from_reads) ++sweeps; }
             if (rc == PASS_TOO_BIG) { too_big = true; break; }
             if (rc) return rc;
             tot_kmers += nk; tot_distinct += ctx->h_stats[0];
@@ -1455,9 +1736,17 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 CK(hipMemcpyAsync(pass_hist.data(), ctx->ghist.p, pass_hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
                 // grow once: the passes hold similar numbers of rows (hash-uniform), so size for all of them after the first
                 const u64 want_rows = std::max<u64>(tot_rows + ns + 1, p == 0 ? (ns + ns / 8 + 1024) * npass : 0);
-                if (ctx->acc_ab.ensure_keep(want_rows * 4, tot_rows * 4, ctx->stream)) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
-                for (int x = 0; x < W; ++x)
-                    if (ctx->acc_w[x].ensure_keep(want_rows * 8, tot_rows * 8, ctx->stream)) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
+                auto grow_rows = [&]() {
+                    bool ok = ctx->acc_ab.ensure_keep(want_rows * 4, tot_rows * 4, ctx->stream) == 0;
+                    for (int x = 0; x < W && ok; ++x) ok = ctx->acc_w[x].ensure_keep(want_rows * 8, tot_rows * 8, ctx->stream) == 0;
+                    return ok;
+                };
+                if (!grow_rows()) {      // the rows need more than was kept for them: the key arrays of the group's remaining passes give way (those passes get a sweep of their own)
+                    (void)hipGetLastError();
+                    if (l0_n && ctx->l0buf.p) { ctx->l0buf.release(); l0_n = p + 1 - l0_lo; }
+                    if (!grow_rows()) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
+                }
+                rows_sized = true;
                 if (ns) {
                     CK(hipMemcpyAsync(ctx->acc_ab.as<u32>() + tot_rows, ctx->out_ab.p, ns * 4, hipMemcpyDeviceToDevice, ctx->stream));
                     for (int x = 0; x < W; ++x)
@@ -1487,18 +1776,19 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         ctx->mark("sort");
         if (npass == 1) CK(hipMemcpyAsync(ctx->hist.data(), ctx->ghist.p, ctx->hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
+        if (W == 1 && ctx->sort_partial && tot_rows && !ctx->h_back[3] && !ctx->h_ovs.empty() && ctx->h_ovs[0]) {
+            if ((rc = sort_oversize(ctx))) return rc;      // sub-buckets the sort listed for another round on their remaining bits
+        } else if (W > 1 && ctx->sort_partial && !ctx->h_ovs.empty() && ctx->h_ovs[0]) ctx->h_back[3] = 1;      // (index pairs of multi-word rows: the full-width order)
         if (W == 1 && ctx->sort_partial && tot_rows && ctx->h_back[3]) {
             // a run of equal 32-bit prefixes was too long for the in-place fix-up: sort full width
             // (srt_* holds a permutation of the rows; sort it back into out_*)
             size_t tmp = 0;
             const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
-            CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->srt_w[0].as<u64>(), ctx->out_w[0].as<u64>(), ctx->srt_ab.as<u32>(),
-                                         ctx->out_ab.as<u32>(), (size_t)tot_rows, 0u, end_bit, ctx->stream));
+            CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->fb_src_k, ctx->fb_dst_k, ctx->fb_src_v, ctx->fb_dst_v, (size_t)tot_rows, 0u, end_bit, ctx->stream));
             CK(ctx->srt_tmp.ensure(tmp));
-            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->srt_w[0].as<u64>(), ctx->out_w[0].as<u64>(), ctx->srt_ab.as<u32>(),
-                                         ctx->out_ab.as<u32>(), (size_t)tot_rows, 0u, end_bit, ctx->stream));
+            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->fb_src_k, ctx->fb_dst_k, ctx->fb_src_v, ctx->fb_dst_v, (size_t)tot_rows, 0u, end_bit, ctx->stream));
             CK(hipStreamSynchronize(ctx->stream));
-            ctx->res_w[0] = ctx->out_w[0].as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>();
+            ctx->res_w[0] = ctx->fb_dst_k; ctx->res_ab = ctx->fb_dst_v;
             ctx->stats.sort_fallback = 1;
         } else if (W > 1 && ctx->sort_partial && tot_rows && ctx->h_back[3]) {
             if ((rc = sort_rows_full_multiword(ctx, tot_rows))) return rc;      // out_w still holds the unsorted rows
@@ -1514,6 +1804,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         ctx->stats.n_levels = (u32)pl.levels;
         ctx->stats.n_final_bins = pl.F;
         ctx->stats.n_passes = npass;
+        ctx->stats.n_read_sweeps = npass > 1 ? sweeps : (from_reads ? 1 : 0);
         if (npass > 1) {      // the names go back: acc_* stays the job-sized buffer (it holds the result now), out_* the pass-sized one --
             std::swap(ctx->out_ab, ctx->acc_ab);      // left swapped, the next count grew the small one to job size again (10 GB of hipMalloc + hipFree per call)
             for (int x = 0; x < W; ++x) std::swap(ctx->out_w[x], ctx->acc_w[x]);
@@ -2008,9 +2299,9 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
                       &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
                       &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->srt_k2, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
                       &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,
-                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent, &ctx->cur_state};
+                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent, &ctx->cur_state, &ctx->rs_ovs, &ctx->smp_keys};
     for (DevBuf* b : bufs) b->release();
-    for (int i = 0; i < 4; ++i) { ctx->out_w[i].release(); ctx->srt_w[i].release(); ctx->acc_w[i].release(); ctx->u_w[i].release(); ctx->s_w[i].release(); }
+    for (int i = 0; i < 4; ++i) { ctx->rs_g[i].release(); ctx->out_w[i].release(); ctx->srt_w[i].release(); ctx->acc_w[i].release(); ctx->u_w[i].release(); ctx->s_w[i].release(); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) { if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]); if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -494,7 +494,7 @@ int dskgpu_group_get_stats(const dskgpu_group* g, dskgpu_stats* out) {
         if (rc != DSKGPU_OK) return rc;
         t.n_bytes += s.n_bytes; t.n_kmers += s.n_kmers; t.n_distinct += s.n_distinct; t.n_solid += s.n_solid;
         t.n_partitions += s.n_partitions; t.n_retries += s.n_retries; t.sort_fallback += s.sort_fallback; t.n_ext_regions += s.n_ext_regions; t.n_heavy += s.n_heavy;
-        t.n_levels = std::max(t.n_levels, s.n_levels); t.n_final_bins += s.n_final_bins; t.n_passes = std::max(t.n_passes, s.n_passes);
+        t.n_levels = std::max(t.n_levels, s.n_levels); t.n_final_bins += s.n_final_bins; t.n_passes = std::max(t.n_passes, s.n_passes); t.n_read_sweeps = std::max(t.n_read_sweeps, s.n_read_sweeps);
     }
     *out = t;
     return DSKGPU_OK;

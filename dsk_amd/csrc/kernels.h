@@ -172,7 +172,12 @@ __device__ __forceinline__ u32 tile_keys_reads(const u64* __restrict__ packed, c
 }
 
 __device__ __forceinline__ bool is_pad_key(u64 h) { return h == DSK_EMPTY; }
-template <int W> __device__ __forceinline__ bool is_pad_key(const KN<W>&) { return false; }
+template <int W> __device__ __forceinline__ bool is_pad_key(const KN<W>& h) {      // (multi-word key arrays with pads: the sampled records of the receive side)
+    bool e = true;
+#pragma unroll
+    for (int x = 0; x < W; ++x) e = e && (h.w[x] == DSK_EMPTY);
+    return e;
+}
 // KEYS: chunk range is in keys; tile t covers keys [begin + t*Tile<W>::KEYS, ...);
 // thread loads keys tid + j*SC_NT (coalesced).
 template <int W>
@@ -521,13 +526,14 @@ __device__ __forceinline__ u32 tile_keys_records(const RecPre<W>& pre, u32 R, u6
 // and put a third of that segment's keys on one rank counter and one sub-partition.  A window that holds such a k-mer simply loses
 // its validity bit (windows without a key are neither ranked nor staged); the compares are VALU work, which this kernel has to spare.
 // A separate instantiation: the plain one keeps its instruction schedule.
-// slice_len != 0 (level 0, MODE 4): BIN-major slices of that length -- bin b owns the region of `out` that starts at key obase[b]
-// (64-bit: a group of passes holds more than 2^32 keys; positions inside a region stay 32-bit), slice (block g, bin b) at g *
-// slice_len in it (area = slice_len, boff[b] = 0), the dump zone behind the last slice -- whose unused tails the block fills
-// with the all-ones sentinel at the end: a bin's region is then ONE key array (with pads that tile_keys_array masks), which
-// the pass reads as its input.
+// slice_len != 0 (level 0, MODE 4): BIN-major slices -- bin b owns the region of `out` that starts at key obase[b] (64-bit: a group
+// of passes holds more than 2^32 keys; positions inside a region stay 32-bit; obase is a device array, copied to LDS), its slices
+// are boff[b] keys long (per bin: sized from the sampled load of the pass, so a pass that holds a k-mer with 10^8 occurrences gets
+// longer slices), slice (block g, bin b) at g * boff[b] in the region, the dump zone behind the last slice of bin 0 -- and the
+// unused tail of every slice is filled with the all-ones sentinel at the end: a bin's region is then ONE key array (with pads
+// that tile_keys_array masks), which the pass reads as its input.
 struct Opt1Spec { const u32* boff; u32 area, dump; u32* ovf; u32* fill; u32 R; u64* nkeys;      // R: words per super-k-mer record (SRC 2)
-                  const u64* hv_keys; unsigned long long* hv_cnt; u32 slice_len; u64 obase[4];      // obase: MODE 4, key offset of every bin's region in `out`
+                  const u64* hv_keys; unsigned long long* hv_cnt; u32 slice_len; const u64* obase; u64 obase0;      // obase: MODE 4, key offset of every bin's region in `out` (device array; obase0 = obase[0])
                   u32 uslice;         // != 0: UNIFORM slices of that many keys (bin b at b * uslice, boff unused) -- no slice-end array in LDS: plans above 1634 bins
                   // records (SRC 2) arriving in slices (a multi-GPU step whose exchange overlaps this kernel): one launch per slice over
                   // the chunks [g0, g0 + gn) (cur_state == nullptr: one launch over all chunks), the blocks' write cursors parked in cur_state[block * P + bin] in between;
@@ -537,7 +543,7 @@ struct Opt1Spec { const u32* boff; u32 area, dump; u32* ovf; u32* fill; u32 R; u
                   u32 abl;            // timing experiments (tools/l1_ablate.sh): 1 = no global stores, 2 = no write-out, 3 = no staging either, 4 = generation only
 #endif
                   };
-#define L0_MAX_PASSES 4            // passes a level-0 sweep materialises together (bins of the MODE 4 scatter)
+#define L0_MAX_PASSES 16           // passes a level-0 sweep materialises together (bins of the MODE 4 scatter)
 
 template <int W, int SRC, int MODE, bool OPT = false, bool HEAVY = false>
 __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
@@ -556,13 +562,15 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
     u32* wsum = delta + P;                                           // 16 (+1 total)
     u32* tot = wsum + 16;
     u32* lim = tot + 1;                                              // P (OPT): end of this block's slice of every bin
+    u64* lob = reinterpret_cast<u64*>(smem + ((reinterpret_cast<char*>(lim + P) - smem + 7) & ~size_t(7)));      // MODE 4: region base of every bin
     const u32 nchunks = *d_nchunks;
     // OPT: this block's slices are CONTIGUOUS in `out` -- slice of bin b at blockIdx * area + boff[b] -- so its P write fronts
     // stay inside a few 2 MB pages (bin-major, the fronts of one block were P regions of grid * slice keys apart: P pages to
     // cycle through on every tile, far more than the CU's translation cache holds)
     const u32 first = OPT ? blockIdx.x * o1.area : 0u;
     if (OPT && o1.uslice) for (u32 b = threadIdx.x; b < P; b += SC_NT) cur[b] = first + b * o1.uslice;
-    else if (OPT) for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] = first + o1.boff[b]; lim[b] = o1.slice_len ? cur[b] + o1.slice_len : first + o1.boff[b + 1]; }
+    else if (OPT && MODE == 4) for (u32 b = threadIdx.x; b < P; b += SC_NT) { const u32 sl = o1.boff[b]; cur[b] = blockIdx.x * sl; lim[b] = cur[b] + sl; lob[b] = o1.obase[b]; }
+    else if (OPT) for (u32 b = threadIdx.x; b < P; b += SC_NT) { cur[b] = first + o1.boff[b]; lim[b] = first + o1.boff[b + 1]; }
     u32 gbeg = blockIdx.x, gend = nchunks;
     if constexpr (SRC == 2 && OPT) {
         if (o1.cur_state) { gbeg += o1.g0; gend = o1.g0 + o1.gn; }
@@ -649,7 +657,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                     // (OPT: tile_scan keeps a bin that outgrew its slice out of the other slices.)  With slices there is a dump zone
                     // behind the last bin: a lane past the tile's keys stores there instead of being masked off, so that every trip
                     // issues exactly 4 stores -- the compiler can then count them (see rank_and_stage)
-                    if (OPT && MODE == 4) out[i < ntile ? o1.obase[key_digit<MODE>(digit_word(hk[u]), ds) & (L0_MAX_PASSES - 1)] + (u64)(dd[u] + i) : o1.obase[0] + (u64)(o1.dump + i)] = hk[u];
+                    if (OPT && MODE == 4) out[i < ntile ? lob[key_digit<MODE>(digit_word(hk[u]), ds) & (L0_MAX_PASSES - 1)] + (u64)(dd[u] + i) : o1.obase0 + (u64)(o1.dump + i)] = hk[u];
 #ifdef DSK_L1_ABLATE
                     else if (OPT && o1.abl == 1) { if (digit_word(hk[u]) == 0x1234567ull + dd[u]) out[o1.dump + i] = hk[u]; }
 #endif
@@ -696,7 +704,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                 Raw raw = load_raw(d.begin);
                 if (OPT) {          // as many (dump-zone) stores behind the first loads as a tile's write-out issues behind the prefetched ones:
 #pragma unroll                      // the loop is then entered with the same in-flight picture on both edges and the wait at its top is exact
-                    for (int u = 0; u < 4 * ((KPT + 3) / 4); ++u) out[(MODE == 4 ? o1.obase[0] : 0ull) + (u64)(o1.dump + u * SC_NT + threadIdx.x)] = (u64)threadIdx.x;
+                    for (int u = 0; u < 4 * ((KPT + 3) / 4); ++u) out[(MODE == 4 ? o1.obase0 : 0ull) + (u64)(o1.dump + u * SC_NT + threadIdx.x)] = (u64)threadIdx.x;
                 }
                 for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
                     const bool live = t0 + wlane < d.end;
@@ -732,6 +740,15 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
 #endif
     if (OPT) {      // how much of each of its slices this block filled; report a slice that was outgrown
         lds_barrier();
+        if constexpr (HEAVY) {      // the occurrences of the k-mers counted apart (every launch of a sliced receive reports its own; k_heavy_rows adds
+#pragma unroll                      //  them to the keys the step placed)
+            for (int x = 0; x < HV_KEYS; ++x) {
+                u32 v = hc[x];
+#pragma unroll
+                for (int dd = 32; dd >= 1; dd >>= 1) v += __shfl_down(v, dd);
+                if ((threadIdx.x & 63) == 0 && v) atomicAdd(&o1.hv_cnt[x], (unsigned long long)v);
+            }
+        }
         if constexpr (SRC == 2) {
             if (o1.cur_state) {
                 for (u32 b = threadIdx.x; b < P; b += SC_NT) o1.cur_state[(u64)blockIdx.x * P + b] = cur[b];
@@ -741,7 +758,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
         bool ovf = false;
         u32 mine = 0;
         for (u32 b = threadIdx.x; b < P; b += SC_NT) {
-            const u32 beg = first + (o1.uslice ? b * o1.uslice : o1.boff[b]), c = cur[b], end = o1.uslice ? beg + o1.uslice : lim[b];
+            const u32 beg = MODE == 4 ? blockIdx.x * o1.boff[b] : first + (o1.uslice ? b * o1.uslice : o1.boff[b]), c = cur[b], end = o1.uslice ? beg + o1.uslice : lim[b];
             if (c > end) ovf = true;
             const u32 f = c > end ? end - beg : c - beg;
             o1.fill[(u64)b * gridDim.x + blockIdx.x] = f;
@@ -752,23 +769,87 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                 lds_barrier();
                 for (u32 b = 0; b < P; ++b) {
                     const u32 c = cur[b] < lim[b] ? cur[b] : lim[b];
-                    for (u32 i = c + threadIdx.x; i < lim[b]; i += SC_NT) out[o1.obase[b & (L0_MAX_PASSES - 1)] + i] = DSK_EMPTY;
+                    for (u32 i = c + threadIdx.x; i < lim[b]; i += SC_NT) out[lob[b & (L0_MAX_PASSES - 1)] + i] = DSK_EMPTY;
                 }
             }
         }
         if (ovf) *o1.ovf = 1u;
-        if constexpr (HEAVY) {
-#pragma unroll
-            for (int x = 0; x < HV_KEYS; ++x) {
-                u32 v = hc[x];
-#pragma unroll
-                for (int dd = 32; dd >= 1; dd >>= 1) v += __shfl_down(v, dd);
-                if ((threadIdx.x & 63) == 0 && v) { atomicAdd(&o1.hv_cnt[x], (unsigned long long)v); mine += v; }      // (they count as keys of the launch)
-            }
-        }
 #pragma unroll
         for (int dd = 32; dd >= 1; dd >>= 1) mine += __shfl_down(mine, dd);
         if ((threadIdx.x & 63) == 0 && mine) atomicAdd(o1.nkeys, (u64)mine);      // keys this launch placed (all of them unless a slice overflowed)
+    }
+}
+
+// ------------------------------------------------------------------ level 0 of a multi-pass count (one-word keys)
+// One sweep over the 2-bit reads: every k-mer whose pass lies in [ds.pass, ds.pass + G) is appended to the slice that this block
+// owns inside that pass's region of `out` (the region starts at key obase[pass - ds.pass], block g's slice at g * slen[..] in it).
+// With <= L0_MAX_PASSES bins and one contiguous slice per (block, bin) there is nothing to stage: a key takes its position from
+// an LDS cursor (one returning atomic; the lanes of a wave that hit the same bin get consecutive positions) and leaves straight
+// from the register it was built in -- no tile in LDS, no tile scan, no barrier inside the loop.  A sweep keeps G of npass
+// passes, a sixth of the windows on a 90 Gbp input: staged through a 16384-slot tile (k_scatter<1, 0, 4>, the first version) it
+// paid for every slot of every tile -- 2.8 ps per window, as much as a full level 1; this way it is bound by the k-mer
+// generation itself.  The stores of a (block, bin) pair fall into a window of a few KB that moves on tile by tile: L2 merges them
+// into whole lines.  The unused tail of every slice is filled with the all-ones sentinel at the end, so a region is ONE key array
+// (tile_keys_array masks the pads).  A slice that would overflow raises *ovf (nothing is written past a slice): the passes of
+// the group then re-generate their keys from the reads.  Key order inside a slice follows the atomics, i.e. it is not the same
+// from run to run -- counts and (sorted) rows are.
+__global__ __launch_bounds__(SC_NT) void k_level0(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                                   const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks,
+                                                   u64* __restrict__ out, int k, DigitSpec ds, u32 G, const u32* __restrict__ slen, const u64* __restrict__ obase,
+                                                   u32* __restrict__ ovf) {
+    __shared__ u32 cur[L0_MAX_PASSES], lim[L0_MAX_PASSES];
+    __shared__ u64 lob[L0_MAX_PASSES];
+    if (threadIdx.x < L0_MAX_PASSES) {
+        const u32 b = threadIdx.x < G ? threadIdx.x : G - 1;
+        const u32 sl = slen[b];
+        cur[threadIdx.x] = blockIdx.x * sl; lim[threadIdx.x] = blockIdx.x * sl + sl; lob[threadIdx.x] = obase[b];
+    }
+    __syncthreads();
+    const u32 nchunks = *d_nchunks;
+    struct Raw { u64 cur, prev; u32 ic, ip; };
+    const u32 wlane = threadIdx.x & (SC_NT / 2 - 1);
+    const bool upper = threadIdx.x >= SC_NT / 2;                      // wave-uniform: which half of its word a thread's 16 windows end in
+    bool over = false;
+    for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
+        const ChunkDesc d = descs[g];
+        if (d.begin >= d.end) continue;
+        auto load_raw = [&](u64 t0) {
+            const u64 wi = t0 + wlane;
+            const u64 wc = wi < d.end ? wi : d.end - 1;                   // clamped: the loads stay unconditional
+            Raw r; r.cur = packed[wc]; r.prev = packed[wc ? wc - 1 : 0]; r.ic = inval[wc]; r.ip = inval[wc ? wc - 1 : 0];
+            if (wc == 0) { r.prev = 0ull; r.ip = 0xFFFFFFFFu; }
+            return r;
+        };
+        Raw raw = load_raw(d.begin);
+        for (u64 t0 = d.begin; t0 < d.end; t0 += Tile<1>::WORDS) {
+            const bool live = t0 + wlane < d.end;
+            u64 h[16]; u32 vm;
+            if (upper) vm = gen_kmers1_words<16>(raw.cur, raw.prev, raw.ic, raw.ip, 16, k, h);
+            else vm = gen_kmers1_words<16>(raw.cur, raw.prev, raw.ic, raw.ip, 0, k, h);
+            if (!live) vm = 0u;
+            const u64 tn = t0 + Tile<1>::WORDS < d.end ? t0 + Tile<1>::WORDS : t0;
+            raw = load_raw(tn);                                          // the next tile's words fly under this tile's work
+            u32 bin[16], pos[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                h[j] = kmix(h[j]);
+                const u32 p = key_pass(h[j], ds) - ds.pass;
+                bin[j] = ((vm >> j) & 1u) && p < G ? p : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) pos[j] = bin[j] != 0xFFFFFFFFu ? atomicAdd(&cur[bin[j]], 1u) : 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (bin[j] != 0xFFFFFFFFu) {
+                    if (pos[j] < lim[bin[j]]) out[lob[bin[j]] + pos[j]] = h[j]; else over = true;
+                }
+        }
+    }
+    __syncthreads();
+    if (over) *ovf = 1u;
+    for (u32 b = 0; b < G; ++b) {                                      // sentinel keys behind what this block wrote into its slices
+        const u32 c = cur[b] < lim[b] ? cur[b] : lim[b];
+        for (u32 i = c + threadIdx.x; i < lim[b]; i += SC_NT) out[lob[b] + i] = DSK_EMPTY;
     }
 }
 
@@ -1639,7 +1720,8 @@ __global__ __launch_bounds__(CNT_NT) void k_count_mw(KN<W>* keys, KN<W>* solid_k
     u32 q = blockIdx.x, begin = 0, end = 0;
     K2 pk[C2_KPT];
     if (q < cp.F) {
-        if (REG) { begin = q * cp.cap; end = begin + cp.subcnt[q]; } else { begin = fstart[q]; end = fstart[q + 1]; }
+        // (REG: the top bit of subcnt = "this sub-partition goes on in extension regions": it reads as empty here, k_count_chained_mw counts it)
+        if (REG) { const u32 c = cp.subcnt[q]; begin = q * cp.cap; end = begin + ((int)c < 0 ? 0u : c); } else { begin = fstart[q]; end = fstart[q + 1]; }
 #pragma unroll
         for (int j = 0; j < C2_KPT; ++j) { const u32 i = begin + tid + j * CNT_NT; if (i < end) pk[j] = keys[i]; }
     }
@@ -1662,7 +1744,7 @@ __global__ __launch_bounds__(CNT_NT) void k_count_mw(KN<W>* keys, KN<W>* solid_k
         const u32 qn = q + gridDim.x;
         u32 nbeg = 0, nend = 0;
         if (qn < cp.F) {
-            if (REG) { nbeg = qn * cp.cap; nend = nbeg + cp.subcnt[qn]; } else { nbeg = fstart[qn]; nend = fstart[qn + 1]; }
+            if (REG) { const u32 c = cp.subcnt[qn]; nbeg = qn * cp.cap; nend = nbeg + ((int)c < 0 ? 0u : c); } else { nbeg = fstart[qn]; nend = fstart[qn + 1]; }
 #pragma unroll
             for (int j = 0; j < C2_KPT; ++j) { const u32 i = nbeg + tid + j * CNT_NT; if (i < nend) pk[j] = keys[i]; }
         }
@@ -1729,6 +1811,129 @@ __global__ __launch_bounds__(CNT_NT) void k_count_mw(KN<W>* keys, KN<W>* solid_k
     lds_barrier();
     if (lane == 0 && ones) atomicAdd(&lh[1], ones);
     lds_barrier();
+    for (int b = tid; b < CNT_LH; b += CNT_NT) {
+        const u32 v = lh[b];
+        if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
+    }
+    if (tid == 0 && ndist_acc) atomicAdd(&gstats[0], ndist_acc);
+}
+
+// Multi-word sub-partitions that went on in extension regions (k_scatter_al's region chains; listed in chain_list): the index table
+// of k_count_mw addresses ONE contiguous key range, a chain is several.  Here a slot holds 1 + the GLOBAL index of the
+// representative key (the host keeps (F + pool) * cap below 2^32 for multi-word keys) and equality is checked against keys[] in
+// HBM -- L2 serves it: a chain is a few MB read once, and its keys come in runs of the same k-mer, so a wave first adds up the
+// lanes that hold its first lane's key (one insert for all of them).  Rare by construction, written for clarity: one block per
+// chained sub-partition.  The chained sub-partitions read as empty in k_count_mw (top bit of subcnt).
+template <int W>
+__device__ __forceinline__ void table_insert2g(const KN<W>* __restrict__ gkeys, u32* slots, u32* tc, unsigned short* lst, u32* ndist, u32* ovf,
+                                               const KN<W>& key, u32 gidx, u32 inc) {
+    u32 slot = (u32)key.w[W - 1] & (C2_SLOTS - 1);
+    for (int probe = 0; probe < C2_SLOTS; ++probe) {
+        u32 v = slots[slot];
+        if (v == 0) {
+            v = atomicCAS(&slots[slot], 0u, gidx + 1u);
+            if (v == 0) { lst[atomicAdd(ndist, 1u)] = (unsigned short)slot; atomicAdd(&tc[slot], inc); return; }
+        }
+        bool same = true;
+#pragma unroll
+        for (int x = 0; x < W; ++x) same = same && (gkeys[v - 1u].w[x] == key.w[x]);
+        if (same) { atomicAdd(&tc[slot], inc); return; }
+        slot = (slot + 1) & (C2_SLOTS - 1);
+    }
+    *ovf = 1;
+}
+template <int W>
+__global__ __launch_bounds__(CNT_NT) void k_count_chained_mw(const KN<W>* __restrict__ keys, KN<W>* __restrict__ solid_keys, u32* __restrict__ abund, u32* __restrict__ nsolid,
+                                                             u64* __restrict__ ghist, u64* __restrict__ gstats, u32* __restrict__ overflow,
+                                                             CountParams cp, const u32* __restrict__ subcnt, const u32* __restrict__ chain_next,
+                                                             const u32* __restrict__ chain_list, const u32* __restrict__ d_nchained, u32 list_cap) {
+    __shared__ u32 slots[C2_SLOTS];
+    __shared__ u32 tc[C2_SLOTS];
+    __shared__ unsigned short lst[C2_SLOTS];
+    __shared__ u32 lh[CNT_LH];
+    __shared__ u32 ctr[4];                      // ndist, out, ovf
+    const int tid = threadIdx.x, lane = tid & 63;
+    const u32 nchained = *d_nchained < list_cap ? *d_nchained : list_cap;
+    if (blockIdx.x >= nchained) return;
+    for (int s = tid; s < C2_SLOTS; s += CNT_NT) { slots[s] = 0; tc[s] = 0; }
+    for (int b = tid; b < CNT_LH; b += CNT_NT) lh[b] = 0;
+    if (tid < 4) ctr[tid] = 0;
+    u32 ones = 0; u64 ndist_acc = 0;
+    __syncthreads();
+    for (u32 li = blockIdx.x; li < nchained; li += gridDim.x) {
+        const u32 q = chain_list[li];
+        const u32 begin = q * cp.cap;
+        u32 rg = q;
+        while (true) {
+            const u32 f = subcnt[rg], nn = f & ~CHAIN_BIT;
+            const u32 rb = rg * cp.cap;
+            for (u32 i0 = 0; i0 < nn; i0 += CNT_NT) {
+                const bool act = i0 + tid < nn;
+                const u32 gi = rb + (act ? i0 + tid : 0u);
+                const KN<W> kv = keys[gi];
+                bool same = act;
+#pragma unroll
+                for (int x = 0; x < W; ++x) {
+                    const u64 f0 = ((u64)__builtin_amdgcn_readfirstlane((u32)(kv.w[x] >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)kv.w[x]);
+                    same = same && kv.w[x] == f0;
+                }
+                const u64 m = __ballot(same);
+                if (same && lane == __ffsll((unsigned long long)m) - 1) table_insert2g<W>(keys, slots, tc, lst, &ctr[0], &ctr[2], kv, gi, (u32)__popcll(m));
+                if (act && !same) table_insert2g<W>(keys, slots, tc, lst, &ctr[0], &ctr[2], kv, gi, 1u);
+            }
+            if (!(f >> 31)) break;
+            rg = chain_next[rg];
+        }
+        __syncthreads();
+        const u32 nd = ctr[0];
+        const bool bad = ctr[2] || nd > cp.maxload;
+        if (bad) {
+            for (int s = tid; s < C2_SLOTS; s += CNT_NT) { slots[s] = 0; tc[s] = 0; }
+            if (tid == 0) *overflow = 1;
+        } else {
+            for (u32 i0 = 0; i0 < nd; i0 += CNT_NT) {
+                const u32 i = i0 + tid;
+                const bool act = i < nd;
+                KN<W> key; u32 c = 0;
+#pragma unroll
+                for (int x = 0; x < W; ++x) key.w[x] = 0;
+                if (act) {
+                    const u32 slot = lst[i];
+                    key = keys[slots[slot] - 1u];
+                    c = tc[slot];
+                    slots[slot] = 0; tc[slot] = 0;
+                }
+                const u64 m1 = __ballot(act && c == 1);
+                if (lane == 0) ones += __popcll(m1);
+                if (act && c > 1) {
+                    const u32 bin = c < cp.histo_max ? c : cp.histo_max;
+                    if (bin < CNT_LH) atomicAdd(&lh[bin], 1u);
+                    else atomicAdd(&ghist[bin], 1ull);
+                }
+                const bool solid = act && c >= cp.amin && c <= cp.amax;
+                const u64 ms = __ballot(solid);
+                if (ms) {
+                    u32 base = 0;
+                    if (lane == 0) base = atomicAdd(&ctr[1], (u32)__popcll(ms));
+                    base = __shfl(base, 0);
+                    if (solid) {
+                        const u32 pos = base + __popcll(ms & ((1ull << lane) - 1));
+                        solid_keys[begin + pos] = key;      // (distinct keys <= maxload < cap: the rows fit the home region)
+                        abund[begin + pos] = c;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            nsolid[q] = bad ? 0u : ctr[1];
+            ndist_acc += bad ? 0u : nd;
+            ctr[0] = 0; ctr[1] = 0; ctr[2] = 0;
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && ones) atomicAdd(&lh[1], ones);
+    __syncthreads();
     for (int b = tid; b < CNT_LH; b += CNT_NT) {
         const u32 v = lh[b];
         if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
@@ -2162,6 +2367,7 @@ __global__ void k_heavy_rows(const u64* __restrict__ hv_keys, const unsigned lon
     const u32 c = c64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)c64;
     atomicAdd(&ghist[c < histo_max ? c : histo_max], 1ull);
     atomicAdd(&gstats[0], 1ull);
+    atomicAdd(&gstats[2], c64);                   // they count as keys the level-1 scatter placed
     if (c >= amin && c <= amax) {
         const u64 at = atomicAdd(&gstats[1], 1ull);
         rows_k[at] = kunmix(key); rows_ab[at] = c;

@@ -33,6 +33,7 @@
 #define RS_MAX_ROWS (384ull << 20)        // most rows this sort takes: 1024 x 1024 sub-buckets of ~380 rows on average (the densest twice that)
 #define RS_BLOCK_ROWS 4096                // larger ones: a whole block (k_rs_big); beyond this: flag
 #define RS_WAVE_CELL_CAP 64               // rows sharing all three digits that are still ordered here (wave path / block path)
+#define RS_OVS_CAP 16384                  // sub-buckets above RS_BLOCK_ROWS rows that a sort may list for another round on their remaining bits
 #define RS_BLOCK_CELL_CAP 16              // block path: cells up to here are ordered by one thread each (insertion), a sub-bucket with a larger one by the bitonic network
 
 // digit X of value v = (v >> shX) & mX; A = top 10 significant bits, B and C the next 8 + 8 (fewer for very small k)
@@ -294,8 +295,13 @@ __global__ __launch_bounds__(RS_CNT) void k_rs_cells(u64* kv, u32* av, const u32
 }
 
 // sub-buckets of 257 .. block_rows rows, one block each (the same placement by the third digit, block-wide)
+// A sub-bucket above block_rows rows (thousands of k-mers that share their first 13 and more bases: the error variants of a k-mer
+// with 10^8 occurrences) is LISTED -- (offset in the whole row array, rows, value bits not yet used) in ovs[1 + 3 i ..], ovs[0] = how
+// many -- and the host sorts each listed range once more on its remaining bits (dskgpu.hip: sort_oversize); only a full list, or
+// rows with no bits left to tell them apart, raise *flag (the full-width fallback).
 __global__ __launch_bounds__(RS_NT) void k_rs_big(u64* kv, u32* av, const u32* __restrict__ sub, RsSpec sp, const u32* __restrict__ biglist,
-                                                  const u32* __restrict__ nbig, u32* __restrict__ flag, u32 block_rows, u32* __restrict__ ties) {
+                                                  const u32* __restrict__ nbig, u32* __restrict__ flag, u32 block_rows, u32* __restrict__ ties,
+                                                  u32 base, u32* __restrict__ ovs) {
     __shared__ u64 rk[RS_BLOCK_ROWS];
     __shared__ u32 ra[RS_BLOCK_ROWS];
     __shared__ u32 wc[2 * RS_CELLS];
@@ -304,7 +310,13 @@ __global__ __launch_bounds__(RS_NT) void k_rs_big(u64* kv, u32* av, const u32* _
     for (u32 x = blockIdx.x; x < nb; x += gridDim.x) {
         const u32 i = biglist[x];
         const u32 o = sub[i], nd = sub[i + 1] - o;
-        if (nd > block_rows) { if (tid == 0) *flag = 1u; continue; }
+        if (nd > block_rows) {
+            if (tid == 0) {
+                const u32 at = sp.shB > 0 ? atomicAdd(&ovs[0], 1u) : RS_OVS_CAP;
+                if (at < RS_OVS_CAP) { ovs[1 + 3 * at] = base + o; ovs[2 + 3 * at] = nd; ovs[3 + 3 * at] = (u32)sp.shB; } else *flag = 1u;
+            }
+            continue;
+        }
         u64* gk = kv + o; u32* ga = av + o;
         u64 k[4]; u32 a[4], r[4];
         __syncthreads();
@@ -362,6 +374,36 @@ __global__ __launch_bounds__(RS_NT) void k_rs_big(u64* kv, u32* av, const u32* _
         for (int t = 0; t < 4; ++t) {
             const u32 j = tid + RS_NT * t;
             if (j < nd) { gk[j] = rk[j]; ga[j] = ra[j]; }
+        }
+    }
+}
+
+// ---- another round for the listed sub-buckets (k_rs_big): the rows of ALL listed ranges are gathered into one array under the
+// composite key (range number << maxbits) | (the value bits the range has not used yet, LEFT-aligned in maxbits bits: the digits right
+// below the range number are then the range's own leading bits, whatever it has left), that array is ordered by ONE MSD sort, and
+// the rows go back to their ranges in the new order (the ranges are disjoint and keep their places).
+#define RS_OVS_SHIFT 48                   // most value bits a listed range may have left
+__global__ __launch_bounds__(256) void k_ovs_gather(const u64* __restrict__ k, const u32* __restrict__ v, const u32* __restrict__ list, const u32* __restrict__ starts, u32 nr,
+                                                    u64* __restrict__ gk, u32* __restrict__ gv, u64* __restrict__ prefix, u32 maxbits) {
+    for (u32 r = blockIdx.x; r < nr; r += gridDim.x) {
+        const u32 off = list[3 * r], len = list[3 * r + 1], bits = list[3 * r + 2], st = starts[r];
+        const u64 mask = (1ull << bits) - 1ull;
+        for (u32 i = threadIdx.x; i < len; i += 256) {
+            const u64 kk = k[(u64)off + i];
+            gk[(u64)st + i] = ((u64)r << maxbits) | ((kk & mask) << (maxbits - bits));
+            gv[(u64)st + i] = v[(u64)off + i];
+            if (i == 0) prefix[r] = kk & ~mask;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_ovs_scatter(u64* __restrict__ k, u32* __restrict__ v, const u32* __restrict__ list, const u32* __restrict__ starts, u32 nr,
+                                                     const u64* __restrict__ gk, const u32* __restrict__ gv, const u64* __restrict__ prefix, u32 maxbits) {
+    for (u32 r = blockIdx.x; r < nr; r += gridDim.x) {
+        const u32 off = list[3 * r], len = list[3 * r + 1], bits = list[3 * r + 2], st = starts[r];
+        const u64 pre = prefix[r];
+        for (u32 i = threadIdx.x; i < len; i += 256) {
+            k[(u64)off + i] = pre | ((gk[(u64)st + i] & ((1ull << maxbits) - 1ull)) >> (maxbits - bits));
+            v[(u64)off + i] = gv[(u64)st + i];
         }
     }
 }

@@ -427,3 +427,32 @@ __global__ __launch_bounds__(SKX_NT) void k_sk_expand(const u64* __restrict__ re
         __syncthreads();
     }
 }
+
+// ---------------------------------------------------------------- receiver: a positional SAMPLE of the records as a key array
+// Sample chunk c = the records [cbeg[c], cbeg[c] + nr) (nr candidates, as a level-1 tile takes them); every candidate gets 16 key
+// slots in out[(c * nr + i) * 16 ..], filled with its k-mers' mixed keys and, behind them (and for candidates past the end of the
+// records), the all-ones sentinel -- a key array with pads, which the histogram / heavy-k-mer kernels of the key-array source read
+// as it is (tile_keys_array masks the pads).  The level-1 slices of the receive side are sized from it, per bin.
+template <int W>
+__global__ __launch_bounds__(SKX_NT) void k_sk_sample_keys(const u64* __restrict__ rec, u64 nrec, u32 R, int k, const u64* __restrict__ cbeg, u32 nr,
+                                                           typename KeyT<W>::T* __restrict__ out) {
+    typedef typename KeyT<W>::T Key;
+    const u64 r0 = cbeg[blockIdx.x];
+    Key* o = out + (u64)blockIdx.x * nr * 16;
+    for (u32 i = threadIdx.x; i < nr; i += SKX_NT) {
+        const u64 r = r0 + i;
+        u64 w[3] = {0ull, 0ull, 0ull};
+        u32 n = 0;
+        if (r < nrec) {
+            const u64* p = rec + r * R;
+            w[0] = p[0]; w[1] = p[1]; if (R == 3) w[2] = p[2];
+            n = (u32)(w[R - 1] & 0xFFu);
+            if (n > 16) n = 16;
+        }
+        for (u32 j = 0; j < 16; ++j) {
+            Key key = empty_key<W>();
+            if (j < n) sk_key(w, (int)j, k, key);
+            o[(u64)i * 16 + j] = key;
+        }
+    }
+}

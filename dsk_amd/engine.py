@@ -55,6 +55,7 @@ class _Stats(C.Structure):
         ("n_passes", C.c_uint64),
         ("n_ext_regions", C.c_uint64),
         ("n_heavy", C.c_uint64),
+        ("n_read_sweeps", C.c_uint64),
     ]
 
 

@@ -92,6 +92,11 @@ REPEAT_WORKLOADS = {
     "c2_repeats_10Mx150": ("c2_10Mx150", 0.002),
     "small_repeats": ("small", 0.002),
     "c2_repeats_nopolya_10Mx150": ("c2_10Mx150", 0.0),      # (experiments: the repeat-rich genome without the poly-A reads)
+    # stand-in for BASELINE.json configs[4] (30x human short reads, ~90 Gbp; SURVEY.md section 8(d) allows "synthetic G = 3 Gbp,
+    # 600 M reads"): the repeat-rich 3 Gbp genome, 600 M x 150 bp, 0.2 % poly-A reads -- ONE k-mer with 1.4 * 10^8 occurrences,
+    # family k-mers with ~10^6.  The reference's own human run: doc/human_log:3-4,20-24 (7 passes, 2.7 * 10^9 solid k-mers).
+    "c5_human30x": ("c5_600Mx150", 0.002),
+    "c5_human30x_shard": ("c5_shard_75Mx150", 0.002),        # one GPU's share of it on 8 GPUs (N x 375 Mbp of genome)
 }
 
 
@@ -118,6 +123,8 @@ def workload(name: str):
         "ecoli50x": (4_640_000, 1_550_000, 150),          # E. coli stand-in for the >=10x goal
         "c3_200Mx150": (600_000_000, 200_000_000, 150),   # configs[2] (whole node)
         "c3_shard_25Mx150": (75_000_000, 25_000_000, 150),  # one GPU's share of configs[2] (200 M reads / 8 GPUs)
+        "c5_600Mx150": (3_000_000_000, 600_000_000, 150),   # configs[4] stand-in (uniform twin; the repeat-rich one: c5_human30x)
+        "c5_shard_75Mx150": (375_000_000, 75_000_000, 150), # one GPU's share of it (600 M reads / 8 GPUs)
         "tiny": (20_000, 10_000, 150),
         "small": (1_000_000, 333_334, 150),
     }

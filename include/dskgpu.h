@@ -202,6 +202,9 @@ typedef struct dskgpu_stats {
     uint64_t n_ext_regions;  /* extension regions taken by sub-partitions that outgrew their home region (repeat-rich
                                 inputs: heavy k-mers stay on the histogram-free path; 0 on repeat-free reads)   */
     uint64_t n_heavy;        /* k-mers counted apart from the partitions (found heavy in the sample pass)       */
+    uint64_t n_read_sweeps;  /* times the (2-bit) reads were walked to generate k-mers: 1 for a single pass; a multi-pass
+                                count materialises the keys of up to 16 passes per sweep -- this is what DSK calls a pass
+                                (each one re-reads the input; README.md:126-130 "below 10")                             */
 } dskgpu_stats;
 int dskgpu_get_stats(const dskgpu_ctx* ctx, dskgpu_stats* out);
 

@@ -295,19 +295,20 @@ def _reads_with_planted_kmers(rng, n_reads, rl, k, planted):
     return np.concatenate([reads, np.full((n_reads, 1), ord("\n"), np.uint8)], axis=1).reshape(-1)
 
 
-def test_region_chains_keep_heavy_kmers_on_the_histogram_free_path(oracle, dev, monkeypatch):
-    """k-mers with thousands of occurrences outgrow the fixed-capacity region of their sub-partition (4360 keys, mean fill
-    2900).  The level-2 scatter then chains extension regions to it and the count kernel walks the chain: no retry, no
-    histogram pass, rows and histogram equal the oracle's.  With the pool switched off (DSKGPU_MAX_EXT=0) the same input
-    takes the exact path after one retry -- the behaviour before the chains."""
+@pytest.mark.parametrize("k", [31, 63])
+def test_region_chains_keep_heavy_kmers_on_the_histogram_free_path(oracle, dev, monkeypatch, k):
+    """k-mers with thousands of occurrences outgrow the fixed-capacity region of their sub-partition (4360 one-word / 2180 two-word
+    keys).  The level-2 scatter then chains extension regions to it and the count kernel walks the chain (k_count_chained, and
+    k_count_chained_mw for two-word keys: k = 63): no retry, no histogram pass, rows and histogram equal the oracle's.  With the
+    pool switched off (DSKGPU_MAX_EXT=0) the same input takes the exact path after one retry -- the behaviour before the chains."""
     from dsk_amd import KmerCounter
     rng = np.random.default_rng(42)
-    stream = _reads_with_planted_kmers(rng, 50_000, 150, 31, [(200, 1), (1500, 2), (2500, 3), (5000, 4), (9000, 5), (14000, 6)])
-    ref = oracle.count(stream, 31)
+    stream = _reads_with_planted_kmers(rng, 50_000, 150, k, [(200, 1), (1500, 2), (2500, 3), (5000, 4), (9000, 5), (14000, 6)])
+    ref = oracle.count(stream, k)
     t = torch.from_numpy(stream).to(dev)
 
     def run():
-        with KmerCounter(kmer_size=31, abundance_min=2, timing=True) as kc:
+        with KmerCounter(kmer_size=k, abundance_min=2, timing=True) as kc:
             kc.set_reads_device(t.data_ptr(), t.numel())
             kc.count()
             rows, ab = kc.rows()
@@ -316,7 +317,7 @@ def test_region_chains_keep_heavy_kmers_on_the_histogram_free_path(oracle, dev, 
     def check(rows, ab, hist, st):
         keep = ref.ab >= 2
         assert st["n_levels"] == 2 and st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct
-        assert (rows[:, 0] == ref.lo[keep]).all() and (ab == ref.ab[keep]).all() and (hist == ref.histogram(10000)).all()
+        assert (rows == ref.words()[keep]).all() and (ab == ref.ab[keep]).all() and (hist == ref.histogram(10000)).all()
 
     assert ref.ab.max() >= 14000
     rows, ab, hist, st, stages = run()
@@ -1002,10 +1003,11 @@ def test_row_sort_paths_agree(oracle, dev, monkeypatch):
     for k, s in ((31, reads), (11, reads), (4, reads)):
         st = check_against_oracle(oracle, s, k, dev, amin=1)
         assert st["sort_fallback"] == 0
-    check_against_oracle(oracle, skew, 31, dev, amin=1)                 # (whichever path the skew takes: same rows)
-    monkeypatch.setenv("DSKGPU_RS_BLOCK_ROWS", "512")
     st = check_against_oracle(oracle, skew, 31, dev, amin=1)
-    assert st["sort_fallback"] == 1
+    assert st["sort_fallback"] == 0                                    # sub-buckets above 4096 rows go round again on their remaining bits
+    monkeypatch.setenv("DSKGPU_RS_BLOCK_ROWS", "512")                   # ... forced: every sub-bucket above 512 rows does
+    st = check_against_oracle(oracle, skew, 31, dev, amin=1)
+    assert st["sort_fallback"] == 0
     monkeypatch.delenv("DSKGPU_RS_BLOCK_ROWS")
     monkeypatch.setenv("DSKGPU_RS_HEAVY", "1000")                       # a first-digit bucket "too heavy" for one block: fallback, same rows
     st = check_against_oracle(oracle, reads, 31, dev, amin=1)
@@ -1019,6 +1021,30 @@ def test_row_sort_paths_agree(oracle, dev, monkeypatch):
     monkeypatch.setenv("DSKGPU_LIB_ROWSORT", "1")
     for k, s in ((31, skew), (11, reads)):
         check_against_oracle(oracle, s, k, dev, amin=1)
+
+
+def test_row_sort_of_huge_row_sets_in_groups(oracle, dev, monkeypatch):
+    """Row sets above what the MSD sort takes in one piece (3 * 10^9 solid k-mers of a 30x human run) are split on their top bits
+    once and ordered group by group (sort_rows_big): forced here on a small input with DSKGPU_RS_MAX_ROWS -- single pass (scratch
+    = srt_*), several passes (scratch inside the level-0 buffer), few value bits, skewed values, and the full-width fallback when
+    one top-10-bit bucket alone exceeds the limit."""
+    from dsk_amd import synth
+    g = synth.make_genome(400_000, dev)
+    reads = synth.make_reads(g, 120_000, 150).cpu().numpy()
+    rng = np.random.default_rng(7)
+    pa = np.full(1_000_000, 65, np.uint8)
+    hit = rng.random(pa.size) < 0.02
+    pa[hit] = rng.choice(np.frombuffer(b"CGT", dtype=np.uint8), size=int(hit.sum()))
+    skew = np.concatenate([pa, np.array([10], np.uint8), reads]).astype(np.uint8)
+    monkeypatch.setenv("DSKGPU_RS_MAX_ROWS", "300000")
+    for k, s in ((31, reads), (31, skew), (13, reads)):
+        st = check_against_oracle(oracle, s, k, dev, amin=1)
+        assert st["n_solid"] > 300000 and st["sort_fallback"] == 0, (k, st)
+    st = check_against_oracle(oracle, reads, 31, dev, amin=1, max_pass_mkeys=2)         # several passes: rows accumulated, scratch carved from l0buf
+    assert st["n_passes"] > 4 and st["n_read_sweeps"] < st["n_passes"] and st["sort_fallback"] == 0
+    monkeypatch.setenv("DSKGPU_RS_MAX_ROWS", "5000")                                   # a 10-bit bucket of uniform rows holds ~14 000: the fallback orders them
+    st = check_against_oracle(oracle, reads, 31, dev, amin=1)
+    assert st["sort_fallback"] == 1
 
 
 @pytest.mark.parametrize("k", [40, 63, 70, 100])
@@ -1187,6 +1213,44 @@ def test_group_count_in_one_process(oracle, golden_dir, dev, monkeypatch, ranks,
                 assert g.exchanged_words() > 0
                 per_rank = [g.rank(r).stats()["n_kmers"] for r in range(ranks)]
                 assert sum(per_rank) == ref.total and min(per_rank) > 0
+
+
+@pytest.mark.parametrize("ranks,k,slices", [(4, 31, "4"), (4, 31, "0"), (2, 63, "4")])
+def test_receive_side_stays_on_the_fast_path_with_repeats(oracle, dev, monkeypatch, ranks, k, slices):
+    """The repeat machinery on the path the multi-GPU metric takes: every rank of a group receives super-k-mer RECORDS, and its
+    level 1 reads them directly.  With a repeat-rich input (`small_repeats`: a high-copy family, tandem arrays, poly-A reads -- one
+    rank owns a k-mer with 10^5 occurrences) the slices of that level are sized per bin from a positional sample of the records
+    (k_sk_sample_keys; from the first slice when the exchange runs in slices), the dominant k-mer is counted apart (one-word
+    keys), level 2 chains extension regions (two-word keys too): no rank retries, none takes a histogram pass, and the union
+    of the ranks' rows equals the oracle's."""
+    from dsk_amd import KmerGroup, synth
+    monkeypatch.setenv("DSKGPU_GROUP_SLICES", slices)
+    monkeypatch.setenv("DSKGPU_SK_MINSLICE", "1")
+    reads, gl, nr, rl = synth.make_workload("small_repeats", dev)
+    ref = oracle.count(reads.cpu().numpy(), k)
+    per = nr // ranks
+    with KmerGroup([0] * ranks, kmer_size=k, abundance_min=2, nb_partitions=1, timing=True) as g:
+        for r in range(ranks):
+            lo, hi = r * per * (rl + 1), (nr if r == ranks - 1 else (r + 1) * per) * (rl + 1)
+            g.rank(r).set_reads_device(reads.data_ptr() + lo, hi - lo)
+        g.count()
+        st = g.stats()
+        assert st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct
+        assert (g.histogram() == ref.histogram(10000)).all()
+        if slices != "0":
+            assert g.sliced_steps() == 1
+        per_rank = [g.rank(r).stats() for r in range(ranks)]
+        stages = [dict(g.rank(r).stage_times()) for r in range(ranks)]
+        assert all(s["n_retries"] == 0 for s in per_rank), per_rank
+        assert all("hist1" not in t and "hist2" not in t for t in stages), stages
+        assert sum(s["n_ext_regions"] for s in per_rank) > 0
+        if k <= 32:
+            assert sum(s["n_heavy"] for s in per_rank) >= 1
+        parts = [g.partition(p) for p in range(g.num_partitions())]
+    kk = np.concatenate([p[0] for p in parts]); aa = np.concatenate([p[1] for p in parts])
+    order = np.argsort(kk[:, 0], kind="stable") if k <= 32 else np.lexsort((kk[:, 0], kk[:, 1]))
+    keep = ref.ab >= 2
+    assert (kk[order] == ref.words()[keep]).all() and (aa[order] == ref.ab[keep]).all()
 
 
 @pytest.mark.parametrize("ranks,k,mode", [(4, 31, "slices"), (2, 63, "slices"), (4, 31, "one_piece"), (4, 31, "one_rank_small"),
