@@ -140,6 +140,7 @@ struct Tuning {
     bool no_level0 = false; u32 l0_passes = 0;  // DSKGPU_NO_LEVEL0: every pass of a multi-pass count re-generates its keys; DSKGPU_L0_PASSES=n: passes per level-0 sweep (tests)
     bool count_v1 = false;                      // DSKGPU_COUNT_V1: k_count1<true> (slot list) instead of the list-free k_count1v3 on regions
     u64 rs_max_rows = 0;                        // DSKGPU_RS_MAX_ROWS: most rows the MSD row sort takes in one piece (tests: the group-wise path of huge row sets on a small input)
+    bool l0_keys = false;                       // DSKGPU_L0_KEYS: level 0 as key arrays (k_level0) even where the record-based one applies (experiments, tests)
     bool l0_staged = false;                     // DSKGPU_L0_STAGED: level 0 through the LDS-staged scatter (k_scatter<1, 0, 4>) instead of k_level0 (experiments)
     u32 mp_pass_mkeys = 0;                      // DSKGPU_MP_PASS_MKEYS: keys (millions) per pass of an input that needs several passes (default 1000)
     bool force_heavy = false;                   // DSKGPU_FORCE_HEAVY: the HEAVY instantiation of the level-1 scatter even when no k-mer is counted apart (timing)
@@ -153,7 +154,7 @@ struct Tuning {
         sk_slice = num("DSKGPU_SK_SLICE", 0); sk_minslice = num("DSKGPU_SK_MINSLICE", 2000);
         table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
         max_ext = getenv("DSKGPU_MAX_EXT") ? atoll(getenv("DSKGPU_MAX_EXT")) : -1;
-        no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); l2_static = on("DSKGPU_L2_STATIC"); force_heavy = on("DSKGPU_FORCE_HEAVY"); count_v1 = on("DSKGPU_COUNT_V1"); no_level0 = on("DSKGPU_NO_LEVEL0"); l0_passes = (u32)num("DSKGPU_L0_PASSES", 0); mp_pass_mkeys = (u32)num("DSKGPU_MP_PASS_MKEYS", 0); rs_max_rows = num("DSKGPU_RS_MAX_ROWS", 0); l0_staged = on("DSKGPU_L0_STAGED");
+        no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); l2_static = on("DSKGPU_L2_STATIC"); force_heavy = on("DSKGPU_FORCE_HEAVY"); count_v1 = on("DSKGPU_COUNT_V1"); no_level0 = on("DSKGPU_NO_LEVEL0"); l0_passes = (u32)num("DSKGPU_L0_PASSES", 0); mp_pass_mkeys = (u32)num("DSKGPU_MP_PASS_MKEYS", 0); rs_max_rows = num("DSKGPU_RS_MAX_ROWS", 0); l0_staged = on("DSKGPU_L0_STAGED"); l0_keys = on("DSKGPU_L0_KEYS");
         lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0); rs_heavy = (u32)num("DSKGPU_RS_HEAVY", 0);
     }
 };
@@ -203,7 +204,8 @@ struct dskgpu_ctx {
     bool sk_slices = false;        // the prepared send layout is slices from a sampled estimate (else exact offsets)
     bool sk_exact = false;         // a slice overflowed on these reads: exact counts from now on
     SkParams sk_sp{};
-    DevBuf sk_sums, sk_cbase, sk_keys, sk_table, sk_load, sk_sent;
+    DevBuf sk_sums, sk_cbase, sk_keys, sk_table, sk_load, sk_sent, sk_lay;      // sk_lay: [region base per owner: u64 x 64][slice per owner: u32 x 64] of a record-based level-0 sweep
+    bool rec_l0_off = false;       // these reads do not take the record-based level 0 (a slice of its sampled layout overflowed)
     u64 h_sk_sent[SK_MAX_OWNERS] = {0};      // k-mers inside the records the last mg_scatter wrote for every owner
     u64 h_sk_est[SK_MAX_OWNERS] = {0};       // sampled layout: estimated k-mers per owner (k_sk_hist on every 16th tile, scaled)
     u32 sk_nslices = 0;                      // dskgpu_mg_slices_prepare: slices of the prepared step (0 = none prepared)
@@ -1645,6 +1647,99 @@ int level0_materialise(dskgpu_ctx* ctx, u64 nwords, u32 lo, u32 npass, u64 reser
     return DSKGPU_OK;
 }
 
+// ---- level 0 of a multi-pass count as super-k-mer RECORDS: the passes are "virtual owners"
+// What the multi-GPU step does between GPUs, one GPU does between its passes: the pass of a k-mer is the OWNER that the minimizer
+// repartition gives its window (owner = table[bucket of the minimizer], G owners = G passes; heavy buckets are split by k-mer),
+// a sweep over the 2-bit reads writes the records of as many owners as HBM holds (k_sk_scatter with an owner window, every owner
+// with its own slice length and region), and every pass then runs its level 1 straight from its records (k_scatter<W, 2, 1>),
+// sized from a sample of them.  Records are 2.3-2.5 bytes per k-mer where a key array takes 8 (16 for two-word keys): a 90 Gbp
+// input goes through in 2-3 sweeps instead of 7, 30 Gbp in one -- and the sender never forms a k-mer, which makes a sweep cheaper
+// than the key-array one as well.  DSK writes super-k-mers to its partition files for the same reason (CHANGELOG.md:13;
+// doc/paper.tex:65-67 for the passes).  Needs 20 <= k <= 64 (records) and <= SK_MAX_OWNERS passes; anything else, or a slice
+// of the sampled layout that overflows, takes the key-array level 0 / the pass filter instead (ctx->rec_l0_off).
+void sk_geometry(dskgpu_ctx* ctx, u64 nwords);
+int upload_table(dskgpu_ctx* ctx);
+struct RecL0 { u32 G = 0; u64 nch = 0; u32 slice[SK_MAX_OWNERS] = {0}; u64 region[SK_MAX_OWNERS] = {0}; };      // region[o]: records of owner o's region (nch * slice[o])
+#define REC_L0_NO 2001             // rec_l0_prepare / _sweep: this input does not take the record path (not an error)
+
+int rec_l0_prepare(dskgpu_ctx* ctx, u64 nwords, u32 G, RecL0* rl) {
+    SkParams& sp = ctx->sk_sp;
+    sk_geometry(ctx, nwords);
+    sp.G = G; sp.olo = 0; sp.ohi = G; sp.oslice = nullptr; sp.obase = nullptr;
+    const u64 nch = sp.nchunks, tpc = sp.tiles_per_chunk;
+    const u32 step = tpc >= 16 ? 16u : 1u;
+    // 1. the repartition table for G owners, from the sampled k-mer load of every minimizer bucket
+    {
+        SkParams ss = sp; ss.sample_step = step; ss.table = nullptr;
+        CK(ctx->sk_load.ensure((size_t)SK_BUCKETS * 8));
+        CK(hipMemsetAsync(ctx->sk_load.p, 0, (size_t)SK_BUCKETS * 8, ctx->stream));
+        hipLaunchKernelGGL(k_sk_sample, dim3(ss.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), ss, ctx->sk_load.as<unsigned long long>());
+        CKL("k_sk_sample");
+        std::vector<uint64_t> loads(SK_BUCKETS);
+        CK(hipMemcpyAsync(loads.data(), ctx->sk_load.p, (size_t)SK_BUCKETS * 8, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        ctx->h_table.resize(SK_BUCKETS);
+        dskgpu_mg_make_table(loads.data(), G, ctx->h_table.data());
+        ctx->table_dirty = true;
+        const int rc = upload_table(ctx);
+        if (rc) return rc;
+    }
+    // 2. records per (owner, chunk), counted on every 16th tile (all tiles of a small input): the slice of an (owner, chunk) pair
+    const u64 M = (u64)G * nch;
+    CK(ctx->mat1.ensure((M + 1) * 4));
+    CK(ctx->sk_sent.ensure(3 * SK_MAX_OWNERS * 8));
+    CK(hipMemsetAsync(ctx->sk_sent.as<u64>() + SK_MAX_OWNERS, 0, SK_MAX_OWNERS * 8, ctx->stream));
+    sp.sample_step = step;
+    hipLaunchKernelGGL(k_sk_hist, dim3((unsigned)nch), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, ctx->mat1.as<u32>(),
+                       ctx->sk_sent.as<unsigned long long>() + SK_MAX_OWNERS);
+    CKL("k_sk_hist");
+    std::vector<u32> cells(M);
+    CK(hipMemcpyAsync(cells.data(), ctx->mat1.p, M * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    const u64 sampled_tiles = (tpc + step - 1) / step;
+    rl->G = G; rl->nch = nch;
+    for (u32 o = 0; o < G; ++o) {
+        u64 tot = 0, mx = 0;
+        for (u64 c = 0; c < nch; ++c) { const u64 v = cells[(size_t)o * nch + c]; tot += v; mx = std::max(mx, v); }
+        u64 sl;
+        if (step == 1) sl = mx + 8;                                                        // every tile counted: the busiest chunk's figure is exact
+        else { sl = tot * tpc / (sampled_tiles * nch) + 1; sl += sl * 2 / 25 + 128; }      // the mean per chunk, scaled, + 8 % + 128 (as the multi-GPU sender)
+        if (ctx->tune.sk_slice) sl = ctx->tune.sk_slice;                                   // tests
+        if (sl * nch >= 0xFFFF0000ull) return REC_L0_NO;                                   // (record positions inside an owner's region stay 32-bit on the reading side)
+        rl->slice[o] = (u32)sl; rl->region[o] = sl * nch;
+    }
+    ctx->mark("level0_size");
+    return DSKGPU_OK;
+}
+
+// one sweep: the records of owners [olo, ohi) into ctx->l0buf; base[o] = first 8-byte word of owner o's region.  -> REC_L0_NO when a
+// slice overflowed (the sampled layout did not hold: the caller starts over on the key-array path)
+int rec_l0_sweep(dskgpu_ctx* ctx, const RecL0& rl, u32 olo, u32 ohi, u64 (&base_words)[SK_MAX_OWNERS]) {
+    SkParams sp = ctx->sk_sp;
+    u64 obase[SK_MAX_OWNERS] = {0}; u32 osl[SK_MAX_OWNERS] = {0};
+    u64 tot = 0;
+    for (u32 o = 0; o < rl.G; ++o) { osl[o] = rl.slice[o]; obase[o] = tot; if (o >= olo && o < ohi) tot += rl.region[o]; base_words[o] = obase[o] * sp.R; }
+    CK(ctx->l0buf.ensure(tot * sp.R * 8 + 64));
+    CK(ctx->sk_lay.ensure(SK_MAX_OWNERS * 12));
+    CK(hipMemcpyAsync(ctx->sk_lay.p, obase, sizeof obase, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemcpyAsync(ctx->sk_lay.as<u64>() + SK_MAX_OWNERS, osl, sizeof osl, hipMemcpyHostToDevice, ctx->stream));
+    sp.olo = olo; sp.ohi = ohi; sp.obase = ctx->sk_lay.as<unsigned long long>(); sp.oslice = reinterpret_cast<const u32*>(ctx->sk_lay.as<u64>() + SK_MAX_OWNERS);
+    sp.c0 = 0; sp.c0g = 0; sp.clen = (u32)rl.nch; sp.rbase = 0; sp.slice = 0;
+    u32* sc = ctx->scalars.as<u32>();
+    CK(hipMemsetAsync(ctx->sk_sent.p, 0, SK_MAX_OWNERS * 8, ctx->stream));
+    CK(hipMemsetAsync(sc + SC_OVF1, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_sk_scatter<true>, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
+                       ctx->mat1.as<u32>(), ctx->l0buf.as<u64>(), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>());
+    CKL("k_sk_scatter(passes)");
+    ctx->mark("level0");
+    CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(ctx->h_sk_sent, ctx->sk_sent.p, SK_MAX_OWNERS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));        // (obase / osl are locals)
+    if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] level 0 (records): passes %u..%u of %u materialised, %.2f GB%s\n", olo, ohi - 1, rl.G, (double)tot * sp.R * 8e-9,
+                                   ctx->h_ovf1 ? " -- a slice overflowed: starting over on the key-array path" : "");
+    return ctx->h_ovf1 ? REC_L0_NO : DSKGPU_OK;
+}
+
 // The pipeline behind dskgpu_count / dskgpu_mg_count: encode once, then one or several passes over
 // the key space (several when the input holds more k-mers than a pass may: < 2^32 offsets, and the
 // ping-pong buffers must fit HBM -- the in-memory counterpart of DSK's disk passes), then the row sort.
@@ -1691,7 +1786,26 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
     u64 pass_keys = max_keys;
     if (W == 1 && from_reads && ctx->have_nvalid && n_keys > max_keys && !ctx->max_keys_per_pass && !ctx->tune.no_level0)
         pass_keys = ctx->tune.mp_pass_mkeys ? (u64)ctx->tune.mp_pass_mkeys * 1000000ull : 1000000000ull;
+    // two-word keys: a pass holds what 32-bit key indices address (regions of 2180 keys at <= 60 % fill)
+    const u64 hard_max = W == 2 && !ctx->max_keys_per_pass ? std::min<u64>(max_keys, 2400000000ull) : max_keys;
     u32 npass = (u32)std::max<u64>(1, (n_keys + pass_keys - 1) / pass_keys);
+    // Several passes from reads, 20 <= k <= 64: the passes are virtual OWNERS and a sweep materialises super-k-mer records (above).
+    bool rec_l0 = W <= 2 && from_reads && ctx->have_nvalid && ctx->sk_mode && ctx->cfg.world_size == 1 && !ctx->tune.no_level0 && !ctx->tune.l0_keys && !ctx->rec_l0_off &&
+                  (npass > 1 || n_keys > hard_max);
+    RecL0 rl;
+    if (rec_l0) {
+        u64 want = ctx->max_keys_per_pass ? max_keys : ctx->tune.mp_pass_mkeys ? (u64)ctx->tune.mp_pass_mkeys * 1000000ull : (W == 1 ? 1200000000ull : 1000000000ull);
+        u64 G = (n_keys + want - 1) / want;
+        if (G < 2) G = 2;
+        if (G > SK_MAX_OWNERS) G = SK_MAX_OWNERS;
+        // (owners are balanced to a few per cent by the repartition table: 15 % head-room under what a pass may hold)
+        if (n_keys / G + n_keys / G / 7 > hard_max && !ctx->max_keys_per_pass) rec_l0 = false;
+        else {
+            const int rc = rec_l0_prepare(ctx, nwords, (u32)G, &rl);
+            if (rc == REC_L0_NO) rec_l0 = false; else if (rc) return rc;
+            else npass = (u32)G;
+        }
+    }
     u64 cap_floor = 0;       // keys the largest pass seen so far really holds (a k-mer with millions of occurrences sits in ONE pass whatever their number)
     for (;;) {
         if (npass > 4096) return fail(ctx, DSKGPU_E_OVERFLOW, "too many passes (one k-mer alone exceeds a pass)");
@@ -1707,13 +1821,46 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         Plan pl{};
         bool too_big = false;
         u32 l0_lo = 0, l0_n = 0; u64 l0_keys[L0_MAX_PASSES] = {0}; u64 l0_base[L0_MAX_PASSES] = {0};       // passes materialised by the last level-0 sweep
-        bool l0_try = W == 1 && from_reads && npass > 1 && ctx->have_nvalid && !ctx->tune.no_level0;
+        bool l0_try = W == 1 && from_reads && npass > 1 && ctx->have_nvalid && !ctx->tune.no_level0 && !rec_l0;
+        u32 r_hi = 0; u64 r_base[SK_MAX_OWNERS] = {0};     // record-based level 0: owners materialised by the last sweep, first word of each one's region
+        bool restart = false;
         u64 sweeps = 0;          // times the encoded reads were walked to generate k-mers (DSK's notion of a pass: README.md:126-130)
         bool rows_sized = false; // the row accumulators are sized for all passes (known after the first one)
         for (u32 p = 0; p < npass; ++p) {
             u64 ns = 0, nk = 0;
             int rc;
             if (npass > 1) { ctx->opt1_off = false; ctx->opt2_off = false; }      // an overflow is a property of ONE pass (the one that holds a k-mer with 10^8 occurrences): the others keep the fast path
+            if (rec_l0) {
+                if (p >= r_hi) {       // the next sweep: as many owners as HBM holds beside a pass's own buffers and the rows still to come
+                    size_t free_b = 0, total_b = 0;
+                    CK(hipMemGetInfo(&free_b, &total_b));
+                    const u64 nper = n_keys / npass + 1;
+                    const u64 have = ctx->bufA.cap + ctx->bufB.cap + ctx->l0buf.cap;
+                    const u64 rows_have = ctx->acc_ab.cap + ctx->acc_w[0].cap + (W > 1 ? ctx->acc_w[1].cap : 0);
+                    const u64 rows_want = rows_sized ? 0 : n_keys / 16 * (8ull * W + 4);
+                    const u64 need = nper * (W == 1 ? 30ull : 50ull) + (4ull << 30) + (rows_want > rows_have ? rows_want - rows_have : 0);
+                    const u64 room = free_b + have > need ? free_b + have - need : 0;
+                    const u64 R8 = (u64)ctx->sk_sp.R * 8;
+                    u64 left = 0; for (u32 o = p; o < npass; ++o) left += rl.region[o] * R8;
+                    const u64 nsw = std::max<u64>(1, (left + std::max<u64>(room, 1) - 1) / std::max<u64>(room, 1));      // sweeps still needed: equal shares
+                    const u64 target = (left + nsw - 1) / nsw;
+                    u64 acc = 0; u32 hi = p;
+                    while (hi < npass && (hi == p || (acc + rl.region[hi] * R8 <= room && acc < target))) { acc += rl.region[hi] * R8; ++hi; }
+                    if (ctx->tune.l0_passes) hi = std::min<u32>(npass, p + ctx->tune.l0_passes);      // tests
+                    rc = rec_l0_sweep(ctx, rl, p, hi, r_base);
+                    if (rc == REC_L0_NO) { restart = true; break; }
+                    if (rc) return rc;
+                    r_hi = hi; ++sweeps;
+                }
+                const u64 nvalid = ctx->h_nvalid;
+                const u64 nk_in = ctx->h_sk_sent[p];
+                ctx->rec_src = ctx->l0buf.as<u64>() + r_base[p]; ctx->rec_n = rl.region[p]; ctx->rec_expanded = false; ctx->rec_sized = false;
+                ctx->rec_hint = 0; ctx->rec_hint_est = false; ctx->rec_slice_end.clear(); ctx->rec_gate = nullptr;
+                if (nk_in == 0) { ns = 0; nk = 0; ctx->h_stats[0] = 0; rc = DSKGPU_OK; CK(hipMemsetAsync(ctx->ghist.p, 0, ((size_t)ctx->cfg.histo_max + 1) * 8, ctx->stream)); }
+                else rc = run_one_pass<W>(ctx, false, nullptr, nk_in, 0, 0u, 1u, nk_in, &ns, &nk, &pl);
+                ctx->rec_src = nullptr;
+                ctx->h_nvalid = nvalid;
+            } else
             if (l0_try && p >= l0_lo + l0_n) {       // the next group of passes: one sweep over the reads writes their keys
                 // (until the first pass has told how many rows a pass leaves, room is kept for one solid row per sixteen k-mers -- what
                 //  20x coverage leaves; should the rows need more, the group's remaining key arrays give way: below)
@@ -1723,7 +1870,8 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 if (l0_n == 0) l0_try = false;       // no room (or a skewed key space): every pass reads the reads
                 else ++sweeps;
             }
-            if (l0_try && p < l0_lo + l0_n) {
+            if (rec_l0) { /* done above */ }
+            else if (l0_try && p < l0_lo + l0_n) {
                 const u64 nvalid = ctx->h_nvalid;    // (a pass from a key array sizes itself from its own key count)
                 const u64 nk_in = l0_keys[p - l0_lo];
                 rc = run_one_pass<W>(ctx, false, reinterpret_cast<const Key*>(ctx->l0buf.as<u64>() + l0_base[p - l0_lo]), nk_in, 0, 0u, 1u, nk_in, &ns, &nk, &pl);
@@ -1744,6 +1892,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 if (!grow_rows()) {      // the rows need more than was kept for them: the key arrays of the group's remaining passes give way (those passes get a sweep of their own)
                     (void)hipGetLastError();
                     if (l0_n && ctx->l0buf.p) { ctx->l0buf.release(); l0_n = p + 1 - l0_lo; }
+                    if (rec_l0 && ctx->l0buf.p) { ctx->l0buf.release(); r_hi = p + 1; }
                     if (!grow_rows()) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
                 }
                 rows_sized = true;
@@ -1758,6 +1907,12 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 ctx->mark("start");
             }
             tot_rows += ns;
+        }
+        if (rec_l0) { ctx->sk_prepared = false; ctx->enc_fresh = false; }      // (the sender state of this context was used for the passes)
+        if (restart) {          // the record layout did not hold for these reads: the same count on the key-array path
+            ctx->rec_l0_off = true;
+            ctx->resolve_marks();
+            return run_pipeline<W>(ctx, from_reads, d_keys_in, nkeys_in);
         }
         if (too_big) {
             // the pass holds more keys than its buffers: give the passes that capacity (more passes would not make THAT pass
@@ -2299,7 +2454,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
                       &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
                       &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->srt_k2, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
                       &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,
-                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent, &ctx->cur_state, &ctx->rs_ovs, &ctx->smp_keys};
+                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent, &ctx->cur_state, &ctx->rs_ovs, &ctx->smp_keys, &ctx->sk_lay};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i) { ctx->rs_g[i].release(); ctx->out_w[i].release(); ctx->srt_w[i].release(); ctx->acc_w[i].release(); ctx->u_w[i].release(); ctx->s_w[i].release(); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -2358,7 +2513,7 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
     CK(hipMemsetAsync(dst + ctx->reads_len + nbytes, '\n', 1, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     ctx->reads_len += nbytes + 1;
-    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false;
+    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->rec_l0_off = false;
     return DSKGPU_OK;
 }
 
@@ -2412,7 +2567,7 @@ int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbyte
     // intermittent failure of the multi-process test was exactly that, in the test's reference count).  Once per read set, not per count.
     CK(hipSetDevice(ctx->cfg.device));
     CK(hipDeviceSynchronize());
-    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false;
+    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->rec_l0_off = false;
     ctx->n_bytes = nbytes;
     ctx->reads_len = 0;
     ctx->bank_ends.clear();

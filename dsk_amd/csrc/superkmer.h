@@ -49,6 +49,13 @@ struct SkParams {
     // slices, each complete -- and on its way -- before the next is written (dskgpu_mg_scatter_slice).
     u32 c0, c0g, clen, rbase;
     const unsigned char* table;   // SK_BUCKETS owners (device memory)
+    // k_sk_scatter<true> for the passes of a multi-pass count on ONE GPU ("virtual owners": owner = pass; dskgpu.hip: rec_l0_*): only
+    // the records of owners [olo, ohi) are written (a sweep materialises as many passes as HBM holds), every owner has its own slice
+    // length oslice[o] (a pass that holds a k-mer with 10^8 occurrences gets longer slices, the others do not pay for it) and its
+    // region starts at record obase[o] of the buffer (64-bit: a sweep holds more than 2^32 records).  oslice == nullptr: the
+    // uniform layout above, all owners.
+    u32 olo, ohi;
+    const u32* oslice; const unsigned long long* obase;
 };
 
 __host__ __device__ __forceinline__ u32 sk_record_words(u32 k) { return (2u * (k + 15u) + 8u + 63u) / 64u; }
@@ -278,17 +285,29 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
     __shared__ u32 H[SK_NT * 17];
     __shared__ u32 cur[SK_MAX_OWNERS];
     __shared__ u32 kc[SK_MAX_OWNERS];
+    __shared__ u32 lim[SK_MAX_OWNERS];                    // SLICES: end of this block's slice of every owner (same units as cur)
+    __shared__ unsigned long long ob[SK_MAX_OWNERS];      // SLICES with per-owner regions: record index where cur[o] == 0 lies
     __shared__ u32 desc[SK_NT / 64][SK_DESC];
     __shared__ unsigned char tab[SK_BUCKETS];
     const u32 c = blockIdx.x + (SLICES ? sp.c0 : 0u);
     for (int i = threadIdx.x; i < SK_BUCKETS / 8; i += SK_NT) reinterpret_cast<u64*>(tab)[i] = reinterpret_cast<const u64*>(sp.table)[i];
     __syncthreads();
-    if (threadIdx.x < sp.G) { cur[threadIdx.x] = SLICES ? sp.rbase + (threadIdx.x * sp.clen + (c - sp.c0g)) * sp.slice : mat[(u64)threadIdx.x * sp.nchunks + c]; kc[threadIdx.x] = 0; }
+    if (threadIdx.x < sp.G) {
+        const u32 o = threadIdx.x;
+        kc[o] = 0; ob[o] = 0ull; lim[o] = 0u;
+        if (!SLICES) cur[o] = mat[(u64)o * sp.nchunks + c];
+        else if (sp.oslice) {          // per-owner slices inside per-owner regions: positions relative to the block's own slice
+            const u32 sl = sp.oslice[o];
+            cur[o] = 0u; lim[o] = (o >= sp.olo && o < sp.ohi) ? sl : 0u;
+            ob[o] = sp.obase[o] + (unsigned long long)(c - sp.c0g) * sl;
+        } else { cur[o] = sp.rbase + (o * sp.clen + (c - sp.c0g)) * sp.slice; lim[o] = cur[o] + sp.slice; }
+    }
     bool over = false;
     const u64 tbeg = (u64)c * sp.tiles_per_chunk;
     const u64 tend = tbeg + sp.tiles_per_chunk < sp.ntiles ? tbeg + sp.tiles_per_chunk : sp.ntiles;
     const int k = (int)sp.k;
     const u32 R = sp.R;
+    const bool sub = SLICES && sp.oslice != nullptr;      // only some owners are written
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (u64 tile = tbeg; tile < tend; ++tile) {
         const long long gfirst = (long long)(tile * SK_GROUPS) - SK_HALO;
@@ -297,11 +316,14 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
         // average), and a loop over a thread's own records runs as often as the busiest of 64 lanes needs (5-6 trips of the
         // ~80-instruction body).  Every thread notes its records -- (lane, first window, k-mers, owner) -- in the wave's
         // list (a light loop), then lane e builds record e, e + 64, ..: it fetches the frame of the noting lane's group itself.
-        const u32 cnt = (u32)__popc(s.bm);
+        // (sub: the records of owners outside [olo, ohi) are not even noted)
+        u32 mybm = s.bm;
+        if (sub) { u32 keep = 0; for (u32 b = s.bm; b; b &= b - 1) { const int i = __builtin_ctz(b); const u32 o = sk_owner(s, i); if (o >= sp.olo && o < sp.ohi) keep |= 1u << i; } mybm = keep; }
+        const u32 cnt = (u32)__popc(mybm);
         const u32 inc = wave_incl_scan(cnt);
         const u32 total = (u32)__shfl((int)inc, 63);
         for (u32 B = 0; B < total; B += SK_DESC) {                          // (wave-uniform; more than SK_DESC records in a wave: several rounds)
-            u32 bm = s.bm, id = inc - cnt - B;
+            u32 bm = mybm, id = inc - cnt - B;
             while (bm) {
                 const int i = __builtin_ctz(bm); bm &= bm - 1;
                 if (id < SK_DESC) desc[wave][id] = (u32)lane | ((u32)i << 6) | ((sk_run_length(s, i) - 1u) << 10) | (sk_owner(s, i) << 14);
@@ -319,12 +341,12 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
                 const u64 w1 = wi >= 1 ? packed[wi - 1] : 0ull;
                 const u64 w2 = wi >= 2 ? packed[wi - 2] : 0ull;
                 const u32 slot = atomicAdd(&cur[own], 1u);
-                if (SLICES && slot >= sp.rbase + (own * sp.clen + (c - sp.c0g) + 1) * sp.slice) { over = true; continue; }
+                if (SLICES && slot >= lim[own]) { over = true; continue; }
                 atomicAdd(&kc[own], n);
                 // bases [bs, bs + nb) of the 96-base frame (w2 : w1 : w0), shifted to the top of the record
                 u64 o[3];
                 sk_extract(w2, w1, w0, 64 + t0 + i - k + 1, (int)n + k - 1, o);
-                u64* dst = send + (u64)slot * R;
+                u64* dst = send + ((u64)ob[own] + slot) * R;
                 if (R == 2) { dst[0] = o[0]; dst[1] = o[1] | n; }
                 else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2] | n; }
             }
@@ -337,8 +359,8 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
     if (SLICES) {
         if (over) *ovf = 1u;
         for (u32 o = 0; o < sp.G; ++o) {                      // zero-length records up to the end of each of this block's slices
-            const u64 end = (u64)(sp.rbase + (o * sp.clen + (c - sp.c0g) + 1) * sp.slice) * R;
-            for (u64 w = (u64)cur[o] * R + threadIdx.x; w < end; w += SK_NT) send[w] = 0ull;
+            const u64 beg = ((u64)ob[o] + (cur[o] < lim[o] ? cur[o] : lim[o])) * R, end = ((u64)ob[o] + lim[o]) * R;
+            for (u64 w = beg + threadIdx.x; w < end; w += SK_NT) send[w] = 0ull;
         }
     }
 }
