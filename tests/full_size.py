@@ -1,0 +1,53 @@
+"""Size-independent checks of a finished count whose rows stay in HBM (3 * 10^9 of them on the 30x human stand-in): shared by
+tests/test_gpu_parity.py and tools/human_standin.py.  Test infrastructure, not product code."""
+import ctypes
+
+import numpy as np
+import torch
+
+
+def device_invariants(kc, st, hist, k, reads, nr, rl, dev):
+    """sum(i * hist[i]) == n_kmers (nothing saturates), sum(hist) == n_distinct, sum(hist[amin:]) == n_solid == rows, rows strictly
+    ascending, histogram of the rows' abundances == hist tail, n_kmers == number of full ACGT windows (closed form: <= 1 'N' per read)."""
+    h = hist.astype(np.int64)
+    idx = np.arange(len(h), dtype=np.int64)
+    sat = int(h[-1])
+    assert int(h.sum()) == st["n_distinct"], "sum(hist) != n_distinct"
+    assert int(h[2:].sum()) == st["n_solid"], "hist tail != n_solid"
+    kp, ap, n = kc.result_device()
+    assert n == st["n_solid"]
+    hip = ctypes.CDLL("libamdhip64.so")
+    step = 1 << 27
+    bins = torch.zeros(len(h), dtype=torch.int64, device=dev)
+    kbuf = torch.empty(step, dtype=torch.int64, device=dev); abuf = torch.empty(step, dtype=torch.int32, device=dev)
+    last = None; ab_sum = 0
+    for r0 in range(0, n, step):
+        m = min(step, n - r0)
+        hip.hipMemcpy(ctypes.c_void_p(kbuf.data_ptr()), ctypes.c_void_p(kp + r0 * 8), ctypes.c_size_t(m * 8), 3)
+        hip.hipMemcpy(ctypes.c_void_p(abuf.data_ptr()), ctypes.c_void_p(ap + r0 * 4), ctypes.c_size_t(m * 4), 3)
+        kk = kbuf[:m]
+        assert bool((kk[1:] > kk[:-1]).all()), "rows not strictly ascending"          # (k <= 31: values < 2^62, signed compare is safe)
+        if last is not None:
+            assert int(kk[0]) > last
+        last = int(kk[-1])
+        a = abuf[:m].to(torch.int64)
+        ab_sum += int(a.sum())
+        bins += torch.bincount(torch.clamp(a, max=len(h) - 1), minlength=len(h))
+    assert (bins.cpu().numpy()[2:] == h[2:]).all(), "histogram of the rows != hist tail"
+    # k-mer occurrences: rows carry the true abundance even where the histogram saturates at its last row
+    assert ab_sum + int(h[1]) == st["n_kmers"], "sum of abundances != n_kmers"
+    if not sat:
+        assert int((h * idx).sum()) == st["n_kmers"]
+    r = reads.view(nr, rl + 1)[:, :rl]
+    n_valid = 0
+    for r0 in range(0, nr, 8_000_000):
+        bad = r[r0:r0 + 8_000_000] == 78
+        has = bad.any(1)
+        q = bad.to(torch.uint8).argmax(1).to(torch.int64)
+        full = rl - k + 1
+        with_n = torch.clamp(q - k + 1, min=0) + torch.clamp(rl - q - k, min=0)
+        n_valid += int(torch.where(has, with_n, torch.full_like(with_n, full)).sum())
+    assert n_valid == st["n_kmers"], (n_valid, st["n_kmers"])
+    return {"rows_checked": int(n), "saturated_histogram_rows": sat}
+
+

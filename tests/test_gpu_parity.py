@@ -621,6 +621,108 @@ def test_full_size_repeat_rich(oracle, dev, monkeypatch):
     assert (hist == ref.histogram(10000)).all() and (rows[:, 0] == ref.lo[keep]).all() and (ab == ref.ab[keep]).all()
 
 
+def _device_rows(kc, dev):
+    """The sorted result of a one-word count as torch tensors (copied out of the context's buffers: they stay valid after it closes)."""
+    import ctypes
+    kp, ap, n = kc.result_device()
+    k = torch.empty(n, dtype=torch.int64, device=dev); a = torch.empty(n, dtype=torch.int32, device=dev)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy(ctypes.c_void_p(k.data_ptr()), ctypes.c_void_p(kp), ctypes.c_size_t(n * 8), 3)
+    hip.hipMemcpy(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(ap), ctypes.c_size_t(n * 4), 3)
+    return k, a
+
+
+def test_human_standin_on_one_gpu(dev):
+    """BASELINE.json configs[4] ("30x human short reads (~90 Gbp), k=31, abundance-min=2, ... multi-pass HBM partitioning"), the
+    stand-in SURVEY.md section 8(d) allows: 600 M x 150 bp reads of a repeat-rich 3 Gbp genome (one high-copy family, tandem arrays,
+    0.2 % poly-A reads: ONE k-mer with 1.4e8 occurrences) counted on ONE GPU -- 7.2e10 k-mers in 60 passes over the key space, the
+    passes' super-k-mer records materialised by 3 sweeps over the reads (the reference's own human run took 7 passes over its
+    input: doc/human_log:3-4; README.md:126-130 "below 10").  No retry, no sort fallback, every size-independent invariant holds
+    (3.4e9 sorted rows checked on the device)."""
+    from dsk_amd import KmerCounter, synth
+    from tests.full_size import device_invariants
+    nr, rl = 600_000_000, 150
+    genome = synth.make_genome_repeats(3_000_000_000, dev)
+    reads = synth.make_reads(genome, nr, rl, polya_rate=0.002)
+    del genome
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    with KmerCounter(kmer_size=31, abundance_min=2) as kc:
+        kc.set_reads_device(reads.data_ptr(), reads.numel())
+        kc.count()
+        st = kc.stats()
+        assert st["n_retries"] == 0 and st["sort_fallback"] == 0, st
+        assert st["n_passes"] > 20 and 1 <= st["n_read_sweeps"] <= 10, st
+        assert st["n_heavy"] >= 1 and st["n_ext_regions"] > 1000, st
+        inv = device_invariants(kc, st, kc.histogram(), 31, reads, nr, rl, dev)
+        assert inv["rows_checked"] == st["n_solid"] > 3_000_000_000 and inv["saturated_histogram_rows"] > 0
+    del reads
+    torch.cuda.empty_cache()
+
+
+def test_human_standin_shard_against_the_exact_path_and_eight_ranks(dev, monkeypatch):
+    """One GPU's share of the same job (75 M reads of the 3 Gbp repeat-rich genome: 9e9 k-mers at 3.75x coverage, several passes):
+    the fast path's rows and histogram must equal, row for row, what the exact histogram + scan path gives (DSKGPU_NO_OPT2), with no
+    retry on the fast path.  And the topology of the 8-GPU job, emulated: a quarter of that shard split over 8 ranks of one
+    in-process group (records by minimizer owner, device copies for the exchange) -- every rank stays on the histogram-free path
+    although one of them owns the poly-A k-mer, and the union of the ranks' rows equals the single-GPU count of the same reads."""
+    from dsk_amd import KmerCounter, KmerGroup, synth
+    from tests.full_size import device_invariants
+    nr, rl = 75_000_000, 150
+    genome = synth.make_genome_repeats(3_000_000_000, dev)
+    reads = synth.make_reads(genome, nr, rl, polya_rate=0.002)
+    del genome
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    with KmerCounter(kmer_size=31, abundance_min=2) as kc:
+        kc.set_reads_device(reads.data_ptr(), reads.numel())
+        kc.count()
+        st, hist = kc.stats(), kc.histogram()
+        assert st["n_retries"] == 0 and st["sort_fallback"] == 0 and st["n_passes"] > 1, st
+        device_invariants(kc, st, hist, 31, reads, nr, rl, dev)
+        k1, a1 = _device_rows(kc, dev)
+    torch.cuda.empty_cache()
+    monkeypatch.setenv("DSKGPU_NO_OPT2", "1")
+    with KmerCounter(kmer_size=31, abundance_min=2) as kc:
+        kc.set_reads_device(reads.data_ptr(), reads.numel())
+        kc.count()
+        st2 = kc.stats()
+        assert (st2["n_kmers"], st2["n_distinct"], st2["n_solid"]) == (st["n_kmers"], st["n_distinct"], st["n_solid"])
+        assert (kc.histogram() == hist).all()
+        k2, a2 = _device_rows(kc, dev)
+    monkeypatch.delenv("DSKGPU_NO_OPT2")
+    assert torch.equal(k1, k2) and torch.equal(a1, a2)
+    del k1, a1, k2, a2
+    torch.cuda.empty_cache()
+    # ---- 8 ranks on a quarter of the shard
+    nq = nr // 4
+    quarter = reads[: nq * (rl + 1)]
+    with KmerCounter(kmer_size=31, abundance_min=2) as kc:
+        kc.set_reads_device(quarter.data_ptr(), quarter.numel())
+        kc.count()
+        sq, hq = kc.stats(), kc.histogram()
+        kq, aq = _device_rows(kc, dev)
+    torch.cuda.empty_cache()
+    ranks = 8
+    per = nq // ranks
+    with KmerGroup([0] * ranks, kmer_size=31, abundance_min=2, nb_partitions=1, timing=True) as g:
+        for r in range(ranks):
+            lo, hi = r * per * (rl + 1), (nq if r == ranks - 1 else (r + 1) * per) * (rl + 1)
+            g.rank(r).set_reads_device(quarter.data_ptr() + lo, hi - lo)
+        g.count()
+        sg = g.stats()
+        assert (sg["n_kmers"], sg["n_distinct"], sg["n_solid"]) == (sq["n_kmers"], sq["n_distinct"], sq["n_solid"])
+        assert (g.histogram() == hq).all()
+        per_rank = [g.rank(r).stats() for r in range(ranks)]
+        stages = [dict(g.rank(r).stage_times()) for r in range(ranks)]
+        assert all(s["n_retries"] == 0 and s["sort_fallback"] == 0 for s in per_rank), per_rank
+        assert all("hist1" not in t and "hist2" not in t for t in stages)
+        assert sum(s["n_heavy"] for s in per_rank) >= 1
+        rows = [_device_rows(g.rank(r), dev) for r in range(ranks)]
+    kk = torch.cat([x[0] for x in rows]); aa = torch.cat([x[1] for x in rows])
+    del rows
+    order = torch.argsort(kk)
+    assert torch.equal(kk[order], kq) and torch.equal(aa[order], aq)
+
+
 def test_full_size_multi_pass(dev):
     """BASELINE.json configs[4] ("multi-pass HBM partitioning"): a full-size input counted in >= 8 passes over the key
     space (forced with max_pass_mkeys on the 25 M-read shard: 3.0e9 k-mers, <= 400 M per pass) must give row for row
