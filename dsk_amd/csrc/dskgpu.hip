@@ -383,22 +383,26 @@ int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chu
     CKL("k_scatter");
     return DSKGPU_OK;
 }
-// super-k-mer records as the source of the histogram-free level-1 scatter (one- and two-word keys); HEAVY: with k-mers counted apart (one-word keys)
-template <int W, bool HEAVY = false>
+// super-k-mer records as the source of the histogram-free level-1 scatter (one- and two-word keys); HEAVY: with k-mers counted apart
+// (one-word keys); MODE 3: one of several passes over the records of a multi-GPU receive side (the pass filter on every key)
+template <int W, bool HEAVY = false, int MODE = 1>
 int launch_scatter_rec(dskgpu_ctx* ctx, const ChunkDesc* descs, const u32* d_nch, u64 max_chunks, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1) {
     const size_t lds = scatter_lds(W, P, !o1.uslice);
     const unsigned grid = scatter_grid(ctx, W, P, max_chunks, !o1.uslice);
-    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, 2, 1, true, HEAVY>)); if (e) return e; }
-    hipLaunchKernelGGL((k_scatter<W, 2, 1, true, HEAVY>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->rec_src, (const u32*)nullptr,
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, 2, MODE, true, HEAVY>)); if (e) return e; }
+    hipLaunchKernelGGL((k_scatter<W, 2, MODE, true, HEAVY>), dim3(grid), dim3(SC_NT), lds, ctx->stream, ctx->rec_src, (const u32*)nullptr,
                        (const typename KeyT<W>::T*)nullptr, descs, d_nch, (const u32*)nullptr, out, (int)ctx->cfg.kmer_size, ds, P, o1);
     CKL("k_scatter(records)");
     return DSKGPU_OK;
 }
-template <> int launch_scatter_rec<4, false>(dskgpu_ctx*, const ChunkDesc*, const u32*, u64, KN<4>*, DigitSpec, u32, Opt1Spec) { return DSKGPU_E_STATE; }
 template <int W>
 int launch_scatter_rec_h(dskgpu_ctx* ctx, bool heavy, const ChunkDesc* descs, const u32* d_nch, u64 max_chunks, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1) {
-    if constexpr (W == 1) { if (heavy) return launch_scatter_rec<1, true>(ctx, descs, d_nch, max_chunks, out, ds, P, o1); }
-    return launch_scatter_rec<W, false>(ctx, descs, d_nch, max_chunks, out, ds, P, o1);
+    const bool mp = ds.npass > 1;
+    if constexpr (W == 1) {
+        if (heavy) return mp ? launch_scatter_rec<1, true, 3>(ctx, descs, d_nch, max_chunks, out, ds, P, o1) : launch_scatter_rec<1, true, 1>(ctx, descs, d_nch, max_chunks, out, ds, P, o1);
+    }
+    if constexpr (W <= 2) return mp ? launch_scatter_rec<W, false, 3>(ctx, descs, d_nch, max_chunks, out, ds, P, o1) : launch_scatter_rec<W, false, 1>(ctx, descs, d_nch, max_chunks, out, ds, P, o1);
+    else return DSKGPU_E_STATE;                     // (records carry k <= 64)
 }
 
 // key-array source with aligned write-out (k_scatter_al) when its LDS footprint fits one CU
@@ -1125,7 +1129,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             CK(ctx->bufA.ensure(std::max<u64>(W == 1 ? slots * 4 : slots * sizeof(Key), (cap + 1) * sizeof(Key))));
             if (W > 1) CK(ctx->abund2.ensure(slots * 4));
         }
-        bool opt1 = opt_cap && !ctx->opt1_off && !ctx->tune.no_opt1 && (npass == 1 || from_reads);   // several passes: reads only (MODE 3)
+        bool opt1 = opt_cap && !ctx->opt1_off && !ctx->tune.no_opt1 && (npass == 1 || from_reads || W <= 2);   // several passes over records / a key array (the multi-GPU receive side): one- and two-word keys
         if (from_rec && (!opt1 || W > 2 || ctx->tune.no_recsrc)) { int e = records_to_keys(); if (e) return e; }
         Opt1Spec o1{nullptr, 0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2, nullptr, nullptr, 0u, nullptr, 0ull, 0u};
         unsigned grid1 = 0;
@@ -1316,7 +1320,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                                                      : launch_scatter_m<1, 0, 1, true, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
                 else rc = DSKGPU_E_STATE;
             } else if (nheavy) {
-                if constexpr (W == 1) rc = launch_scatter_m<1, 1, 1, true, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+                if constexpr (W == 1) rc = npass > 1 ? launch_scatter_m<1, 1, 3, true, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1)
+                                                     : launch_scatter_m<1, 1, 1, true, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
                 else rc = DSKGPU_E_STATE;
             }
             else if (from_reads && npass > 1) rc = launch_scatter_m<W, 0, 3, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
@@ -1329,6 +1334,10 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             }
 #endif
             else if (from_reads) rc = launch_scatter_m<W, 0, 1, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+            else if (npass > 1) {
+                if constexpr (W <= 2) rc = launch_scatter_m<W, 1, 3, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+                else rc = DSKGPU_E_STATE;
+            }
             else rc = launch_scatter_m<W, 1, 1, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
             if (rc) return rc;
             ctx->mark("scatter1");

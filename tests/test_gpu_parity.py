@@ -813,6 +813,49 @@ def test_multi_pass_on_the_receive_side(oracle, dev, k, explicit):
         c.close()
 
 
+@pytest.mark.parametrize("k,explicit", [(31, False), (31, True), (63, False)])
+def test_receive_side_multi_pass_on_the_fast_path(oracle, dev, k, explicit):
+    """The receive side of a multi-GPU job whose share of the k-mer space needs several passes (30x human on 8 GPUs: 9e9 k-mers per
+    rank), with repeat-rich reads: every pass runs the histogram-free level 1 with the pass filter straight from the RECORDS
+    (k_scatter<W, 2, 3>; from the key array for explicit keys), slices sized from the sample, heavy k-mers counted apart, region
+    chains at level 2 -- no histogram pass, no retry, rows equal to the oracle's."""
+    from dsk_amd import KmerCounter, synth
+    world = 2
+    reads, gl, nr, rl = synth.make_workload("small_repeats", dev)
+    host = reads.cpu().numpy()
+    per = nr // world
+    ctxs, sends, counts, shards = [], [], [], []
+    for r in range(world):
+        lo, hi = r * per * (rl + 1), (nr if r == world - 1 else (r + 1) * per) * (rl + 1)
+        shard = reads[lo:hi].clone()
+        kc = KmerCounter(kmer_size=k, abundance_min=2, world_size=world, rank=r, mg_explicit=explicit, max_pass_mkeys=5, timing=True)
+        kc.set_reads_device(shard.data_ptr(), shard.numel())
+        send = torch.zeros(kc.mg_send_capacity_words(), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        counts.append(kc.mg_scatter(send.data_ptr(), send.numel()))
+        ctxs.append(kc); sends.append(send); shards.append(shard)
+    rows_k, rows_a, hist = [], [], np.zeros(10001, np.uint64)
+    for d in range(world):
+        recv = torch.cat([sends[src][sum(counts[src][:d]): sum(counts[src][:d]) + counts[src][d]] for src in range(world)])
+        torch.cuda.synchronize()
+        ctxs[d].mg_count(recv.data_ptr(), recv.numel())
+        st, stages = ctxs[d].stats(), dict(ctxs[d].stage_times())
+        assert st["n_passes"] >= 3 and st["n_levels"] == 2, st
+        assert st["n_retries"] == 0 and "hist1" not in stages and "hist2" not in stages, (st, stages)
+        kk, aa = ctxs[d].rows()
+        rows_k.append(kk); rows_a.append(aa); hist += ctxs[d].histogram()
+    assert sum(c.stats()["n_ext_regions"] for c in ctxs) > 0
+    kk = np.concatenate(rows_k); aa = np.concatenate(rows_a)
+    ref = oracle.count(host, k)
+    assert (hist == ref.histogram(10000)).all()
+    keep = ref.ab >= 2
+    order = np.argsort(kk[:, 0]) if k <= 32 else np.lexsort((kk[:, 0], kk[:, 1]))
+    assert (kk[order] == ref.words()[keep]).all() and (aa[order] == ref.ab[keep]).all()
+    assert sum(c.stats()["n_kmers"] for c in ctxs) == ref.total
+    for c in ctxs:
+        c.close()
+
+
 @pytest.mark.parametrize("world,k,explicit", [(2, 31, False), (4, 27, False), (2, 63, False), (8, 20, False), (4, 46, False), (2, 64, False),
                                               (2, 32, False), (2, 31, True), (2, 63, True), (4, 15, False)])
 def test_multi_gpu_path_on_one_device(oracle, golden_dir, dev, world, k, explicit):
