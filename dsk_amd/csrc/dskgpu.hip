@@ -1325,14 +1325,6 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 else rc = DSKGPU_E_STATE;
             }
             else if (from_reads && npass > 1) rc = launch_scatter_m<W, 0, 3, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
-#ifdef DSK_L1_ABLATE
-            else if (from_reads && getenv("DSKGPU_L1_ABL")) {      // the ablated launch first (its own mark), then the real one
-                Opt1Spec oa = o1; oa.abl = (u32)atoi(getenv("DSKGPU_L1_ABL"));
-                rc = launch_scatter_m<W, 0, 1, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, oa);
-                ctx->mark("scatter1_abl");
-                if (!rc) rc = launch_scatter_m<W, 0, 1, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
-            }
-#endif
             else if (from_reads) rc = launch_scatter_m<W, 0, 1, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
             else if (npass > 1) {
                 if constexpr (W <= 2) rc = launch_scatter_m<W, 1, 3, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);

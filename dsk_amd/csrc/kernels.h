@@ -539,9 +539,6 @@ struct Opt1Spec { const u32* boff; u32 area, dump; u32* ovf; u32* fill; u32 R; u
                   // the chunks [g0, g0 + gn) (cur_state == nullptr: one launch over all chunks), the blocks' write cursors parked in cur_state[block * P + bin] in between;
                   // `resume` picks them up, only the `last` launch reports fill / overflow / keys placed
                   u32* cur_state; u32 g0, gn, resume, last;
-#ifdef DSK_L1_ABLATE
-                  u32 abl;            // timing experiments (tools/l1_ablate.sh): 1 = no global stores, 2 = no write-out, 3 = no staging either, 4 = generation only
-#endif
                   };
 #define L0_MAX_PASSES 16           // passes a level-0 sweep materialises together (bins of the MODE 4 scatter)
 
@@ -593,9 +590,6 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
         // of those stores (a full store round trip per tile); issued before them, they are older and the wait leaves the
         // stores in flight -- which needs their number to be known: the write-out is a fixed KPT / 4 trips of 4 predicated stores
         auto rank_and_stage = [&](Key (&h)[KPT], u32 vm) {
-#ifdef DSK_L1_ABLATE
-            if (o1.abl >= 4) { u64 x = 0; for (int j = 0; j < KPT; ++j) x ^= digit_word(h[j]); if (x == 0x1234567ull) out[0] = h[0]; return; }
-#endif
             if constexpr (HEAVY && W == 1) {      // the k-mers counted apart leave the tile here (one-word keys)
 #pragma unroll
                 for (int x = 0; x < HV_KEYS; ++x) {
@@ -628,17 +622,11 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
             lds_barrier();
             tile_scan<SC_NT>(cnt, off, delta, cur, (int)P, wsum, tot, OPT ? SliceGuard{o1.uslice ? nullptr : lim, o1.dump, o1.uslice, first} : SliceGuard{nullptr, 0u, 0u, 0u});
             lds_barrier();
-#ifdef DSK_L1_ABLATE
-            if (o1.abl >= 3) { lds_barrier(); return; }
-#endif
 #pragma unroll
             for (int j = 0; j < KPT; ++j) if ((rk[j] >> 16) < P) stage[off[rk[j] >> 16] + (rk[j] & 0xFFFFu)] = h[j];
             lds_barrier();
         };
         auto write_out = [&]() {
-#ifdef DSK_L1_ABLATE
-            if (o1.abl >= 2) return;
-#endif
             const u32 ntile = *tot;
 #pragma unroll
             for (int it = 0; it < (KPT + 3) / 4; ++it) {
@@ -658,9 +646,6 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                     // behind the last bin: a lane past the tile's keys stores there instead of being masked off, so that every trip
                     // issues exactly 4 stores -- the compiler can then count them (see rank_and_stage)
                     if (OPT && MODE == 4) out[i < ntile ? lob[key_digit<MODE>(digit_word(hk[u]), ds) & (L0_MAX_PASSES - 1)] + (u64)(dd[u] + i) : o1.obase0 + (u64)(o1.dump + i)] = hk[u];
-#ifdef DSK_L1_ABLATE
-                    else if (OPT && o1.abl == 1) { if (digit_word(hk[u]) == 0x1234567ull + dd[u]) out[o1.dump + i] = hk[u]; }
-#endif
                     else if (OPT) out[i < ntile ? (u64)(dd[u] + i) : (u64)(o1.dump + i)] = hk[u];
                     else if (i < ntile) out[(u64)(dd[u] + i)] = hk[u];
                 }
@@ -735,9 +720,6 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
             }
         }
     }
-#ifdef DSK_L1_ABLATE
-    if (OPT && o1.abl) return;
-#endif
     if (OPT) {      // how much of each of its slices this block filled; report a slice that was outgrown
         lds_barrier();
         if constexpr (HEAVY) {      // the occurrences of the k-mers counted apart (every launch of a sliced receive reports its own; k_heavy_rows adds
