@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the file -> .h5 wall-clock block (dsk binary)")
     ap.add_argument("--no-repeat-rich", action="store_true", help="skip the repeat-rich twin of the workload (extra block, headline unchanged)")
     ap.add_argument("--no-human-standin", action="store_true", help="skip the configs[4] stand-in block (600 M x 150 bp of a repeat-rich 3 Gbp genome on this one GPU, ~20 s)")
+    ap.add_argument("--no-place-compare", action="store_true", help="skip the plain-hipMalloc leg that yields ms_per_step_no_place (profiling runs: one set of launches per kernel)")
     ap.add_argument("--no-place", action="store_true", help="plain hipMalloc for the big device buffers instead of the best-placed of 8 candidates (DSKGPU_F_PLACE)")
     return ap.parse_args()
 
@@ -359,7 +360,7 @@ def main():
     # the same steps on plain hipMalloc buffers first (3 warm-up + 10 timed, same process, before any context asks for placement --
     # the flag is process-wide): reported next to the headline as ms_per_step_no_place
     no_place_ms = None
-    if world == 1 and not args.no_place:
+    if world == 1 and not args.no_place and not args.no_place_compare:
         with KmerCounter(kmer_size=args.kmer_size, abundance_min=args.abundance_min, device=local_rank, sort=not args.no_sort, stream=stream) as kp:
             kp.set_reads_device(reads.data_ptr(), n_bytes)
             for _ in range(3):
