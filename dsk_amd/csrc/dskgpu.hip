@@ -877,6 +877,17 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
             // are the rows that share all of them
             const int e = msd_sort_pairs(ctx, ctx->srt_k.as<u64>(), ctx->srt_idx.as<u32>(), ctx->s_val.as<u64>(), ctx->srt_idx2.as<u32>(), n, 63);
             if (e) return e;
+            // sub-buckets the sort listed for another round (thousands of rows sharing 26 and more leading bits): ordered before the rows are
+            // gathered by index (one host round trip; a 63-bit prefix leaves ties to k_fix_runs_multi either way)
+            CK(hipMemcpyAsync(&ctx->h_back[3], flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipMemcpyAsync(ctx->h_ovs.data(), ctx->rs_ovs.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+            if (!ctx->h_back[3] && ctx->h_ovs[0]) {
+                ctx->rs_res_k = ctx->srt_k.as<u64>(); ctx->rs_res_v = ctx->srt_idx.as<u32>(); ctx->rs_tmp_k = ctx->s_val.as<u64>(); ctx->rs_tmp_v = ctx->srt_idx2.as<u32>();
+                const int e2 = sort_oversize(ctx);
+                if (e2) return e2;
+                ctx->h_ovs.assign(1, 0);
+            }
             idx = ctx->srt_idx.as<u32>(); skey = ctx->srt_k.as<u64>(); run_shift = 0; ties = ctx->scalars.as<u32>() + SC_RSTIES;
         } else {
             const unsigned begin_bit = 63u - SORT_TOP_BITS;
@@ -901,7 +912,6 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
         else hipLaunchKernelGGL(k_fix_runs_multi<4>, dim3(gfix), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), skey, n, run_shift, flag, ties);
         CKL("sort_rows");
         CK(hipMemcpyAsync(&ctx->h_back[3], flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (msd) CK(hipMemcpyAsync(ctx->h_ovs.data(), ctx->rs_ovs.p, 4, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sort_partial = true;
         for (int x = 0; x < W; ++x) ctx->res_w[x] = ctx->srt_w[x].as<u64>();
         ctx->res_ab = ctx->srt_ab.as<u32>();
