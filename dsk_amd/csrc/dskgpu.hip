@@ -205,6 +205,7 @@ struct dskgpu_ctx {
     bool sk_exact = false;         // a slice overflowed on these reads: exact counts from now on
     SkParams sk_sp{};
     DevBuf sk_sums, sk_cbase, sk_keys, sk_table, sk_load, sk_sent, sk_lay;      // sk_lay: [region base per owner: u64 x 64][slice per owner: u32 x 64] of a record-based level-0 sweep
+    u64 last_rows = 0;             // solid rows of the last count of the current reads (0 = not counted yet): sizes what a multi-pass count keeps free for its rows
     bool rec_l0_off = false;       // these reads do not take the record-based level 0 (a slice of its sampled layout overflowed)
     u64 h_sk_sent[SK_MAX_OWNERS] = {0};      // k-mers inside the records the last mg_scatter wrote for every owner
     u64 h_sk_est[SK_MAX_OWNERS] = {0};       // sampled layout: estimated k-mers per owner (k_sk_hist on every 16th tile, scaled)
@@ -374,7 +375,7 @@ unsigned scatter_grid(const dskgpu_ctx* ctx, int W, u32 P, u64 max_chunks, bool 
 }
 template <int W, int SRC, int MODE, bool OPT = false, bool HEAVY = false>
 int launch_scatter_m(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const ChunkDesc* descs, const u32* d_nch,
-                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1 = Opt1Spec{nullptr, 0u, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 0u, nullptr, 0ull, 0u}) {
+                     u64 max_chunks, const u32* scanned, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1 = Opt1Spec{nullptr, 0u, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 0u, nullptr, 0ull, {0ull, 0ull, 0ull, 0ull}, 0u}) {
     const size_t lds = scatter_lds(W, P, OPT && !o1.uslice);
     const unsigned grid = scatter_grid(ctx, W, P, max_chunks, OPT && !o1.uslice);
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_scatter<W, SRC, MODE, OPT, HEAVY>)); if (e) return e; }
@@ -398,8 +399,8 @@ int launch_scatter_rec(dskgpu_ctx* ctx, const ChunkDesc* descs, const u32* d_nch
 template <int W>
 int launch_scatter_rec_h(dskgpu_ctx* ctx, bool heavy, const ChunkDesc* descs, const u32* d_nch, u64 max_chunks, typename KeyT<W>::T* out, DigitSpec ds, u32 P, Opt1Spec o1) {
     const bool mp = ds.npass > 1;
-    if constexpr (W == 1) {
-        if (heavy) return mp ? launch_scatter_rec<1, true, 3>(ctx, descs, d_nch, max_chunks, out, ds, P, o1) : launch_scatter_rec<1, true, 1>(ctx, descs, d_nch, max_chunks, out, ds, P, o1);
+    if constexpr (W <= 2) {
+        if (heavy) return mp ? launch_scatter_rec<W, true, 3>(ctx, descs, d_nch, max_chunks, out, ds, P, o1) : launch_scatter_rec<W, true, 1>(ctx, descs, d_nch, max_chunks, out, ds, P, o1);
     }
     if constexpr (W <= 2) return mp ? launch_scatter_rec<W, false, 3>(ctx, descs, d_nch, max_chunks, out, ds, P, o1) : launch_scatter_rec<W, false, 1>(ctx, descs, d_nch, max_chunks, out, ds, P, o1);
     else return DSKGPU_E_STATE;                     // (records carry k <= 64)
@@ -983,7 +984,14 @@ template <> int expand_records<4>(dskgpu_ctx*, u64) { return DSKGPU_E_STATE; }  
 // large share of a bin.  k_collect_heavy gathers about HV_COLLECT sampled keys of up to HV_SLOTS such bins; a k-mer that makes up
 // >= 5 % of a bin's collected keys is heavy: the HV_KEYS heaviest go to hv_buf = [keys | counts | rows], and the level-1
 // scatter counts them apart.  ctx->h_load is reduced by what they take away (slice sizes, order of the level-2 segments).
-int find_heavy(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u32 nts, const Plan& pl, u32* nheavy_out) {
+// hv_buf (u64 words): [keys: HV_KEYS x W][counts: HV_KEYS][rows, word x of row r at (W + 1 + x) * HV_KEYS + r][abundances: HV_KEYS x u32]
+template <int W> struct HvLayout { static constexpr size_t keys = 0, counts = (size_t)HV_KEYS * W, rows = (size_t)HV_KEYS * (W + 1), ab = (size_t)HV_KEYS * (2 * W + 1), words = (size_t)HV_KEYS * (2 * W + 2); };
+template <int W>
+int find_heavy(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_keys_in, u32 nts, const Plan& pl, u32* nheavy_out) {
+    typedef typename KeyT<W>::T Key;
+    struct HK { u64 w[W]; bool operator<(const HK& o) const { for (int x = W - 1; x >= 0; --x) if (w[x] != o.w[x]) return w[x] < o.w[x]; return false; }
+                bool operator==(const HK& o) const { for (int x = 0; x < W; ++x) if (w[x] != o.w[x]) return false; return true; } };
+    static_assert(sizeof(HK) == sizeof(Key), "host mirror of a device key");
     *nheavy_out = 0;
     const u32 P1 = pl.P1;
     std::vector<double> sorted(ctx->h_load);
@@ -992,12 +1000,15 @@ int find_heavy(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u32 nts, 
     std::vector<u32> flagged;
     for (u32 b = 0; b < P1; ++b) if (ctx->h_load[b] > 1.2 * median + 4096.0) flagged.push_back(b);
     if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] find_heavy: median load %.0f, %zu bins above 1.2 x\n", median, flagged.size());
-    if (flagged.empty() && ctx->tune.force_heavy) {
-        CK(ctx->hv_buf.ensure((size_t)HV_KEYS * (8 + 8 + 8 + 4)));
-        CK(hipMemsetAsync(ctx->hv_buf.p, 0xFF, HV_KEYS * 8, ctx->stream));
-        CK(hipMemsetAsync(ctx->hv_buf.as<u64>() + HV_KEYS, 0, HV_KEYS * 8, ctx->stream));
-        *nheavy_out = 1;
-    }
+    u64* hvb = nullptr;
+    auto reset_buf = [&]() -> int {      // keys all-ones (= unused), counts zero
+        CK(ctx->hv_buf.ensure(HvLayout<W>::words * 8));
+        hvb = ctx->hv_buf.as<u64>();
+        CK(hipMemsetAsync(hvb + HvLayout<W>::keys, 0xFF, (size_t)HV_KEYS * W * 8, ctx->stream));
+        CK(hipMemsetAsync(hvb + HvLayout<W>::counts, 0, HV_KEYS * 8, ctx->stream));
+        return DSKGPU_OK;
+    };
+    if (flagged.empty() && ctx->tune.force_heavy) { const int e = reset_buf(); if (e) return e; *nheavy_out = 1; }
     if (flagged.empty()) return DSKGPU_OK;
     std::sort(flagged.begin(), flagged.end(), [&](u32 a, u32 b) { return ctx->h_load[a] > ctx->h_load[b]; });
     if (flagged.size() > HV_SLOTS) flagged.resize(HV_SLOTS);
@@ -1007,8 +1018,8 @@ int find_heavy(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u32 nts, 
     CK(ctx->hv_lut.ensure(P1));
     const unsigned grid = (unsigned)std::min<u64>(nts, (u64)ctx->num_cu * 2);
     const size_t per_slot = (size_t)grid * HV_BLOCK_KEYS;
-    CK(ctx->hv_collect.ensure((size_t)HV_SLOTS * per_slot * 8 + (size_t)HV_SLOTS * grid * 4 + HV_SLOTS * 4));
-    u32* d_kept = reinterpret_cast<u32*>(ctx->hv_collect.as<u64>() + (size_t)HV_SLOTS * per_slot);
+    CK(ctx->hv_collect.ensure((size_t)HV_SLOTS * per_slot * sizeof(Key) + (size_t)HV_SLOTS * grid * 4 + HV_SLOTS * 4));
+    u32* d_kept = reinterpret_cast<u32*>(ctx->hv_collect.as<Key>() + (size_t)HV_SLOTS * per_slot);
     u32* d_step = d_kept + (size_t)HV_SLOTS * grid;
     // keep every step-th sampled key of a bin, so that about HV_COLLECT are collected (h_mom: the bin's keys in the sample)
     ctx->h_hv_step.assign(HV_SLOTS, 1);
@@ -1020,21 +1031,21 @@ int find_heavy(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u32 nts, 
     auto launch = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(SC_NT), 0, ctx->stream, (const u64*)ctx->packed.as<u64>(), (const u32*)ctx->inval.as<u32>(), d_keys_in,
                            (const ChunkDesc*)ctx->smp_descs.as<ChunkDesc>(), (const u32*)(sc + SC_NCH_S), (int)ctx->cfg.kmer_size, pl.d1, P1,
-                           (const unsigned char*)ctx->hv_lut.as<unsigned char>(), d_kept, ctx->hv_collect.as<u64>(), (const u32*)d_step);
+                           (const unsigned char*)ctx->hv_lut.as<unsigned char>(), d_kept, ctx->hv_collect.as<Key>(), (const u32*)d_step);
     };
-    if (from_reads) { if (mp) launch(k_collect_heavy<0, 3>); else launch(k_collect_heavy<0, 1>); }
-    else { if (mp) launch(k_collect_heavy<1, 3>); else launch(k_collect_heavy<1, 1>); }
+    if (from_reads) { if (mp) launch(k_collect_heavy<W, 0, 3>); else launch(k_collect_heavy<W, 0, 1>); }
+    else { if (mp) launch(k_collect_heavy<W, 1, 3>); else launch(k_collect_heavy<W, 1, 1>); }
     CKL("k_collect_heavy");
     ctx->h_hv_cnt.resize(nf * grid);
-    ctx->h_hv_coll.resize(nf * per_slot);
+    ctx->h_hv_coll.resize(nf * per_slot * W);
     CK(hipMemcpyAsync(ctx->h_hv_cnt.data(), d_kept, nf * grid * 4, hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipMemcpyAsync(ctx->h_hv_coll.data(), ctx->hv_collect.p, nf * per_slot * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(ctx->h_hv_coll.data(), ctx->hv_collect.p, nf * per_slot * sizeof(Key), hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     // candidates over all flagged bins: (estimated occurrences, key, bin); the HV_KEYS largest are counted apart
-    struct Cand { double est; u64 key; u32 bin; };
+    struct Cand { double est; HK key; u32 bin; };
     std::vector<Cand> cands;
     for (size_t f = 0; f < nf; ++f) {
-        u64* kk = ctx->h_hv_coll.data() + f * per_slot;       // the blocks' kept keys, made dense in place
+        HK* kk = reinterpret_cast<HK*>(ctx->h_hv_coll.data()) + f * per_slot;       // the blocks' kept keys, made dense in place
         u32 n = 0;
         for (unsigned g = 0; g < grid; ++g) {
             const u32 c = std::min<u32>(ctx->h_hv_cnt[f * grid + g], HV_BLOCK_KEYS);
@@ -1054,18 +1065,17 @@ int find_heavy(dskgpu_ctx* ctx, bool from_reads, const u64* d_keys_in, u32 nts, 
     }
     std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.est > b.est; });
     if (cands.size() > HV_KEYS) cands.resize(HV_KEYS);
-    ctx->h_hv_keys.assign(HV_KEYS, DSK_EMPTY);
+    ctx->h_hv_keys.assign((size_t)HV_KEYS * W, DSK_EMPTY);
     for (size_t x = 0; x < cands.size(); ++x) {
-        ctx->h_hv_keys[x] = cands[x].key;
+        for (int y = 0; y < W; ++y) ctx->h_hv_keys[x * W + y] = cands[x].key.w[y];
         ctx->h_load[cands[x].bin] -= cands[x].est;            // they never reach the bin: slices and the order of the level-2 segments follow
         ctx->h_seg_work[cands[x].bin] -= cands[x].est;
     }
     u32 nheavy = (u32)cands.size();
     if (!nheavy && ctx->tune.force_heavy) nheavy = 1;         // (timing experiments: the HEAVY kernel with no heavy key)
     if (nheavy) {
-        CK(ctx->hv_buf.ensure((size_t)HV_KEYS * (8 + 8 + 8 + 4)));
-        CK(hipMemcpyAsync(ctx->hv_buf.p, ctx->h_hv_keys.data(), HV_KEYS * 8, hipMemcpyHostToDevice, ctx->stream));
-        CK(hipMemsetAsync(ctx->hv_buf.as<u64>() + HV_KEYS, 0, HV_KEYS * 8, ctx->stream));
+        { const int e = reset_buf(); if (e) return e; }
+        CK(hipMemcpyAsync(hvb + HvLayout<W>::keys, ctx->h_hv_keys.data(), (size_t)HV_KEYS * W * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     *nheavy_out = nheavy;
     return DSKGPU_OK;
@@ -1141,7 +1151,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         }
         bool opt1 = opt_cap && !ctx->opt1_off && !ctx->tune.no_opt1 && (npass == 1 || from_reads || W <= 2);   // several passes over records / a key array (the multi-GPU receive side): one- and two-word keys
         if (from_rec && (!opt1 || W > 2 || ctx->tune.no_recsrc)) { int e = records_to_keys(); if (e) return e; }
-        Opt1Spec o1{nullptr, 0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2, nullptr, nullptr, 0u, nullptr, 0ull, 0u};
+        Opt1Spec o1{nullptr, 0u, 0u, sc + SC_OVF1, nullptr, ctx->sk_sp.R, ctx->gstats.as<u64>() + 2, nullptr, nullptr, 0u, nullptr, 0ull, {0ull, 0ull, 0ull, 0ull}, 0u};
         unsigned grid1 = 0;
         u32 nheavy = 0;                  // k-mers the level-2 scatter counts apart (find_heavy)
         // (the per-bin slice ends need 4 more bytes of LDS per bin: plans above 1634 level-1 bins keep UNIFORM slices, mean-sized, no sample)
@@ -1256,8 +1266,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 // its bin stands far above the others.  Collect sampled keys of those bins, find the dominant k-mer(s) on the host
                 // and let the level-1 scatter count them apart (k_scatter<.., HEAVY>) -- everything lighter is what the region
                 // chains are for.
-                if constexpr (W == 1) {
-                    if (sampled && opt_cap && !ctx->tune.no_heavy) { const int e2 = find_heavy(ctx, from_reads, d_keys_s, (u32)nts, pl, &nheavy); if (e2) return e2; }
+                if constexpr (W <= 2) {
+                    if (sampled && opt_cap && !ctx->tune.no_heavy) { const int e2 = find_heavy<W>(ctx, from_reads, d_keys_s, (u32)nts, pl, &nheavy); if (e2) return e2; }
                 }
                 ctx->mark("sample1");
             }
@@ -1309,7 +1319,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         int rc;
         const ChunkDesc* dd1 = ctx->descs1.as<ChunkDesc>();
         if (opt1) {
-            if (nheavy) { o1.hv_keys = ctx->hv_buf.as<u64>(); o1.hv_cnt = reinterpret_cast<unsigned long long*>(ctx->hv_buf.as<u64>() + HV_KEYS); }
+            if constexpr (W <= 2) { if (nheavy) { o1.hv_keys = ctx->hv_buf.as<u64>() + HvLayout<W>::keys; o1.hv_cnt = reinterpret_cast<unsigned long long*>(ctx->hv_buf.as<u64>() + HvLayout<W>::counts); } }
             if (from_rec && ctx->rec_slice_end.size() > 1) {
                 // the records arrive in slices: one launch per slice, each behind the arrival of its slice (rec_gate), the blocks'
                 // write cursors parked in between
@@ -1326,12 +1336,12 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             }
             else if (from_rec) { if (!(rc = rec_gate_all(ctx))) rc = launch_scatter_rec_h<W>(ctx, nheavy != 0, dd1, sc + SC_NCH1, nch1, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1); }
             else if (nheavy && from_reads) {
-                if constexpr (W == 1) rc = npass > 1 ? launch_scatter_m<1, 0, 3, true, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1)
-                                                     : launch_scatter_m<1, 0, 1, true, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+                if constexpr (W <= 2) rc = npass > 1 ? launch_scatter_m<W, 0, 3, true, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1)
+                                                     : launch_scatter_m<W, 0, 1, true, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
                 else rc = DSKGPU_E_STATE;
             } else if (nheavy) {
-                if constexpr (W == 1) rc = npass > 1 ? launch_scatter_m<1, 1, 3, true, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1)
-                                                     : launch_scatter_m<1, 1, 1, true, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
+                if constexpr (W <= 2) rc = npass > 1 ? launch_scatter_m<W, 1, 3, true, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1)
+                                                     : launch_scatter_m<W, 1, 1, true, true>(ctx, d_keys_in, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
                 else rc = DSKGPU_E_STATE;
             }
             else if (from_reads && npass > 1) rc = launch_scatter_m<W, 0, 3, true>(ctx, nullptr, dd1, sc + SC_NCH1, nch1, nullptr, ctx->bufA.as<Key>(), pl.d1, pl.P1, o1);
@@ -1478,12 +1488,15 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 CKL("k_count_chained");
             }
         }
-        if (nheavy) {      // the k-mers the level-1 scatter counted apart: histogram, distinct count, rows (appended behind the compacted ones below)
+        if constexpr (W <= 2) {
+          if (nheavy) {      // the k-mers the level-1 scatter counted apart: histogram, distinct count, rows (appended behind the compacted ones below)
             const u32 slots = HV_KEYS;
             u64* hvb = ctx->hv_buf.as<u64>();
-            hipLaunchKernelGGL(k_heavy_rows, dim3((slots + 255) / 256), dim3(256), 0, ctx->stream, (const u64*)hvb, (const unsigned long long*)(hvb + slots), slots,
-                               cp.amin, cp.amax, cp.histo_max, ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), hvb + 2 * (size_t)slots, reinterpret_cast<u32*>(hvb + 3 * (size_t)slots));
+            hipLaunchKernelGGL(k_heavy_rows<W>, dim3((slots + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const Key*>(hvb + HvLayout<W>::keys),
+                               (const unsigned long long*)(hvb + HvLayout<W>::counts), slots, cp.amin, cp.amax, cp.histo_max, ctx->ghist.as<u64>(), ctx->gstats.as<u64>(),
+                               hvb + HvLayout<W>::rows, reinterpret_cast<u32*>(hvb + HvLayout<W>::ab));
             CKL("k_heavy_rows");
+          }
         }
         ctx->mark("count");
         if ((rc = run_scan(ctx, ctx->nsolid.as<u32>(), sc + SC_F, pl.F))) return rc;
@@ -1523,10 +1536,12 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         CK(ctx->out_ab.ensure((ns + 1) * 4));
         RowsOut ro{};
         for (int x = 0; x < W; ++x) { CK(ctx->out_w[x].ensure((ns + 1) * 8)); ro.w[x] = ctx->out_w[x].as<u64>(); }
-        if (nhs) {
-            const size_t slots = HV_KEYS;
-            CK(hipMemcpyAsync(ctx->out_w[0].as<u64>() + h_nsolid, ctx->hv_buf.as<u64>() + 2 * slots, nhs * 8, hipMemcpyDeviceToDevice, ctx->stream));
-            CK(hipMemcpyAsync(ctx->out_ab.as<u32>() + h_nsolid, ctx->hv_buf.as<u64>() + 3 * slots, nhs * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if constexpr (W <= 2) {
+          if (nhs) {
+            for (int x = 0; x < W; ++x)
+                CK(hipMemcpyAsync(ctx->out_w[x].as<u64>() + h_nsolid, ctx->hv_buf.as<u64>() + HvLayout<W>::rows + (size_t)x * HV_KEYS, nhs * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            CK(hipMemcpyAsync(ctx->out_ab.as<u32>() + h_nsolid, ctx->hv_buf.as<u64>() + HvLayout<W>::ab, nhs * 4, hipMemcpyDeviceToDevice, ctx->stream));
+          }
         }
         ctx->stats.n_heavy += nheavy;
         hipLaunchKernelGGL(k_compact<W>, dim3((pl.F + 3) / 4), dim3(256), 0, ctx->stream, (const Key*)solid_keys, (const u32*)solid_ab,
@@ -1637,7 +1652,7 @@ int level0_materialise(dskgpu_ctx* ctx, u64 nwords, u32 lo, u32 npass, u64 reser
     if (ctx->tune.l0_staged) {      // (experiments: the first version -- the histogram-free scatter with the pass as its digit, staged through LDS tiles)
         CK(ctx->mat1.ensure(((size_t)L0_MAX_PASSES * grid + 1) * 4));
         CK(hipMemsetAsync(ctx->gstats.as<u64>() + 2, 0, 8, ctx->stream));
-        Opt1Spec o1{d_slen, (u32)slice[0], (u32)(slice[0] * grid), sc + SC_OVF1, ctx->mat1.as<u32>(), 0u, ctx->gstats.as<u64>() + 2, nullptr, nullptr, (u32)slice[0], d_obase, obase[0], 0u};
+        Opt1Spec o1{d_slen, (u32)slice[0], (u32)(slice[0] * grid), sc + SC_OVF1, ctx->mat1.as<u32>(), 0u, ctx->gstats.as<u64>() + 2, nullptr, nullptr, (u32)slice[0], d_obase, obase[0], {0ull, 0ull, 0ull, 0ull}, 0u};
         const int rc = launch_scatter_m<1, 0, 4, true>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, nullptr, ctx->l0buf.as<u64>(), ds, G, o1);
         if (rc) return rc;
     } else {
@@ -1848,8 +1863,9 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                     const u64 nper = n_keys / npass + 1;
                     const u64 have = ctx->bufA.cap + ctx->bufB.cap + ctx->l0buf.cap;
                     const u64 rows_have = ctx->acc_ab.cap + ctx->acc_w[0].cap + (W > 1 ? ctx->acc_w[1].cap : 0);
-                    const u64 rows_want = rows_sized ? 0 : n_keys / 16 * (8ull * W + 4);
-                    const u64 need = nper * (W == 1 ? 30ull : 50ull) + (4ull << 30) + (rows_want > rows_have ? rows_want - rows_have : 0);
+                    // (rows still to come: known from the last count of these reads, else one solid row per sixteen k-mers until the first pass has told)
+                    const u64 rows_want = rows_sized ? 0 : ctx->last_rows ? (ctx->last_rows + ctx->last_rows / 32) * (8ull * W + 4) : n_keys / 16 * (8ull * W + 4);
+                    const u64 need = nper * (W == 1 ? 26ull : 46ull) + (4ull << 30) + (rows_want > rows_have ? rows_want - rows_have : 0);
                     const u64 room = free_b + have > need ? free_b + have - need : 0;
                     const u64 R8 = (u64)ctx->sk_sp.R * 8;
                     u64 left = 0; for (u32 o = p; o < npass; ++o) left += rl.region[o] * R8;
@@ -1894,7 +1910,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             if (npass > 1) {      // append this pass's rows and histogram to the job's
                 CK(hipMemcpyAsync(pass_hist.data(), ctx->ghist.p, pass_hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
                 // grow once: the passes hold similar numbers of rows (hash-uniform), so size for all of them after the first
-                const u64 want_rows = std::max<u64>(tot_rows + ns + 1, p == 0 ? (ns + ns / 8 + 1024) * npass : 0);
+                const u64 want_rows = std::max<u64>(tot_rows + ns + 1, p == 0 ? (ctx->last_rows ? ctx->last_rows + ctx->last_rows / 64 + 1024 : (ns + ns / 8 + 1024) * npass) : 0);
                 auto grow_rows = [&]() {
                     bool ok = ctx->acc_ab.ensure_keep(want_rows * 4, tot_rows * 4, ctx->stream) == 0;
                     for (int x = 0; x < W && ok; ++x) ok = ctx->acc_w[x].ensure_keep(want_rows * 8, tot_rows * 8, ctx->stream) == 0;
@@ -1971,6 +1987,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         ctx->stats.n_final_bins = pl.F;
         ctx->stats.n_passes = npass;
         ctx->stats.n_read_sweeps = npass > 1 ? sweeps : (from_reads ? 1 : 0);
+        if (from_reads) ctx->last_rows = tot_rows;
         if (npass > 1) {      // the names go back: acc_* stays the job-sized buffer (it holds the result now), out_* the pass-sized one --
             std::swap(ctx->out_ab, ctx->acc_ab);      // left swapped, the next count grew the small one to job size again (10 GB of hipMalloc + hipFree per call)
             for (int x = 0; x < W; ++x) std::swap(ctx->out_w[x], ctx->acc_w[x]);
@@ -2524,7 +2541,7 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
     CK(hipMemsetAsync(dst + ctx->reads_len + nbytes, '\n', 1, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     ctx->reads_len += nbytes + 1;
-    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->rec_l0_off = false;
+    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
     return DSKGPU_OK;
 }
 
@@ -2578,7 +2595,7 @@ int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbyte
     // intermittent failure of the multi-process test was exactly that, in the test's reference count).  Once per read set, not per count.
     CK(hipSetDevice(ctx->cfg.device));
     CK(hipDeviceSynchronize());
-    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->rec_l0_off = false;
+    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
     ctx->n_bytes = nbytes;
     ctx->reads_len = 0;
     ctx->bank_ends.clear();

@@ -178,6 +178,8 @@ template <int W> __device__ __forceinline__ bool is_pad_key(const KN<W>& h) {   
     for (int x = 0; x < W; ++x) e = e && (h.w[x] == DSK_EMPTY);
     return e;
 }
+__device__ __forceinline__ bool keys_same(u64 a, u64 b) { return a == b; }
+template <int W> __device__ __forceinline__ bool keys_same(const KN<W>& a, const KN<W>& b) { return key_eq(a, b); }
 // KEYS: chunk range is in keys; tile t covers keys [begin + t*Tile<W>::KEYS, ...);
 // thread loads keys tid + j*SC_NT (coalesced).
 template <int W>
@@ -534,6 +536,11 @@ __device__ __forceinline__ u32 tile_keys_records(const RecPre<W>& pre, u32 R, u6
 // that tile_keys_array masks), which the pass reads as its input.
 struct Opt1Spec { const u32* boff; u32 area, dump; u32* ovf; u32* fill; u32 R; u64* nkeys;      // R: words per super-k-mer record (SRC 2)
                   const u64* hv_keys; unsigned long long* hv_cnt; u32 slice_len; const u64* obase; u64 obase0;      // obase: MODE 4, key offset of every bin's region in `out` (device array; obase0 = obase[0])
+                  // anchor[]: never read on a live path.  ONE run-time-dead access with a dynamic index (the sentinel fill at the end of k_scatter) keeps the
+                  // compiler from scalarising this whole kernel-argument struct into SGPRs up front: its fields are then loaded from the kernarg segment
+                  // where they are used, and the level-1 kernels -- all at the 128-VGPR limit -- keep 8 bytes per lane out of scratch (records source:
+                  // 5.15 -> 4.81 ms on the emulated rank of 8; found by bisecting a regression that came with nothing but a change of this struct)
+                  u64 anchor[4];
                   u32 uslice;         // != 0: UNIFORM slices of that many keys (bin b at b * uslice, boff unused) -- no slice-end array in LDS: plans above 1634 bins
                   // records (SRC 2) arriving in slices (a multi-GPU step whose exchange overlaps this kernel): one launch per slice over
                   // the chunks [g0, g0 + gn) (cur_state == nullptr: one launch over all chunks), the blocks' write cursors parked in cur_state[block * P + bin] in between;
@@ -559,7 +566,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
     u32* wsum = delta + P;                                           // 16 (+1 total)
     u32* tot = wsum + 16;
     u32* lim = tot + 1;                                              // P (OPT): end of this block's slice of every bin
-    u64* lob = reinterpret_cast<u64*>(smem + ((reinterpret_cast<char*>(lim + P) - smem + 7) & ~size_t(7)));      // MODE 4: region base of every bin
+    u64* lob = MODE == 4 ? reinterpret_cast<u64*>(smem + ((reinterpret_cast<char*>(lim + P) - smem + 7) & ~size_t(7))) : nullptr;      // MODE 4: region base of every bin
     const u32 nchunks = *d_nchunks;
     // OPT: this block's slices are CONTIGUOUS in `out` -- slice of bin b at blockIdx * area + boff[b] -- so its P write fronts
     // stay inside a few 2 MB pages (bin-major, the fronts of one block were P regions of grid * slice keys apart: P pages to
@@ -573,10 +580,10 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
         if (o1.cur_state) { gbeg += o1.g0; gend = o1.g0 + o1.gn; }
         if (o1.resume) for (u32 b = threadIdx.x; b < P; b += SC_NT) cur[b] = o1.cur_state[(u64)blockIdx.x * P + b];
     }
-    u64 hk[HV_KEYS]; u32 hc[HV_KEYS]; int nhk = 0;       // (nhk: how many are in use -- the list is dense, a wave-uniform count)
+    Key hvk[HV_KEYS]; u32 hc[HV_KEYS]; int nhk = 0;       // (nhk: how many are in use -- the list is dense, a wave-uniform count)
     if constexpr (HEAVY) {
 #pragma unroll
-        for (int x = 0; x < HV_KEYS; ++x) { hk[x] = o1.hv_keys[x]; hc[x] = 0; if (hk[x] != DSK_EMPTY) nhk = x + 1; }
+        for (int x = 0; x < HV_KEYS; ++x) { hvk[x] = reinterpret_cast<const Key*>(o1.hv_keys)[x]; hc[x] = 0; if (!is_empty_key(hvk[x])) nhk = x + 1; }
     }
     for (u32 g = gbeg; g < gend; g += gridDim.x) {
         const ChunkDesc d = descs[g];
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
         // of those stores (a full store round trip per tile); issued before them, they are older and the wait leaves the
         // stores in flight -- which needs their number to be known: the write-out is a fixed KPT / 4 trips of 4 predicated stores
         auto rank_and_stage = [&](Key (&h)[KPT], u32 vm) {
-            if constexpr (HEAVY && W == 1) {      // the k-mers counted apart leave the tile here (one-word keys)
+            if constexpr (HEAVY && W <= 2) {      // the k-mers counted apart leave the tile here (one- and two-word keys)
 #pragma unroll
                 for (int x = 0; x < HV_KEYS; ++x) {
                     if (x < nhk) {                   // (uniform: one k-mer counted apart costs one compare per key, not HV_KEYS)
@@ -598,7 +605,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                         // VALU + 3 SALU instructions per key: +0.26 ms on a kernel that is bound by its instruction count)
                         u32 hits = 0;
 #pragma unroll
-                        for (int j = 0; j < KPT; ++j) hits |= (h[j] == hk[x]) ? (1u << j) : 0u;
+                        for (int j = 0; j < KPT; ++j) hits |= keys_same(h[j], hvk[x]) ? (1u << j) : 0u;
                         hits &= vm;
                         hc[x] += (u32)__popc(hits);
                         vm &= ~hits;
@@ -751,7 +758,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                 lds_barrier();
                 for (u32 b = 0; b < P; ++b) {
                     const u32 c = cur[b] < lim[b] ? cur[b] : lim[b];
-                    for (u32 i = c + threadIdx.x; i < lim[b]; i += SC_NT) out[lob[b & (L0_MAX_PASSES - 1)] + i] = DSK_EMPTY;
+                    for (u32 i = c + threadIdx.x; i < lim[b]; i += SC_NT) out[(MODE == 4 ? lob[b & (L0_MAX_PASSES - 1)] : o1.anchor[b & 3]) + i] = DSK_EMPTY;      // (slice_len != 0 only with MODE 4: see Opt1Spec::anchor)
                 }
             }
         }
@@ -2290,10 +2297,12 @@ __global__ __launch_bounds__(256) void k_bin_moments(const u32* __restrict__ mat
 #define HV_SLOTS 16
 #define HV_COLLECT 2048            // keys aimed at per slot, over all blocks
 #define HV_BLOCK_KEYS 32           // entries of a block per slot
-template <int SRC, int MODE>
-__global__ __launch_bounds__(SC_NT) void k_collect_heavy(const u64* __restrict__ packed, const u32* __restrict__ inval, const u64* __restrict__ keys,
+template <int W, int SRC, int MODE>
+__global__ __launch_bounds__(SC_NT) void k_collect_heavy(const u64* __restrict__ packed, const u32* __restrict__ inval, const typename KeyT<W>::T* __restrict__ keys,
                                                          const ChunkDesc* __restrict__ descs, const u32* __restrict__ d_nchunks, int k, DigitSpec ds, u32 P,
-                                                         const unsigned char* __restrict__ lut, u32* __restrict__ kept, u64* __restrict__ out, const u32* __restrict__ keep_step) {
+                                                         const unsigned char* __restrict__ lut, u32* __restrict__ kept, typename KeyT<W>::T* __restrict__ out, const u32* __restrict__ keep_step) {
+    typedef typename KeyT<W>::T Key;
+    constexpr int KPT = Tile<W>::KPT;
     __shared__ unsigned char slut[MAX_BINS + 8];
     __shared__ u32 lcnt[HV_SLOTS], lstep[HV_SLOTS];
     const int lane = threadIdx.x & 63;
@@ -2304,14 +2313,15 @@ __global__ __launch_bounds__(SC_NT) void k_collect_heavy(const u64* __restrict__
     const u32 nchunks = *d_nchunks;
     for (u32 g = blockIdx.x; g < nchunks; g += gridDim.x) {
         const ChunkDesc d = descs[g];
-        const u64 step = SRC == 0 ? Tile<1>::WORDS : Tile<1>::KEYS;
+        const u64 step = SRC == 0 ? Tile<W>::WORDS : Tile<W>::KEYS;
         for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
-            u64 h[16];
-            const u32 vm = SRC == 0 ? tile_keys_reads(packed, inval, t0, d.end, k, h) : tile_keys_array<1>(keys, t0, d.end, h);
+            Key h[KPT];
+            u32 vm;
+            if constexpr (SRC == 0) vm = tile_keys_reads(packed, inval, t0, d.end, k, h); else vm = tile_keys_array<W>(keys, t0, d.end, h);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < KPT; ++j) {
                 u32 f = 0xFFu;
-                if ((vm & (1u << j)) && key_in_pass<MODE>(h[j], ds)) f = slut[key_digit<MODE>(h[j], ds)];
+                if ((vm & (1u << j)) && key_in_pass<MODE>(digit_word(h[j]), ds)) f = slut[key_digit<MODE>(digit_word(h[j]), ds)];
                 u64 todo = __ballot(f != 0xFFu);
                 while (todo) {                   // one LDS atomic per wave and slot: the lanes of a slot take consecutive arrival numbers
                     const int lead = __ffsll((unsigned long long)todo) - 1;
@@ -2339,20 +2349,27 @@ __global__ __launch_bounds__(SC_NT) void k_collect_heavy(const u64* __restrict__
 }
 // The k-mers counted apart by the level-1 scatter (HEAVY) join the result here: histogram, distinct count and, when solid, a row
 // (value restored from the mixed key) in rows_k / rows_ab; gstats[1] = rows written.  One thread per slot.
-__global__ void k_heavy_rows(const u64* __restrict__ hv_keys, const unsigned long long* __restrict__ hv_cnt, u32 nslots, u32 amin, u32 amax, u32 histo_max,
-                             u64* __restrict__ ghist, u64* __restrict__ gstats, u64* __restrict__ rows_k, u32* __restrict__ rows_ab) {
+template <int W>
+__global__ void k_heavy_rows(const typename KeyT<W>::T* __restrict__ hv_keys, const unsigned long long* __restrict__ hv_cnt, u32 nslots, u32 amin, u32 amax, u32 histo_max,
+                             u64* __restrict__ ghist, u64* __restrict__ gstats, u64* __restrict__ rows_k /* word x of row r at [x * nslots + r] */, u32* __restrict__ rows_ab) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nslots) return;
-    const u64 key = hv_keys[i];
+    const typename KeyT<W>::T key = hv_keys[i];
     const unsigned long long c64 = hv_cnt[i];
-    if (key == DSK_EMPTY || c64 == 0ull) return;
+    if (is_empty_key(key) || c64 == 0ull) return;
     const u32 c = c64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)c64;
     atomicAdd(&ghist[c < histo_max ? c : histo_max], 1ull);
     atomicAdd(&gstats[0], 1ull);
     atomicAdd(&gstats[2], c64);                   // they count as keys the level-1 scatter placed
     if (c >= amin && c <= amax) {
         const u64 at = atomicAdd(&gstats[1], 1ull);
-        rows_k[at] = kunmix(key); rows_ab[at] = c;
+        if constexpr (W == 1) rows_k[at] = kunmix(key);
+        else {
+            KN<W> kx = key; kunmixN(kx);
+#pragma unroll
+            for (int x = 0; x < W; ++x) rows_k[(u64)x * nslots + at] = kx.w[x];
+        }
+        rows_ab[at] = c;
     }
 }
 __global__ void k_copy_u32(u32* __restrict__ dst, const u32* __restrict__ src, u64 n) {
