@@ -1863,9 +1863,8 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                     const u64 nper = n_keys / npass + 1;
                     const u64 have = ctx->bufA.cap + ctx->bufB.cap + ctx->l0buf.cap;
                     const u64 rows_have = ctx->acc_ab.cap + ctx->acc_w[0].cap + (W > 1 ? ctx->acc_w[1].cap : 0);
-                    // (rows still to come: known from the last count of these reads, else one solid row per sixteen k-mers until the first pass has told)
-                    const u64 rows_want = rows_sized ? 0 : ctx->last_rows ? (ctx->last_rows + ctx->last_rows / 32) * (8ull * W + 4) : n_keys / 16 * (8ull * W + 4);
-                    const u64 need = nper * (W == 1 ? 26ull : 46ull) + (4ull << 30) + (rows_want > rows_have ? rows_want - rows_have : 0);
+                    const u64 rows_want = rows_sized ? 0 : n_keys / 16 * (8ull * W + 4);
+                    const u64 need = nper * (W == 1 ? 30ull : 50ull) + (4ull << 30) + (rows_want > rows_have ? rows_want - rows_have : 0);
                     const u64 room = free_b + have > need ? free_b + have - need : 0;
                     const u64 R8 = (u64)ctx->sk_sp.R * 8;
                     u64 left = 0; for (u32 o = p; o < npass; ++o) left += rl.region[o] * R8;
@@ -1910,7 +1909,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             if (npass > 1) {      // append this pass's rows and histogram to the job's
                 CK(hipMemcpyAsync(pass_hist.data(), ctx->ghist.p, pass_hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
                 // grow once: the passes hold similar numbers of rows (hash-uniform), so size for all of them after the first
-                const u64 want_rows = std::max<u64>(tot_rows + ns + 1, p == 0 ? (ctx->last_rows ? ctx->last_rows + ctx->last_rows / 64 + 1024 : (ns + ns / 8 + 1024) * npass) : 0);
+                const u64 want_rows = std::max<u64>(tot_rows + ns + 1, p == 0 ? (ns + ns / 8 + 1024) * npass : 0);
                 auto grow_rows = [&]() {
                     bool ok = ctx->acc_ab.ensure_keep(want_rows * 4, tot_rows * 4, ctx->stream) == 0;
                     for (int x = 0; x < W && ok; ++x) ok = ctx->acc_w[x].ensure_keep(want_rows * 8, tot_rows * 8, ctx->stream) == 0;
