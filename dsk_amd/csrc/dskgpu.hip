@@ -181,6 +181,7 @@ struct dskgpu_ctx {
     DevBuf packed, inval;          // K1 output
     DevBuf bufA, bufB;             // partition ping-pong
     DevBuf mat1, mat2, sums, descs1, descs2, seg, fstart, nsolid, scalars, ghist, gstats, chain_next;
+    DevBuf fix_list;               // multi-word row sort: [count | (first row, rows) x FIX_LIST_CAP] of the prefix runs above FIX_CAP rows
     DevBuf rs_g[4];                // row sort: the gathered rows of the listed sub-buckets, one buffer per round (sort_oversize)
     DevBuf rs_ovs;                 // row sort: [count | (offset, rows, bits left) x RS_OVS_CAP] of the sub-buckets listed for another round
     std::vector<u32> h_ovs;
@@ -909,8 +910,17 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
             else hipLaunchKernelGGL(k_gather_rows<4>, dim3(gb4), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), ri, ctx->out_ab.as<u32>(), idx, n);
         }
         const unsigned gfix = (unsigned)std::min<u64>(gb, (u64)ctx->num_cu * 32);      // grid-stride kernel: when there are no ties its blocks leave at once
-        if (W == 2) hipLaunchKernelGGL(k_fix_runs_multi<2>, dim3(gfix), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), skey, n, run_shift, flag, ties);
-        else hipLaunchKernelGGL(k_fix_runs_multi<4>, dim3(gfix), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), skey, n, run_shift, flag, ties);
+        CK(ctx->fix_list.ensure((1 + 2 * (size_t)FIX_LIST_CAP) * 4));
+        CK(hipMemsetAsync(ctx->fix_list.p, 0, 4, ctx->stream));
+        u32* fl = ctx->fix_list.as<u32>();
+        const unsigned glong = (unsigned)ctx->num_cu;
+        if (W == 2) {
+            hipLaunchKernelGGL(k_fix_runs_multi<2>, dim3(gfix), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), skey, n, run_shift, flag, ties, fl);
+            hipLaunchKernelGGL(k_fix_long_runs<2>, dim3(glong), dim3(1024), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), (const u32*)fl, ties);
+        } else {
+            hipLaunchKernelGGL(k_fix_runs_multi<4>, dim3(gfix), dim3(256), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), skey, n, run_shift, flag, ties, fl);
+            hipLaunchKernelGGL(k_fix_long_runs<4>, dim3(glong), dim3(1024), 0, ctx->stream, ro, ctx->srt_ab.as<u32>(), (const u32*)fl, ties);
+        }
         CKL("sort_rows");
         CK(hipMemcpyAsync(&ctx->h_back[3], flag, 4, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sort_partial = true;
@@ -2481,7 +2491,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
                       &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
                       &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->srt_k2, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
                       &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,
-                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent, &ctx->cur_state, &ctx->rs_ovs, &ctx->smp_keys, &ctx->sk_lay};
+                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent, &ctx->cur_state, &ctx->rs_ovs, &ctx->smp_keys, &ctx->sk_lay, &ctx->fix_list};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i) { ctx->rs_g[i].release(); ctx->out_w[i].release(); ctx->srt_w[i].release(); ctx->acc_w[i].release(); ctx->u_w[i].release(); ctx->s_w[i].release(); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);

@@ -2155,18 +2155,28 @@ __device__ __forceinline__ bool row_less(const u64 (&a)[W], const RowsOut& r, u6
     for (int x = W - 1; x >= 0; --x) { const u64 v = r.w[x][j]; if (a[x] != v) return a[x] < v; }
     return false;
 }
+// Runs of 33 .. FIX_BLOCK_ROWS rows (16384: the one- and two-error variants of a 63-mer are 4300; the error variants of a k-mer with 10^5 and more occurrences share their first 63 bits) are
+// LISTED -- list[0] = how many, then (first row, rows) pairs -- and ordered by k_fix_long_runs, one block per run; beyond that, or
+// when the list is full, *flag (the full-width fallback).
+#define FIX_LIST_CAP 4096
+#define FIX_BLOCK_ROWS 16384
 template <int W>
 __global__ __launch_bounds__(256) void k_fix_runs_multi(RowsOut rows, u32* __restrict__ ab, const u64* __restrict__ key, u64 n, int sh, u32* __restrict__ flag,
-                                                        const u32* __restrict__ ties) {
+                                                        const u32* __restrict__ ties, u32* __restrict__ list) {
     if (ties && *ties == 0u) return;                         // the sort saw no two equal keys: nothing to order
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {      // (grid-stride: the launch may be capped)
         const u64 p = key[i] >> sh;
         if (i > 0 && (key[i - 1] >> sh) == p) continue;         // not a run head
         u64 e = i + 1;
-        while (e < n && e - i <= FIX_CAP && (key[e] >> sh) == p) ++e;
+        while (e < n && e - i <= FIX_BLOCK_ROWS && (key[e] >> sh) == p) ++e;
         const u64 L = e - i;
         if (L == 1) continue;
-        if (L > FIX_CAP) { *flag = 1; continue; }
+        if (L > FIX_CAP) {
+            if (L > FIX_BLOCK_ROWS || i + L >= 0xFFFFFFFFull || list == nullptr) { *flag = 1; continue; }
+            const u32 at = atomicAdd(&list[0], 1u);
+            if (at < FIX_LIST_CAP) { list[1 + 2 * at] = (u32)i; list[2 + 2 * at] = (u32)L; } else *flag = 1;
+            continue;
+        }
         for (u64 a = i + 1; a < e; ++a) {
             u64 kv[W]; const u32 av = ab[a];
 #pragma unroll
@@ -2180,6 +2190,61 @@ __global__ __launch_bounds__(256) void k_fix_runs_multi(RowsOut rows, u32* __res
 #pragma unroll
             for (int x = 0; x < W; ++x) rows.w[x][b] = kv[x];
             ab[b] = av;
+        }
+    }
+}
+// one block per listed run: a bitonic network over the run's row numbers in LDS (rows compared word by word in HBM / L2 -- the run
+// is a few hundred KB), then every thread fetches the rows of its final positions, and after a barrier writes them there
+template <int W>
+__global__ __launch_bounds__(1024) void k_fix_long_runs(RowsOut rows, u32* __restrict__ ab, const u32* __restrict__ list, const u32* __restrict__ ties) {
+    if (ties && *ties == 0u) return;
+    __shared__ unsigned short idx[FIX_BLOCK_ROWS];
+    const u32 nl = list[0] < FIX_LIST_CAP ? list[0] : FIX_LIST_CAP;
+    for (u32 r = blockIdx.x; r < nl; r += gridDim.x) {
+        const u64 base = list[1 + 2 * r]; const u32 L = list[2 + 2 * r];
+        u32 np2 = 2; while (np2 < L) np2 <<= 1;
+        __syncthreads();
+        for (u32 j = threadIdx.x; j < np2; j += 1024) idx[j] = (unsigned short)(j < L ? j : 0xFFFFu);      // (pads order behind every row)
+        __syncthreads();
+        auto less = [&](u32 a, u32 b) {          // row a < row b (row numbers inside the run; a pad is larger than any row)
+            if (a == 0xFFFFu || b == 0xFFFFu) return a != 0xFFFFu && b == 0xFFFFu;
+#pragma unroll
+            for (int x = W - 1; x >= 0; --x) { const u64 va = rows.w[x][base + a], vb = rows.w[x][base + b]; if (va != vb) return va < vb; }
+            return false;
+        };
+        for (u32 kk = 2; kk <= np2; kk <<= 1)
+            for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+                for (u32 x = threadIdx.x; x < np2; x += 1024) {
+                    const u32 y = x ^ jj;
+                    if (y > x) {
+                        const u32 a0 = idx[x], a1 = idx[y];
+                        const bool up = (x & kk) == 0;
+                        if (less(a1, a0) == up) { idx[x] = (unsigned short)a1; idx[y] = (unsigned short)a0; }
+                    }
+                }
+                __syncthreads();
+            }
+        constexpr int RPT = FIX_BLOCK_ROWS / 1024;
+        u64 kv[RPT][W]; u32 av[RPT];
+#pragma unroll
+        for (int t = 0; t < RPT; ++t) {
+            const u32 j = threadIdx.x + 1024 * t;
+            if (j < L) {
+                const u32 src = idx[j];
+#pragma unroll
+                for (int x = 0; x < W; ++x) kv[t][x] = rows.w[x][base + src];
+                av[t] = ab[base + src];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < RPT; ++t) {
+            const u32 j = threadIdx.x + 1024 * t;
+            if (j < L) {
+#pragma unroll
+                for (int x = 0; x < W; ++x) rows.w[x][base + j] = kv[t][x];
+                ab[base + j] = av[t];
+            }
         }
     }
 }

@@ -312,8 +312,11 @@ __global__ __launch_bounds__(RS_NT) void k_rs_big(u64* kv, u32* av, const u32* _
         const u32 o = sub[i], nd = sub[i + 1] - o;
         if (nd > block_rows) {
             if (tid == 0) {
-                const u32 at = sp.shB > 0 ? atomicAdd(&ovs[0], 1u) : RS_OVS_CAP;
-                if (at < RS_OVS_CAP) { ovs[1 + 3 * at] = base + o; ovs[2 + 3 * at] = nd; ovs[3 + 3 * at] = (u32)sp.shB; } else *flag = 1u;
+                if (sp.shB <= 0) *ties = 1u;          // no value bits below the two digits: the rows of this sub-bucket are EQUAL keys (63-bit prefixes of multi-word
+                else {                                //  rows) -- in order as far as this sort goes, the caller's tie pass does the rest
+                    const u32 at = atomicAdd(&ovs[0], 1u);
+                    if (at < RS_OVS_CAP) { ovs[1 + 3 * at] = base + o; ovs[2 + 3 * at] = nd; ovs[3 + 3 * at] = (u32)sp.shB; } else *flag = 1u;
+                }
             }
             continue;
         }

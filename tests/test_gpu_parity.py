@@ -361,8 +361,7 @@ def test_repeat_rich_reads_stay_on_the_histogram_free_path(oracle, dev, monkeypa
     check(rows, ab, hist, st)
     assert st["n_retries"] == 0 and "hist1" not in stages and "hist2" not in stages
     assert st["n_ext_regions"] > 0 and st["n_heavy"] >= 1          # (k = 63: two-word keys take the same path -- region chains, the poly-A k-mer counted apart)
-    if k <= 32:
-        assert st["sort_fallback"] == 0      # (two-word rows: the ~100 error variants of poly-A that share their first 63 bits exceed the in-place run fix-up: full-width order)
+    assert st["sort_fallback"] == 0          # (two-word rows: the ~100 error variants of poly-A that share their first 63 bits are ordered by k_fix_long_runs)
     monkeypatch.setenv("DSKGPU_NO_SAMPLE", "1")
     rows, ab, hist, st, stages = run()
     check(rows, ab, hist, st)
@@ -1199,7 +1198,8 @@ def test_row_sort_of_huge_row_sets_in_groups(oracle, dev, monkeypatch):
 def test_multiword_row_sort_prefix_runs_and_fallback(oracle, dev, k):
     """Multi-word rows are ordered as (top 63 value bits, row index) pairs by the hand-written sort, rows that share all 63 bits
     by a tie pass with full comparison: 25 or 300 rows sharing a 20-base prefix stay on that path (the 300 in one cell are
-    ordered by the block path's bitonic network); more than 32 rows that share ALL 63 bits take the full-width fallback."""
+    ordered by the block path's bitonic network); more than 32 rows that share ALL 63 bits are listed and ordered by one block per
+    run (up to 4096 rows; beyond: the full-width fallback)."""
     rng = np.random.default_rng(12)
     tails = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(300, k - 20))
     noise = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=60_000).tobytes()
@@ -1215,11 +1215,12 @@ def test_multiword_row_sort_prefix_runs_and_fallback(oracle, dev, k):
     s = np.frombuffer(b"\n".join(recs) + b"\n" + noise + b"\n", dtype=np.uint8)
     st = check_against_oracle(oracle, s, k, dev, amin=1)
     assert st["sort_fallback"] == 0
-    if k >= 63:      # 60 rows with equal sort keys: beyond what the tie pass orders in place
-        recs = [long_head + t.tobytes()[: k - 36] for t in tails[:60]]
-        s = np.frombuffer(b"\n".join(recs) + b"\n" + noise + b"\n", dtype=np.uint8)
-        st = check_against_oracle(oracle, s, k, dev, amin=1)
-        assert st["sort_fallback"] == 1
+    if k >= 63:      # 60 / 300 rows with equal sort keys: beyond what the tie pass orders in place -- listed, and ordered by one block each (k_fix_long_runs)
+        for nshare in (60, 300):
+            recs = [long_head + t.tobytes()[: k - 36] for t in tails[:nshare]]
+            s = np.frombuffer(b"\n".join(recs) + b"\n" + noise + b"\n", dtype=np.uint8)
+            st = check_against_oracle(oracle, s, k, dev, amin=1)
+            assert st["sort_fallback"] == 0
 
 
 @pytest.mark.parametrize("k,mkeys,n_reads", [(31, 2, 100_000), (27, 1, 60_000), (63, 1, 60_000)])
