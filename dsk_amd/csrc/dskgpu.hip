@@ -138,6 +138,7 @@ struct Tuning {
     bool verbose = false;                       // DSKGPU_VERBOSE: trace of the plan decisions on stderr
     bool l2_static = false;                     // DSKGPU_L2_STATIC: segments of the level-2 scatter round-robin over the blocks instead of by work counter
     bool no_level0 = false; u32 l0_passes = 0;  // DSKGPU_NO_LEVEL0: every pass of a multi-pass count re-generates its keys; DSKGPU_L0_PASSES=n: passes per level-0 sweep (tests)
+    bool count_mw_v1 = false;                   // DSKGPU_COUNT_MW_V1: k_count_mw (index table, full compares) instead of the top-word table k_count2v3 on two-word regions
     bool count_v1 = false;                      // DSKGPU_COUNT_V1: k_count1<true> (slot list) instead of the list-free k_count1v3 on regions
     u64 rs_max_rows = 0;                        // DSKGPU_RS_MAX_ROWS: most rows the MSD row sort takes in one piece (tests: the group-wise path of huge row sets on a small input)
     bool l0_keys = false;                       // DSKGPU_L0_KEYS: level 0 as key arrays (k_level0) even where the record-based one applies (experiments, tests)
@@ -154,7 +155,7 @@ struct Tuning {
         sk_slice = num("DSKGPU_SK_SLICE", 0); sk_minslice = num("DSKGPU_SK_MINSLICE", 2000);
         table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
         max_ext = getenv("DSKGPU_MAX_EXT") ? atoll(getenv("DSKGPU_MAX_EXT")) : -1;
-        no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); l2_static = on("DSKGPU_L2_STATIC"); force_heavy = on("DSKGPU_FORCE_HEAVY"); count_v1 = on("DSKGPU_COUNT_V1"); no_level0 = on("DSKGPU_NO_LEVEL0"); l0_passes = (u32)num("DSKGPU_L0_PASSES", 0); mp_pass_mkeys = (u32)num("DSKGPU_MP_PASS_MKEYS", 0); rs_max_rows = num("DSKGPU_RS_MAX_ROWS", 0); l0_staged = on("DSKGPU_L0_STAGED"); l0_keys = on("DSKGPU_L0_KEYS");
+        no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); l2_static = on("DSKGPU_L2_STATIC"); force_heavy = on("DSKGPU_FORCE_HEAVY"); count_v1 = on("DSKGPU_COUNT_V1"); count_mw_v1 = on("DSKGPU_COUNT_MW_V1"); no_level0 = on("DSKGPU_NO_LEVEL0"); l0_passes = (u32)num("DSKGPU_L0_PASSES", 0); mp_pass_mkeys = (u32)num("DSKGPU_MP_PASS_MKEYS", 0); rs_max_rows = num("DSKGPU_RS_MAX_ROWS", 0); l0_staged = on("DSKGPU_L0_STAGED"); l0_keys = on("DSKGPU_L0_KEYS");
         lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0); rs_heavy = (u32)num("DSKGPU_RS_HEAVY", 0);
     }
 };
@@ -229,6 +230,7 @@ struct dskgpu_ctx {
     u64* fb_src_k = nullptr; u32* fb_src_v = nullptr; u64* fb_dst_k = nullptr; u32* fb_dst_v = nullptr;   // one-word row sort: where the full-width fallback finds a permutation of the rows / leaves them sorted
     bool sentinel_ok = true;       // the all-ones key is not the mixed form of a canonical k-mer of this k (checked at create)
     bool opt1_off = false;         // same for the histogram-free level-1 scatter (block-owned slices)
+    bool mw_v3_off = false;        // the top-word table of k_count2v3 met two k-mers it cannot tell apart on these reads: k_count_mw from now on
     bool opt2_off = false;         // the fixed-capacity level-2 scatter overflowed on these reads: use the exact path   // host landing zone of the async size read-back
     std::vector<ChunkDesc> h_descs1, h_descs2;
     std::vector<const void*> big_lds_fns;   // kernels whose dynamic-LDS limit this context has raised (allow_big_lds)
@@ -449,6 +451,14 @@ inline void launch_count_impl(dskgpu_ctx* ctx, unsigned grid, u64* keys, u64* so
 }
 template <int W>
 inline void launch_count_impl(dskgpu_ctx* ctx, unsigned grid, KN<W>* keys, KN<W>* solid_keys, u32* solid_ab, u32* ovf, const CountParams& cp) {
+    if constexpr (W == 2) {
+        if (cp.cap && cp.cap <= C2V_NKEYS * CNT_NT && !ctx->tune.count_mw_v1 && !ctx->mw_v3_off) {      // regions: the table keyed by the mixed top word
+            CountParams c2 = cp; c2.maxload = std::min<u32>(cp.maxload, C2V_SLOTS * 7 / 8);
+            hipLaunchKernelGGL((k_count2v3<CNT_NT, C2V_KPT, C2V_NKEYS>), dim3(grid), dim3(CNT_NT), 0, ctx->stream, (const K2*)keys, solid_keys, solid_ab,
+                               ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, c2, cp.subcnt);
+            return;
+        }
+    }
     if (cp.cap) hipLaunchKernelGGL((k_count_mw<W, true>), dim3(grid), dim3(CNT_NT), 0, ctx->stream, keys, solid_keys, ctx->fstart.as<u32>(), solid_ab,
                                    ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, cp);
     else hipLaunchKernelGGL((k_count_mw<W, false>), dim3(grid), dim3(CNT_NT), 0, ctx->stream, keys, solid_keys, ctx->fstart.as<u32>(), solid_ab,
@@ -1480,47 +1490,74 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         const unsigned cgrid = (unsigned)std::min<u64>(pl.F, (u64)ctx->num_cu * 2);
         Key* solid_keys = W == 1 ? fkeys : scratch->as<Key>();
         u32* solid_ab = W == 1 ? scratch->as<u32>() : ctx->abund2.as<u32>();
-        launch_count<W>(ctx, cgrid, fkeys, solid_keys, solid_ab, sc + SC_OVERFLOW, cp);
-        CKL("k_count");
+        // the count stage as one unit: two-word keys may run it twice (k_count2v3, then -- when its verification bit went up -- k_count_mw:
+        // the keys are still there, two-word rows go to the free buffer)
+        auto count_stage = [&]() -> int {
+            launch_count<W>(ctx, cgrid, fkeys, solid_keys, solid_ab, sc + SC_OVERFLOW, cp);
+            CKL("k_count");
+            if constexpr (W == 2) {
+                if (opt_cap && max_ext) {
+                    hipLaunchKernelGGL(k_count_chained_mw<2>, dim3((unsigned)std::min<u64>(max_ext, (u64)ctx->num_cu * 2)), dim3(CNT_NT), 0, ctx->stream, (const Key*)fkeys, solid_keys, solid_ab,
+                                       ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), sc + SC_OVERFLOW, cp, (const u32*)cp.subcnt,
+                                       (const u32*)ctx->chain_next.as<u32>(), (const u32*)(ctx->chain_next.as<u32>() + nregions + 1), (const u32*)(sc + SC_NCHAINED), max_ext);
+                    CKL("k_count_chained_mw");
+                }
+            }
+            if constexpr (W == 1) {
+                if (opt_cap && max_ext) {      // the sub-partitions that went on in extension regions (none on repeat-free reads: the blocks leave at once)
+                    hipLaunchKernelGGL(k_count_chained, dim3((unsigned)std::min<u64>(max_ext, (u64)ctx->num_cu * 2)), dim3(CNT_NT), 0, ctx->stream, fkeys, solid_keys, solid_ab,
+                                       ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), sc + SC_OVERFLOW, cp, (const u32*)cp.subcnt,
+                                       (const u32*)ctx->chain_next.as<u32>(), (const u32*)(ctx->chain_next.as<u32>() + nregions + 1), (const u32*)(sc + SC_NCHAINED), max_ext);
+                    CKL("k_count_chained");
+                }
+            }
+            if constexpr (W <= 2) {
+              if (nheavy) {      // the k-mers the level-1 scatter counted apart: histogram, distinct count, rows (appended behind the compacted ones below)
+                const u32 slots = HV_KEYS;
+                u64* hvb = ctx->hv_buf.as<u64>();
+                hipLaunchKernelGGL(k_heavy_rows<W>, dim3((slots + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const Key*>(hvb + HvLayout<W>::keys),
+                                   (const unsigned long long*)(hvb + HvLayout<W>::counts), slots, cp.amin, cp.amax, cp.histo_max, ctx->ghist.as<u64>(), ctx->gstats.as<u64>(),
+                                   hvb + HvLayout<W>::rows, reinterpret_cast<u32*>(hvb + HvLayout<W>::ab));
+                CKL("k_heavy_rows");
+              }
+            }
+            return DSKGPU_OK;
+        };
+        // count, scan of the solid rows per sub-partition, sizes back to the host (one sync)
+        auto count_and_sizes = [&]() -> int {
+            if (int e = count_stage()) return e;
+            ctx->mark("count");
+            if (int e = run_scan(ctx, ctx->nsolid.as<u32>(), sc + SC_F, pl.F)) return e;
+            ctx->mark("scan_solid");
+            CK(hipMemcpyAsync(&ctx->h_back[0], sc + SC_OVERFLOW, 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipMemcpyAsync(&ctx->h_back[1], ctx->nsolid.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
+            // k-mers of the pass: the last sub-partition offset, or (fixed-capacity regions) the level-1 total
+            if (!opt1) CK(hipMemcpyAsync(&ctx->h_back[2], opt_cap ? ctx->mat1.as<u32>() + M1 : ctx->fstart.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipMemcpyAsync(&ctx->h_ovf2, sc + SC_OVF2, 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipMemcpyAsync(&ctx->h_ext, sc + SC_EXT, 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipMemcpyAsync(&ctx->h_stats[0], ctx->gstats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+            return DSKGPU_OK;
+        };
+        if constexpr (W == 2) CK(hipMemcpyAsync(ctx->gstats.as<u64>() + 3, ctx->gstats.as<u64>() + 2, 8, hipMemcpyDeviceToDevice, ctx->stream));      // (the keys level 1 placed, before k_heavy_rows adds to them: see below)
+        if ((rc = count_and_sizes())) return rc;
         if constexpr (W == 2) {
-            if (opt_cap && max_ext) {
-                hipLaunchKernelGGL(k_count_chained_mw<2>, dim3((unsigned)std::min<u64>(max_ext, (u64)ctx->num_cu * 2)), dim3(CNT_NT), 0, ctx->stream, (const Key*)fkeys, solid_keys, solid_ab,
-                                   ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), sc + SC_OVERFLOW, cp, (const u32*)cp.subcnt,
-                                   (const u32*)ctx->chain_next.as<u32>(), (const u32*)(ctx->chain_next.as<u32>() + nregions + 1), (const u32*)(sc + SC_NCHAINED), max_ext);
-                CKL("k_count_chained_mw");
+            // k_count2v3 keys its table by the mixed top word alone and checks every key's low word afterwards.  Two different k-mers of the pass with
+            // the same top word (birthday bound of a 64-bit hash: n^2 / 2^65 -- 0.5 % of the runs at 4 * 10^8 distinct k-mers), or one whose top word
+            // is the empty-slot value: the COUNT STAGE runs again with the index-table kernel (the keys are untouched: two-word rows go to the other
+            // buffer), and the rest of the reads' passes use that kernel too.  Tests craft both cases.
+            if ((ctx->h_back[0] & (CNT_OVF_VERIFY | CNT_OVF_SENTINEL)) && !((opt_cap && ctx->h_ovf2) || (opt1 && ctx->h_ovf1))) {
+                if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] pass %u/%u: the top-word table met k-mers it cannot tell apart (flags %u): counting again with k_count_mw\n", pass, npass, ctx->h_back[0]);
+                ctx->mw_v3_off = true;
+                ctx->stats.n_retries += 1;
+                CK(hipMemsetAsync(ctx->ghist.p, 0, ((size_t)ctx->cfg.histo_max + 1) * 8, ctx->stream));
+                CK(hipMemsetAsync(ctx->gstats.p, 0, 2 * 8, ctx->stream));
+                CK(hipMemcpyAsync(ctx->gstats.as<u64>() + 2, ctx->gstats.as<u64>() + 3, 8, hipMemcpyDeviceToDevice, ctx->stream));
+                CK(hipMemsetAsync(sc + SC_OVERFLOW, 0, 4, ctx->stream));
+                if ((rc = count_and_sizes())) return rc;
             }
         }
-        if constexpr (W == 1) {
-            if (opt_cap && max_ext) {      // the sub-partitions that went on in extension regions (none on repeat-free reads: the blocks leave at once)
-                hipLaunchKernelGGL(k_count_chained, dim3((unsigned)std::min<u64>(max_ext, (u64)ctx->num_cu * 2)), dim3(CNT_NT), 0, ctx->stream, fkeys, solid_keys, solid_ab,
-                                   ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), sc + SC_OVERFLOW, cp, (const u32*)cp.subcnt,
-                                   (const u32*)ctx->chain_next.as<u32>(), (const u32*)(ctx->chain_next.as<u32>() + nregions + 1), (const u32*)(sc + SC_NCHAINED), max_ext);
-                CKL("k_count_chained");
-            }
-        }
-        if constexpr (W <= 2) {
-          if (nheavy) {      // the k-mers the level-1 scatter counted apart: histogram, distinct count, rows (appended behind the compacted ones below)
-            const u32 slots = HV_KEYS;
-            u64* hvb = ctx->hv_buf.as<u64>();
-            hipLaunchKernelGGL(k_heavy_rows<W>, dim3((slots + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const Key*>(hvb + HvLayout<W>::keys),
-                               (const unsigned long long*)(hvb + HvLayout<W>::counts), slots, cp.amin, cp.amax, cp.histo_max, ctx->ghist.as<u64>(), ctx->gstats.as<u64>(),
-                               hvb + HvLayout<W>::rows, reinterpret_cast<u32*>(hvb + HvLayout<W>::ab));
-            CKL("k_heavy_rows");
-          }
-        }
-        ctx->mark("count");
-        if ((rc = run_scan(ctx, ctx->nsolid.as<u32>(), sc + SC_F, pl.F))) return rc;
-        ctx->mark("scan_solid");
-        // ---------------- host sync: sizes
-        CK(hipMemcpyAsync(&ctx->h_back[0], sc + SC_OVERFLOW, 4, hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipMemcpyAsync(&ctx->h_back[1], ctx->nsolid.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
-        // k-mers of the pass: the last sub-partition offset, or (fixed-capacity regions) the level-1 total
-        if (!opt1) CK(hipMemcpyAsync(&ctx->h_back[2], opt_cap ? ctx->mat1.as<u32>() + M1 : ctx->fstart.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipMemcpyAsync(&ctx->h_ovf2, sc + SC_OVF2, 4, hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipMemcpyAsync(&ctx->h_ext, sc + SC_EXT, 4, hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipMemcpyAsync(&ctx->h_stats[0], ctx->gstats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipStreamSynchronize(ctx->stream));
         const u32 h_ovf = ctx->h_back[0], h_nsolid = ctx->h_back[1], h_nk = opt1 ? (u32)ctx->h_stats[2] : ctx->h_back[2];
         if ((opt_cap && ctx->h_ovf2) || (opt1 && ctx->h_ovf1)) {       // a slice / region overflowed: repeat this attempt with exact offsets
             ctx->resolve_marks();
@@ -1532,7 +1569,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             --attempt;
             continue;
         }
-        if (h_ovf) {
+        if (h_ovf & 1u) {
             ctx->resolve_marks();
             if (attempt >= 3) return fail(ctx, DSKGPU_E_OVERFLOW, "hash table overflow after 3 retries");
             extra_bits += 1;
@@ -1865,7 +1902,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         for (u32 p = 0; p < npass; ++p) {
             u64 ns = 0, nk = 0;
             int rc;
-            if (npass > 1) { ctx->opt1_off = false; ctx->opt2_off = false; }      // an overflow is a property of ONE pass (the one that holds a k-mer with 10^8 occurrences): the others keep the fast path
+            if (npass > 1) { ctx->opt1_off = false; ctx->opt2_off = false; ctx->mw_v3_off = false; }      // an overflow is a property of ONE pass (the one that holds a k-mer with 10^8 occurrences): the others keep the fast path
             if (rec_l0) {
                 if (p >= r_hi) {       // the next sweep: as many owners as HBM holds beside a pass's own buffers and the rows still to come
                     size_t free_b = 0, total_b = 0;
@@ -2550,7 +2587,7 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
     CK(hipMemsetAsync(dst + ctx->reads_len + nbytes, '\n', 1, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     ctx->reads_len += nbytes + 1;
-    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
+    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->mw_v3_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
     return DSKGPU_OK;
 }
 
@@ -2604,7 +2641,7 @@ int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbyte
     // intermittent failure of the multi-process test was exactly that, in the test's reference count).  Once per read set, not per count.
     CK(hipSetDevice(ctx->cfg.device));
     CK(hipDeviceSynchronize());
-    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
+    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->mw_v3_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
     ctx->n_bytes = nbytes;
     ctx->reads_len = 0;
     ctx->bank_ends.clear();

@@ -1807,6 +1807,174 @@ __global__ __launch_bounds__(CNT_NT) void k_count_mw(KN<W>* keys, KN<W>* solid_k
     if (tid == 0 && ndist_acc) atomicAdd(&gstats[0], ndist_acc);
 }
 
+// ---- k_count2v3 (two-word keys, fixed-capacity regions): the table of k_count1v3 keyed by the MIXED TOP WORD alone.  kmixN folds
+// the low word into the top one before the 64-bit finalizer, so the mixed top word is a 64-bit hash of the whole k-mer: two different
+// keys of one sub-partition (~ 1300 keys) share it with probability ~ 4 * 10^-14.  The insert is then the one-word insert (read,
+// 64-bit CAS when the slot is empty, add) -- no keys staged in LDS, no index table with a second dependent 16-byte read per probe, no
+// slot list -- plus ONE store by the claiming lane (the low word, tl[slot]) and ONE read per key after the barrier: every key checks
+// the low word of the slot it was counted on.  A key that disagrees, or a key whose mixed top word IS the empty-slot value, ORs
+// bit 1 into *overflow: the host then repeats the attempt with k_count_mw (index table, full compares) -- exact by construction,
+// never expected (tests force it with crafted k-mers).  7.0 -> see DESIGN section 6 "k = 63".
+#define C2V_SLOTS 2048
+#define C2V_NKEYS 3                 // a region holds at most cap <= C2V_NKEYS * CNT_NT keys
+#define C2V_KPT 2                   // keys per thread prefetched (2048 of a mean of ~ 1300)
+#define CNT_OVF_VERIFY 2u           // bits of *overflow: "the top-word table cannot be trusted on this input" -- two k-mers with one top word,
+#define CNT_OVF_SENTINEL 4u         //  a k-mer whose top word is the empty-slot value
+__device__ __forceinline__ u32 table_insert3w(u64* tk, u64* tl, u32* tc, u32* ovf, u64 top, u64 low) {      // -> slot | claimed << 31, CNT_NONE when not placed
+    u32 slot = (u32)top & (C2V_SLOTS - 1), res = CNT_NONE;
+    bool pend = true;
+    for (int probe = 0; probe < C2V_SLOTS; ++probe) {
+        u64 old = 0ull;
+        if (pend) old = tk[slot];
+        const bool e = pend && old == DSK_EMPTY;
+        u32 mine = 0u;
+        if (e) { old = atomicCAS(&tk[slot], DSK_EMPTY, top); if (old == DSK_EMPTY) { mine = 0x80000000u; old = top; tl[slot] = low; } }
+        const bool m = pend && old == top;
+        if (m) { atomicAdd(&tc[slot], 1u); res = slot | mine; }
+        pend = pend && !m;
+        slot = (slot + 1) & (C2V_SLOTS - 1);
+        if (!__ballot(pend)) return res;
+    }
+    *ovf = 1;
+    return res;
+}
+
+template <int NT, int KPT, int NKEYS>
+__global__ __launch_bounds__(NT, 8) void k_count2v3(const K2* __restrict__ keys, K2* __restrict__ solid_keys, u32* __restrict__ abund, u32* __restrict__ nsolid,
+                                                 u64* __restrict__ ghist, u64* __restrict__ gstats,
+                                                 u32* __restrict__ overflow, CountParams cp, const u32* __restrict__ subcnt) {
+    __shared__ u64 tk[C2V_SLOTS];
+    __shared__ u64 tl[C2V_SLOTS];
+    __shared__ u32 tc[C2V_SLOTS];
+    __shared__ u32 lh[CNT_LH];
+    __shared__ u32 s_ctr[2][4];                 // [parity][ndist, out, ovf]
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int s = tid; s < C2V_SLOTS; s += NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
+    for (int b = tid; b < CNT_LH; b += NT) lh[b] = 0;
+    if (tid < 8) s_ctr[tid >> 2][tid & 3] = 0;
+    u32 ones = 0;
+    u64 ndist_acc = 0;
+    auto range_lo = [&](u32 qq) { const u32 c = qq < cp.F ? qq : cp.F - 1; return subcnt[c]; };
+    auto count_of = [&](u32 qq, u32 lo) { return qq < cp.F ? ((int)lo < 0 ? 0u : lo) : 0u; };      // (chained: counted by k_count_chained_mw)
+    struct Sub { u32 q; u32 begin; u32 n; };                                                       // (32-bit offsets: the host keeps F * cap below 2^32 for two-word keys)
+    auto load_keys = [&](const Sub& sb, K2 (&pk)[KPT]) {
+        const u32 last = sb.n ? sb.n - 1 : 0u;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) { const u32 i = tid + j * NT; pk[j] = keys[sb.begin + (i < sb.n ? i : last)]; }
+    };
+    auto sub_of = [&](u32 qq, u32 lo) { Sub sb; sb.q = qq; sb.begin = qq < cp.F ? qq * cp.cap : 0u; sb.n = count_of(qq, lo); return sb; };
+    const u32 G = gridDim.x;
+    K2 pa[KPT], pb[KPT];
+    Sub sa = sub_of(blockIdx.x, range_lo(blockIdx.x));
+    Sub sb = sub_of(blockIdx.x + G, range_lo(blockIdx.x + G));
+    u32 rq = blockIdx.x + 2 * G, rlo = range_lo(rq);
+    load_keys(sa, pa);
+    load_keys(sb, pb);
+    lds_barrier();
+    int par = 0;
+    auto one = [&](Sub& cur, K2 (&pk)[KPT]) {
+        u32* ctr = s_ctr[par];
+        const u32 q = cur.q, n = cur.n, begin = cur.begin;
+        u32 at[NKEYS];                                       // where every key of this lane was counted (bit 31: this lane claimed the slot)
+        u64 lw[NKEYS > KPT ? NKEYS - KPT : 1];               // low words of the keys past the prefetched ones
+        bool sentinel = false;
+#pragma unroll
+        for (int j = 0; j < NKEYS; ++j) at[j] = CNT_NONE;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+            if ((u32)(tid + j * NT) < n) { at[j] = table_insert3w(tk, tl, tc, &ctr[2], pk[j].w[1], pk[j].w[0]); sentinel = sentinel || pk[j].w[1] == DSK_EMPTY; }
+#pragma unroll
+        for (int j = KPT; j < NKEYS; ++j) {
+            lw[j - KPT] = 0ull;
+            if ((u32)(tid + j * NT) < n) {
+                const K2 kx = keys[begin + tid + j * NT];
+                lw[j - KPT] = kx.w[0];
+                at[j] = table_insert3w(tk, tl, tc, &ctr[2], kx.w[1], kx.w[0]);
+                sentinel = sentinel || kx.w[1] == DSK_EMPTY;
+            }
+        }
+        {
+            u32 mine = 0;
+#pragma unroll
+            for (int j = 0; j < NKEYS; ++j) mine += (u32)__popcll(__ballot(at[j] != CNT_NONE && (at[j] >> 31)));
+            if (lane == 0 && mine) atomicAdd(&ctr[0], mine);
+        }
+        lds_barrier();
+        {   // every key against the low word of its slot (the claiming lanes' stores are visible now)
+            bool wrong = false;
+#pragma unroll
+            for (int j = 0; j < NKEYS; ++j) {
+                const u64 low = j < KPT ? pk[j < KPT ? j : 0].w[0] : lw[j < KPT ? 0 : j - KPT];
+                if (at[j] != CNT_NONE) wrong = wrong || tl[at[j] & (C2V_SLOTS - 1)] != low;
+            }
+            if (wrong) atomicOr(overflow, CNT_OVF_VERIFY);
+            if (sentinel) atomicOr(overflow, CNT_OVF_SENTINEL);
+        }
+        cur = sub_of(rq, rlo);
+        load_keys(cur, pk);
+        rq += G; rlo = range_lo(rq);
+        const u32 nd = ctr[0];
+        const bool bad = ctr[2] || nd > cp.maxload;            // block-uniform
+        if (bad) {
+            lds_barrier();                                     // (the other waves' checks read tl; the reset below touches tk / tc only, but keep the phases apart)
+            for (int s = tid; s < C2V_SLOTS; s += NT) { tk[s] = DSK_EMPTY; tc[s] = 0; }
+            if (tid == 0) atomicOr(overflow, 1u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NKEYS; ++j) {
+                const bool act = at[j] != CNT_NONE && (at[j] >> 31);
+                if (!__ballot(act)) continue;                      // (wave-uniform)
+                u64 top = 0, low = 0; u32 c = 0;
+                if (act) {
+                    const u32 slot = at[j] & (C2V_SLOTS - 1);
+                    top = tk[slot]; low = tl[slot]; c = tc[slot];
+                    tk[slot] = DSK_EMPTY; tc[slot] = 0;
+                }
+                const u64 m1 = __ballot(act && c == 1);
+                if (lane == 0) ones += __popcll(m1);
+                if (act && c > 1) {
+                    const u32 bin = c < cp.histo_max ? c : cp.histo_max;
+                    if (bin < CNT_LH) atomicAdd(&lh[bin], 1u);
+                    else atomicAdd(&ghist[bin], 1ull);
+                }
+                const bool solid = act && c >= cp.amin && c <= cp.amax;
+                const u64 ms = __ballot(solid);
+                if (ms) {
+                    u32 base = 0;
+                    if (lane == 0) base = atomicAdd(&ctr[1], (u32)__popcll(ms));
+                    base = __shfl(base, 0);
+                    if (solid) {
+                        const u32 pos = base + __popcll(ms & ((1ull << lane) - 1));
+                        K2 row; row.w[0] = low; row.w[1] = top;
+                        solid_keys[begin + pos] = row;
+                        abund[begin + pos] = c;
+                    }
+                }
+            }
+        }
+        lds_barrier();
+        if (tid == 0) {
+            nsolid[q] = bad ? 0u : ctr[1];
+            ndist_acc += bad ? 0u : nd;
+            ctr[0] = 0; ctr[1] = 0; ctr[2] = 0;     // this parity is next used two barriers from now
+        }
+        par ^= 1;
+    };
+    while (sa.q < cp.F) {
+        one(sa, pa);
+        if (sb.q >= cp.F) break;
+        one(sb, pb);
+    }
+    lds_barrier();
+    if (lane == 0 && ones) atomicAdd(&lh[1], ones);
+    lds_barrier();
+    for (int b = tid; b < CNT_LH; b += NT) {
+        const u32 v = lh[b];
+        if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
+    }
+    if (tid == 0 && ndist_acc) atomicAdd(&gstats[0], ndist_acc);
+}
+
 // Multi-word sub-partitions that went on in extension regions (k_scatter_al's region chains; listed in chain_list): the index table
 // of k_count_mw addresses ONE contiguous key range, a chain is several.  Here a slot holds 1 + the GLOBAL index of the
 // representative key (the host keeps (F + pool) * cap below 2^32 for multi-word keys) and equality is checked against keys[] in
@@ -1878,7 +2046,7 @@ __global__ __launch_bounds__(CNT_NT) void k_count_chained_mw(const KN<W>* __rest
         const bool bad = ctr[2] || nd > cp.maxload;
         if (bad) {
             for (int s = tid; s < C2_SLOTS; s += CNT_NT) { slots[s] = 0; tc[s] = 0; }
-            if (tid == 0) *overflow = 1;
+            if (tid == 0) atomicOr(overflow, 1u);      // (bit 1 of the word belongs to k_count2v3)
         } else {
             for (u32 i0 = 0; i0 < nd; i0 += CNT_NT) {
                 const u32 i = i0 + tid;

@@ -59,26 +59,33 @@ typedef KN<2> K2;
 #define DSK_GOLD 0x9e3779b97f4a7c15ULL
 
 // Only the top word has to be mixed: radix digits, table slot and owner are bit fields of it, the other words are
-// just compared for equality.  top' = kmix(top ^ sum_i w[i] * A_i) with odd multipliers (multilinear hash of the
-// lower words folded into the top one, then the 64-bit finalizer): a bijection on the W words for any fold,
-// W + 1 multiplies instead of 2 (W + 1).
+// just compared for equality.  top' = kmix(top ^ t), t = XOR over the lower words of kmum(word, odd constant): a bijection on the
+// W words (for fixed lower words it is one in the top word).  kmum = low half XOR high half of the full 128-bit product: a
+// difference in ANY bit p of a word moves bits p .. p + 63 of the product, so it reaches all 64 bits of t whatever p is -- which
+// makes top' a 64-bit hash of the WHOLE key (two different keys share it with probability 2^-64, related or not), and that is
+// what k_count2v3 needs: its table is keyed by top' alone.  Two weaker folds were in use before and both were caught by that
+// kernel's verification on real-looking reads: `low * odd constant` (a multiply only carries upward: two k-mers that differ in
+// base 0 and base 32 alone share top'), and kmix(low) (its first step x ^= x >> 32 cancels differences 32 bits = 16 bases apart,
+// after which the multiply again sees a single high bit: 8 colliding pairs among the 1.1 * 10^7 distinct 63-mers of `small_repeats`).
+// Both were fine for the partition; neither is a hash of the low word's high bits.
 __host__ __device__ __forceinline__ u64 kfold_mult(int i) {
     return i == 0 ? 0x9e3779b97f4a7c15ULL : i == 1 ? 0xc2b2ae3d27d4eb4fULL : 0x165667b19e3779f9ULL;
 }
-template <int W>
-__host__ __device__ __forceinline__ void kmixN(KN<W>& x) {
-    u64 t = 0;
-#pragma unroll
-    for (int i = 0; i < W - 1; ++i) t += x.w[i] * kfold_mult(i);
-    x.w[W - 1] = kmix(x.w[W - 1] ^ t);
+__host__ __device__ __forceinline__ u64 kmum(u64 a, u64 c) {
+    const unsigned __int128 p = (unsigned __int128)a * c;
+    return (u64)p ^ (u64)(p >> 64);
 }
 template <int W>
-__host__ __device__ __forceinline__ void kunmixN(KN<W>& x) {
+__host__ __device__ __forceinline__ u64 kfold_low(const KN<W>& x) {
     u64 t = 0;
 #pragma unroll
-    for (int i = 0; i < W - 1; ++i) t += x.w[i] * kfold_mult(i);
-    x.w[W - 1] = kunmix(x.w[W - 1]) ^ t;
+    for (int i = 0; i < W - 1; ++i) t ^= kmum(x.w[i], kfold_mult(i));
+    return t;
 }
+template <int W>
+__host__ __device__ __forceinline__ void kmixN(KN<W>& x) { x.w[W - 1] = kmix(x.w[W - 1] ^ kfold_low(x)); }
+template <int W>
+__host__ __device__ __forceinline__ void kunmixN(KN<W>& x) { x.w[W - 1] = kunmix(x.w[W - 1]) ^ kfold_low(x); }
 template <int W>
 __host__ __device__ __forceinline__ bool key_eq(const KN<W>& a, const KN<W>& b) {
     bool e = true;

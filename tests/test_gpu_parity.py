@@ -460,6 +460,64 @@ def test_two_word_kmers_synthetic_two_levels(oracle, dev):
     assert st["n_levels"] == 2
 
 
+def _craft_top_word_twins(k, rng):
+    """Two different canonical k-mers (33 <= k <= 64) with the SAME mixed top word, and one whose mixed top word is the empty-slot
+    value of the count tables (kmer_device.h: kmixN -- top' = kmix(top ^ kmum(low, A0))) -> three base strings."""
+    M = (1 << 64) - 1
+    CINV = 0x4f74430c22a54005
+
+    def kmum(a):                      # low half ^ high half of the 128-bit product
+        p = a * 0x9e3779b97f4a7c15
+        return (p & M) ^ (p >> 64)
+
+    def kunmix(x):
+        x ^= x >> 32; x = (x * CINV) & M; x ^= x >> 32
+        return x
+
+    def revcomp(v):
+        r = 0
+        for _ in range(k):
+            r = (r << 2) | ((v & 3) ^ 2)
+            v >>= 2
+        return r
+
+    def text(v):
+        return "".join("ACTG"[(v >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+    def find(x, avoid=None):          # a canonical k-mer with top ^ kmum(low) == x
+        while True:
+            low = int(rng.integers(0, 1 << 62)) << 2 | int(rng.integers(0, 4))
+            top = x ^ kmum(low)
+            v = (top << 64) | low
+            if top >> (2 * k - 64) == 0 and v <= revcomp(v) and v != avoid:
+                return v
+    first = None
+    while first is None:
+        v = int(rng.integers(0, 1 << 62)) << (2 * k - 62) | int(rng.integers(0, 1 << 62))
+        v &= (1 << (2 * k)) - 1
+        if v <= revcomp(v):
+            first = v
+    x = (first >> 64) ^ kmum(first & M)
+    return text(first), text(find(x, first)), text(find(kunmix(M)))
+
+
+@pytest.mark.parametrize("which", ["twins", "sentinel"])
+def test_two_word_top_word_table_falls_back_on_what_it_cannot_tell_apart(oracle, dev, which):
+    """k_count2v3 keys its table by the mixed top word alone and checks every key's low word afterwards: two different k-mers that
+    share the top word, or a k-mer whose top word is the empty-slot value, send the attempt to k_count_mw -- same rows as the oracle."""
+    from dsk_amd import synth
+    k = 63
+    g = synth.make_genome(500_000, dev)
+    reads = synth.make_reads(g, 150_000, 150).cpu().numpy()
+    st = check_against_oracle(oracle, reads, k, dev)
+    assert st["n_levels"] == 2 and st["n_retries"] == 0
+    a, b, c = _craft_top_word_twins(k, np.random.default_rng(5))
+    extra = (a + "\n") * 3 + (b + "\n") * 5 if which == "twins" else (c + "\n") * 4
+    stream = np.concatenate([reads, np.frombuffer(extra.encode(), dtype=np.uint8)])
+    st = check_against_oracle(oracle, stream, k, dev)
+    assert st["n_retries"] == 1          # the verification bit went up once, k_count_mw counted the pass
+
+
 def test_two_word_edge_cases(oracle, golden_dir, dev):
     s, _ = oracle.load_bank(os.path.join(golden_dir, "longread.fasta"))
     check_against_oracle(oracle, s, 41, dev, amin=1)
