@@ -453,7 +453,7 @@ template <int W>
 inline void launch_count_impl(dskgpu_ctx* ctx, unsigned grid, KN<W>* keys, KN<W>* solid_keys, u32* solid_ab, u32* ovf, const CountParams& cp) {
     if constexpr (W == 2) {
         if (cp.cap && cp.cap <= C2V_NKEYS * CNT_NT && !ctx->tune.count_mw_v1 && !ctx->mw_v3_off) {      // regions: the table keyed by the mixed top word
-            CountParams c2 = cp; c2.maxload = std::min<u32>(cp.maxload, C2V_SLOTS * 7 / 8);
+            CountParams c2 = cp; c2.maxload = std::min<u32>(cp.maxload, C2V_MAXLOAD);
             hipLaunchKernelGGL((k_count2v3<CNT_NT, C2V_KPT, C2V_NKEYS>), dim3(grid), dim3(CNT_NT), 0, ctx->stream, (const K2*)keys, solid_keys, solid_ab,
                                ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, c2, cp.subcnt);
             return;
@@ -476,11 +476,16 @@ struct Plan {
 };
 
 #define TARGET_KEYS 2900      // mean keys per final sub-partition (the count kernel prefetches 3072 per sub-partition; table: 4096 slots, 3584 usable)
-#define TARGET_KEYS2 1280     // two-word keys: 2048-slot index table, 1792 usable
+#define TARGET_KEYS2 2560     // two-word keys: 3072-slot top-word table (k_count2v3), 2688 usable; 4096-slot index table (k_count_mw)
+#define TARGET_KEYS4 640      // four-word keys: 1024 staged per sub-partition
 #define MAX_LEVEL_BINS 2048
 #define ONE_LEVEL_BINS 1024
 #define CH2 65536u            // keys per level-2 chunk
 #define OPT_GROUPS 545u
+#define OPT_GROUPS2 1023u     // two-word keys: regions of 1023 groups of 64 B = 4092 keys (the count kernels are paced by their two barriers per
+                              // sub-partition, not by its keys: half as many sub-partitions of twice the size -- see DESIGN section 6 "k = 63")
+inline u32 opt_groups(int W) { return W == 2 ? OPT_GROUPS2 : OPT_GROUPS; }
+inline u64 target_keys(int W) { return W == 1 ? TARGET_KEYS : W == 2 ? TARGET_KEYS2 : TARGET_KEYS4; }
 #define OPT_CAP 4360u          // segment-owned level-2 scatter: keys per sub-partition region (mean <= TARGET_KEYS).
                               // 545 groups of 64 B -- an ODD number, so the region starts (and the write fronts that advance
                               // through all regions in step) spread over every HBM channel instead of camping on a few
@@ -488,7 +493,7 @@ struct Plan {
 // Final sub-partitions F = P1 * P2 sized to the input (any integer, not a power
 // of two: digits use the multiply-shift reduction of key_digit()).
 bool make_plan(u64 n_upper, int extra_bits, int W, bool balanced, u32 num_cu, Plan* pl) {
-    const u64 target = W == 1 ? TARGET_KEYS : W == 2 ? TARGET_KEYS2 : TARGET_KEYS2 / 2;   // four-word keys: 1024 staged per sub-partition
+    const u64 target = target_keys(W);
     u64 F = ((n_upper + target - 1) / target) << extra_bits;
     if (F < 2) F = 2;
     if (F <= ONE_LEVEL_BINS) { pl->levels = 1; pl->P1 = (u32)F; pl->P2 = 1; }
@@ -1147,7 +1152,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         // attempt back through the exact histogram + scan path.
         u32 opt_cap = 0;                 // level 2: keys per sub-partition region (0 = exact offsets)
         if (pl.levels == 2 && ctx->sentinel_ok && !ctx->opt2_off && !ctx->tune.no_opt2 && ascatter_lds(W, pl.P2) <= 160 * 1024)
-            opt_cap = OPT_GROUPS * (8u / W);                                                    // 545 groups of 64 B whatever the key width
+            opt_cap = opt_groups(W) * (8u / W);                                                 // 545 (two-word keys: 1091) groups of 64 B
         if (opt_cap && ctx->tune.opt_cap) opt_cap = ctx->tune.opt_cap;                       // experiments / tests
         if (W > 1 && (u64)pl.F * opt_cap >= 0xFFFF0000ull) opt_cap = 0;                       // k_count<W> keeps 32-bit offsets
         // extension regions behind the home regions (region chains, kernels.h): an eighth of the home regions + 4096; their offsets
@@ -2616,8 +2621,8 @@ int dskgpu_reserve_work(dskgpu_ctx* ctx, uint64_t nbytes) {
     const u64 nwords = (nbytes + 31) / 32;
     CK(ctx->packed.ensure((nwords + 1) * 8));
     CK(ctx->inval.ensure((nwords + 1) * 4));
-    const u64 target = ctx->W == 1 ? TARGET_KEYS : ctx->W == 2 ? TARGET_KEYS2 : TARGET_KEYS2 / 2;
-    const u64 F = n / target + 2, cap = OPT_GROUPS * (8u / (u64)ctx->W);
+    const u64 target = target_keys(ctx->W);
+    const u64 F = n / target + 2, cap = opt_groups(ctx->W) * (8u / (u64)ctx->W);
     const u64 regions = F + (ctx->W == 1 ? F / 8 + 4096 : 0);
     {   // a reservation is a convenience: never more than 60 % of what is free (the sizes are upper bounds from a byte count; ranks that
         // share a device and DSKGPU_PLACE's candidates need room too) -- beyond that dskgpu_count sizes the buffers itself

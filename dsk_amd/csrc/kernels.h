@@ -1647,8 +1647,8 @@ __global__ __launch_bounds__(CNT_NT) void k_count_chained(u64* keys, u64* solid_
 // first C2_STAGE of them; later ones are re-read from HBM), a slot is claimed
 // with a 32-bit CAS on the index, and equality is checked against the staged
 // representative -- no thread ever waits on another.
-#define C2_SLOTS 2048
-#define C2_MAXLOAD 1792
+#define C2_SLOTS 4096
+#define C2_MAXLOAD 3584
 // staged keys: 32 KB of LDS whatever the key width (2048 two-word, 1024 four-word keys)
 template <int W> struct CStage { static constexpr int N = 4096 / W; static constexpr int KPT = N / CNT_NT; };
 
@@ -1815,13 +1815,14 @@ __global__ __launch_bounds__(CNT_NT) void k_count_mw(KN<W>* keys, KN<W>* solid_k
 // the low word of the slot it was counted on.  A key that disagrees, or a key whose mixed top word IS the empty-slot value, ORs
 // bit 1 into *overflow: the host then repeats the attempt with k_count_mw (index table, full compares) -- exact by construction,
 // never expected (tests force it with crafted k-mers).  7.0 -> see DESIGN section 6 "k = 63".
-#define C2V_SLOTS 2048
-#define C2V_NKEYS 3                 // a region holds at most cap <= C2V_NKEYS * CNT_NT keys
-#define C2V_KPT 2                   // keys per thread prefetched (2048 of a mean of ~ 1300)
+#define C2V_SLOTS 3072              // (not a power of two: 20 bytes per slot, two blocks per CU; home slot by multiply-shift)
+#define C2V_MAXLOAD 2688            // 0.875
+#define C2V_NKEYS 4                 // a region holds at most cap <= C2V_NKEYS * CNT_NT keys
+#define C2V_KPT 2                   // keys per thread prefetched two sub-partitions ahead (2048 of a mean of <= 2560; the third is requested first thing)
 #define CNT_OVF_VERIFY 2u           // bits of *overflow: "the top-word table cannot be trusted on this input" -- two k-mers with one top word,
 #define CNT_OVF_SENTINEL 4u         //  a k-mer whose top word is the empty-slot value
 __device__ __forceinline__ u32 table_insert3w(u64* tk, u64* tl, u32* tc, u32* ovf, u64 top, u64 low) {      // -> slot | claimed << 31, CNT_NONE when not placed
-    u32 slot = (u32)top & (C2V_SLOTS - 1), res = CNT_NONE;
+    u32 slot = (u32)(((u64)(u32)top * C2V_SLOTS) >> 32), res = CNT_NONE;
     bool pend = true;
     for (int probe = 0; probe < C2V_SLOTS; ++probe) {
         u64 old = 0ull;
@@ -1832,7 +1833,7 @@ __device__ __forceinline__ u32 table_insert3w(u64* tk, u64* tl, u32* tc, u32* ov
         const bool m = pend && old == top;
         if (m) { atomicAdd(&tc[slot], 1u); res = slot | mine; }
         pend = pend && !m;
-        slot = (slot + 1) & (C2V_SLOTS - 1);
+        slot = slot + 1 == C2V_SLOTS ? 0u : slot + 1;
         if (!__ballot(pend)) return res;
     }
     *ovf = 1;
@@ -1880,6 +1881,10 @@ __global__ __launch_bounds__(NT, 8) void k_count2v3(const K2* __restrict__ keys,
         bool sentinel = false;
 #pragma unroll
         for (int j = 0; j < NKEYS; ++j) at[j] = CNT_NONE;
+        // the first key past the prefetched ones is requested now and flies under the inserts of those (a mean sub-partition is 2560 keys:
+        // half the lanes have one; three prefetched keys per lane in two register sets do not fit 64 VGPRs)
+        K2 late; late.w[0] = late.w[1] = 0ull;
+        if (NKEYS > KPT && (u32)(tid + KPT * NT) < n) late = keys[begin + tid + KPT * NT];
 #pragma unroll
         for (int j = 0; j < KPT; ++j)
             if ((u32)(tid + j * NT) < n) { at[j] = table_insert3w(tk, tl, tc, &ctr[2], pk[j].w[1], pk[j].w[0]); sentinel = sentinel || pk[j].w[1] == DSK_EMPTY; }
@@ -1887,7 +1892,8 @@ __global__ __launch_bounds__(NT, 8) void k_count2v3(const K2* __restrict__ keys,
         for (int j = KPT; j < NKEYS; ++j) {
             lw[j - KPT] = 0ull;
             if ((u32)(tid + j * NT) < n) {
-                const K2 kx = keys[begin + tid + j * NT];
+                K2 kx;
+                if (j == KPT) kx = late; else kx = keys[begin + tid + j * NT];
                 lw[j - KPT] = kx.w[0];
                 at[j] = table_insert3w(tk, tl, tc, &ctr[2], kx.w[1], kx.w[0]);
                 sentinel = sentinel || kx.w[1] == DSK_EMPTY;
@@ -1905,7 +1911,7 @@ __global__ __launch_bounds__(NT, 8) void k_count2v3(const K2* __restrict__ keys,
 #pragma unroll
             for (int j = 0; j < NKEYS; ++j) {
                 const u64 low = j < KPT ? pk[j < KPT ? j : 0].w[0] : lw[j < KPT ? 0 : j - KPT];
-                if (at[j] != CNT_NONE) wrong = wrong || tl[at[j] & (C2V_SLOTS - 1)] != low;
+                if (at[j] != CNT_NONE) wrong = wrong || tl[at[j] & 0x7FFFFFFFu] != low;
             }
             if (wrong) atomicOr(overflow, CNT_OVF_VERIFY);
             if (sentinel) atomicOr(overflow, CNT_OVF_SENTINEL);
@@ -1926,7 +1932,7 @@ __global__ __launch_bounds__(NT, 8) void k_count2v3(const K2* __restrict__ keys,
                 if (!__ballot(act)) continue;                      // (wave-uniform)
                 u64 top = 0, low = 0; u32 c = 0;
                 if (act) {
-                    const u32 slot = at[j] & (C2V_SLOTS - 1);
+                    const u32 slot = at[j] & 0x7FFFFFFFu;
                     top = tk[slot]; low = tl[slot]; c = tc[slot];
                     tk[slot] = DSK_EMPTY; tc[slot] = 0;
                 }
