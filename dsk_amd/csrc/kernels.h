@@ -711,6 +711,45 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
                     write_out();
                 }
             }
+        } else if constexpr (SRC == 0 && W == 2) {
+            // two-word keys from the reads, the same way: lane l of wave w takes the 8 windows ending in quarter (w >> 2) of word
+            // (w & 3) * 64 + l of the tile (256 words = 8192 windows), so the quarter -- the window offset t0 = 0 / 8 / 16 / 24 -- is
+            // wave-uniform and a compile-time constant inside each branch below (every shift of the generator by a fixed amount, the
+            // validity masks scalar), and the six words a thread needs for the NEXT tile are requested before the stores of this one.
+            struct Raw2 { u64 cur, p1, p2; u32 ic, i1, i2; };
+            const u32 wlane = threadIdx.x & (SC_NT / 4 - 1);
+            const u32 quarter = threadIdx.x / (SC_NT / 4);                    // wave-uniform
+            auto load_raw = [&](u64 t0) {
+                const u64 wi = t0 + wlane;
+                const u64 wc = wi < d.end ? wi : d.end - 1;                   // clamped: the loads stay unconditional (and countable)
+                Raw2 r; r.cur = packed[wc]; r.p1 = packed[wc >= 1 ? wc - 1 : 0]; r.p2 = packed[wc >= 2 ? wc - 2 : 0];
+                r.ic = inval[wc]; r.i1 = inval[wc >= 1 ? wc - 1 : 0]; r.i2 = inval[wc >= 2 ? wc - 2 : 0];
+                if (wc < 1) { r.p1 = 0ull; r.i1 = 0xFFFFFFFFu; }
+                if (wc < 2) { r.p2 = 0ull; r.i2 = 0xFFFFFFFFu; }
+                return r;
+            };
+            if (d.begin < d.end) {
+                Raw2 raw = load_raw(d.begin);
+                if (OPT) {          // (see the one-word loop: the same in-flight picture on both edges of the loop)
+                    Key fillk; fillk.w[0] = fillk.w[1] = (u64)threadIdx.x;
+#pragma unroll
+                    for (int u = 0; u < 4 * ((KPT + 3) / 4); ++u) out[(u64)(o1.dump + u * SC_NT + threadIdx.x)] = fillk;
+                }
+                for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
+                    const bool live = t0 + wlane < d.end;
+                    if (quarter == 0) vma = gen_kmers2_words<8>(raw.cur, raw.p1, raw.p2, raw.ic, raw.i1, raw.i2, 0, k, ha);
+                    else if (quarter == 1) vma = gen_kmers2_words<8>(raw.cur, raw.p1, raw.p2, raw.ic, raw.i1, raw.i2, 8, k, ha);
+                    else if (quarter == 2) vma = gen_kmers2_words<8>(raw.cur, raw.p1, raw.p2, raw.ic, raw.i1, raw.i2, 16, k, ha);
+                    else vma = gen_kmers2_words<8>(raw.cur, raw.p1, raw.p2, raw.ic, raw.i1, raw.i2, 24, k, ha);
+                    if (!live) vma = 0u;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) kmixN(ha[j]);
+                    rank_and_stage(ha, vma);
+                    const u64 tn = t0 + step < d.end ? t0 + step : t0;      // (the last tile re-reads its own words: same number of loads every trip)
+                    raw = load_raw(tn);
+                    write_out();
+                }
+            }
         } else if constexpr (SRC == 0) {
             for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
                 vma = tile_keys_reads(packed, inval, t0, d.end, k, ha);

@@ -149,15 +149,9 @@ __device__ __forceinline__ u32 gen_kmers1(const u64* __restrict__ packed, const 
 // ---------------------------------------------------------------- two-word k-mers (33 <= k <= 64)
 
 // Windows ending at bases 32*wi + t0 + j, j < NP.  Needs packed[wi-2..wi].
+// (the words of the frame already in registers: cur / p1 / p2 = packed[wi], [wi-1], [wi-2]; ic / i1 / i2 = their invalid masks)
 template <int NP>
-__device__ __forceinline__ u32 gen_kmers2(const u64* __restrict__ packed, const u32* __restrict__ inval,
-                                          u64 wi, int t0, int k, K2 (&canon)[NP]) {
-    const u64 cur = packed[wi];
-    const u64 p1 = wi >= 1 ? packed[wi - 1] : 0ull;
-    const u64 p2 = wi >= 2 ? packed[wi - 2] : 0ull;
-    const u32 ic = inval[wi];
-    const u32 i1 = wi >= 1 ? inval[wi - 1] : 0xFFFFFFFFu;
-    const u32 i2 = wi >= 2 ? inval[wi - 2] : 0xFFFFFFFFu;
+__device__ __forceinline__ u32 gen_kmers2_words(u64 cur, u64 p1, u64 p2, u32 ic, u32 i1, u32 i2, int t0, int k, K2 (&canon)[NP]) {
     // 96-bit invalid window: bit (95-i) <-> base i of (p2:p1:cur); keep as hi32:lo64
     const u64 inv_lo = ((u64)i1 << 32) | ic;
     const u32 inv_hi = i2;
@@ -199,6 +193,12 @@ __device__ __forceinline__ u32 gen_kmers2(const u64* __restrict__ packed, const 
         if (((inv_lo & lo_bits) == 0) && ((inv_hi & hi_bits) == 0)) vmask |= (1u << j);
     }
     return vmask;
+}
+template <int NP>
+__device__ __forceinline__ u32 gen_kmers2(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                          u64 wi, int t0, int k, K2 (&canon)[NP]) {
+    return gen_kmers2_words<NP>(packed[wi], wi >= 1 ? packed[wi - 1] : 0ull, wi >= 2 ? packed[wi - 2] : 0ull,
+                                inval[wi], wi >= 1 ? inval[wi - 1] : 0xFFFFFFFFu, wi >= 2 ? inval[wi - 2] : 0xFFFFFFFFu, t0, k, canon);
 }
 
 // ---------------------------------------------------------------- W-word k-mers (general; used for 65 <= k <= 128 with W = 4)
