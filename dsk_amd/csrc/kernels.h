@@ -927,10 +927,18 @@ __global__ __launch_bounds__(256) void k_count_valid(const u32* __restrict__ inv
 //   bound = (pos + t) & ~(G-1);  e = bound > pos ? bound - pos : 0;  rn' = t - e;  pos' = pos + e
 // Write-out is bin-centric: a lane group of G lanes owns a bin for the tile, writes its complete
 // groups and then refreshes its carry, so no barrier separates the two.
+#ifndef AL_G2
+#define AL_G2 4              // two-word keys: keys per aligned group of the level-2 write-out (4 = 64 bytes; 8 = 128 bytes: experiments)
+#define AL_KPT2 6            //                keys per thread and tile
+#endif
+#ifndef AL_G1
+#define AL_G1 8              // one-word keys: the same (8 = 64 bytes; 16 = 128 bytes: experiments)
+#define AL_KPT1 12
+#endif
 template <int W> struct ATile {
-    static constexpr int G = 8 / W;              // keys per 64-byte group
+    static constexpr int G = W == 2 ? AL_G2 : W == 1 ? AL_G1 : 8 / W;      // keys per aligned group (64 bytes)
     static constexpr int CARRY = G - 1;
-    static constexpr int KPT = 12 / W;           // 12288 one-word / 6144 two-word keys per tile = 96 KB
+    static constexpr int KPT = W == 2 ? AL_KPT2 : W == 1 ? AL_KPT1 : 12 / W; // 12288 one-word / 6144 two-word keys per tile = 96 KB
     static constexpr int KEYS = SC_NT * KPT;
 };
 // A bin that receives more than AL_BIG_KEYS keys in ONE tile (a k-mer with tens of thousands of occurrences: 2 % of a tile) is
@@ -942,7 +950,7 @@ template <int W> struct ATile {
 #define SLICED_MAX 320      // most level-1 slices per bin (= blocks of the level-1 launch: 256 CUs x 1) the level-2 loader can walk
 #endif
 __host__ __device__ inline size_t ascatter_lds(int W, u32 P) {
-    const size_t key = 8 * (size_t)W, keys = (size_t)SC_NT * (12 / W), G = 8 / W;
+    const size_t key = 8 * (size_t)W, keys = (size_t)SC_NT * (W == 2 ? AL_KPT2 : W == 1 ? AL_KPT1 : 12 / W), G = W == 2 ? AL_G2 : W == 1 ? AL_G1 : 8 / W;
     return keys * key + (size_t)P * (G - 1) * key + (size_t)(P + 1) * 4 + (size_t)P * 4 + (size_t)(P + 1) * 12 + (size_t)P * 2 + 20 * 4 + 32
            + SLICED_MAX * 4 + 16      // + prefix sums of the slice fills (SLICED input)
            + 2 * AL_BIG * 2 + 16;     // + the lists (one per tile parity) of bins with a long run in the tile (written by the whole block)

@@ -422,6 +422,8 @@ def test_randomized_two_level_inputs(oracle, dev, seed):
     k = int(rng.choice([15, 21, 27, 31, 32, 33, 41, 55, 63, 64, 70, 96]))
     rl = int(rng.choice([max(k + 5, 80), 150, 251, 1000]))
     n_kmers = int(rng.choice([4_500_000, 6_000_000]))                     # > 1024 sub-partitions for every width, also with 1 % N (the plan counts valid windows)
+    if 32 < k <= 64:
+        n_kmers *= 2                                                      # (two-word sub-partitions hold 2560 keys)
     n_reads = n_kmers // (rl - k + 1) + 1
     cov = float(rng.choice([1.5, 8.0, 40.0]))
     glen = max(1000, int(n_reads * rl / cov))

@@ -40,6 +40,10 @@ avg_ns = {r["Name"]: float(r["AverageNs"]) for r in rows}
 stage_of = [("k_encode", "encode"), ("k_hist<1, 0,", "sample1"), ("k_bin_moments", "sample1"), ("k_scatter<1, 0,", "scatter1"), ("k_hist<1, 1,", "hist2"),
             ("k_scatter<1, 1,", "scatter2"), ("k_scatter_al<1,", "scatter2"), ("k_count1<", "count"), ("k_count1v3<", "count"), ("k_count_chained", "count"),
             ("k_compact<1>", "compact"),
+            # two-word keys (k = 33..64)
+            ("k_hist<2, 0,", "sample1"), ("k_scatter<2, 0,", "scatter1"), ("k_scatter_al<2,", "scatter2"), ("k_count2v3<", "count"), ("k_count_mw<2", "count"),
+            ("k_count_chained_mw", "count"), ("k_compact<2>", "compact"), ("k_top_key_aos<2>", "sort"), ("k_gather_aos<2>", "sort"), ("k_fix_runs_multi<2>", "sort"),
+            ("k_fix_long_runs<2>", "sort"),
             ("k_rs_hist", "sort"), ("k_rs_scatter", "sort"), ("k_rs_split", "sort"), ("k_rs_cells", "sort"), ("k_rs_big", "sort")]
 summary = {}
 lines = [f"# PMC summary ({tag})", "",
@@ -76,7 +80,8 @@ try:
 except Exception:
     meta["commit"] = None
 summary["_meta"] = meta
-json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+# pmc_summary.json is what bench.py reads for the default workload: only the k = 31 bench profile writes it
+json.dump(summary, open(os.path.join(dst, "pmc_summary.json" if int(meta["kmer_size"]) == 31 else f"{tag}_pmc_summary.json"), "w"), indent=1)
 bench = [l for l in open(os.path.join(src, "bench_trace.log")) if l.startswith('{"metric"')]
 if bench:
     open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w").write(bench[-1])
