@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file -> .h5 wall-clock block (dsk binary)")
     ap.add_argument("--no-repeat-rich", action="store_true", help="skip the repeat-rich twin of the workload (extra block, headline unchanged)")
+    ap.add_argument("--no-k63", action="store_true", help="skip the k = 63 count of the same reads (two-word keys, configs[3]'s key width: extra block, headline unchanged)")
     ap.add_argument("--no-human-standin", action="store_true", help="skip the configs[4] stand-in block (600 M x 150 bp of a repeat-rich 3 Gbp genome on this one GPU, ~20 s)")
     ap.add_argument("--no-place-compare", action="store_true", help="skip the plain-hipMalloc leg that yields ms_per_step_no_place (profiling runs: one set of launches per kernel)")
     ap.add_argument("--no-place", action="store_true", help="plain hipMalloc for the big device buffers instead of the best-placed of 8 candidates (DSKGPU_F_PLACE)")
@@ -534,6 +535,35 @@ def main():
                                   **{k: rst[k] for k in ("n_retries", "sort_fallback", "n_ext_regions", "n_heavy")}}
             kc.set_reads_device(reads.data_ptr(), n_bytes)
             del rr
+        # the same reads with two-word keys (k = 63: the key width of BASELINE.json's configs[3]).  An extra block, its own context
+        # (same placement setting); the headline above stays k = 31.
+        if world == 1 and not args.no_k63 and args.kmer_size == 31 and rl >= 63:
+            with KmerCounter(kmer_size=63, abundance_min=args.abundance_min, device=local_rank, timing=True, sort=not args.no_sort,
+                             stream=stream, place=not args.no_place) as k2:
+                k2.set_reads_device(reads.data_ptr(), n_bytes)
+                for _ in range(max(2, args.warmup)):
+                    k2.count()
+                torch.cuda.synchronize()
+                acc2 = {}
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    k2.count()
+                    for name, ms in k2.stage_times():
+                        acc2.setdefault(name, []).append(ms)
+                torch.cuda.synchronize()
+                ms2 = (time.perf_counter() - t1) / args.steps * 1e3
+                st2 = k2.stats()
+                stage2 = {name: sum(v) / len(v) for name, v in acc2.items()}
+                fr2 = {}
+                for name in ("scatter1", "scatter2", "count"):
+                    ab = algorithmic_bytes(name, n_bytes, st2["n_kmers"], W=16)
+                    if ab and stage2.get(name):
+                        fr2[name] = {"algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(stage2[name], 4), "frac": round(ab / (stage2[name] * 1e-3) / 8e12, 4)}
+                out["k63"] = {"workload": args.workload + " at k = 63 (two-word keys)", "ms_per_step": round(ms2, 3),
+                              "kmer_occurrences_per_s": st2["n_kmers"] / (ms2 * 1e-3), "distinct_kmers_per_s": st2["n_distinct"] / (ms2 * 1e-3),
+                              "n_kmers": st2["n_kmers"], "n_distinct": st2["n_distinct"], "n_solid": st2["n_solid"],
+                              "stage_ms": {name: round(v, 4) for name, v in stage2.items()}, "roofline_kernels": fr2,
+                              **{name: st2[name] for name in ("n_passes", "n_retries", "sort_fallback")}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(reads, rl, args.cpu_sample_reads, args.kmer_size)
         elif not args.no_cpu_baseline:
