@@ -14,6 +14,7 @@
 #include "kernels.h"
 #include "superkmer.h"
 #include "rowsort.h"
+#include "rowsort2.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -123,6 +124,7 @@ struct Tuning {
     bool no_aligned = false;                    // DSKGPU_NO_ALIGNED: plain write-out for key-array scatters
     bool balanced_plan = false;                 // DSKGPU_BALANCED_PLAN: P1 ~ P2
     bool fullsort = false;                      // DSKGPU_FULLSORT: full-width row sort
+    bool rows2_pairs = false;                   // DSKGPU_ROWS2_PAIRS: two-word rows as (top 63 bits, row index) pairs + gather + tie pass (the path before rowsort2.h)
     bool lib_rowsort = false;                   // DSKGPU_LIB_ROWSORT: one-word rows through the library radix sort on a 32-bit prefix + run fix-up (the path before rowsort.h)
     u32 rs_heavy = 0;                           // DSKGPU_RS_HEAVY: rows of a first-digit bucket above which the row sort gives up (tests)
     u32 rs_bbits = 0;                           // DSKGPU_RS_BBITS: forced width of the row sort's second digit (8..10; tests)
@@ -156,7 +158,7 @@ struct Tuning {
         table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
         max_ext = getenv("DSKGPU_MAX_EXT") ? atoll(getenv("DSKGPU_MAX_EXT")) : -1;
         no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); l2_static = on("DSKGPU_L2_STATIC"); force_heavy = on("DSKGPU_FORCE_HEAVY"); count_v1 = on("DSKGPU_COUNT_V1"); count_mw_v1 = on("DSKGPU_COUNT_MW_V1"); no_level0 = on("DSKGPU_NO_LEVEL0"); l0_passes = (u32)num("DSKGPU_L0_PASSES", 0); mp_pass_mkeys = (u32)num("DSKGPU_MP_PASS_MKEYS", 0); rs_max_rows = num("DSKGPU_RS_MAX_ROWS", 0); l0_staged = on("DSKGPU_L0_STAGED"); l0_keys = on("DSKGPU_L0_KEYS");
-        lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0); rs_heavy = (u32)num("DSKGPU_RS_HEAVY", 0);
+        lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rows2_pairs = on("DSKGPU_ROWS2_PAIRS"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0); rs_heavy = (u32)num("DSKGPU_RS_HEAVY", 0);
     }
 };
 
@@ -340,9 +342,9 @@ int run_scan(dskgpu_ctx* ctx, u32* a, const u32* d_len, u64 max_len) {
 
 // Kernels that stage a whole tile need more dynamic LDS than the 64 KB default: raise the limit once per context
 // (a context is bound to one device and driven by one thread, so no process-wide flag is involved).
-int allow_big_lds(dskgpu_ctx* ctx, const void* fn) {
+int allow_big_lds(dskgpu_ctx* ctx, const void* fn, int bytes = 160 * 1024) {      // (bytes: kernels with static LDS next to the dynamic block ask for what they use)
     for (const void* f : ctx->big_lds_fns) if (f == fn) return DSKGPU_OK;
-    CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     ctx->big_lds_fns.push_back(fn);
     return DSKGPU_OK;
 }
@@ -686,6 +688,97 @@ int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int
     return DSKGPU_OK;
 }
 
+// ---- the same sort for two-word rows (rowsort2.h): the rows themselves -- (hi, lo, abundance) in three arrays -- ordered in place on
+// the `total` low bits of hi:lo (t: scratch of the same size).  What it lists (sub-buckets above RS_BLOCK_ROWS rows) is left in
+// ctx->rs_ovs for the caller's next round; a heavy first-digit bucket or a full list raises SC_SORTFLAG.  k holds a complete
+// permutation of the rows either way.
+int msd_sort_rows2(dskgpu_ctx* ctx, Rows2 k, Rows2 t, u64 n, int total, bool reset_flags, u32 base) {
+    int wantB = n <= (96ull << 20) ? 8 : n <= (192ull << 20) ? 9 : 10;
+    if (ctx->tune.rs_bbits >= 8 && ctx->tune.rs_bbits <= 10) wantB = (int)ctx->tune.rs_bbits;      // tests
+    const int bA = std::min(10, total), r1 = total - bA, bB = std::min(wantB, r1), r2 = r1 - bB, bC = std::min(8, r2), r3 = r2 - bC;
+    const u32 BB = 1u << wantB;
+    RsSpec sp{r1, r2, r3, (1u << bA) - 1u, (1u << bB) - 1u, (1u << bC) - 1u};
+    const u64 ncu = (u64)ctx->num_cu;
+    u64 nch = (n + 65535) / 65536;
+    nch = (nch + ncu - 1) / ncu * ncu;
+    nch = std::max<u64>(1, std::min<u64>(nch, (n + RS2_TILE - 1) / RS2_TILE));
+    const u64 chunk = (n + nch - 1) / nch;
+    nch = (n + chunk - 1) / chunk;
+    const u64 M = (u64)RS_ABINS * nch;
+    const u64 nsubw = (u64)RS_ABINS * (BB + 1);
+    CK(ctx->srt_tmp.ensure((M + 2 + 2 * nsubw + 16) * 4));
+    u32* matrix = static_cast<u32*>(ctx->srt_tmp.p);
+    u32* sub = matrix + M + 2;
+    u32* biglist = sub + nsubw;
+    u32* sc = ctx->scalars.as<u32>();
+    ctx->h_rs[0] = (u32)M; ctx->h_rs[1] = 0; ctx->h_rs[2] = 0; ctx->h_rs[3] = 0;
+    CK(hipMemcpyAsync(sc + SC_RSLEN, ctx->h_rs, 16, hipMemcpyHostToDevice, ctx->stream));
+    CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
+    if (reset_flags) { CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream)); CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream)); }
+    const size_t ldsA = Rs2Lds<RS_ABINS, RS2_TILE>::bytes;
+    const size_t ldsB = BB == 256 ? Rs2Lds<256, RS2_BTILE>::bytes : BB == 512 ? Rs2Lds<512, RS2_BTILE>::bytes : Rs2Lds<1024, RS2_BTILE>::bytes;
+    const size_t ldsBig = (size_t)RS_BLOCK_ROWS * 20 + 2 * RS_CELLS * 4;
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_scatter)); if (e) return e; }
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_big), (int)ldsBig); if (e) return e; }
+    const Rows2C kc{k.hi, k.lo, k.ab}, tc{t.hi, t.lo, t.ab};
+    hipLaunchKernelGGL(k2_hist, dim3((unsigned)nch), dim3(RS_NT), 0, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, sp);
+    CKL("k2_hist");
+    { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
+    hipLaunchKernelGGL(k2_scatter, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, t, sp);
+    CKL("k2_scatter");
+    u32 heavy = (u32)std::min<u64>(0xFFFFFFFFull, n / RS_ABINS * 16 + 65536);
+    if (ctx->tune.rs_heavy) heavy = ctx->tune.rs_heavy;
+    const unsigned gridB = (unsigned)std::min<u64>(ncu * (160 * 1024 / (ldsB + 1024)), RS_ABINS);
+    auto split = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(gridB), dim3(RS_BNT), ldsB, ctx->stream, tc, (u32)nch, matrix, k, sub, sp, sc + SC_RSWORK2, heavy, sc + SC_SORTFLAG);
+    };
+    if (BB == 256) split(k2_split<256>); else if (BB == 512) split(k2_split<512>); else split(k2_split<1024>);
+    CKL("k2_split");
+    const u32 nsub = RS_ABINS * BB;
+    hipLaunchKernelGGL(k2_cells, dim3(nsub / (RS_CNT / 64)), dim3(RS_CNT), 0, ctx->stream, k, sub, nsub, BB, sp, biglist, sc + SC_RSWORK);
+    CKL("k2_cells");
+    const u32 block_rows = ctx->tune.rs_block_rows ? std::min<u32>(ctx->tune.rs_block_rows, RS_BLOCK_ROWS) : RS_BLOCK_ROWS;
+    hipLaunchKernelGGL(k2_big, dim3((unsigned)std::min<u64>(ncu, 256)), dim3(RS_NT), ldsBig, ctx->stream, k, sub, sp, biglist, sc + SC_RSWORK, sc + SC_SORTFLAG, block_rows, base, ctx->rs_ovs.as<u32>());
+    CKL("k2_big");
+    return DSKGPU_OK;
+}
+
+// two-word rows, <= RS_MAX_ROWS: out_* ordered in place; the sub-buckets the sort lists go round again on their remaining bits,
+// range by range (a handful on real reads; each round consumes 26-28 bits: at most ceil(128 / 18) rounds).  Leaves the flag
+// read-back in flight like the other sorts (ctx->h_back[3] != 0 after the caller's sync: the full-width fallback, which reads out_*)
+int sort_rows2_msd(dskgpu_ctx* ctx, u64 n) {
+    for (int x = 0; x < 2; ++x) CK(ctx->srt_w[x].ensure(n * 8));
+    CK(ctx->srt_ab.ensure(n * 4));
+    const Rows2 K{ctx->out_w[1].as<u64>(), ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>()};
+    const Rows2 T{ctx->srt_w[1].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>()};
+    u32* sc = ctx->scalars.as<u32>();
+    { const int e = msd_sort_rows2(ctx, K, T, n, 2 * (int)ctx->cfg.kmer_size, true, 0u); if (e) return e; }
+    std::vector<u32> list;
+    for (int round = 0; ; ++round) {
+        u32 cnt = 0;
+        CK(hipMemcpyAsync(&ctx->h_back[3], sc + SC_SORTFLAG, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(&cnt, ctx->rs_ovs.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        if (ctx->h_back[3] || cnt == 0) break;
+        if (cnt > RS2_OVS_CAP || round >= 8) { ctx->h_back[3] = 1; CK(hipMemsetAsync(sc + SC_SORTFLAG, 0xFF, 4, ctx->stream)); break; }
+        list.resize(3 * (size_t)cnt);
+        CK(hipMemcpyAsync(list.data(), ctx->rs_ovs.as<u32>() + 1, list.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream));
+        if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] two-word row sort, round %d: %u sub-bucket(s) above %u rows go round again (first: %u rows, %u bits left)\n", round + 1, cnt, (u32)RS_BLOCK_ROWS, list[1], list[2]);
+        for (u32 r = 0; r < cnt; ++r) {
+            const u64 off = list[3 * r]; const u32 len = list[3 * r + 1], bits = list[3 * r + 2];
+            const Rows2 k2{K.hi + off, K.lo + off, K.ab + off}, t2{T.hi + off, T.lo + off, T.ab + off};
+            const int e = msd_sort_rows2(ctx, k2, t2, len, (int)bits, false, (u32)off);
+            if (e) return e;
+        }
+    }
+    CK(hipMemcpyAsync(&ctx->h_back[3], sc + SC_SORTFLAG, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->h_ovs.assign(1, 0);
+    ctx->sort_partial = true;
+    return DSKGPU_OK;
+}
+
 // one-word rows: out_* ordered in place (srt_* = scratch and, for run_pipeline's fallback, a complete permutation of the rows)
 int sort_rows_msd(dskgpu_ctx* ctx, u64 n) {
     const int e = msd_sort_pairs(ctx, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), n,
@@ -868,6 +961,8 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
         ctx->res_w[0] = ctx->srt_w[0].as<u64>(); ctx->res_ab = ctx->srt_ab.as<u32>();
         return DSKGPU_OK;
     }
+    // two-word rows: the rows themselves through the MSD sort (rowsort2.h)
+    if (W == 2 && !ctx->tune.fullsort && !ctx->tune.lib_rowsort && !ctx->tune.rows2_pairs && n <= RS_MAX_ROWS && 2u * ctx->cfg.kmer_size > 64u) return sort_rows2_msd(ctx, n);
     // multi-word rows: radix sort of (top 63 bits of the value, row index) on the key's top 32 bits, gather,
     // then the runs of equal prefix are ordered in place by full comparison (exact fallback: sort_rows_full_multiword)
     if (!ctx->tune.fullsort && 2u * ctx->cfg.kmer_size > 64u) {
