@@ -241,6 +241,7 @@ struct dskgpu_ctx {
     // results
     bool have_result = false;
     bool sort_partial = false;
+    bool rows2_in_scratch = false; Rows2 rows2_scratch{};      // two-word rows above RS_MAX_ROWS: the result (and the fallback's input) is the scratch copy
     u64 n_rows = 0;
     const u64* res_w[4] = {nullptr, nullptr, nullptr, nullptr}; const u32* res_ab = nullptr;
     dskgpu_stats stats{};
@@ -743,16 +744,10 @@ int msd_sort_rows2(dskgpu_ctx* ctx, Rows2 k, Rows2 t, u64 n, int total, bool res
     return DSKGPU_OK;
 }
 
-// two-word rows, <= RS_MAX_ROWS: out_* ordered in place; the sub-buckets the sort lists go round again on their remaining bits,
-// range by range (a handful on real reads; each round consumes 26-28 bits: at most ceil(128 / 18) rounds).  Leaves the flag
-// read-back in flight like the other sorts (ctx->h_back[3] != 0 after the caller's sync: the full-width fallback, which reads out_*)
-int sort_rows2_msd(dskgpu_ctx* ctx, u64 n) {
-    for (int x = 0; x < 2; ++x) CK(ctx->srt_w[x].ensure(n * 8));
-    CK(ctx->srt_ab.ensure(n * 4));
-    const Rows2 K{ctx->out_w[1].as<u64>(), ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>()};
-    const Rows2 T{ctx->srt_w[1].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>()};
+// the sub-buckets a two-word sort listed (ctx->rs_ovs; offsets are absolute rows of R, the array that holds the result; S = scratch of
+// the same shape): every listed range goes round again on the bits it has not used, until nothing is listed any more
+int rows2_rounds(dskgpu_ctx* ctx, Rows2 R, Rows2 S) {
     u32* sc = ctx->scalars.as<u32>();
-    { const int e = msd_sort_rows2(ctx, K, T, n, 2 * (int)ctx->cfg.kmer_size, true, 0u); if (e) return e; }
     std::vector<u32> list;
     for (int round = 0; ; ++round) {
         u32 cnt = 0;
@@ -768,14 +763,101 @@ int sort_rows2_msd(dskgpu_ctx* ctx, u64 n) {
         if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] two-word row sort, round %d: %u sub-bucket(s) above %u rows go round again (first: %u rows, %u bits left)\n", round + 1, cnt, (u32)RS_BLOCK_ROWS, list[1], list[2]);
         for (u32 r = 0; r < cnt; ++r) {
             const u64 off = list[3 * r]; const u32 len = list[3 * r + 1], bits = list[3 * r + 2];
-            const Rows2 k2{K.hi + off, K.lo + off, K.ab + off}, t2{T.hi + off, T.lo + off, T.ab + off};
+            const Rows2 k2{R.hi + off, R.lo + off, R.ab + off}, t2{S.hi + off, S.lo + off, S.ab + off};
             const int e = msd_sort_rows2(ctx, k2, t2, len, (int)bits, false, (u32)off);
             if (e) return e;
         }
     }
+    return DSKGPU_OK;
+}
+
+// two-word rows, <= RS_MAX_ROWS: out_* ordered in place; the sub-buckets the sort lists go round again on their remaining bits,
+// range by range (a handful on real reads; each round consumes 26-28 bits: at most ceil(128 / 18) rounds).  Leaves the flag
+// read-back in flight like the other sorts (ctx->h_back[3] != 0 after the caller's sync: the full-width fallback, which reads out_*)
+int sort_rows2_msd(dskgpu_ctx* ctx, u64 n) {
+    for (int x = 0; x < 2; ++x) CK(ctx->srt_w[x].ensure(n * 8));
+    CK(ctx->srt_ab.ensure(n * 4));
+    const Rows2 K{ctx->out_w[1].as<u64>(), ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>()};
+    const Rows2 T{ctx->srt_w[1].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>()};
+    u32* sc = ctx->scalars.as<u32>();
+    { const int e = msd_sort_rows2(ctx, K, T, n, 2 * (int)ctx->cfg.kmer_size, true, 0u); if (e) return e; }
+    { const int e = rows2_rounds(ctx, K, T); if (e) return e; }
     CK(hipMemcpyAsync(&ctx->h_back[3], sc + SC_SORTFLAG, 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->h_ovs.assign(1, 0);
     ctx->sort_partial = true;
+    return DSKGPU_OK;
+}
+
+// two-word row sets above RS_MAX_ROWS (all of configs[3]'s volume on one GPU: 7 * 10^8 rows): sort_rows_big's scheme with the
+// rowsort2.h kernels -- step A once over all rows (out_* -> scratch), then the groups of 10-bit buckets that share their top `sb` bits
+// are ordered one by one (in the scratch copy, out_* their scratch), then the listed sub-buckets' rounds.  Result: ctx->res_* = the
+// scratch copy; on a raised flag the caller copies it back to out_* for the full-width fallback (ctx->rows2_in_scratch).
+int sort_rows2_big(dskgpu_ctx* ctx, u64 n) {
+    const Rows2 K{ctx->out_w[1].as<u64>(), ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>()};
+    const size_t n_al = (size_t)((n + 31) & ~(u64)31), need = n_al * 20 + 256;
+    Rows2 T;
+    if (ctx->l0buf.cap >= need) { T.hi = ctx->l0buf.as<u64>(); T.lo = T.hi + n_al; T.ab = reinterpret_cast<u32*>(T.lo + n_al); }
+    else {
+        size_t free_b = 0, total_b = 0;
+        CK(hipMemGetInfo(&free_b, &total_b));
+        if (ctx->srt_w[0].cap + ctx->srt_w[1].cap + ctx->srt_ab.cap + free_b < need + ((size_t)2 << 30)) { ctx->l0buf.release(); ctx->bufA.release(); ctx->bufB.release(); }
+        for (int x = 0; x < 2; ++x) CK(ctx->srt_w[x].ensure(n * 8));
+        CK(ctx->srt_ab.ensure(n * 4));
+        T = Rows2{ctx->srt_w[1].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>()};
+    }
+    const int total = 2 * (int)ctx->cfg.kmer_size;
+    const int bA = std::min(10, total);
+    RsSpec sp{total - bA, 0, 0, (1u << bA) - 1u, 0u, 0u};
+    const u64 ncu = (u64)ctx->num_cu;
+    u64 nch = (n + 65535) / 65536;
+    nch = (nch + ncu - 1) / ncu * ncu;
+    const u64 chunk = (n + nch - 1) / nch;
+    nch = (n + chunk - 1) / chunk;
+    const u64 M = (u64)RS_ABINS * nch;
+    if (M >= 0xFFFFFFF0ull) return fail(ctx, DSKGPU_E_ARG, "row sort: too many rows");
+    CK(ctx->mat2.ensure((M + 2) * 4));
+    u32* matrix = ctx->mat2.as<u32>();
+    u32* sc = ctx->scalars.as<u32>();
+    ctx->h_rs[0] = (u32)M; ctx->h_rs[1] = 0; ctx->h_rs[2] = 0; ctx->h_rs[3] = 0;
+    CK(hipMemcpyAsync(sc + SC_RSLEN, ctx->h_rs, 16, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream));
+    CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
+    CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream));
+    ctx->h_ovs.assign(1, 0);
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_scatter)); if (e) return e; }
+    const Rows2C kc{K.hi, K.lo, K.ab};
+    hipLaunchKernelGGL(k2_hist, dim3((unsigned)nch), dim3(RS_NT), 0, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, sp);
+    CKL("k2_hist");
+    { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
+    const size_t ldsA = Rs2Lds<RS_ABINS, RS2_TILE>::bytes;
+    hipLaunchKernelGGL(k2_scatter, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, T, sp);
+    CKL("k2_scatter");
+    std::vector<u32> start(RS_ABINS + 1);
+    CK(hipMemcpy2DAsync(start.data(), 4, matrix, nch * 4, 4, RS_ABINS + 1, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    start[RS_ABINS] = (u32)n;
+    const u64 rs_max = ctx->tune.rs_max_rows ? std::min<u64>(ctx->tune.rs_max_rows, RS_MAX_ROWS) : RS_MAX_ROWS;
+    int sb = -1;
+    for (int bits = 0; bits <= bA && sb < 0; ++bits) {
+        const u32 per = (1u << bA) >> bits;
+        bool ok = true;
+        for (u32 g0 = 0; g0 < (1u << bA) && ok; g0 += per) ok = (u64)start[g0 + per] - start[g0] <= rs_max;
+        if (ok) sb = bits;
+    }
+    ctx->res_w[1] = T.hi; ctx->res_w[0] = T.lo; ctx->res_ab = T.ab; ctx->sort_partial = true;
+    ctx->rows2_in_scratch = true; ctx->rows2_scratch = T;
+    if (sb < 0) { ctx->h_back[3] = 1; return DSKGPU_OK; }
+    const u32 per = (1u << bA) >> sb;
+    for (u32 g0 = 0; g0 < (1u << bA); g0 += per) {
+        const u64 b = start[g0], e = start[g0 + per];
+        if (e - b < 2 || total - sb < 1) continue;
+        const Rows2 r2{T.hi + b, T.lo + b, T.ab + b}, s2{K.hi + b, K.lo + b, K.ab + b};
+        const int rc = msd_sort_rows2(ctx, r2, s2, e - b, total - sb, false, (u32)b);
+        if (rc) return rc;
+    }
+    { const int e = rows2_rounds(ctx, T, K); if (e) return e; }
+    CK(hipMemcpyAsync(&ctx->h_back[3], sc + SC_SORTFLAG, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] two-word row sort: %llu rows in %u groups on their top %d bits, MSD sort per group\n", (unsigned long long)n, 1u << sb, sb);
     return DSKGPU_OK;
 }
 
@@ -927,6 +1009,7 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     for (int x = 0; x < 4; ++x) ctx->res_w[x] = x < W ? ctx->out_w[x].as<u64>() : nullptr;
     ctx->res_ab = ctx->out_ab.as<u32>();
     ctx->sort_partial = false;
+    ctx->rows2_in_scratch = false;
     ctx->h_ovs.assign(1, 0);
     if (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT)) return DSKGPU_OK;
     const u64 rs_max = ctx->tune.rs_max_rows ? std::min<u64>(ctx->tune.rs_max_rows, RS_MAX_ROWS) : RS_MAX_ROWS;
@@ -962,7 +1045,8 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
         return DSKGPU_OK;
     }
     // two-word rows: the rows themselves through the MSD sort (rowsort2.h)
-    if (W == 2 && !ctx->tune.fullsort && !ctx->tune.lib_rowsort && !ctx->tune.rows2_pairs && n <= RS_MAX_ROWS && 2u * ctx->cfg.kmer_size > 64u) return sort_rows2_msd(ctx, n);
+    if (W == 2 && !ctx->tune.fullsort && !ctx->tune.lib_rowsort && !ctx->tune.rows2_pairs && 2u * ctx->cfg.kmer_size > 64u && n < 0xFFFF0000ull)
+        return n <= rs_max ? sort_rows2_msd(ctx, n) : sort_rows2_big(ctx, n);
     // multi-word rows: radix sort of (top 63 bits of the value, row index) on the key's top 32 bits, gather,
     // then the runs of equal prefix are ordered in place by full comparison (exact fallback: sort_rows_full_multiword)
     if (!ctx->tune.fullsort && 2u * ctx->cfg.kmer_size > 64u) {
@@ -2119,7 +2203,12 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             ctx->res_w[0] = ctx->fb_dst_k; ctx->res_ab = ctx->fb_dst_v;
             ctx->stats.sort_fallback = 1;
         } else if (W > 1 && ctx->sort_partial && tot_rows && ctx->h_back[3]) {
-            if ((rc = sort_rows_full_multiword(ctx, tot_rows))) return rc;      // out_w still holds the unsorted rows
+            if (ctx->rows2_in_scratch) {      // (two-word rows above RS_MAX_ROWS: the complete permutation is the scratch copy)
+                CK(hipMemcpyAsync(ctx->out_w[1].p, ctx->rows2_scratch.hi, tot_rows * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                CK(hipMemcpyAsync(ctx->out_w[0].p, ctx->rows2_scratch.lo, tot_rows * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                CK(hipMemcpyAsync(ctx->out_ab.p, ctx->rows2_scratch.ab, tot_rows * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            if ((rc = sort_rows_full_multiword(ctx, tot_rows))) return rc;      // out_w holds the unsorted rows
             CK(hipStreamSynchronize(ctx->stream));
             ctx->stats.sort_fallback = 1;
         }

@@ -1249,8 +1249,17 @@ def test_row_sort_of_huge_row_sets_in_groups(oracle, dev, monkeypatch):
         assert st["n_solid"] > 300000 and st["sort_fallback"] == 0, (k, st)
     st = check_against_oracle(oracle, reads, 31, dev, amin=1, max_pass_mkeys=2)         # several passes: rows accumulated, scratch carved from l0buf
     assert st["n_passes"] > 4 and st["n_read_sweeps"] < st["n_passes"] and st["sort_fallback"] == 0
+    for k, s in ((63, reads), (35, reads)):                                            # two-word rows: sort_rows2_big (rowsort2.h kernels, the same scheme)
+        st = check_against_oracle(oracle, s, k, dev, amin=1)
+        assert st["n_solid"] > 300000 and st["sort_fallback"] == 0, (k, st)
+    st = check_against_oracle(oracle, skew, 63, dev, amin=1)                           # (at k = 63 nearly every poly-A window is its own k-mer: 900 000 rows
+    assert st["n_solid"] > 300000                                                      #  start with AAAAA -- one 10-bit bucket above the limit: the fallback)
+    st = check_against_oracle(oracle, reads, 63, dev, amin=1, max_pass_mkeys=2)
+    assert st["n_passes"] > 4 and st["sort_fallback"] == 0
     monkeypatch.setenv("DSKGPU_RS_MAX_ROWS", "5000")                                   # a 10-bit bucket of uniform rows holds ~14 000: the fallback orders them
     st = check_against_oracle(oracle, reads, 31, dev, amin=1)
+    assert st["sort_fallback"] == 1
+    st = check_against_oracle(oracle, reads, 63, dev, amin=1)                          # (two-word rows: the scratch copy goes back to out_* first)
     assert st["sort_fallback"] == 1
 
 
