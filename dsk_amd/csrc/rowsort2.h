@@ -18,6 +18,9 @@
 #define RS2_TILE (RS_NT * RS2_RPT)
 #define RS2_BTILE (RS_BNT * RS2_RPT)
 #define RS2_OVS_CAP 64                    // listed sub-buckets per sort call
+#ifndef RS2_WAVE_ROWS
+#define RS2_WAVE_ROWS 256                  // step C: a wave orders sub-buckets up to this size alone (4 rows per lane: half the registers and LDS of 512 --
+#endif                                    //  sub-buckets average 140 rows; larger ones go to the block path)
 
 // digit of the 128-bit value hi:lo at bit `sh` (wave-uniform)
 __device__ __forceinline__ u32 rs2_dig(u64 hi, u64 lo, int sh, u32 m) {
@@ -180,12 +183,12 @@ __global__ __launch_bounds__(RS_BNT) void k2_split(Rows2C v, u32 nch, const u32*
     }
 }
 
-// step C: one wave per sub-bucket (2 <= nd <= RS_WAVE_ROWS rows, ordered in place): placed by the third digit, a row that shares its
+// step C: one wave per sub-bucket (2 <= nd <= RS2_WAVE_ROWS rows, ordered in place): placed by the third digit, a row that shares its
 // cell counts the smaller rows of the cell (whole value) and moves to its final slot.  -> false when a cell holds more than
 // RS_WAVE_CELL_CAP rows (the caller hands the sub-bucket to k2_big)
 __device__ __forceinline__ bool rs2_wave_sort(u64* gh, u64* gl, u32* ga, u32 nd, u64* rh, u64* rl, u32* ra, u32* wc, int sh, u32 m) {
     const u32 lane = threadIdx.x & 63;
-    constexpr int RPL = RS_WAVE_ROWS / 64;
+    constexpr int RPL = RS2_WAVE_ROWS / 64;
     u64 h[RPL], l[RPL]; u32 a[RPL], r[RPL];
 #pragma unroll
     for (int t = 0; t < RPL; ++t) { const u32 i = lane + 64 * t; if (i < nd) { h[t] = gh[i]; l[t] = gl[i]; a[t] = ga[i]; } }
@@ -243,9 +246,9 @@ __device__ __forceinline__ bool rs2_wave_sort(u64* gh, u64* gl, u32* ga, u32 nd,
 }
 
 __global__ __launch_bounds__(RS_CNT) void k2_cells(Rows2 v, const u32* __restrict__ sub, u32 nsub, u32 bb, RsSpec sp, u32* __restrict__ biglist, u32* __restrict__ nbig) {
-    __shared__ u64 rh[RS_CNT / 64][RS_WAVE_ROWS];
-    __shared__ u64 rl[RS_CNT / 64][RS_WAVE_ROWS];
-    __shared__ u32 ra[RS_CNT / 64][RS_WAVE_ROWS];
+    __shared__ u64 rh[RS_CNT / 64][RS2_WAVE_ROWS];
+    __shared__ u64 rl[RS_CNT / 64][RS2_WAVE_ROWS];
+    __shared__ u32 ra[RS_CNT / 64][RS2_WAVE_ROWS];
     __shared__ u32 wc[RS_CNT / 64][RS_CELLS + 1];
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 id = blockIdx.x * (RS_CNT / 64) + wave;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(RS_CNT) void k2_cells(Rows2 v, const u32* __restric
     const u32 o = sub[i], nd = sub[i + 1] - o;
     if (nd < 2) return;
     bool done = false;
-    if (nd <= RS_WAVE_ROWS) done = rs2_wave_sort(v.hi + o, v.lo + o, v.ab + o, nd, rh[wave], rl[wave], ra[wave], wc[wave], sp.shC, sp.mC);
+    if (nd <= RS2_WAVE_ROWS) done = rs2_wave_sort(v.hi + o, v.lo + o, v.ab + o, nd, rh[wave], rl[wave], ra[wave], wc[wave], sp.shC, sp.mC);
     if (!done && lane == 0) biglist[atomicAdd(nbig, 1u)] = i;
 }
 
