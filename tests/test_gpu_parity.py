@@ -1230,6 +1230,43 @@ def test_row_sort_paths_agree(oracle, dev, monkeypatch):
         check_against_oracle(oracle, s, k, dev, amin=1)
 
 
+def test_two_word_row_sort_paths_agree(oracle, dev, monkeypatch):
+    """Two-word rows (k = 33..64) go through their own MSD sort as whole rows (rowsort2.h): uniform and skewed values, few value
+    bits above the first word (k = 33, 35), sub-buckets that go round again (natural: poly-A variants; forced: every sub-bucket above
+    512 rows), the full-width fallback behind a 'heavy' first-digit bucket, the wider second digits, and the (63-bit key, index)
+    path kept behind DSKGPU_ROWS2_PAIRS -- all the same rows as the oracle."""
+    from dsk_amd import synth
+    g = synth.make_genome(200_000, dev)
+    reads = synth.make_reads(g, 60_000, 150).cpu().numpy()
+    rng = np.random.default_rng(5)
+    pa = np.full(600_000, 65, np.uint8)
+    hit = rng.random(pa.size) < 0.01
+    pa[hit] = rng.choice(np.frombuffer(b"CGT", dtype=np.uint8), size=int(hit.sum()))
+    skew = np.concatenate([pa, np.array([10], np.uint8), reads]).astype(np.uint8)
+    for k, s in ((63, reads), (64, reads), (33, reads), (35, reads), (47, skew)):
+        st = check_against_oracle(oracle, s, k, dev, amin=1)
+        assert st["sort_fallback"] == 0, (k, st)
+    st = check_against_oracle(oracle, skew, 63, dev, amin=1)
+    assert st["sort_fallback"] == 0                                    # sub-buckets above 4096 rows go round again on their remaining bits
+    monkeypatch.setenv("DSKGPU_RS_BLOCK_ROWS", "512")                   # ... forced: every sub-bucket above 512 rows does
+    for k, s in ((63, skew), (35, reads)):
+        st = check_against_oracle(oracle, s, k, dev, amin=1)
+        assert st["sort_fallback"] == 0, (k, st)
+    monkeypatch.delenv("DSKGPU_RS_BLOCK_ROWS")
+    monkeypatch.setenv("DSKGPU_RS_HEAVY", "1000")                       # a first-digit bucket "too heavy" for one block: fallback, same rows
+    st = check_against_oracle(oracle, reads, 63, dev, amin=1)
+    assert st["sort_fallback"] == 1
+    monkeypatch.delenv("DSKGPU_RS_HEAVY")
+    for bbits in ("9", "10"):
+        monkeypatch.setenv("DSKGPU_RS_BBITS", bbits)
+        for k, s in ((63, reads), (63, skew), (35, reads)):
+            check_against_oracle(oracle, s, k, dev, amin=1)
+    monkeypatch.delenv("DSKGPU_RS_BBITS")
+    monkeypatch.setenv("DSKGPU_ROWS2_PAIRS", "1")
+    for k, s in ((63, skew), (35, reads)):
+        check_against_oracle(oracle, s, k, dev, amin=1)
+
+
 def test_row_sort_of_huge_row_sets_in_groups(oracle, dev, monkeypatch):
     """Row sets above what the MSD sort takes in one piece (3 * 10^9 solid k-mers of a 30x human run) are split on their top bits
     once and ordered group by group (sort_rows_big): forced here on a small input with DSKGPU_RS_MAX_ROWS -- single pass (scratch
