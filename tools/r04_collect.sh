@@ -21,3 +21,12 @@ grep -v '^[WE]2026' gpurun_out/kt_${tag}_c3/run.log | grep -v amdgpu.ids > profi
 stats gpurun_out/kt_${tag}_mg/t_kernel_stats.csv profiles/${tag}_multigpu_rank_kernel_stats.csv
 { for f in gpurun_out/kt_${tag}_mg/run.log gpurun_out/${tag}_mg_sliced.txt gpurun_out/${tag}_mg_shard.txt gpurun_out/${tag}_mg_k63.txt; do echo "# $f"; grep -v '^[WE]2026' $f | grep -v amdgpu.ids; done; } > profiles/${tag}_multigpu_rank_stage_times.txt
 ls -la profiles | grep $tag
+# k = 63 refresh (tools/r04_profiles_k63.sh <tag2>): profiles/<tag2>_k63*
+if [ -n "$2" ]; then
+  t2=$2
+  python3 tools/prof_summary.py ${t2}_k63pmc > /dev/null
+  stats gpurun_out/kt_${t2}_k63/t_kernel_stats.csv profiles/${t2}_k63_kernel_stats.csv
+  grep -h '^{"metric"' gpurun_out/kt_${t2}_k63/run.log | tail -1 > profiles/${t2}_k63_bench_c2_k63.json
+  { for f in gpurun_out/${t2}_c3_k63.txt gpurun_out/${t2}_mg_k63.txt gpurun_out/${t2}_mg_shard_k63.txt; do echo "# $f"; grep -v '^[WE]2026' $f | grep -v amdgpu.ids; done; } > profiles/${t2}_k63_large_inputs_and_ranks.txt
+  ls -la profiles | grep ${t2}_k63
+fi
