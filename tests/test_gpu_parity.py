@@ -520,6 +520,49 @@ def test_two_word_top_word_table_falls_back_on_what_it_cannot_tell_apart(oracle,
     assert st["n_retries"] == 1          # the verification bit went up once, k_count_mw counted the pass
 
 
+def test_two_word_top_word_twins_in_several_passes_and_on_the_receive_side(oracle, dev):
+    """The same crafted k-mers (two 63-mers with one mixed top word) where the count stage runs per pass: a multi-pass count from the
+    reads and the receive side of a two-rank job.  Passes and owners are functions of the MINIMIZER, so the twins may or may
+    not meet in one table; either way the rows must be the oracle's, with at most one re-count."""
+    from dsk_amd import KmerCounter, synth
+    k = 63
+    g = synth.make_genome(500_000, dev)
+    reads = synth.make_reads(g, 150_000, 150).cpu().numpy()
+    a, b, _ = _craft_top_word_twins(k, np.random.default_rng(5))
+    extra = np.frombuffer(((a + "\n") * 3 + (b + "\n") * 5).encode(), dtype=np.uint8)
+    stream = np.concatenate([reads, extra])
+    st = check_against_oracle(oracle, stream, k, dev, max_pass_mkeys=4)
+    assert st["n_passes"] >= 3 and st["n_retries"] <= 1, st              # (a re-count only when the twins' minimizers put them into the same pass)
+    world = 2
+    half = (150_000 // 2) * 151
+    shards = [np.concatenate([reads[:half], extra[: 3 * 64]]), np.concatenate([reads[half:], extra[3 * 64:]])]      # twin a on rank 0, twin b on rank 1
+    ctxs, sends, counts, keep_alive = [], [], [], []
+    for r in range(world):
+        t = torch.from_numpy(shards[r].copy()).to(dev)
+        kc = KmerCounter(kmer_size=k, abundance_min=2, world_size=world, rank=r)
+        kc.set_reads_device(t.data_ptr(), t.numel())
+        send = torch.zeros(kc.mg_send_capacity_words(), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        counts.append(kc.mg_scatter(send.data_ptr(), send.numel()))
+        ctxs.append(kc); sends.append(send); keep_alive.append(t)
+    rows_k, rows_a, hist, retries = [], [], np.zeros(10001, np.uint64), 0
+    for d in range(world):
+        recv = torch.cat([sends[src][sum(counts[src][:d]): sum(counts[src][:d]) + counts[src][d]] for src in range(world)])
+        torch.cuda.synchronize()
+        ctxs[d].mg_count(recv.data_ptr(), recv.numel())
+        kk, aa = ctxs[d].rows()
+        rows_k.append(kk); rows_a.append(aa); hist += ctxs[d].histogram(); retries += ctxs[d].stats()["n_retries"]
+    kk = np.concatenate(rows_k); aa = np.concatenate(rows_a)
+    ref = oracle.count(stream, k)
+    keep = ref.ab >= 2
+    order = np.lexsort((kk[:, 0], kk[:, 1]))
+    assert (hist == ref.histogram(10000)).all()
+    assert (kk[order] == ref.words()[keep]).all() and (aa[order] == ref.ab[keep]).all()
+    assert retries <= 1              # (1 when both twins have the same owner -- their minimizers decide)
+    for c in ctxs:
+        c.close()
+
+
 def test_two_word_edge_cases(oracle, golden_dir, dev):
     s, _ = oracle.load_bank(os.path.join(golden_dir, "longread.fasta"))
     check_against_oracle(oracle, s, 41, dev, amin=1)
