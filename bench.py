@@ -373,7 +373,7 @@ def main():
             torch.cuda.synchronize()
             no_place_ms = (time.perf_counter() - tp) / 10 * 1e3
     kc = KmerCounter(kmer_size=args.kmer_size, abundance_min=args.abundance_min, device=local_rank, timing=True,
-                     sort=not args.no_sort, world_size=world, rank=rank, stream=stream, place=not args.no_place)
+                     sort=not args.no_sort, world_size=world, rank=rank, stream=stream, place=not args.no_place and not share_gpu)      # (ranks sharing one GPU: no room for placement candidates)
     kc.set_reads_device(reads.data_ptr(), n_bytes)
 
     sharded = None
