@@ -904,8 +904,12 @@ __global__ __launch_bounds__(256) void k_count_valid(const u32* __restrict__ inv
                 const u32 iv = inval[w - q];
                 if (iv == 0) run += 32; else { run += __builtin_ctz(iv); break; }
             }
-#pragma unroll
-            for (int t = 0; t < 32; ++t) { run = ((ic >> (31 - t)) & 1u) ? 0 : run + 1; c += run >= k ? 1u : 0u; }
+            // k > 32: behind an invalid base of THIS word no window of the word can be whole again, so only the bases before the first
+            // invalid one (f of them) can end a valid window -- base t does if run + t + 1 >= k
+            const int f = ic ? __clz((int)ic) : 32;
+            const int need = k - 1 - run;
+            const int good = f - (need > 0 ? need : 0);
+            c += good > 0 ? (u32)good : 0u;
         }
     }
 #pragma unroll
