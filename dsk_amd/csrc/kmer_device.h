@@ -19,7 +19,7 @@ typedef unsigned int u32;
 
 // Empty-slot sentinel of the one-word LDS table.  Tables hold MIXED keys, so what matters is the
 // pre-image kunmix(~0): it must not be a canonical k-mer of the k being counted (sentinel_is_a_kmer() in dskgpu.hip checks
-// that when a context is created; tests/host/test_kmer.cpp walks every k in 1..128) -- then no real key collides.
+// that when a context is created) -- then no real key collides.  tests/host/test_mixer.cpp runs the mixers on the host.
 #define DSK_EMPTY 0xFFFFFFFFFFFFFFFFull
 
 // ---------------------------------------------------------------- hashing

@@ -289,6 +289,16 @@ def test_kmer_model_unit(bins):
     assert "ALL OK" in out, out
 
 
+def test_key_mixers_unit(bins):
+    """C++ unit test of the device header's key mixers compiled for the host (tests/host/test_mixer.cpp): kmix / kmixN are bijections,
+    and the mixed top word of a two-word key is a hash of the whole key -- the pairs that exposed the two earlier folds are pinned."""
+    exe = os.path.join(ROOT, "tests", "host", "test_mixer")
+    if not os.path.exists(exe):
+        pytest.skip("no hipcc on this machine")
+    out = subprocess.run([exe], stdout=subprocess.PIPE).stdout.decode()
+    assert "ALL OK" in out, out
+
+
 def test_boundary_names_compile_and_run(bins, tmp_path):
     """A caller written with exactly the names SURVEY.md section 8(b) lists (Group::getPartition<Count>, Tool::createIterator,
     LOCAL, Integer::apply<Functor,Parameter>, StorageFactory, OptionFailure::displayErrors ...) builds against the host layer
