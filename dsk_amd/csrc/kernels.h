@@ -886,7 +886,25 @@ __global__ __launch_bounds__(256) void k_count_valid(const u32* __restrict__ inv
     __shared__ u32 ws[4];
     const u64 stride = (u64)gridDim.x * 256;
     u32 c = 0;
-    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < nwords; w += stride) {
+    u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (k <= 32) {
+        // four words per trip, their eight loads in flight together (one word per trip left the kernel waiting for memory: 0.081 ms
+        // for 0.19 GB)
+        for (; w + 3 * stride < nwords; w += 4 * stride) {
+            u32 ic4[4], ip4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const u64 x = w + u * stride; ic4[u] = inval[x]; ip4[u] = x ? inval[x - 1] : 0xFFFFFFFFu; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                u64 bad = ((u64)ip4[u] << 32) | ic4[u];
+                int rem = k - 1;
+#pragma unroll
+                for (int st = 1; st <= 16; st <<= 1) { const int sh = rem < st ? rem : st; bad |= bad >> sh; rem -= sh; }
+                c += 32u - (u32)__popc((u32)bad);
+            }
+        }
+    }
+    for (; w < nwords; w += stride) {
         const u32 ic = inval[w];
         if (k <= 32) {
             // frame of 64 bases (previous word : this word), bit (63 - i) <-> base i.  A window ending at base e is bad if
