@@ -669,9 +669,11 @@ int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int
     { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
     hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, k, v, n, (u32)chunk, (u32)nch, matrix, tk, tv, sp);
     CKL("k_rs_scatter");
-    // a bucket above 16 x the mean (+ 64 K rows) is not a k-mer spectrum any more (canonical k-mers: at most ~2 x): one block would
+    // a bucket above 64 x the mean (+ 256 K rows) is not a k-mer spectrum any more (canonical k-mers: at most ~2 x; a low-complexity stretch of
+    // 200 kb puts 180 K rows under AAAAA: that is still one block's 0.2 ms -- the limit was 16 x + 64 K until seeds 208 / 292 / 319 of
+    // tools/stress_two_word.py took the 12 ms library fallback for it): one block would
     // walk it alone, so it goes to the full-width fallback instead
-    u32 heavy = (u32)std::min<u64>(0xFFFFFFFFull, n / RS_ABINS * 16 + 65536);
+    u32 heavy = (u32)std::min<u64>(0xFFFFFFFFull, n / RS_ABINS * 64 + 262144);
     if (ctx->tune.rs_heavy) heavy = ctx->tune.rs_heavy;
     const unsigned gridB = (unsigned)std::min<u64>(ncu * (160 * 1024 / (ldsB + 1024)), RS_ABINS);
     auto split = [&](auto kern) {
@@ -727,7 +729,7 @@ int msd_sort_rows2(dskgpu_ctx* ctx, Rows2 k, Rows2 t, u64 n, int total, bool res
     { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
     hipLaunchKernelGGL(k2_scatter, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, t, sp);
     CKL("k2_scatter");
-    u32 heavy = (u32)std::min<u64>(0xFFFFFFFFull, n / RS_ABINS * 16 + 65536);
+    u32 heavy = (u32)std::min<u64>(0xFFFFFFFFull, n / RS_ABINS * 64 + 262144);
     if (ctx->tune.rs_heavy) heavy = ctx->tune.rs_heavy;
     const unsigned gridB = (unsigned)std::min<u64>(ncu * (160 * 1024 / (ldsB + 1024)), RS_ABINS);
     auto split = [&](auto kern) {

@@ -14,7 +14,7 @@
 //      its final slot.  Sub-buckets of 513..4096 rows are listed and done by whole blocks (k_rs_big).
 //
 // Skew: buckets are exact (any distribution of values works); what the kernels do not order themselves -- a first-digit
-// bucket above 16 x the mean (one block would walk it alone) or a sub-bucket above 4096 rows -- raises *flag, and the host orders
+// bucket above 64 x the mean + 256 K rows (one block would walk it alone) or a sub-bucket above 4096 rows -- raises *flag, and the host orders
 // the rows with the full-width library sort instead (stats.sort_fallback): never seen on reads, provoked in tests.  Cells of any
 // size are ordered here: above 64 rows by a block (k_rs_big), there above 16 with a bitonic network over the sub-bucket (the error
 // variants of a poly-A k-mer share 13 and more leading bases).

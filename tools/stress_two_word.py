@@ -52,6 +52,8 @@ for seed in range(first, first + count):
     stream = np.concatenate([reads, np.full((n_reads, 1), ord("\n"), np.uint8)], axis=1).reshape(-1)
     amin = int(rng.choice([1, 2, 3]))
     kw = {"max_pass_mkeys": 4} if rng.random() < 0.25 else {}
+    if os.environ.get("STRESS_K"):
+        k = int(os.environ["STRESS_K"])              # (the same input counted at another k)
     t = torch.from_numpy(stream).to(dev)
     with KmerCounter(kmer_size=k, abundance_min=amin, **kw) as kc:
         kc.set_reads_device(t.data_ptr(), t.numel())
