@@ -671,7 +671,7 @@ int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int
     CKL("k_rs_scatter");
     // a bucket above 64 x the mean (+ 256 K rows) is not a k-mer spectrum any more (canonical k-mers: at most ~2 x; a low-complexity stretch of
     // 200 kb puts 180 K rows under AAAAA: that is still one block's 0.2 ms -- the limit was 16 x + 64 K until seeds 208 / 292 / 319 of
-    // tools/stress_two_word.py took the 12 ms library fallback for it): one block would
+    // tools/stress_random.py took the 12 ms library fallback for it): one block would
     // walk it alone, so it goes to the full-width fallback instead
     u32 heavy = (u32)std::min<u64>(0xFFFFFFFFull, n / RS_ABINS * 64 + 262144);
     if (ctx->tune.rs_heavy) heavy = ctx->tune.rs_heavy;

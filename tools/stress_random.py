@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Seeded random two-level inputs at two-word key widths (k = 33..64) against the CPU oracle, many seeds: the round-4 two-word paths
 (k_count2v3 + its re-count, 2560-key sub-partitions, rowsort2.h) under varying read length, coverage, N rate, read order, repeats.
-   python tools/stress_two_word.py [first_seed=100] [n_seeds=40]"""
+   python tools/stress_random.py [first_seed=100] [n_seeds=40]
+STRESS_KS=15,21,27,31,32 draws k from another list (one-word keys); STRESS_K=k counts the seed's input at another k."""
 import os
 import sys
 
@@ -20,7 +21,7 @@ dev = torch.device("cuda:0")
 bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    k = int(rng.choice([33, 34, 41, 47, 55, 62, 63, 64]))
+    k = int(rng.choice([int(x) for x in os.environ["STRESS_KS"].split(",")] if os.environ.get("STRESS_KS") else [33, 34, 41, 47, 55, 62, 63, 64]))
     rl = int(rng.choice([max(k + 5, 80), 150, 251, 1000]))
     n_kmers = int(rng.choice([9_000_000, 12_000_000, 20_000_000]))
     n_reads = n_kmers // (rl - k + 1) + 1
