@@ -446,6 +446,20 @@ def test_randomized_two_level_inputs(oracle, dev, seed):
     assert st["n_levels"] == 2
 
 
+@pytest.mark.parametrize("seed,ks", [(208, None), (292, None), (319, None), (304, None), (273, None), (545, (15, 21, 27, 31, 32)), (511, (15, 21, 27, 31, 32))])
+def test_randomized_low_complexity_and_tiny_passes(oracle, dev, seed, ks):
+    """Inputs of tools/stress_random.py (240 two-word + 150 one-word seeds ran against the oracle: profiles/r04_stress/) that took a
+    path of their own: a 200 kb low-complexity stretch (180 K rows under one 10-bit prefix: seeds 208 / 292 / 319 made the row sorts'
+    'heavy bucket' limit 64 x the mean instead of 16 x), tandem arrays at 200 x coverage, and multi-pass counts of tiny passes whose
+    sampled slices overflow (retries, same rows)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from stress_random import make_input
+    stream, k, amin, kw, desc = make_input(seed, ks) if ks else make_input(seed)
+    st = check_against_oracle(oracle, stream, k, dev, amin=amin, **kw)
+    assert st["sort_fallback"] == 0, (desc, st)
+
+
 @pytest.mark.parametrize("k", [33, 47, 63, 64])
 def test_two_word_kmers_golden(oracle, golden_dir, dev, k):
     s, _ = oracle.load_bank(os.path.join(golden_dir, "read50x_ref10K_e001.fasta.gz"))

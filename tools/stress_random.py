@@ -14,14 +14,11 @@ sys.path.insert(0, ROOT)
 from dsk_amd import KmerCounter          # noqa: E402
 from tests.oracle_py import Oracle       # noqa: E402
 
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-oracle = Oracle(os.path.join(ROOT, "oracle", "libdsk_oracle.so"))
-dev = torch.device("cuda:0")
-bad = 0
-for seed in range(first, first + count):
+
+def make_input(seed, ks=(33, 34, 41, 47, 55, 62, 63, 64)):
+    """-> (stream, k, abundance_min, KmerCounter keywords, description) of one seeded input"""
     rng = np.random.default_rng(seed)
-    k = int(rng.choice([int(x) for x in os.environ["STRESS_KS"].split(",")] if os.environ.get("STRESS_KS") else [33, 34, 41, 47, 55, 62, 63, 64]))
+    k = int(rng.choice(list(ks)))
     rl = int(rng.choice([max(k + 5, 80), 150, 251, 1000]))
     n_kmers = int(rng.choice([9_000_000, 12_000_000, 20_000_000]))
     n_reads = n_kmers // (rl - k + 1) + 1
@@ -53,19 +50,35 @@ for seed in range(first, first + count):
     stream = np.concatenate([reads, np.full((n_reads, 1), ord("\n"), np.uint8)], axis=1).reshape(-1)
     amin = int(rng.choice([1, 2, 3]))
     kw = {"max_pass_mkeys": 4} if rng.random() < 0.25 else {}
-    if os.environ.get("STRESS_K"):
-        k = int(os.environ["STRESS_K"])              # (the same input counted at another k)
-    t = torch.from_numpy(stream).to(dev)
-    with KmerCounter(kmer_size=k, abundance_min=amin, **kw) as kc:
-        kc.set_reads_device(t.data_ptr(), t.numel())
-        kc.count(); torch.cuda.synchronize()
-        rows, ab = kc.rows(); hist = kc.histogram(); st = kc.stats()
-    ref = oracle.count(stream, k)
-    keep = ref.ab >= amin
-    ok = (st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct and rows.shape[0] == int(keep.sum())
-          and (rows == ref.words()[keep]).all() and (ab == ref.ab[keep]).all() and (hist == ref.histogram(10000)).all())
-    bad += not ok
-    print(f"seed {seed}: k {k} rl {rl} cov {cov} N {nrate} kind {kind:.2f} passes {st['n_passes']} levels {st['n_levels']} retries {st['n_retries']} "
-          f"fallback {st['sort_fallback']} ext {st['n_ext_regions']} heavy {st['n_heavy']} kmers {ref.total} distinct {ref.distinct} {'ok' if ok else 'MISMATCH'}", flush=True)
-print("stress ok" if not bad else f"stress FAILED: {bad}")
-sys.exit(1 if bad else 0)
+    return stream, k, amin, kw, f"k {k} rl {rl} cov {cov} N {nrate} kind {kind:.2f}"
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    oracle = Oracle(os.path.join(ROOT, "oracle", "libdsk_oracle.so"))
+    dev = torch.device("cuda:0")
+    ks = [int(x) for x in os.environ["STRESS_KS"].split(",")] if os.environ.get("STRESS_KS") else (33, 34, 41, 47, 55, 62, 63, 64)
+    bad = 0
+    for seed in range(first, first + count):
+        stream, k, amin, kw, desc = make_input(seed, ks)
+        if os.environ.get("STRESS_K"):
+            k = int(os.environ["STRESS_K"])              # (the same input counted at another k)
+        t = torch.from_numpy(stream).to(dev)
+        with KmerCounter(kmer_size=k, abundance_min=amin, **kw) as kc:
+            kc.set_reads_device(t.data_ptr(), t.numel())
+            kc.count(); torch.cuda.synchronize()
+            rows, ab = kc.rows(); hist = kc.histogram(); st = kc.stats()
+        ref = oracle.count(stream, k)
+        keep = ref.ab >= amin
+        ok = (st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct and rows.shape[0] == int(keep.sum())
+              and (rows == ref.words()[keep]).all() and (ab == ref.ab[keep]).all() and (hist == ref.histogram(10000)).all())
+        bad += not ok
+        print(f"seed {seed}: {desc} (counted at k {k}) passes {st['n_passes']} levels {st['n_levels']} retries {st['n_retries']} "
+              f"fallback {st['sort_fallback']} ext {st['n_ext_regions']} heavy {st['n_heavy']} kmers {ref.total} distinct {ref.distinct} {'ok' if ok else 'MISMATCH'}", flush=True)
+    print("stress ok" if not bad else f"stress FAILED: {bad}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
