@@ -196,7 +196,7 @@ typedef struct dskgpu_stats {
     uint32_t n_partitions;   /* output partitions                        */
     uint32_t n_levels;       /* radix-partition levels used              */
     uint32_t n_final_bins;   /* hash-aggregate sub-partitions            */
-    uint32_t n_retries;      /* table-overflow retries                   */
+    uint32_t n_retries;      /* attempts repeated: a count table overflowed (finer plan), a sampled slice / the region pool overflowed (exact path), or (two-word keys) the top-word table met two k-mers with one top word (count stage again with full compares) */
     uint64_t sort_fallback;  /* 1 if the row sort needed its full-width fallback */
     uint64_t n_passes;       /* passes over the key space (1 unless the input exceeds a pass) */
     uint64_t n_ext_regions;  /* extension regions taken by sub-partitions that outgrew their home region (repeat-rich
