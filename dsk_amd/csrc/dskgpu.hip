@@ -480,14 +480,19 @@ struct Plan {
 
 #define TARGET_KEYS 2900      // mean keys per final sub-partition (the count kernel prefetches 3072 per sub-partition; table: 4096 slots, 3584 usable)
 #define TARGET_KEYS2 2560     // two-word keys: 3072-slot top-word table (k_count2v3), 2688 usable; 4096-slot index table (k_count_mw)
+#ifndef TARGET_KEYS4
 #define TARGET_KEYS4 640      // four-word keys: 1024 staged per sub-partition
+#endif
+#ifndef OPT_GROUPS4
+#define OPT_GROUPS4 OPT_GROUPS
+#endif
 #define MAX_LEVEL_BINS 2048
 #define ONE_LEVEL_BINS 1024
 #define CH2 65536u            // keys per level-2 chunk
 #define OPT_GROUPS 545u
 #define OPT_GROUPS2 1023u     // two-word keys: regions of 1023 groups of 64 B = 4092 keys (the count kernels are paced by their two barriers per
                               // sub-partition, not by its keys: half as many sub-partitions of twice the size -- see DESIGN section 6 "k = 63")
-inline u32 opt_groups(int W) { return W == 2 ? (AL_G2 == 8 ? 1022u : OPT_GROUPS2) : (W == 1 && AL_G1 == 16) ? 546u : OPT_GROUPS; }      // (AL_G2 == 8, experiments: 511 groups of 128 B)
+inline u32 opt_groups(int W) { return W == 2 ? (AL_G2 == 8 ? 1022u : OPT_GROUPS2) : (W == 1 && AL_G1 == 16) ? 546u : W == 4 ? OPT_GROUPS4 : OPT_GROUPS; }      // (AL_G2 == 8, experiments: 511 groups of 128 B)
 inline u64 target_keys(int W) { return W == 1 ? TARGET_KEYS : W == 2 ? TARGET_KEYS2 : TARGET_KEYS4; }
 #define OPT_CAP 4360u          // segment-owned level-2 scatter: keys per sub-partition region (mean <= TARGET_KEYS).
                               // 545 groups of 64 B -- an ODD number, so the region starts (and the write fronts that advance

@@ -638,6 +638,18 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
 #pragma unroll
             for (int it = 0; it < (KPT + 3) / 4; ++it) {
                 const u32 i0 = (u32)it * 4 * SC_NT;
+                if constexpr (W >= 4) {      // four-word keys: one key at a time (four 32-byte keys in flight spilled 96 bytes per lane to scratch: 22.7 -> see DESIGN section 6)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const u32 i = i0 + u * SC_NT + threadIdx.x;
+                        const Key kv = stage[i];
+                        const u32 dg = key_digit<MODE>(digit_word(kv), ds);
+                        const u32 d1 = delta[MODE == 4 ? (dg < P ? dg : 0u) : dg];
+                        if (OPT) out[i < ntile ? (u64)(d1 + i) : (u64)(o1.dump + i)] = kv;
+                        else if (i < ntile) out[(u64)(d1 + i)] = kv;
+                    }
+                    continue;
+                }
                 Key hk[4]; u32 dd[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) hk[u] = stage[i0 + u * SC_NT + threadIdx.x];      // (slots past the tile's keys hold stale keys: readable, never stored as keys)
