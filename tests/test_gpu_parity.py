@@ -448,7 +448,7 @@ def test_randomized_two_level_inputs(oracle, dev, seed):
 
 @pytest.mark.parametrize("seed,ks", [(208, None), (292, None), (319, None), (304, None), (273, None), (545, (15, 21, 27, 31, 32)), (511, (15, 21, 27, 31, 32))])
 def test_randomized_low_complexity_and_tiny_passes(oracle, dev, seed, ks):
-    """Inputs of tools/stress_random.py (240 two-word + 150 one-word seeds ran against the oracle: profiles/r04_stress/) that took a
+    """Inputs of tools/stress_random.py (about a thousand seeds ran against the oracle: profiles/r04_stress/) that took a
     path of their own: a 200 kb low-complexity stretch (180 K rows under one 10-bit prefix: seeds 208 / 292 / 319 made the row sorts'
     'heavy bucket' limit 64 x the mean instead of 16 x), tandem arrays at 200 x coverage, and multi-pass counts of tiny passes whose
     sampled slices overflow (retries, same rows)."""
