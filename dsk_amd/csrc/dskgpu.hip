@@ -146,6 +146,7 @@ struct Tuning {
     bool l0_keys = false;                       // DSKGPU_L0_KEYS: level 0 as key arrays (k_level0) even where the record-based one applies (experiments, tests)
     bool l0_staged = false;                     // DSKGPU_L0_STAGED: level 0 through the LDS-staged scatter (k_scatter<1, 0, 4>) instead of k_level0 (experiments)
     u32 mp_pass_mkeys = 0;                      // DSKGPU_MP_PASS_MKEYS: keys (millions) per pass of an input that needs several passes (default 1000)
+    u64 rs_slab_rows = 0;                       // DSKGPU_RS_SLAB_ROWS: rows per slab of the row sort for >= 2^32 rows (tests: forces that path, with small slabs, on a small input)
     bool force_heavy = false;                   // DSKGPU_FORCE_HEAVY: the HEAVY instantiation of the level-1 scatter even when no k-mer is counted apart (timing)
     void read() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
@@ -158,6 +159,7 @@ struct Tuning {
         table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
         max_ext = getenv("DSKGPU_MAX_EXT") ? atoll(getenv("DSKGPU_MAX_EXT")) : -1;
         no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); l2_static = on("DSKGPU_L2_STATIC"); force_heavy = on("DSKGPU_FORCE_HEAVY"); count_v1 = on("DSKGPU_COUNT_V1"); count_mw_v1 = on("DSKGPU_COUNT_MW_V1"); no_level0 = on("DSKGPU_NO_LEVEL0"); l0_passes = (u32)num("DSKGPU_L0_PASSES", 0); mp_pass_mkeys = (u32)num("DSKGPU_MP_PASS_MKEYS", 0); rs_max_rows = num("DSKGPU_RS_MAX_ROWS", 0); l0_staged = on("DSKGPU_L0_STAGED"); l0_keys = on("DSKGPU_L0_KEYS");
+        rs_slab_rows = num("DSKGPU_RS_SLAB_ROWS", 0);
         lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rows2_pairs = on("DSKGPU_ROWS2_PAIRS"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0); rs_heavy = (u32)num("DSKGPU_RS_HEAVY", 0);
     }
 };
@@ -186,6 +188,8 @@ struct dskgpu_ctx {
     DevBuf mat1, mat2, sums, descs1, descs2, seg, fstart, nsolid, scalars, ghist, gstats, chain_next;
     DevBuf fix_list;               // multi-word row sort: [count | (first row, rows) x FIX_LIST_CAP] of the prefix runs above FIX_CAP rows
     DevBuf rs_g[4];                // row sort: the gathered rows of the listed sub-buckets, one buffer per round (sort_oversize)
+    DevBuf rs_del, rs_lens;        // row sort of >= 2^32 rows: per (slab, bin) 64-bit output offsets; the slabs' matrix lengths
+    std::vector<u64> h_rs_del; std::vector<u32> h_rs_lens, h_rs_lin;
     DevBuf rs_ovs;                 // row sort: [count | (offset, rows, bits left) x RS_OVS_CAP] of the sub-buckets listed for another round
     std::vector<u32> h_ovs;
     u64* rs_res_k = nullptr; u32* rs_res_v = nullptr; u64* rs_tmp_k = nullptr; u32* rs_tmp_v = nullptr;   // the partially sorted rows and their scratch twin (sort_oversize)
@@ -201,7 +205,11 @@ struct dskgpu_ctx {
     std::vector<u64> bank_ends;    // end offset of every declared bank in the read stream
     DevBuf u_w[4], s_w[4], u_val, s_val, m_flag, m_pos, m_sum, gh2d;
     std::vector<u64> hist2d;
-    std::vector<u32> h_starts;
+    std::vector<u32> h_starts;     // explicit-key exchange: first key of every owner in the send buffer
+    std::vector<u64> h_rstart;     // record exchange: first RECORD of every owner in the send buffer (64-bit: no limit on a rank's shard)
+    std::vector<u32> h_sk_cells;   // ... records per (owner, chunk) as the sizing pass counted them
+    std::vector<u64> h_sk_cb64;    // ... exact layout: their exclusive scan (owner-major) = record index of every (owner, chunk) pair
+    DevBuf sk_cb64;                // ... the same on the device (k_sk_scatter<false>)
     // multi-GPU exchange as super-k-mer records (superkmer.h)
     bool enc_fresh = false;        // packed / inval hold the encoding of the current reads, left by dskgpu_mg_sample for the sender's sizing pass of the same step
     bool sk_mode = false, sk_prepared = false;
@@ -587,7 +595,13 @@ namespace {
 
 // Index permutation that sorts n rows of W words (struct-of-arrays in `rows`) ascending: W stable 64-bit
 // radix passes, least significant word first.  Result in ctx->srt_idx.
+int sort_index_multiword(dskgpu_ctx* ctx, const u64* const* rows, u64 n, int W);
 int sort_index_multiword(dskgpu_ctx* ctx, DevBuf* rows, u64 n, int W) {
+    const u64* p[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int x = 0; x < W; ++x) p[x] = rows[x].as<u64>();
+    return sort_index_multiword(ctx, p, n, W);
+}
+int sort_index_multiword(dskgpu_ctx* ctx, const u64* const* rows, u64 n, int W) {
     CK(ctx->srt_k.ensure(n * 8));
     CK(ctx->srt_idx.ensure(n * 4));
     CK(ctx->srt_idx2.ensure(n * 4));
@@ -602,7 +616,7 @@ int sort_index_multiword(dskgpu_ctx* ctx, DevBuf* rows, u64 n, int W) {
     CK(rocprim::radix_sort_pairs(nullptr, tmp2, ctx->srt_k.as<u64>(), keys_sorted.as<u64>(), idx, idx2, (size_t)n, 0u, top_bits, ctx->stream));
     CK(ctx->srt_tmp.ensure(std::max(tmp, tmp2)));
     for (int x = 0; x < W; ++x) {
-        const u64* src = rows[x].as<u64>();
+        const u64* src = rows[x];
         const unsigned bits = x == W - 1 ? top_bits : 64u;
         if (x == 0) {
             CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, src, keys_sorted.as<u64>(), idx, idx2, (size_t)n, 0u, bits, ctx->stream));
@@ -668,11 +682,11 @@ int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int
     if (reset_flags) { CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream)); CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream)); }
     const size_t ldsA = RsLds<RS_ABINS, RS_TILE>::bytes;
     const size_t ldsB = BB == 256 ? RsLds<256, RS_BTILE>::bytes : BB == 512 ? RsLds<512, RS_BTILE>::bytes : RsLds<1024, RS_BTILE>::bytes;
-    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_scatter)); if (e) return e; }
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_scatter<false>)); if (e) return e; }
     hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)nch), dim3(RS_NT), 0, ctx->stream, k, n, (u32)chunk, (u32)nch, matrix, sp);
     CKL("k_rs_hist");
     { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
-    hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, k, v, n, (u32)chunk, (u32)nch, matrix, tk, tv, sp);
+    hipLaunchKernelGGL(k_rs_scatter<false>, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, k, v, n, (u32)chunk, (u32)nch, matrix, tk, tv, sp, (const u64*)nullptr);
     CKL("k_rs_scatter");
     // a bucket above 64 x the mean (+ 256 K rows) is not a k-mer spectrum any more (canonical k-mers: at most ~2 x; a low-complexity stretch of
     // 200 kb puts 180 K rows under AAAAA: that is still one block's 0.2 ms -- the limit was 16 x + 64 K until seeds 208 / 292 / 319 of
@@ -726,13 +740,13 @@ int msd_sort_rows2(dskgpu_ctx* ctx, Rows2 k, Rows2 t, u64 n, int total, bool res
     const size_t ldsA = Rs2Lds<RS_ABINS, RS2_TILE>::bytes;
     const size_t ldsB = BB == 256 ? Rs2Lds<256, RS2_BTILE>::bytes : BB == 512 ? Rs2Lds<512, RS2_BTILE>::bytes : Rs2Lds<1024, RS2_BTILE>::bytes;
     const size_t ldsBig = (size_t)RS_BLOCK_ROWS * 20 + 2 * RS_CELLS * 4;
-    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_scatter)); if (e) return e; }
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_scatter<false>)); if (e) return e; }
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_big), (int)ldsBig); if (e) return e; }
     const Rows2C kc{k.hi, k.lo, k.ab}, tc{t.hi, t.lo, t.ab};
     hipLaunchKernelGGL(k2_hist, dim3((unsigned)nch), dim3(RS_NT), 0, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, sp);
     CKL("k2_hist");
     { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
-    hipLaunchKernelGGL(k2_scatter, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, t, sp);
+    hipLaunchKernelGGL(k2_scatter<false>, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, t, sp, (const u64*)nullptr);
     CKL("k2_scatter");
     u32 heavy = (u32)std::min<u64>(0xFFFFFFFFull, n / RS_ABINS * 64 + 262144);
     if (ctx->tune.rs_heavy) heavy = ctx->tune.rs_heavy;
@@ -831,13 +845,13 @@ int sort_rows2_big(dskgpu_ctx* ctx, u64 n) {
     CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
     CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream));
     ctx->h_ovs.assign(1, 0);
-    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_scatter)); if (e) return e; }
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_scatter<false>)); if (e) return e; }
     const Rows2C kc{K.hi, K.lo, K.ab};
     hipLaunchKernelGGL(k2_hist, dim3((unsigned)nch), dim3(RS_NT), 0, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, sp);
     CKL("k2_hist");
     { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
     const size_t ldsA = Rs2Lds<RS_ABINS, RS2_TILE>::bytes;
-    hipLaunchKernelGGL(k2_scatter, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, T, sp);
+    hipLaunchKernelGGL(k2_scatter<false>, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, T, sp, (const u64*)nullptr);
     CKL("k2_scatter");
     std::vector<u32> start(RS_ABINS + 1);
     CK(hipMemcpy2DAsync(start.data(), 4, matrix, nch * 4, 4, RS_ABINS + 1, hipMemcpyDeviceToHost, ctx->stream));
@@ -968,12 +982,12 @@ int sort_rows_big(dskgpu_ctx* ctx, u64 n) {
     CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream));
     ctx->h_ovs.assign(1, 0);
     ctx->rs_res_k = tk; ctx->rs_res_v = tv; ctx->rs_tmp_k = k; ctx->rs_tmp_v = v;
-    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_scatter)); if (e) return e; }
+    { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_scatter<false>)); if (e) return e; }
     hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)nch), dim3(RS_NT), 0, ctx->stream, k, n, (u32)chunk, (u32)nch, matrix, sp);
     CKL("k_rs_hist");
     { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
     const size_t ldsA = RsLds<RS_ABINS, RS_TILE>::bytes;
-    hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, k, v, n, (u32)chunk, (u32)nch, matrix, tk, tv, sp);
+    hipLaunchKernelGGL(k_rs_scatter<false>, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, k, v, n, (u32)chunk, (u32)nch, matrix, tk, tv, sp, (const u64*)nullptr);
     CKL("k_rs_scatter");
     // bucket starts -> host (entry b * nch of the scanned matrix; the scan leaves the total behind the last entry)
     std::vector<u32> start(RS_ABINS + 1);
@@ -1010,6 +1024,178 @@ int sort_rows_big(dskgpu_ctx* ctx, u64 n) {
     return DSKGPU_OK;
 }
 
+
+// ---- row sets of 2^32 rows and more (one- and two-word rows): `-abundance-min 1` on a 200 M-read input, the solid k-mers of a deeper
+// human run.  The reference streams rows to Partition<Count> without any such bound (utils/dsk2ascii.cpp:61,77).  The MSD kernels
+// index rows with 32 bits, so step A runs SLAB by slab (2^31 rows each): per slab the first-digit histogram and its (32-bit, slab-
+// local) scan, then the host lays the 1024 buckets out over ALL rows in 64 bits -- bucket b = [B[b], B[b + 1]), inside it the slabs'
+// shares in slab order -- and hands every slab's scatter a 64-bit offset per bin (k_rs_scatter<true>: output index = slab-local
+// index + gdel[bin]).  After that every bucket is far below 2^32 rows and the groups of buckets that share their top bits (<= RS_MAX_ROWS
+// rows each) are ordered one by one with the ordinary MSD sort, each group with its own flag / list round trip: what a group's sort
+// does not order itself goes through the library radix sort FOR THAT GROUP (one-word rows; a group is < 2^32 rows) -- exact for any
+// value distribution.  Scratch = a second copy of the rows (the level-0 buffer of the multi-pass count when it is large enough).
+template <int W>
+int sort_rows_huge(dskgpu_ctx* ctx, u64 n) {
+    static_assert(W == 1 || W == 2, "one- and two-word rows");
+    const size_t n_al = (size_t)((n + 31) & ~(u64)31), row_bytes = W == 1 ? 12 : 20, need = n_al * row_bytes + 256;
+    u64* k = ctx->out_w[0].as<u64>(); u32* v = ctx->out_ab.as<u32>();
+    u64* tk = nullptr; u32* tv = nullptr;              // one-word rows: the scratch copy (becomes the result)
+    Rows2 K{nullptr, nullptr, nullptr}, T{nullptr, nullptr, nullptr};
+    if (W == 2) K = Rows2{ctx->out_w[1].as<u64>(), ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>()};
+    if (ctx->l0buf.cap >= need) {
+        u64* base = ctx->l0buf.as<u64>();
+        if (W == 1) { tk = base; tv = reinterpret_cast<u32*>(tk + n_al); }
+        else { T.hi = base; T.lo = T.hi + n_al; T.ab = reinterpret_cast<u32*>(T.lo + n_al); }
+    } else {
+        ctx->l0buf.release(); ctx->bufA.release(); ctx->bufB.release();       // (the next count allocates them again)
+        for (int x = 0; x < W; ++x) CK(ctx->srt_w[x].ensure(n * 8));
+        CK(ctx->srt_ab.ensure(n * 4));
+        if (W == 1) { tk = ctx->srt_w[0].as<u64>(); tv = ctx->srt_ab.as<u32>(); }
+        else T = Rows2{ctx->srt_w[1].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>()};
+    }
+    const int total = W == 1 ? (int)std::min(64u, 2u * ctx->cfg.kmer_size) : 2 * (int)ctx->cfg.kmer_size;
+    const int bA = std::min(10, total);
+    const u32 NB = 1u << bA;
+    RsSpec sp{total - bA, 0, 0, NB - 1u, 0u, 0u};
+    const u64 ncu = (u64)ctx->num_cu;
+    const u64 slab = ctx->tune.rs_slab_rows ? std::max<u64>(ctx->tune.rs_slab_rows, 1024) : (1ull << 31);
+    const u32 S = (u32)((n + slab - 1) / slab);
+    // per slab: chunks of ~64 K rows (a multiple of the CU count of them), matrix of RS_ABINS x nch counters
+    std::vector<u64> s_n(S), s_nch(S), s_chunk(S), s_moff(S + 1, 0);
+    for (u32 sl = 0; sl < S; ++sl) {
+        const u64 ns = std::min<u64>(slab, n - (u64)sl * slab);
+        u64 nch = (ns + 65535) / 65536;
+        nch = (nch + ncu - 1) / ncu * ncu;
+        const u64 tile = W == 1 ? RS_TILE : RS2_TILE;
+        nch = std::max<u64>(1, std::min<u64>(nch, (ns + tile - 1) / tile));
+        const u64 chunk = (ns + nch - 1) / nch;
+        nch = (ns + chunk - 1) / chunk;
+        s_n[sl] = ns; s_nch[sl] = nch; s_chunk[sl] = chunk;
+        s_moff[sl + 1] = s_moff[sl] + (u64)RS_ABINS * nch + 2;
+    }
+    CK(ctx->mat2.ensure(s_moff[S] * 4));
+    CK(ctx->rs_lens.ensure((size_t)S * 4));
+    ctx->h_rs_lens.resize(S);
+    for (u32 sl = 0; sl < S; ++sl) ctx->h_rs_lens[sl] = (u32)((u64)RS_ABINS * s_nch[sl]);
+    CK(hipMemcpyAsync(ctx->rs_lens.p, ctx->h_rs_lens.data(), (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream));
+    u32* sc = ctx->scalars.as<u32>();
+    CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
+    ctx->h_rs_lin.assign((size_t)S * (RS_ABINS + 1), 0);
+    for (u32 sl = 0; sl < S; ++sl) {
+        const u64 r0 = (u64)sl * slab;
+        u32* matrix = ctx->mat2.as<u32>() + s_moff[sl];
+        if (W == 1) hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)s_nch[sl]), dim3(RS_NT), 0, ctx->stream, (const u64*)(k + r0), s_n[sl], (u32)s_chunk[sl], (u32)s_nch[sl], matrix, sp);
+        else { const Rows2C kc{K.hi + r0, K.lo + r0, K.ab + r0}; hipLaunchKernelGGL(k2_hist, dim3((unsigned)s_nch[sl]), dim3(RS_NT), 0, ctx->stream, kc, s_n[sl], (u32)s_chunk[sl], (u32)s_nch[sl], matrix, sp); }
+        CKL("k_rs_hist(slab)");
+        { const int e = run_scan(ctx, matrix, ctx->rs_lens.as<u32>() + sl, (u64)RS_ABINS * s_nch[sl]); if (e) return e; }
+        // bucket starts inside the slab (entry b * nch of the scanned matrix; the scan leaves the slab's total behind the last entry)
+        CK(hipMemcpy2DAsync(ctx->h_rs_lin.data() + (size_t)sl * (RS_ABINS + 1), 4, matrix, s_nch[sl] * 4, 4, RS_ABINS + 1, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    CK(hipStreamSynchronize(ctx->stream));
+    // the buckets over all rows, and every (slab, bin) pair's place inside its bucket
+    std::vector<u64> B(RS_ABINS + 1, 0);
+    for (u32 b = 0; b < RS_ABINS; ++b) {
+        u64 t = 0;
+        for (u32 sl = 0; sl < S; ++sl) { const u32* lin = ctx->h_rs_lin.data() + (size_t)sl * (RS_ABINS + 1); t += (u64)(lin[b + 1] - lin[b]); }
+        B[b + 1] = B[b] + t;
+    }
+    if (B[RS_ABINS] != n) return fail(ctx, DSKGPU_E_DEVICE, "row sort: the slabs' histograms do not add up to the rows");
+    ctx->h_rs_del.assign((size_t)S * RS_ABINS, 0);
+    {
+        std::vector<u64> at(B.begin(), B.end() - 1);              // next free row of every bucket
+        for (u32 sl = 0; sl < S; ++sl) {
+            const u32* lin = ctx->h_rs_lin.data() + (size_t)sl * (RS_ABINS + 1);
+            for (u32 b = 0; b < RS_ABINS; ++b) { ctx->h_rs_del[(size_t)sl * RS_ABINS + b] = at[b] - (u64)lin[b]; at[b] += (u64)(lin[b + 1] - lin[b]); }      // (wraps in 64 bits: added back by the kernel)
+        }
+    }
+    CK(ctx->rs_del.ensure(ctx->h_rs_del.size() * 8));
+    CK(hipMemcpyAsync(ctx->rs_del.p, ctx->h_rs_del.data(), ctx->h_rs_del.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (W == 1) { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_scatter<true>)); if (e) return e; }
+    else { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_scatter<true>)); if (e) return e; }
+    const size_t ldsA1 = RsLds<RS_ABINS, RS_TILE>::bytes, ldsA2 = Rs2Lds<RS_ABINS, RS2_TILE>::bytes;
+    for (u32 sl = 0; sl < S; ++sl) {
+        const u64 r0 = (u64)sl * slab;
+        const u32* matrix = ctx->mat2.as<u32>() + s_moff[sl];
+        const u64* gdel = ctx->rs_del.as<u64>() + (size_t)sl * RS_ABINS;
+        if (W == 1) hipLaunchKernelGGL(k_rs_scatter<true>, dim3((unsigned)s_nch[sl]), dim3(RS_NT), ldsA1, ctx->stream, (const u64*)(k + r0), (const u32*)(v + r0), s_n[sl],
+                                       (u32)s_chunk[sl], (u32)s_nch[sl], matrix, tk, tv, sp, gdel);
+        else { const Rows2C kc{K.hi + r0, K.lo + r0, K.ab + r0};
+               hipLaunchKernelGGL(k2_scatter<true>, dim3((unsigned)s_nch[sl]), dim3(RS_NT), ldsA2, ctx->stream, kc, s_n[sl], (u32)s_chunk[sl], (u32)s_nch[sl], matrix, T, sp, gdel); }
+        CKL("k_rs_scatter(slab)");
+    }
+    CK(hipStreamSynchronize(ctx->stream));                    // (h_rs_del / h_rs_lens were read from host vectors)
+    // groups of buckets that share their top sb bits, each <= RS_MAX_ROWS rows; a single bucket above that stands alone (library sort)
+    const u64 rs_max = ctx->tune.rs_max_rows ? std::min<u64>(ctx->tune.rs_max_rows, RS_MAX_ROWS) : RS_MAX_ROWS;
+    int sb = bA;
+    for (int bits = 0; bits <= bA; ++bits) {
+        const u32 per = NB >> bits;
+        bool ok = true;
+        for (u32 g0 = 0; g0 < NB && ok; g0 += per) ok = B[g0 + per] - B[g0] <= rs_max;
+        if (ok) { sb = bits; break; }
+    }
+    const u32 per = NB >> sb;
+    ctx->h_ovs.assign(1, 0);
+    u32 ngroups = 0, nlib = 0;
+    for (u32 g0 = 0; g0 < NB; g0 += per) {
+        const u64 b = B[g0], e = B[g0 + per], m = e - b;
+        if (m < 2 || total - sb < 1) continue;
+        ++ngroups;
+        bool lib = m > rs_max;
+        if (!lib) {
+            CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream)); CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream));
+            if (W == 1) {
+                const int rc = msd_sort_pairs(ctx, tk + b, tv + b, k + b, v + b, m, total - sb, false, 0u);
+                if (rc) return rc;
+                ctx->h_ovs.assign(1, 0);
+                CK(hipMemcpyAsync(&ctx->h_back[3], sc + SC_SORTFLAG, 4, hipMemcpyDeviceToHost, ctx->stream));
+                CK(hipMemcpyAsync(ctx->h_ovs.data(), ctx->rs_ovs.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+                CK(hipStreamSynchronize(ctx->stream));
+                if (!ctx->h_back[3] && ctx->h_ovs[0]) { const int e2 = sort_oversize_round(ctx, tk + b, tv + b, 0); if (e2) return e2; CK(hipStreamSynchronize(ctx->stream)); }
+            } else {
+                const Rows2 r2{T.hi + b, T.lo + b, T.ab + b}, s2{K.hi + b, K.lo + b, K.ab + b};
+                const int rc = msd_sort_rows2(ctx, r2, s2, m, total - sb, false, 0u);
+                if (rc) return rc;
+                { const int e2 = rows2_rounds(ctx, r2, s2); if (e2) return e2; }      // (synchronises; leaves the flag in h_back[3])
+            }
+            lib = ctx->h_back[3] != 0;
+        }
+        if (lib && m >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_OVERFLOW, "row sort: one value range of the >= 2^32 rows holds 2^32 rows itself (not a k-mer spectrum)");
+        if (lib && W == 2) {
+            // two-word rows of this group in full-width order: W stable radix passes over an index permutation, gathered into the
+            // other copy and copied back (the group's rows in T are a complete permutation whatever the MSD kernels did to them)
+            const u64* src[2] = {T.lo + b, T.hi + b};
+            { const int rc = sort_index_multiword(ctx, src, m, 2); if (rc) return rc; }
+            const unsigned gb = (unsigned)((m + 255) / 256);
+            const u32* idx = ctx->srt_idx.as<u32>();
+            hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, K.lo + b, (const u64*)(T.lo + b), idx, m);
+            hipLaunchKernelGGL(k_gather<u64>, dim3(gb), dim3(256), 0, ctx->stream, K.hi + b, (const u64*)(T.hi + b), idx, m);
+            hipLaunchKernelGGL(k_gather<u32>, dim3(gb), dim3(256), 0, ctx->stream, K.ab + b, (const u32*)(T.ab + b), idx, m);
+            CKL("row sort: group gather");
+            CK(hipMemcpyAsync(T.lo + b, K.lo + b, m * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            CK(hipMemcpyAsync(T.hi + b, K.hi + b, m * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            CK(hipMemcpyAsync(T.ab + b, K.ab + b, m * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+            ctx->stats.sort_fallback = 1; ++nlib;
+        } else if (lib) {
+            size_t tmp = 0;
+            const unsigned end_bit = (unsigned)(total - sb);
+            CK(rocprim::radix_sort_pairs(nullptr, tmp, tk + b, k + b, tv + b, v + b, (size_t)m, 0u, end_bit, ctx->stream));
+            CK(ctx->srt_tmp.ensure(tmp));
+            CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, tk + b, k + b, tv + b, v + b, (size_t)m, 0u, end_bit, ctx->stream));
+            CK(hipMemcpyAsync(tk + b, k + b, m * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            CK(hipMemcpyAsync(tv + b, v + b, m * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+            ctx->stats.sort_fallback = 1; ++nlib;
+        }
+    }
+    if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] row sort: %llu rows (>= 2^32 path) in %u slab(s), %u group(s) on their top %d bits, %u through the library sort\n", (unsigned long long)n, S, ngroups, sb, nlib);
+    ctx->h_back[3] = 0; ctx->h_ovs.assign(1, 0);
+    ctx->sort_partial = false; ctx->rows2_in_scratch = false;
+    if (W == 1) { ctx->res_w[0] = tk; ctx->res_ab = tv; }
+    else { ctx->res_w[1] = T.hi; ctx->res_w[0] = T.lo; ctx->res_ab = T.ab; }
+    return DSKGPU_OK;
+}
+
 // ---- result post-processing: sort rows by k-mer value
 int sort_rows(dskgpu_ctx* ctx, u64 n) {
     const int W = ctx->W;
@@ -1020,6 +1206,9 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     ctx->h_ovs.assign(1, 0);
     if (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT)) return DSKGPU_OK;
     const u64 rs_max = ctx->tune.rs_max_rows ? std::min<u64>(ctx->tune.rs_max_rows, RS_MAX_ROWS) : RS_MAX_ROWS;
+    // 2^32 rows and more (or DSKGPU_RS_SLAB_ROWS: tests): step A slab by slab with 64-bit bucket offsets
+    if ((n >= 0xFFFF0000ull || ctx->tune.rs_slab_rows) && W <= 2 && (W == 1 || 2u * ctx->cfg.kmer_size > 64u)) return W == 1 ? sort_rows_huge<1>(ctx, n) : sort_rows_huge<2>(ctx, n);
+    if (n >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "row sort: 2^32 rows and more are supported for k <= 64");
     if (W == 1 && !ctx->tune.fullsort && !ctx->tune.lib_rowsort && n > rs_max && n < 0xFFFF0000ull) return sort_rows_big(ctx, n);
     CK(ctx->srt_w[0].ensure(n * 8));
     CK(ctx->srt_ab.ensure(n * 4));
@@ -1993,7 +2182,7 @@ int rec_l0_sweep(dskgpu_ctx* ctx, const RecL0& rl, u32 olo, u32 ohi, u64 (&base_
     CK(hipMemsetAsync(ctx->sk_sent.p, 0, SK_MAX_OWNERS * 8, ctx->stream));
     CK(hipMemsetAsync(sc + SC_OVF1, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_sk_scatter<true>, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
-                       ctx->mat1.as<u32>(), ctx->l0buf.as<u64>(), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>());
+                       (const unsigned long long*)nullptr, ctx->l0buf.as<u64>(), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>());
     CKL("k_sk_scatter(passes)");
     ctx->mark("level0");
     CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2057,7 +2246,16 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
     bool rec_l0 = W <= 2 && from_reads && ctx->have_nvalid && ctx->sk_mode && ctx->cfg.world_size == 1 && !ctx->tune.no_level0 && !ctx->tune.l0_keys && !ctx->rec_l0_off &&
                   (npass > 1 || n_keys > hard_max);
     RecL0 rl;
+    // The record-based level 0 borrows the multi-GPU sender state of this context (sk_sp: G "owners" = passes, the owner window, the
+    // repartition table for G owners).  Whatever way this function is left, the context gets back the state dskgpu_create /
+    // dskgpu_mg_set_table gave it: a later dskgpu_mg_* call on a world_size = 1 context must see ONE owner again (it
+    // looped over up to 64 owners into the caller's world_size-sized arrays).
+    struct SenderStateGuard {
+        dskgpu_ctx* c; SkParams sp; std::vector<uint8_t> table; bool armed = false;
+        ~SenderStateGuard() { if (armed) { c->sk_sp = sp; c->h_table.swap(table); c->table_dirty = true; c->sk_prepared = false; c->enc_fresh = false; } }
+    } sender_guard{ctx, ctx->sk_sp, ctx->h_table};
     if (rec_l0) {
+        sender_guard.armed = true;
         u64 want = ctx->max_keys_per_pass ? max_keys : ctx->tune.mp_pass_mkeys ? (u64)ctx->tune.mp_pass_mkeys * 1000000ull : (W == 1 ? 1200000000ull : 1000000000ull);
         u64 G = (n_keys + want - 1) / want;
         if (G < 2) G = 2;
@@ -2312,7 +2510,6 @@ void sk_geometry(dskgpu_ctx* ctx, u64 nwords) {
 int sk_prepare(dskgpu_ctx* ctx) {
     ctx->st_names.clear(); ctx->st_ms.clear(); ctx->marks.clear(); ctx->ev_used = 0;
     ctx->sk_prepared = false;
-    if (ctx->n_bytes >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "read shard too large for 32-bit record offsets");
     ctx->mark("start");
     u64 nwords = 0;
     int rc = DSKGPU_OK;
@@ -2327,13 +2524,15 @@ int sk_prepare(dskgpu_ctx* ctx) {
     CK(ctx->scalars.ensure(SC_COUNT * 4));
     u32* h_sc = ctx->h_sc;
     std::memset(h_sc, 0, sizeof(ctx->h_sc));
-    h_sc[SC_MLEN1] = (u32)M;
     u32* sc = ctx->scalars.as<u32>();
     CK(hipMemcpyAsync(sc, h_sc, sizeof(ctx->h_sc), hipMemcpyHostToDevice, ctx->stream));
     CK(ctx->mat1.ensure((M + 1) * 4));
     // Exact layout: count every record, one scan places them.  Slice layout (default): count the records of every
     // 16th tile only, give every (owner, chunk) pair one slice of the estimated mean + 8 % + 128 records; the scatter
     // pads the slices with zero-length records.  Saves the full counting pass (1.95 of 5 ms); ~8 % more words to send.
+    // Either way every record position is 64-bit from here on (the count matrix -- <= 64 owners x 2048 chunks of u32 -- comes to
+    // the host, where it is summed / scanned in 64 bits): a rank's shard may be of any size.  The reference's own human run is
+    // ONE execute() over 160 GB of reads (doc/human_log:3-4,20-24; README.md:126-130); on 8 GPUs that is 11.3 GB per rank.
     const bool slices = !ctx->sk_exact && !ctx->tune.sk_exact && tpc >= 8;
     sp.sample_step = slices ? 16u : 1u;
     CK(ctx->sk_sent.ensure(3 * SK_MAX_OWNERS * 8));            // [k-mers sent per owner | sampled k-mers per owner | overflow flag of a sliced step]
@@ -2343,30 +2542,39 @@ int sk_prepare(dskgpu_ctx* ctx) {
     CKL("k_sk_hist");
     CK(hipMemcpyAsync(ctx->h_sk_est, ctx->sk_sent.as<u64>() + SK_MAX_OWNERS, SK_MAX_OWNERS * 8, hipMemcpyDeviceToHost, ctx->stream));
     ctx->mark("mg_hist");
-    if ((rc = run_scan(ctx, ctx->mat1.as<u32>(), sc + SC_MLEN1, M))) return rc;
-    ctx->h_starts.assign(sp.G + 1, 0);
-    for (u32 o = 0; o <= sp.G; ++o)
-        CK(hipMemcpyAsync(&ctx->h_starts[o], ctx->mat1.as<u32>() + (u64)o * nch, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->h_sk_cells.resize(M);
+    CK(hipMemcpyAsync(ctx->h_sk_cells.data(), ctx->mat1.p, M * 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
+    ctx->h_rstart.assign(sp.G + 1, 0);
     ctx->sk_slices = false;
     if (slices) {
         u64 worst = 0;                                       // sampled records of the busiest owner
-        for (u32 o = 0; o < sp.G; ++o) worst = std::max<u64>(worst, ctx->h_starts[o + 1] - ctx->h_starts[o]);
+        for (u32 o = 0; o < sp.G; ++o) { u64 t = 0; for (u64 c = 0; c < nch; ++c) t += ctx->h_sk_cells[(size_t)o * nch + c]; worst = std::max(worst, t); }
         const u64 sampled_tiles = (tpc + sp.sample_step - 1) / sp.sample_step;            // per chunk
         u64 slice = worst * tpc / (sampled_tiles * nch) + 1;                              // records per (owner, chunk), estimated
         const u64 min_slice = ctx->tune.sk_minslice;                                      // (tests lower it)
         const bool small = slice < min_slice || worst < 20000;    // fixed slack too visible in the send volume, or too few sampled records to trust the estimate
         slice += slice * 2 / 25 + 128;
         if (ctx->tune.sk_slice) slice = ctx->tune.sk_slice;                               // tests
-        if (!small && slice * nch * sp.G < 0xFFFF0000ull) {
+        if (!small && slice < 0xFFFF0000ull) {                                            // (a block's cursor inside ONE slice is 32-bit)
             sp.slice = (u32)slice;
             for (u32 o = 0; o < sp.G; ++o) ctx->h_sk_est[o] = ctx->h_sk_est[o] * tpc / sampled_tiles;      // sampled tiles -> all tiles
-            for (u32 o = 0; o <= sp.G; ++o) ctx->h_starts[o] = (u32)(o * nch * slice);
+            for (u32 o = 0; o <= sp.G; ++o) ctx->h_rstart[o] = (u64)o * nch * slice;
             ctx->sk_slices = true;
-        } else {                                             // small input, or too many records to index: count exactly after all
+        } else {                                             // small input: count exactly after all
             ctx->sk_exact = true;
             return sk_prepare(ctx);
         }
+    } else {
+        // exact layout: the 64-bit exclusive scan of the owner-major count matrix
+        ctx->h_sk_cb64.resize(M + 1);
+        u64 run = 0;
+        for (u64 i = 0; i < M; ++i) { ctx->h_sk_cb64[i] = run; run += ctx->h_sk_cells[i]; }
+        ctx->h_sk_cb64[M] = run;
+        for (u32 o = 0; o <= sp.G; ++o) ctx->h_rstart[o] = ctx->h_sk_cb64[(u64)o * nch];
+        CK(ctx->sk_cb64.ensure((M + 1) * 8));
+        CK(hipMemcpyAsync(ctx->sk_cb64.p, ctx->h_sk_cb64.data(), (M + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
     }
     ctx->resolve_marks();
     ctx->sk_prepared = true;
@@ -2378,17 +2586,18 @@ int sk_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t*
     int rc;
     if (!ctx->sk_prepared && (rc = sk_prepare(ctx))) return rc;
     const SkParams& sp = ctx->sk_sp;
-    if (capacity_words < (u64)ctx->h_starts[sp.G] * sp.R) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
+    if (capacity_words < ctx->h_rstart[sp.G] * sp.R) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
     ctx->marks.clear(); ctx->ev_used = 0;
     ctx->mark("start");
     u32* sc = ctx->scalars.as<u32>();
     CK(hipMemsetAsync(ctx->sk_sent.p, 0, SK_MAX_OWNERS * 8, ctx->stream));
-    if (ctx->sk_slices)
+    if (ctx->sk_slices) {
+        CK(hipMemsetAsync(sc + SC_OVF1, 0, 4, ctx->stream));
         hipLaunchKernelGGL(k_sk_scatter<true>, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
-                           ctx->mat1.as<u32>(), static_cast<u64*>(d_send), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>());
-    else
+                           (const unsigned long long*)nullptr, static_cast<u64*>(d_send), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>());
+    } else
         hipLaunchKernelGGL(k_sk_scatter<false>, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
-                           ctx->mat1.as<u32>(), static_cast<u64*>(d_send), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>());
+                           (const unsigned long long*)ctx->sk_cb64.as<unsigned long long>(), static_cast<u64*>(d_send), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>());
     CKL("k_sk_scatter");
     ctx->mark("mg_scatter");
     if (ctx->sk_slices) CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2400,7 +2609,7 @@ int sk_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t*
         if ((rc = sk_prepare(ctx))) return rc;
         return sk_scatter(ctx, d_send, capacity_words, send_words);      // may report "send buffer too small": ask for the capacity again
     }
-    for (u32 o = 0; o < sp.G; ++o) send_words[o] = (u64)(ctx->h_starts[o + 1] - ctx->h_starts[o]) * sp.R;
+    for (u32 o = 0; o < sp.G; ++o) send_words[o] = (ctx->h_rstart[o + 1] - ctx->h_rstart[o]) * sp.R;
     ctx->sk_prepared = false;      // packed/mat1 are scratch of the next call
     return DSKGPU_OK;
 }
@@ -2431,7 +2640,7 @@ int sk_slices_prepare(dskgpu_ctx* ctx, u32 want, u32* nslices, uint64_t* send_wo
 int sk_scatter_slice(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, u32 sl) {
     if (!ctx->sk_prepared || !ctx->sk_slices || sl >= ctx->sk_nslices) return fail(ctx, DSKGPU_E_STATE, "dskgpu_mg_scatter_slice without dskgpu_mg_slices_prepare");
     SkParams sp = ctx->sk_sp;
-    if (capacity_words < (u64)ctx->h_starts[sp.G] * sp.R) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
+    if (capacity_words < ctx->h_rstart[sp.G] * sp.R) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
     if (sl == 0) {
         ctx->marks.clear(); ctx->ev_used = 0;
         ctx->mark("start");
@@ -2439,12 +2648,12 @@ int sk_scatter_slice(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, u32
         CK(hipMemsetAsync(ctx->sk_sent.as<u64>() + 2 * SK_MAX_OWNERS, 0, 8, ctx->stream));
     }
     u32 cb, ce; sk_slice_range(sp, ctx->sk_nslices, sl, &cb, &ce);
-    sp.c0 = cb; sp.c0g = cb; sp.clen = ce - cb; sp.rbase = cb * sp.G * sp.slice;
+    sp.c0 = cb; sp.c0g = cb; sp.clen = ce - cb; sp.rbase = (u64)cb * sp.G * sp.slice;
     // (the overflow flag of a sliced step lives apart from the scalars: the receiver's pipeline, which runs before the flag is
     //  read, resets those)
     if (ce > cb)
         hipLaunchKernelGGL(k_sk_scatter<true>, dim3(ce - cb), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
-                           ctx->mat1.as<u32>(), static_cast<u64*>(d_send), reinterpret_cast<u32*>(ctx->sk_sent.as<u64>() + 2 * SK_MAX_OWNERS),
+                           (const unsigned long long*)nullptr, static_cast<u64*>(d_send), reinterpret_cast<u32*>(ctx->sk_sent.as<u64>() + 2 * SK_MAX_OWNERS),
                            ctx->sk_sent.as<unsigned long long>());
     CKL("k_sk_scatter");
     if (sl + 1 == ctx->sk_nslices) ctx->mark("mg_scatter");
@@ -2724,7 +2933,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
                       &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
                       &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->srt_k2, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
                       &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,
-                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent, &ctx->cur_state, &ctx->rs_ovs, &ctx->smp_keys, &ctx->sk_lay, &ctx->fix_list};
+                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent, &ctx->cur_state, &ctx->rs_ovs, &ctx->smp_keys, &ctx->sk_lay, &ctx->fix_list, &ctx->sk_cb64, &ctx->rs_del, &ctx->rs_lens};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i) { ctx->rs_g[i].release(); ctx->out_w[i].release(); ctx->srt_w[i].release(); ctx->acc_w[i].release(); ctx->u_w[i].release(); ctx->s_w[i].release(); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -2885,13 +3094,15 @@ uint64_t dskgpu_mg_send_capacity_words(dskgpu_ctx* ctx) {
     if (!ctx->sk_mode) return (ctx->n_bytes + 1) * (u64)ctx->W;
     if (hipSetDevice(ctx->cfg.device) != hipSuccess) return 0;
     if (!ctx->sk_prepared && sk_prepare(ctx) != DSKGPU_OK) return 0;     // the error text stays in the ctx; dskgpu_mg_scatter reports it
-    return (u64)ctx->h_starts[ctx->sk_sp.G] * ctx->sk_sp.R + 1;
+    return ctx->h_rstart[ctx->sk_sp.G] * ctx->sk_sp.R + 1;
 }
 
 int dskgpu_mg_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t* send_words) {
     if (!ctx || !d_send || !send_words) return DSKGPU_E_ARG;
     CK(hipSetDevice(ctx->cfg.device));
     if (ctx->sk_mode) return sk_scatter(ctx, d_send, capacity_words, send_words);
+    // (explicit keys -- k < 20, k > 64 or DSKGPU_F_MG_EXPLICIT -- keep 32-bit key offsets in the send buffer: one key per byte at most)
+    if (ctx->n_bytes >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "explicit-key exchange: a rank's read shard must stay below 4.29 GB (super-k-mer records, 20 <= k <= 64, have no such limit)");
     if (capacity_words < dskgpu_mg_send_capacity_words(ctx)) return fail(ctx, DSKGPU_E_ARG, "send buffer too small");
     const int rc = ctx->W == 1 ? mg_scatter_impl<1>(ctx, d_send, send_words) : ctx->W == 2 ? mg_scatter_impl<2>(ctx, d_send, send_words) : mg_scatter_impl<4>(ctx, d_send, send_words);
     if (rc == DSKGPU_OK) for (u32 o = 0; o < ctx->cfg.world_size; ++o) ctx->h_sk_sent[o] = send_words[o] / (u64)ctx->W;
@@ -2903,7 +3114,6 @@ int dskgpu_mg_sample(dskgpu_ctx* ctx, uint64_t* loads) {
     std::memset(loads, 0, (size_t)SK_BUCKETS * 8);
     if (!ctx->sk_mode) return DSKGPU_OK;            // explicit keys: the owner is a bit field of the k-mer hash, balanced by construction
     CK(hipSetDevice(ctx->cfg.device));
-    if (ctx->n_bytes >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "read shard too large for 32-bit record offsets");
     u64 nwords = 0;
     int rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords);
     if (rc) return rc;

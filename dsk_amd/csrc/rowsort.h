@@ -78,9 +78,12 @@ __global__ __launch_bounds__(RS_NT) void k_rs_hist(const u64* __restrict__ v, u6
 
 // rows [beg, end) -> their bins, through LDS-staged tiles of NT * RS_RPT rows; L.cur[] = next free output index per bin,
 // L.cnt[0..P] zero on entry.  The next tile's rows are loaded before the current tile enters its LDS phases.
-template <int P, int NT>
+// gdel (HUGE: row sets of 2^32 rows and more, step A slab by slab): a 64-bit offset per bin that is added to the (32-bit, slab-local)
+// output index -- the slab's rows of bin b then land behind the rows the earlier slabs put there (dskgpu.hip: sort_rows_huge).
+template <int P, int NT, bool HUGE = false>
 __device__ __forceinline__ void rs_scatter_range(const u64* __restrict__ v, const u32* __restrict__ ab, u64 beg, u64 end,
-                                                 u64* __restrict__ ov, u32* __restrict__ oab, int sh, u32 m, const RsLds<P, NT * RS_RPT>& L) {
+                                                 u64* __restrict__ ov, u32* __restrict__ oab, int sh, u32 m, const RsLds<P, NT * RS_RPT>& L,
+                                                 const u64* __restrict__ gdel = nullptr) {
     constexpr u32 TILE = NT * RS_RPT;
     const u32 tid = threadIdx.x;
     u64 kk[RS_RPT], kn[RS_RPT]; u32 aa[RS_RPT], an[RS_RPT];
@@ -117,8 +120,10 @@ __device__ __forceinline__ void rs_scatter_range(const u64* __restrict__ v, cons
             const u32 i = tid + (u32)j * NT;
             if (i < ntile) {
                 const u64 k = L.skey[i];
-                const u32 dst = L.delta[rs_dig(k, sh, m)] + i;
-                ov[dst] = k; oab[dst] = L.sab[i];
+                const u32 dg = rs_dig(k, sh, m);
+                const u32 dst = L.delta[dg] + i;
+                if constexpr (HUGE) { const u64 d64 = (u64)dst + gdel[dg]; ov[d64] = k; oab[d64] = L.sab[i]; }
+                else { ov[dst] = k; oab[dst] = L.sab[i]; }
             }
         }
         // no barrier: the next tile's rank phase only touches cnt; its first barrier orders this write-out before the next stage writes
@@ -131,8 +136,10 @@ __device__ __forceinline__ void rs_scatter_range(const u64* __restrict__ v, cons
 }
 
 // step A: chunk c scatters its rows to the 1024 buckets (offsets from the scanned matrix)
+template <bool HUGE = false>
 __global__ __launch_bounds__(RS_NT) void k_rs_scatter(const u64* __restrict__ v, const u32* __restrict__ ab, u64 n, u32 chunk, u32 nch,
-                                                      const u32* __restrict__ scanned, u64* __restrict__ ov, u32* __restrict__ oab, RsSpec sp) {
+                                                      const u32* __restrict__ scanned, u64* __restrict__ ov, u32* __restrict__ oab, RsSpec sp,
+                                                      const u64* __restrict__ gdel) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RsLds<RS_ABINS, RS_TILE> L(smem);
     const u32 c = blockIdx.x;
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(RS_NT) void k_rs_scatter(const u64* __restrict__ v,
     lds_barrier();
     const u64 beg = (u64)c * chunk;
     const u64 end = beg + chunk < n ? beg + chunk : n;
-    rs_scatter_range<RS_ABINS, RS_NT>(v, ab, beg, end, ov, oab, sp.shA, sp.mA, L);
+    rs_scatter_range<RS_ABINS, RS_NT, HUGE>(v, ab, beg, end, ov, oab, sp.shA, sp.mA, L, gdel);
 }
 
 // step B: a block splits one bucket at a time (rows [scanned[b * nch], scanned[(b + 1) * nch]) of v / ab) into 256 sub-buckets on

@@ -70,8 +70,9 @@ __global__ __launch_bounds__(RS_NT) void k2_hist(Rows2C v, u64 n, u32 chunk, u32
 }
 
 // rows [beg, end) -> their bins, through LDS-staged tiles of NT * RS2_RPT rows (the structure of rs_scatter_range)
-template <int P, int NT>
-__device__ __forceinline__ void rs2_scatter_range(Rows2C v, u64 beg, u64 end, Rows2 o, int sh, u32 m, const Rs2Lds<P, NT * RS2_RPT>& L) {
+template <int P, int NT, bool HUGE = false>
+__device__ __forceinline__ void rs2_scatter_range(Rows2C v, u64 beg, u64 end, Rows2 o, int sh, u32 m, const Rs2Lds<P, NT * RS2_RPT>& L,
+                                                  const u64* __restrict__ gdel = nullptr) {      // (gdel: see rs_scatter_range)
     constexpr u32 TILE = NT * RS2_RPT;
     const u32 tid = threadIdx.x;
     u64 kh[RS2_RPT], kl[RS2_RPT], nh[RS2_RPT], nl[RS2_RPT]; u32 aa[RS2_RPT], an[RS2_RPT];
@@ -108,8 +109,10 @@ __device__ __forceinline__ void rs2_scatter_range(Rows2C v, u64 beg, u64 end, Ro
             const u32 i = tid + (u32)j * NT;
             if (i < ntile) {
                 const u64 h = L.shi[i], l = L.slo[i];
-                const u32 dst = L.delta[rs2_dig(h, l, sh, m)] + i;
-                o.hi[dst] = h; o.lo[dst] = l; o.ab[dst] = L.sab[i];
+                const u32 dg = rs2_dig(h, l, sh, m);
+                const u32 dst = L.delta[dg] + i;
+                if constexpr (HUGE) { const u64 d64 = (u64)dst + gdel[dg]; o.hi[d64] = h; o.lo[d64] = l; o.ab[d64] = L.sab[i]; }
+                else { o.hi[dst] = h; o.lo[dst] = l; o.ab[dst] = L.sab[i]; }
             }
         }
         if (more) {
@@ -121,7 +124,9 @@ __device__ __forceinline__ void rs2_scatter_range(Rows2C v, u64 beg, u64 end, Ro
 }
 
 // step A: chunk c scatters its rows to the 1024 buckets (offsets from the scanned matrix)
-__global__ __launch_bounds__(RS_NT) void k2_scatter(Rows2C v, u64 n, u32 chunk, u32 nch, const u32* __restrict__ scanned, Rows2 o, RsSpec sp) {
+template <bool HUGE = false>
+__global__ __launch_bounds__(RS_NT) void k2_scatter(Rows2C v, u64 n, u32 chunk, u32 nch, const u32* __restrict__ scanned, Rows2 o, RsSpec sp,
+                                                    const u64* __restrict__ gdel) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Rs2Lds<RS_ABINS, RS2_TILE> L(smem);
     const u32 c = blockIdx.x;
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(RS_NT) void k2_scatter(Rows2C v, u64 n, u32 chunk, 
     lds_barrier();
     const u64 beg = (u64)c * chunk;
     const u64 end = beg + chunk < n ? beg + chunk : n;
-    rs2_scatter_range<RS_ABINS, RS_NT>(v, beg, end, o, sp.shA, sp.mA, L);
+    rs2_scatter_range<RS_ABINS, RS_NT, HUGE>(v, beg, end, o, sp.shA, sp.mA, L, gdel);
 }
 
 // step B: a block splits one bucket at a time into BB sub-buckets on the second digit; starts (row indices) to sub[b * (BB + 1) ..]

@@ -6,14 +6,14 @@ import numpy as np
 import torch
 
 
-def device_invariants(kc, st, hist, k, reads, nr, rl, dev):
+def device_invariants(kc, st, hist, k, reads, nr, rl, dev, amin=2):
     """sum(i * hist[i]) == n_kmers (nothing saturates), sum(hist) == n_distinct, sum(hist[amin:]) == n_solid == rows, rows strictly
     ascending, histogram of the rows' abundances == hist tail, n_kmers == number of full ACGT windows (closed form: <= 1 'N' per read)."""
     h = hist.astype(np.int64)
     idx = np.arange(len(h), dtype=np.int64)
     sat = int(h[-1])
     assert int(h.sum()) == st["n_distinct"], "sum(hist) != n_distinct"
-    assert int(h[2:].sum()) == st["n_solid"], "hist tail != n_solid"
+    assert int(h[amin:].sum()) == st["n_solid"], "hist tail != n_solid"
     kp, ap, n = kc.result_device()
     assert n == st["n_solid"]
     hip = ctypes.CDLL("libamdhip64.so")
@@ -33,9 +33,9 @@ def device_invariants(kc, st, hist, k, reads, nr, rl, dev):
         a = abuf[:m].to(torch.int64)
         ab_sum += int(a.sum())
         bins += torch.bincount(torch.clamp(a, max=len(h) - 1), minlength=len(h))
-    assert (bins.cpu().numpy()[2:] == h[2:]).all(), "histogram of the rows != hist tail"
+    assert (bins.cpu().numpy()[amin:] == h[amin:]).all(), "histogram of the rows != hist tail"
     # k-mer occurrences: rows carry the true abundance even where the histogram saturates at its last row
-    assert ab_sum + int(h[1]) == st["n_kmers"], "sum of abundances != n_kmers"
+    assert ab_sum + int((h[:amin] * idx[:amin]).sum()) == st["n_kmers"], "sum of abundances != n_kmers"
     if not sat:
         assert int((h * idx).sum()) == st["n_kmers"]
     r = reads.view(nr, rl + 1)[:, :rl]

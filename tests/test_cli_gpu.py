@@ -118,3 +118,47 @@ def test_abundance_min_auto_on_gpu(bins, tmp_path, oracle):
     """f2 through the HIP binary: `-abundance-min auto` -> cutoff / nbsolids_auto attributes and the filtered rows."""
     from tests.test_host_cli import run_abundance_min_auto
     run_abundance_min_auto(bins, str(tmp_path), oracle)
+
+
+def test_nb_gpus_on_a_file_with_more_than_4_gb_per_rank(bins, tmp_path):
+    """`dsk -nb-gpus 2` on a file whose halves exceed 2^32 bytes of reads each (60 M x 150 bp: 4.53 GB per
+    rank -- what `-nb-gpus 2|4` meets on configs[2]'s 200 M-read file; the reference counts any file in one execute(),
+    src/DSK.cpp:55-60) reproduces the 1-GPU run: same histogram, same k-mer totals, same solid rows (a high -abundance-min keeps the
+    text dump small: the tail of the 50x coverage peak)."""
+    import re
+    import torch
+    from dsk_amd import synth
+    from tests.test_host_cli import h5_histo
+    tmp = str(tmp_path)
+    dev = torch.device("cuda:0")
+    nr, rl = 60_000_000, 150
+    reads = synth.make_reads(synth.make_genome(180_000_000, dev), nr, rl).view(nr, rl + 1)
+    fa = os.path.join(tmp, "big.fa")
+    with open(fa, "wb") as f:                         # ">r\nSEQ\n" records, written in pieces of 4 M reads
+        for r0 in range(0, nr, 4_000_000):
+            part = reads[r0: r0 + 4_000_000]
+            rec = torch.empty((part.shape[0], 3 + rl + 1), dtype=torch.uint8, device=dev)
+            rec[:, 0] = 62; rec[:, 1] = 114; rec[:, 2] = 10
+            rec[:, 3:] = part
+            rec.cpu().numpy().tofile(f)
+            del rec
+    del reads
+    torch.cuda.empty_cache()
+    assert os.path.getsize(fa) == nr * (3 + rl + 1)
+    val = lambda l: int(l.split()[0].translate(bytes.maketrans(b"ACTG", b"0123")), 4)
+    got = {}
+    for n in (1, 2):
+        name = f"big_{n}"
+        r = subprocess.run([bins["dsk"], "-file", fa, "-kmer-size", "31", "-abundance-min", "48", "-out", name, "-nb-gpus", str(n), "-verbose", "1"],
+                           cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        info = r.stdout.decode()
+        figures = tuple(int(re.search(key + r"\s*:\s*(\d+)", info).group(1)) for key in ("kmers_nb_valid", "kmers_nb_distinct", "kmers_nb_solid"))
+        subprocess.check_call([bins["dsk2ascii"], "-file", name, "-out", name + ".txt", "-verbose", "0"], cwd=tmp)
+        lines = open(os.path.join(tmp, name + ".txt"), "rb").read().splitlines()
+        lines.sort(key=val)
+        got[n] = (figures, h5_histo(name + ".h5", tmp), lines)
+        os.remove(os.path.join(tmp, name + ".h5"))
+    os.remove(fa)
+    assert got[1][0][0] > 7_000_000_000 and 1000 < got[1][0][2] == len(got[1][2]) < 20_000_000
+    assert got[1] == got[2]

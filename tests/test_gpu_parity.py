@@ -681,9 +681,10 @@ def full_size_invariants(st, h, kmers, ab, k, reads, nr, rl, dev):
 @pytest.mark.parametrize("workload,k", [("ecoli50x", 31), ("c2_10Mx150", 31), ("c2_10Mx150", 63),
                                         ("c3_shard_25Mx150", 31), ("c3_shard_25Mx150", 63),
                                         ("c3_200Mx150", 31), ("c3_200Mx150", 63)])
-def test_full_size_invariants(dev, workload, k, monkeypatch):
-    """Size-independent properties at BASELINE.json's full sizes, too big for the oracle in seconds: configs[1] =
-    c2_10Mx150; c3_shard_25Mx150 = one GPU's share (25 M reads, 3.0e9 k-mers at k = 31) of configs[2] (k = 31) and
+def test_full_size_invariants(oracle, dev, workload, k, monkeypatch):
+    """Size-independent properties at BASELINE.json's full sizes.  configs[1] = c2_10Mx150 (the headline workload) is ALSO compared
+    with the CPU oracle at full size, row for row and histogram bin for bin, at k = 31 and k = 63 (the oracle counts it in seconds
+    on the GPU box's host cores); c3_shard_25Mx150 = one GPU's share (25 M reads, 3.0e9 k-mers at k = 31) of configs[2] (k = 31) and
     configs[3] (k = 63, two-word keys); c3_200Mx150 = the WHOLE volume of configs[2] / configs[3] (200 M reads, 30 GB of reads,
     2.4e10 / 1.76e10 k-mers) on this one GPU, as several passes over the key space -- the 8-GPU topology itself is the driver's
     to run."""
@@ -704,6 +705,17 @@ def test_full_size_invariants(dev, workload, k, monkeypatch):
         st2, h2, (kmers2, ab2) = count()
         monkeypatch.delenv("DSKGPU_NO_OPT2")
         assert (h2 == h).all() and (kmers2 == kmers).all() and (ab2 == ab).all() and st2["n_distinct"] == st["n_distinct"]
+        del kmers2, ab2
+        # ... and both must equal the CPU oracle's count of the same 1.51 GB stream (the parity gate)
+        ref = oracle.count(reads.cpu().numpy(), k, threads=os.cpu_count())
+        keep = ref.ab >= 2
+        assert st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct and st["n_solid"] == int(keep.sum())
+        assert (h == ref.histogram(10000).astype(np.int64)).all()
+        assert (ab == ref.ab[keep]).all()
+        assert (kmers[:, 0] == ref.lo[keep]).all()
+        if k > 32:
+            assert (kmers[:, 1] == ref.hi[keep]).all()
+        del ref, keep
     full_size_invariants(st, h, kmers, ab, k, reads, nr, rl, dev)
 
 
@@ -840,6 +852,108 @@ def test_human_standin_shard_against_the_exact_path_and_eight_ranks(dev, monkeyp
     del rows
     order = torch.argsort(kk)
     assert torch.equal(kk[order], kq) and torch.equal(aa[order], aq)
+
+
+def test_full_size_more_than_2_pow_32_rows(dev):
+    """More than 2^32 solid rows on one GPU (`-abundance-min 1` keeps every distinct k-mer; the reference streams
+    rows to Partition<Count> without a bound, utils/dsk2ascii.cpp:61,77): 60 M x 150 bp reads at 4 % substitutions -- 7.2e9 k-mers,
+    > 5e9 distinct, nearly all of them error k-mers seen once -- counted in several passes, the rows ordered by the slab-wise MSD sort
+    (sort_rows_huge).  Checked on the device: strictly ascending over all rows, sum of abundances == n_kmers, histogram of the rows
+    == the histogram, n_kmers == the closed-form number of valid windows."""
+    from dsk_amd import KmerCounter, synth
+    from tests.full_size import device_invariants
+    nr, rl = 60_000_000, 150
+    reads = synth.make_reads(synth.make_genome(180_000_000, dev), nr, rl, error_rate=0.04)
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    with KmerCounter(kmer_size=31, abundance_min=1) as kc:
+        kc.set_reads_device(reads.data_ptr(), reads.numel())
+        kc.count()
+        st = kc.stats()
+        assert st["n_solid"] == st["n_distinct"] > (1 << 32), st
+        assert st["n_retries"] == 0 and st["sort_fallback"] == 0 and st["n_passes"] > 1, st
+        inv = device_invariants(kc, st, kc.histogram(), 31, reads, nr, rl, dev, amin=1)
+        assert inv["rows_checked"] == st["n_solid"]
+    del reads
+    torch.cuda.empty_cache()
+
+
+def test_full_size_group_with_shards_above_4_gb(dev):
+    """a rank's read shard may be of any size (the sender's record positions are 64-bit).  Two ranks of one
+    in-process group, each holding 30 M x 150 bp = 4.53 GB of reads (> 2^32 bytes: what `dsk -nb-gpus 2|4` sees on configs[2]'s
+    200 M-read file, and a rank of the 8-GPU human job: doc/human_log:3-4): the union of the ranks' rows equals the single-GPU count
+    of the same 60 M reads row for row, the histograms add up."""
+    from dsk_amd import KmerCounter, KmerGroup, synth
+    nr, rl = 60_000_000, 150
+    reads = synth.make_reads(synth.make_genome(180_000_000, dev), nr, rl)
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    with KmerCounter(kmer_size=31, abundance_min=2) as kc:
+        kc.set_reads_device(reads.data_ptr(), reads.numel())
+        kc.count()
+        st1, h1 = kc.stats(), kc.histogram()
+        k1, a1 = _device_rows(kc, dev)
+    torch.cuda.empty_cache()
+    ranks, per = 2, nr // 2
+    assert per * (rl + 1) > (1 << 32)
+    with KmerGroup([0] * ranks, kmer_size=31, abundance_min=2, nb_partitions=1) as g:
+        for r in range(ranks):
+            g.rank(r).set_reads_device(reads.data_ptr() + r * per * (rl + 1), per * (rl + 1))
+        g.count()
+        sg = g.stats()
+        assert (sg["n_kmers"], sg["n_distinct"], sg["n_solid"]) == (st1["n_kmers"], st1["n_distinct"], st1["n_solid"])
+        assert (g.histogram() == h1).all()
+        got = [g.rank(r).stats()["n_kmers"] for r in range(ranks)]
+        assert max(got) <= 1.1 * (sum(got) / ranks)
+        assert g.exchanged_words() * 8 < 0.45 * sg["n_kmers"] * 8 / 2 * 1.2          # records, half of them stay on their rank
+        rows = [_device_rows(g.rank(r), dev) for r in range(ranks)]
+    kk = torch.cat([x[0] for x in rows]); aa = torch.cat([x[1] for x in rows])
+    del rows
+    order = torch.argsort(kk)
+    assert torch.equal(kk[order], k1) and torch.equal(aa[order], a1)
+
+
+def test_full_size_sender_on_a_human_rank_shard(dev):
+    """ONE rank of the 8-GPU human job as a sender -- the 75 M-read shard of the repeat-rich stand-in,
+    11.3 GB of reads (2.6 x the old 32-bit limit) -- through dskgpu_mg_sample -> make_table -> dskgpu_mg_scatter; every owner's
+    records are then counted by a context of that owner (one GPU after the other).  The k-mers the sender packed per owner add up to
+    the valid windows, every owner's count accepts that figure, and the owners' distinct k-mers and histograms add up to the
+    single-GPU count of the same shard (owners are disjoint in k-mer space)."""
+    from dsk_amd import KmerCounter, synth
+    from dsk_amd.engine import make_table
+    from dsk_amd.multi import scatter_records
+    world = 8
+    reads, gl, nr, rl = synth.make_workload("c5_human30x_shard", dev)
+    assert reads.numel() > 11_000_000_000
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    with KmerCounter(kmer_size=31, abundance_min=2) as kc:
+        kc.set_reads_device(reads.data_ptr(), reads.numel())
+        kc.count()
+        st1, h1 = kc.stats(), kc.histogram().astype(np.int64)
+    torch.cuda.empty_cache()
+    with KmerCounter(kmer_size=31, abundance_min=2, world_size=world, rank=0) as snd:
+        snd.set_reads_device(reads.data_ptr(), reads.numel())
+        table = make_table(snd.mg_sample(), world)               # (one rank's loads stand for the sum: every shard is a uniform sample of the job)
+        snd.mg_set_table(table)
+        send, counts = scatter_records(snd, None, dev)
+        sent = snd.mg_sent_kmers()
+        torch.cuda.synchronize()
+    assert sum(sent) == st1["n_kmers"] and len(counts) == world and min(counts) > 0
+    assert sum(counts) * 8 < 0.45 * st1["n_kmers"] * 8                                  # super-k-mer records: < 45 % of explicit keys' bytes
+    assert max(sent) <= 1.25 * (sum(sent) / world), sent                                # the repartition table balances the owners (poly-A included)
+    tot_k = tot_d = tot_s = 0
+    hist = np.zeros_like(h1)
+    off = 0
+    for o in range(world):
+        with KmerCounter(kmer_size=31, abundance_min=2, world_size=world, rank=o) as rcv:
+            rcv.mg_set_table(table)
+            rcv.mg_count(send.data_ptr() + off * 8, counts[o], sent[o])             # (a wrong k-mer figure is refused: DSKGPU_E_ARG)
+            s = rcv.stats()
+            assert s["sort_fallback"] == 0, (o, s)
+            tot_k += s["n_kmers"]; tot_d += s["n_distinct"]; tot_s += s["n_solid"]
+            hist += rcv.histogram().astype(np.int64)
+        off += counts[o]
+        torch.cuda.empty_cache()
+    assert (tot_k, tot_d, tot_s) == (st1["n_kmers"], st1["n_distinct"], st1["n_solid"])
+    assert (hist == h1).all()
 
 
 def test_full_size_multi_pass(dev):
@@ -1355,6 +1469,64 @@ def test_row_sort_of_huge_row_sets_in_groups(oracle, dev, monkeypatch):
     assert st["sort_fallback"] == 1
     st = check_against_oracle(oracle, reads, 63, dev, amin=1)                          # (two-word rows: the scratch copy goes back to out_* first)
     assert st["sort_fallback"] == 1
+
+
+def test_row_sort_of_2_pow_32_rows_and_more_slab_by_slab(oracle, dev, monkeypatch):
+    """Row sets of >= 2^32 rows (sort_rows_huge: `-abundance-min 1` on a 200 M-read input; the reference streams rows to
+    Partition<Count> without a bound, utils/dsk2ascii.cpp:61,77): step A runs slab by slab with 64-bit bucket offsets, then group by
+    group.  Forced here on a small input with DSKGPU_RS_SLAB_ROWS (slabs of 100 000 rows: 8-20 of them) -- one- and two-word rows,
+    a single pass and several, few value bits, skewed values (a group that takes the per-group library sort), and together with
+    small groups (DSKGPU_RS_MAX_ROWS).  The full-size case is test_full_size_more_than_2_pow_32_rows."""
+    from dsk_amd import synth
+    g = synth.make_genome(400_000, dev)
+    reads = synth.make_reads(g, 120_000, 150).cpu().numpy()
+    rng = np.random.default_rng(7)
+    pa = np.full(1_000_000, 65, np.uint8)
+    hit = rng.random(pa.size) < 0.02
+    pa[hit] = rng.choice(np.frombuffer(b"CGT", dtype=np.uint8), size=int(hit.sum()))
+    skew = np.concatenate([pa, np.array([10], np.uint8), reads]).astype(np.uint8)
+    monkeypatch.setenv("DSKGPU_RS_SLAB_ROWS", "100000")
+    for k, s in ((31, reads), (13, reads), (63, reads), (35, reads), (31, skew)):
+        st = check_against_oracle(oracle, s, k, dev, amin=1)
+        assert st["n_solid"] > 300000 and st["sort_fallback"] == 0, (k, st)
+    st = check_against_oracle(oracle, reads, 31, dev, amin=1, max_pass_mkeys=2)         # several passes: rows accumulated, scratch carved from l0buf
+    assert st["n_passes"] > 4 and st["sort_fallback"] == 0
+    monkeypatch.setenv("DSKGPU_RS_MAX_ROWS", "300000")                                  # groups of <= 300 000 rows
+    for k, s in ((31, reads), (63, reads)):
+        st = check_against_oracle(oracle, s, k, dev, amin=1)
+        assert st["sort_fallback"] == 0, (k, st)
+    monkeypatch.setenv("DSKGPU_RS_MAX_ROWS", "100000")
+    st = check_against_oracle(oracle, skew, 63, dev, amin=1)                            # one 10-bit bucket (900 000 rows under AAAAA) above the group limit:
+    assert st["sort_fallback"] == 1, st                                                 #  the full-width order for THAT group, the others by the MSD kernels
+    monkeypatch.setenv("DSKGPU_RS_MAX_ROWS", "3000")                                    # (one-word rows: most 10-bit buckets above the limit -> the library
+    st = check_against_oracle(oracle, reads, 31, dev, amin=1)                           #  sort bucket by bucket, the MSD kernels for the small ones)
+    assert st["sort_fallback"] == 1, st
+
+
+def test_multi_pass_count_leaves_the_sender_state_alone(oracle, dev):
+    """the record-based level 0 of a multi-pass count borrows the context's multi-GPU sender state (owners =
+    passes, a repartition table for that many owners) -- and must give it back: a later dskgpu_mg_* call on the same world_size = 1
+    context sees ONE owner again (it used to loop over up to 64 owners into the caller's one-entry arrays)."""
+    from dsk_amd import KmerCounter, synth
+    from dsk_amd.multi import scatter_records
+    reads = synth.make_reads(synth.make_genome(300_000, dev), 100_000, 150)
+    ref = oracle.count(reads.cpu().numpy(), 31)
+    with KmerCounter(kmer_size=31, abundance_min=1, max_pass_mkeys=2) as kc:
+        kc.set_reads_device(reads.data_ptr(), reads.numel())
+        kc.count()
+        st = kc.stats()
+        assert st["n_passes"] > 4 and st["n_read_sweeps"] < st["n_passes"]            # the record-based level 0 ran
+        assert st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct
+        send, counts = scatter_records(kc, None, dev)                                 # the degenerate exchange: every record to owner 0
+        assert len(counts) == 1 and counts[0] > 0
+        assert kc.mg_sent_kmers() == [ref.total]
+        torch.cuda.synchronize()
+        kc.mg_count(send.data_ptr(), counts[0], ref.total)
+        st2 = kc.stats()
+        assert st2["n_kmers"] == ref.total and st2["n_distinct"] == ref.distinct
+        assert (kc.histogram() == ref.histogram(10000)).all()
+        kc.count()                                                                    # ... and the multi-pass count again, afterwards
+        assert kc.stats()["n_distinct"] == ref.distinct
 
 
 @pytest.mark.parametrize("k", [40, 63, 70, 100])
