@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-k63", action="store_true", help="skip the k = 63 count of the same reads (two-word keys, configs[3]'s key width: extra block, headline unchanged)")
     ap.add_argument("--no-human-standin", action="store_true", help="skip the configs[4] stand-in block (600 M x 150 bp of a repeat-rich 3 Gbp genome on this one GPU, ~20 s)")
     ap.add_argument("--no-place-compare", action="store_true", help="skip the plain-hipMalloc leg that yields ms_per_step_no_place (profiling runs: one set of launches per kernel)")
+    ap.add_argument("--check-parity", action="store_true", help="N > 1: before the timed steps, count the first 1/64 of every rank's shard (a) sharded over the N ranks and "
+                                                                "(b) on rank 0 alone, and require identical totals and histograms (exit code 3 otherwise)")
+    ap.add_argument("--no-self-check", action="store_true", help="N > 1: skip the invariants every rank checks on its own result after the timed steps")
     ap.add_argument("--no-place", action="store_true", help="plain hipMalloc for the big device buffers instead of the best-placed of 8 candidates (DSKGPU_F_PLACE)")
     return ap.parse_args()
 
@@ -282,6 +285,43 @@ def human_standin_block(k, amin, dev):
             "reference_context": "the reference's own human run: 7 passes over the input, 2.7e9 solid k-mers (doc/human_log:3-4,20-24); README.md:126-130 asks for 'below 10' passes"}
 
 
+def valid_windows(reads_u8, n_reads, read_len, k):
+    """Number of full ACGT windows of a synthetic read stream (<= 1 'N' per read, dsk_amd/synth.py), closed form on the device."""
+    import torch
+    r = reads_u8.view(n_reads, read_len + 1)[:, :read_len]
+    total = 0
+    for r0 in range(0, n_reads, 8_000_000):
+        bad = r[r0:r0 + 8_000_000] == 78
+        has = bad.any(1)
+        q = bad.to(torch.uint8).argmax(1).to(torch.int64)
+        with_n = torch.clamp(q - k + 1, min=0) + torch.clamp(read_len - q - k, min=0)
+        total += int(torch.where(has, with_n, torch.full_like(with_n, read_len - k + 1)).sum())
+    return total
+
+
+def rows_strictly_ascending(kc, dev, words):
+    """This rank's sorted result, checked where it lies (HBM): every row's value above its predecessor's -> (ok, rows, sum of abundances)."""
+    import ctypes
+    import torch
+    kp, ap, n = kc.result_device()
+    if n == 0:
+        return True, 0, 0
+    hip = ctypes.CDLL("libamdhip64.so")
+    step = 1 << 26
+    kb = torch.empty(step, dtype=torch.int64, device=dev); ab = torch.empty(step, dtype=torch.int32, device=dev)
+    ok, last, ab_sum = True, None, 0
+    for r0 in range(0, n, step):
+        m = min(step, n - r0)
+        hip.hipMemcpy(ctypes.c_void_p(ab.data_ptr()), ctypes.c_void_p(ap + r0 * 4), ctypes.c_size_t(m * 4), 3)
+        ab_sum += int(ab[:m].to(torch.int64).sum())
+        if words == 1:          # (k <= 31: values < 2^62, a signed compare is safe; wider keys: the abundances only -- word 0 alone does not order them)
+            hip.hipMemcpy(ctypes.c_void_p(kb.data_ptr()), ctypes.c_void_p(kp + r0 * 8), ctypes.c_size_t(m * 8), 3)
+            kk = kb[:m]
+            ok = ok and bool((kk[1:] > kk[:-1]).all()) and (last is None or int(kk[0]) > last)
+            last = int(kk[-1])
+    return ok, int(n), ab_sum
+
+
 def self_launch(args):
     """`python bench.py --gpus N` started bare (no WORLD_SIZE): become the launcher of the N ranks.  This process never
     touches the GPU (torch is not even imported here): the ranks are children of torch.distributed.run, rank 0's JSON line
@@ -381,6 +421,48 @@ def main():
         from dsk_amd.multi import ShardedCounter
         sharded = ShardedCounter(kc, dev, wait_timeout_s=COLLECTIVE_TIMEOUT_S)
 
+    # ---- N > 1, --check-parity: the sharded count of a 1/64 sample against ONE context counting the same reads (rank 0) -- identical
+    # totals and histograms, or the run fails before anything is timed
+    parity = None
+    if world > 1 and args.check_parity:
+        ns = max(1000, nr // 64)
+        smp = reads[: ns * (rl + 1)]
+        kc.set_reads_device(smp.data_ptr(), smp.numel())
+        sharded.count()
+        ps = kc.stats()
+        ph = torch.from_numpy(kc.histogram().astype("int64")).to(rdev)
+        pt = torch.tensor([ps["n_kmers"], ps["n_distinct"], ps["n_solid"]], dtype=torch.int64, device=rdev)
+        dist.all_reduce(ph, op=dist.ReduceOp.SUM); dist.all_reduce(pt, op=dist.ReduceOp.SUM)
+        gathered = [torch.empty_like(smp) for _ in range(world)] if rank == 0 else None
+        if share_gpu:
+            host = [torch.empty(smp.numel(), dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+            dist.gather(smp.cpu(), host, dst=0)
+            if rank == 0:
+                gathered = [h.to(dev) for h in host]
+        else:
+            dist.gather(smp, gathered, dst=0)
+        flag = torch.zeros(1, dtype=torch.int64, device=rdev)
+        if rank == 0:
+            allr = torch.cat(gathered)
+            torch.cuda.synchronize()
+            with KmerCounter(kmer_size=args.kmer_size, abundance_min=args.abundance_min, device=local_rank) as k1:
+                k1.set_reads_device(allr.data_ptr(), allr.numel())
+                k1.count()
+                s1, h1 = k1.stats(), k1.histogram().astype("int64")
+            same = ([int(x) for x in pt.tolist()] == [s1["n_kmers"], s1["n_distinct"], s1["n_solid"]]) and bool((ph.cpu().numpy() == h1).all())
+            parity = {"sample_reads_per_rank": ns, "sharded": [int(x) for x in pt.tolist()], "one_gpu": [s1["n_kmers"], s1["n_distinct"], s1["n_solid"]],
+                      "histograms_equal": bool((ph.cpu().numpy() == h1).all()), "ok": bool(same)}
+            flag[0] = 0 if same else 1
+            del allr, gathered
+        dist.broadcast(flag, src=0)
+        if int(flag.item()):
+            if rank == 0:
+                print("bench.py --check-parity FAILED: " + json.dumps(parity), file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(3)
+        kc.set_reads_device(reads.data_ptr(), n_bytes)
+        torch.cuda.empty_cache()
+
     stage_acc = {}
     sliced_steps = [0]
 
@@ -416,6 +498,48 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     st = kc.stats()
+
+    # ---- N > 1: every rank checks its own share of the result, the job-wide sums are checked after the reductions below -- a wrong
+    # exchange must not print a `value` (exit code 3)
+    self_check = None
+    if world > 1 and not args.no_self_check:
+        h = kc.histogram().astype("int64")
+        asc, rows_n, ab_sum = rows_strictly_ascending(kc, dev, kc.words)
+        amin = args.abundance_min
+        local_ok = asc and rows_n == st["n_solid"] and int(h.sum()) == st["n_distinct"] and int(h[amin:].sum()) == st["n_solid"]
+        if int(h[-1]) == 0:          # nothing saturates the last histogram row: sum(i * hist[i]) is this rank's k-mer count
+            local_ok = local_ok and int((h * torch.arange(len(h)).numpy()).sum()) == st["n_kmers"]
+        local_ok = local_ok and ab_sum + int((h[:amin] * torch.arange(amin).numpy()).sum()) == st["n_kmers"]
+        chk = torch.tensor([0 if local_ok else 1, valid_windows(reads, nr, rl, args.kmer_size), st["n_kmers"]], dtype=torch.int64, device=rdev)
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+        bad_ranks, windows, counted = [int(x) for x in chk.tolist()]
+        self_check = {"ranks_with_a_failed_local_check": bad_ranks, "valid_windows_of_all_shards": windows, "kmers_counted_by_all_ranks": counted,
+                      "local_checks": "rows strictly ascending (one-word keys), rows == n_solid == sum(hist[amin:]), sum(hist) == n_distinct, sum(i*hist) == sum of abundances (+ below amin) == n_kmers",
+                      "ok": bad_ranks == 0 and windows == counted}
+        if not self_check["ok"]:
+            if rank == 0:
+                print("bench.py self-check FAILED: " + json.dumps(self_check), file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(3)
+    # ---- N > 1: the exchange alone, once, outside the timed region: one step in one piece with the all-to-all bracketed by
+    # synchronisation (inside a sliced step it overlaps the sender and the receiver's level 1 and cannot be timed by itself)
+    exchange_alone = None
+    if world > 1:
+        from dsk_amd.multi import exchange, scatter_records
+        with torch.cuda.stream(sharded.stream) if sharded.stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
+            sharded.send, counts = scatter_records(kc, sharded.send, dev)
+            torch.cuda.synchronize(); dist.barrier()
+            te = time.perf_counter()
+            outb, rcounts = exchange(sharded.send, counts, None, sharded.recv)
+            torch.cuda.synchronize()
+            ex_s = time.perf_counter() - te
+        et = torch.tensor([ex_s], dtype=torch.float64, device=rdev)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        off_rank = sum(c for p_, c in enumerate(counts) if p_ != rank) * 8
+        exchange_alone = {"ms": round(float(et.item()) * 1e3, 3), "bytes_leaving_this_rank": int(off_rank), "bytes_sent_incl_own_share": int(sum(counts)) * 8,
+                          "gb_per_s_per_rank_off_gpu": round(off_rank / max(float(et.item()), 1e-9) / 1e9, 2),
+                          "note": "one all-to-all-v of a whole step's records (counts round + payload), max over ranks; xGMI egress when every rank has its own GPU"}
+        del outb
 
     # whole-job aggregates (MAX time over ranks, SUM of units)
     tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
@@ -505,6 +629,11 @@ def main():
                                      "per_kmer_on_the_wire": round(int(sent_w) * 8 / max(1.0, n_kmers / world), 3),
                                      "format": "super-k-mer records (2-3 words per <= 16 k-mers)" if 20 <= args.kmer_size <= 64 else "explicit keys"}
             out["sliced_steps"] = sliced_steps[0]
+            out["rccl_ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                 "devices": "one GPU shared by all ranks (development)" if share_gpu else "one GPU per rank"}
+            out["exchange_alone"] = exchange_alone
+            out["self_check"] = self_check
+            out["check_parity"] = parity
             if roofline:
                 roofline["per_rank"] = ("rank 0's kernels: mg_scatter = the sender (2-bit stream -> records), scatter1 = level 1 straight from the received "
                                         "records -- in a sliced step its stage time includes the wait for the slices' arrival")
