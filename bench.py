@@ -259,8 +259,8 @@ def human_standin_block(k, amin, dev):
     """BASELINE.json configs[4] (30x human short reads, ~90 Gbp, multi-pass) as the stand-in SURVEY.md section 8(d) allows: 600 M x 150 bp
     reads of a repeat-rich 3 Gbp genome (dsk_amd/synth.py c5_human30x: one high-copy family, tandem arrays, 0.2 % poly-A reads), all
     of it on this ONE GPU -- the 8-GPU topology is the driver's to run.  In a process of its own (tools/human_standin.py: 265 GB of
-    HBM, plain hipMalloc buffers): one count that allocates every buffer, one timed, the size-independent invariants checked on
-    the device."""
+    HBM, plain hipMalloc buffers): the reads encoded once and their bytes released (dskgpu_encode_reads), one count that allocates every
+    buffer, one timed, the size-independent invariants checked on the device."""
     import subprocess
     import torch
     free_b, total_b = torch.cuda.mem_get_info()
@@ -282,6 +282,8 @@ def human_standin_block(k, amin, dev):
             "passes_over_the_key_space": r["n_passes"], "sweeps_over_the_reads": r["n_read_sweeps"],
             **{x: r[x] for x in ("n_kmers", "n_distinct", "n_solid", "n_retries", "sort_fallback", "n_ext_regions", "n_heavy")},
             "stage_ms": r["stage_ms"], "hbm_used_gb": r["hbm_used_gb"], "invariants": r.get("invariants"),
+            "ascii_reads_resident_during_count": r.get("ascii_reads_resident_during_count"), "encode_reads_s": r.get("encode_reads_s"),
+            "input_handling": "the reads are encoded once (dskgpu_encode_reads: 2 bits per base + the invalid-base mask, 34 GB) and their 90 GB of bytes given back before the count",
             "reference_context": "the reference's own human run: 7 passes over the input, 2.7e9 solid k-mers (doc/human_log:3-4,20-24); README.md:126-130 asks for 'below 10' passes"}
 
 

@@ -211,6 +211,7 @@ struct dskgpu_ctx {
     std::vector<u64> h_sk_cb64;    // ... exact layout: their exclusive scan (owner-major) = record index of every (owner, chunk) pair
     DevBuf sk_cb64;                // ... the same on the device (k_sk_scatter<false>)
     // multi-GPU exchange as super-k-mer records (superkmer.h)
+    bool enc_keep = false;         // dskgpu_encode_reads: packed / inval hold the 2-bit form of the current reads and the ASCII bytes are gone (d_reads == nullptr)
     bool enc_fresh = false;        // packed / inval hold the encoding of the current reads, left by dskgpu_mg_sample for the sender's sizing pass of the same step
     bool sk_mode = false, sk_prepared = false;
     bool sk_slices = false;        // the prepared send layout is slices from a sampled estimate (else exact offsets)
@@ -336,6 +337,13 @@ int run_encode(dskgpu_ctx* ctx, const uint8_t* d_bytes, u64 n, u64* nwords_out) 
     }
     *nwords_out = nwords;
     return DSKGPU_OK;
+}
+
+// the 2-bit form of the context's current reads: encoded now, or kept from dskgpu_encode_reads (the ASCII bytes may be gone by then)
+int encode_current(dskgpu_ctx* ctx, u64* nwords_out) {
+    if (ctx->enc_keep) { *nwords_out = (ctx->n_bytes + 31) / 32; ctx->enc_fresh = false; return DSKGPU_OK; }
+    if (!ctx->d_reads && ctx->n_bytes) return fail(ctx, DSKGPU_E_STATE, "the reads were released (dskgpu_encode_reads) and their 2-bit form has been overwritten: set the reads again");
+    return run_encode(ctx, ctx->d_reads, ctx->n_bytes, nwords_out);
 }
 
 // ---- scan launcher: exclusive scan of a[0..*d_len) in place, total -> a[*d_len]
@@ -2206,7 +2214,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
     u64 nwords = 0;
     ctx->mark("start");
     if (from_reads) {
-        int rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords);
+        int rc = encode_current(ctx, &nwords);
         if (rc) return rc;
         ctx->mark("encode");
     }
@@ -2448,7 +2456,7 @@ int mg_scatter_impl(dskgpu_ctx* ctx, void* d_send, uint64_t* send_words) {
     ctx->st_names.clear(); ctx->st_ms.clear(); ctx->marks.clear(); ctx->ev_used = 0;
     ctx->mark("start");
     u64 nwords = 0;
-    int rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords);
+    int rc = encode_current(ctx, &nwords);
     if (rc) return rc;
     ctx->mark("encode");
     const u32 G = ctx->cfg.world_size;
@@ -2514,7 +2522,7 @@ int sk_prepare(dskgpu_ctx* ctx) {
     u64 nwords = 0;
     int rc = DSKGPU_OK;
     if (ctx->enc_fresh) { nwords = (ctx->n_bytes + 31) / 32; ctx->enc_fresh = false; }      // (the repartition sample of this step just encoded these reads)
-    else if ((rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords))) return rc;
+    else if ((rc = encode_current(ctx, &nwords))) return rc;
     ctx->mark("encode");
     SkParams& sp = ctx->sk_sp;
     sk_geometry(ctx, nwords);
@@ -2734,6 +2742,7 @@ int banks_begin(dskgpu_ctx* ctx) {
     j.ends = ctx->bank_ends;
     if (j.ends.empty() || j.ends.back() < ctx->n_bytes) j.ends.push_back(ctx->n_bytes);
     if (j.ends.size() > 32) return fail(ctx, DSKGPU_E_ARG, "at most 32 banks are supported by the solidity kinds");
+    if (ctx->enc_keep) return fail(ctx, DSKGPU_E_STATE, "per-bank counts (-solidity-kind, -histo2D) need the reads themselves: not after dskgpu_encode_reads");
     j.cfg = ctx->cfg; j.base = ctx->d_reads; j.total = ctx->n_bytes;
     j.nu = 0; j.tot_kmers = 0; j.passes = 1; j.retries = 0; j.active = true;
     ctx->cfg.abundance_min = 1; ctx->cfg.abundance_max = 0xFFFFFFFFu; ctx->cfg.flags |= DSKGPU_F_NO_SORT;
@@ -2992,7 +3001,7 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
     CK(hipMemsetAsync(dst + ctx->reads_len + nbytes, '\n', 1, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     ctx->reads_len += nbytes + 1;
-    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->mw_v3_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
+    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->enc_keep = false; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->mw_v3_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
     return DSKGPU_OK;
 }
 
@@ -3046,10 +3055,25 @@ int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbyte
     // intermittent failure of the multi-process test was exactly that, in the test's reference count).  Once per read set, not per count.
     CK(hipSetDevice(ctx->cfg.device));
     CK(hipDeviceSynchronize());
-    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->mw_v3_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
+    ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->enc_keep = false; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->mw_v3_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
     ctx->n_bytes = nbytes;
     ctx->reads_len = 0;
     ctx->bank_ends.clear();
+    return DSKGPU_OK;
+}
+
+int dskgpu_encode_reads(dskgpu_ctx* ctx) {
+    if (!ctx) return DSKGPU_E_ARG;
+    CK(hipSetDevice(ctx->cfg.device));
+    if (ctx->enc_keep) return DSKGPU_OK;
+    if (!ctx->d_reads && ctx->n_bytes) return fail(ctx, DSKGPU_E_STATE, "no reads to encode");
+    u64 nwords = 0;
+    const int rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords);
+    if (rc) return rc;
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->enc_keep = true;
+    ctx->d_reads = nullptr;                    // the caller's buffer is never read again
+    ctx->reads_own.release(); ctx->reads_len = 0;      // pushed reads: their ASCII copy in HBM goes too (a later push starts a new read set)
     return DSKGPU_OK;
 }
 
@@ -3115,7 +3139,7 @@ int dskgpu_mg_sample(dskgpu_ctx* ctx, uint64_t* loads) {
     if (!ctx->sk_mode) return DSKGPU_OK;            // explicit keys: the owner is a bit field of the k-mer hash, balanced by construction
     CK(hipSetDevice(ctx->cfg.device));
     u64 nwords = 0;
-    int rc = run_encode(ctx, ctx->d_reads, ctx->n_bytes, &nwords);
+    int rc = encode_current(ctx, &nwords);
     if (rc) return rc;
     sk_geometry(ctx, nwords);
     SkParams sp = ctx->sk_sp;
@@ -3311,6 +3335,7 @@ int dskgpu_k_encode(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, void*
     if (!ctx || !d_packed || !d_invalid) return DSKGPU_E_ARG;
     CK(hipSetDevice(ctx->cfg.device));
     u64 nwords = 0;
+    if (ctx->enc_keep) { ctx->enc_keep = false; }      // (a test hook that encodes other bytes: the kept 2-bit form of the reads is overwritten)
     int rc = run_encode(ctx, static_cast<const uint8_t*>(d_bytes), nbytes, &nwords);
     if (rc) return rc;
     CK(hipMemcpyAsync(d_packed, ctx->packed.p, nwords * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -3323,6 +3348,7 @@ int dskgpu_k_enumerate(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, vo
     if (!ctx || !d_kmers || !d_valid) return DSKGPU_E_ARG;
     CK(hipSetDevice(ctx->cfg.device));
     u64 nwords = 0;
+    if (ctx->enc_keep) { ctx->enc_keep = false; }      // (a test hook that encodes other bytes: the kept 2-bit form of the reads is overwritten)
     int rc = run_encode(ctx, static_cast<const uint8_t*>(d_bytes), nbytes, &nwords);
     if (rc) return rc;
     if (nwords) {
@@ -3348,6 +3374,7 @@ int dskgpu_k_minimizers(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes, v
     if (m < 1 || m > 16 || m > k) return fail(ctx, DSKGPU_E_ARG, "minimizer_size must be in 1..16 and <= kmer_size");
     CK(hipSetDevice(ctx->cfg.device));
     u64 nwords = 0;
+    if (ctx->enc_keep) { ctx->enc_keep = false; }      // (a test hook that encodes other bytes: the kept 2-bit form of the reads is overwritten)
     int rc = run_encode(ctx, static_cast<const uint8_t*>(d_bytes), nbytes, &nwords);
     if (rc) return rc;
     if (nbytes) {

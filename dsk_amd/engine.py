@@ -82,7 +82,7 @@ SOLIDITY = {"sum": 0, "min": 1, "max": 2, "one": 3, "all": 4, "custom": 5}
 # every symbol include/dskgpu.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "dskgpu_create", "dskgpu_destroy", "dskgpu_last_error", "dskgpu_version", "dskgpu_device_count", "dskgpu_set_stream",
-    "dskgpu_push_reads", "dskgpu_reserve_reads", "dskgpu_reserve_work", "dskgpu_set_reads_device", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
+    "dskgpu_push_reads", "dskgpu_reserve_reads", "dskgpu_reserve_work", "dskgpu_set_reads_device", "dskgpu_encode_reads", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
     "dskgpu_count", "dskgpu_mg_scatter", "dskgpu_mg_sample", "dskgpu_mg_make_table", "dskgpu_mg_set_table",
     "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_mg_sent_kmers", "dskgpu_mg_count_sized",
     "dskgpu_mg_slices_prepare", "dskgpu_mg_scatter_slice", "dskgpu_mg_slices_finish", "dskgpu_mg_count_sliced", "dskgpu_get_stats", "dskgpu_histogram",
@@ -129,6 +129,7 @@ def load_library():
     lib.dskgpu_reserve_work.argtypes = [vp, u64]
     lib.dskgpu_set_reads_device.argtypes = [vp, vp, u64]
     lib.dskgpu_count.argtypes = [vp]
+    lib.dskgpu_encode_reads.argtypes = [vp]
     lib.dskgpu_next_bank.argtypes = [vp]
     lib.dskgpu_set_banks.argtypes = [vp, C.POINTER(u64), u32]
     lib.dskgpu_histogram2d.argtypes = [vp, C.POINTER(u64), u32]
@@ -285,6 +286,10 @@ class KmerCounter:
 
     def set_reads_device(self, ptr: int, nbytes: int) -> None:
         self._ck(self._lib.dskgpu_set_reads_device(self._h, C.c_void_p(ptr), nbytes))
+
+    def encode_reads(self) -> None:
+        """Encode the current reads to their 2-bit form now and let go of the bytes: the buffer given to set_reads_device may be freed."""
+        self._ck(self._lib.dskgpu_encode_reads(self._h))
 
     def next_bank(self) -> None:
         self._ck(self._lib.dskgpu_next_bank(self._h))

@@ -112,6 +112,16 @@ int dskgpu_reserve_work(dskgpu_ctx* ctx, uint64_t nbytes);
  * dskgpu_set_stream, or a synchronisation of its own) before dskgpu_count. */
 int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbytes);
 
+/* Optional: turn the current reads into their 2-bit form NOW (the first stage of every count: 0.375 bytes per base) and let go of
+ * the bytes: a device-resident stream handed over with dskgpu_set_reads_device is never read again after this call returns -- the
+ * caller may free or overwrite it --, reads that were pushed lose their copy in HBM.  Every later dskgpu_count / dskgpu_mg_* of
+ * these reads starts from the kept encoding.  For inputs whose ASCII form would crowd the partitions out of HBM: 90 Gbp of reads
+ * are 90 GB as bytes and 34 GB encoded, and the difference decides how many sweeps over the reads a multi-pass count needs
+ * (README.md:126-130: DSK reads its bank once per pass and keeps nothing of it in memory).  Not with per-bank modes
+ * (-solidity-kind other than sum, -histo2D), which re-read bank by bank: DSKGPU_E_STATE there.  A new dskgpu_push_reads /
+ * dskgpu_set_reads_device starts a new read set. */
+int dskgpu_encode_reads(dskgpu_ctx* ctx);
+
 /* Banks: the comma-separated inputs of `-file` are separate banks (README.md:52-58).  Call
  * dskgpu_next_bank between the pushes of two banks, or give the end offset of every bank of a
  * device-resident stream.  Only needed for -solidity-kind != sum and -histo2D; at most 32 banks. */

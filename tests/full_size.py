@@ -6,7 +6,21 @@ import numpy as np
 import torch
 
 
-def device_invariants(kc, st, hist, k, reads, nr, rl, dev, amin=2):
+def valid_windows(reads, nr, rl, k):
+    """number of full ACGT windows of a synthetic read stream (<= 1 'N' per read), closed form on the device"""
+    r = reads.view(nr, rl + 1)[:, :rl]
+    n_valid = 0
+    for r0 in range(0, nr, 8_000_000):
+        bad = r[r0:r0 + 8_000_000] == 78
+        has = bad.any(1)
+        q = bad.to(torch.uint8).argmax(1).to(torch.int64)
+        full = rl - k + 1
+        with_n = torch.clamp(q - k + 1, min=0) + torch.clamp(rl - q - k, min=0)
+        n_valid += int(torch.where(has, with_n, torch.full_like(with_n, full)).sum())
+    return n_valid
+
+
+def device_invariants(kc, st, hist, k, reads, nr, rl, dev, amin=2, n_valid=None):
     """sum(i * hist[i]) == n_kmers (nothing saturates), sum(hist) == n_distinct, sum(hist[amin:]) == n_solid == rows, rows strictly
     ascending, histogram of the rows' abundances == hist tail, n_kmers == number of full ACGT windows (closed form: <= 1 'N' per read)."""
     h = hist.astype(np.int64)
@@ -38,15 +52,8 @@ def device_invariants(kc, st, hist, k, reads, nr, rl, dev, amin=2):
     assert ab_sum + int((h[:amin] * idx[:amin]).sum()) == st["n_kmers"], "sum of abundances != n_kmers"
     if not sat:
         assert int((h * idx).sum()) == st["n_kmers"]
-    r = reads.view(nr, rl + 1)[:, :rl]
-    n_valid = 0
-    for r0 in range(0, nr, 8_000_000):
-        bad = r[r0:r0 + 8_000_000] == 78
-        has = bad.any(1)
-        q = bad.to(torch.uint8).argmax(1).to(torch.int64)
-        full = rl - k + 1
-        with_n = torch.clamp(q - k + 1, min=0) + torch.clamp(rl - q - k, min=0)
-        n_valid += int(torch.where(has, with_n, torch.full_like(with_n, full)).sum())
+    if n_valid is None:          # (n_valid given: the reads themselves are gone -- released after dskgpu_encode_reads)
+        n_valid = valid_windows(reads, nr, rl, k)
     assert n_valid == st["n_kmers"], (n_valid, st["n_kmers"])
     return {"rows_checked": int(n), "saturated_histogram_rows": sat}
 

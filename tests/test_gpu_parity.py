@@ -636,6 +636,41 @@ def test_push_reads_staging_and_reserve(oracle, dev):
         assert st["n_kmers"] == ref.total and (rows[:, 0] == ref.lo[keep]).all() and (ab == ref.ab[keep]).all(), mode
 
 
+def test_encode_reads_lets_go_of_the_bytes(oracle, dev):
+    """dskgpu_encode_reads: the reads become their 2-bit form once and the caller's buffer is never read again -- overwritten here
+    with other reads right after the call; single pass, several passes (record-based level 0) and the multi-GPU sender all start from
+    the kept encoding.  Per-bank modes need the bytes: DSKGPU_E_STATE.  New reads start a new read set."""
+    from dsk_amd import KmerCounter, synth
+    from dsk_amd.engine import DskGpuError
+    from dsk_amd.multi import scatter_records
+    reads = synth.make_reads(synth.make_genome(300_000, dev), 100_000, 150)
+    other = synth.make_reads(synth.make_genome(300_000, dev, seed=99), 100_000, 150, seed=100)
+    ref = oracle.count(reads.cpu().numpy(), 31)
+    buf = reads.clone()
+    for mkeys in (0, 2):
+        with KmerCounter(kmer_size=31, abundance_min=1, max_pass_mkeys=mkeys) as kc:
+            buf.copy_(reads); torch.cuda.synchronize()
+            kc.set_reads_device(buf.data_ptr(), buf.numel())
+            kc.encode_reads()
+            buf.copy_(other); torch.cuda.synchronize()            # the bytes are gone
+            for _ in range(2):
+                kc.count()
+                st = kc.stats()
+                assert (st["n_kmers"], st["n_distinct"]) == (ref.total, ref.distinct) and (kc.histogram() == ref.histogram(10000)).all()
+                assert (kc.rows()[0][:, 0] == ref.lo).all()
+            send, counts = scatter_records(kc, None, dev)           # the sender too
+            assert kc.mg_sent_kmers() == [ref.total]
+            kc.set_reads_device(buf.data_ptr(), buf.numel())        # a new read set: the other reads
+            kc.count()
+            assert kc.stats()["n_distinct"] != ref.distinct
+    with KmerCounter(kmer_size=31, abundance_min=1, solidity_kind="min") as kc:
+        kc.set_reads_device(reads.data_ptr(), reads.numel())
+        kc.set_banks([reads.numel() // 2 // 151 * 151, reads.numel()])
+        kc.encode_reads()
+        with pytest.raises(DskGpuError):
+            kc.count()
+
+
 def test_determinism_and_reuse(dev):
     from dsk_amd import synth, KmerCounter
     g = synth.make_genome(200_000, dev)

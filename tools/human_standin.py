@@ -9,7 +9,7 @@ sys.path.insert(0, ".")
 from dsk_amd import KmerCounter, synth
 
 
-from tests.full_size import device_invariants      # noqa: E402
+from tests.full_size import device_invariants, valid_windows      # noqa: E402
 
 
 def main():
@@ -27,8 +27,20 @@ def main():
     t_gen = time.perf_counter() - t0
     out = {"workload": f"c5_human30x stand-in: {nr} reads x {rl} bp of a repeat-rich 3 Gbp genome (1 % one 300 bp family, 4 tandem arrays, 0.2 % poly-A reads)",
            "kmer_size": k, "generate_s": round(t_gen, 1)}
+    keep_ascii = len(sys.argv) > 5 and sys.argv[5] == "keep-ascii"          # (the round-4 way: the 90 GB of bytes stay in HBM during the count)
     with KmerCounter(kmer_size=k, abundance_min=amin, timing=True) as kc:
         kc.set_reads_device(reads.data_ptr(), reads.numel())
+        n_valid = None
+        if not keep_ascii:
+            # the reads are turned into their 2-bit form once (dskgpu_encode_reads: 0.375 B per base) and the bytes are given back: what
+            # DSK does with its bank -- read once per pass, nothing of it kept (README.md:126-130) -- and what decides how many sweeps
+            # over the reads the passes need (90 GB of bytes + 34 GB encoded left room for a third of the records)
+            n_valid = valid_windows(reads, nr, rl, k)
+            t0 = time.perf_counter(); kc.encode_reads(); out["encode_reads_s"] = round(time.perf_counter() - t0, 3)
+            del reads
+            reads = None
+            torch.cuda.empty_cache()
+        out["ascii_reads_resident_during_count"] = bool(keep_ascii)
         times = []
         for _ in range(steps + 1):                 # the first count also allocates every buffer
             t0 = time.perf_counter(); kc.count(); times.append(time.perf_counter() - t0)
@@ -40,7 +52,7 @@ def main():
         free_b, total_b = torch.cuda.mem_get_info()
         out["hbm_used_gb"] = round((total_b - free_b) * 1e-9, 1)
         if k <= 31 and amin == 2:
-            out["invariants"] = device_invariants(kc, st, hist, k, reads, nr, rl, dev)
+            out["invariants"] = device_invariants(kc, st, hist, k, reads, nr, rl, dev, n_valid=n_valid)
     print(json.dumps(out))
 
 
