@@ -187,6 +187,9 @@ def e2e_block(k, amin, budget_s=150.0):
     def run_dsk(path, extra=()):
         best, info = None, {}
         for _ in range(3):
+            for stale in (os.path.join(tmp, "o.h5"),):          # (a fresh output every time: truncating the previous run's 0.7 GB file is not part of a run)
+                if os.path.exists(stale):
+                    os.remove(stale)
             t0 = time.perf_counter()
             p = subprocess.run([dsk, "-file", path, "-kmer-size", str(k), "-abundance-min", str(amin), "-out", os.path.join(tmp, "o"), "-verbose", "1", *extra],
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT)

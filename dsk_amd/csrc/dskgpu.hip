@@ -180,7 +180,7 @@ struct dskgpu_ctx {
 
     // input
     DevBuf reads_own; u64 reads_len = 0;
-    void* pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_used[2] = {false, false};   // pinned H2D staging
+    void* pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_used[2] = {false, false}; int pin_next = 0;   // pinned H2D staging
     const uint8_t* d_reads = nullptr; u64 n_bytes = 0;
 
     DevBuf packed, inval;          // K1 output
@@ -2965,6 +2965,16 @@ int dskgpu_set_stream(dskgpu_ctx* ctx, void* hip_stream) {
     return DSKGPU_OK;
 }
 
+#define PIN_CHUNK ((size_t)32 << 20)
+static int ensure_pinned(dskgpu_ctx* ctx) {      // the two pinned staging buffers of dskgpu_push_reads (also set up by dskgpu_reserve_reads: off the first push's path)
+    if (ctx->pin[0] && ctx->pin[1]) return DSKGPU_OK;
+    for (int i = 0; i < 2; ++i) {
+        if (!ctx->pin[i]) CK(hipHostMalloc(&ctx->pin[i], PIN_CHUNK, hipHostMallocDefault));
+        if (!ctx->pin_ev[i]) CK(hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
+    }
+    return DSKGPU_OK;
+}
+
 int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
     if (!ctx || (!bytes && nbytes)) return DSKGPU_E_ARG;
     CK(hipSetDevice(ctx->cfg.device));
@@ -2981,15 +2991,10 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
     if (nbytes) {
         // pageable host memory -> two pinned staging buffers -> HBM: the CPU copy of one chunk
         // overlaps the DMA of the previous one (a direct pageable hipMemcpy reached 4.5 GB/s)
-        const size_t CH = (size_t)32 << 20;
-        if (!ctx->pin[0]) {
-            for (int i = 0; i < 2; ++i) {
-                CK(hipHostMalloc(&ctx->pin[i], CH, hipHostMallocDefault));
-                CK(hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
-            }
-        }
-        int slot = 0;
-        for (u64 off = 0; off < nbytes; off += CH, slot ^= 1) {
+        const size_t CH = PIN_CHUNK;
+        { const int e = ensure_pinned(ctx); if (e) return e; }
+        for (u64 off = 0; off < nbytes; off += CH, ctx->pin_next ^= 1) {
+            const int slot = ctx->pin_next;       // (alternates ACROSS calls too: the copy of this call's first piece overlaps the DMA of the last call's last one)
             const size_t len = (size_t)std::min<u64>(CH, nbytes - off);
             if (ctx->pin_used[slot]) CK(hipEventSynchronize(ctx->pin_ev[slot]));
             std::memcpy(ctx->pin[slot], bytes + off, len);
@@ -2999,7 +3004,9 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
         }
     }
     CK(hipMemsetAsync(dst + ctx->reads_len + nbytes, '\n', 1, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    // (no synchronisation here: the caller's bytes were copied to the pinned staging buffers above, and everything that reads the
+    //  device copy -- the count, a later growth of the buffer -- is ordered behind the DMA on the context's stream.  A bank that
+    //  hands over a few MB per call keeps the link busy this way instead of paying a round trip per call.)
     ctx->reads_len += nbytes + 1;
     ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->enc_keep = false; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->mw_v3_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
     return DSKGPU_OK;
@@ -3008,6 +3015,7 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
 int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes) {
     if (!ctx) return DSKGPU_E_ARG;
     CK(hipSetDevice(ctx->cfg.device));
+    { const int e = ensure_pinned(ctx); if (e) return e; }
     if (nbytes + 1 <= ctx->reads_own.cap) return DSKGPU_OK;
     DevBuf nb;
     CK(nb.ensure(nbytes + 1));

@@ -56,6 +56,11 @@ struct RecordParser {
         if (out.size() >= chunkBytes) flush();
     }
     void append_seq(const char* p, size_t n) {
+        // the rule: a sequence line holds no blank and no CR and is copied as it is (one vectorised scan + memcpy: the per-character
+        // loop below kept 32 parser threads at 12 GB/s on a 3 GB FASTQ file -- longer than the device runtime takes to start)
+        unsigned char any = 0;
+        for (size_t i = 0; i < n; ++i) any |= (unsigned char)((unsigned char)p[i] <= (unsigned char)' ');
+        if (!any) { out.append(p, n); seqlen += n; return; }
         for (size_t i = 0; i < n; ++i) { char c = p[i]; if (c != '\r' && c != ' ' && c != '\t') { out.push_back(c); ++seqlen; } }
     }
     void on_line(const char* p, size_t n) {
@@ -72,7 +77,8 @@ struct RecordParser {
                 if (n && p[0] == '+') { st = QUAL; qleft = seqlen; if (qleft == 0) { end_record(); st = HEADER; } return; }
                 append_seq(p, n); return;
             case QUAL: {
-                size_t q = 0; for (size_t i = 0; i < n; ++i) if (p[i] != '\r') ++q;
+                size_t cr = 0; for (size_t i = 0; i < n; ++i) cr += (size_t)(p[i] == '\r');      // (a counting loop the compiler vectorises)
+                const size_t q = n - cr;
                 if (q >= qleft) { end_record(); st = HEADER; } else qleft -= q;
                 return;
             }

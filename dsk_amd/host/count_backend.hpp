@@ -52,4 +52,9 @@ ICountBackend* createBackend();               // throws dsk::Exception when none
 
 ICountBackend* createGpuBackend();            // gpu_backend.cpp (links libdskgpu.so)
 
+// The `dsk` executable leaves with _exit() right after the run and says so here.  (What a backend may do with that is its business; the GPU
+// backend still gives its buffers back -- see ~GpuBackend.)
+void setProcessExitsAfterRun(bool yes);
+bool processExitsAfterRun();
+
 }  // namespace dsk

@@ -28,6 +28,7 @@ int main(int argc, char* argv[]) {
         }
     }
     dsk::setBackendFactory(dsk::createGpuBackend);   // the only backend this binary knows: the HIP engine
+    dsk::setProcessExitsAfterRun(true);              // (this process ends with _exit below: no buffer-by-buffer teardown of the engine)
     try {
         dsk::DSK().run(argc, argv);
     } catch (dsk::OptionFailure& e) {

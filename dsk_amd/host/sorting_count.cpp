@@ -168,14 +168,20 @@ void SortingCountBase::execute() {
         { std::lock_guard<std::mutex> lk(startup.mu); startup.done = true; }
         startup.cv.notify_all();
     });
+    // (r05, measured and dropped: keeping what the parser threads produce before the engine is up in a host-side list -- so that the parse
+    //  hides behind the device start-up -- costs a copy of every chunk under the sink's mutex: 0.1 s MORE on the 3 GB FASTQ file.)
     bool pushing = false;
     auto push = [&](const char* d, size_t n) { if (!pushing) { startup.wait_push(); pushing = true; } be->push(d, n); nbytes += n; };      // (callers serialise the sink)
+    // chunk handed to the sink: a parser thread fills its own buffer of this size, so 32 threads first-touch 32 of them (64 MB chunks: 2 GB
+    // of fresh pages for a 1.5 GB stream); small chunks stop the threads early while the engine starts up.  DSK_CHUNK_MB: experiments.
+    size_t chunk_bytes = (size_t)8 << 20;        // (measured on the 3 GB FASTQ file, time from "engine up" to "all reads on the device": 8 MB 0.09 s, 16 MB 0.11, 32 MB 0.17, 64 MB 0.13)
+    if (const char* e = getenv("DSK_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, atoi(e)) << 20;
     uint64_t nseq = 0;
     std::vector<IBank*> subs = bank_->banks();   // one bank per comma-separated input (README.md:52-58)
     const bool per_bank = cfg.solidity_kind != 0 || cfg.histo2d;
     if (per_bank || subs.size() < 2) {           // bank boundaries matter: stream the banks in order
         for (IBank* sub : subs) {
-            nseq += sub->stream((size_t)64 << 20, push);
+            nseq += sub->stream(chunk_bytes, push);
             if (!pushing) { startup.wait_push(); pushing = true; }
             be->nextBank();
         }
@@ -187,7 +193,7 @@ void SortingCountBase::execute() {
                 const size_t i = next.fetch_add(1);
                 if (i >= subs.size()) return;
                 try {
-                    seqs += subs[i]->stream((size_t)32 << 20, [&](const char* d, size_t n) { std::lock_guard<std::mutex> g(mu); push(d, n); });
+                    seqs += subs[i]->stream(chunk_bytes, [&](const char* d, size_t n) { std::lock_guard<std::mutex> g(mu); push(d, n); });
                 } catch (Exception& e) { std::lock_guard<std::mutex> g(mu); if (err.empty()) err = e.getMessage(); next = subs.size(); }
                 catch (std::exception& e) { std::lock_guard<std::mutex> g(mu); if (err.empty()) err = e.what(); next = subs.size(); }
                 catch (...) { std::lock_guard<std::mutex> g(mu); if (err.empty()) err = "unknown failure while reading the input"; next = subs.size(); }
