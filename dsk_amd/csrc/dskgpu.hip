@@ -29,6 +29,13 @@ thread_local std::string g_create_err;
 // fill: 1.70 / 1.79), the same virtual address changes class after a free + malloc, and the kernels' "two speeds" (level 1: 3.8 /
 // 4.5 ms) follow (tools/micro/write_place.hip).  With DSKGPU_PLACE = K > 1 every allocation of >= 256 MB is the best of up to K
 // candidates, each timed with that store pattern (one-off: ~0.1 s per candidate of 10 GB); the others are freed.
+// the row sort's device scalars (matrix length, two work counters [, the ties flag]) set from KERNEL ARGUMENTS: the sorts are called many
+// times back to back from host loops, and an asynchronous copy from one host-side array would only be correct as long as the runtime
+// stages pageable copies synchronously
+__global__ void k_set_rs_scalars(u32* __restrict__ sc4, u32 len, u32 nwords) {
+    if (threadIdx.x == 0) sc4[0] = len;
+    else if (threadIdx.x < nwords) sc4[threadIdx.x] = 0u;
+}
 __global__ __launch_bounds__(1024) void k_place_probe(unsigned long long* __restrict__ out, unsigned long long n) {
     const unsigned long long per_block = n / gridDim.x, per_stream = per_block / 512;
     unsigned long long* base = out + (unsigned long long)blockIdx.x * per_block;
@@ -237,7 +244,6 @@ struct dskgpu_ctx {
     // records handed to dskgpu_mg_count: the level-1 scatter reads them directly (SRC 2); expanded lazily for the exact path
     const u64* rec_src = nullptr; u64 rec_n = 0; u64 rec_nch = 0, rec_rpc = 0; bool rec_expanded = false;
     u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0, h_ext = 0; u64 h_nvalid = 0; bool have_nvalid = false;
-    u32 h_rs[4] = {0, 0, 0, 0};    // host source of the row sort's device scalars (matrix length, list length, work counter, ties seen)
     u64* fb_src_k = nullptr; u32* fb_src_v = nullptr; u64* fb_dst_k = nullptr; u32* fb_dst_v = nullptr;   // one-word row sort: where the full-width fallback finds a permutation of the rows / leaves them sorted
     bool sentinel_ok = true;       // the all-ones key is not the mixed form of a canonical k-mer of this k (checked at create)
     bool opt1_off = false;         // same for the histogram-free level-1 scatter (block-owned slices)
@@ -684,8 +690,7 @@ int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int
     u32* sub = matrix + M + 2;
     u32* biglist = sub + nsubw;
     u32* sc = ctx->scalars.as<u32>();
-    ctx->h_rs[0] = (u32)M; ctx->h_rs[1] = 0; ctx->h_rs[2] = 0; ctx->h_rs[3] = 0;
-    CK(hipMemcpyAsync(sc + SC_RSLEN, ctx->h_rs, reset_flags ? 16 : 12, hipMemcpyHostToDevice, ctx->stream));      // (length, two work counters [, ties seen])
+    hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, (u32)M, reset_flags ? 4u : 3u);      // (length, two work counters [, ties seen])
     CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
     if (reset_flags) { CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream)); CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream)); }
     const size_t ldsA = RsLds<RS_ABINS, RS_TILE>::bytes;
@@ -741,8 +746,7 @@ int msd_sort_rows2(dskgpu_ctx* ctx, Rows2 k, Rows2 t, u64 n, int total, bool res
     u32* sub = matrix + M + 2;
     u32* biglist = sub + nsubw;
     u32* sc = ctx->scalars.as<u32>();
-    ctx->h_rs[0] = (u32)M; ctx->h_rs[1] = 0; ctx->h_rs[2] = 0; ctx->h_rs[3] = 0;
-    CK(hipMemcpyAsync(sc + SC_RSLEN, ctx->h_rs, 16, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, (u32)M, reset_flags ? 4u : 3u);
     CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
     if (reset_flags) { CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream)); CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream)); }
     const size_t ldsA = Rs2Lds<RS_ABINS, RS2_TILE>::bytes;
@@ -847,8 +851,7 @@ int sort_rows2_big(dskgpu_ctx* ctx, u64 n) {
     CK(ctx->mat2.ensure((M + 2) * 4));
     u32* matrix = ctx->mat2.as<u32>();
     u32* sc = ctx->scalars.as<u32>();
-    ctx->h_rs[0] = (u32)M; ctx->h_rs[1] = 0; ctx->h_rs[2] = 0; ctx->h_rs[3] = 0;
-    CK(hipMemcpyAsync(sc + SC_RSLEN, ctx->h_rs, 16, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, (u32)M, 4u);
     CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream));
     CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
     CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream));
@@ -983,8 +986,7 @@ int sort_rows_big(dskgpu_ctx* ctx, u64 n) {
     CK(ctx->mat2.ensure((M + 2) * 4));
     u32* matrix = ctx->mat2.as<u32>();
     u32* sc = ctx->scalars.as<u32>();
-    ctx->h_rs[0] = (u32)M; ctx->h_rs[1] = 0; ctx->h_rs[2] = 0; ctx->h_rs[3] = 0;
-    CK(hipMemcpyAsync(sc + SC_RSLEN, ctx->h_rs, 16, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, (u32)M, 4u);
     CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream));
     CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
     CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream));
@@ -1597,7 +1599,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             // reads: alike), so only that slice has to have arrived.
             const Key* d_keys_s = d_keys_in;             // the key array the sample kernels read
             double smp_density = 1.0;                    // records: real keys per slot of the sample array (a level-1 tile is full, a sample tile is not)
-            bool rec_sample_ok = true;
+            bool rec_sample_ok = ctx->sentinel_ok;       // (the sample array is padded with the all-ones key, which the key-array kernels skip: only when it is no k-mer of this k)
             u64 rec_units = 0;
             if constexpr (W <= 2) {
               if (from_rec && !ctx->tune.no_sample && !uniform1) {
@@ -3036,8 +3038,6 @@ int dskgpu_reserve_work(dskgpu_ctx* ctx, uint64_t nbytes) {
     const u64 n = std::min<u64>(nbytes + 1, max_keys + max_keys / 4);
     const u64 key = 8ull * (u64)ctx->W;
     const u64 nwords = (nbytes + 31) / 32;
-    CK(ctx->packed.ensure((nwords + 1) * 8));
-    CK(ctx->inval.ensure((nwords + 1) * 4));
     const u64 target = target_keys(ctx->W);
     const u64 F = n / target + 2, cap = opt_groups(ctx->W) * (8u / (u64)ctx->W);
     const u64 regions = F + (ctx->W == 1 ? F / 8 + 4096 : 0);
@@ -3047,9 +3047,11 @@ int dskgpu_reserve_work(dskgpu_ctx* ctx, uint64_t nbytes) {
         const u64 want = (nwords + 1) * 12 + std::max<u64>((n + n / 8 + (1u << 20)) * key, ctx->W == 1 ? F * cap * 4 : 0) + (regions * cap + (1u << 16)) * key;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const u64 have = ctx->packed.cap + ctx->inval.cap + ctx->bufA.cap + ctx->bufB.cap;
-            if (want > have && want - have > (u64)free_b * 6 / 10) return fail(ctx, DSKGPU_E_NOMEM, "dskgpu_reserve_work: the reservation exceeds 60 % of the free device memory (not reserved; dskgpu_count sizes its own buffers)");
+            if (want > have && want - have > (u64)free_b * 6 / 10) return fail(ctx, DSKGPU_NOT_RESERVED, "dskgpu_reserve_work: the reservation exceeds 60 % of the free device memory (nothing was reserved; dskgpu_count sizes its own buffers)");
         }
     }
+    CK(ctx->packed.ensure((nwords + 1) * 8));
+    CK(ctx->inval.ensure((nwords + 1) * 4));
     CK(ctx->bufA.ensure(std::max<u64>((n + n / 8 + (1u << 20)) * key, ctx->W == 1 ? F * cap * 4 : 0)));
     CK(ctx->bufB.ensure((regions * cap + (1u << 16)) * key));
     if (ctx->W > 1) CK(ctx->abund2.ensure((F * cap + (1u << 16)) * 4));

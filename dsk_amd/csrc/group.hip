@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -142,6 +143,12 @@ struct dskgpu_group {
     // their stream synchronisation returns, the step fails on every rank with a message -- and the group, whose communicators
     // are gone, refuses further counts (create a new one).
     std::atomic<int> comms_aborted{0};
+    // comm_mu[r] is held by rank r's thread while it is inside RCCL host calls on comm[r] (GroupStart .. GroupEnd), after it has seen
+    // comms_aborted == 0 under the lock.  abort_comms TRIES each lock: a communicator whose rank is inside RCCL is aborted under its
+    // feet -- the use ncclCommAbort exists for -- and one whose rank is outside stays locked for the abort, so that rank cannot
+    // enter RCCL with a handle that is being freed.  The handles are never written after creation; group destroy skips
+    // ncclCommDestroy for aborted ones.
+    std::vector<std::unique_ptr<std::mutex>> comm_mu;
 };
 
 namespace {
@@ -150,8 +157,20 @@ int group_fail(dskgpu_group* g, int code, const std::string& msg) { g->err = msg
 
 void abort_comms(dskgpu_group* g) {
     if (!g->use_rccl || g->comms_aborted.exchange(1)) return;
-    for (auto& c : g->comm) if (c) { (void)g_rccl.CommAbort(c); c = nullptr; }
+    for (size_t r = 0; r < g->comm.size(); ++r) {
+        if (!g->comm[r]) continue;
+        const bool got = g->comm_mu[r]->try_lock();
+        (void)g_rccl.CommAbort(g->comm[r]);
+        if (got) g->comm_mu[r]->unlock();
+    }
 }
+// rank r may use its communicator: lock held on return (release with comm_leave); false = the communicators were aborted
+bool comm_enter(dskgpu_group* g, uint32_t r) {
+    g->comm_mu[r]->lock();
+    if (g->comms_aborted.load()) { g->comm_mu[r]->unlock(); return false; }
+    return true;
+}
+void comm_leave(dskgpu_group* g, uint32_t r) { g->comm_mu[r]->unlock(); }
 
 // one rank of one sharded count
 void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
@@ -224,6 +243,7 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
                     if (g->rc[r] != DSKGPU_OK || g->comms_aborted.load()) { abort_comms(g); break; }      // (the peers' posted receives end with an error instead of waiting for this rank)
                     RcclApi& a = g_rccl;
                     (void)hipStreamWaitEvent(cs, g->ev_sent[r][sl], 0);
+                    if (!comm_enter(g, r)) { fail(DSKGPU_E_DEVICE, "the exchange was aborted: another rank failed"); break; }
                     ncclResult_t e = a.GroupStart();
                     uint64_t so = sbase[sl], ro = rbase[sl];
                     for (uint32_t p = 0; p < n && e == ncclSuccess; ++p) {
@@ -233,6 +253,7 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
                         so += ws; ro += wr;
                     }
                     const ncclResult_t e2 = a.GroupEnd();
+                    comm_leave(g, r);
                     if (e == ncclSuccess) e = e2;
                     if (e != ncclSuccess) { fail(DSKGPU_E_DEVICE, std::string("RCCL exchange: ") + a.GetErrorString(e)); abort_comms(g); break; }
                 } else {
@@ -304,14 +325,18 @@ void rank_body(dskgpu_group* g, uint32_t r, Barrier* bar) {
     uint64_t* rb = static_cast<uint64_t*>(g->recv[r].p);
     if (g->use_rccl) {
         RcclApi& a = g_rccl;
-        ncclResult_t e = a.GroupStart();
-        for (uint32_t p = 0; p < n && e == ncclSuccess; ++p) {
-            if (g->counts[r][p]) e = a.Send(sb + soff[p], g->counts[r][p], ncclUint64, (int)p, g->comm[r], g->stream[r]);
-            if (e == ncclSuccess && g->counts[p][r]) e = a.Recv(rb + roff[p], g->counts[p][r], ncclUint64, (int)p, g->comm[r], g->stream[r]);
+        if (!comm_enter(g, r)) fail(DSKGPU_E_DEVICE, "the exchange was aborted: another rank failed");
+        else {
+            ncclResult_t e = a.GroupStart();
+            for (uint32_t p = 0; p < n && e == ncclSuccess; ++p) {
+                if (g->counts[r][p]) e = a.Send(sb + soff[p], g->counts[r][p], ncclUint64, (int)p, g->comm[r], g->stream[r]);
+                if (e == ncclSuccess && g->counts[p][r]) e = a.Recv(rb + roff[p], g->counts[p][r], ncclUint64, (int)p, g->comm[r], g->stream[r]);
+            }
+            const ncclResult_t e2 = a.GroupEnd();
+            comm_leave(g, r);
+            if (e == ncclSuccess) e = e2;
+            if (e != ncclSuccess) { fail(DSKGPU_E_DEVICE, std::string("RCCL exchange: ") + a.GetErrorString(e)); abort_comms(g); }
         }
-        const ncclResult_t e2 = a.GroupEnd();
-        if (e == ncclSuccess) e = e2;
-        if (e != ncclSuccess) { fail(DSKGPU_E_DEVICE, std::string("RCCL exchange: ") + a.GetErrorString(e)); abort_comms(g); }
     } else {
         for (uint32_t s = 0; s < n; ++s) {
             const uint64_t w = g->counts[s][r];
@@ -364,6 +389,7 @@ int dskgpu_group_create(const dskgpu_config* cfg, const int32_t* devices, uint32
     auto bail = [&](int code, const std::string& msg) { g_group_create_err = msg; dskgpu_group_destroy(g); return code; };
     if (g->use_rccl && !distinct) return bail(DSKGPU_E_ARG, "transport rccl needs one device per rank");
     g->ctx.assign(n_ranks, nullptr); g->stream.assign(n_ranks, nullptr); g->comm.assign(n_ranks, nullptr);
+    for (uint32_t r = 0; r < n_ranks; ++r) g->comm_mu.emplace_back(new std::mutex());
     g->send.resize(n_ranks); g->recv.resize(n_ranks);
     g->counts.assign(n_ranks, std::vector<uint64_t>(n_ranks, 0));
     g->kmers.assign(n_ranks, std::vector<uint64_t>(n_ranks, 0));
@@ -417,7 +443,7 @@ void dskgpu_group_destroy(dskgpu_group* g) {
     for (uint32_t r = 0; r < g->ctx.size(); ++r) {
         if (r < g->dev.size()) (void)hipSetDevice(g->dev[r]);
         if (r < g->stream.size() && g->stream[r]) (void)hipStreamSynchronize(g->stream[r]);
-        if (r < g->comm.size() && g->comm[r]) (void)g_rccl.CommDestroy(g->comm[r]);
+        if (r < g->comm.size() && g->comm[r] && !g->comms_aborted.load()) (void)g_rccl.CommDestroy(g->comm[r]);      // (an aborted communicator is already freed)
         if (g->ctx[r]) { (void)dskgpu_set_stream(g->ctx[r], nullptr); dskgpu_destroy(g->ctx[r]); }
         if (r < g->send.size()) { g->send[r].release(); g->recv[r].release(); }
         if (r < g->stream.size() && g->stream[r]) (void)hipStreamDestroy(g->stream[r]);

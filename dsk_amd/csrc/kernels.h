@@ -707,8 +707,13 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
             if (d.begin < d.end) {
                 Raw raw = load_raw(d.begin);
                 if (OPT) {          // as many (dump-zone) stores behind the first loads as a tile's write-out issues behind the prefetched ones:
-#pragma unroll                      // the loop is then entered with the same in-flight picture on both edges and the wait at its top is exact
-                    for (int u = 0; u < 4 * ((KPT + 3) / 4); ++u) out[(MODE == 4 ? o1.obase0 : 0ull) + (u64)(o1.dump + u * SC_NT + threadIdx.x)] = (u64)threadIdx.x;
+                    // the loop is then entered with the same in-flight picture on both edges and the wait at its top is exact.
+                    // (The base is made opaque per chunk: left to itself the compiler hoisted all 16 store addresses out of the CHUNK loop, kept
+                    //  them in 32 VGPRs across the whole launch and spilled three of them -- profiles/r05_resource_usage.md.)
+                    u64* dz = out + (MODE == 4 ? o1.obase0 : 0ull) + (u64)(o1.dump + threadIdx.x);
+                    asm volatile("" : "+v"(dz));
+#pragma unroll
+                    for (int u = 0; u < 4 * ((KPT + 3) / 4); ++u) dz[u * SC_NT] = (u64)threadIdx.x;
                 }
                 for (u64 t0 = d.begin; t0 < d.end; t0 += step) {
                     const bool live = t0 + wlane < d.end;

@@ -281,8 +281,13 @@ class KmerCounter:
     def reserve_reads(self, nbytes: int) -> None:
         self._ck(self._lib.dskgpu_reserve_reads(self._h, nbytes))
 
-    def reserve_work(self, nbytes: int) -> None:
-        self._ck(self._lib.dskgpu_reserve_work(self._h, nbytes))
+    def reserve_work(self, nbytes: int) -> bool:
+        """-> False when the engine declined (DSKGPU_NOT_RESERVED: the request exceeds 60 % of the free HBM; count() sizes its own buffers)."""
+        rc = self._lib.dskgpu_reserve_work(self._h, nbytes)
+        if rc == 1:
+            return False
+        self._ck(rc)
+        return True
 
     def set_reads_device(self, ptr: int, nbytes: int) -> None:
         self._ck(self._lib.dskgpu_set_reads_device(self._h, C.c_void_p(ptr), nbytes))

@@ -62,7 +62,7 @@ public:
     void prepare(uint64_t n) override {
         // optional by contract: a reservation that does not fit (its sizes are upper bounds from file-size hints) is not an error --
         // dskgpu_count sizes its buffers from the real k-mer count, in several passes if need be
-        auto soft = [&](int rc) { return rc == DSKGPU_E_NOMEM ? DSKGPU_OK : rc; };
+        auto soft = [&](int rc) { return rc == DSKGPU_NOT_RESERVED ? DSKGPU_OK : rc; };      // (a genuine out-of-memory error of an allocation stays an error)
         if (!grp_) { ck(soft(dskgpu_reserve_work(ctx_, n))); return; }
         const uint32_t N = dskgpu_group_size(grp_);
         for (uint32_t r = 0; r < N; ++r) ckr(r, soft(dskgpu_reserve_work(dskgpu_group_ctx(grp_, r), n / N + n / (8 * N) + 4096)));

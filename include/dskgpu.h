@@ -38,6 +38,8 @@ extern "C" {
 #define DSKGPU_E_NOMEM (-3)     /* device allocation failed                */
 #define DSKGPU_E_STATE (-4)     /* call out of order                       */
 #define DSKGPU_E_OVERFLOW (-5)  /* internal table overflow after retries   */
+#define DSKGPU_NOT_RESERVED 1   /* dskgpu_reserve_work only: nothing was reserved (the request exceeds 60 % of the free HBM) -- not an
+                                   error: dskgpu_count sizes its own buffers, in several passes if need be; nothing was allocated */
 
 typedef struct dskgpu_ctx dskgpu_ctx;
 
@@ -104,7 +106,7 @@ int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes);
  * hipMalloc on a 10 M-read input) instead of inside the first dskgpu_count.  May run on another host thread WHILE the reads
  * are pushed -- it touches nothing dskgpu_push_reads / dskgpu_reserve_reads use -- but must have returned before dskgpu_count.
  * Stands where SortingCountAlgorithm's configure step sizes its passes and partitions before execute() fills them. */
-int dskgpu_reserve_work(dskgpu_ctx* ctx, uint64_t nbytes);
+int dskgpu_reserve_work(dskgpu_ctx* ctx, uint64_t nbytes);   /* DSKGPU_OK, DSKGPU_NOT_RESERVED (a soft refusal, see above), or an error */
 /* Use a read stream already resident in HBM (caller keeps ownership and must
  * keep it alive until dskgpu_count returns).  Replaces any pushed reads.  The call waits for all device work this
  * process has submitted so far (hipDeviceSynchronize): bytes that another stream is still writing when it is made
