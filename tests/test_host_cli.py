@@ -35,6 +35,74 @@ def h5_histo(h5, cwd):
     return subprocess.check_output(cmd, shell=True, cwd=cwd).decode()
 
 
+def make_messy_inputs(tmp, n_reads, genome_len, seed=20251003):
+    """What real sequencer output has and the synthetic workloads lack, as three files in `tmp` -- messy.fastq, messy.fastq.gz (8
+    concatenated gzip members: what `cat a.gz b.gz` leaves) and messy.fa (every record on two sequence lines): read lengths from 36 to
+    251, long headers with blanks, quality lines that begin with '@', '>' or '+', CRLF records among LF ones, lower-case reads, runs of N.
+    -> the clean read stream (np.uint8: the sequences separated by one newline)."""
+    import gzip
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=genome_len).tobytes()
+    lower = genome.lower()
+    qual_pool = bytes(rng.integers(33, 127, size=1 << 16, dtype=np.uint8))
+    hdr_pool = [("@SRR%07d.%d %d:N:0:ATCACG+TTAGGC length=%d  " % (rng.integers(1e6), i, i, 150)).encode() + b"x" * int(rng.integers(0, 90)) for i in range(997)]
+    starts = rng.integers(0, len(genome) - 260, size=n_reads)
+    lens = rng.integers(36, 252, size=n_reads)
+    kinds = rng.integers(0, 100, size=n_reads)
+    qoff = rng.integers(0, len(qual_pool) - 260, size=n_reads)
+    fq, fa, seqs = [], [], []
+    for i in range(n_reads):
+        s, ln, kd = int(starts[i]), int(lens[i]), int(kinds[i])
+        seq = (lower if kd < 7 else genome)[s: s + ln]                     # 7 % lower-case reads
+        if kd in (7, 8):                                                    # 2 %: a run of N inside
+            seq = seq[: ln // 3] + b"N" * (1 + kd) + seq[ln // 3 + 1 + kd:]
+        q = qual_pool[int(qoff[i]): int(qoff[i]) + ln]
+        if kd in (9, 10, 11):                                               # 3 %: quality line starting with a record marker
+            q = (b"@", b">", b"+")[kd - 9] + q[1:]
+        eol = b"\r\n" if kd >= 90 else b"\n"                              # 10 % CRLF records
+        fq.append(hdr_pool[i % 997] + eol + seq + eol + b"+" + eol + q + eol)
+        fa.append(b">" + hdr_pool[i % 997][1:] + eol + seq[: ln // 2] + eol + seq[ln // 2:] + eol)
+        seqs.append(seq)
+    clean = np.frombuffer(b"\n".join(seqs) + b"\n", dtype=np.uint8)
+    with open(os.path.join(tmp, "messy.fastq"), "wb") as f:
+        f.write(b"".join(fq))
+    with open(os.path.join(tmp, "messy.fastq.gz"), "wb") as f:
+        per = (n_reads + 7) // 8
+        for m in range(8):
+            f.write(gzip.compress(b"".join(fq[m * per: (m + 1) * per]), compresslevel=1))
+    with open(os.path.join(tmp, "messy.fa"), "wb") as f:
+        f.write(b"".join(fa))
+    return clean
+
+
+def run_messy_case(dsk, tmp, n_reads, want, extra_env=None):
+    """dsk on the three messy files: sequences, k-mer totals and histogram must be `want` = (n_kmers, n_distinct, n_solid, histogram)."""
+    import re
+    want_histo = "".join(f"{i}\t{int(want[3][i])}\n" for i in range(1, 10001))
+    for name in ("messy.fastq", "messy.fastq.gz", "messy.fa"):
+        r = subprocess.run([dsk, "-file", name, "-kmer-size", "31", "-abundance-min", "3", "-out", "m", "-verbose", "1"], cwd=tmp,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **(extra_env or {})))
+        assert r.returncode == 0, (name, r.stderr.decode()[-1500:])
+        info = r.stdout.decode()
+        got = tuple(int(re.search(key + r"\s*:\s*(\d+)", info).group(1)) for key in ("nb_sequences", "kmers_nb_valid", "kmers_nb_distinct", "kmers_nb_solid"))
+        assert got == (n_reads, want[0], want[1], want[2]), (name, got, want[:3])
+        assert h5_histo("m.h5", tmp) == want_histo, name
+        os.remove(os.path.join(tmp, "m.h5"))
+
+
+def test_messy_fastq_fasta_and_multi_member_gzip(bins, tmp_path, oracle):
+    """The parser on sequencer-like input (see make_messy_inputs), serial and with the file cut into record-aligned ranges for several
+    threads (a quality line that starts with '@' must not be taken for a record start), against the oracle on the clean stream."""
+    tmp = str(tmp_path)
+    n_reads = 25_000
+    clean = make_messy_inputs(tmp, n_reads, 60_000)
+    ref = oracle.count(clean, 31)
+    want = (ref.total, ref.distinct, int((ref.ab >= 3).sum()), ref.histogram(10000))
+    run_messy_case(bins["dsk"], tmp, n_reads, want)
+    run_messy_case(bins["dsk"], tmp, n_reads, want, {"DSK_PARSE_MIN_BYTES": "1", "DSK_CHUNK_MB": "1"})
+
+
 def run_six_cases(dsk, dsk2ascii, tmp):
     def run(*args, **kw):
         return subprocess.run(list(args), cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, **kw)
