@@ -58,7 +58,9 @@ struct RsLds {
 };
 
 // per-chunk histogram of the first digit -> matrix[bin * nch + chunk]
-__global__ __launch_bounds__(RS_NT) void k_rs_hist(const u64* __restrict__ v, u64 n, u32 chunk, u32 nch, u32* __restrict__ matrix, RsSpec sp) {
+// (c0: first matrix column of this launch -- the rows counted here are chunks c0, c0 + 1, .. of a row set whose first c0 chunks come from
+//  somewhere else: k_rs_hist_sp below)
+__global__ __launch_bounds__(RS_NT) void k_rs_hist(const u64* __restrict__ v, u64 n, u32 chunk, u32 nch, u32* __restrict__ matrix, RsSpec sp, u32 c0 = 0) {
     __shared__ u32 lh[RS_ABINS];
     const u32 c = blockIdx.x;
     for (u32 b = threadIdx.x; b < RS_ABINS; b += RS_NT) lh[b] = 0;
@@ -73,6 +75,30 @@ __global__ __launch_bounds__(RS_NT) void k_rs_hist(const u64* __restrict__ v, u6
         for (int j = 0; j < 8; ++j) if (ok[j]) atomicAdd(&lh[rs_dig(x[j], sp.shA, sp.mA)], 1u);
     }
     __syncthreads();
+    for (u32 b = threadIdx.x; b < RS_ABINS; b += RS_NT) matrix[(u64)b * nch + c0 + c] = lh[b];
+}
+
+// ---- step A straight from the count kernels' output (one-word rows, a single pass): the solid rows of sub-partition q lie where
+// the count kernel left them -- ns_q = soff[q + 1] - soff[q] of them from key index base(q) on (q * cap for fixed-capacity regions,
+// fstart[q] with exact offsets), keys still MIXED, abundances at the same index of `ab`.  Until round 5 k_compact gathered them into a
+// dense array first (0.5 GB read + 0.5 GB written, 0.30 ms) that step A then read again; here step A reads the regions itself:
+// chunk c = the sub-partitions [c * qpc, (c + 1) * qpc), i.e. the logical rows [soff[c * qpc], soff[(c + 1) * qpc)).
+struct RsSparse { const u64* keys; const u32* ab; const u32* soff; const u32* fstart; u32 cap, F, qpc; };
+__device__ __forceinline__ u64 rs_sp_base(const RsSparse& s, u32 q) { return s.cap ? (u64)q * s.cap : (u64)s.fstart[q]; }
+
+// histogram of the first digit, one wave per sub-partition in turn -> matrix[bin * nch + chunk]
+__global__ __launch_bounds__(RS_NT) void k_rs_hist_sp(RsSparse s, u32 nch, u32* __restrict__ matrix, RsSpec sp) {
+    __shared__ u32 lh[RS_ABINS];
+    const u32 c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (u32 b = threadIdx.x; b < RS_ABINS; b += RS_NT) lh[b] = 0;
+    __syncthreads();
+    const u32 q0 = c * s.qpc, q1 = q0 + s.qpc < s.F ? q0 + s.qpc : s.F;
+    for (u32 q = q0 + wave; q < q1; q += RS_NT / 64) {
+        const u32 o = s.soff[q], ns = s.soff[q + 1] - o;
+        const u64 b = rs_sp_base(s, q);
+        for (u32 i = lane; i < ns; i += 64) atomicAdd(&lh[rs_dig(kunmix(s.keys[b + i]), sp.shA, sp.mA)], 1u);
+    }
+    __syncthreads();
     for (u32 b = threadIdx.x; b < RS_ABINS; b += RS_NT) matrix[(u64)b * nch + c] = lh[b];
 }
 
@@ -80,8 +106,23 @@ __global__ __launch_bounds__(RS_NT) void k_rs_hist(const u64* __restrict__ v, u6
 // L.cnt[0..P] zero on entry.  The next tile's rows are loaded before the current tile enters its LDS phases.
 // gdel (HUGE: row sets of 2^32 rows and more, step A slab by slab): a 64-bit offset per bin that is added to the (32-bit, slab-local)
 // output index -- the slab's rows of bin b then land behind the rows the earlier slabs put there (dskgpu.hip: sort_rows_huge).
-template <int P, int NT, bool HUGE = false>
-__device__ __forceinline__ void rs_scatter_range(const u64* __restrict__ v, const u32* __restrict__ ab, u64 beg, u64 end,
+// where a tile's rows come from: a dense (value, abundance) array, or the sparse regions of the count kernels (RsSparse; lsoff = the chunk's
+// slice of soff in LDS: the sub-partition of logical row r is found there by bisection, its key is un-mixed on the way in)
+struct RsDenseSrc {
+    const u64* v; const u32* ab;
+    __device__ __forceinline__ void get(u64 r, u64& k, u32& a) const { k = v[r]; a = ab[r]; }
+};
+struct RsSparseSrc {
+    RsSparse s; const u32* lsoff; u32 q0, nq;            // lsoff[x] = soff[q0 + x], x = 0 .. nq
+    __device__ __forceinline__ void get(u64 r, u64& k, u32& a) const {
+        u32 lo = 0, hi = nq;                              // largest x with lsoff[x] <= r (behind a run of empty sub-partitions: the one that holds r)
+        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if ((u64)lsoff[mid] <= r) lo = mid; else hi = mid; }
+        const u64 src = rs_sp_base(s, q0 + lo) + (r - (u64)lsoff[lo]);
+        k = kunmix(s.keys[src]); a = s.ab[src];
+    }
+};
+template <int P, int NT, bool HUGE = false, class Src = RsDenseSrc>
+__device__ __forceinline__ void rs_scatter_range(const Src src_rows, u64 beg, u64 end,
                                                  u64* __restrict__ ov, u32* __restrict__ oab, int sh, u32 m, const RsLds<P, NT * RS_RPT>& L,
                                                  const u64* __restrict__ gdel = nullptr) {
     constexpr u32 TILE = NT * RS_RPT;
@@ -91,7 +132,7 @@ __device__ __forceinline__ void rs_scatter_range(const u64* __restrict__ v, cons
         const u64 left = end - t0;
         const u32 n = left < (u64)TILE ? (u32)left : TILE;
 #pragma unroll
-        for (int j = 0; j < RS_RPT; ++j) { const u32 i = tid + (u32)j * NT; const u64 src = t0 + (i < n ? i : n - 1); k[j] = v[src]; a[j] = ab[src]; }
+        for (int j = 0; j < RS_RPT; ++j) { const u32 i = tid + (u32)j * NT; src_rows.get(t0 + (i < n ? i : n - 1), k[j], a[j]); }
     };
     if (beg < end) load(beg, kk, aa);
     for (u64 t0 = beg; t0 < end; t0 += TILE) {
@@ -139,16 +180,31 @@ __device__ __forceinline__ void rs_scatter_range(const u64* __restrict__ v, cons
 template <bool HUGE = false>
 __global__ __launch_bounds__(RS_NT) void k_rs_scatter(const u64* __restrict__ v, const u32* __restrict__ ab, u64 n, u32 chunk, u32 nch,
                                                       const u32* __restrict__ scanned, u64* __restrict__ ov, u32* __restrict__ oab, RsSpec sp,
-                                                      const u64* __restrict__ gdel) {
+                                                      const u64* __restrict__ gdel, u32 c0 = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RsLds<RS_ABINS, RS_TILE> L(smem);
     const u32 c = blockIdx.x;
-    for (u32 b = threadIdx.x; b < RS_ABINS; b += RS_NT) { L.cur[b] = scanned[(u64)b * nch + c]; L.cnt[b] = 0; }
+    for (u32 b = threadIdx.x; b < RS_ABINS; b += RS_NT) { L.cur[b] = scanned[(u64)b * nch + c0 + c]; L.cnt[b] = 0; }
     if (threadIdx.x == 0) L.cnt[RS_ABINS] = 0;
     lds_barrier();
     const u64 beg = (u64)c * chunk;
     const u64 end = beg + chunk < n ? beg + chunk : n;
-    rs_scatter_range<RS_ABINS, RS_NT, HUGE>(v, ab, beg, end, ov, oab, sp.shA, sp.mA, L, gdel);
+    rs_scatter_range<RS_ABINS, RS_NT, HUGE>(RsDenseSrc{v, ab}, beg, end, ov, oab, sp.shA, sp.mA, L, gdel);
+}
+// the same from the sparse regions: chunk c = sub-partitions [c * qpc, ..); its slice of soff sits behind the scatter's LDS
+#define RS_SP_MAXQ 1024                      // most sub-partitions per chunk (the LDS slice of soff; the bisection is <= 10 steps)
+__global__ __launch_bounds__(RS_NT) void k_rs_scatter_sp(RsSparse s, u32 nch, const u32* __restrict__ scanned, u64* __restrict__ ov, u32* __restrict__ oab, RsSpec sp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const RsLds<RS_ABINS, RS_TILE> L(smem);
+    u32* lsoff = reinterpret_cast<u32*>(smem + RsLds<RS_ABINS, RS_TILE>::bytes);
+    const u32 c = blockIdx.x;
+    const u32 q0 = c * s.qpc, q1 = q0 + s.qpc < s.F ? q0 + s.qpc : s.F, nq = q1 > q0 ? q1 - q0 : 0u;
+    for (u32 b = threadIdx.x; b < RS_ABINS; b += RS_NT) { L.cur[b] = scanned[(u64)b * nch + c]; L.cnt[b] = 0; }
+    for (u32 x = threadIdx.x; x <= nq; x += RS_NT) lsoff[x] = s.soff[q0 + x];
+    if (threadIdx.x == 0) L.cnt[RS_ABINS] = 0;
+    lds_barrier();
+    if (nq == 0) return;
+    rs_scatter_range<RS_ABINS, RS_NT, false, RsSparseSrc>(RsSparseSrc{s, lsoff, q0, nq}, (u64)lsoff[0], (u64)lsoff[nq], ov, oab, sp.shA, sp.mA, L);
 }
 
 // step B: a block splits one bucket at a time (rows [scanned[b * nch], scanned[(b + 1) * nch]) of v / ab) into 256 sub-buckets on
@@ -197,7 +253,7 @@ __global__ __launch_bounds__(RS_BNT) void k_rs_split(const u64* __restrict__ v, 
         __syncthreads();
         for (u32 d = tid; d <= BB; d += RS_BNT) L.cnt[d] = 0;
         __syncthreads();
-        rs_scatter_range<BB, RS_BNT>(v, ab, beg, end, ov, oab, sp.shB, sp.mB, L);
+        rs_scatter_range<BB, RS_BNT>(RsDenseSrc{v, ab}, beg, end, ov, oab, sp.shB, sp.mB, L);
     }
 }
 

@@ -1439,6 +1439,17 @@ def test_row_sort_paths_agree(oracle, dev, monkeypatch):
     monkeypatch.setenv("DSKGPU_LIB_ROWSORT", "1")
     for k, s in ((31, skew), (11, reads)):
         check_against_oracle(oracle, s, k, dev, amin=1)
+    monkeypatch.delenv("DSKGPU_LIB_ROWSORT")
+    # r05: the sort's first step reads the rows where the count kernel left them (default above); DSKGPU_SORT_COMPACT = the dense copy
+    # first (k_compact), as several passes and wide keys still do -- the same rows, through both region layouts (fixed-capacity regions
+    # and, with DSKGPU_NO_OPT2, exact offsets), with k-mers counted apart (the dense tail) and with the full-width fallback
+    for env in ({"DSKGPU_SORT_COMPACT": "1"}, {"DSKGPU_NO_OPT2": "1"}, {"DSKGPU_RS_HEAVY": "1000"}):
+        for name, val in env.items():
+            monkeypatch.setenv(name, val)
+        for k, s in ((31, reads), (31, skew), (11, reads)):
+            check_against_oracle(oracle, s, k, dev, amin=1)
+        for name in env:
+            monkeypatch.delenv(name)
 
 
 def test_two_word_row_sort_paths_agree(oracle, dev, monkeypatch):
