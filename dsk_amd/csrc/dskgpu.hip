@@ -124,7 +124,7 @@ struct Stage { const char* name; hipEvent_t ev; };
 
 }  // namespace
 
-// Test / experiment switches (DESIGN.md "Environment switches"): read ONCE from the environment when a context is
+// Test / experiment switches (NOTEBOOK.md "Environment switches"): read ONCE from the environment when a context is
 // created; none of them changes results.  The launch paths only look at this struct.
 struct Tuning {
     bool no_opt1 = false, no_opt2 = false;      // DSKGPU_NO_OPT1 / _NO_OPT2: exact histogram + scan path at level 1 / at both levels
@@ -518,7 +518,7 @@ struct Plan {
 #define CH2 65536u            // keys per level-2 chunk
 #define OPT_GROUPS 545u
 #define OPT_GROUPS2 1023u     // two-word keys: regions of 1023 groups of 64 B = 4092 keys (the count kernels are paced by their two barriers per
-                              // sub-partition, not by its keys: half as many sub-partitions of twice the size -- see DESIGN section 6 "k = 63")
+                              // sub-partition, not by its keys: half as many sub-partitions of twice the size -- see NOTEBOOK.md section 6 "k = 63")
 inline u32 opt_groups(int W) { return W == 2 ? (AL_G2 == 8 ? 1022u : OPT_GROUPS2) : (W == 1 && AL_G1 == 16) ? 546u : W == 4 ? OPT_GROUPS4 : OPT_GROUPS; }      // (AL_G2 == 8, experiments: 511 groups of 128 B)
 inline u64 target_keys(int W) { return W == 1 ? TARGET_KEYS : W == 2 ? TARGET_KEYS2 : TARGET_KEYS4; }
 #define OPT_CAP 4360u          // segment-owned level-2 scatter: keys per sub-partition region (mean <= TARGET_KEYS).
@@ -533,7 +533,7 @@ bool make_plan(u64 n_upper, int extra_bits, int W, bool balanced, u32 num_cu, Pl
     if (F < 2) F = 2;
     if (F <= ONE_LEVEL_BINS) { pl->levels = 1; pl->P1 = (u32)F; pl->P2 = 1; }
     else {
-        // Level 1 costs more per key the more bins it has (3.05 ps + 1.7 fs per bin and key, DESIGN section 6: every tile leaves a
+        // Level 1 costs more per key the more bins it has (3.05 ps + 1.7 fs per bin and key, NOTEBOOK.md section 6: every tile leaves a
         // partial line per bin), level 2 costs the same for any number of bins its kernel holds (the per-bin carry must fit LDS:
         // p2max).  So: the FEWEST level-1 bins that keep level 2 inside that kernel -- but at least one segment per CU, and a
         // multiple of the CU count: level 2 gives every block whole segments (level-1 bins), one block per CU, and a count that is

@@ -638,7 +638,7 @@ __global__ __launch_bounds__(SC_NT, 4) void k_scatter(const u64* __restrict__ pa
 #pragma unroll
             for (int it = 0; it < (KPT + 3) / 4; ++it) {
                 const u32 i0 = (u32)it * 4 * SC_NT;
-                if constexpr (W >= 4) {      // four-word keys: one key at a time (four 32-byte keys in flight spilled 96 bytes per lane to scratch: 22.7 -> see DESIGN section 6)
+                if constexpr (W >= 4) {      // four-word keys: one key at a time (four 32-byte keys in flight spilled 96 bytes per lane to scratch: 22.7 -> see NOTEBOOK.md section 6)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const u32 i = i0 + u * SC_NT + threadIdx.x;
@@ -1900,7 +1900,7 @@ __global__ __launch_bounds__(CNT_NT) void k_count_mw(KN<W>* keys, KN<W>* solid_k
 // slot list -- plus ONE store by the claiming lane (the low word, tl[slot]) and ONE read per key after the barrier: every key checks
 // the low word of the slot it was counted on.  A key that disagrees, or a key whose mixed top word IS the empty-slot value, ORs
 // bit 1 into *overflow: the host then repeats the attempt with k_count_mw (index table, full compares) -- exact by construction,
-// never expected (tests force it with crafted k-mers).  7.0 -> see DESIGN section 6 "k = 63".
+// never expected (tests force it with crafted k-mers).  7.0 -> see NOTEBOOK.md section 6 "k = 63".
 #define C2V_SLOTS 3072              // (not a power of two: 20 bytes per slot, two blocks per CU; home slot by multiply-shift)
 #define C2V_MAXLOAD 2688            // 0.875
 #define C2V_NKEYS 4                 // a region holds at most cap <= C2V_NKEYS * CNT_NT keys

@@ -2011,7 +2011,7 @@ def test_sliced_step_with_real_processes(dev, world, k):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DSKGPU_SK_MINSLICE="1")
     # (no retry: the intermittent r03 failure was the tool's own reference count reading the concatenated reads before torch had
-    #  written them -- tools/stress_multi.py, profiles/r04_stress/, DESIGN.md section 5 -- and a red here is a red)
+    #  written them -- tools/stress_multi.py, profiles/r04_stress/, NOTEBOOK.md section 5 -- and a red here is a red)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "tools", "check_multi.py"), str(k), "400000"],
                        cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)

@@ -11,7 +11,7 @@ what tests/test_gpu_parity.py::test_sliced_step_with_real_processes runs once, l
 * the single-context reference is computed twice on rank 0: once straight after torch.cat (no synchronisation between torch's
   stream, which builds the concatenated reads, and the context's own non-blocking stream) and once after torch.cuda.synchronize().
   STRESS_RACE=1 puts a long matmul chain in front of the torch.cat, which makes that window deterministic.  The r03 intermittent
-  failure of test_sliced_step_with_real_processes is exactly a difference between the two references.
+  failure of test_sliced_step_with_real_processes is exactly a difference between the two references (NOTEBOOK.md section 5).
 Exit code 0 = every iteration agreed with the synchronised reference."""
 import os
 import sys
