@@ -166,6 +166,150 @@ __global__ __launch_bounds__(NT) void k_count_tag(u64* keys, u64* solid_keys, u3
     if (tid == 0 && ndist_acc) atomicAdd(&gstats[0], ndist_acc);
 }
 
+// T3: no stored high word, no per-key verification read.  Every key adds (hi << 32 | 1) to ONE 64-bit word of its slot: low half = count, high half
+// = sum of the high words of everything counted there (mod 2^32).  The lane that claimed the slot still holds ITS high word in a register at sweep
+// time and checks sum == count * hi: two k-mers with one tag in a slot make the sum differ (c_B * (hi_B - hi_A) != 0 mod 2^32 as long as c_B < 2^19:
+// inside a sub-partition the high words differ by less than 2^14).  Exact, one LDS atomic per key as in the product kernel -- but a 64-bit one.
+__device__ __forceinline__ u32 tag_insert3(u32* tg, unsigned long long* tcs, u32* ovf, u32 tag, u32 hi) {
+    u32 slot = tag & (CNT_SLOTS - 1), res = CNT_NONE;
+    bool pend = true;
+    const unsigned long long inc = ((unsigned long long)hi << 32) | 1ull;
+    for (int probe = 0; probe < CNT_SLOTS; ++probe) {
+        u32 old = 0u;
+        if (pend) old = tg[slot];
+        const bool e = pend && old == TAG_EMPTY;
+        u32 mine = 0u;
+        if (e) { old = atomicCAS(&tg[slot], TAG_EMPTY, tag); if (old == TAG_EMPTY) { mine = 0x80000000u; old = tag; } }
+        const bool m = pend && old == tag;
+        if (m) { atomicAdd(&tcs[slot], inc); res = slot | mine; }
+        pend = pend && !m;
+        slot = (slot + 1) & (CNT_SLOTS - 1);
+        if (!__ballot(pend)) return res;
+    }
+    *ovf = 1;
+    return res;
+}
+template <int NT, int KPT, int NKEYS>
+__global__ __launch_bounds__(NT) void k_count_tag3(u64* keys, u64* solid_keys, u32* __restrict__ abund, u32* __restrict__ nsolid,
+                                                   u64* __restrict__ ghist, u64* __restrict__ gstats,
+                                                   u32* __restrict__ overflow, CountParams cp, const u32* __restrict__ subcnt) {
+    __shared__ u32 tg[CNT_SLOTS];
+    __shared__ unsigned long long tcs[CNT_SLOTS];
+    __shared__ u32 lh[CNT_LH];
+    __shared__ u32 s_ctr[2][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int s = tid; s < CNT_SLOTS; s += NT) { tg[s] = TAG_EMPTY; tcs[s] = 0ull; }
+    for (int b = tid; b < CNT_LH; b += NT) lh[b] = 0;
+    if (tid < 8) s_ctr[tid >> 2][tid & 3] = 0;
+    u32 ones = 0;
+    u64 ndist_acc = 0;
+    auto range_lo = [&](u32 qq) { const u32 c = qq < cp.F ? qq : cp.F - 1; return subcnt[c]; };
+    auto count_of = [&](u32 qq, u32 lo) { return qq < cp.F ? ((int)lo < 0 ? 0u : lo) : 0u; };
+    struct Sub { u32 q; u64 begin; u32 n; };
+    auto load_keys = [&](const Sub& sb, u64 (&pk)[KPT]) {
+        const u32 last = sb.n ? sb.n - 1 : 0u;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) { const u32 i = tid + j * NT; pk[j] = keys[sb.begin + (i < sb.n ? i : last)]; }
+    };
+    auto sub_of = [&](u32 qq, u32 lo) { Sub sb; sb.q = qq; sb.begin = qq < cp.F ? (u64)qq * cp.cap : 0ull; sb.n = count_of(qq, lo); return sb; };
+    const u32 G = gridDim.x;
+    u64 pa[KPT], pb[KPT];
+    Sub sa = sub_of(blockIdx.x, range_lo(blockIdx.x));
+    Sub sb = sub_of(blockIdx.x + G, range_lo(blockIdx.x + G));
+    u32 rq = blockIdx.x + 2 * G, rlo = range_lo(rq);
+    load_keys(sa, pa);
+    load_keys(sb, pb);
+    lds_barrier();
+    int par = 0;
+    auto one = [&](Sub& cur, u64 (&pk)[KPT]) {
+        u32* ctr = s_ctr[par];
+        const u32 q = cur.q, n = cur.n; const u64 begin = cur.begin;
+        u32 at[NKEYS], hiw[NKEYS];
+#pragma unroll
+        for (int j = 0; j < NKEYS; ++j) { at[j] = CNT_NONE; hiw[j] = 0; }
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+            if ((u32)(tid + j * NT) < n) { hiw[j] = (u32)(pk[j] >> 32); at[j] = tag_insert3(tg, tcs, &ctr[2], (u32)pk[j], hiw[j]); }
+#pragma unroll
+        for (int j = KPT; j < NKEYS; ++j)
+            if ((u32)(tid + j * NT) < n) { const u64 kx = keys[begin + tid + j * NT]; hiw[j] = (u32)(kx >> 32); at[j] = tag_insert3(tg, tcs, &ctr[2], (u32)kx, hiw[j]); }
+        {
+            u32 mine = 0;
+#pragma unroll
+            for (int j = 0; j < NKEYS; ++j) mine += (u32)__popcll(__ballot(at[j] != CNT_NONE && (at[j] >> 31)));
+            if (lane == 0 && mine) atomicAdd(&ctr[0], mine);
+        }
+        cur = sub_of(rq, rlo);
+        load_keys(cur, pk);
+        rq += G; rlo = range_lo(rq);
+        lds_barrier();
+        const u32 nd = ctr[0];
+        const bool bad = ctr[2] || nd > cp.maxload;
+        if (bad) {
+            for (int s = tid; s < CNT_SLOTS; s += NT) { tg[s] = TAG_EMPTY; tcs[s] = 0ull; }
+            if (tid == 0) atomicOr(overflow, 1u);
+        } else {
+            bool wrong = false;
+#pragma unroll
+            for (int j = 0; j < NKEYS; ++j) {
+                const bool act = at[j] != CNT_NONE && (at[j] >> 31);
+                if (!__ballot(act)) continue;
+                u64 key = 0; u32 c = 0;
+                if (act) {
+                    const u32 slot = at[j] & 0x7FFFFFFFu;
+                    const unsigned long long cs = tcs[slot];
+                    c = (u32)cs;
+                    wrong = wrong || (u32)(cs >> 32) != c * hiw[j];
+                    key = ((u64)hiw[j] << 32) | tg[slot];
+                    tg[slot] = TAG_EMPTY; tcs[slot] = 0ull;
+                }
+                const u64 m1 = __ballot(act && c == 1);
+                if (lane == 0) ones += __popcll(m1);
+                if (act && c > 1) {
+                    const u32 bin = c < cp.histo_max ? c : cp.histo_max;
+                    if (bin < CNT_LH) atomicAdd(&lh[bin], 1u);
+                    else atomicAdd(&ghist[bin], 1ull);
+                }
+                const bool solid = act && c >= cp.amin && c <= cp.amax;
+                const u64 ms = __ballot(solid);
+                if (ms) {
+                    u32 base = 0;
+                    if (lane == 0) base = atomicAdd(&ctr[1], (u32)__popcll(ms));
+                    base = __shfl(base, 0);
+                    if (solid) {
+                        const u32 pos = base + __popcll(ms & ((1ull << lane) - 1));
+                        solid_keys[begin + cp.cap - 1 - pos] = key;      // rows from the END of the region: the keys stay intact for a re-count
+                        abund[begin + cp.cap - 1 - pos] = c;
+                    }
+                }
+            }
+            if (wrong) ctr[3] = 1u;
+        }
+        lds_barrier();
+        if (tid == 0) {
+            const bool redo = ctr[3] != 0;
+            if (redo) atomicOr(overflow, 2u);
+            nsolid[q] = (bad || redo) ? 0u : ctr[1];
+            ndist_acc += (bad || redo) ? 0u : nd;
+            ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0;
+        }
+        par ^= 1;
+    };
+    while (sa.q < cp.F) {
+        one(sa, pa);
+        if (sb.q >= cp.F) break;
+        one(sb, pb);
+    }
+    lds_barrier();
+    if (lane == 0 && ones) atomicAdd(&lh[1], ones);
+    lds_barrier();
+    for (int b = tid; b < CNT_LH; b += NT) {
+        const u32 v = lh[b];
+        if (v) atomicAdd(&ghist[b < (int)cp.histo_max ? b : (int)cp.histo_max], (u64)v);
+    }
+    if (tid == 0 && ndist_acc) atomicAdd(&gstats[0], ndist_acc);
+}
+
 int main() {
     const u32 F = 414000, cap = 4360, n = 2900, ngen = 73, copies = 30;
     u64* keys; u32* subcnt; u64* ghist; u64* gstats; u32* nsolid; u32* abund; u32* ovf;
@@ -180,7 +324,8 @@ int main() {
         hipEventRecord(a);
         if (which == 0) hipLaunchKernelGGL((k_count1v3<CNT_NT, CNT_KPT, CNT_V3_KEYS>), dim3(512), dim3(CNT_NT), 0, 0, keys, keys, abund, nsolid, ghist, gstats, ovf, cp, (const u32*)subcnt);
         else if (which == 1) hipLaunchKernelGGL((k_count_tag<CNT_NT, CNT_KPT, CNT_V3_KEYS, false>), dim3(512), dim3(CNT_NT), 0, 0, keys, keys, abund, nsolid, ghist, gstats, ovf, cp, (const u32*)subcnt);
-        else hipLaunchKernelGGL((k_count_tag<CNT_NT, CNT_KPT, CNT_V3_KEYS, true>), dim3(512), dim3(CNT_NT), 0, 0, keys, keys, abund, nsolid, ghist, gstats, ovf, cp, (const u32*)subcnt);
+        else if (which == 2) hipLaunchKernelGGL((k_count_tag<CNT_NT, CNT_KPT, CNT_V3_KEYS, true>), dim3(512), dim3(CNT_NT), 0, 0, keys, keys, abund, nsolid, ghist, gstats, ovf, cp, (const u32*)subcnt);
+        else hipLaunchKernelGGL((k_count_tag3<CNT_NT, CNT_KPT, CNT_V3_KEYS>), dim3(512), dim3(CNT_NT), 0, 0, keys, keys, abund, nsolid, ghist, gstats, ovf, cp, (const u32*)subcnt);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         u64 st[4]; u32 o; hipMemcpy(st, gstats, 32, hipMemcpyDeviceToHost); hipMemcpy(&o, ovf, 4, hipMemcpyDeviceToHost);
@@ -190,6 +335,7 @@ int main() {
         run(0, "A   k_count1v3 (64-bit keys in the table)");
         run(1, "T1  u32 tag table, no verification (upper bound)");
         run(2, "T2  u32 tag table + high word stored and verified");
+        run(3, "T3  u32 tag + u64 (count | sum of high words), checked in the sweep");
     }
     return 0;
 }
