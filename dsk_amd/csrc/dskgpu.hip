@@ -116,6 +116,20 @@ struct DevBuf {
 };
 
 enum Scalar { SC_NCH1 = 0, SC_MLEN1, SC_NCH2, SC_MLEN2, SC_OVERFLOW, SC_F, SC_SORTFLAG, SC_OVF2, SC_OVF1, SC_RSLEN, SC_RSWORK, SC_RSWORK2, SC_RSTIES, SC_EXT, SC_NCHAINED, SC_NCH_S, SC_MLEN_S, SC_WORK2, SC_COUNT = 24 };
+// everything the host wants to know after the count stage of a pass, gathered into ONE 80-byte record: seven 4- and 32-byte copies from
+// four buffers into pageable host memory cost ~20 us of idle GPU each (the runtime stages every one of them), 0.12 ms of a 14 ms step
+__global__ void k_gather_back(const u32* __restrict__ sc, const u32* __restrict__ nsolid_total, const u32* __restrict__ nk, const u64* __restrict__ gstats,
+                              u64* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        out[0] = sc[SC_OVERFLOW]; out[1] = *nsolid_total; out[2] = nk ? *nk : 0u; out[3] = sc[SC_OVF2]; out[4] = sc[SC_OVF1]; out[5] = sc[SC_EXT];
+        out[6] = gstats[0]; out[7] = gstats[1]; out[8] = gstats[2]; out[9] = gstats[3];
+    }
+}
+// the row sort's two words for the host (its "could not finish in place" flag, the number of listed sub-buckets), put behind the abundance
+// histogram so that the end of a step is ONE copy
+__global__ void k_sort_back(const u32* __restrict__ sc, const u32* __restrict__ ovs, u64* __restrict__ out) {
+    if (threadIdx.x == 0) { out[0] = sc[SC_SORTFLAG]; out[1] = ovs ? ovs[0] : 0u; }
+}
 #ifndef SORT_TOP_BITS
 #define SORT_TOP_BITS 32u      // 4 radix passes; 40 bits (5 passes) cost 0.3 ms more on 43 M rows, the in-place run fix-up absorbs the extra ties
 #endif
@@ -244,6 +258,8 @@ struct dskgpu_ctx {
     std::vector<u32> h_sk_sums; std::vector<u64> h_sk_cbase;
     // records handed to dskgpu_mg_count: the level-1 scatter reads them directly (SRC 2); expanded lazily for the exact path
     const u64* rec_src = nullptr; u64 rec_n = 0; u64 rec_nch = 0, rec_rpc = 0; bool rec_expanded = false;
+    int sort_back = 0; u64* hist_pin = nullptr; size_t hist_pin_n = 0;      // (sort_back: 1 = flag + sub-bucket count still on the device, 2 = flag only; see k_sort_back)
+    DevBuf back_dev; u64* back_host = nullptr;      // the count stage's read-back record (k_gather_back) and its pinned landing zone
     u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0, h_ext = 0; u64 h_nvalid = 0; bool have_nvalid = false;
     u64* fb_src_k = nullptr; u32* fb_src_v = nullptr; u64* fb_dst_k = nullptr; u32* fb_dst_v = nullptr;   // one-word row sort: where the full-width fallback finds a permutation of the rows / leaves them sorted
     bool sentinel_ok = true;       // the all-ones key is not the mixed form of a canonical k-mer of this k (checked at create)
@@ -848,8 +864,9 @@ int sort_rows2_msd(dskgpu_ctx* ctx, u64 n) {
     u32* sc = ctx->scalars.as<u32>();
     { const int e = msd_sort_rows2(ctx, K, T, n, 2 * (int)ctx->cfg.kmer_size, true, 0u); if (e) return e; }
     { const int e = rows2_rounds(ctx, K, T); if (e) return e; }
-    CK(hipMemcpyAsync(&ctx->h_back[3], sc + SC_SORTFLAG, 4, hipMemcpyDeviceToHost, ctx->stream));
+    (void)sc;
     ctx->h_ovs.assign(1, 0);
+    ctx->sort_back = 2;
     ctx->sort_partial = true;
     return DSKGPU_OK;
 }
@@ -932,9 +949,8 @@ int sort_rows_msd(dskgpu_ctx* ctx, u64 n) {
                                  (int)std::min(64u, 2u * ctx->cfg.kmer_size), true, 0u, ctx->sp_rows.valid ? &ctx->sp_rows : nullptr);
     ctx->sp_rows.valid = false;
     if (e) return e;
-    CK(hipMemcpyAsync(&ctx->h_back[3], ctx->scalars.as<u32>() + SC_SORTFLAG, 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->h_ovs.assign(1, 0);
-    CK(hipMemcpyAsync(ctx->h_ovs.data(), ctx->rs_ovs.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sort_back = 1;      // (flag and sub-bucket count travel with the histogram: run_pipeline)
     ctx->sort_partial = true;
     ctx->res_w[0] = ctx->out_w[0].as<u64>(); ctx->res_ab = ctx->out_ab.as<u32>();
     ctx->rs_res_k = ctx->out_w[0].as<u64>(); ctx->rs_res_v = ctx->out_ab.as<u32>(); ctx->rs_tmp_k = ctx->srt_w[0].as<u64>(); ctx->rs_tmp_v = ctx->srt_ab.as<u32>();
@@ -1960,15 +1976,20 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             ctx->mark("count");
             if (int e = run_scan(ctx, ctx->nsolid.as<u32>(), sc + SC_F, pl.F)) return e;
             ctx->mark("scan_solid");
-            CK(hipMemcpyAsync(&ctx->h_back[0], sc + SC_OVERFLOW, 4, hipMemcpyDeviceToHost, ctx->stream));
-            CK(hipMemcpyAsync(&ctx->h_back[1], ctx->nsolid.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
-            // k-mers of the pass: the last sub-partition offset, or (fixed-capacity regions) the level-1 total
-            if (!opt1) CK(hipMemcpyAsync(&ctx->h_back[2], opt_cap ? ctx->mat1.as<u32>() + M1 : ctx->fstart.as<u32>() + pl.F, 4, hipMemcpyDeviceToHost, ctx->stream));
-            CK(hipMemcpyAsync(&ctx->h_ovf2, sc + SC_OVF2, 4, hipMemcpyDeviceToHost, ctx->stream));
-            CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
-            CK(hipMemcpyAsync(&ctx->h_ext, sc + SC_EXT, 4, hipMemcpyDeviceToHost, ctx->stream));
-            CK(hipMemcpyAsync(&ctx->h_stats[0], ctx->gstats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+            // (k-mers of the pass: the last sub-partition offset, or -- fixed-capacity regions -- the level-1 total; with block-owned slices
+            //  the scatter's own count in gstats[2])
+            CK(ctx->back_dev.ensure(16 * 8));
+            if (!ctx->back_host) CK(hipHostMalloc(reinterpret_cast<void**>(&ctx->back_host), 16 * 8, hipHostMallocDefault));
+            const u32* nkp = opt1 ? nullptr : (opt_cap ? ctx->mat1.as<u32>() + M1 : ctx->fstart.as<u32>() + pl.F);
+            hipLaunchKernelGGL(k_gather_back, dim3(1), dim3(64), 0, ctx->stream, (const u32*)sc, (const u32*)(ctx->nsolid.as<u32>() + pl.F), nkp,
+                               (const u64*)ctx->gstats.as<u64>(), ctx->back_dev.as<u64>());
+            CKL("k_gather_back");
+            CK(hipMemcpyAsync(ctx->back_host, ctx->back_dev.p, 10 * 8, hipMemcpyDeviceToHost, ctx->stream));
             CK(hipStreamSynchronize(ctx->stream));
+            const u64* bh = ctx->back_host;
+            ctx->h_back[0] = (u32)bh[0]; ctx->h_back[1] = (u32)bh[1]; if (!opt1) ctx->h_back[2] = (u32)bh[2];
+            ctx->h_ovf2 = (u32)bh[3]; ctx->h_ovf1 = (u32)bh[4]; ctx->h_ext = (u32)bh[5];
+            for (int x = 0; x < 4; ++x) ctx->h_stats[x] = bh[6 + x];
             return DSKGPU_OK;
         };
         if constexpr (W == 2) CK(hipMemcpyAsync(ctx->gstats.as<u64>() + 3, ctx->gstats.as<u64>() + 2, 8, hipMemcpyDeviceToDevice, ctx->stream));      // (the keys level 1 placed, before k_heavy_rows adds to them: see below)
@@ -2281,7 +2302,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         ctx->mark("encode");
     }
     CK(ctx->scalars.ensure(SC_COUNT * 4));
-    CK(ctx->ghist.ensure(((size_t)ctx->cfg.histo_max + 1) * 8));
+    CK(ctx->ghist.ensure(((size_t)ctx->cfg.histo_max + 1 + 2) * 8));      // (+ 2: k_sort_back's words)
     CK(ctx->gstats.ensure(4 * 8));
     ctx->have_nvalid = false;
     if (from_reads && nwords) {
@@ -2460,10 +2481,31 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             for (int x = 0; x < W; ++x) std::swap(ctx->out_w[x], ctx->acc_w[x]);
         }
         int rc;
+        ctx->sort_back = 0;
         if ((rc = sort_rows(ctx, tot_rows))) return rc;
         ctx->mark("sort");
-        if (npass == 1) CK(hipMemcpyAsync(ctx->hist.data(), ctx->ghist.p, ctx->hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipStreamSynchronize(ctx->stream));
+        if (ctx->sort_back) {      // histogram + the sort's two words: one copy into pinned memory (three pageable ones were ~25 us of idle GPU each)
+            const size_t nh = ctx->hist.size();
+            if (ctx->hist_pin_n < nh + 2) {
+                if (ctx->hist_pin) CK(hipHostFree(ctx->hist_pin));
+                ctx->hist_pin = nullptr; ctx->hist_pin_n = 0;
+                CK(hipHostMalloc(reinterpret_cast<void**>(&ctx->hist_pin), (nh + 2) * 8, hipHostMallocDefault));
+                ctx->hist_pin_n = nh + 2;
+            }
+            u64* gh = ctx->ghist.as<u64>();
+            hipLaunchKernelGGL(k_sort_back, dim3(1), dim3(64), 0, ctx->stream, (const u32*)ctx->scalars.as<u32>(),
+                               ctx->sort_back == 1 ? (const u32*)ctx->rs_ovs.as<u32>() : (const u32*)nullptr, gh + nh);
+            CKL("k_sort_back");
+            const size_t from = npass == 1 ? 0 : nh;
+            CK(hipMemcpyAsync(ctx->hist_pin + from, gh + from, (nh + 2 - from) * 8, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+            ctx->h_back[3] = (u32)ctx->hist_pin[nh]; ctx->h_ovs.assign(1, (u32)ctx->hist_pin[nh + 1]);
+            if (npass == 1) memcpy(ctx->hist.data(), ctx->hist_pin, nh * 8);
+            ctx->sort_back = 0;
+        } else {
+            if (npass == 1) CK(hipMemcpyAsync(ctx->hist.data(), ctx->ghist.p, ctx->hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+        }
         if (W == 1 && ctx->sort_partial && tot_rows && !ctx->h_back[3] && !ctx->h_ovs.empty() && ctx->h_ovs[0]) {
             if ((rc = sort_oversize(ctx))) return rc;      // sub-buckets the sort listed for another round on their remaining bits
         } else if (W > 1 && ctx->sort_partial && !ctx->h_ovs.empty() && ctx->h_ovs[0]) ctx->h_back[3] = 1;      // (index pairs of multi-word rows: the full-width order)
@@ -3005,7 +3047,9 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
                       &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
                       &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->srt_k2, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
                       &ctx->s_val, &ctx->m_flag, &ctx->m_pos, &ctx->m_sum, &ctx->gh2d,
-                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent, &ctx->cur_state, &ctx->rs_ovs, &ctx->smp_keys, &ctx->sk_lay, &ctx->fix_list, &ctx->sk_cb64, &ctx->rs_del, &ctx->rs_lens};
+                      &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent, &ctx->cur_state, &ctx->rs_ovs, &ctx->smp_keys, &ctx->sk_lay, &ctx->fix_list, &ctx->sk_cb64, &ctx->rs_del, &ctx->rs_lens, &ctx->back_dev};
+    if (ctx->back_host) (void)hipHostFree(ctx->back_host);
+    if (ctx->hist_pin) (void)hipHostFree(ctx->hist_pin);
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i) { ctx->rs_g[i].release(); ctx->out_w[i].release(); ctx->srt_w[i].release(); ctx->acc_w[i].release(); ctx->u_w[i].release(); ctx->s_w[i].release(); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
