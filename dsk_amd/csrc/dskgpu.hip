@@ -32,9 +32,12 @@ thread_local std::string g_create_err;
 // the row sort's device scalars (matrix length, two work counters [, the ties flag]) set from KERNEL ARGUMENTS: the sorts are called many
 // times back to back from host loops, and an asynchronous copy from one host-side array would only be correct as long as the runtime
 // stages pageable copies synchronously
-__global__ void k_set_rs_scalars(u32* __restrict__ sc4, u32 len, u32 nwords) {
+// (z0, z1: two more words to clear -- the sort's "not finished in place" flag and the count of listed sub-buckets -- or null)
+__global__ void k_set_rs_scalars(u32* __restrict__ sc4, u32 len, u32 nwords, u32* __restrict__ z0 = nullptr, u32* __restrict__ z1 = nullptr) {
     if (threadIdx.x == 0) sc4[0] = len;
     else if (threadIdx.x < nwords) sc4[threadIdx.x] = 0u;
+    if (threadIdx.x == 32 && z0) *z0 = 0u;
+    if (threadIdx.x == 33 && z1) *z1 = 0u;
 }
 __global__ __launch_bounds__(1024) void k_place_probe(unsigned long long* __restrict__ out, unsigned long long n) {
     const unsigned long long per_block = n / gridDim.x, per_stream = per_block / 512;
@@ -127,6 +130,15 @@ __global__ void k_gather_back(const u32* __restrict__ sc, const u32* __restrict_
 }
 // the row sort's two words for the host (its "could not finish in place" flag, the number of listed sub-buckets), put behind the abundance
 // histogram so that the end of a step is ONE copy
+// start of a pass attempt: the device scalars (from kernel arguments), an empty abundance histogram, zeroed statistics -- one launch where a
+// copy and two memsets were four (a memset of 80 008 bytes is two fill kernels)
+struct ScalarSet { u32 v[SC_COUNT]; };
+__global__ __launch_bounds__(256) void k_setup_pass(u32* __restrict__ sc, ScalarSet h, u64* __restrict__ ghist, u32 nh, u64* __restrict__ gstats, u32 nstats) {
+    const u32 t = blockIdx.x * 256 + threadIdx.x;
+    if (t < SC_COUNT) sc[t] = h.v[t];
+    if (t < nstats) gstats[t] = 0ull;
+    for (u32 i = t; i < nh; i += gridDim.x * 256) ghist[i] = 0ull;
+}
 __global__ void k_sort_back(const u32* __restrict__ sc, const u32* __restrict__ ovs, u64* __restrict__ out) {
     if (threadIdx.x == 0) { out[0] = sc[SC_SORTFLAG]; out[1] = ovs ? ovs[0] : 0u; }
 }
@@ -143,7 +155,6 @@ struct Stage { const char* name; hipEvent_t ev; };
 struct Tuning {
     bool no_opt1 = false, no_opt2 = false;      // DSKGPU_NO_OPT1 / _NO_OPT2: exact histogram + scan path at level 1 / at both levels
     bool no_aligned = false;                    // DSKGPU_NO_ALIGNED: plain write-out for key-array scatters
-    bool balanced_plan = false;                 // DSKGPU_BALANCED_PLAN: P1 ~ P2
     bool fullsort = false;                      // DSKGPU_FULLSORT: full-width row sort
     bool rows2_pairs = false;                   // DSKGPU_ROWS2_PAIRS: two-word rows as (top 63 bits, row index) pairs + gather + tie pass (the path before rowsort2.h)
     bool lib_rowsort = false;                   // DSKGPU_LIB_ROWSORT: one-word rows through the library radix sort on a 32-bit prefix + run fix-up (the path before rowsort.h)
@@ -159,28 +170,23 @@ struct Tuning {
     bool no_sample = false;                     // DSKGPU_NO_SAMPLE: level-1 slices from the mean load instead of the sampled per-bin loads
     bool no_heavy = false;                      // DSKGPU_NO_HEAVY: no k-mer is counted apart by the level-1 scatter
     bool verbose = false;                       // DSKGPU_VERBOSE: trace of the plan decisions on stderr
-    bool l2_static = false;                     // DSKGPU_L2_STATIC: segments of the level-2 scatter round-robin over the blocks instead of by work counter
     bool no_level0 = false; u32 l0_passes = 0;  // DSKGPU_NO_LEVEL0: every pass of a multi-pass count re-generates its keys; DSKGPU_L0_PASSES=n: passes per level-0 sweep (tests)
-    bool count_mw_v1 = false;                   // DSKGPU_COUNT_MW_V1: k_count_mw (index table, full compares) instead of the top-word table k_count2v3 on two-word regions
-    bool count_v1 = false;                      // DSKGPU_COUNT_V1: k_count1<true> (slot list) instead of the list-free k_count1v3 on regions
     u64 rs_max_rows = 0;                        // DSKGPU_RS_MAX_ROWS: most rows the MSD row sort takes in one piece (tests: the group-wise path of huge row sets on a small input)
     bool l0_keys = false;                       // DSKGPU_L0_KEYS: level 0 as key arrays (k_level0) even where the record-based one applies (experiments, tests)
-    bool l0_staged = false;                     // DSKGPU_L0_STAGED: level 0 through the LDS-staged scatter (k_scatter<1, 0, 4>) instead of k_level0 (experiments)
     u32 mp_pass_mkeys = 0;                      // DSKGPU_MP_PASS_MKEYS: keys (millions) per pass of an input that needs several passes (default 1000)
     bool sort_compact = false;                  // DSKGPU_SORT_COMPACT: k_compact + dense step A (the path before r05: A/B runs; still the path of several passes and wide keys)
     u64 rs_slab_rows = 0;                       // DSKGPU_RS_SLAB_ROWS: rows per slab of the row sort for >= 2^32 rows (tests: forces that path, with small slabs, on a small input)
-    bool force_heavy = false;                   // DSKGPU_FORCE_HEAVY: the HEAVY instantiation of the level-1 scatter even when no k-mer is counted apart (timing)
     void read() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         auto num = [](const char* n, u64 dflt) { const char* e = getenv(n); return e ? (u64)atoll(e) : dflt; };
         no_opt1 = on("DSKGPU_NO_OPT1"); no_opt2 = on("DSKGPU_NO_OPT2"); no_aligned = on("DSKGPU_NO_ALIGNED");
-        balanced_plan = on("DSKGPU_BALANCED_PLAN"); fullsort = on("DSKGPU_FULLSORT"); sk_exact = on("DSKGPU_SK_EXACT");
+        fullsort = on("DSKGPU_FULLSORT"); sk_exact = on("DSKGPU_SK_EXACT");
         no_recsrc = on("DSKGPU_NO_RECSRC");
         opt_cap = (u32)num("DSKGPU_OPT_CAP", 0) & ~7u; opt_slice = num("DSKGPU_OPT_SLICE", 0) & ~7ull;
         sk_slice = num("DSKGPU_SK_SLICE", 0); sk_minslice = num("DSKGPU_SK_MINSLICE", 2000);
         table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
         max_ext = getenv("DSKGPU_MAX_EXT") ? atoll(getenv("DSKGPU_MAX_EXT")) : -1;
-        no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); l2_static = on("DSKGPU_L2_STATIC"); force_heavy = on("DSKGPU_FORCE_HEAVY"); count_v1 = on("DSKGPU_COUNT_V1"); count_mw_v1 = on("DSKGPU_COUNT_MW_V1"); no_level0 = on("DSKGPU_NO_LEVEL0"); l0_passes = (u32)num("DSKGPU_L0_PASSES", 0); mp_pass_mkeys = (u32)num("DSKGPU_MP_PASS_MKEYS", 0); rs_max_rows = num("DSKGPU_RS_MAX_ROWS", 0); l0_staged = on("DSKGPU_L0_STAGED"); l0_keys = on("DSKGPU_L0_KEYS");
+        no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); no_level0 = on("DSKGPU_NO_LEVEL0"); l0_passes = (u32)num("DSKGPU_L0_PASSES", 0); mp_pass_mkeys = (u32)num("DSKGPU_MP_PASS_MKEYS", 0); rs_max_rows = num("DSKGPU_RS_MAX_ROWS", 0); l0_keys = on("DSKGPU_L0_KEYS");
         rs_slab_rows = num("DSKGPU_RS_SLAB_ROWS", 0); sort_compact = on("DSKGPU_SORT_COMPACT");
         lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rows2_pairs = on("DSKGPU_ROWS2_PAIRS"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0); rs_heavy = (u32)num("DSKGPU_RS_HEAVY", 0);
     }
@@ -259,6 +265,7 @@ struct dskgpu_ctx {
     // records handed to dskgpu_mg_count: the level-1 scatter reads them directly (SRC 2); expanded lazily for the exact path
     const u64* rec_src = nullptr; u64 rec_n = 0; u64 rec_nch = 0, rec_rpc = 0; bool rec_expanded = false;
     int sort_back = 0; u64* hist_pin = nullptr; size_t hist_pin_n = 0;      // (sort_back: 1 = flag + sub-bucket count still on the device, 2 = flag only; see k_sort_back)
+    u64* land = nullptr;                             // 64 KB of pinned host memory: where the small per-step read-backs land (landing())
     DevBuf back_dev; u64* back_host = nullptr;      // the count stage's read-back record (k_gather_back) and its pinned landing zone
     u32 h_back[4] = {0}; u64 h_stats[4] = {0}; u32 h_ovf2 = 0, h_ovf1 = 0, h_ext = 0; u64 h_nvalid = 0; bool have_nvalid = false;
     u64* fb_src_k = nullptr; u32* fb_src_v = nullptr; u64* fb_dst_k = nullptr; u32* fb_dst_v = nullptr;   // one-word row sort: where the full-width fallback finds a permutation of the rows / leaves them sorted
@@ -328,6 +335,15 @@ namespace {
     } while (0)
 
 int fail(dskgpu_ctx* ctx, int code, const std::string& msg) { ctx->err = msg; return code; }
+
+// Pinned host memory for the small read-backs a step waits on (a copy into pageable memory is staged by the runtime: ~10 us more of idle
+// GPU per host round trip).  nullptr when the allocation fails or the request is larger: the caller then copies into its own buffer.
+#define LAND_BYTES (64u << 10)
+void* landing(dskgpu_ctx* ctx, size_t bytes) {
+    if (bytes > LAND_BYTES) return nullptr;
+    if (!ctx->land && hipHostMalloc(reinterpret_cast<void**>(&ctx->land), LAND_BYTES, hipHostMallocDefault) != hipSuccess) { ctx->land = nullptr; (void)hipGetLastError(); }
+    return ctx->land;
+}
 
 // Is the all-ones key (the pad / empty-slot sentinel) the mixed form of a real canonical k-mer of this k?
 // (It never is for k <= 32; for wider keys it is checked here once and the sentinel-based paths are switched off if so.)
@@ -485,7 +501,7 @@ int launch_scatter(dskgpu_ctx* ctx, const typename KeyT<W>::T* keys, const Chunk
 
 // fixed-capacity regions or exact offsets: a compile-time switch of the count kernels (k_count1 / k_count_mw)
 inline void launch_count_impl(dskgpu_ctx* ctx, unsigned grid, u64* keys, u64* solid_keys, u32* solid_ab, u32* ovf, const CountParams& cp) {
-    if (!ctx->tune.count_v1 && cp.cap && cp.cap <= CNT_V3_KEYS * CNT_NT) {      // regions: the list-free kernel
+    if (cp.cap && cp.cap <= CNT_V3_KEYS * CNT_NT) {      // regions: the list-free kernel
         hipLaunchKernelGGL((k_count1v3<CNT_NT, CNT_KPT, CNT_V3_KEYS>), dim3(grid), dim3(CNT_NT), 0, ctx->stream, keys, solid_keys, solid_ab,
                            ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, cp, cp.subcnt);
         return;
@@ -498,7 +514,7 @@ inline void launch_count_impl(dskgpu_ctx* ctx, unsigned grid, u64* keys, u64* so
 template <int W>
 inline void launch_count_impl(dskgpu_ctx* ctx, unsigned grid, KN<W>* keys, KN<W>* solid_keys, u32* solid_ab, u32* ovf, const CountParams& cp) {
     if constexpr (W == 2) {
-        if (cp.cap && cp.cap <= C2V_NKEYS * CNT_NT && !ctx->tune.count_mw_v1 && !ctx->mw_v3_off) {      // regions: the table keyed by the mixed top word
+        if (cp.cap && cp.cap <= C2V_NKEYS * CNT_NT && !ctx->mw_v3_off) {      // regions: the table keyed by the mixed top word
             CountParams c2 = cp; c2.maxload = std::min<u32>(cp.maxload, C2V_MAXLOAD);
             hipLaunchKernelGGL((k_count2v3<CNT_NT, C2V_KPT, C2V_NKEYS>), dim3(grid), dim3(CNT_NT), 0, ctx->stream, (const K2*)keys, solid_keys, solid_ab,
                                ctx->nsolid.as<u32>(), ctx->ghist.as<u64>(), ctx->gstats.as<u64>(), ovf, c2, cp.subcnt);
@@ -543,7 +559,7 @@ inline u64 target_keys(int W) { return W == 1 ? TARGET_KEYS : W == 2 ? TARGET_KE
 
 // Final sub-partitions F = P1 * P2 sized to the input (any integer, not a power
 // of two: digits use the multiply-shift reduction of key_digit()).
-bool make_plan(u64 n_upper, int extra_bits, int W, bool balanced, u32 num_cu, Plan* pl) {
+bool make_plan(u64 n_upper, int extra_bits, int W, u32 num_cu, Plan* pl) {
     const u64 target = target_keys(W);
     u64 F = ((n_upper + target - 1) / target) << extra_bits;
     if (F < 2) F = 2;
@@ -555,8 +571,9 @@ bool make_plan(u64 n_upper, int extra_bits, int W, bool balanced, u32 num_cu, Pl
         // multiple of the CU count: level 2 gives every block whole segments (level-1 bins), one block per CU, and a count that is
         // not a multiple leaves some blocks one segment more than the rest (770 segments on 256 CUs cost 20 %).
         u64 p2max = MAX_LEVEL_BINS; while (p2max > 64 && ascatter_lds(W, (u32)p2max) > 160 * 1024) --p2max;
-        u64 p1 = 1; while (p1 * p1 < F) ++p1;                                  // balanced split: small inputs, DSKGPU_BALANCED_PLAN
-        if (!balanced && F >= (u64)num_cu * 64) {
+        u64 p1 = 1; while (p1 * p1 < F) ++p1;                                  // balanced split: small inputs
+        const bool large = F >= (u64)num_cu * 64;
+        if (large) {
             p1 = std::max<u64>((F + p2max - 2) / (p2max - 1), num_cu);         // (p2max - 1: room for the odd-P2 adjustment below)
             p1 = (p1 + num_cu - 1) / num_cu * num_cu;
             if (p1 > MAX_LEVEL_BINS - 8) p1 = MAX_LEVEL_BINS - 8;
@@ -565,7 +582,7 @@ bool make_plan(u64 n_upper, int extra_bits, int W, bool balanced, u32 num_cu, Pl
         // An ODD number of level-2 bins: the regions of sub-partition q start q * 545 groups of 64 B into the buffer, and the
         // blocks walk their segments in step, so with an even P2 (768 * 545 * 64 B = a multiple of 8 KB between segments) all
         // write fronts sit on the same few HBM channels -- measured 6.0 ms at P2 = 768 against 4.7-5.0 ms at P2 = 769.
-        if (!balanced && p2 % 2 == 0 && p2 + 1 <= p2max) ++p2;
+        if (p2 % 2 == 0 && p2 + 1 <= p2max) ++p2;
         if (p1 > MAX_LEVEL_BINS || p2 > MAX_LEVEL_BINS) return false;
         pl->levels = 2; pl->P1 = (u32)p1; pl->P2 = (u32)p2;
     }
@@ -727,9 +744,9 @@ int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int
     u32* sub = matrix + M + 2;
     u32* biglist = sub + nsubw;
     u32* sc = ctx->scalars.as<u32>();
-    hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, (u32)M, reset_flags ? 4u : 3u);      // (length, two work counters [, ties seen])
     CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
-    if (reset_flags) { CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream)); CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream)); }
+    hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, (u32)M, reset_flags ? 4u : 3u,      // (length, two work counters [, ties seen])
+                       reset_flags ? sc + SC_SORTFLAG : (u32*)nullptr, reset_flags ? ctx->rs_ovs.as<u32>() : (u32*)nullptr);
     const size_t ldsA = RsLds<RS_ABINS, RS_TILE>::bytes;
     const size_t ldsB = BB == 256 ? RsLds<256, RS_BTILE>::bytes : BB == 512 ? RsLds<512, RS_BTILE>::bytes : RsLds<1024, RS_BTILE>::bytes;
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_scatter<false>)); if (e) return e; }
@@ -795,9 +812,9 @@ int msd_sort_rows2(dskgpu_ctx* ctx, Rows2 k, Rows2 t, u64 n, int total, bool res
     u32* sub = matrix + M + 2;
     u32* biglist = sub + nsubw;
     u32* sc = ctx->scalars.as<u32>();
-    hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, (u32)M, reset_flags ? 4u : 3u);
     CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
-    if (reset_flags) { CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream)); CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream)); }
+    hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, (u32)M, reset_flags ? 4u : 3u,
+                       reset_flags ? sc + SC_SORTFLAG : (u32*)nullptr, reset_flags ? ctx->rs_ovs.as<u32>() : (u32*)nullptr);
     const size_t ldsA = Rs2Lds<RS_ABINS, RS2_TILE>::bytes;
     const size_t ldsB = BB == 256 ? Rs2Lds<256, RS2_BTILE>::bytes : BB == 512 ? Rs2Lds<512, RS2_BTILE>::bytes : Rs2Lds<1024, RS2_BTILE>::bytes;
     const size_t ldsBig = (size_t)RS_BLOCK_ROWS * 20 + 2 * RS_CELLS * 4;
@@ -901,10 +918,8 @@ int sort_rows2_big(dskgpu_ctx* ctx, u64 n) {
     CK(ctx->mat2.ensure((M + 2) * 4));
     u32* matrix = ctx->mat2.as<u32>();
     u32* sc = ctx->scalars.as<u32>();
-    hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, (u32)M, 4u);
-    CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream));
     CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
-    CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, (u32)M, 4u, sc + SC_SORTFLAG, ctx->rs_ovs.as<u32>());
     ctx->h_ovs.assign(1, 0);
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_scatter<false>)); if (e) return e; }
     const Rows2C kc{K.hi, K.lo, K.ab};
@@ -1036,10 +1051,8 @@ int sort_rows_big(dskgpu_ctx* ctx, u64 n) {
     CK(ctx->mat2.ensure((M + 2) * 4));
     u32* matrix = ctx->mat2.as<u32>();
     u32* sc = ctx->scalars.as<u32>();
-    hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, (u32)M, 4u);
-    CK(hipMemsetAsync(sc + SC_SORTFLAG, 0, 4, ctx->stream));
     CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
-    CK(hipMemsetAsync(ctx->rs_ovs.p, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, (u32)M, 4u, sc + SC_SORTFLAG, ctx->rs_ovs.as<u32>());
     ctx->h_ovs.assign(1, 0);
     ctx->rs_res_k = tk; ctx->rs_res_v = tv; ctx->rs_tmp_k = k; ctx->rs_tmp_v = v;
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_scatter<false>)); if (e) return e; }
@@ -1474,7 +1487,6 @@ int find_heavy(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_ke
         CK(hipMemsetAsync(hvb + HvLayout<W>::counts, 0, HV_KEYS * 8, ctx->stream));
         return DSKGPU_OK;
     };
-    if (flagged.empty() && ctx->tune.force_heavy) { const int e = reset_buf(); if (e) return e; *nheavy_out = 1; }
     if (flagged.empty()) return DSKGPU_OK;
     std::sort(flagged.begin(), flagged.end(), [&](u32 a, u32 b) { return ctx->h_load[a] > ctx->h_load[b]; });
     if (flagged.size() > HV_SLOTS) flagged.resize(HV_SLOTS);
@@ -1538,7 +1550,6 @@ int find_heavy(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_ke
         ctx->h_seg_work[cands[x].bin] -= cands[x].est;
     }
     u32 nheavy = (u32)cands.size();
-    if (!nheavy && ctx->tune.force_heavy) nheavy = 1;         // (timing experiments: the HEAVY kernel with no heavy key)
     if (nheavy) {
         { const int e = reset_buf(); if (e) return e; }
         CK(hipMemcpyAsync(hvb + HvLayout<W>::keys, ctx->h_hv_keys.data(), (size_t)HV_KEYS * W * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1563,7 +1574,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         // + 2 % (cap holds 6 % head-room: sized for it, 7 passes of 200 M reads needed 1792 level-1 bins, more than the LDS of the
         // histogram-free level 1 holds)
         const u64 plan_n = (from_reads && ctx->have_nvalid) ? std::min<u64>(cap, npass == 1 ? ctx->h_nvalid + 1 : ctx->h_nvalid / npass + ctx->h_nvalid / npass / 50 + 4096) : cap;
-        if (!make_plan(plan_n, extra_bits, W, ctx->tune.balanced_plan, (u32)ctx->num_cu, &pl))
+        if (!make_plan(plan_n, extra_bits, W, (u32)ctx->num_cu, &pl))
             return fail(ctx, DSKGPU_E_OVERFLOW, "cannot partition finer (table overflow persists)");
         pl.d1.world = pl.d2.world = ctx->cfg.world_size; pl.d1.npass = pl.d2.npass = npass; pl.d1.pass = pl.d2.pass = pass;
         // ---------------- level 1
@@ -1706,8 +1717,12 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 hipLaunchKernelGGL(k_bin_moments, dim3((pl.P1 + 3) / 4), dim3(256), 0, ctx->stream, (const u32*)ctx->smp_mat.as<u32>(), (u32)nts, pl.P1, mom);
                 CKL("k_bin_moments");
                 ctx->h_mom.resize((size_t)pl.P1 * 2);
-                CK(hipMemcpyAsync(ctx->h_mom.data(), mom, (size_t)pl.P1 * 16, hipMemcpyDeviceToHost, ctx->stream));
-                CK(hipStreamSynchronize(ctx->stream));
+                {
+                    void* lz = landing(ctx, (size_t)pl.P1 * 16);
+                    CK(hipMemcpyAsync(lz ? lz : (void*)ctx->h_mom.data(), mom, (size_t)pl.P1 * 16, hipMemcpyDeviceToHost, ctx->stream));
+                    CK(hipStreamSynchronize(ctx->stream));
+                    if (lz) std::memcpy(ctx->h_mom.data(), lz, (size_t)pl.P1 * 16);
+                }
                 u64 stot = 0;
                 for (u32 b = 0; b < pl.P1; ++b) stot += ctx->h_mom[2 * b];
                 if (stot >= (u64)pl.P1 * 64) {        // enough sampled keys to say something per bin
@@ -1778,10 +1793,14 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         h_sc[SC_NCH1] = nch1; h_sc[SC_MLEN1] = (u32)M1; h_sc[SC_F] = pl.F;
         if (opt1) h_sc[SC_NCH2] = pl.P1;                       // level-2 chunks = the level-1 bin regions
         h_sc[SC_WORK2] = (u32)std::min<u64>(pl.P1, (u64)ctx->num_cu);   // work counter of the segment-owned level-2 scatter: first segment not taken in the first round
-        CK(hipMemcpyAsync(sc, h_sc, sizeof(ctx->h_sc), hipMemcpyHostToDevice, ctx->stream));
-        // histogram / distinct counters of THIS pass attempt (a table-overflow retry must not double count)
-        CK(hipMemsetAsync(ctx->ghist.p, 0, ((size_t)ctx->cfg.histo_max + 1) * 8, ctx->stream));
-        CK(hipMemsetAsync(ctx->gstats.p, 0, 4 * 8, ctx->stream));
+        // (with them: histogram / distinct counters of THIS pass attempt -- a table-overflow retry must not double count)
+        {
+            static_assert(sizeof(ctx->h_sc) == sizeof(ScalarSet), "scalar block");
+            ScalarSet hs; std::memcpy(hs.v, h_sc, sizeof hs.v);
+            const u32 nh = ctx->cfg.histo_max + 1;
+            hipLaunchKernelGGL(k_setup_pass, dim3(std::min<u32>(64u, (nh + 255) / 256)), dim3(256), 0, ctx->stream, sc, hs, ctx->ghist.as<u64>(), nh, ctx->gstats.as<u64>(), 4u);
+            CKL("k_setup_pass");
+        }
         ctx->mark("setup");
         int rc;
         const ChunkDesc* dd1 = ctx->descs1.as<ChunkDesc>();
@@ -1877,7 +1896,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             ctx->mark("plan2");
             OptSpec os{opt_cap, ctx->mat2.as<u32>(), sc + SC_OVF2, opt1 ? o1.fill : nullptr, 0u, grid1, (u64)o1.area,
                        pl.F, max_ext, ctx->chain_next.as<u32>(), sc + SC_EXT, ctx->chain_next.as<u32>() + nregions + 1, sc + SC_NCHAINED,
-                       ctx->tune.l2_static ? nullptr : sc + SC_WORK2, nullptr};
+                       sc + SC_WORK2, nullptr};
             if (ctx->tune.verbose && opt1) { CK(ctx->dbg.ensure((size_t)pl.P1 * 24)); os.dbg = ctx->dbg.as<unsigned long long>(); }
             if (opt1) rc = launch_scatter_al<W, 2, true, true>(ctx, ctx->bufA.as<Key>(), ctx->descs2.as<ChunkDesc>(), sc + SC_NCH2, (u64)pl.P1 * 2, nullptr,
                                                                ctx->bufB.as<Key>(), pl.d2, pl.P2, os);
@@ -2089,7 +2108,7 @@ int level0_materialise(dskgpu_ctx* ctx, u64 nwords, u32 lo, u32 npass, u64 reser
     u32 nch1 = 0;
     build_descs1(ctx, nwords, Tile<1>::WORDS, (u64)ctx->num_cu * 8, &nch1);
     // (k_level0 keeps nothing but its cursors in LDS: two blocks per CU, 32 waves, hide each other's atomics and stores)
-    const unsigned grid = ctx->tune.l0_staged ? scatter_grid(ctx, 1, L0_MAX_PASSES, nch1, true) : (unsigned)std::max<u64>(1, std::min<u64>(nch1, (u64)ctx->num_cu));
+    const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>(nch1, (u64)ctx->num_cu));
     const u64 cpb = (nch1 + grid - 1) / grid;
     const double share = (double)cpb / (double)nch1;                                // the busiest block's share of the chunks
     const u64 tail = 2 * Tile<1>::KEYS;
@@ -2167,17 +2186,9 @@ int level0_materialise(dskgpu_ctx* ctx, u64 nwords, u32 lo, u32 npass, u64 reser
     CK(hipMemcpyAsync(ctx->boff.p, ctx->h_boff.data(), ctx->h_boff.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     const u32* d_slen = ctx->boff.as<u32>();
     const u64* d_obase = reinterpret_cast<const u64*>(ctx->boff.as<u32>() + L0_MAX_PASSES + 4);
-    if (ctx->tune.l0_staged) {      // (experiments: the first version -- the histogram-free scatter with the pass as its digit, staged through LDS tiles)
-        CK(ctx->mat1.ensure(((size_t)L0_MAX_PASSES * grid + 1) * 4));
-        CK(hipMemsetAsync(ctx->gstats.as<u64>() + 2, 0, 8, ctx->stream));
-        Opt1Spec o1{d_slen, (u32)slice[0], (u32)(slice[0] * grid), sc + SC_OVF1, ctx->mat1.as<u32>(), 0u, ctx->gstats.as<u64>() + 2, nullptr, nullptr, (u32)slice[0], d_obase, obase[0], {0ull, 0ull, 0ull, 0ull}, 0u};
-        const int rc = launch_scatter_m<1, 0, 4, true>(ctx, nullptr, ctx->descs1.as<ChunkDesc>(), sc + SC_NCH1, nch1, nullptr, ctx->l0buf.as<u64>(), ds, G, o1);
-        if (rc) return rc;
-    } else {
-        hipLaunchKernelGGL(k_level0, dim3(grid), dim3(SC_NT), 0, ctx->stream, (const u64*)ctx->packed.as<u64>(), (const u32*)ctx->inval.as<u32>(), (const ChunkDesc*)ctx->descs1.as<ChunkDesc>(),
-                           (const u32*)(sc + SC_NCH1), ctx->l0buf.as<u64>(), (int)ctx->cfg.kmer_size, ds, G, d_slen, d_obase, sc + SC_OVF1);
-        CKL("k_level0");
-    }
+    hipLaunchKernelGGL(k_level0, dim3(grid), dim3(SC_NT), 0, ctx->stream, (const u64*)ctx->packed.as<u64>(), (const u32*)ctx->inval.as<u32>(), (const ChunkDesc*)ctx->descs1.as<ChunkDesc>(),
+                       (const u32*)(sc + SC_NCH1), ctx->l0buf.as<u64>(), (int)ctx->cfg.kmer_size, ds, G, d_slen, d_obase, sc + SC_OVF1);
+    CKL("k_level0");
     ctx->mark("level0");
     CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
@@ -2312,8 +2323,12 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         hipLaunchKernelGGL(k_count_valid, dim3((unsigned)std::min<u64>((nwords + 255) / 256, (u64)ctx->num_cu * 8)), dim3(256), 0, ctx->stream,
                            ctx->inval.as<u32>(), nwords, (int)ctx->cfg.kmer_size, ctx->gstats.as<u64>() + 3);
         CKL("k_count_valid");
-        CK(hipMemcpyAsync(&ctx->h_nvalid, ctx->gstats.as<u64>() + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipStreamSynchronize(ctx->stream));
+        {
+            void* lz = landing(ctx, 8);
+            CK(hipMemcpyAsync(lz ? lz : (void*)&ctx->h_nvalid, ctx->gstats.as<u64>() + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+            if (lz) std::memcpy(&ctx->h_nvalid, lz, 8);
+        }
         ctx->have_nvalid = true;
     }
     const u64 max_keys = ctx->max_keys_per_pass ? ctx->max_keys_per_pass : 0xD0000000ull;      // (3.49 G: level 1 then needs <= 1536 bins, what its LDS holds with the slice ends)
@@ -3050,6 +3065,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
                       &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent, &ctx->cur_state, &ctx->rs_ovs, &ctx->smp_keys, &ctx->sk_lay, &ctx->fix_list, &ctx->sk_cb64, &ctx->rs_del, &ctx->rs_lens, &ctx->back_dev};
     if (ctx->back_host) (void)hipHostFree(ctx->back_host);
     if (ctx->hist_pin) (void)hipHostFree(ctx->hist_pin);
+    if (ctx->land) (void)hipHostFree(ctx->land);
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i) { ctx->rs_g[i].release(); ctx->out_w[i].release(); ctx->srt_w[i].release(); ctx->acc_w[i].release(); ctx->u_w[i].release(); ctx->s_w[i].release(); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
