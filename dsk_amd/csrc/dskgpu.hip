@@ -133,11 +133,14 @@ __global__ void k_gather_back(const u32* __restrict__ sc, const u32* __restrict_
 // start of a pass attempt: the device scalars (from kernel arguments), an empty abundance histogram, zeroed statistics -- one launch where a
 // copy and two memsets were four (a memset of 80 008 bytes is two fill kernels)
 struct ScalarSet { u32 v[SC_COUNT]; };
-__global__ __launch_bounds__(256) void k_setup_pass(u32* __restrict__ sc, ScalarSet h, u64* __restrict__ ghist, u32 nh, u64* __restrict__ gstats, u32 nstats) {
+// (zero / nzero: the level-2 region fill counts, zeroed here as well when the pass takes the fixed-capacity regions)
+__global__ __launch_bounds__(256) void k_setup_pass(u32* __restrict__ sc, ScalarSet h, u64* __restrict__ ghist, u32 nh, u64* __restrict__ gstats, u32 nstats,
+                                                    u32* __restrict__ zero, u64 nzero) {
     const u32 t = blockIdx.x * 256 + threadIdx.x;
     if (t < SC_COUNT) sc[t] = h.v[t];
     if (t < nstats) gstats[t] = 0ull;
     for (u32 i = t; i < nh; i += gridDim.x * 256) ghist[i] = 0ull;
+    for (u64 i = t; i < nzero; i += (u64)gridDim.x * 256) zero[i] = 0u;
 }
 __global__ void k_sort_back(const u32* __restrict__ sc, const u32* __restrict__ ovs, u64* __restrict__ out) {
     if (threadIdx.x == 0) { out[0] = sc[SC_SORTFLAG]; out[1] = ovs ? ovs[0] : 0u; }
@@ -1798,7 +1801,11 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             static_assert(sizeof(ctx->h_sc) == sizeof(ScalarSet), "scalar block");
             ScalarSet hs; std::memcpy(hs.v, h_sc, sizeof hs.v);
             const u32 nh = ctx->cfg.histo_max + 1;
-            hipLaunchKernelGGL(k_setup_pass, dim3(std::min<u32>(64u, (nh + 255) / 256)), dim3(256), 0, ctx->stream, sc, hs, ctx->ghist.as<u64>(), nh, ctx->gstats.as<u64>(), 4u);
+            u64 nzero = 0;
+            if (pl.levels == 2 && opt_cap) { nzero = nregions + 1; CK(ctx->mat2.ensure((size_t)nzero * 4)); }      // level 2's keys per region (home regions, then the extension pool)
+            const u64 work = std::max<u64>(nh, nzero);
+            hipLaunchKernelGGL(k_setup_pass, dim3((unsigned)std::min<u64>(1024, (work + 255) / 256)), dim3(256), 0, ctx->stream, sc, hs, ctx->ghist.as<u64>(), nh, ctx->gstats.as<u64>(), 4u,
+                               nzero ? ctx->mat2.as<u32>() : (u32*)nullptr, nzero);
             CKL("k_setup_pass");
         }
         ctx->mark("setup");
@@ -1871,7 +1878,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             CK(ctx->seg.ensure((size_t)pl.P1 * sizeof(SegInfo)));
             CK(ctx->mat2.ensure(((size_t)nregions + 1) * 4));                  // here: keys per region (home regions, then the extension pool)
             CK(ctx->chain_next.ensure(((size_t)nregions + 1 + max_ext + 1) * 4));   // links (only read where subcnt has its chain bit set), then the list of chained sub-partitions
-            CK(hipMemsetAsync(ctx->mat2.p, 0, ((size_t)nregions + 1) * 4, ctx->stream));
+            // (zeroed by k_setup_pass)
             if (opt1) {      // segments = the level-1 bin regions (slices + sentinel tails)
                 ctx->h_descs2.resize(pl.P1);
                 // heaviest segments first (the kernel hands them out by a work counter): a segment that holds a repeat family takes a
