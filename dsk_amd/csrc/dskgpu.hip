@@ -714,7 +714,7 @@ int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int
     // second digit: 8 bits up to 96 M rows, 9 up to 192 M, 10 beyond (sub-buckets stay near 200 rows: one wave each in step C)
     int wantB = n <= (96ull << 20) ? 8 : n <= (192ull << 20) ? 9 : 10;
     if (ctx->tune.rs_bbits >= 8 && ctx->tune.rs_bbits <= 10) wantB = (int)ctx->tune.rs_bbits;      // tests
-    const int bA = std::min(10, total), r1 = total - bA, bB = std::min(wantB, r1), r2 = r1 - bB, bC = std::min(8, r2), r3 = r2 - bC;
+    const int bA = std::min(RS_ABITS, total), r1 = total - bA, bB = std::min(wantB, r1), r2 = r1 - bB, bC = std::min(8, r2), r3 = r2 - bC;
     const u32 BB = 1u << wantB;
     RsSpec sp{r1, r2, r3, (1u << bA) - 1u, (1u << bB) - 1u, (1u << bC) - 1u};
     // chunks of step A: about 64 K rows each, a multiple of the CU count of them (whole rounds of blocks), at least one tile each
@@ -799,7 +799,7 @@ int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int
 int msd_sort_rows2(dskgpu_ctx* ctx, Rows2 k, Rows2 t, u64 n, int total, bool reset_flags, u32 base) {
     int wantB = n <= (96ull << 20) ? 8 : n <= (192ull << 20) ? 9 : 10;
     if (ctx->tune.rs_bbits >= 8 && ctx->tune.rs_bbits <= 10) wantB = (int)ctx->tune.rs_bbits;      // tests
-    const int bA = std::min(10, total), r1 = total - bA, bB = std::min(wantB, r1), r2 = r1 - bB, bC = std::min(8, r2), r3 = r2 - bC;
+    const int bA = std::min(RS2_ABITS, total), r1 = total - bA, bB = std::min(wantB, r1), r2 = r1 - bB, bC = std::min(8, r2), r3 = r2 - bC;
     const u32 BB = 1u << wantB;
     RsSpec sp{r1, r2, r3, (1u << bA) - 1u, (1u << bB) - 1u, (1u << bC) - 1u};
     const u64 ncu = (u64)ctx->num_cu;
@@ -808,8 +808,8 @@ int msd_sort_rows2(dskgpu_ctx* ctx, Rows2 k, Rows2 t, u64 n, int total, bool res
     nch = std::max<u64>(1, std::min<u64>(nch, (n + RS2_TILE - 1) / RS2_TILE));
     const u64 chunk = (n + nch - 1) / nch;
     nch = (n + chunk - 1) / chunk;
-    const u64 M = (u64)RS_ABINS * nch;
-    const u64 nsubw = (u64)RS_ABINS * (BB + 1);
+    const u64 M = (u64)RS2_ABINS * nch;
+    const u64 nsubw = (u64)RS2_ABINS * (BB + 1);
     CK(ctx->srt_tmp.ensure((M + 2 + 2 * nsubw + 16) * 4));
     u32* matrix = static_cast<u32*>(ctx->srt_tmp.p);
     u32* sub = matrix + M + 2;
@@ -818,7 +818,7 @@ int msd_sort_rows2(dskgpu_ctx* ctx, Rows2 k, Rows2 t, u64 n, int total, bool res
     CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
     hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, (u32)M, reset_flags ? 4u : 3u,
                        reset_flags ? sc + SC_SORTFLAG : (u32*)nullptr, reset_flags ? ctx->rs_ovs.as<u32>() : (u32*)nullptr);
-    const size_t ldsA = Rs2Lds<RS_ABINS, RS2_TILE>::bytes;
+    const size_t ldsA = Rs2Lds<RS2_ABINS, RS2_TILE>::bytes;
     const size_t ldsB = BB == 256 ? Rs2Lds<256, RS2_BTILE>::bytes : BB == 512 ? Rs2Lds<512, RS2_BTILE>::bytes : Rs2Lds<1024, RS2_BTILE>::bytes;
     const size_t ldsBig = (size_t)RS_BLOCK_ROWS * 20 + 2 * RS_CELLS * 4;
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_scatter<false>)); if (e) return e; }
@@ -829,15 +829,15 @@ int msd_sort_rows2(dskgpu_ctx* ctx, Rows2 k, Rows2 t, u64 n, int total, bool res
     { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
     hipLaunchKernelGGL(k2_scatter<false>, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, t, sp, (const u64*)nullptr);
     CKL("k2_scatter");
-    u32 heavy = (u32)std::min<u64>(0xFFFFFFFFull, n / RS_ABINS * 64 + 262144);
+    u32 heavy = (u32)std::min<u64>(0xFFFFFFFFull, n / RS2_ABINS * 64 + 262144);
     if (ctx->tune.rs_heavy) heavy = ctx->tune.rs_heavy;
-    const unsigned gridB = (unsigned)std::min<u64>(ncu * (160 * 1024 / (ldsB + 1024)), RS_ABINS);
+    const unsigned gridB = (unsigned)std::min<u64>(ncu * (160 * 1024 / (ldsB + 1024)), RS2_ABINS);
     auto split = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(gridB), dim3(RS_BNT), ldsB, ctx->stream, tc, (u32)nch, matrix, k, sub, sp, sc + SC_RSWORK2, heavy, sc + SC_SORTFLAG);
     };
     if (BB == 256) split(k2_split<256>); else if (BB == 512) split(k2_split<512>); else split(k2_split<1024>);
     CKL("k2_split");
-    const u32 nsub = RS_ABINS * BB;
+    const u32 nsub = RS2_ABINS * BB;
     hipLaunchKernelGGL(k2_cells, dim3(nsub / (RS_CNT / 64)), dim3(RS_CNT), 0, ctx->stream, k, sub, nsub, BB, sp, biglist, sc + SC_RSWORK);
     CKL("k2_cells");
     const u32 block_rows = ctx->tune.rs_block_rows ? std::min<u32>(ctx->tune.rs_block_rows, RS_BLOCK_ROWS) : RS_BLOCK_ROWS;
@@ -909,14 +909,14 @@ int sort_rows2_big(dskgpu_ctx* ctx, u64 n) {
         T = Rows2{ctx->srt_w[1].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>()};
     }
     const int total = 2 * (int)ctx->cfg.kmer_size;
-    const int bA = std::min(10, total);
+    const int bA = std::min(RS2_ABITS, total);
     RsSpec sp{total - bA, 0, 0, (1u << bA) - 1u, 0u, 0u};
     const u64 ncu = (u64)ctx->num_cu;
     u64 nch = (n + 65535) / 65536;
     nch = (nch + ncu - 1) / ncu * ncu;
     const u64 chunk = (n + nch - 1) / nch;
     nch = (n + chunk - 1) / chunk;
-    const u64 M = (u64)RS_ABINS * nch;
+    const u64 M = (u64)RS2_ABINS * nch;
     if (M >= 0xFFFFFFF0ull) return fail(ctx, DSKGPU_E_ARG, "row sort: too many rows");
     CK(ctx->mat2.ensure((M + 2) * 4));
     u32* matrix = ctx->mat2.as<u32>();
@@ -929,13 +929,13 @@ int sort_rows2_big(dskgpu_ctx* ctx, u64 n) {
     hipLaunchKernelGGL(k2_hist, dim3((unsigned)nch), dim3(RS_NT), 0, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, sp);
     CKL("k2_hist");
     { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
-    const size_t ldsA = Rs2Lds<RS_ABINS, RS2_TILE>::bytes;
+    const size_t ldsA = Rs2Lds<RS2_ABINS, RS2_TILE>::bytes;
     hipLaunchKernelGGL(k2_scatter<false>, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, T, sp, (const u64*)nullptr);
     CKL("k2_scatter");
-    std::vector<u32> start(RS_ABINS + 1);
-    CK(hipMemcpy2DAsync(start.data(), 4, matrix, nch * 4, 4, RS_ABINS + 1, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<u32> start(RS2_ABINS + 1);
+    CK(hipMemcpy2DAsync(start.data(), 4, matrix, nch * 4, 4, RS2_ABINS + 1, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
-    start[RS_ABINS] = (u32)n;
+    start[RS2_ABINS] = (u32)n;
     const u64 rs_max = ctx->tune.rs_max_rows ? std::min<u64>(ctx->tune.rs_max_rows, RS_MAX_ROWS) : RS_MAX_ROWS;
     int sb = -1;
     for (int bits = 0; bits <= bA && sb < 0; ++bits) {
@@ -1042,7 +1042,7 @@ int sort_rows_big(dskgpu_ctx* ctx, u64 n) {
         tk = ctx->srt_w[0].as<u64>(); tv = ctx->srt_ab.as<u32>();
     }
     const int total = (int)std::min(64u, 2u * ctx->cfg.kmer_size);
-    const int bA = std::min(10, total);
+    const int bA = std::min(RS_ABITS, total);
     RsSpec sp{total - bA, 0, 0, (1u << bA) - 1u, 0u, 0u};
     const u64 ncu = (u64)ctx->num_cu;
     u64 nch = (n + 65535) / 65536;
@@ -1113,6 +1113,8 @@ int sort_rows_big(dskgpu_ctx* ctx, u64 n) {
 template <int W>
 int sort_rows_huge(dskgpu_ctx* ctx, u64 n) {
     static_assert(W == 1 || W == 2, "one- and two-word rows");
+    constexpr int ABITS = W == 1 ? RS_ABITS : RS2_ABITS;       // first digit of the one- / two-word kernels
+    constexpr u32 ABINS = 1u << ABITS;
     const size_t n_al = (size_t)((n + 31) & ~(u64)31), row_bytes = W == 1 ? 12 : 20, need = n_al * row_bytes + 256;
     u64* k = ctx->out_w[0].as<u64>(); u32* v = ctx->out_ab.as<u32>();
     u64* tk = nullptr; u32* tv = nullptr;              // one-word rows: the scratch copy (becomes the result)
@@ -1130,13 +1132,13 @@ int sort_rows_huge(dskgpu_ctx* ctx, u64 n) {
         else T = Rows2{ctx->srt_w[1].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>()};
     }
     const int total = W == 1 ? (int)std::min(64u, 2u * ctx->cfg.kmer_size) : 2 * (int)ctx->cfg.kmer_size;
-    const int bA = std::min(10, total);
+    const int bA = std::min(ABITS, total);
     const u32 NB = 1u << bA;
     RsSpec sp{total - bA, 0, 0, NB - 1u, 0u, 0u};
     const u64 ncu = (u64)ctx->num_cu;
     const u64 slab = ctx->tune.rs_slab_rows ? std::max<u64>(ctx->tune.rs_slab_rows, 1024) : (1ull << 31);
     const u32 S = (u32)((n + slab - 1) / slab);
-    // per slab: chunks of ~64 K rows (a multiple of the CU count of them), matrix of RS_ABINS x nch counters
+    // per slab: chunks of ~64 K rows (a multiple of the CU count of them), matrix of ABINS x nch counters
     std::vector<u64> s_n(S), s_nch(S), s_chunk(S), s_moff(S + 1, 0);
     for (u32 sl = 0; sl < S; ++sl) {
         const u64 ns = std::min<u64>(slab, n - (u64)sl * slab);
@@ -1147,52 +1149,52 @@ int sort_rows_huge(dskgpu_ctx* ctx, u64 n) {
         const u64 chunk = (ns + nch - 1) / nch;
         nch = (ns + chunk - 1) / chunk;
         s_n[sl] = ns; s_nch[sl] = nch; s_chunk[sl] = chunk;
-        s_moff[sl + 1] = s_moff[sl] + (u64)RS_ABINS * nch + 2;
+        s_moff[sl + 1] = s_moff[sl] + (u64)ABINS * nch + 2;
     }
     CK(ctx->mat2.ensure(s_moff[S] * 4));
     CK(ctx->rs_lens.ensure((size_t)S * 4));
     ctx->h_rs_lens.resize(S);
-    for (u32 sl = 0; sl < S; ++sl) ctx->h_rs_lens[sl] = (u32)((u64)RS_ABINS * s_nch[sl]);
+    for (u32 sl = 0; sl < S; ++sl) ctx->h_rs_lens[sl] = (u32)((u64)ABINS * s_nch[sl]);
     CK(hipMemcpyAsync(ctx->rs_lens.p, ctx->h_rs_lens.data(), (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream));
     u32* sc = ctx->scalars.as<u32>();
     CK(ctx->rs_ovs.ensure((1 + 3 * RS_OVS_CAP) * 4));
-    ctx->h_rs_lin.assign((size_t)S * (RS_ABINS + 1), 0);
+    ctx->h_rs_lin.assign((size_t)S * (ABINS + 1), 0);
     for (u32 sl = 0; sl < S; ++sl) {
         const u64 r0 = (u64)sl * slab;
         u32* matrix = ctx->mat2.as<u32>() + s_moff[sl];
         if (W == 1) hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)s_nch[sl]), dim3(RS_NT), 0, ctx->stream, (const u64*)(k + r0), s_n[sl], (u32)s_chunk[sl], (u32)s_nch[sl], matrix, sp, 0u);
         else { const Rows2C kc{K.hi + r0, K.lo + r0, K.ab + r0}; hipLaunchKernelGGL(k2_hist, dim3((unsigned)s_nch[sl]), dim3(RS_NT), 0, ctx->stream, kc, s_n[sl], (u32)s_chunk[sl], (u32)s_nch[sl], matrix, sp); }
         CKL("k_rs_hist(slab)");
-        { const int e = run_scan(ctx, matrix, ctx->rs_lens.as<u32>() + sl, (u64)RS_ABINS * s_nch[sl]); if (e) return e; }
+        { const int e = run_scan(ctx, matrix, ctx->rs_lens.as<u32>() + sl, (u64)ABINS * s_nch[sl]); if (e) return e; }
         // bucket starts inside the slab (entry b * nch of the scanned matrix; the scan leaves the slab's total behind the last entry)
-        CK(hipMemcpy2DAsync(ctx->h_rs_lin.data() + (size_t)sl * (RS_ABINS + 1), 4, matrix, s_nch[sl] * 4, 4, RS_ABINS + 1, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpy2DAsync(ctx->h_rs_lin.data() + (size_t)sl * (ABINS + 1), 4, matrix, s_nch[sl] * 4, 4, ABINS + 1, hipMemcpyDeviceToHost, ctx->stream));
     }
     CK(hipStreamSynchronize(ctx->stream));
     // the buckets over all rows, and every (slab, bin) pair's place inside its bucket
-    std::vector<u64> B(RS_ABINS + 1, 0);
-    for (u32 b = 0; b < RS_ABINS; ++b) {
+    std::vector<u64> B(ABINS + 1, 0);
+    for (u32 b = 0; b < ABINS; ++b) {
         u64 t = 0;
-        for (u32 sl = 0; sl < S; ++sl) { const u32* lin = ctx->h_rs_lin.data() + (size_t)sl * (RS_ABINS + 1); t += (u64)(lin[b + 1] - lin[b]); }
+        for (u32 sl = 0; sl < S; ++sl) { const u32* lin = ctx->h_rs_lin.data() + (size_t)sl * (ABINS + 1); t += (u64)(lin[b + 1] - lin[b]); }
         B[b + 1] = B[b] + t;
     }
-    if (B[RS_ABINS] != n) return fail(ctx, DSKGPU_E_DEVICE, "row sort: the slabs' histograms do not add up to the rows");
-    ctx->h_rs_del.assign((size_t)S * RS_ABINS, 0);
+    if (B[ABINS] != n) return fail(ctx, DSKGPU_E_DEVICE, "row sort: the slabs' histograms do not add up to the rows");
+    ctx->h_rs_del.assign((size_t)S * ABINS, 0);
     {
         std::vector<u64> at(B.begin(), B.end() - 1);              // next free row of every bucket
         for (u32 sl = 0; sl < S; ++sl) {
-            const u32* lin = ctx->h_rs_lin.data() + (size_t)sl * (RS_ABINS + 1);
-            for (u32 b = 0; b < RS_ABINS; ++b) { ctx->h_rs_del[(size_t)sl * RS_ABINS + b] = at[b] - (u64)lin[b]; at[b] += (u64)(lin[b + 1] - lin[b]); }      // (wraps in 64 bits: added back by the kernel)
+            const u32* lin = ctx->h_rs_lin.data() + (size_t)sl * (ABINS + 1);
+            for (u32 b = 0; b < ABINS; ++b) { ctx->h_rs_del[(size_t)sl * ABINS + b] = at[b] - (u64)lin[b]; at[b] += (u64)(lin[b + 1] - lin[b]); }      // (wraps in 64 bits: added back by the kernel)
         }
     }
     CK(ctx->rs_del.ensure(ctx->h_rs_del.size() * 8));
     CK(hipMemcpyAsync(ctx->rs_del.p, ctx->h_rs_del.data(), ctx->h_rs_del.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     if (W == 1) { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k_rs_scatter<true>)); if (e) return e; }
     else { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_scatter<true>)); if (e) return e; }
-    const size_t ldsA1 = RsLds<RS_ABINS, RS_TILE>::bytes, ldsA2 = Rs2Lds<RS_ABINS, RS2_TILE>::bytes;
+    const size_t ldsA1 = RsLds<RS_ABINS, RS_TILE>::bytes, ldsA2 = Rs2Lds<RS2_ABINS, RS2_TILE>::bytes;
     for (u32 sl = 0; sl < S; ++sl) {
         const u64 r0 = (u64)sl * slab;
         const u32* matrix = ctx->mat2.as<u32>() + s_moff[sl];
-        const u64* gdel = ctx->rs_del.as<u64>() + (size_t)sl * RS_ABINS;
+        const u64* gdel = ctx->rs_del.as<u64>() + (size_t)sl * ABINS;
         if (W == 1) hipLaunchKernelGGL(k_rs_scatter<true>, dim3((unsigned)s_nch[sl]), dim3(RS_NT), ldsA1, ctx->stream, (const u64*)(k + r0), (const u32*)(v + r0), s_n[sl],
                                        (u32)s_chunk[sl], (u32)s_nch[sl], matrix, tk, tv, sp, gdel, 0u);
         else { const Rows2C kc{K.hi + r0, K.lo + r0, K.ab + r0};

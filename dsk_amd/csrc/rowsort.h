@@ -24,7 +24,10 @@
 #define RS_NT 1024                        // step A: one 1024-thread block per chunk, 8192-row tiles
 #define RS_RPT 8
 #define RS_TILE (RS_NT * RS_RPT)
-#define RS_ABINS 1024
+#ifndef RS_ABITS
+#define RS_ABITS 10                       // step A: bits of the first digit (experiments: -DRS_ABITS=11)
+#endif
+#define RS_ABINS (1 << RS_ABITS)
 #define RS_BNT 512                        // step B: 512-thread blocks, 4096-row tiles (52 KB of LDS: three blocks per CU hide each
                                           //   other's memory latency; a heavy bucket is ~20 tiles)
 #define RS_BTILE (RS_BNT * RS_RPT)

@@ -14,6 +14,10 @@
 #pragma once
 #include "rowsort.h"
 
+#ifndef RS2_ABITS
+#define RS2_ABITS 11                      // step A: 2048 buckets (r05: 1.91-1.97 ms against 2.42-2.53 with the one-word sort's 1024 on the k = 63 bench rows --
+#endif                                    //   steps B and C work on 2048- / 256-row units here, half the one-word sort's: half-size buckets suit them)
+#define RS2_ABINS (1 << RS2_ABITS)
 #define RS2_RPT 4                         // rows per thread and tile (20 bytes per row: 4096-row tiles in step A, 2048 in step B)
 #define RS2_TILE (RS_NT * RS2_RPT)
 #define RS2_BTILE (RS_BNT * RS2_RPT)
@@ -51,9 +55,9 @@ struct Rows2C { const u64* hi; const u64* lo; const u32* ab; };
 
 // per-chunk histogram of the first digit -> matrix[bin * nch + chunk]
 __global__ __launch_bounds__(RS_NT) void k2_hist(Rows2C v, u64 n, u32 chunk, u32 nch, u32* __restrict__ matrix, RsSpec sp) {
-    __shared__ u32 lh[RS_ABINS];
+    __shared__ u32 lh[RS2_ABINS];
     const u32 c = blockIdx.x;
-    for (u32 b = threadIdx.x; b < RS_ABINS; b += RS_NT) lh[b] = 0;
+    for (u32 b = threadIdx.x; b < RS2_ABINS; b += RS_NT) lh[b] = 0;
     __syncthreads();
     const u64 beg = (u64)c * chunk;
     const u64 end = beg + chunk < n ? beg + chunk : n;
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(RS_NT) void k2_hist(Rows2C v, u64 n, u32 chunk, u32
         for (int j = 0; j < 8; ++j) if (ok[j]) atomicAdd(&lh[rs2_dig(xh[j], xl[j], sp.shA, sp.mA)], 1u);
     }
     __syncthreads();
-    for (u32 b = threadIdx.x; b < RS_ABINS; b += RS_NT) matrix[(u64)b * nch + c] = lh[b];
+    for (u32 b = threadIdx.x; b < RS2_ABINS; b += RS_NT) matrix[(u64)b * nch + c] = lh[b];
 }
 
 // rows [beg, end) -> their bins, through LDS-staged tiles of NT * RS2_RPT rows (the structure of rs_scatter_range)
@@ -128,14 +132,14 @@ template <bool HUGE = false>
 __global__ __launch_bounds__(RS_NT) void k2_scatter(Rows2C v, u64 n, u32 chunk, u32 nch, const u32* __restrict__ scanned, Rows2 o, RsSpec sp,
                                                     const u64* __restrict__ gdel) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Rs2Lds<RS_ABINS, RS2_TILE> L(smem);
+    const Rs2Lds<RS2_ABINS, RS2_TILE> L(smem);
     const u32 c = blockIdx.x;
-    for (u32 b = threadIdx.x; b < RS_ABINS; b += RS_NT) { L.cur[b] = scanned[(u64)b * nch + c]; L.cnt[b] = 0; }
-    if (threadIdx.x == 0) L.cnt[RS_ABINS] = 0;
+    for (u32 b = threadIdx.x; b < RS2_ABINS; b += RS_NT) { L.cur[b] = scanned[(u64)b * nch + c]; L.cnt[b] = 0; }
+    if (threadIdx.x == 0) L.cnt[RS2_ABINS] = 0;
     lds_barrier();
     const u64 beg = (u64)c * chunk;
     const u64 end = beg + chunk < n ? beg + chunk : n;
-    rs2_scatter_range<RS_ABINS, RS_NT, HUGE>(v, beg, end, o, sp.shA, sp.mA, L, gdel);
+    rs2_scatter_range<RS2_ABINS, RS_NT, HUGE>(v, beg, end, o, sp.shA, sp.mA, L, gdel);
 }
 
 // step B: a block splits one bucket at a time into BB sub-buckets on the second digit; starts (row indices) to sub[b * (BB + 1) ..]
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(RS_BNT) void k2_split(Rows2C v, u32 nch, const u32*
         if (tid == 0) s_b = atomicAdd(work, 1u);
         __syncthreads();
         const u32 b = s_b;
-        if (b >= RS_ABINS) break;
+        if (b >= RS2_ABINS) break;
         const u32 beg = scanned[(u64)b * nch], end = scanned[(u64)(b + 1) * nch];
         if (end - beg > heavy) {
             if (tid == 0) *flag = 1u;
