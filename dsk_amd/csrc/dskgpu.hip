@@ -128,8 +128,6 @@ __global__ void k_gather_back(const u32* __restrict__ sc, const u32* __restrict_
         out[6] = gstats[0]; out[7] = gstats[1]; out[8] = gstats[2]; out[9] = gstats[3];
     }
 }
-// the row sort's two words for the host (its "could not finish in place" flag, the number of listed sub-buckets), put behind the abundance
-// histogram so that the end of a step is ONE copy
 // start of a pass attempt: the device scalars (from kernel arguments), an empty abundance histogram, zeroed statistics -- one launch where a
 // copy and two memsets were four (a memset of 80 008 bytes is two fill kernels)
 struct ScalarSet { u32 v[SC_COUNT]; };
@@ -142,6 +140,8 @@ __global__ __launch_bounds__(256) void k_setup_pass(u32* __restrict__ sc, Scalar
     for (u32 i = t; i < nh; i += gridDim.x * 256) ghist[i] = 0ull;
     for (u64 i = t; i < nzero; i += (u64)gridDim.x * 256) zero[i] = 0u;
 }
+// the row sort's two words for the host (its "could not finish in place" flag, the number of listed sub-buckets), put behind the abundance
+// histogram so that the end of a step is ONE copy
 __global__ void k_sort_back(const u32* __restrict__ sc, const u32* __restrict__ ovs, u64* __restrict__ out) {
     if (threadIdx.x == 0) { out[0] = sc[SC_SORTFLAG]; out[1] = ovs ? ovs[0] : 0u; }
 }
