@@ -581,7 +581,7 @@ def main():
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_vs_measured_copy": round(gbs / HBM_COPY_GBS, 4)}
             d = price(dom)
             roofline = {"bound": "hbm", "kernel": dom, "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
-                        "traffic": None,      # PMC counters are not collected inside a timed run; see traffic_from_profiles
+                        "traffic": None,      # PMC counters are not collected inside a timed run: filled below from the committed PMC passes of this command
                         "peak_measured_copy": HBM_COPY_GBS, "frac_vs_measured_copy": d["frac_vs_measured_copy"],
                         "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "avg_launch_ms": d["avg_launch_ms"],
                         # every partition + hash kernel of the step, priced the same way (HIP events on the launching stream)
@@ -593,6 +593,9 @@ def main():
                     if prof.get("_meta", {}).get("workload") == args.workload and prof.get("_meta", {}).get("kmer_size") == args.kmer_size and world == 1:
                         roofline["traffic_from_profiles"] = {"profile": prof["_meta"].get("id"), "commit": prof["_meta"].get("commit"),
                                                              "hbm_bytes_per_launch": {st: prof[st]["hbm_bytes_per_launch"] for st in roofline["kernels"] if st in prof}}
+                        if dom in prof:      # the dominant kernel's HBM bytes per launch, from those passes (not collected live)
+                            roofline["traffic"] = prof[dom]["hbm_bytes_per_launch"]
+                            roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, %s (commit %s)" % (prof["_meta"].get("id"), prof["_meta"].get("commit"))
                 except Exception:
                     pass
             # the whole step against the same roof: algorithmic bytes of this two-level design (bases read as
