@@ -74,20 +74,26 @@ __global__ __launch_bounds__(256) void k_encode(const uint8_t* __restrict__ s, u
                 x[q] = v;
             }
         }
+        // Four bytes at a time.  Codes: (c >> 1) & 3 of every byte, the four 2-bit fields gathered MSB first by one multiply (byte 0 ->
+        // bits 31..30, byte 1 -> 29..28, ...: no two partial products meet in the top byte).  Validity: a byte is a base iff
+        // (c & 0xC0) == 0x40 and its low five bits are one of A 00001, C 00011, G 00111, T 10100 -- bit (c & 31) of a 32-bit mask
+        // (the shift takes c's low five bits by itself); the per-byte flags are gathered by a second multiply.  (r05: ~6 VALU
+        // instructions per base instead of ~9 -- the kernel is not as memory-bound as its 4.7 TB/s suggest.)
         u64 pk = 0; u32 iv = 0;
+        constexpr u32 BASES = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
+            const u32 xx = x[q];
+            const u32 codes = ((((xx >> 1) & 0x03030303u) * 0x40100401u) >> 24);                       // 8 bits: bases 4q .. 4q + 3
+            const u32 hi = (xx & 0xC0C0C0C0u) ^ 0x40404040u;                                            // zero byte <=> 0x40 <= c < 0x80
+            u32 ok = 0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const u32 c = (x[q] >> (8 * b)) & 0xFFu;
-                const u32 code = (c >> 1) & 3u;
-                // upper-cased byte must equal "ACTG"[code]
-                const u32 expect = (0x47544341u >> (8 * code)) & 0xFFu;
-                const u32 bad = ((c & 0xDFu) != expect) ? 1u : 0u;
-                const int j = q * 4 + b;
-                pk |= (u64)code << (62 - 2 * j);
-                iv |= bad << (31 - j);
-            }
+            for (int b = 0; b < 4; ++b) ok |= ((BASES >> ((xx >> (8 * b)) & 31u)) & 1u) << (8 * b);     // bit 8b: the low five bits name a base
+            const u32 hz = (((hi & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | hi) >> 7;                              // bit 8b: byte b of hi is NOT zero
+            const u32 good = ok & ~hz & 0x01010101u;
+            const u32 bad4 = (((good ^ 0x01010101u) * 0x08040201u) >> 24) & 0xFu;                       // bit 3: byte 0 ... bit 0: byte 3
+            pk |= (u64)codes << (56 - 8 * q);
+            iv |= bad4 << (28 - 4 * q);
         }
         packed[w] = pk;
         inval[w] = iv;
