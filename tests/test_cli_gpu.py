@@ -184,3 +184,33 @@ def test_messy_fastq_at_gb_scale(bins, tmp_path):
         st, hist = kc.stats(), kc.histogram()
     del t
     run_messy_case(bins["dsk"], tmp, n_reads, (st["n_kmers"], st["n_distinct"], st["n_solid"], hist))
+
+
+def test_bench_line_contract():
+    """`python bench.py` prints ONE JSON line with the fields the driver reads (metric / value / unit / n_gpus / steps / warmup /
+    ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus the `roofline` and `cpu_baseline`
+    objects -- checked here on the small workload so that a change to bench.py cannot break the contract unseen.  (The numbers of
+    such a small input mean nothing; the default run is the measurement.)"""
+    import json
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "small", "--steps", "2", "--warmup", "1", "--no-e2e", "--no-k63",
+                        "--no-human-standin", "--no-repeat-rich", "--no-place-compare", "--cpu-sample-reads", "50000"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "u64" and d["data"].startswith("synthetic") and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and abs(d["value"] - d["n_distinct"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == d["unit"]
