@@ -284,6 +284,7 @@ struct dskgpu_ctx {
     // instead of a dense copy made by k_compact (rowsort.h: RsSparse)
     u32 job_passes = 1;            // passes of the running count as run_pipeline sees them (a pass of a record-based multi-pass count runs as "pass 0 of 1" inside run_one_pass)
     struct SparseRows { bool valid = false; RsSparse s{}; u64 n_sparse = 0; const u64* tail_k = nullptr; const u32* tail_v = nullptr; u32 n_tail = 0; } sp_rows;
+    struct SparseRows2 { bool valid = false; Rs2Sparse s{}; u64 n_sparse = 0; Rows2C tail{nullptr, nullptr, nullptr}; u32 n_tail = 0; } sp_rows2;      // (two-word rows)
     // results
     bool have_result = false;
     bool sort_partial = false;
@@ -796,7 +797,8 @@ int msd_sort_pairs(dskgpu_ctx* ctx, u64* k, u32* v, u64* tk, u32* tv, u64 n, int
 // the `total` low bits of hi:lo (t: scratch of the same size).  What it lists (sub-buckets above RS_BLOCK_ROWS rows) is left in
 // ctx->rs_ovs for the caller's next round; a heavy first-digit bucket or a full list raises SC_SORTFLAG.  k holds a complete
 // permutation of the rows either way.
-int msd_sort_rows2(dskgpu_ctx* ctx, Rows2 k, Rows2 t, u64 n, int total, bool reset_flags, u32 base) {
+// spr: step A reads the rows in the count kernel's regions (+ a dense tail: the rows of the k-mers counted apart), as in msd_sort_pairs
+int msd_sort_rows2(dskgpu_ctx* ctx, Rows2 k, Rows2 t, u64 n, int total, bool reset_flags, u32 base, const dskgpu_ctx::SparseRows2* spr = nullptr) {
     int wantB = n <= (96ull << 20) ? 8 : n <= (192ull << 20) ? 9 : 10;
     if (ctx->tune.rs_bbits >= 8 && ctx->tune.rs_bbits <= 10) wantB = (int)ctx->tune.rs_bbits;      // tests
     const int bA = std::min(RS2_ABITS, total), r1 = total - bA, bB = std::min(wantB, r1), r2 = r1 - bB, bC = std::min(8, r2), r3 = r2 - bC;
@@ -806,8 +808,21 @@ int msd_sort_rows2(dskgpu_ctx* ctx, Rows2 k, Rows2 t, u64 n, int total, bool res
     u64 nch = (n + 65535) / 65536;
     nch = (nch + ncu - 1) / ncu * ncu;
     nch = std::max<u64>(1, std::min<u64>(nch, (n + RS2_TILE - 1) / RS2_TILE));
-    const u64 chunk = (n + nch - 1) / nch;
+    u64 chunk = (n + nch - 1) / nch;
     nch = (n + chunk - 1) / chunk;
+    Rs2Sparse sps{}; u64 nch_sp = 0;
+    if (spr) {      // chunks = groups of qpc consecutive sub-partitions (about 64 K rows, at most RS_SP_MAXQ of them) + one chunk for the dense tail
+        sps = spr->s;
+        const u64 F = sps.F;
+        u64 want = std::max<u64>(1, (spr->n_sparse + 65535) / 65536);
+        want = (want + ncu - 1) / ncu * ncu;
+        u64 qpc = std::max<u64>(1, (F + want - 1) / want);
+        if (qpc > RS_SP_MAXQ) qpc = RS_SP_MAXQ;
+        nch_sp = (F + qpc - 1) / qpc;
+        sps.qpc = (u32)qpc;
+        nch = nch_sp + (spr->n_tail ? 1 : 0);
+        chunk = spr->n_tail;
+    }
     const u64 M = (u64)RS2_ABINS * nch;
     const u64 nsubw = (u64)RS2_ABINS * (BB + 1);
     CK(ctx->srt_tmp.ensure((M + 2 + 2 * nsubw + 16) * 4));
@@ -824,11 +839,23 @@ int msd_sort_rows2(dskgpu_ctx* ctx, Rows2 k, Rows2 t, u64 n, int total, bool res
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_scatter<false>)); if (e) return e; }
     { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_big), (int)ldsBig); if (e) return e; }
     const Rows2C kc{k.hi, k.lo, k.ab}, tc{t.hi, t.lo, t.ab};
-    hipLaunchKernelGGL(k2_hist, dim3((unsigned)nch), dim3(RS_NT), 0, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, sp);
-    CKL("k2_hist");
-    { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
-    hipLaunchKernelGGL(k2_scatter<false>, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, t, sp, (const u64*)nullptr);
-    CKL("k2_scatter");
+    if (spr) {
+        const size_t ldsS = ldsA + ((size_t)RS_SP_MAXQ + 1) * 4;
+        { const int e = allow_big_lds(ctx, reinterpret_cast<const void*>(&k2_scatter_sp)); if (e) return e; }
+        hipLaunchKernelGGL(k2_hist_sp, dim3((unsigned)nch_sp), dim3(RS_NT), 0, ctx->stream, sps, (u32)nch, matrix, sp);
+        if (spr->n_tail) hipLaunchKernelGGL(k2_hist, dim3(1), dim3(RS_NT), 0, ctx->stream, spr->tail, (u64)spr->n_tail, (u32)chunk, (u32)nch, matrix, sp, (u32)nch_sp);
+        CKL("k2_hist_sp");
+        { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
+        hipLaunchKernelGGL(k2_scatter_sp, dim3((unsigned)nch_sp), dim3(RS_NT), ldsS, ctx->stream, sps, (u32)nch, (const u32*)matrix, t, sp);
+        if (spr->n_tail) hipLaunchKernelGGL(k2_scatter<false>, dim3(1), dim3(RS_NT), ldsA, ctx->stream, spr->tail, (u64)spr->n_tail, (u32)chunk, (u32)nch, matrix, t, sp, (const u64*)nullptr, (u32)nch_sp);
+        CKL("k2_scatter_sp");
+    } else {
+        hipLaunchKernelGGL(k2_hist, dim3((unsigned)nch), dim3(RS_NT), 0, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, sp, 0u);
+        CKL("k2_hist");
+        { const int e = run_scan(ctx, matrix, sc + SC_RSLEN, M); if (e) return e; }
+        hipLaunchKernelGGL(k2_scatter<false>, dim3((unsigned)nch), dim3(RS_NT), ldsA, ctx->stream, kc, n, (u32)chunk, (u32)nch, matrix, t, sp, (const u64*)nullptr, 0u);
+        CKL("k2_scatter");
+    }
     u32 heavy = (u32)std::min<u64>(0xFFFFFFFFull, n / RS2_ABINS * 64 + 262144);
     if (ctx->tune.rs_heavy) heavy = ctx->tune.rs_heavy;
     const unsigned gridB = (unsigned)std::min<u64>(ncu * (160 * 1024 / (ldsB + 1024)), RS2_ABINS);
@@ -882,7 +909,7 @@ int sort_rows2_msd(dskgpu_ctx* ctx, u64 n) {
     const Rows2 K{ctx->out_w[1].as<u64>(), ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>()};
     const Rows2 T{ctx->srt_w[1].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>()};
     u32* sc = ctx->scalars.as<u32>();
-    { const int e = msd_sort_rows2(ctx, K, T, n, 2 * (int)ctx->cfg.kmer_size, true, 0u); if (e) return e; }
+    { const int e = msd_sort_rows2(ctx, K, T, n, 2 * (int)ctx->cfg.kmer_size, true, 0u, ctx->sp_rows2.valid ? &ctx->sp_rows2 : nullptr); ctx->sp_rows2.valid = false; if (e) return e; }
     { const int e = rows2_rounds(ctx, K, T); if (e) return e; }
     (void)sc;
     ctx->h_ovs.assign(1, 0);
@@ -965,7 +992,7 @@ int sort_rows2_big(dskgpu_ctx* ctx, u64 n) {
 int sort_rows_msd(dskgpu_ctx* ctx, u64 n) {
     const int e = msd_sort_pairs(ctx, ctx->out_w[0].as<u64>(), ctx->out_ab.as<u32>(), ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), n,
                                  (int)std::min(64u, 2u * ctx->cfg.kmer_size), true, 0u, ctx->sp_rows.valid ? &ctx->sp_rows : nullptr);
-    ctx->sp_rows.valid = false;
+    ctx->sp_rows.valid = false; ctx->sp_rows2.valid = false;
     if (e) return e;
     ctx->h_ovs.assign(1, 0);
     ctx->sort_back = 1;      // (flag and sub-bucket count travel with the histogram: run_pipeline)
@@ -1282,13 +1309,15 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     ctx->sort_partial = false;
     ctx->rows2_in_scratch = false;
     ctx->h_ovs.assign(1, 0);
-    if (ctx->sp_rows.valid && (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT) || W != 1)) return fail(ctx, DSKGPU_E_STATE, "row sort: sparse rows on a path that cannot read them");
+    if ((ctx->sp_rows.valid && (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT) || W != 1)) || (ctx->sp_rows2.valid && (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT) || W != 2)))
+        return fail(ctx, DSKGPU_E_STATE, "row sort: sparse rows on a path that cannot read them");
     if (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT)) return DSKGPU_OK;
     if (ctx->sp_rows.valid) {      // the rows of a single one-word pass, still in the count kernel's regions (run_one_pass made sure this sort takes them)
         CK(ctx->srt_w[0].ensure(n * 8)); CK(ctx->srt_ab.ensure(n * 4));
         ctx->fb_src_k = ctx->srt_w[0].as<u64>(); ctx->fb_src_v = ctx->srt_ab.as<u32>(); ctx->fb_dst_k = ctx->out_w[0].as<u64>(); ctx->fb_dst_v = ctx->out_ab.as<u32>();
         return sort_rows_msd(ctx, n);
     }
+    if (ctx->sp_rows2.valid) return sort_rows2_msd(ctx, n);      // (the two-word twin)
     const u64 rs_max = ctx->tune.rs_max_rows ? std::min<u64>(ctx->tune.rs_max_rows, RS_MAX_ROWS) : RS_MAX_ROWS;
     // 2^32 rows and more (or DSKGPU_RS_SLAB_ROWS: tests): step A slab by slab with 64-bit bucket offsets
     if ((n >= 0xFFFF0000ull || ctx->tune.rs_slab_rows) && W <= 2 && (W == 1 || 2u * ctx->cfg.kmer_size > 64u)) return W == 1 ? sort_rows_huge<1>(ctx, n) : sort_rows_huge<2>(ctx, n);
@@ -1571,7 +1600,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                  u32 pass, u32 npass, u64 cap, u64* ns_out, u64* nk_out, Plan* plan_out) {
     typedef typename KeyT<W>::T Key;
     u32* sc = ctx->scalars.as<u32>();
-    ctx->sp_rows.valid = false;
+    ctx->sp_rows.valid = false; ctx->sp_rows2.valid = false;
     int extra_bits = 0;
     for (int attempt = 0;; ++attempt) {
         Plan pl;
@@ -2086,6 +2115,18 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 ctx->sp_rows.n_tail = (u32)nhs;
                 ctx->sp_rows.tail_k = nhs ? ctx->out_w[0].as<u64>() + h_nsolid : nullptr;        // (copied there above: dense, already un-mixed)
                 ctx->sp_rows.tail_v = nhs ? ctx->out_ab.as<u32>() + h_nsolid : nullptr;
+            }
+        }
+        if constexpr (W == 2) {      // (two-word rows: the same, through rowsort2.h's sparse step A -- sort_rows2_msd is what sort_rows picks under these conditions)
+            const u64 rs_max = ctx->tune.rs_max_rows ? std::min<u64>(ctx->tune.rs_max_rows, RS_MAX_ROWS) : RS_MAX_ROWS;
+            sparse_sort = npass == 1 && ctx->job_passes == 1 && ns > 0 && ns <= rs_max && !(ctx->cfg.flags & DSKGPU_F_NO_SORT) && !ctx->tune.fullsort && !ctx->tune.lib_rowsort &&
+                          !ctx->tune.rows2_pairs && !ctx->tune.rs_slab_rows && !ctx->tune.sort_compact && !ctx->bank_job.active && 2u * ctx->cfg.kmer_size > 64u;
+            if (sparse_sort) {
+                ctx->sp_rows2.valid = true;
+                ctx->sp_rows2.s = Rs2Sparse{(const K2*)solid_keys, (const u32*)solid_ab, (const u32*)ctx->nsolid.as<u32>(), (const u32*)ctx->fstart.as<u32>(), opt_cap, pl.F, 0u};
+                ctx->sp_rows2.n_sparse = h_nsolid;
+                ctx->sp_rows2.n_tail = (u32)nhs;
+                ctx->sp_rows2.tail = nhs ? Rows2C{ctx->out_w[1].as<u64>() + h_nsolid, ctx->out_w[0].as<u64>() + h_nsolid, ctx->out_ab.as<u32>() + h_nsolid} : Rows2C{nullptr, nullptr, nullptr};
             }
         }
         if (!sparse_sort) {

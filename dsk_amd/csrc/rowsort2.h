@@ -54,7 +54,8 @@ struct Rows2 { u64* hi; u64* lo; u32* ab; };
 struct Rows2C { const u64* hi; const u64* lo; const u32* ab; };
 
 // per-chunk histogram of the first digit -> matrix[bin * nch + chunk]
-__global__ __launch_bounds__(RS_NT) void k2_hist(Rows2C v, u64 n, u32 chunk, u32 nch, u32* __restrict__ matrix, RsSpec sp) {
+// (c0: first matrix column of this launch, as in k_rs_hist)
+__global__ __launch_bounds__(RS_NT) void k2_hist(Rows2C v, u64 n, u32 chunk, u32 nch, u32* __restrict__ matrix, RsSpec sp, u32 c0 = 0) {
     __shared__ u32 lh[RS2_ABINS];
     const u32 c = blockIdx.x;
     for (u32 b = threadIdx.x; b < RS2_ABINS; b += RS_NT) lh[b] = 0;
@@ -70,12 +71,47 @@ __global__ __launch_bounds__(RS_NT) void k2_hist(Rows2C v, u64 n, u32 chunk, u32
         for (int j = 0; j < 8; ++j) if (ok[j]) atomicAdd(&lh[rs2_dig(xh[j], xl[j], sp.shA, sp.mA)], 1u);
     }
     __syncthreads();
-    for (u32 b = threadIdx.x; b < RS2_ABINS; b += RS_NT) matrix[(u64)b * nch + c] = lh[b];
+    for (u32 b = threadIdx.x; b < RS2_ABINS; b += RS_NT) matrix[(u64)b * nch + c0 + c] = lh[b];
 }
 
+// ---- step A straight from the count kernel's output (two-word rows of a single pass; rowsort.h has the one-word twin): the solid rows
+// of sub-partition q lie where k_count2v3 / k_count_mw left them -- ns_q = soff[q + 1] - soff[q] two-word keys (still MIXED) from key
+// index base(q) on, abundances at the same index of `ab`.  k_compact<2> gathered them into three dense arrays first (0.26 ms at k = 63).
+struct Rs2Sparse { const K2* keys; const u32* ab; const u32* soff; const u32* fstart; u32 cap, F, qpc; };
+__device__ __forceinline__ u64 rs2_sp_base(const Rs2Sparse& s, u32 q) { return s.cap ? (u64)q * s.cap : (u64)s.fstart[q]; }
+__global__ __launch_bounds__(RS_NT) void k2_hist_sp(Rs2Sparse s, u32 nch, u32* __restrict__ matrix, RsSpec sp) {
+    __shared__ u32 lh[RS2_ABINS];
+    const u32 c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (u32 b = threadIdx.x; b < RS2_ABINS; b += RS_NT) lh[b] = 0;
+    __syncthreads();
+    const u32 q0 = c * s.qpc, q1 = q0 + s.qpc < s.F ? q0 + s.qpc : s.F;
+    for (u32 q = q0 + wave; q < q1; q += RS_NT / 64) {
+        const u32 o = s.soff[q], ns = s.soff[q + 1] - o;
+        const u64 b = rs2_sp_base(s, q);
+        for (u32 i = lane; i < ns; i += 64) { K2 kx = s.keys[b + i]; kunmixN(kx); atomicAdd(&lh[rs2_dig(kx.w[1], kx.w[0], sp.shA, sp.mA)], 1u); }
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < RS2_ABINS; b += RS_NT) matrix[(u64)b * nch + c] = lh[b];
+}
+// where a tile's rows come from: three dense arrays, or the sparse regions (lsoff = the chunk's slice of soff in LDS, as in RsSparseSrc)
+struct Rs2DenseSrc {
+    Rows2C v;
+    __device__ __forceinline__ void get(u64 r, u64& h, u64& l, u32& a) const { h = v.hi[r]; l = v.lo[r]; a = v.ab[r]; }
+};
+struct Rs2SparseSrc {
+    Rs2Sparse s; const u32* lsoff; u32 q0, nq;
+    __device__ __forceinline__ void get(u64 r, u64& h, u64& l, u32& a) const {
+        u32 lo = 0, hi = nq;
+        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if ((u64)lsoff[mid] <= r) lo = mid; else hi = mid; }
+        const u64 src = rs2_sp_base(s, q0 + lo) + (r - (u64)lsoff[lo]);
+        K2 kx = s.keys[src]; kunmixN(kx);
+        h = kx.w[1]; l = kx.w[0]; a = s.ab[src];
+    }
+};
+
 // rows [beg, end) -> their bins, through LDS-staged tiles of NT * RS2_RPT rows (the structure of rs_scatter_range)
-template <int P, int NT, bool HUGE = false>
-__device__ __forceinline__ void rs2_scatter_range(Rows2C v, u64 beg, u64 end, Rows2 o, int sh, u32 m, const Rs2Lds<P, NT * RS2_RPT>& L,
+template <int P, int NT, bool HUGE = false, class Src = Rs2DenseSrc>
+__device__ __forceinline__ void rs2_scatter_range(const Src v, u64 beg, u64 end, Rows2 o, int sh, u32 m, const Rs2Lds<P, NT * RS2_RPT>& L,
                                                   const u64* __restrict__ gdel = nullptr) {      // (gdel: see rs_scatter_range)
     constexpr u32 TILE = NT * RS2_RPT;
     const u32 tid = threadIdx.x;
@@ -84,7 +120,7 @@ __device__ __forceinline__ void rs2_scatter_range(Rows2C v, u64 beg, u64 end, Ro
         const u64 left = end - t0;
         const u32 n = left < (u64)TILE ? (u32)left : TILE;
 #pragma unroll
-        for (int j = 0; j < RS2_RPT; ++j) { const u32 i = tid + (u32)j * NT; const u64 src = t0 + (i < n ? i : n - 1); h[j] = v.hi[src]; l[j] = v.lo[src]; a[j] = v.ab[src]; }
+        for (int j = 0; j < RS2_RPT; ++j) { const u32 i = tid + (u32)j * NT; v.get(t0 + (i < n ? i : n - 1), h[j], l[j], a[j]); }
     };
     if (beg < end) load(beg, kh, kl, aa);
     for (u64 t0 = beg; t0 < end; t0 += TILE) {
@@ -130,16 +166,30 @@ __device__ __forceinline__ void rs2_scatter_range(Rows2C v, u64 beg, u64 end, Ro
 // step A: chunk c scatters its rows to the 1024 buckets (offsets from the scanned matrix)
 template <bool HUGE = false>
 __global__ __launch_bounds__(RS_NT) void k2_scatter(Rows2C v, u64 n, u32 chunk, u32 nch, const u32* __restrict__ scanned, Rows2 o, RsSpec sp,
-                                                    const u64* __restrict__ gdel) {
+                                                    const u64* __restrict__ gdel, u32 c0 = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Rs2Lds<RS2_ABINS, RS2_TILE> L(smem);
     const u32 c = blockIdx.x;
-    for (u32 b = threadIdx.x; b < RS2_ABINS; b += RS_NT) { L.cur[b] = scanned[(u64)b * nch + c]; L.cnt[b] = 0; }
+    for (u32 b = threadIdx.x; b < RS2_ABINS; b += RS_NT) { L.cur[b] = scanned[(u64)b * nch + c0 + c]; L.cnt[b] = 0; }
     if (threadIdx.x == 0) L.cnt[RS2_ABINS] = 0;
     lds_barrier();
     const u64 beg = (u64)c * chunk;
     const u64 end = beg + chunk < n ? beg + chunk : n;
-    rs2_scatter_range<RS2_ABINS, RS_NT, HUGE>(v, beg, end, o, sp.shA, sp.mA, L, gdel);
+    rs2_scatter_range<RS2_ABINS, RS_NT, HUGE>(Rs2DenseSrc{v}, beg, end, o, sp.shA, sp.mA, L, gdel);
+}
+// the same from the sparse regions: chunk c = sub-partitions [c * qpc, ..); its slice of soff sits behind the scatter's LDS
+__global__ __launch_bounds__(RS_NT) void k2_scatter_sp(Rs2Sparse s, u32 nch, const u32* __restrict__ scanned, Rows2 o, RsSpec sp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Rs2Lds<RS2_ABINS, RS2_TILE> L(smem);
+    u32* lsoff = reinterpret_cast<u32*>(smem + Rs2Lds<RS2_ABINS, RS2_TILE>::bytes);
+    const u32 c = blockIdx.x;
+    const u32 q0 = c * s.qpc, q1 = q0 + s.qpc < s.F ? q0 + s.qpc : s.F, nq = q1 > q0 ? q1 - q0 : 0u;
+    for (u32 b = threadIdx.x; b < RS2_ABINS; b += RS_NT) { L.cur[b] = scanned[(u64)b * nch + c]; L.cnt[b] = 0; }
+    for (u32 x = threadIdx.x; x <= nq; x += RS_NT) lsoff[x] = s.soff[q0 + x];
+    if (threadIdx.x == 0) L.cnt[RS2_ABINS] = 0;
+    lds_barrier();
+    if (nq == 0) return;
+    rs2_scatter_range<RS2_ABINS, RS_NT, false, Rs2SparseSrc>(Rs2SparseSrc{s, lsoff, q0, nq}, (u64)lsoff[0], (u64)lsoff[nq], o, sp.shA, sp.mA, L);
 }
 
 // step B: a block splits one bucket at a time into BB sub-buckets on the second digit; starts (row indices) to sub[b * (BB + 1) ..]
@@ -188,7 +238,7 @@ __global__ __launch_bounds__(RS_BNT) void k2_split(Rows2C v, u32 nch, const u32*
         __syncthreads();
         for (u32 d = tid; d <= BB; d += RS_BNT) L.cnt[d] = 0;
         __syncthreads();
-        rs2_scatter_range<BB, RS_BNT>(v, beg, end, o, sp.shB, sp.mB, L);
+        rs2_scatter_range<BB, RS_BNT>(Rs2DenseSrc{v}, beg, end, o, sp.shB, sp.mB, L);
     }
 }
 

@@ -1487,6 +1487,17 @@ def test_two_word_row_sort_paths_agree(oracle, dev, monkeypatch):
     monkeypatch.setenv("DSKGPU_ROWS2_PAIRS", "1")
     for k, s in ((63, skew), (35, reads)):
         check_against_oracle(oracle, s, k, dev, amin=1)
+    monkeypatch.delenv("DSKGPU_ROWS2_PAIRS")
+    # r05: step A of the two-word sort reads the rows where the count kernel left them, like the one-word sort (default above);
+    # DSKGPU_SORT_COMPACT = the dense copy first (k_compact<2>) -- the same rows, through both region layouts (fixed-capacity regions and,
+    # with DSKGPU_NO_OPT2, exact offsets), with k-mers counted apart (the skewed input: the dense tail) and with the full-width fallback
+    for env in ({"DSKGPU_SORT_COMPACT": "1"}, {"DSKGPU_NO_OPT2": "1"}, {"DSKGPU_RS_HEAVY": "1000"}):
+        for name, val in env.items():
+            monkeypatch.setenv(name, val)
+        for k, s in ((63, reads), (63, skew), (35, reads), (47, skew)):
+            check_against_oracle(oracle, s, k, dev, amin=1)
+        for name in env:
+            monkeypatch.delenv(name)
 
 
 def test_row_sort_of_huge_row_sets_in_groups(oracle, dev, monkeypatch):
