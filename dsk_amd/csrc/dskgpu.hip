@@ -284,6 +284,9 @@ struct dskgpu_ctx {
     // instead of a dense copy made by k_compact (rowsort.h: RsSparse)
     u32 job_passes = 1;            // passes of the running count as run_pipeline sees them (a pass of a record-based multi-pass count runs as "pass 0 of 1" inside run_one_pass)
     struct SparseRows { bool valid = false; RsSparse s{}; u64 n_sparse = 0; const u64* tail_k = nullptr; const u32* tail_v = nullptr; u32 n_tail = 0; } sp_rows;
+    // multi-pass jobs: where a pass may put its dense rows straight away -- the job's accumulators, from row `rows` on (run_pipeline sets it
+    // once they are sized; run_one_pass sets `took` when it did: the pass's rows are then already appended)
+    struct RowSink { bool active = false, took = false; u32* ab = nullptr; u64* w[4] = {nullptr, nullptr, nullptr, nullptr}; u64 rows = 0, cap = 0; } sink;
     struct SparseRows2 { bool valid = false; Rs2Sparse s{}; u64 n_sparse = 0; Rows2C tail{nullptr, nullptr, nullptr}; u32 n_tail = 0; } sp_rows2;      // (two-word rows)
     // results
     bool have_result = false;
@@ -2089,14 +2092,24 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         // ---------------- dense rows of this pass
         const u64 nhs = nheavy ? ctx->h_stats[1] : 0;                    // solid rows of the k-mers counted apart
         const u64 ns = h_nsolid + nhs;
-        CK(ctx->out_ab.ensure((ns + 1) * 4));
+        // (a pass of a multi-pass job whose accumulators have room: the rows go there directly -- no copy of 0.7 GB per pass afterwards)
+        const bool to_sink = ctx->sink.active && ctx->sink.rows + ns + 1 <= ctx->sink.cap;
         RowsOut ro{};
-        for (int x = 0; x < W; ++x) { CK(ctx->out_w[x].ensure((ns + 1) * 8)); ro.w[x] = ctx->out_w[x].as<u64>(); }
+        u32* rows_ab = nullptr;
+        if (to_sink) {
+            rows_ab = ctx->sink.ab + ctx->sink.rows;
+            for (int x = 0; x < W; ++x) ro.w[x] = ctx->sink.w[x] + ctx->sink.rows;
+            ctx->sink.took = true;
+        } else {
+            CK(ctx->out_ab.ensure((ns + 1) * 4));
+            rows_ab = ctx->out_ab.as<u32>();
+            for (int x = 0; x < W; ++x) { CK(ctx->out_w[x].ensure((ns + 1) * 8)); ro.w[x] = ctx->out_w[x].as<u64>(); }
+        }
         if constexpr (W <= 2) {
           if (nhs) {
             for (int x = 0; x < W; ++x)
-                CK(hipMemcpyAsync(ctx->out_w[x].as<u64>() + h_nsolid, ctx->hv_buf.as<u64>() + HvLayout<W>::rows + (size_t)x * HV_KEYS, nhs * 8, hipMemcpyDeviceToDevice, ctx->stream));
-            CK(hipMemcpyAsync(ctx->out_ab.as<u32>() + h_nsolid, ctx->hv_buf.as<u64>() + HvLayout<W>::ab, nhs * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                CK(hipMemcpyAsync(ro.w[x] + h_nsolid, ctx->hv_buf.as<u64>() + HvLayout<W>::rows + (size_t)x * HV_KEYS, nhs * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            CK(hipMemcpyAsync(rows_ab + h_nsolid, ctx->hv_buf.as<u64>() + HvLayout<W>::ab, nhs * 4, hipMemcpyDeviceToDevice, ctx->stream));
           }
         }
         ctx->stats.n_heavy += nheavy;
@@ -2113,8 +2126,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 ctx->sp_rows.s = RsSparse{(const u64*)solid_keys, (const u32*)solid_ab, (const u32*)ctx->nsolid.as<u32>(), (const u32*)ctx->fstart.as<u32>(), opt_cap, pl.F, 0u};
                 ctx->sp_rows.n_sparse = h_nsolid;
                 ctx->sp_rows.n_tail = (u32)nhs;
-                ctx->sp_rows.tail_k = nhs ? ctx->out_w[0].as<u64>() + h_nsolid : nullptr;        // (copied there above: dense, already un-mixed)
-                ctx->sp_rows.tail_v = nhs ? ctx->out_ab.as<u32>() + h_nsolid : nullptr;
+                ctx->sp_rows.tail_k = nhs ? ro.w[0] + h_nsolid : nullptr;        // (copied there above: dense, already un-mixed)
+                ctx->sp_rows.tail_v = nhs ? rows_ab + h_nsolid : nullptr;
             }
         }
         if constexpr (W == 2) {      // (two-word rows: the same, through rowsort2.h's sparse step A -- sort_rows2_msd is what sort_rows picks under these conditions)
@@ -2126,12 +2139,12 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 ctx->sp_rows2.s = Rs2Sparse{(const K2*)solid_keys, (const u32*)solid_ab, (const u32*)ctx->nsolid.as<u32>(), (const u32*)ctx->fstart.as<u32>(), opt_cap, pl.F, 0u};
                 ctx->sp_rows2.n_sparse = h_nsolid;
                 ctx->sp_rows2.n_tail = (u32)nhs;
-                ctx->sp_rows2.tail = nhs ? Rows2C{ctx->out_w[1].as<u64>() + h_nsolid, ctx->out_w[0].as<u64>() + h_nsolid, ctx->out_ab.as<u32>() + h_nsolid} : Rows2C{nullptr, nullptr, nullptr};
+                ctx->sp_rows2.tail = nhs ? Rows2C{ro.w[1] + h_nsolid, ro.w[0] + h_nsolid, rows_ab + h_nsolid} : Rows2C{nullptr, nullptr, nullptr};
             }
         }
         if (!sparse_sort) {
             hipLaunchKernelGGL(k_compact<W>, dim3((pl.F + 3) / 4), dim3(256), 0, ctx->stream, (const Key*)solid_keys, (const u32*)solid_ab,
-                               ctx->fstart.as<u32>(), ctx->nsolid.as<u32>(), pl.F, ro, ctx->out_ab.as<u32>(), opt_cap);
+                               ctx->fstart.as<u32>(), ctx->nsolid.as<u32>(), pl.F, ro, rows_ab, opt_cap);
             CKL("k_compact");
         }
         ctx->mark("compact");
@@ -2352,6 +2365,7 @@ template <int W>
 int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_keys_in, u64 nkeys_in) {
     typedef typename KeyT<W>::T Key;
     ctx->have_result = false;
+    ctx->sink = dskgpu_ctx::RowSink{};
     if (from_reads) { ctx->st_names.clear(); ctx->st_ms.clear(); }   // from keys: keep the mg_scatter stages of this step
     ctx->marks.clear(); ctx->ev_used = 0;
     const u64 n_upper = from_reads ? ctx->n_bytes : nkeys_in;
@@ -2448,6 +2462,13 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         for (u32 p = 0; p < npass; ++p) {
             u64 ns = 0, nk = 0;
             int rc;
+            ctx->sink = dskgpu_ctx::RowSink{};
+            if (npass > 1 && rows_sized) {      // the pass compacts its rows straight behind the job's (when they fit: run_one_pass)
+                ctx->sink.active = true; ctx->sink.rows = tot_rows; ctx->sink.ab = ctx->acc_ab.as<u32>();
+                u64 cap_rows = ctx->acc_ab.cap / 4;
+                for (int x = 0; x < W; ++x) { ctx->sink.w[x] = ctx->acc_w[x].as<u64>(); cap_rows = std::min<u64>(cap_rows, ctx->acc_w[x].cap / 8); }
+                ctx->sink.cap = cap_rows;
+            }
             if (npass > 1) { ctx->opt1_off = false; ctx->opt2_off = false; ctx->mw_v3_off = false; }      // an overflow is a property of ONE pass (the one that holds a k-mer with 10^8 occurrences): the others keep the fast path
             if (rec_l0) {
                 if (p >= r_hi) {       // the next sweep: as many owners as HBM holds beside a pass's own buffers and the rows still to come
@@ -2503,9 +2524,12 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 CK(hipMemcpyAsync(pass_hist.data(), ctx->ghist.p, pass_hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
                 // grow once: the passes hold similar numbers of rows (hash-uniform), so size for all of them after the first
                 const u64 want_rows = std::max<u64>(tot_rows + ns + 1, p == 0 ? (ns + ns / 8 + 1024) * npass : 0);
+                const bool took = ctx->sink.took;                        // (the rows are in the accumulators already)
+                const u64 keep_rows = tot_rows + (took ? ns : 0);
+                ctx->sink = dskgpu_ctx::RowSink{};
                 auto grow_rows = [&]() {
-                    bool ok = ctx->acc_ab.ensure_keep(want_rows * 4, tot_rows * 4, ctx->stream) == 0;
-                    for (int x = 0; x < W && ok; ++x) ok = ctx->acc_w[x].ensure_keep(want_rows * 8, tot_rows * 8, ctx->stream) == 0;
+                    bool ok = ctx->acc_ab.ensure_keep(want_rows * 4, keep_rows * 4, ctx->stream) == 0;
+                    for (int x = 0; x < W && ok; ++x) ok = ctx->acc_w[x].ensure_keep(want_rows * 8, keep_rows * 8, ctx->stream) == 0;
                     return ok;
                 };
                 if (!grow_rows()) {      // the rows need more than was kept for them: the key arrays of the group's remaining passes give way (those passes get a sweep of their own)
@@ -2515,7 +2539,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                     if (!grow_rows()) return fail(ctx, DSKGPU_E_NOMEM, "row accumulation");
                 }
                 rows_sized = true;
-                if (ns) {
+                if (ns && !took) {
                     CK(hipMemcpyAsync(ctx->acc_ab.as<u32>() + tot_rows, ctx->out_ab.p, ns * 4, hipMemcpyDeviceToDevice, ctx->stream));
                     for (int x = 0; x < W; ++x)
                         CK(hipMemcpyAsync(ctx->acc_w[x].as<u64>() + tot_rows, ctx->out_w[x].p, ns * 8, hipMemcpyDeviceToDevice, ctx->stream));
