@@ -243,8 +243,8 @@ def e2e_block(k, amin, budget_s=150.0):
                 blk["bgzf"] = run_dsk(fq + ".bgzf.gz")
                 if os.path.exists(cli):                       # the CPU restatement's own CLI on the same file
                     cpu = {}
-                    # ("all_cores": up to 32 threads -- the restatement peaks there on the 2 x 64-core host, oracle/dsk_oracle.c; more are slower)
-                    for label, threads in (("all_cores", min(os.cpu_count() or 1, 32)), ("one_thread", 1)):
+                    # ("best_threads": up to 32 threads -- the restatement peaks there on the 2 x 64-core host, oracle/dsk_oracle.c; more are slower)
+                    for label, threads in (("best_threads", min(os.cpu_count() or 1, 32)), ("one_thread", 1)):
                         if label == "one_thread" and time.perf_counter() - t_start > budget_s * 0.5:
                             cpu[label] = {"skipped": "time budget"}
                             continue
@@ -253,8 +253,8 @@ def e2e_block(k, amin, budget_s=150.0):
                                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
                         cpu[label] = {"wall_s": round(time.perf_counter() - t0, 3), "cores": threads, "rc": p.returncode}
                     blk["cpu_restatement_cli"] = cpu
-                    if "wall_s" in blk["plain"] and cpu.get("all_cores", {}).get("wall_s"):
-                        blk["speedup_vs_cpu_restatement_all_cores"] = round(cpu["all_cores"]["wall_s"] / blk["plain"]["wall_s"], 2)
+                    if "wall_s" in blk["plain"] and cpu.get("best_threads", {}).get("wall_s"):
+                        blk["speedup_vs_cpu_restatement_best_threads"] = round(cpu["best_threads"]["wall_s"] / blk["plain"]["wall_s"], 2)
                     if "wall_s" in blk["plain"] and cpu.get("one_thread", {}).get("wall_s"):
                         blk["speedup_vs_cpu_restatement_one_thread"] = round(cpu["one_thread"]["wall_s"] / blk["plain"]["wall_s"], 2)
             out[name] = blk
@@ -582,7 +582,9 @@ def main():
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_vs_measured_copy": round(gbs / HBM_COPY_GBS, 4)}
             d = price(dom)
             roofline = {"bound": "hbm", "kernel": dom, "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
-                        "traffic": None,      # PMC counters are not collected inside a timed run: filled below from the committed PMC passes of this command
+                        "traffic": None,      # PMC counters are not collected inside a timed run (and .git does not travel to the GPU box, so a committed
+                                              # profile cannot be matched to this tree's commit): always null; what an EARLIER profiled run of this command
+                                              # measured is quoted beside it as traffic_from_profiles, with the commit it was taken at
                         "peak_measured_copy": HBM_COPY_GBS, "frac_vs_measured_copy": d["frac_vs_measured_copy"],
                         "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "avg_launch_ms": d["avg_launch_ms"],
                         # every partition + hash kernel of the step, priced the same way (HIP events on the launching stream)
@@ -594,17 +596,28 @@ def main():
                     if prof.get("_meta", {}).get("workload") == args.workload and prof.get("_meta", {}).get("kmer_size") == args.kmer_size and world == 1:
                         roofline["traffic_from_profiles"] = {"profile": prof["_meta"].get("id"), "commit": prof["_meta"].get("commit"),
                                                              "hbm_bytes_per_launch": {st: prof[st]["hbm_bytes_per_launch"] for st in roofline["kernels"] if st in prof}}
-                        if dom in prof:      # the dominant kernel's HBM bytes per launch, from those passes (not collected live)
-                            roofline["traffic"] = prof[dom]["hbm_bytes_per_launch"]
-                            roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, %s (commit %s)" % (prof["_meta"].get("id"), prof["_meta"].get("commit"))
+                        if dom in prof:      # the dominant kernel's HBM bytes per launch, from those passes (an earlier run: not collected live)
+                            roofline["traffic_from_profiles"]["dominant_kernel_hbm_bytes_per_launch"] = prof[dom]["hbm_bytes_per_launch"]
+                            roofline["traffic_from_profiles"]["source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, %s (commit %s)" % (prof["_meta"].get("id"), prof["_meta"].get("commit"))
                 except Exception:
                     pass
-            # the whole step against the same roof: algorithmic bytes of this two-level design (bases read as
-            # ASCII + 2-bit, every key written and read once per level, solid rows written) over the wall time of a step
-            step_bytes = n_bytes * 1.375 + local_kmers * (4 * W) + st["n_solid"] * (W + 4)
+            # the whole step against the same roof, by the contract's figure: per k-mer occurrence the bases read as
+            # ASCII (L/n bytes) + W written by the partition kernels + W read, a (W + 4)-byte slot touched and 4 bytes written by the hash
+            # kernel = 33.25 B at k = 31 / 57.7 B at k = 63 on 150 bp reads; the compaction term (distinct (W + 4) / 0.7 read, solid
+            # (W + 4) written) is reported beside it.  step_design_bytes = what THIS two-level design moves at least (bases as ASCII + 2-bit,
+            # every key written and read once per level, solid rows written) -- until r05 that figure was printed as step_algorithmic_bytes.
+            step_bytes = n_bytes + local_kmers * (3 * W + 8)
+            k6_bytes = st["n_distinct"] * (W + 4) / 0.7 + st["n_solid"] * (W + 4)
             roofline["step_algorithmic_bytes"] = int(step_bytes)
             roofline["step_frac"] = round(step_bytes / per_step / 1e9 / HBM_PEAK_GBS, 4)
             roofline["step_frac_vs_measured_copy"] = round(step_bytes / per_step / 1e9 / HBM_COPY_GBS, 4)
+            roofline["step_algorithmic_bytes_with_compaction_term"] = int(step_bytes + k6_bytes)
+            roofline["step_design_bytes"] = int(n_bytes * 1.375 + local_kmers * (4 * W) + st["n_solid"] * (W + 4))
+            ph = [x for x in ("scatter1", "scatter2", "count") if x in stage_ms]
+            if len(ph) == 3 and world == 1:      # the north_star's "partition + hash kernels" figure: their algorithmic bytes over their summed launch times
+                pb = sum(algorithmic_bytes(x, n_bytes, local_kmers, W, st["n_solid"], sent_w, recv_w) for x in ph)
+                pm = sum(stage_ms[x] for x in ph)
+                roofline["partition_plus_hash"] = {"algorithmic_bytes": int(pb), "ms": round(pm, 4), "frac": round(pb / (pm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         out = {
             "metric": "distinct k-mers counted/sec (whole node), k=%d" % args.kmer_size,
             "value": n_distinct / per_step,

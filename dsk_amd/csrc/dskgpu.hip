@@ -3245,8 +3245,11 @@ int dskgpu_reserve_work(dskgpu_ctx* ctx, uint64_t nbytes) {
             if (want > have && want - have > (u64)free_b * 6 / 10) return fail(ctx, DSKGPU_NOT_RESERVED, "dskgpu_reserve_work: the reservation exceeds 60 % of the free device memory (nothing was reserved; dskgpu_count sizes its own buffers)");
         }
     }
-    CK(ctx->packed.ensure((nwords + 1) * 8));
-    CK(ctx->inval.ensure((nwords + 1) * 4));
+    // (after dskgpu_encode_reads the encoded stream is the ONLY copy of the reads and DevBuf::ensure does not keep contents: it stays)
+    if (!ctx->enc_keep) {
+        CK(ctx->packed.ensure((nwords + 1) * 8));
+        CK(ctx->inval.ensure((nwords + 1) * 4));
+    }
     CK(ctx->bufA.ensure(std::max<u64>((n + n / 8 + (1u << 20)) * key, ctx->W == 1 ? F * cap * 4 : 0)));
     CK(ctx->bufB.ensure((regions * cap + (1u << 16)) * key));
     if (ctx->W > 1) CK(ctx->abund2.ensure((F * cap + (1u << 16)) * 4));

@@ -232,6 +232,9 @@ __global__ __launch_bounds__(RS_BNT) void k_rs_split(const u64* __restrict__ v, 
         if (end - beg > heavy) {                         // one bucket with a large share of all rows (values far from any k-mer spectrum):
             if (tid == 0) *flag = 1u;                    // a single block would take it alone -> leave the rows to the full-width fallback
             for (u32 d = tid; d <= BB; d += RS_BNT) sub[(u64)b * (BB + 1) + d] = d < BB ? beg : end;
+            // (the rows of this bucket still have to reach the output array: a fallback that sorts FROM it -- the per-group library
+            //  sort of sort_rows_big / sort_rows_huge -- wants a complete permutation there, as k2_split leaves one)
+            for (u32 i = beg + tid; i < end; i += RS_BNT) { ov[i] = v[i]; oab[i] = ab[i]; }
             continue;
         }
         for (u32 d = tid; d <= BB; d += RS_BNT) L.cnt[d] = 0;

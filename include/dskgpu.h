@@ -98,13 +98,17 @@ int dskgpu_set_stream(dskgpu_ctx* ctx, void* hip_stream);
 
 /* ---- input: replaces the Bank iteration inside execute() (src/DSK.cpp:51,60) */
 /* Append host bytes of the read stream (copied to the device; may be called
- * repeatedly; a separator is implied between calls). */
+ * repeatedly; a separator is implied between calls).  `bytes` may be reused as soon as the call returns (it is staged), but the
+ * DMA to the device may still be in flight then: an asynchronous copy error is reported by the next call that synchronises
+ * (dskgpu_count, dskgpu_encode_reads, dskgpu_set_stream, a buffer growth), not by this one. */
 int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes);
 /* Optional: size the device-side read buffer once (e.g. from Bank::getSize) instead of growing it push by push. */
 int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes);
 /* Optional: allocate the partition buffers of a count over up to `nbytes` read-stream bytes now (tens of GB of HBM: 0.2 s of
  * hipMalloc on a 10 M-read input) instead of inside the first dskgpu_count.  May run on another host thread WHILE the reads
  * are pushed -- it touches nothing dskgpu_push_reads / dskgpu_reserve_reads use -- but must have returned before dskgpu_count.
+ * Call order: before dskgpu_encode_reads or never -- after it the kept encoding is the only copy of the reads, and this call
+ * then leaves the encoded stream's buffers as they are (it only sizes the partition buffers).
  * Stands where SortingCountAlgorithm's configure step sizes its passes and partitions before execute() fills them. */
 int dskgpu_reserve_work(dskgpu_ctx* ctx, uint64_t nbytes);   /* DSKGPU_OK, DSKGPU_NOT_RESERVED (a soft refusal, see above), or an error */
 /* Use a read stream already resident in HBM (caller keeps ownership and must

@@ -1563,6 +1563,16 @@ def test_row_sort_of_2_pow_32_rows_and_more_slab_by_slab(oracle, dev, monkeypatc
     monkeypatch.setenv("DSKGPU_RS_MAX_ROWS", "3000")                                    # (one-word rows: most 10-bit buckets above the limit -> the library
     st = check_against_oracle(oracle, reads, 31, dev, amin=1)                           #  sort bucket by bucket, the MSD kernels for the small ones)
     assert st["sort_fallback"] == 1, st
+    # a HEAVY first-digit bucket INSIDE a group's MSD sort (k_rs_split flags it and skips it) -- the per-group
+    # library sort then reads the group from the split's output array, which must hold a complete permutation of the group's rows
+    monkeypatch.setenv("DSKGPU_RS_MAX_ROWS", "300000")
+    monkeypatch.setenv("DSKGPU_RS_HEAVY", "1000")
+    for k, s in ((31, reads), (31, skew)):
+        st = check_against_oracle(oracle, s, k, dev, amin=1)
+        assert st["sort_fallback"] == 1, (k, st)
+    monkeypatch.delenv("DSKGPU_RS_SLAB_ROWS")                                           # the same inside sort_rows_big's groups
+    st = check_against_oracle(oracle, reads, 31, dev, amin=1)
+    assert st["n_solid"] > 300000 and st["sort_fallback"] == 1, st
 
 
 def test_multi_pass_count_leaves_the_sender_state_alone(oracle, dev):
