@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--check-parity", action="store_true", help="N > 1: before the timed steps, count the first 1/64 of every rank's shard (a) sharded over the N ranks and "
                                                                 "(b) on rank 0 alone, and require identical totals and histograms (exit code 3 otherwise)")
     ap.add_argument("--no-self-check", action="store_true", help="N > 1: skip the invariants every rank checks on its own result after the timed steps")
+    ap.add_argument("--row-order", choices=("partition", "global"), default="partition",
+                    help="N = 1: order of the solid rows the timed steps produce.  partition (default) = the reference's Partition<Count> contract: "
+                         "ascending inside every output partition (DSKGPU_F_PARTITION_ORDER, one pass over the rows); global = ascending over all rows "
+                         "(three passes).  The other one is timed beside it (ms_per_step_global_order / _partition_order)")
     ap.add_argument("--no-place", action="store_true", help="plain hipMalloc for the big device buffers instead of the best-placed of 8 candidates (DSKGPU_F_PLACE)")
     return ap.parse_args()
 
@@ -413,7 +417,8 @@ def main():
     # the flag is process-wide): reported next to the headline as ms_per_step_no_place
     no_place_ms = None
     if world == 1 and not args.no_place and not args.no_place_compare:
-        with KmerCounter(kmer_size=args.kmer_size, abundance_min=args.abundance_min, device=local_rank, sort=not args.no_sort, stream=stream) as kp:
+        with KmerCounter(kmer_size=args.kmer_size, abundance_min=args.abundance_min, device=local_rank, sort=not args.no_sort, stream=stream,
+                         partition_order=args.row_order == "partition") as kp:
             kp.set_reads_device(reads.data_ptr(), n_bytes)
             for _ in range(3):
                 kp.count()
@@ -424,7 +429,8 @@ def main():
             torch.cuda.synchronize()
             no_place_ms = (time.perf_counter() - tp) / 10 * 1e3
     kc = KmerCounter(kmer_size=args.kmer_size, abundance_min=args.abundance_min, device=local_rank, timing=True,
-                     sort=not args.no_sort, world_size=world, rank=rank, stream=stream, place=not args.no_place and not share_gpu)      # (ranks sharing one GPU: no room for placement candidates)
+                     sort=not args.no_sort, world_size=world, rank=rank, stream=stream, place=not args.no_place and not share_gpu,      # (ranks sharing one GPU: no room for placement candidates)
+                     partition_order=world == 1 and args.row_order == "partition")
     kc.set_reads_device(reads.data_ptr(), n_bytes)
 
     sharded = None
@@ -509,6 +515,22 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     st = kc.stats()
+    # N = 1: the same steps with the OTHER row order (same context, same buffers), outside the timed region
+    other_order_ms = None
+    if world == 1 and not args.no_sort and not args.no_place_compare:
+        kc.set_row_order(args.row_order != "partition")
+        for _ in range(2):
+            kc.count()
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(10):
+            kc.count()
+        torch.cuda.synchronize()
+        other_order_ms = (time.perf_counter() - tp) / 10 * 1e3
+        other_stage = dict(kc.stage_times())
+        kc.set_row_order(args.row_order == "partition")
+        kc.count()                      # (the result the checks below look at is the timed configuration's)
+        torch.cuda.synchronize()
 
     # ---- N > 1: every rank checks its own share of the result, the job-wide sums are checked after the reductions below -- a wrong
     # exchange must not print a `value` (exit code 3)
@@ -648,6 +670,10 @@ def main():
                                   "candidates": 8}),
             "first_step_s": round(first_step_s, 3),
             "ms_per_step_no_place": None if no_place_ms is None else round(no_place_ms, 3),
+            "row_order": ("partition: ascending inside each of %d output partitions -- the reference's Partition<Count> contract (utils/dsk2ascii.cpp:61,77,85-104), DSKGPU_F_PARTITION_ORDER" % st["n_partitions"])
+                         if (world == 1 and args.row_order == "partition" and not args.no_sort) else "global: ascending over all rows",
+            ("ms_per_step_global_order" if args.row_order == "partition" else "ms_per_step_partition_order"): None if other_order_ms is None else round(other_order_ms, 3),
+            "sort_ms_other_row_order": None if other_order_ms is None else round(other_stage.get("sort", 0.0), 3),
             "roofline": roofline,
         }
         if world > 1:
@@ -695,7 +721,7 @@ def main():
         # (same placement setting); the headline above stays k = 31.
         if world == 1 and not args.no_k63 and args.kmer_size == 31 and rl >= 63:
             with KmerCounter(kmer_size=63, abundance_min=args.abundance_min, device=local_rank, timing=True, sort=not args.no_sort,
-                             stream=stream, place=not args.no_place) as k2:
+                             stream=stream, place=not args.no_place, partition_order=args.row_order == "partition") as k2:
                 k2.set_reads_device(reads.data_ptr(), n_bytes)
                 for _ in range(max(2, args.warmup)):
                     k2.count()

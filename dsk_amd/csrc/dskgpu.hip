@@ -15,6 +15,7 @@
 #include "superkmer.h"
 #include "rowsort.h"
 #include "rowsort2.h"
+#include "partsort.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -175,6 +176,8 @@ struct Tuning {
     bool verbose = false;                       // DSKGPU_VERBOSE: trace of the plan decisions on stderr
     bool no_level0 = false; u32 l0_passes = 0;  // DSKGPU_NO_LEVEL0: every pass of a multi-pass count re-generates its keys; DSKGPU_L0_PASSES=n: passes per level-0 sweep (tests)
     u64 rs_max_rows = 0;                        // DSKGPU_RS_MAX_ROWS: most rows the MSD row sort takes in one piece (tests: the group-wise path of huge row sets on a small input)
+    u32 ps_maxc = 0;                            // DSKGPU_PS_MAXC: rows sharing a value bin that the partition-order sort still orders (tests: 1 provokes its fallback to the global order)
+    bool sk_generic = false;                    // DSKGPU_SK_GENERIC: the sender kernels with k and m at run time even for k = 31 / 63 (tests: both forms write the same records)
     bool l0_keys = false;                       // DSKGPU_L0_KEYS: level 0 as key arrays (k_level0) even where the record-based one applies (experiments, tests)
     u32 mp_pass_mkeys = 0;                      // DSKGPU_MP_PASS_MKEYS: keys (millions) per pass of an input that needs several passes (default 1000)
     bool sort_compact = false;                  // DSKGPU_SORT_COMPACT: k_compact + dense step A (the path before r05: A/B runs; still the path of several passes and wide keys)
@@ -189,7 +192,7 @@ struct Tuning {
         sk_slice = num("DSKGPU_SK_SLICE", 0); sk_minslice = num("DSKGPU_SK_MINSLICE", 2000);
         table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
         max_ext = getenv("DSKGPU_MAX_EXT") ? atoll(getenv("DSKGPU_MAX_EXT")) : -1;
-        no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); no_level0 = on("DSKGPU_NO_LEVEL0"); l0_passes = (u32)num("DSKGPU_L0_PASSES", 0); mp_pass_mkeys = (u32)num("DSKGPU_MP_PASS_MKEYS", 0); rs_max_rows = num("DSKGPU_RS_MAX_ROWS", 0); l0_keys = on("DSKGPU_L0_KEYS");
+        no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); no_level0 = on("DSKGPU_NO_LEVEL0"); l0_passes = (u32)num("DSKGPU_L0_PASSES", 0); mp_pass_mkeys = (u32)num("DSKGPU_MP_PASS_MKEYS", 0); rs_max_rows = num("DSKGPU_RS_MAX_ROWS", 0); l0_keys = on("DSKGPU_L0_KEYS"); sk_generic = on("DSKGPU_SK_GENERIC"); ps_maxc = (u32)num("DSKGPU_PS_MAXC", 0);
         rs_slab_rows = num("DSKGPU_RS_SLAB_ROWS", 0); sort_compact = on("DSKGPU_SORT_COMPACT");
         lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rows2_pairs = on("DSKGPU_ROWS2_PAIRS"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0); rs_heavy = (u32)num("DSKGPU_RS_HEAVY", 0);
     }
@@ -291,6 +294,11 @@ struct dskgpu_ctx {
     // results
     bool have_result = false;
     bool sort_partial = false;
+    // DSKGPU_F_PARTITION_ORDER (partsort.h): the rows ascending inside each output partition only.  part_mode: the last result is laid
+    // out that way, h_part_off[p] = first row of partition p (n_parts + 1 entries, pinned); part_off_this_count: the flag was raised
+    // (a partition or a bin above what a block orders) and this count takes the global sort instead
+    bool part_mode = false, part_off_this_count = false; u32 n_parts = 0; u32* h_part_off = nullptr; size_t h_part_cap = 0; DevBuf part_off;
+    SparseRows sp_rows_saved;
     bool rows2_in_scratch = false; Rows2 rows2_scratch{};      // two-word rows above RS_MAX_ROWS: the result (and the fallback's input) is the scratch copy
     u64 n_rows = 0;
     const u64* res_w[4] = {nullptr, nullptr, nullptr, nullptr}; const u32* res_ab = nullptr;
@@ -1304,6 +1312,41 @@ int sort_rows_huge(dskgpu_ctx* ctx, u64 n) {
     return DSKGPU_OK;
 }
 
+// ---- DSKGPU_F_PARTITION_ORDER: one-word rows of a single pass, ordered inside output partitions of <= PS_CAP rows by one LDS pass
+// (partsort.h).  In: the sparse rows (ctx->sp_rows).  Out: srt_w[0] / srt_ab dense, partition after partition; part_off on the device
+// and (after the caller's synchronisation) in h_part_off; SC_SORTFLAG raised when a block could not order its partition.
+int sort_rows_partition_order(dskgpu_ctx* ctx, u64 n) {
+    const dskgpu_ctx::SparseRows spr = ctx->sp_rows;
+    ctx->sp_rows_saved = spr;
+    ctx->sp_rows.valid = false; ctx->sp_rows2.valid = false;
+    const u64 F = spr.s.F;
+    const u64 mean = std::max<u64>(1, (spr.n_sparse + F - 1) / std::max<u64>(F, 1));
+    const u32 qpp = (u32)std::min<u64>(std::max<u64>(1, (u64)(PS_CAP * 3 / 4) / mean), PS_MAXQ);
+    const u32 nps = (u32)((F + qpp - 1) / qpp), nparts = nps + (spr.n_tail ? 1u : 0u);
+    CK(ctx->srt_w[0].ensure(n * 8)); CK(ctx->srt_ab.ensure(n * 4));
+    CK(ctx->part_off.ensure(((size_t)nparts + 2) * 4));
+    if (ctx->h_part_cap < (size_t)nparts + 2) {
+        if (ctx->h_part_off) CK(hipHostFree(ctx->h_part_off));
+        ctx->h_part_off = nullptr; ctx->h_part_cap = 0;
+        CK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_part_off), ((size_t)nparts + 2) * 4 * 2, hipHostMallocDefault));
+        ctx->h_part_cap = ((size_t)nparts + 2) * 2;
+    }
+    u32* sc = ctx->scalars.as<u32>();
+    hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, 0u, 1u, sc + SC_SORTFLAG, (u32*)nullptr);
+    const int sh = std::max(0, (int)std::min(64u, 2u * ctx->cfg.kmer_size) - 12);
+    const PsParams pp{qpp, nps, sh, spr.n_tail, ctx->tune.ps_maxc ? std::min<u32>(ctx->tune.ps_maxc, PS_MAXC) : PS_MAXC};
+    hipLaunchKernelGGL(k_part_sort, dim3(nparts), dim3(PS_NT), 0, ctx->stream, spr.s, spr.tail_k, spr.tail_v, pp,
+                       ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), ctx->part_off.as<u32>(), sc + SC_SORTFLAG);
+    CKL("k_part_sort");
+    CK(hipMemcpyAsync(ctx->h_part_off, ctx->part_off.p, ((size_t)nparts + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->part_mode = true; ctx->n_parts = nparts;
+    ctx->h_ovs.assign(1, 0);
+    ctx->sort_back = 2;            // (the flag travels with the histogram: run_pipeline)
+    ctx->sort_partial = false;
+    ctx->res_w[0] = ctx->srt_w[0].as<u64>(); ctx->res_ab = ctx->srt_ab.as<u32>();
+    return DSKGPU_OK;
+}
+
 // ---- result post-processing: sort rows by k-mer value
 int sort_rows(dskgpu_ctx* ctx, u64 n) {
     const int W = ctx->W;
@@ -1311,10 +1354,12 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     ctx->res_ab = ctx->out_ab.as<u32>();
     ctx->sort_partial = false;
     ctx->rows2_in_scratch = false;
+    ctx->part_mode = false;
     ctx->h_ovs.assign(1, 0);
     if ((ctx->sp_rows.valid && (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT) || W != 1)) || (ctx->sp_rows2.valid && (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT) || W != 2)))
         return fail(ctx, DSKGPU_E_STATE, "row sort: sparse rows on a path that cannot read them");
     if (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT)) return DSKGPU_OK;
+    if (ctx->sp_rows.valid && (ctx->cfg.flags & DSKGPU_F_PARTITION_ORDER) && !ctx->part_off_this_count && n < 0xFFFF0000ull) return sort_rows_partition_order(ctx, n);
     if (ctx->sp_rows.valid) {      // the rows of a single one-word pass, still in the count kernel's regions (run_one_pass made sure this sort takes them)
         CK(ctx->srt_w[0].ensure(n * 8)); CK(ctx->srt_ab.ensure(n * 4));
         ctx->fb_src_k = ctx->srt_w[0].as<u64>(); ctx->fb_src_v = ctx->srt_ab.as<u32>(); ctx->fb_dst_k = ctx->out_w[0].as<u64>(); ctx->fb_dst_v = ctx->out_ab.as<u32>();
@@ -2276,6 +2321,11 @@ int level0_materialise(dskgpu_ctx* ctx, u64 nwords, u32 lo, u32 npass, u64 reser
 // doc/paper.tex:65-67 for the passes).  Needs 20 <= k <= 64 (records) and <= SK_MAX_OWNERS passes; anything else, or a slice
 // of the sampled layout that overflows, takes the key-array level 0 / the pass filter instead (ctx->rec_l0_off).
 void sk_geometry(dskgpu_ctx* ctx, u64 nwords);
+// the sender kernels with k and m at compile time for the BASELINE configs (superkmer.h: sk_tile_fx), at run time otherwise
+#define SK_DISPATCH(ctx_, SP_, CALL) do { \
+        if (!(ctx_)->tune.sk_generic && (SP_).k == 31 && (SP_).m == 10) { CALL(31, 10); } \
+        else if (!(ctx_)->tune.sk_generic && (SP_).k == 63 && (SP_).m == 10) { CALL(63, 10); } \
+        else { CALL(0, 0); } } while (0)
 int upload_table(dskgpu_ctx* ctx);
 struct RecL0 { u32 G = 0; u64 nch = 0; u32 slice[SK_MAX_OWNERS] = {0}; u64 region[SK_MAX_OWNERS] = {0}; };      // region[o]: records of owner o's region (nch * slice[o])
 #define REC_L0_NO 2001             // rec_l0_prepare / _sweep: this input does not take the record path (not an error)
@@ -2291,7 +2341,9 @@ int rec_l0_prepare(dskgpu_ctx* ctx, u64 nwords, u32 G, RecL0* rl) {
         SkParams ss = sp; ss.sample_step = step; ss.table = nullptr;
         CK(ctx->sk_load.ensure((size_t)SK_BUCKETS * 8));
         CK(hipMemsetAsync(ctx->sk_load.p, 0, (size_t)SK_BUCKETS * 8, ctx->stream));
-        hipLaunchKernelGGL(k_sk_sample, dim3(ss.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), ss, ctx->sk_load.as<unsigned long long>());
+#define SK_CALL(K_, M_) hipLaunchKernelGGL((k_sk_sample<K_, M_>), dim3(ss.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), ss, ctx->sk_load.as<unsigned long long>())
+        SK_DISPATCH(ctx, ss, SK_CALL);
+#undef SK_CALL
         CKL("k_sk_sample");
         std::vector<uint64_t> loads(SK_BUCKETS);
         CK(hipMemcpyAsync(loads.data(), ctx->sk_load.p, (size_t)SK_BUCKETS * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -2308,8 +2360,10 @@ int rec_l0_prepare(dskgpu_ctx* ctx, u64 nwords, u32 G, RecL0* rl) {
     CK(ctx->sk_sent.ensure(3 * SK_MAX_OWNERS * 8));
     CK(hipMemsetAsync(ctx->sk_sent.as<u64>() + SK_MAX_OWNERS, 0, SK_MAX_OWNERS * 8, ctx->stream));
     sp.sample_step = step;
-    hipLaunchKernelGGL(k_sk_hist, dim3((unsigned)nch), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, ctx->mat1.as<u32>(),
-                       ctx->sk_sent.as<unsigned long long>() + SK_MAX_OWNERS);
+#define SK_CALL(K_, M_) hipLaunchKernelGGL((k_sk_hist<K_, M_>), dim3((unsigned)nch), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, ctx->mat1.as<u32>(), \
+                                          ctx->sk_sent.as<unsigned long long>() + SK_MAX_OWNERS)
+    SK_DISPATCH(ctx, sp, SK_CALL);
+#undef SK_CALL
     CKL("k_sk_hist");
     std::vector<u32> cells(M);
     CK(hipMemcpyAsync(cells.data(), ctx->mat1.p, M * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2346,8 +2400,10 @@ int rec_l0_sweep(dskgpu_ctx* ctx, const RecL0& rl, u32 olo, u32 ohi, u64 (&base_
     u32* sc = ctx->scalars.as<u32>();
     CK(hipMemsetAsync(ctx->sk_sent.p, 0, SK_MAX_OWNERS * 8, ctx->stream));
     CK(hipMemsetAsync(sc + SC_OVF1, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_sk_scatter<true>, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
-                       (const unsigned long long*)nullptr, ctx->l0buf.as<u64>(), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>());
+#define SK_CALL(K_, M_) hipLaunchKernelGGL((k_sk_scatter<true, K_, M_>), dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, \
+                                          (const unsigned long long*)nullptr, ctx->l0buf.as<u64>(), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>())
+    SK_DISPATCH(ctx, sp, SK_CALL);
+#undef SK_CALL
     CKL("k_sk_scatter(passes)");
     ctx->mark("level0");
     CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2570,6 +2626,8 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             for (int x = 0; x < W; ++x) std::swap(ctx->out_w[x], ctx->acc_w[x]);
         }
         int rc;
+        ctx->part_off_this_count = false;
+      sort_again:
         ctx->sort_back = 0;
         if ((rc = sort_rows(ctx, tot_rows))) return rc;
         ctx->mark("sort");
@@ -2594,6 +2652,12 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         } else {
             if (npass == 1) CK(hipMemcpyAsync(ctx->hist.data(), ctx->ghist.p, ctx->hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
             CK(hipStreamSynchronize(ctx->stream));
+        }
+        if (ctx->part_mode && ctx->h_back[3]) {      // a partition (or a value bin of one) above what a block orders in LDS: the global sort, on the same sparse rows
+            if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] row sort: a partition exceeds what one block orders -- global order instead of partition order\n");
+            ctx->part_mode = false; ctx->part_off_this_count = true; ctx->h_back[3] = 0;
+            ctx->sp_rows = ctx->sp_rows_saved;
+            goto sort_again;
         }
         if (W == 1 && ctx->sort_partial && tot_rows && !ctx->h_back[3] && !ctx->h_ovs.empty() && ctx->h_ovs[0]) {
             if ((rc = sort_oversize(ctx))) return rc;      // sub-buckets the sort listed for another round on their remaining bits
@@ -2635,6 +2699,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             for (int x = 0; x < W; ++x) std::swap(ctx->out_w[x], ctx->acc_w[x]);
         }
         u32 np = ctx->cfg.nb_partitions ? ctx->cfg.nb_partitions : 4u;
+        if (ctx->part_mode) np = ctx->n_parts;      // (partition order: the partitions are what the blocks of k_part_sort ordered)
         ctx->stats.n_partitions = np;
         ctx->have_result = true;
         return DSKGPU_OK;
@@ -2692,6 +2757,7 @@ int upload_table(dskgpu_ctx* ctx) {
         ctx->table_dirty = false;
     }
     ctx->sk_sp.table = ctx->sk_table.as<unsigned char>();
+    ctx->sk_sp.has_split = std::find(ctx->h_table.begin(), ctx->h_table.end(), (uint8_t)SK_SPLIT) != ctx->h_table.end() ? 1u : 0u;
     return DSKGPU_OK;
 }
 // tiles / chunks of the sender kernels over the encoded stream
@@ -2699,7 +2765,9 @@ void sk_geometry(dskgpu_ctx* ctx, u64 nwords) {
     SkParams& sp = ctx->sk_sp;
     sp.ngroups = nwords * 2;
     sp.ntiles = std::max<u64>(1, (sp.ngroups + SK_GROUPS - 1) / SK_GROUPS);
-    u64 nch = std::min<u64>(std::max<u64>(1, sp.ntiles / 8), (u64)ctx->num_cu * 8);     // >= 8 tiles per chunk when there are that many
+    // whole rounds of blocks: the k = 31 kernels (68 VGPRs, 50 KB of LDS) run three 512-thread blocks per CU, the others two
+    const u64 per_cu = (!ctx->tune.sk_generic && sp.k == 31 && sp.m == 10) ? 9 : 8;
+    u64 nch = std::min<u64>(std::max<u64>(1, sp.ntiles / 8), (u64)ctx->num_cu * per_cu);     // >= 8 tiles per chunk when there are that many
     const u64 tpc = (sp.ntiles + nch - 1) / nch;
     nch = (sp.ntiles + tpc - 1) / tpc;
     sp.tiles_per_chunk = (u32)tpc; sp.nchunks = (u32)nch;
@@ -2739,8 +2807,10 @@ int sk_prepare(dskgpu_ctx* ctx) {
     sp.sample_step = slices ? 16u : 1u;
     CK(ctx->sk_sent.ensure(3 * SK_MAX_OWNERS * 8));            // [k-mers sent per owner | sampled k-mers per owner | overflow flag of a sliced step]
     CK(hipMemsetAsync(ctx->sk_sent.as<u64>() + SK_MAX_OWNERS, 0, SK_MAX_OWNERS * 8, ctx->stream));
-    hipLaunchKernelGGL(k_sk_hist, dim3((unsigned)nch), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, ctx->mat1.as<u32>(),
-                       ctx->sk_sent.as<unsigned long long>() + SK_MAX_OWNERS);
+#define SK_CALL(K_, M_) hipLaunchKernelGGL((k_sk_hist<K_, M_>), dim3((unsigned)nch), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, ctx->mat1.as<u32>(), \
+                                          ctx->sk_sent.as<unsigned long long>() + SK_MAX_OWNERS)
+    SK_DISPATCH(ctx, sp, SK_CALL);
+#undef SK_CALL
     CKL("k_sk_hist");
     CK(hipMemcpyAsync(ctx->h_sk_est, ctx->sk_sent.as<u64>() + SK_MAX_OWNERS, SK_MAX_OWNERS * 8, hipMemcpyDeviceToHost, ctx->stream));
     ctx->mark("mg_hist");
@@ -2795,11 +2865,16 @@ int sk_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t*
     CK(hipMemsetAsync(ctx->sk_sent.p, 0, SK_MAX_OWNERS * 8, ctx->stream));
     if (ctx->sk_slices) {
         CK(hipMemsetAsync(sc + SC_OVF1, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(k_sk_scatter<true>, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
-                           (const unsigned long long*)nullptr, static_cast<u64*>(d_send), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>());
-    } else
-        hipLaunchKernelGGL(k_sk_scatter<false>, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
-                           (const unsigned long long*)ctx->sk_cb64.as<unsigned long long>(), static_cast<u64*>(d_send), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>());
+#define SK_CALL(K_, M_) hipLaunchKernelGGL((k_sk_scatter<true, K_, M_>), dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, \
+                                          (const unsigned long long*)nullptr, static_cast<u64*>(d_send), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>())
+        SK_DISPATCH(ctx, sp, SK_CALL);
+#undef SK_CALL
+    } else {
+#define SK_CALL(K_, M_) hipLaunchKernelGGL((k_sk_scatter<false, K_, M_>), dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, \
+                                          (const unsigned long long*)ctx->sk_cb64.as<unsigned long long>(), static_cast<u64*>(d_send), sc + SC_OVF1, ctx->sk_sent.as<unsigned long long>())
+        SK_DISPATCH(ctx, sp, SK_CALL);
+#undef SK_CALL
+    }
     CKL("k_sk_scatter");
     ctx->mark("mg_scatter");
     if (ctx->sk_slices) CK(hipMemcpyAsync(&ctx->h_ovf1, sc + SC_OVF1, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2853,10 +2928,13 @@ int sk_scatter_slice(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, u32
     sp.c0 = cb; sp.c0g = cb; sp.clen = ce - cb; sp.rbase = (u64)cb * sp.G * sp.slice;
     // (the overflow flag of a sliced step lives apart from the scalars: the receiver's pipeline, which runs before the flag is
     //  read, resets those)
-    if (ce > cb)
-        hipLaunchKernelGGL(k_sk_scatter<true>, dim3(ce - cb), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
-                           (const unsigned long long*)nullptr, static_cast<u64*>(d_send), reinterpret_cast<u32*>(ctx->sk_sent.as<u64>() + 2 * SK_MAX_OWNERS),
-                           ctx->sk_sent.as<unsigned long long>());
+    if (ce > cb) {
+#define SK_CALL(K_, M_) hipLaunchKernelGGL((k_sk_scatter<true, K_, M_>), dim3(ce - cb), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, \
+                                          (const unsigned long long*)nullptr, static_cast<u64*>(d_send), reinterpret_cast<u32*>(ctx->sk_sent.as<u64>() + 2 * SK_MAX_OWNERS), \
+                                          ctx->sk_sent.as<unsigned long long>())
+        SK_DISPATCH(ctx, sp, SK_CALL);
+#undef SK_CALL
+    }
     CKL("k_sk_scatter");
     if (sl + 1 == ctx->sk_nslices) ctx->mark("mg_scatter");
     return DSKGPU_OK;
@@ -3139,6 +3217,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
                       &ctx->sk_sums, &ctx->sk_cbase, &ctx->sk_keys, &ctx->sk_table, &ctx->sk_load, &ctx->sk_sent, &ctx->cur_state, &ctx->rs_ovs, &ctx->smp_keys, &ctx->sk_lay, &ctx->fix_list, &ctx->sk_cb64, &ctx->rs_del, &ctx->rs_lens, &ctx->back_dev};
     if (ctx->back_host) (void)hipHostFree(ctx->back_host);
     if (ctx->hist_pin) (void)hipHostFree(ctx->hist_pin);
+    if (ctx->h_part_off) (void)hipHostFree(ctx->h_part_off);
     if (ctx->land) (void)hipHostFree(ctx->land);
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i) { ctx->rs_g[i].release(); ctx->out_w[i].release(); ctx->srt_w[i].release(); ctx->acc_w[i].release(); ctx->u_w[i].release(); ctx->s_w[i].release(); }
@@ -3355,8 +3434,10 @@ int dskgpu_mg_sample(dskgpu_ctx* ctx, uint64_t* loads) {
     sp.table = nullptr;
     CK(ctx->sk_load.ensure((size_t)SK_BUCKETS * 8));
     CK(hipMemsetAsync(ctx->sk_load.p, 0, (size_t)SK_BUCKETS * 8, ctx->stream));
-    hipLaunchKernelGGL(k_sk_sample, dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp,
-                       ctx->sk_load.as<unsigned long long>());
+#define SK_CALL(K_, M_) hipLaunchKernelGGL((k_sk_sample<K_, M_>), dim3(sp.nchunks), dim3(SK_NT), 0, ctx->stream, ctx->packed.as<u64>(), ctx->inval.as<u32>(), sp, \
+                                          ctx->sk_load.as<unsigned long long>())
+    SK_DISPATCH(ctx, sp, SK_CALL);
+#undef SK_CALL
     CKL("k_sk_sample");
     CK(hipMemcpyAsync(loads, ctx->sk_load.p, (size_t)SK_BUCKETS * 8, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
@@ -3486,9 +3567,16 @@ int dskgpu_histogram(const dskgpu_ctx* ctx, uint64_t* out, uint32_t nbins) {
     return DSKGPU_OK;
 }
 
+int dskgpu_set_row_order(dskgpu_ctx* ctx, int partition_order) {
+    if (!ctx) return DSKGPU_E_ARG;
+    if (partition_order) ctx->cfg.flags |= DSKGPU_F_PARTITION_ORDER; else ctx->cfg.flags &= ~DSKGPU_F_PARTITION_ORDER;
+    return DSKGPU_OK;
+}
+
 uint32_t dskgpu_num_partitions(const dskgpu_ctx* ctx) { return (ctx && ctx->have_result) ? ctx->stats.n_partitions : 0; }
 
 static void part_range(const dskgpu_ctx* ctx, uint32_t p, u64* b, u64* e) {
+    if (ctx->part_mode) { *b = ctx->h_part_off[p]; *e = ctx->h_part_off[p + 1]; return; }
     const u64 P = ctx->stats.n_partitions, n = ctx->n_rows;
     *b = n * p / P; *e = n * (p + 1) / P;
 }

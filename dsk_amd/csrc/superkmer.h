@@ -50,6 +50,7 @@ struct SkParams {
     u32 c0, c0g, clen;
     u64 rbase;                    // (64-bit: a rank's shard of a 90 Gbp job holds more than 2^32 records' worth of slices)
     const unsigned char* table;   // SK_BUCKETS owners (device memory)
+    u32 has_split;                // the table holds SK_SPLIT entries (set with the table: the kernels skip the split bookkeeping otherwise)
     // k_sk_scatter<true> for the passes of a multi-pass count on ONE GPU ("virtual owners": owner = pass; dskgpu.hip: rec_l0_*): only
     // the records of owners [olo, ohi) are written (a sweep materialises as many passes as HBM holds), every owner has its own slice
     // length oslice[o] (a pass that holds a k-mer with 10^8 occurrences gets longer slices, the others do not pay for it) and its
@@ -217,6 +218,142 @@ __device__ __forceinline__ SkThread sk_tile(const u64* __restrict__ packed, cons
     return r;
 }
 
+// ---------------------------------------------------------------- the same tile with k and m known at compile time
+// Round 6 (profiles/r06_records.md): the sender is paced by its instruction count -- 64 VALU instructions per window, the vector
+// ALUs busy 76 % of the kernel with every issue port taken together above 100 % -- and writes exactly its records (WRITE_SIZE =
+// 1.00 x), so what pays is fewer instructions.  With k and m fixed (the BASELINE configs: k = 31 and k = 63, m = 10) every shift is
+// an immediate, the hashes of the neighbouring groups come out of LDS as 128-bit reads (lane stride 20 words: 16-byte aligned and
+// conflict-free for the eight lanes of a 128-bit access group) and the sliding-window minimum is one running minimum over the
+// w - 1 positions to the left, nearest first: pm[x] = min over the x nearest, window i = min(own prefix, pm[w - 1 - i]).
+// Same SkThread, bit for bit, as sk_tile (tests: the records of both paths are compared byte for byte).
+#define SK_HSTRIDE 20                     // u32 words per thread in the hash exchange area of sk_tile_fx
+template <int K, int M, bool SAMPLE = false>
+__device__ __forceinline__ SkThread sk_tile_fx(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                               const SkParams& sp, long long gfirst, u32* H, const unsigned char* tab, u32* load = nullptr) {
+    constexpr int W = K - M + 1;              // m-mers per window
+    constexpr int NL = W - 1;                 // positions left of the group's first one that its windows reach
+    static_assert(W >= 16 && NL <= 16 * SK_HALO && M >= 1 && M <= 16, "window geometry");
+    const int t = threadIdx.x;
+    const long long g = gfirst + t;
+    const bool live = g >= 0 && (u64)g < sp.ngroups;
+    u32 h[16];
+    u64 wi = 0; int t0 = 0;
+    if (live) {
+        wi = (u64)g >> 1; t0 = (int)(g & 1) << 4;
+        const u64 cur = packed[wi];
+        const u64 prev = wi ? packed[wi - 1] : 0ull;
+        const u64 x = t0 ? cur : ((prev << 32) | (cur >> 32));
+        const u64 rcx = rev_pairs(x) ^ 0xAAAAAAAAAAAAAAAAull;
+        constexpr u32 mmask = (M == 16) ? 0xFFFFFFFFu : ((1u << (2 * M)) - 1u);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const u32 fw = (u32)(x >> (2 * (15 - j))) & mmask;
+            const u32 rv = (u32)(rcx >> (2 * (17 + j - M))) & mmask;
+            h[j] = fmix32(fw < rv ? fw : rv);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) h[j] = 0xFFFFFFFFu;
+    }
+    uint4* Hv = reinterpret_cast<uint4*>(H);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Hv[5 * t + q] = make_uint4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+    sk_lds_barrier();
+    SkThread r; r.vm = 0; r.bm = 0; r.ow_lo = 0; r.ow_hi = 0;
+    if (live && t >= SK_HALO) {
+        // pm[x] = min over the NL - 15 + x nearest left positions (x = 0 with NL == 15: none)
+        u32 pm[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) pm[x] = 0xFFFFFFFFu;
+        {
+            u32 run = 0xFFFFFFFFu;
+            constexpr int NG = (NL + 15) / 16;
+#pragma unroll
+            for (int gq = 1; gq <= NG; ++gq) {
+#pragma unroll
+                for (int q = 3; q >= 0; --q) {
+                    if (16 * gq - (4 * q + 3) > NL) continue;                   // (constant: the whole quad lies beyond the windows' reach)
+                    const uint4 v = Hv[5 * (t - gq) + q];
+                    const u32 e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int c = 3; c >= 0; --c) {
+                        const int d = 16 * gq - (4 * q + c);                    // distance of this position from the group's first one
+                        if (d > NL) continue;
+                        run = e[c] < run ? e[c] : run;
+                        if (d >= NL - 15 && d >= 1) pm[d - (NL - 15)] = run;
+                    }
+                }
+            }
+        }
+        u32 mn[16];
+        {
+            u32 pr = h[0];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i > 0) pr = h[i] < pr ? h[i] : pr;
+                mn[i] = pm[15 - i] < pr ? pm[15 - i] : pr;
+            }
+        }
+        const u32 ic = inval[wi];
+        const u32 i1 = wi >= 1 ? inval[wi - 1] : 0xFFFFFFFFu;
+        const u32 i2 = wi >= 2 ? inval[wi - 2] : 0xFFFFFFFFu;
+        u64 bad_lo = ((u64)i1 << 32) | ic, bad_hi = i2;
+        {
+            // (only bits 16 - t0 .. 31 - t0 of the smeared mask are looked at, and a bit travels k - 1 places down: for k <= 33 nothing
+            //  of the frame's third word can reach them)
+            int rem = K - 1;
+#pragma unroll
+            for (int st = 1; st <= 32; st <<= 1) {
+                const int sh = rem < st ? rem : st;
+                if (sh) {
+                    if constexpr (K <= 33) bad_lo |= bad_lo >> sh;
+                    else { bad_lo |= (bad_lo >> sh) | (bad_hi << (64 - sh)); bad_hi |= bad_hi >> sh; }
+                }
+                rem -= sh;
+            }
+        }
+        const u32 bad16 = (u32)(bad_lo >> (16 - t0)) & 0xFFFFu;
+        if constexpr (SAMPLE) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (!((bad16 >> (15 - i)) & 1u)) atomicAdd(&load[(mn[i] & 0xFFFFu) >> 4], 1u);
+        } else {
+            u32 ow[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ow[i >> 2] |= (u32)tab[(mn[i] & 0xFFFFu) >> 4] << (8 * (i & 3));
+            r.vm = __brev(~bad16 & 0xFFFFu) >> 16;
+            auto nib = [](u32 w) { return (w * 0x10204080u) >> 28; };
+            u32 splitm = 0;
+            u64 lo = ((u64)ow[1] << 32) | ow[0], hi = ((u64)ow[3] << 32) | ow[2];
+            if (sp.has_split) {                                               // (uniform: most tables route every bucket by its minimizer)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) splitm |= nib((ow[q] >> 7) & 0x01010101u) << (4 * q);
+                splitm &= r.vm;
+                for (u32 sm = splitm; sm; sm &= sm - 1) {
+                    const int i = __builtin_ctz(sm);
+                    const u64 o = sk_kmer_owner(packed, wi, t0, i, K, sp.G);
+                    if (i < 8) lo = (lo & ~(0xFFull << (8 * i))) | (o << (8 * i));
+                    else hi = (hi & ~(0xFFull << (8 * (i - 8)))) | (o << (8 * (i - 8)));
+                }
+                lo &= 0x3F3F3F3F3F3F3F3Full; hi &= 0x3F3F3F3F3F3F3F3Full;  // what is left of a 255 belongs to a window without a k-mer
+            }
+            r.ow_lo = lo; r.ow_hi = hi;
+            const u32 w0 = (u32)lo, w1 = (u32)(lo >> 32), w2 = (u32)hi, w3 = (u32)(hi >> 32);
+            auto diff = [&](u32 w, u32 prev_top) { const u32 x = w ^ ((w << 8) | prev_top); return nib(((x + 0x3F3F3F3Fu) >> 6) & 0x01010101u); };
+            const u32 d = diff(w0, 0u) | (diff(w1, w0 >> 24) << 4) | (diff(w2, w1 >> 24) << 8) | (diff(w3, w2 >> 24) << 12);
+            r.bm = r.vm & (~(r.vm << 1) | d | splitm | (splitm << 1)) & 0xFFFFu;
+        }
+    }
+    return r;
+}
+// K == 0: k and m at run time (sk_tile); H holds SK_NT * SK_HSTRIDE words either way
+template <int K, int M, bool SAMPLE = false>
+__device__ __forceinline__ SkThread sk_tile_any(const u64* __restrict__ packed, const u32* __restrict__ inval,
+                                                const SkParams& sp, long long gfirst, u32* H, const unsigned char* tab, u32* load = nullptr) {
+    if constexpr (K != 0) return sk_tile_fx<K, M, SAMPLE>(packed, inval, sp, gfirst, H, tab, load);
+    else return sk_tile<SAMPLE>(packed, inval, sp, gfirst, H, tab, load);
+}
+
 // number of k-mers of the record starting at window i
 __device__ __forceinline__ u32 sk_run_length(const SkThread& s, int i) {
     const u32 stop = ((~s.vm | s.bm) & 0xFFFFu) >> (i + 1);
@@ -226,9 +363,11 @@ __device__ __forceinline__ u32 sk_run_length(const SkThread& s, int i) {
 // ---------------------------------------------------------------- sender: records per (owner, chunk)
 // kmers[o] += k-mers inside the records counted for owner o (with sample_step > 1: of the sampled tiles -- the estimate that
 // sizes the receivers of a sliced step before any record exists)
+// <K, M>: k and m at compile time (sk_tile_fx); <0, 0>: at run time
+template <int K = 0, int M = 0>
 __global__ __launch_bounds__(SK_NT) void k_sk_hist(const u64* __restrict__ packed, const u32* __restrict__ inval,
                                                    SkParams sp, u32* __restrict__ mat, unsigned long long* __restrict__ kmers) {
-    __shared__ u32 H[SK_NT * 17];
+    __shared__ __attribute__((aligned(16))) u32 H[SK_NT * SK_HSTRIDE];
     __shared__ u32 cnt[SK_MAX_OWNERS];
     __shared__ u32 kcn[SK_MAX_OWNERS];
     __shared__ unsigned char tab[SK_BUCKETS];
@@ -239,7 +378,7 @@ __global__ __launch_bounds__(SK_NT) void k_sk_hist(const u64* __restrict__ packe
     const u64 tbeg = (u64)c * sp.tiles_per_chunk;
     const u64 tend = tbeg + sp.tiles_per_chunk < sp.ntiles ? tbeg + sp.tiles_per_chunk : sp.ntiles;
     for (u64 tile = tbeg; tile < tend; tile += sp.sample_step) {
-        const SkThread s = sk_tile(packed, inval, sp, (long long)(tile * SK_GROUPS) - SK_HALO, H, tab);
+        const SkThread s = sk_tile_any<K, M>(packed, inval, sp, (long long)(tile * SK_GROUPS) - SK_HALO, H, tab);
         u32 bm = s.bm;
         while (bm) {
             const int i = __builtin_ctz(bm); bm &= bm - 1;
@@ -257,9 +396,10 @@ __global__ __launch_bounds__(SK_NT) void k_sk_hist(const u64* __restrict__ packe
 
 // ---------------------------------------------------------------- repartition: sampled k-mer load per minimizer bucket
 // Every sample_step-th tile; load[] += the number of valid windows whose minimizer falls into the bucket.
+template <int K = 0, int M = 0>
 __global__ __launch_bounds__(SK_NT) void k_sk_sample(const u64* __restrict__ packed, const u32* __restrict__ inval,
                                                      SkParams sp, unsigned long long* __restrict__ gload) {
-    __shared__ u32 H[SK_NT * 17];
+    __shared__ __attribute__((aligned(16))) u32 H[SK_NT * SK_HSTRIDE];
     __shared__ u32 load[SK_BUCKETS];
     for (int i = threadIdx.x; i < SK_BUCKETS; i += SK_NT) load[i] = 0;
     __syncthreads();
@@ -267,7 +407,7 @@ __global__ __launch_bounds__(SK_NT) void k_sk_sample(const u64* __restrict__ pac
     const u64 tbeg = (u64)c * sp.tiles_per_chunk;
     const u64 tend = tbeg + sp.tiles_per_chunk < sp.ntiles ? tbeg + sp.tiles_per_chunk : sp.ntiles;
     for (u64 tile = tbeg; tile < tend; tile += sp.sample_step) {
-        (void)sk_tile<true>(packed, inval, sp, (long long)(tile * SK_GROUPS) - SK_HALO, H, nullptr, load);
+        (void)sk_tile_any<K, M, true>(packed, inval, sp, (long long)(tile * SK_GROUPS) - SK_HALO, H, nullptr, load);
         sk_lds_barrier();
     }
     __syncthreads();
@@ -276,69 +416,88 @@ __global__ __launch_bounds__(SK_NT) void k_sk_sample(const u64* __restrict__ pac
 
 // ---------------------------------------------------------------- sender: write the records
 // `cbase` (exact layout, !SLICES) holds the exclusive scan of the (owner-major) count matrix: the 64-bit record index of every
-// (owner, chunk) pair.  Every position is 64-bit: a block keeps, per owner, the record index of its first slot (ob) and a 32-bit
+// (owner, chunk) pair.  Every position is 64-bit: a block keeps, per owner, the WORD index of its first slot (obw) and a 32-bit
 // cursor relative to it -- a shard of any size goes through (30x human on 8 GPUs: 11.3 GB of reads per rank; ~1.5 * 10^9 records).
 // SLICES: no exact counts -- every (owner, chunk) pair owns a slice of sp.slice records (sized from a sampled
 // estimate); what a block leaves unused is filled with zero-length records (n = 0: the receiver skips them), a slice
 // that would overflow raises *ovf (nothing is written past a slice) and the host repeats with exact counts.
-template <bool SLICES>
+// The bases behind a record's last k-mer (up to the 64 R - 8 bits a record holds) are whatever followed in the read stream: no
+// receiver looks past k-mer n - 1, and clearing them cost 15 instructions per record in a kernel paced by its instruction count.
+template <bool SLICES, int K = 0, int M = 0>
 __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ packed, const u32* __restrict__ inval,
                                                       SkParams sp, const unsigned long long* __restrict__ cbase, u64* __restrict__ send, u32* __restrict__ ovf,
                                                       unsigned long long* __restrict__ kmers) {      // kmers[o] += k-mers inside the records written for owner o
-    __shared__ u32 H[SK_NT * 17];
+    __shared__ __attribute__((aligned(16))) u32 H[SK_NT * SK_HSTRIDE];
     __shared__ u32 cur[SK_MAX_OWNERS];
     __shared__ u32 kc[SK_MAX_OWNERS];
     __shared__ u32 lim[SK_MAX_OWNERS];                    // SLICES: end of this block's slice of every owner (same units as cur)
-    __shared__ unsigned long long ob[SK_MAX_OWNERS];      // record index where cur[o] == 0 lies (this block's first slot of owner o)
-    __shared__ u32 desc[SK_NT / 64][SK_DESC];
+    __shared__ unsigned long long obw[SK_MAX_OWNERS];     // WORD index of the record where cur[o] == 0 lies (this block's first slot of owner o)
+    __shared__ unsigned short desc[SK_NT / 64][SK_DESC];  // lane | first window << 6 | owner << 10
     __shared__ unsigned char tab[SK_BUCKETS];
     const u32 c = blockIdx.x + (SLICES ? sp.c0 : 0u);
     for (int i = threadIdx.x; i < SK_BUCKETS / 8; i += SK_NT) reinterpret_cast<u64*>(tab)[i] = reinterpret_cast<const u64*>(sp.table)[i];
-    __syncthreads();
+    const u32 R = sp.R;
     if (threadIdx.x < sp.G) {
         const u32 o = threadIdx.x;
-        kc[o] = 0; ob[o] = 0ull; lim[o] = 0u;
-        if (!SLICES) { cur[o] = 0u; ob[o] = cbase[(u64)o * sp.nchunks + c]; }
+        unsigned long long ob = 0ull;
+        kc[o] = 0; cur[o] = 0u; lim[o] = 0u;
+        if (!SLICES) ob = cbase[(u64)o * sp.nchunks + c];
         else if (sp.oslice) {          // per-owner slices inside per-owner regions: positions relative to the block's own slice
             const u32 sl = sp.oslice[o];
-            cur[o] = 0u; lim[o] = (o >= sp.olo && o < sp.ohi) ? sl : 0u;
-            ob[o] = sp.obase[o] + (unsigned long long)(c - sp.c0g) * sl;
-        } else { cur[o] = 0u; lim[o] = sp.slice; ob[o] = sp.rbase + ((u64)o * sp.clen + (u64)(c - sp.c0g)) * sp.slice; }
+            lim[o] = (o >= sp.olo && o < sp.ohi) ? sl : 0u;
+            ob = sp.obase[o] + (unsigned long long)(c - sp.c0g) * sl;
+        } else { lim[o] = sp.slice; ob = sp.rbase + ((u64)o * sp.clen + (u64)(c - sp.c0g)) * sp.slice; }
+        obw[o] = ob * R;
     }
+    __syncthreads();
     bool over = false;
     const u64 tbeg = (u64)c * sp.tiles_per_chunk;
     const u64 tend = tbeg + sp.tiles_per_chunk < sp.ntiles ? tbeg + sp.tiles_per_chunk : sp.ntiles;
-    const int k = (int)sp.k;
-    const u32 R = sp.R;
+    const int k = K ? K : (int)sp.k;
     const bool sub = SLICES && sp.oslice != nullptr;      // only some owners are written
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (u64 tile = tbeg; tile < tend; ++tile) {
         const long long gfirst = (long long)(tile * SK_GROUPS) - SK_HALO;
-        const SkThread s = sk_tile(packed, inval, sp, gfirst, H, tab);
+        const SkThread s = sk_tile_any<K, M>(packed, inval, sp, gfirst, H, tab);
         // The records of a WAVE are dealt out to its lanes, one record per lane and trip: a thread holds 0..16 records (2.3 on
-        // average), and a loop over a thread's own records runs as often as the busiest of 64 lanes needs (5-6 trips of the
-        // ~80-instruction body).  Every thread notes its records -- (lane, first window, k-mers, owner) -- in the wave's
-        // list (a light loop), then lane e builds record e, e + 64, ..: it fetches the frame of the noting lane's group itself.
-        // (sub: the records of owners outside [olo, ohi) are not even noted)
+        // average), and a loop over a thread's own records runs as often as the busiest of 64 lanes needs (5-6 trips).  Every
+        // thread notes (lane, first window, owner) of its records in the wave's list -- a short loop body --; lane e then builds
+        // record e, e + 64, ..: the run length comes from the noting lane's window masks (one cross-lane read), the frame of its
+        // group from the 2-bit stream.
         u32 mybm = s.bm;
-        if (sub) { u32 keep = 0; for (u32 b = s.bm; b; b &= b - 1) { const int i = __builtin_ctz(b); const u32 o = sk_owner(s, i); if (o >= sp.olo && o < sp.ohi) keep |= 1u << i; } mybm = keep; }
+        if (sub) {      // (virtual owners: the records of owners outside [olo, ohi) are not even noted) -- byte-parallel range test, owners < 64
+            auto nib = [](u32 w) { return (w * 0x10204080u) >> 28; };
+            const u32 lo4 = sp.olo * 0x01010101u, hi4 = ((sp.ohi - 1u) | 0x80u) * 0x01010101u;
+            auto inr = [&](u32 w) { return nib(((((w | 0x80808080u) - lo4) & (hi4 - w)) >> 7) & 0x01010101u); };
+            const u32 w0 = (u32)s.ow_lo, w1 = (u32)(s.ow_lo >> 32), w2 = (u32)s.ow_hi, w3 = (u32)(s.ow_hi >> 32);
+            mybm &= inr(w0) | (inr(w1) << 4) | (inr(w2) << 8) | (inr(w3) << 12);
+        }
+        const u32 vmbm = s.vm | (s.bm << 16);
+        const u32 ow0 = (u32)s.ow_lo, ow1 = (u32)(s.ow_lo >> 32), ow2 = (u32)s.ow_hi, ow3 = (u32)(s.ow_hi >> 32);
         const u32 cnt = (u32)__popc(mybm);
         const u32 inc = wave_incl_scan(cnt);
         const u32 total = (u32)__shfl((int)inc, 63);
         for (u32 B = 0; B < total; B += SK_DESC) {                          // (wave-uniform; more than SK_DESC records in a wave: several rounds)
             u32 bm = mybm, id = inc - cnt - B;
             while (bm) {
-                const int i = __builtin_ctz(bm); bm &= bm - 1;
-                if (id < SK_DESC) desc[wave][id] = (u32)lane | ((u32)i << 6) | ((sk_run_length(s, i) - 1u) << 10) | (sk_owner(s, i) << 14);
+                const u32 i = (u32)__builtin_ctz(bm); bm &= bm - 1;
+                // owner of window i = byte i of (ow3 : ow2 : ow1 : ow0): a byte permute over the half it lies in
+                const u32 own = (i < 8u ? __builtin_amdgcn_perm(ow1, ow0, i) : __builtin_amdgcn_perm(ow3, ow2, i - 8u)) & 0x3Fu;
+                if (id < SK_DESC) desc[wave][id] = (unsigned short)((u32)lane | (i << 6) | (own << 10));
                 ++id;
             }
-            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_wave_barrier();          // (the LDS executes a wave's accesses in order: no wait needed between its lanes)
             const u32 m = total - B < SK_DESC ? total - B : SK_DESC;
-            for (u32 e = (u32)lane; e < m; e += 64) {
-                const u32 dsc = desc[wave][e];
-                const int i = (int)((dsc >> 6) & 15u);
-                const u32 n = ((dsc >> 10) & 15u) + 1u, own = dsc >> 14;
-                const u64 g = (u64)(gfirst + (long long)((wave << 6) + (int)(dsc & 63u)));
+            for (u32 e0 = 0; e0 < m; e0 += 64) {                              // (wave-uniform trips: the cross-lane read below needs its SOURCE lane active)
+                const u32 e = e0 + (u32)lane;
+                const u32 dsc = desc[wave][e < m ? e : 0u];
+                const u32 L = dsc & 63u, i = (dsc >> 6) & 15u, own = dsc >> 10;
+                const u32 vb = (u32)__shfl((int)vmbm, (int)L);
+                if (e >= m) continue;
+                // k-mers of the record that starts at window i: up to the next start, the next window without a k-mer, or the group's end
+                const u32 stop = ((((~vb) | (vb >> 16)) & 0xFFFFu) | 0x10000u) >> (i + 1);
+                const u32 n = (u32)__builtin_ctz(stop) + 1u;
+                const u64 g = (u64)(gfirst + (long long)((wave << 6) + (int)L));
                 const u64 wi = g >> 1; const int t0 = (int)(g & 1) << 4;
                 const u64 w0 = packed[wi];
                 const u64 w1 = wi >= 1 ? packed[wi - 1] : 0ull;
@@ -346,12 +505,16 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
                 const u32 slot = atomicAdd(&cur[own], 1u);
                 if (SLICES && slot >= lim[own]) { over = true; continue; }
                 atomicAdd(&kc[own], n);
-                // bases [bs, bs + nb) of the 96-base frame (w2 : w1 : w0), shifted to the top of the record
-                u64 o[3];
-                sk_extract(w2, w1, w0, 64 + t0 + i - k + 1, (int)n + k - 1, o);
-                u64* dst = send + ((u64)ob[own] + slot) * R;
-                if (R == 2) { dst[0] = o[0]; dst[1] = o[1] | n; }
-                else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2] | n; }
+                // the record's bases start at base bs of the 96-base frame (w2 : w1 : w0): the frame shifted left by 2 * bs bits
+                const int sh = 2 * (64 + t0 + (int)i - k + 1), ws = sh >> 6, b = sh & 63;
+                const u64 fa = ws == 0 ? w2 : ws == 1 ? w1 : w0;
+                const u64 fb = ws == 0 ? w1 : ws == 1 ? w0 : 0ull;
+                const u64 fc = ws == 0 ? w0 : 0ull;
+                const u64 o0 = (fa << b) | ((fb >> 1) >> (63 - b));
+                const u64 o1 = (fb << b) | ((fc >> 1) >> (63 - b));
+                u64* dst = send + obw[own] + (u64)slot * R;
+                if (R == 2) { dst[0] = o0; dst[1] = (o1 & ~0xFFull) | n; }
+                else { dst[0] = o0; dst[1] = o1; dst[2] = ((fc << b) & ~0xFFull) | n; }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -362,7 +525,7 @@ __global__ __launch_bounds__(SK_NT) void k_sk_scatter(const u64* __restrict__ pa
     if (SLICES) {
         if (over) *ovf = 1u;
         for (u32 o = 0; o < sp.G; ++o) {                      // zero-length records up to the end of each of this block's slices
-            const u64 beg = ((u64)ob[o] + (cur[o] < lim[o] ? cur[o] : lim[o])) * R, end = ((u64)ob[o] + lim[o]) * R;
+            const u64 beg = obw[o] + (u64)(cur[o] < lim[o] ? cur[o] : lim[o]) * R, end = obw[o] + (u64)lim[o] * R;
             for (u64 w = beg + threadIdx.x; w < end; w += SK_NT) send[w] = 0ull;
         }
     }

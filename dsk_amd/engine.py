@@ -77,6 +77,7 @@ F_NO_SORT = 2
 F_HISTO2D = 4
 F_MG_EXPLICIT = 8
 F_PLACE = 16
+F_PARTITION_ORDER = 32
 SOLIDITY = {"sum": 0, "min": 1, "max": 2, "one": 3, "all": 4, "custom": 5}
 
 # every symbol include/dskgpu.h declares (checked by tests/test_abi.py)
@@ -86,7 +87,7 @@ EXPORTS = [
     "dskgpu_count", "dskgpu_mg_scatter", "dskgpu_mg_sample", "dskgpu_mg_make_table", "dskgpu_mg_set_table",
     "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_mg_sent_kmers", "dskgpu_mg_count_sized",
     "dskgpu_mg_slices_prepare", "dskgpu_mg_scatter_slice", "dskgpu_mg_slices_finish", "dskgpu_mg_count_sliced", "dskgpu_get_stats", "dskgpu_histogram",
-    "dskgpu_num_partitions", "dskgpu_partition_size", "dskgpu_partition_copy", "dskgpu_result_device",
+    "dskgpu_set_row_order", "dskgpu_num_partitions", "dskgpu_partition_size", "dskgpu_partition_copy", "dskgpu_result_device",
     "dskgpu_stage_times", "dskgpu_k_encode", "dskgpu_k_enumerate", "dskgpu_k_minimizers",
     "dskgpu_group_create", "dskgpu_group_destroy", "dskgpu_group_last_error", "dskgpu_group_size", "dskgpu_group_ctx",
     "dskgpu_group_transport", "dskgpu_group_count", "dskgpu_group_exchanged_words", "dskgpu_group_sliced_steps", "dskgpu_group_histogram", "dskgpu_group_histogram2d",
@@ -151,6 +152,7 @@ def load_library():
     lib.dskgpu_histogram.argtypes = [vp, C.POINTER(u64), u32]
     lib.dskgpu_num_partitions.argtypes = [vp]
     lib.dskgpu_num_partitions.restype = u32
+    lib.dskgpu_set_row_order.argtypes = [vp, C.c_int]
     lib.dskgpu_partition_size.argtypes = [vp, u32]
     lib.dskgpu_partition_size.restype = u64
     lib.dskgpu_partition_copy.argtypes = [vp, u32, vp, vp]
@@ -190,7 +192,7 @@ def load_library():
 
 
 def _make_config(kmer_size, abundance_min, abundance_max, histo_max, device, nb_partitions, timing, sort, world_size, rank,
-                 minimizer_size, max_pass_mkeys, solidity_kind, solidity_custom, histo2d, mg_explicit, place=False) -> "_Config":
+                 minimizer_size, max_pass_mkeys, solidity_kind, solidity_custom, histo2d, mg_explicit, place=False, partition_order=False) -> "_Config":
     cfg = _Config()
     cfg.kmer_size = kmer_size
     cfg.abundance_min = abundance_min
@@ -200,7 +202,7 @@ def _make_config(kmer_size, abundance_min, abundance_max, histo_max, device, nb_
     cfg.nb_partitions = nb_partitions
     cfg.minimizer_size = minimizer_size
     cfg.max_pass_mkeys = max_pass_mkeys
-    cfg.flags = (F_TIMING if timing else 0) | (0 if sort else F_NO_SORT) | (F_HISTO2D if histo2d else 0) | (F_MG_EXPLICIT if mg_explicit else 0) | (F_PLACE if place else 0)
+    cfg.flags = (F_TIMING if timing else 0) | (0 if sort else F_NO_SORT) | (F_HISTO2D if histo2d else 0) | (F_MG_EXPLICIT if mg_explicit else 0) | (F_PLACE if place else 0) | (F_PARTITION_ORDER if partition_order else 0)
     cfg.solidity_kind = SOLIDITY[solidity_kind]
     cfg.solidity_custom = solidity_custom
     cfg.world_size = world_size
@@ -226,13 +228,15 @@ class KmerCounter:
                  histo_max: int = 10000, device: int = 0, nb_partitions: int = 0, timing: bool = False,
                  sort: bool = True, world_size: int = 1, rank: int = 0, stream: Optional[int] = None,
                  minimizer_size: int = 0, max_pass_mkeys: int = 0, solidity_kind: str = "sum", solidity_custom: int = 0,
-                 histo2d: bool = False, mg_explicit: bool = False, place: bool = False):
-        """place: DSKGPU_F_PLACE -- every big device buffer becomes the best-placed of 8 candidate allocations (one-off cost of a
+                 histo2d: bool = False, mg_explicit: bool = False, place: bool = False, partition_order: bool = False):
+        """partition_order: DSKGPU_F_PARTITION_ORDER -- rows ascending inside every output partition only (the reference's Partition<Count>
+        contract; thousands of small partitions), one pass over the rows instead of the three of the global order.
+        place: DSKGPU_F_PLACE -- every big device buffer becomes the best-placed of 8 candidate allocations (one-off cost of a
         few seconds at the first count, steps ~6 % faster and no longer box- and process-dependent): for contexts that count often."""
         self._lib = load_library()
         self._owned = True
         cfg = _make_config(kmer_size, abundance_min, abundance_max, histo_max, device, nb_partitions, timing, sort, world_size, rank,
-                           minimizer_size, max_pass_mkeys, solidity_kind, solidity_custom, histo2d, mg_explicit, place)
+                           minimizer_size, max_pass_mkeys, solidity_kind, solidity_custom, histo2d, mg_explicit, place, partition_order)
         self.kmer_size = kmer_size
         self.histo_max = histo_max
         self.words = (kmer_size + 31) // 32          # 64-bit words of a k-mer at the ABI (1..4)
@@ -410,6 +414,12 @@ class KmerCounter:
         ab = np.zeros(n, dtype=np.uint32)
         self._ck(self._lib.dskgpu_partition_copy(self._h, p, C.c_void_p(kmers.ctypes.data), C.c_void_p(ab.ctypes.data)))
         return kmers, ab
+
+    def set_row_order(self, partition_order: bool) -> None:
+        self._ck(self._lib.dskgpu_set_row_order(self._h, 1 if partition_order else 0))
+
+    def partition_sizes(self) -> np.ndarray:
+        return np.array([int(self._lib.dskgpu_partition_size(self._h, p)) for p in range(self.num_partitions())], dtype=np.int64)
 
     def rows(self) -> Tuple[np.ndarray, np.ndarray]:
         """All solid rows, partitions concatenated in index order (what dsk2ascii walks)."""

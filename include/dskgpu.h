@@ -68,6 +68,13 @@ typedef struct dskgpu_config {
 #define DSKGPU_F_NO_SORT 2u       /* leave solid rows unsorted (bench ablation) */
 #define DSKGPU_F_MG_EXPLICIT 8u   /* multi-GPU: exchange one explicit key per k-mer instead of super-k-mer records */
 #define DSKGPU_F_HISTO2D 4u       /* also build the 2-D histogram: bank 0 (genome) x the other banks (reads), -histo2D */
+#define DSKGPU_F_PARTITION_ORDER 32u /* the REFERENCE's row order instead of the global one: rows ascending inside an output partition, partitions = runs of
+                                   * hash sub-partitions of at most 4096 rows (dskgpu_num_partitions of them: thousands) -- what Partition<Count> "solid"
+                                   * guarantees its readers (utils/dsk2ascii.cpp:61,77,85-104: partition after partition, the rows of each as they
+                                   * come; gatb-core's partitions are classes of the minimizer hash).  One pass over the rows instead of three
+                                   * (csrc/partsort.h).  Honoured by a single-pass count of one-word k-mers (k <= 32); every other path -- and an
+                                   * input on which a partition would exceed what one block orders -- keeps the global order, which satisfies the
+                                   * same contract with nb_partitions value ranges. */
 #define DSKGPU_F_PLACE 16u        /* pick the place of every big device buffer: where a buffer lies in HBM changes the rate of
                                    * scattered stores into it by up to 40 % (tools/micro/write_place.hip; the "two speeds" of the
                                    * partition kernels).  Each allocation >= 256 MB becomes the best of up to 8 candidates, timed
@@ -235,8 +242,11 @@ int dskgpu_histogram(const dskgpu_ctx* ctx, uint64_t* out, uint32_t nbins);
 int dskgpu_histogram2d(const dskgpu_ctx* ctx, uint64_t* out, uint32_t nrows);
 
 /* Output partitions = `Partition<Count> "solid"` (utils/dsk2ascii.cpp:61,77).
- * Rows are ascending by k-mer value inside a partition and partitions are
- * ascending value ranges, so the concatenation is globally sorted. */
+ * Rows are ascending by k-mer value inside a partition; by default the partitions are
+ * ascending value ranges too, so the concatenation is globally sorted (with
+ * DSKGPU_F_PARTITION_ORDER only the order inside a partition is guaranteed). */
+/* Row order of the NEXT counts of this context: non-zero = DSKGPU_F_PARTITION_ORDER (see the flag), 0 = the global order. */
+int dskgpu_set_row_order(dskgpu_ctx* ctx, int partition_order);
 uint32_t dskgpu_num_partitions(const dskgpu_ctx* ctx);
 uint64_t dskgpu_partition_size(const dskgpu_ctx* ctx, uint32_t p);
 /* kmers: size*words u64 (row-major, LSW first, words = ceil(k/32)); abundance: size u32. Host memory. */

@@ -1326,6 +1326,61 @@ def test_super_kmer_record_invariants(oracle, golden_dir, dev, monkeypatch, worl
         assert len(have) == len(want) and (have == want).all()
 
 
+@pytest.mark.parametrize("k,world", [(31, 8), (63, 4), (31, 64)])
+def test_sender_with_compile_time_k_writes_the_same_records(dev, monkeypatch, k, world):
+    """Round 6: for the BASELINE configs (k = 31 / 63, m = 10) the sender kernels know k and m at compile time (superkmer.h:
+    sk_tile_fx -- immediate shifts, 128-bit LDS reads, one running minimum); DSKGPU_SK_GENERIC selects the run-time form.  Both must
+    write the same records for every owner, byte for byte: default table and a balanced table with split buckets (noisy
+    poly-A reads), exact and sampled layouts, and the sampled bucket loads must agree too."""
+    from dsk_amd import KmerCounter, synth, make_table
+    from dsk_amd.multi import scatter_records
+    rng = np.random.default_rng(11)
+    normal = synth.make_reads(synth.make_genome(300_000, dev), 150_000, 150).cpu().numpy().reshape(-1, 151)
+    polya = np.full((30_000, 151), ord("A"), dtype=np.uint8); polya[:, 150] = 10
+    noise = rng.random((30_000, 150)) < 0.05
+    polya[:, :150][noise] = rng.choice(np.frombuffer(b"CGTN", dtype=np.uint8), int(noise.sum()))
+    reads = np.concatenate([normal, polya]); rng.shuffle(reads)
+    t = torch.from_numpy(reads.reshape(-1).copy()).to(dev)
+
+    def run(generic, table, exact):
+        if generic:
+            monkeypatch.setenv("DSKGPU_SK_GENERIC", "1")
+        else:
+            monkeypatch.delenv("DSKGPU_SK_GENERIC", raising=False)
+        if exact:
+            monkeypatch.setenv("DSKGPU_SK_EXACT", "1"); monkeypatch.delenv("DSKGPU_SK_MINSLICE", raising=False)
+        else:
+            monkeypatch.setenv("DSKGPU_SK_MINSLICE", "1"); monkeypatch.delenv("DSKGPU_SK_EXACT", raising=False)
+        with KmerCounter(kmer_size=k, abundance_min=1, world_size=world, rank=0) as kc:
+            kc.set_reads_device(t.data_ptr(), t.numel())
+            loads = kc.mg_sample()
+            if table is not None:
+                kc.mg_set_table(table)
+            send, counts = scatter_records(kc, None, dev)
+            torch.cuda.synchronize()
+            return loads, counts, send[: sum(counts)].cpu().numpy().copy(), kc.mg_sent_kmers()
+
+    loads, _, _, _ = run(False, None, True)
+    table = make_table(loads, world)
+    assert (table == 255).sum() >= 1                       # the poly-A bucket is split: the by-k-mer route is exercised
+    for tab in (None, table):
+        for exact in (True, False):
+            la, ca, sa, ka = run(False, tab, exact)
+            lb, cb, sb, kb = run(True, tab, exact)
+            assert (la == lb).all() and ka == kb and (ca == cb or not exact), (k, world, exact)
+            assert sum(ka) > 0
+            # the same records for every owner -- as a multiset: the two forms cut the stream into different chunks (three blocks per
+            # CU against two), a chunk's records are dealt to slots by LDS atomics, and the sampled layout pads its slices
+            R = (2 * (k + 15) + 8 + 63) // 64
+            ea, eb = np.cumsum([0] + ca), np.cumsum([0] + cb)
+            for o in range(world):
+                ra = sa[ea[o]: ea[o + 1]].view(np.uint64).reshape(-1, R); rb = sb[eb[o]: eb[o + 1]].view(np.uint64).reshape(-1, R)
+                ra = ra[(ra[:, R - 1] & np.uint64(0xFF)) != 0]; rb = rb[(rb[:, R - 1] & np.uint64(0xFF)) != 0]
+                assert len(ra) == len(rb), (k, world, exact, o)
+                ia = np.lexsort(ra.T[::-1]); ib = np.lexsort(rb.T[::-1])
+                assert (ra[ia] == rb[ib]).all(), (k, world, exact, o, "records differ")
+
+
 def test_sender_slices_and_their_exact_fallback(oracle, dev, monkeypatch):
     """Multi-GPU sender: the records go to (owner, chunk) slices sized from a sampled count and padded with zero-length
     records; a slice that overflows switches the context to exact counts (which may need a larger send buffer)."""
@@ -1566,13 +1621,74 @@ def test_row_sort_of_2_pow_32_rows_and_more_slab_by_slab(oracle, dev, monkeypatc
     # a HEAVY first-digit bucket INSIDE a group's MSD sort (k_rs_split flags it and skips it) -- the per-group
     # library sort then reads the group from the split's output array, which must hold a complete permutation of the group's rows
     monkeypatch.setenv("DSKGPU_RS_MAX_ROWS", "300000")
-    monkeypatch.setenv("DSKGPU_RS_HEAVY", "1000")
+    monkeypatch.setenv("DSKGPU_RS_HEAVY", "100")                                        # (a group of <= 300 000 rows has ~290 per first-digit bucket)
     for k, s in ((31, reads), (31, skew)):
         st = check_against_oracle(oracle, s, k, dev, amin=1)
         assert st["sort_fallback"] == 1, (k, st)
     monkeypatch.delenv("DSKGPU_RS_SLAB_ROWS")                                           # the same inside sort_rows_big's groups
     st = check_against_oracle(oracle, reads, 31, dev, amin=1)
     assert st["n_solid"] > 300000 and st["sort_fallback"] == 1, st
+
+
+def test_partition_order_is_the_reference_contract(oracle, golden_dir, dev, monkeypatch):
+    """DSKGPU_F_PARTITION_ORDER (csrc/partsort.h): the rows in the order the reference's readers are promised -- ascending INSIDE each
+    output partition, partition after partition (utils/dsk2ascii.cpp:61,77,85-104) -- from one pass over the rows instead of the
+    three of the global order.  Checked: same multiset of (k-mer, abundance) rows and same histogram as the oracle, every
+    partition strictly ascending, no partition above what a block orders, the partition sizes add up; a partition / value bin a
+    block cannot order (provoked: DSKGPU_PS_MAXC=1) takes the global sort and the rows come out globally ascending; paths the flag
+    does not cover (two-word k-mers, several passes) keep the global order."""
+    from dsk_amd import KmerCounter, synth
+    g = synth.make_genome(600_000, dev)
+    reads = synth.make_reads(g, 250_000, 150)
+    gold, _ = oracle.load_bank(os.path.join(golden_dir, "read50x_ref10K_e001.fasta.gz"))
+    rng = np.random.default_rng(5)
+    pa = np.full(300_000, 65, np.uint8)
+    hit = rng.random(pa.size) < 0.03
+    pa[hit] = rng.choice(np.frombuffer(b"CGT", dtype=np.uint8), size=int(hit.sum()))
+    skew = np.concatenate([pa, np.array([10], np.uint8), reads.cpu().numpy()]).astype(np.uint8)
+
+    def run(stream, k, amin, **kw):
+        t = torch.from_numpy(np.ascontiguousarray(stream)).to(dev)
+        with KmerCounter(kmer_size=k, abundance_min=amin, partition_order=True, **kw) as kc:
+            kc.set_reads_device(t.data_ptr(), t.numel())
+            kc.count()
+            sizes = kc.partition_sizes()
+            kk, ab = kc.rows()
+            return kk, ab, sizes, kc.histogram(), kc.stats()
+
+    def check(stream, k, amin, expect_parts=True, **kw):
+        kk, ab, sizes, hist, st = run(stream, k, amin, **kw)
+        ref = oracle.count(np.ascontiguousarray(stream), k)
+        keep = (ref.ab >= amin)
+        want_k, want_a = ref.words()[keep], ref.ab[keep]
+        assert st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct and st["n_solid"] == len(want_a), (k, amin, st)
+        assert (hist == ref.histogram(10000)).all()
+        assert sizes.sum() == len(want_a) == kk.shape[0] and st["n_partitions"] == len(sizes)
+        order = np.lexsort(kk.T)                                  # (word 0 least significant: the last key of lexsort is the primary one)
+        assert (kk[order] == want_k).all() and (ab[order] == want_a).all(), (k, amin)
+        if kk.shape[1] == 1:
+            asc = kk[1:, 0] > kk[:-1, 0]
+            starts = np.cumsum(sizes)[:-1]
+            inside = np.ones(len(asc), dtype=bool); inside[starts[(starts > 0) & (starts <= len(asc))] - 1] = False
+            assert asc[inside].all(), (k, amin, "a partition is not ascending")
+            if expect_parts is True:
+                assert len(sizes) > 4 and sizes.max() <= 4096 and not asc.all(), (k, amin, len(sizes), sizes.max())
+            elif expect_parts is False:
+                assert asc.all(), (k, amin, "global order expected")
+        return st
+
+    for k, amin in ((31, 2), (31, 1), (21, 2), (13, 1), (32, 2)):
+        check(reads.cpu().numpy(), k, amin)
+    check(gold, 27, 1)
+    check(skew, 31, 1)
+    check(skew, 31, 2)
+    check(reads.cpu().numpy(), 5, 1, expect_parts=None)           # (512 distinct 5-mers: a tiny row set, either layout)
+    monkeypatch.setenv("DSKGPU_PS_MAXC", "1")                      # two rows in one value bin: the block gives up, the global sort takes over
+    st = check(reads.cpu().numpy(), 31, 1, expect_parts=False)
+    assert st["n_partitions"] == 4
+    monkeypatch.delenv("DSKGPU_PS_MAXC")
+    check(reads.cpu().numpy(), 31, 1, expect_parts=False, max_pass_mkeys=2)      # several passes: dense accumulated rows, global order
+    check(reads.cpu().numpy(), 63, 2, expect_parts=False)                        # two-word rows: not covered by the flag (yet)
 
 
 def test_multi_pass_count_leaves_the_sender_state_alone(oracle, dev):

@@ -1,6 +1,6 @@
 #!/bin/bash
-# copy what tools/r04_profiles.sh <tag> left under gpurun_out/ (scratch) into profiles/ (tracked): run HERE after the gpurun call
-tag=${1:-r04b}
+# copy what tools/profile_set.sh <tag> left under gpurun_out/ (scratch) into profiles/ (tracked): run HERE after the gpurun call
+tag=${1:?tag}
 python3 tools/prof_summary.py $tag > /dev/null
 python3 tools/prof_summary.py ${tag}_k63pmc > /dev/null
 stats() { python3 - "$1" "$2" <<'PY'
@@ -21,7 +21,7 @@ grep -v '^[WE]2026' gpurun_out/kt_${tag}_c3/run.log | grep -v amdgpu.ids > profi
 stats gpurun_out/kt_${tag}_mg/t_kernel_stats.csv profiles/${tag}_multigpu_rank_kernel_stats.csv
 { for f in gpurun_out/kt_${tag}_mg/run.log gpurun_out/${tag}_mg_sliced.txt gpurun_out/${tag}_mg_shard.txt gpurun_out/${tag}_mg_k63.txt; do echo "# $f"; grep -v '^[WE]2026' $f | grep -v amdgpu.ids; done; } > profiles/${tag}_multigpu_rank_stage_times.txt
 ls -la profiles | grep $tag
-# k = 63 refresh (tools/r04_profiles_k63.sh <tag2>): profiles/<tag2>_k63*
+# k = 63 refresh (tools/profile_set.sh <tag2>): profiles/<tag2>_k63*
 if [ -n "$2" ]; then
   t2=$2
   python3 tools/prof_summary.py ${t2}_k63pmc > /dev/null

@@ -1,7 +1,7 @@
 #!/bin/bash
-# round-5 profiles (same set as round 4) (GPU box): kernel trace + PMC of the bench workload, kernel trace at k = 63, of the human stand-in, and the
+# the profile set of a round (GPU box): kernel trace + PMC of the bench workload, kernel trace at k = 63, of the human stand-in, and the
 # emulated rank of an 8-GPU job.  Raw output under gpurun_out/; tools/prof_summary.py + the copies below condense it into profiles/.
-tag=${1:-r05b}
+tag=${1:?tag, e.g. r06a}
 bash tools/prof.sh $tag --no-repeat-rich --steps 20 --warmup 5 > gpurun_out/prof_$tag.log 2>&1
 python3 bench.py --no-human-standin > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 bash tools/prof.sh ${tag}_k63pmc --kmer-size 63 --no-repeat-rich --steps 10 --warmup 3 > gpurun_out/prof_${tag}_k63pmc.log 2>&1
