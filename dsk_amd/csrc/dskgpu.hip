@@ -298,7 +298,7 @@ struct dskgpu_ctx {
     // out that way, h_part_off[p] = first row of partition p (n_parts + 1 entries, pinned); part_off_this_count: the flag was raised
     // (a partition or a bin above what a block orders) and this count takes the global sort instead
     bool part_mode = false, part_off_this_count = false; u32 n_parts = 0; u32* h_part_off = nullptr; size_t h_part_cap = 0; DevBuf part_off;
-    SparseRows sp_rows_saved;
+    SparseRows sp_rows_saved; SparseRows2 sp_rows2_saved;
     bool rows2_in_scratch = false; Rows2 rows2_scratch{};      // two-word rows above RS_MAX_ROWS: the result (and the fallback's input) is the scratch copy
     u64 n_rows = 0;
     const u64* res_w[4] = {nullptr, nullptr, nullptr, nullptr}; const u32* res_ab = nullptr;
@@ -1316,14 +1316,19 @@ int sort_rows_huge(dskgpu_ctx* ctx, u64 n) {
 // (partsort.h).  In: the sparse rows (ctx->sp_rows).  Out: srt_w[0] / srt_ab dense, partition after partition; part_off on the device
 // and (after the caller's synchronisation) in h_part_off; SC_SORTFLAG raised when a block could not order its partition.
 int sort_rows_partition_order(dskgpu_ctx* ctx, u64 n) {
+    const int W = ctx->W;
     const dskgpu_ctx::SparseRows spr = ctx->sp_rows;
-    ctx->sp_rows_saved = spr;
+    const dskgpu_ctx::SparseRows2 spr2 = ctx->sp_rows2;
+    ctx->sp_rows_saved = spr; ctx->sp_rows2_saved = spr2;
     ctx->sp_rows.valid = false; ctx->sp_rows2.valid = false;
-    const u64 F = spr.s.F;
-    const u64 mean = std::max<u64>(1, (spr.n_sparse + F - 1) / std::max<u64>(F, 1));
-    const u32 qpp = (u32)std::min<u64>(std::max<u64>(1, (u64)(PS_CAP * 3 / 4) / mean), PS_MAXQ);
-    const u32 nps = (u32)((F + qpp - 1) / qpp), nparts = nps + (spr.n_tail ? 1u : 0u);
-    CK(ctx->srt_w[0].ensure(n * 8)); CK(ctx->srt_ab.ensure(n * 4));
+    const u64 F = W == 1 ? spr.s.F : spr2.s.F, n_sparse = W == 1 ? spr.n_sparse : spr2.n_sparse;
+    const u32 n_tail = W == 1 ? spr.n_tail : spr2.n_tail;
+    const u64 cap_rows = W == 1 ? PS_CAP : PS2_CAP;
+    const u64 mean = std::max<u64>(1, (n_sparse + F - 1) / std::max<u64>(F, 1));
+    const u32 qpp = (u32)std::min<u64>(std::max<u64>(1, (cap_rows * 3 / 4) / mean), PS_MAXQ);
+    const u32 nps = (u32)((F + qpp - 1) / qpp), nparts = nps + (n_tail ? 1u : 0u);
+    for (int x = 0; x < W; ++x) CK(ctx->srt_w[x].ensure(n * 8));
+    CK(ctx->srt_ab.ensure(n * 4));
     CK(ctx->part_off.ensure(((size_t)nparts + 2) * 4));
     if (ctx->h_part_cap < (size_t)nparts + 2) {
         if (ctx->h_part_off) CK(hipHostFree(ctx->h_part_off));
@@ -1333,17 +1338,22 @@ int sort_rows_partition_order(dskgpu_ctx* ctx, u64 n) {
     }
     u32* sc = ctx->scalars.as<u32>();
     hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, 0u, 1u, sc + SC_SORTFLAG, (u32*)nullptr);
-    const int sh = std::max(0, (int)std::min(64u, 2u * ctx->cfg.kmer_size) - 12);
-    const PsParams pp{qpp, nps, sh, spr.n_tail, ctx->tune.ps_maxc ? std::min<u32>(ctx->tune.ps_maxc, PS_MAXC) : PS_MAXC};
-    hipLaunchKernelGGL(k_part_sort, dim3(nparts), dim3(PS_NT), 0, ctx->stream, spr.s, spr.tail_k, spr.tail_v, pp,
-                       ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), ctx->part_off.as<u32>(), sc + SC_SORTFLAG);
+    const int sh = std::max(0, 2 * (int)ctx->cfg.kmer_size - 12);
+    const PsParams pp{qpp, nps, W == 1 ? std::min(sh, 52) : sh, n_tail, ctx->tune.ps_maxc ? std::min<u32>(ctx->tune.ps_maxc, PS_MAXC) : PS_MAXC};
+    if (W == 1)
+        hipLaunchKernelGGL(k_part_sort, dim3(nparts), dim3(PS_NT), 0, ctx->stream, spr.s, spr.tail_k, spr.tail_v, pp,
+                           ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), ctx->part_off.as<u32>(), sc + SC_SORTFLAG);
+    else
+        hipLaunchKernelGGL(k_part_sort2, dim3(nparts), dim3(PS_NT), 0, ctx->stream, spr2.s, spr2.tail, pp,
+                           Rows2{ctx->srt_w[1].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>()}, ctx->part_off.as<u32>(), sc + SC_SORTFLAG);
     CKL("k_part_sort");
     CK(hipMemcpyAsync(ctx->h_part_off, ctx->part_off.p, ((size_t)nparts + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->part_mode = true; ctx->n_parts = nparts;
     ctx->h_ovs.assign(1, 0);
     ctx->sort_back = 2;            // (the flag travels with the histogram: run_pipeline)
     ctx->sort_partial = false;
-    ctx->res_w[0] = ctx->srt_w[0].as<u64>(); ctx->res_ab = ctx->srt_ab.as<u32>();
+    for (int x = 0; x < W; ++x) ctx->res_w[x] = ctx->srt_w[x].as<u64>();
+    ctx->res_ab = ctx->srt_ab.as<u32>();
     return DSKGPU_OK;
 }
 
@@ -1359,7 +1369,7 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     if ((ctx->sp_rows.valid && (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT) || W != 1)) || (ctx->sp_rows2.valid && (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT) || W != 2)))
         return fail(ctx, DSKGPU_E_STATE, "row sort: sparse rows on a path that cannot read them");
     if (n == 0 || (ctx->cfg.flags & DSKGPU_F_NO_SORT)) return DSKGPU_OK;
-    if (ctx->sp_rows.valid && (ctx->cfg.flags & DSKGPU_F_PARTITION_ORDER) && !ctx->part_off_this_count && n < 0xFFFF0000ull) return sort_rows_partition_order(ctx, n);
+    if ((ctx->sp_rows.valid || ctx->sp_rows2.valid) && (ctx->cfg.flags & DSKGPU_F_PARTITION_ORDER) && !ctx->part_off_this_count && n < 0xFFFF0000ull) return sort_rows_partition_order(ctx, n);
     if (ctx->sp_rows.valid) {      // the rows of a single one-word pass, still in the count kernel's regions (run_one_pass made sure this sort takes them)
         CK(ctx->srt_w[0].ensure(n * 8)); CK(ctx->srt_ab.ensure(n * 4));
         ctx->fb_src_k = ctx->srt_w[0].as<u64>(); ctx->fb_src_v = ctx->srt_ab.as<u32>(); ctx->fb_dst_k = ctx->out_w[0].as<u64>(); ctx->fb_dst_v = ctx->out_ab.as<u32>();
@@ -2656,7 +2666,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         if (ctx->part_mode && ctx->h_back[3]) {      // a partition (or a value bin of one) above what a block orders in LDS: the global sort, on the same sparse rows
             if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] row sort: a partition exceeds what one block orders -- global order instead of partition order\n");
             ctx->part_mode = false; ctx->part_off_this_count = true; ctx->h_back[3] = 0;
-            ctx->sp_rows = ctx->sp_rows_saved;
+            ctx->sp_rows = ctx->sp_rows_saved; ctx->sp_rows2 = ctx->sp_rows2_saved;
             goto sort_again;
         }
         if (W == 1 && ctx->sort_partial && tot_rows && !ctx->h_back[3] && !ctx->h_ovs.empty() && ctx->h_ovs[0]) {

@@ -126,3 +126,102 @@ __global__ __launch_bounds__(PS_NT) void k_part_sort(RsSparse s, const u64* __re
     __syncthreads();
     for (u32 i = tid; i < n; i += PS_NT) { ov[(u64)r0 + i] = lk[i]; oab[(u64)r0 + i] = la[i]; }
 }
+
+// ---- the same for two-word rows (33 <= k <= 64): (hi, lo, abundance) in three arrays, PS2_CAP rows per block
+#define PS2_RPT 4
+#define PS2_CAP (PS_NT * PS2_RPT)         // 2048 rows: 40 KB of rows + 16 KB of bins, two blocks per CU
+__device__ __forceinline__ u32 ps2_bin(u64 hi, u64 lo, int sh) {      // the top 12 of the 2k value bits: (hi : lo) >> sh
+    const u64 v = sh >= 64 ? hi >> (sh - 64) : sh == 0 ? lo : ((hi << (64 - sh)) | (lo >> sh));
+    return v < PS_BINS ? (u32)v : PS_BINS - 1;
+}
+__global__ __launch_bounds__(PS_NT) void k_part_sort2(Rs2Sparse s, Rows2C tail, PsParams pp, Rows2 o, u32* __restrict__ part_off, u32* __restrict__ flag) {
+    __shared__ u64 lh[PS2_CAP];
+    __shared__ u64 ll[PS2_CAP];
+    __shared__ u32 la[PS2_CAP];
+    __shared__ u32 cnt[PS_BINS];
+    __shared__ u32 lsoff[PS_MAXQ + 1];
+    __shared__ u32 wsum[PS_NT / 64 + 1];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 p = blockIdx.x;
+    const bool is_tail = p >= pp.nparts_sparse;
+    const u32 q0 = is_tail ? s.F : p * pp.qpp, q1 = is_tail ? s.F : (q0 + pp.qpp < s.F ? q0 + pp.qpp : s.F), nq = q1 - q0;
+    for (u32 x = tid; x <= nq; x += PS_NT) lsoff[x] = s.soff[q0 + x];
+    for (u32 b = tid; b < PS_BINS; b += PS_NT) cnt[b] = 0;
+    __syncthreads();
+    const u32 r0 = is_tail ? s.soff[s.F] : lsoff[0];
+    const u32 n = is_tail ? pp.n_tail : lsoff[nq] - r0;
+    if (tid == 0) {
+        part_off[p] = r0;
+        if (p + 1 == gridDim.x) part_off[p + 1] = r0 + n;
+    }
+    if (n > PS2_CAP) { if (tid == 0) *flag = 1u; return; }
+    if (n == 0) return;
+    u64 kh[PS2_RPT], kl[PS2_RPT]; u32 a[PS2_RPT], rb[PS2_RPT];
+#pragma unroll
+    for (int j = 0; j < PS2_RPT; ++j) {
+        const u32 i = tid + (u32)j * PS_NT;
+        const u32 r = r0 + (i < n ? i : n - 1);
+        if (is_tail) { kh[j] = tail.hi[r - r0]; kl[j] = tail.lo[r - r0]; a[j] = tail.ab[r - r0]; }
+        else {
+            u32 lo = 0, hi = nq;
+            while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (lsoff[mid] <= r) lo = mid; else hi = mid; }
+            const u64 src = rs2_sp_base(s, q0 + lo) + (u64)(r - lsoff[lo]);
+            K2 kx = s.keys[src]; kunmixN(kx);
+            kh[j] = kx.w[1]; kl[j] = kx.w[0]; a[j] = s.ab[src];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PS2_RPT; ++j) {
+        const u32 i = tid + (u32)j * PS_NT;
+        const u32 bin = ps2_bin(kh[j], kl[j], pp.sh);
+        rb[j] = i < n ? (bin << 16) | atomicAdd(&cnt[bin], 1u) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    {
+        constexpr int CPT = PS_BINS / PS_NT;
+        u32 c[CPT], sum = 0;
+#pragma unroll
+        for (int x = 0; x < CPT; ++x) { c[x] = cnt[tid * CPT + x]; sum += c[x]; }
+        const u32 inc = wave_incl_scan(sum);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        u32 run = inc - sum;
+#pragma unroll
+        for (int x = 0; x < PS_NT / 64; ++x) { const u32 v = wsum[x]; if ((u32)x < wave) run += v; }
+        bool heavy = false;
+#pragma unroll
+        for (int x = 0; x < CPT; ++x) { cnt[tid * CPT + x] = (run << 16) | c[x]; run += c[x]; heavy = heavy || c[x] > pp.maxc; }
+        if (heavy) *flag = 1u;
+    }
+    __syncthreads();
+    u32 pos[PS2_RPT], cb[PS2_RPT];
+#pragma unroll
+    for (int j = 0; j < PS2_RPT; ++j) {
+        pos[j] = 0; cb[j] = 0;
+        if (rb[j] != 0xFFFFFFFFu) {
+            cb[j] = cnt[rb[j] >> 16];
+            pos[j] = (cb[j] >> 16) + (rb[j] & 0xFFFFu);
+            lh[pos[j]] = kh[j]; ll[pos[j]] = kl[j]; la[pos[j]] = a[j];
+        }
+    }
+    __syncthreads();
+    bool moved = false;
+#pragma unroll
+    for (int j = 0; j < PS2_RPT; ++j) {
+        const u32 c = cb[j] & 0xFFFFu;
+        if (rb[j] != 0xFFFFFFFFu && c > 1u) {
+            const u32 ob = cb[j] >> 16, cc = c < PS_MAXC ? c : PS_MAXC;
+            u32 less = 0;
+            for (u32 x = 0; x < cc; ++x) { const u64 h = lh[ob + x], l = ll[ob + x]; less += (h < kh[j] || (h == kh[j] && l < kl[j])) ? 1u : 0u; }
+            pos[j] = ob + less; moved = true;
+        }
+    }
+    __syncthreads();
+    if (moved) {
+#pragma unroll
+        for (int j = 0; j < PS2_RPT; ++j)
+            if (rb[j] != 0xFFFFFFFFu && (cb[j] & 0xFFFFu) > 1u) { lh[pos[j]] = kh[j]; ll[pos[j]] = kl[j]; la[pos[j]] = a[j]; }
+    }
+    __syncthreads();
+    for (u32 i = tid; i < n; i += PS_NT) { o.hi[(u64)r0 + i] = lh[i]; o.lo[(u64)r0 + i] = ll[i]; o.ab[(u64)r0 + i] = la[i]; }
+}

@@ -4,6 +4,8 @@
 
 #include <sys/stat.h>
 #include <zlib.h>
+#include "pgzip.hpp"
+#include <stdexcept>
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -152,9 +154,10 @@ public:
             uint64_t n = 0;
             if (stream_parallel(chunkBytes, sink, size, nthreads, n)) return n;
         }
-        if (gz && size >= (1u << 20)) {
+        if (gz && (size >= (1u << 20) || getenv("DSK_PGZIP_CHUNK_BYTES"))) {      // (the switch: tests run the parallel gzip path on small files)
             uint64_t n = 0;
             if (nthreads > 1 && stream_bgzf(chunkBytes, sink, size, nthreads, n)) return n;
+            if (nthreads > 1 && !getenv("DSK_NO_PGZIP") && stream_pgz(chunkBytes, sink, size, nthreads, n)) return n;
             return stream_gz_pipelined(chunkBytes, sink);
         }
         return stream_serial(chunkBytes, sink);
@@ -324,7 +327,56 @@ private:
         if (!ok) throw Exception("corrupt BGZF file '%s'", path_.c_str());
         return true;
     }
-    // Ordinary gzip: one deflate stream cannot be split, but inflating and parsing overlap -- a producer
+    // Ordinary gzip, ONE member (what `gzip reads.fastq` writes): inflated on the thread pool by the two-pass scheme of pgzip.hpp --
+    // block starts searched inside the stream, chunks inflated with a symbolic window, windows resolved in order --, slab by slab;
+    // every slab is parsed like a memory-mapped plain file, the cut last record carried into the next one.  Returns false when the
+    // file is not such a gzip (several members, no dynamic blocks, a first slab that does not pass): nothing was consumed then.
+    bool stream_pgz(size_t chunkBytes, const Sink& sink, uint64_t size, unsigned nthreads, uint64_t& nseq) {
+        int fd = open(path_.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) return false;
+        std::vector<char> slab; std::string carry;
+        nseq = 0; char kind = 0; bool first = true;
+        struct NotRecords {};                                  // the first slab does not start like a FASTA / FASTQ file: the lenient serial parser takes the file
+        size_t pgz_chunk = 0;
+        if (const char* e = getenv("DSK_PGZIP_CHUNK_BYTES")) pgz_chunk = (size_t)atoll(e);
+        bool ok = false;
+        try {
+            ok = pgz_inflate((const uint8_t*)m, size, std::min(nthreads, 64u), pgz_chunk, [&](const char* data, size_t len, bool last) {
+                slab.resize(carry.size() + len);
+                std::memcpy(slab.data(), carry.data(), carry.size());
+                std::memcpy(slab.data() + carry.size(), data, len);
+                const char* base = slab.data(); const char* end = base + slab.size(); const char* p = base;
+                if (first) { kind = record_kind(p, end); first = false; if (!kind) throw NotRecords{}; }
+                const char* stop = end;
+                if (!last) {                                     // keep the (possibly cut) last record for the next slab
+                    uint64_t back = 1u << 16;
+                    const char* q = end;
+                    for (;;) {
+                        const char* from = (uint64_t)(end - p) > back ? end - back : p;
+                        q = next_record_start(base, from, end, kind);
+                        if (q < end || from == p) break;
+                        back *= 16;
+                    }
+                    if (q < end) for (;;) { const char* r = next_record_start(base, q + 1, end, kind); if (r >= end) break; q = r; }
+                    stop = q < end ? q : p;
+                }
+                if (stop > p) nseq += parse_parallel(base, p, stop, kind, chunkBytes, sink, nthreads);
+                carry.assign(stop, (size_t)(end - stop));
+            });
+        } catch (const NotRecords&) {
+            munmap(m, size);
+            return false;
+        } catch (const std::runtime_error& e) {
+            munmap(m, size);
+            throw Exception("%s: file '%s'", e.what(), path_.c_str());
+        }
+        munmap(m, size);
+        return ok;
+    }
+    // Ordinary gzip otherwise: one deflate stream inflated by zlib, but inflating and parsing overlap -- a producer
     // thread inflates 4 MB buffers into a small queue while the caller parses and hands chunks to the sink.
     uint64_t stream_gz_pipelined(size_t chunkBytes, const Sink& sink) {
         gzFile f = gzopen(path_.c_str(), "rb");

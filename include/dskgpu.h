@@ -72,7 +72,7 @@ typedef struct dskgpu_config {
                                    * hash sub-partitions of at most 4096 rows (dskgpu_num_partitions of them: thousands) -- what Partition<Count> "solid"
                                    * guarantees its readers (utils/dsk2ascii.cpp:61,77,85-104: partition after partition, the rows of each as they
                                    * come; gatb-core's partitions are classes of the minimizer hash).  One pass over the rows instead of three
-                                   * (csrc/partsort.h).  Honoured by a single-pass count of one-word k-mers (k <= 32); every other path -- and an
+                                   * (csrc/partsort.h).  Honoured by a single-pass count of one- and two-word k-mers (k <= 64; 2048 rows per partition above k = 32); every other path -- and an
                                    * input on which a partition would exceed what one block orders -- keeps the global order, which satisfies the
                                    * same contract with nb_partitions value ranges. */
 #define DSKGPU_F_PLACE 16u        /* pick the place of every big device buffer: where a buffer lies in HBM changes the rate of

@@ -1636,7 +1636,7 @@ def test_partition_order_is_the_reference_contract(oracle, golden_dir, dev, monk
     three of the global order.  Checked: same multiset of (k-mer, abundance) rows and same histogram as the oracle, every
     partition strictly ascending, no partition above what a block orders, the partition sizes add up; a partition / value bin a
     block cannot order (provoked: DSKGPU_PS_MAXC=1) takes the global sort and the rows come out globally ascending; paths the flag
-    does not cover (two-word k-mers, several passes) keep the global order."""
+    does not cover (k > 64, several passes) keep the global order."""
     from dsk_amd import KmerCounter, synth
     g = synth.make_genome(600_000, dev)
     reads = synth.make_reads(g, 250_000, 150)
@@ -1688,7 +1688,20 @@ def test_partition_order_is_the_reference_contract(oracle, golden_dir, dev, monk
     assert st["n_partitions"] == 4
     monkeypatch.delenv("DSKGPU_PS_MAXC")
     check(reads.cpu().numpy(), 31, 1, expect_parts=False, max_pass_mkeys=2)      # several passes: dense accumulated rows, global order
-    check(reads.cpu().numpy(), 63, 2, expect_parts=False)                        # two-word rows: not covered by the flag (yet)
+    # two-word rows (33 <= k <= 64): 2048 rows per partition; every partition ascending on (high word, low word)
+    for k, amin in ((63, 2), (63, 1), (33, 1), (40, 2), (64, 1)):
+        kk, ab, sizes, hist, st = run(reads.cpu().numpy(), k, amin)
+        ref = oracle.count(reads.cpu().numpy(), k)
+        keep = ref.ab >= amin
+        order = np.lexsort(kk.T)
+        assert (kk[order] == ref.words()[keep]).all() and (ab[order] == ref.ab[keep]).all() and (hist == ref.histogram(10000)).all(), (k, amin)
+        assert len(sizes) > 4 and sizes.max() <= 2048 and sizes.sum() == kk.shape[0] == st["n_solid"], (k, amin, len(sizes), sizes.max())
+        asc = (kk[1:, 1] > kk[:-1, 1]) | ((kk[1:, 1] == kk[:-1, 1]) & (kk[1:, 0] > kk[:-1, 0]))
+        starts = np.cumsum(sizes)[:-1]
+        inside = np.ones(len(asc), dtype=bool); inside[starts[(starts > 0) & (starts <= len(asc))] - 1] = False
+        assert asc[inside].all() and not asc.all(), (k, amin)
+    check(skew, 63, 1, expect_parts=None)
+    check(reads.cpu().numpy(), 101, 2, expect_parts=None)                        # four-word rows: not covered by the flag, global order
 
 
 def test_multi_pass_count_leaves_the_sender_state_alone(oracle, dev):

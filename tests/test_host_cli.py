@@ -455,12 +455,27 @@ def test_gzip_and_bgzf_inputs(bins, tmp_path, fmt):
     with gzip.open(os.path.join(tmp, "std.gz"), "wb", compresslevel=1) as f:
         f.write(data)
     write_bgzf(os.path.join(tmp, "blocked.gz"), data)
+    # one ordinary gzip member at several levels: inflated in parallel from the middle of the deflate stream (host/pgzip.cpp; chunks of
+    # 60 KB here so that a 1 MB file is many chunks in several slabs) -- and a file of two members, which that path declines
+    for lvl in (6, 9):
+        with gzip.open(os.path.join(tmp, f"std{lvl}.gz"), "wb", compresslevel=lvl) as f:
+            f.write(data)
+    with open(os.path.join(tmp, "two.gz"), "wb") as f:
+        f.write(gzip.compress(data[: len(data) // 2], 6) if data[len(data) // 2 - 1: len(data) // 2] == b"\n" else gzip.compress(data, 6))
+        f.write(gzip.compress(data[len(data) // 2:], 6) if data[len(data) // 2 - 1: len(data) // 2] == b"\n" else gzip.compress(b"", 6))
+    pgz = {"DSK_PGZIP_CHUNK_BYTES": "60000", "DSK_PGZIP_TRACE": "1"}
     dumps = {}
     for name, src, env in (("plain", "plain." + fmt, {"DSK_PARSE_MIN_BYTES": "100000"}), ("std", "std.gz", {}), ("bgzf", "blocked.gz", {}),
                            ("bgzf_slabs", "blocked.gz", {"DSK_BGZF_SLAB_BYTES": "300000"}),
+                           ("pgz1", "std.gz", pgz), ("pgz6", "std6.gz", pgz), ("pgz9", "std9.gz", pgz), ("pgz_two_members", "two.gz", pgz),
+                           ("no_pgz", "std6.gz", {"DSK_NO_PGZIP": "1"}),
                            ("serial", "plain." + fmt, {"DSK_PARSE_MIN_BYTES": str(1 << 40)})):
-        subprocess.check_call([bins["dsk"], "-file", src, "-kmer-size", "25", "-abundance-min", "1", "-out", name, "-verbose", "0"],
-                              cwd=tmp, env=dict(os.environ, **env))
+        r = subprocess.run([bins["dsk"], "-file", src, "-kmer-size", "25", "-abundance-min", "1", "-out", name, "-verbose", "0"],
+                           cwd=tmp, env=dict(os.environ, **env), stderr=subprocess.PIPE)
+        assert r.returncode == 0, (name, r.stderr.decode()[-800:])
+        if name in ("pgz1", "pgz6", "pgz9"):                 # the parallel path really ran: every slab's chunks all passed
+            slabs = [l for l in r.stderr.decode().splitlines() if "[pgzip] slab" in l]
+            assert len(slabs) >= 2 and all("0 good" not in l for l in slabs), r.stderr.decode()[-800:]
         subprocess.check_call([bins["dsk2ascii"], "-file", name, "-out", name + ".txt", "-verbose", "0"], cwd=tmp)
         dumps[name] = hashlib.md5(open(os.path.join(tmp, name + ".txt"), "rb").read()).hexdigest()
     assert len(set(dumps.values())) == 1, dumps
