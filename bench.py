@@ -54,7 +54,7 @@ def parse():
                                                                 "(b) on rank 0 alone, and require identical totals and histograms (exit code 3 otherwise)")
     ap.add_argument("--no-self-check", action="store_true", help="N > 1: skip the invariants every rank checks on its own result after the timed steps")
     ap.add_argument("--row-order", choices=("partition", "global"), default="partition",
-                    help="N = 1: order of the solid rows the timed steps produce.  partition (default) = the reference's Partition<Count> contract: "
+                    help="order of the solid rows (of every rank) the timed steps produce.  partition (default) = the reference's Partition<Count> contract: "
                          "ascending inside every output partition (DSKGPU_F_PARTITION_ORDER, one pass over the rows); global = ascending over all rows "
                          "(three passes).  The other one is timed beside it (ms_per_step_global_order / _partition_order)")
     ap.add_argument("--no-place", action="store_true", help="plain hipMalloc for the big device buffers instead of the best-placed of 8 candidates (DSKGPU_F_PLACE)")
@@ -315,12 +315,21 @@ def valid_windows(reads_u8, n_reads, read_len, k):
 
 
 def rows_strictly_ascending(kc, dev, words):
-    """This rank's sorted result, checked where it lies (HBM): every row's value above its predecessor's -> (ok, rows, sum of abundances)."""
+    """This rank's sorted result, checked where it lies (HBM): every row's value above its predecessor's -- inside every output
+    partition when the rows are in partition order (the partitions' offsets come from the engine; their sizes must add up)
+    -> (ok, rows, sum of abundances)."""
     import ctypes
+    import numpy as np
     import torch
     kp, ap, n = kc.result_device()
     if n == 0:
         return True, 0, 0
+    starts = None
+    if kc.num_partitions() > 64:            # partition order (DSKGPU_F_PARTITION_ORDER): a row may be smaller than its predecessor only where a partition starts
+        off = kc.partition_offsets().astype(np.int64)
+        if int(off[-1]) != n or bool((np.diff(off) < 0).any()):
+            return False, int(n), 0
+        starts = torch.from_numpy(off[1:-1].copy()).to(dev)
     hip = ctypes.CDLL("libamdhip64.so")
     step = 1 << 26
     kb = torch.empty(step, dtype=torch.int64, device=dev); ab = torch.empty(step, dtype=torch.int32, device=dev)
@@ -332,7 +341,13 @@ def rows_strictly_ascending(kc, dev, words):
         if words == 1:          # (k <= 31: values < 2^62, a signed compare is safe; wider keys: the abundances only -- word 0 alone does not order them)
             hip.hipMemcpy(ctypes.c_void_p(kb.data_ptr()), ctypes.c_void_p(kp + r0 * 8), ctypes.c_size_t(m * 8), 3)
             kk = kb[:m]
-            ok = ok and bool((kk[1:] > kk[:-1]).all()) and (last is None or int(kk[0]) > last)
+            asc = kk[1:] > kk[:-1]
+            if starts is not None:
+                if m > 1:
+                    asc[starts[(starts > r0) & (starts < r0 + m)] - r0 - 1] = True
+                ok = ok and bool(asc.all()) and (last is None or int(kk[0]) > last or bool((starts == r0).any()))
+            else:
+                ok = ok and bool(asc.all()) and (last is None or int(kk[0]) > last)
             last = int(kk[-1])
     return ok, int(n), ab_sum
 
@@ -430,7 +445,7 @@ def main():
             no_place_ms = (time.perf_counter() - tp) / 10 * 1e3
     kc = KmerCounter(kmer_size=args.kmer_size, abundance_min=args.abundance_min, device=local_rank, timing=True,
                      sort=not args.no_sort, world_size=world, rank=rank, stream=stream, place=not args.no_place and not share_gpu,      # (ranks sharing one GPU: no room for placement candidates)
-                     partition_order=world == 1 and args.row_order == "partition")
+                     partition_order=args.row_order == "partition")      # (every rank of a multi-GPU job orders its own share the same way)
     kc.set_reads_device(reads.data_ptr(), n_bytes)
 
     sharded = None
@@ -547,7 +562,7 @@ def main():
         dist.all_reduce(chk, op=dist.ReduceOp.SUM)
         bad_ranks, windows, counted = [int(x) for x in chk.tolist()]
         self_check = {"ranks_with_a_failed_local_check": bad_ranks, "valid_windows_of_all_shards": windows, "kmers_counted_by_all_ranks": counted,
-                      "local_checks": "rows strictly ascending (one-word keys), rows == n_solid == sum(hist[amin:]), sum(hist) == n_distinct, sum(i*hist) == sum of abundances (+ below amin) == n_kmers",
+                      "local_checks": "rows strictly ascending inside every output partition (one-word keys; the partitions' sizes add up to the rows), rows == n_solid == sum(hist[amin:]), sum(hist) == n_distinct, sum(i*hist) == sum of abundances (+ below amin) == n_kmers",
                       "ok": bad_ranks == 0 and windows == counted}
         if not self_check["ok"]:
             if rank == 0:
@@ -671,7 +686,7 @@ def main():
             "first_step_s": round(first_step_s, 3),
             "ms_per_step_no_place": None if no_place_ms is None else round(no_place_ms, 3),
             "row_order": ("partition: ascending inside each of %d output partitions -- the reference's Partition<Count> contract (utils/dsk2ascii.cpp:61,77,85-104), DSKGPU_F_PARTITION_ORDER" % st["n_partitions"])
-                         if (world == 1 and args.row_order == "partition" and not args.no_sort) else "global: ascending over all rows",
+                         if (args.row_order == "partition" and not args.no_sort) else "global: ascending over all rows",
             ("ms_per_step_global_order" if args.row_order == "partition" else "ms_per_step_partition_order"): None if other_order_ms is None else round(other_order_ms, 3),
             "sort_ms_other_row_order": None if other_order_ms is None else round(other_stage.get("sort", 0.0), 3),
             "roofline": roofline,

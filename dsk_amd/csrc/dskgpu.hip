@@ -299,6 +299,12 @@ struct dskgpu_ctx {
     // (a partition or a bin above what a block orders) and this count takes the global sort instead
     bool part_mode = false, part_off_this_count = false; u32 n_parts = 0; u32* h_part_off = nullptr; size_t h_part_cap = 0; DevBuf part_off;
     SparseRows sp_rows_saved; SparseRows2 sp_rows2_saved;
+    // ... and for the passes of a multi-pass count: every pass orders its rows partition by partition straight into the job's row arrays
+    // (one k_part_sort launch instead of k_compact), the offsets of its partitions -- relative to the pass's first row -- go to
+    // mp_part_off[off_index ..], one flag (mp_flag) serves the whole job; at the end the offsets become 64-bit row numbers (h_part_off64)
+    struct MpPart { u64 row_base; u32 nparts, off_index; };
+    std::vector<MpPart> mp_parts; DevBuf mp_part_off, mp_flag; u32 mp_off_used = 0; bool mp_part_ok = false;
+    std::vector<u64> h_part_off64; std::vector<u32> h_mp_off;
     bool rows2_in_scratch = false; Rows2 rows2_scratch{};      // two-word rows above RS_MAX_ROWS: the result (and the fallback's input) is the scratch copy
     u64 n_rows = 0;
     const u64* res_w[4] = {nullptr, nullptr, nullptr, nullptr}; const u32* res_ab = nullptr;
@@ -1315,18 +1321,38 @@ int sort_rows_huge(dskgpu_ctx* ctx, u64 n) {
 // ---- DSKGPU_F_PARTITION_ORDER: one-word rows of a single pass, ordered inside output partitions of <= PS_CAP rows by one LDS pass
 // (partsort.h).  In: the sparse rows (ctx->sp_rows).  Out: srt_w[0] / srt_ab dense, partition after partition; part_off on the device
 // and (after the caller's synchronisation) in h_part_off; SC_SORTFLAG raised when a block could not order its partition.
-int sort_rows_partition_order(dskgpu_ctx* ctx, u64 n) {
-    const int W = ctx->W;
-    const dskgpu_ctx::SparseRows spr = ctx->sp_rows;
-    const dskgpu_ctx::SparseRows2 spr2 = ctx->sp_rows2;
-    ctx->sp_rows_saved = spr; ctx->sp_rows2_saved = spr2;
-    ctx->sp_rows.valid = false; ctx->sp_rows2.valid = false;
+// one launch: the sparse rows `spr` / `spr2` (W = 1 / 2) -> dense rows at ov / o2, partition offsets (relative to the first row) at d_part_off
+// [0 .. *nparts], *d_flag raised when a block could not order its partition (the rows are complete either way)
+int launch_part_sort(dskgpu_ctx* ctx, int W, const dskgpu_ctx::SparseRows& spr, const dskgpu_ctx::SparseRows2& spr2, u64* ov, u32* oab, Rows2 o2,
+                     u32* d_part_off, u32* d_flag, u32* nparts_out, u32* qpp_out) {
     const u64 F = W == 1 ? spr.s.F : spr2.s.F, n_sparse = W == 1 ? spr.n_sparse : spr2.n_sparse;
     const u32 n_tail = W == 1 ? spr.n_tail : spr2.n_tail;
     const u64 cap_rows = W == 1 ? PS_CAP : PS2_CAP;
     const u64 mean = std::max<u64>(1, (n_sparse + F - 1) / std::max<u64>(F, 1));
     const u32 qpp = (u32)std::min<u64>(std::max<u64>(1, (cap_rows * 3 / 4) / mean), PS_MAXQ);
     const u32 nps = (u32)((F + qpp - 1) / qpp), nparts = nps + (n_tail ? 1u : 0u);
+    const int sh = std::max(0, 2 * (int)ctx->cfg.kmer_size - 12);
+    const PsParams pp{qpp, nps, W == 1 ? std::min(sh, 52) : sh, n_tail, ctx->tune.ps_maxc ? std::min<u32>(ctx->tune.ps_maxc, PS_MAXC) : PS_MAXC};
+    if (W == 1) hipLaunchKernelGGL(k_part_sort, dim3(nparts), dim3(PS_NT), 0, ctx->stream, spr.s, spr.tail_k, spr.tail_v, pp, ov, oab, d_part_off, d_flag);
+    else hipLaunchKernelGGL(k_part_sort2, dim3(nparts), dim3(PS_NT), 0, ctx->stream, spr2.s, spr2.tail, pp, o2, d_part_off, d_flag);
+    CKL("k_part_sort");
+    *nparts_out = nparts; if (qpp_out) *qpp_out = qpp;
+    return DSKGPU_OK;
+}
+// partitions a launch will make for F sub-partitions holding n_sparse rows (+ a tail)
+u32 part_sort_nparts(int W, u64 F, u64 n_sparse, u32 n_tail) {
+    const u64 cap_rows = W == 1 ? PS_CAP : PS2_CAP;
+    const u64 mean = std::max<u64>(1, (n_sparse + F - 1) / std::max<u64>(F, 1));
+    const u32 qpp = (u32)std::min<u64>(std::max<u64>(1, (cap_rows * 3 / 4) / mean), PS_MAXQ);
+    return (u32)((F + qpp - 1) / qpp) + (n_tail ? 1u : 0u);
+}
+int sort_rows_partition_order(dskgpu_ctx* ctx, u64 n) {
+    const int W = ctx->W;
+    const dskgpu_ctx::SparseRows spr = ctx->sp_rows;
+    const dskgpu_ctx::SparseRows2 spr2 = ctx->sp_rows2;
+    ctx->sp_rows_saved = spr; ctx->sp_rows2_saved = spr2;
+    ctx->sp_rows.valid = false; ctx->sp_rows2.valid = false;
+    const u32 nparts = part_sort_nparts(W, W == 1 ? spr.s.F : spr2.s.F, W == 1 ? spr.n_sparse : spr2.n_sparse, W == 1 ? spr.n_tail : spr2.n_tail);
     for (int x = 0; x < W; ++x) CK(ctx->srt_w[x].ensure(n * 8));
     CK(ctx->srt_ab.ensure(n * 4));
     CK(ctx->part_off.ensure(((size_t)nparts + 2) * 4));
@@ -1338,17 +1364,11 @@ int sort_rows_partition_order(dskgpu_ctx* ctx, u64 n) {
     }
     u32* sc = ctx->scalars.as<u32>();
     hipLaunchKernelGGL(k_set_rs_scalars, dim3(1), dim3(64), 0, ctx->stream, sc + SC_RSLEN, 0u, 1u, sc + SC_SORTFLAG, (u32*)nullptr);
-    const int sh = std::max(0, 2 * (int)ctx->cfg.kmer_size - 12);
-    const PsParams pp{qpp, nps, W == 1 ? std::min(sh, 52) : sh, n_tail, ctx->tune.ps_maxc ? std::min<u32>(ctx->tune.ps_maxc, PS_MAXC) : PS_MAXC};
-    if (W == 1)
-        hipLaunchKernelGGL(k_part_sort, dim3(nparts), dim3(PS_NT), 0, ctx->stream, spr.s, spr.tail_k, spr.tail_v, pp,
-                           ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), ctx->part_off.as<u32>(), sc + SC_SORTFLAG);
-    else
-        hipLaunchKernelGGL(k_part_sort2, dim3(nparts), dim3(PS_NT), 0, ctx->stream, spr2.s, spr2.tail, pp,
-                           Rows2{ctx->srt_w[1].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>()}, ctx->part_off.as<u32>(), sc + SC_SORTFLAG);
-    CKL("k_part_sort");
+    u32 np = 0;
+    { const int rc = launch_part_sort(ctx, W, spr, spr2, ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>(), Rows2{ctx->srt_w[1].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->srt_ab.as<u32>()},
+                                      ctx->part_off.as<u32>(), sc + SC_SORTFLAG, &np, nullptr); if (rc) return rc; }
     CK(hipMemcpyAsync(ctx->h_part_off, ctx->part_off.p, ((size_t)nparts + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->part_mode = true; ctx->n_parts = nparts;
+    ctx->part_mode = true; ctx->n_parts = nparts; ctx->h_part_off64.clear();
     ctx->h_ovs.assign(1, 0);
     ctx->sort_back = 2;            // (the flag travels with the histogram: run_pipeline)
     ctx->sort_partial = false;
@@ -2197,7 +2217,31 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 ctx->sp_rows2.tail = nhs ? Rows2C{ro.w[1] + h_nsolid, ro.w[0] + h_nsolid, rows_ab + h_nsolid} : Rows2C{nullptr, nullptr, nullptr};
             }
         }
-        if (!sparse_sort) {
+        bool mp_part = false;
+        if constexpr (W <= 2) {      // DSKGPU_F_PARTITION_ORDER in a multi-pass count: the pass's rows ordered partition by partition on their way into the dense arrays
+            mp_part = !sparse_sort && ctx->job_passes > 1 && ctx->mp_part_ok && ns > 0 && h_nsolid < 0xFFFF0000ull && (W == 1 || 2u * ctx->cfg.kmer_size > 64u);
+            if (!sparse_sort && ctx->job_passes > 1 && ns > 0 && !mp_part) ctx->mp_part_ok = false;      // (one pass outside the scheme: the job keeps the global order)
+            if (mp_part) {
+                dskgpu_ctx::SparseRows spr{}; dskgpu_ctx::SparseRows2 spr2{};
+                if constexpr (W == 1) {
+                    spr.s = RsSparse{(const u64*)solid_keys, (const u32*)solid_ab, (const u32*)ctx->nsolid.as<u32>(), (const u32*)ctx->fstart.as<u32>(), opt_cap, pl.F, 0u};
+                    spr.n_sparse = h_nsolid; spr.n_tail = (u32)nhs; spr.tail_k = nhs ? ro.w[0] + h_nsolid : nullptr; spr.tail_v = nhs ? rows_ab + h_nsolid : nullptr;
+                } else {
+                    spr2.s = Rs2Sparse{(const K2*)solid_keys, (const u32*)solid_ab, (const u32*)ctx->nsolid.as<u32>(), (const u32*)ctx->fstart.as<u32>(), opt_cap, pl.F, 0u};
+                    spr2.n_sparse = h_nsolid; spr2.n_tail = (u32)nhs;
+                    spr2.tail = nhs ? Rows2C{ro.w[1] + h_nsolid, ro.w[0] + h_nsolid, rows_ab + h_nsolid} : Rows2C{nullptr, nullptr, nullptr};
+                }
+                const u32 np_est = part_sort_nparts(W, pl.F, h_nsolid, (u32)nhs);
+                if (ctx->mp_part_off.ensure_keep(((size_t)ctx->mp_off_used + np_est + 2) * 4, (size_t)ctx->mp_off_used * 4, ctx->stream)) return fail(ctx, DSKGPU_E_NOMEM, "partition offsets");
+                u32 np = 0;
+                const int prc = launch_part_sort(ctx, W, spr, spr2, ro.w[0], rows_ab, Rows2{W == 2 ? ro.w[1] : nullptr, ro.w[0], rows_ab},
+                                                 ctx->mp_part_off.as<u32>() + ctx->mp_off_used, ctx->mp_flag.as<u32>(), &np, nullptr);
+                if (prc) return prc;
+                ctx->mp_parts.push_back(dskgpu_ctx::MpPart{0ull, np, ctx->mp_off_used});      // (row_base: the caller knows where the pass's rows start in the job)
+                ctx->mp_off_used += np + 1;
+            }
+        }
+        if (!sparse_sort && !mp_part) {
             hipLaunchKernelGGL(k_compact<W>, dim3((pl.F + 3) / 4), dim3(256), 0, ctx->stream, (const Key*)solid_keys, (const u32*)solid_ab,
                                ctx->fstart.as<u32>(), ctx->nsolid.as<u32>(), pl.F, ro, rows_ab, opt_cap);
             CKL("k_compact");
@@ -2525,9 +2569,13 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         u64 sweeps = 0;          // times the encoded reads were walked to generate k-mers (DSK's notion of a pass: README.md:126-130)
         bool rows_sized = false; // the row accumulators are sized for all passes (known after the first one)
         ctx->job_passes = npass;
+        ctx->mp_parts.clear(); ctx->mp_off_used = 0;
+        ctx->mp_part_ok = npass > 1 && W <= 2 && (ctx->cfg.flags & DSKGPU_F_PARTITION_ORDER) && !(ctx->cfg.flags & DSKGPU_F_NO_SORT) && !ctx->bank_job.active;
+        if (ctx->mp_part_ok) { CK(ctx->mp_flag.ensure(256)); CK(hipMemsetAsync(ctx->mp_flag.p, 0, 4, ctx->stream)); }
         for (u32 p = 0; p < npass; ++p) {
             u64 ns = 0, nk = 0;
             int rc;
+            const size_t mp_before = ctx->mp_parts.size();
             ctx->sink = dskgpu_ctx::RowSink{};
             if (npass > 1 && rows_sized) {      // the pass compacts its rows straight behind the job's (when they fit: run_one_pass)
                 ctx->sink.active = true; ctx->sink.rows = tot_rows; ctx->sink.ab = ctx->acc_ab.as<u32>();
@@ -2586,6 +2634,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             if (rc == PASS_TOO_BIG) { too_big = true; break; }
             if (rc) return rc;
             tot_kmers += nk; tot_distinct += ctx->h_stats[0];
+            if (ctx->mp_parts.size() > mp_before) ctx->mp_parts.back().row_base = tot_rows;
             if (npass > 1) {      // append this pass's rows and histogram to the job's
                 CK(hipMemcpyAsync(pass_hist.data(), ctx->ghist.p, pass_hist.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
                 // grow once: the passes hold similar numbers of rows (hash-uniform), so size for all of them after the first
@@ -2630,13 +2679,35 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             if (seen + (1u << 20) < 0xFFFF0000ull && seen > cap_floor) cap_floor = seen + (1u << 20); else { npass *= 2; cap_floor = 0; }
             continue;
         }
+        // ---------------- partition order over all passes: every pass ordered its partitions on the way in -- nothing left to sort unless a block gave up
+        bool mp_done = false;
+        if (npass > 1 && ctx->mp_part_ok && !ctx->mp_parts.empty()) {
+            u32 h_flag = 1;
+            ctx->h_mp_off.resize(ctx->mp_off_used);
+            CK(hipMemcpyAsync(&h_flag, ctx->mp_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipMemcpyAsync(ctx->h_mp_off.data(), ctx->mp_part_off.p, (size_t)ctx->mp_off_used * 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+            if (!h_flag) {
+                ctx->h_part_off64.clear();
+                for (const auto& mp : ctx->mp_parts)
+                    for (u32 i = 0; i < mp.nparts; ++i) ctx->h_part_off64.push_back(mp.row_base + ctx->h_mp_off[mp.off_index + i]);
+                ctx->h_part_off64.push_back(tot_rows);
+                ctx->part_mode = true; ctx->n_parts = (u32)(ctx->h_part_off64.size() - 1);
+                for (int x = 0; x < 4; ++x) ctx->res_w[x] = x < W ? ctx->acc_w[x].as<u64>() : nullptr;
+                ctx->res_ab = ctx->acc_ab.as<u32>();
+                ctx->sort_partial = false; ctx->sp_rows.valid = false; ctx->sp_rows2.valid = false;
+                ctx->h_back[3] = 0; ctx->h_ovs.assign(1, 0);
+                mp_done = true;
+            } else if (ctx->tune.verbose) fprintf(stderr, "[dskgpu] row order: a partition of one pass exceeds what one block orders -- global order over all passes instead\n");
+        }
         // ---------------- row sort over all passes
-        if (npass > 1) {      // make the accumulated rows the sort input
+        if (npass > 1 && !mp_done) {      // make the accumulated rows the sort input
             std::swap(ctx->out_ab, ctx->acc_ab);
             for (int x = 0; x < W; ++x) std::swap(ctx->out_w[x], ctx->acc_w[x]);
         }
         int rc;
         ctx->part_off_this_count = false;
+        if (mp_done) goto sort_done;
       sort_again:
         ctx->sort_back = 0;
         if ((rc = sort_rows(ctx, tot_rows))) return rc;
@@ -2693,6 +2764,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             CK(hipStreamSynchronize(ctx->stream));
             ctx->stats.sort_fallback = 1;
         }
+      sort_done:
         ctx->resolve_marks();
         ctx->n_rows = tot_rows;
         ctx->stats.n_bytes = from_reads ? ctx->n_bytes : 0;
@@ -2704,7 +2776,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         ctx->stats.n_passes = npass;
         ctx->stats.n_read_sweeps = npass > 1 ? sweeps : (from_reads ? 1 : 0);
         if (from_reads) ctx->last_rows = tot_rows;
-        if (npass > 1) {      // the names go back: acc_* stays the job-sized buffer (it holds the result now), out_* the pass-sized one --
+        if (npass > 1 && !mp_done) {      // the names go back: acc_* stays the job-sized buffer (it holds the result now), out_* the pass-sized one --
             std::swap(ctx->out_ab, ctx->acc_ab);      // left swapped, the next count grew the small one to job size again (10 GB of hipMalloc + hipFree per call)
             for (int x = 0; x < W; ++x) std::swap(ctx->out_w[x], ctx->acc_w[x]);
         }
@@ -3586,7 +3658,11 @@ int dskgpu_set_row_order(dskgpu_ctx* ctx, int partition_order) {
 uint32_t dskgpu_num_partitions(const dskgpu_ctx* ctx) { return (ctx && ctx->have_result) ? ctx->stats.n_partitions : 0; }
 
 static void part_range(const dskgpu_ctx* ctx, uint32_t p, u64* b, u64* e) {
-    if (ctx->part_mode) { *b = ctx->h_part_off[p]; *e = ctx->h_part_off[p + 1]; return; }
+    if (ctx->part_mode) {
+        if (!ctx->h_part_off64.empty()) { *b = ctx->h_part_off64[p]; *e = ctx->h_part_off64[p + 1]; }      // (several passes: 64-bit row numbers)
+        else { *b = ctx->h_part_off[p]; *e = ctx->h_part_off[p + 1]; }
+        return;
+    }
     const u64 P = ctx->stats.n_partitions, n = ctx->n_rows;
     *b = n * p / P; *e = n * (p + 1) / P;
 }
@@ -3594,6 +3670,15 @@ static void part_range(const dskgpu_ctx* ctx, uint32_t p, u64* b, u64* e) {
 uint64_t dskgpu_partition_size(const dskgpu_ctx* ctx, uint32_t p) {
     if (!ctx || !ctx->have_result || p >= ctx->stats.n_partitions) return 0;
     u64 b, e; part_range(ctx, p, &b, &e); return e - b;
+}
+
+int dskgpu_partition_offsets(const dskgpu_ctx* ctx, uint64_t* offsets) {
+    if (!ctx || !offsets) return DSKGPU_E_ARG;
+    if (!ctx->have_result) return DSKGPU_E_STATE;
+    const u32 P = ctx->stats.n_partitions;
+    for (u32 p = 0; p < P; ++p) { u64 b, e; part_range(ctx, p, &b, &e); offsets[p] = b; if (p + 1 == P) offsets[P] = e; }
+    if (P == 0) offsets[0] = 0;
+    return DSKGPU_OK;
 }
 
 int dskgpu_partition_copy(const dskgpu_ctx* cctx, uint32_t p, uint64_t* kmers, uint32_t* abundance) {

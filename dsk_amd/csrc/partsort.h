@@ -17,17 +17,24 @@
 //   store  LDS -> the dense result arrays, coalesced
 //
 // What the block does not order itself raises *flag and the host orders ALL rows with the global sort instead (exact for any
-// input): a partition above PS_CAP rows (a sub-partition that alone holds more solid rows than a block takes: -abundance-min 1
-// on a repeat family), or a bin above PS_MAXC rows (thousands of solid k-mers sharing 6 leading bases inside one hash class).
+// input): a partition above PS_CAP rows (consecutive sub-partitions far above the mean: -abundance-min 1 on a repeat family), or -- a
+// test switch only, DSKGPU_PS_MAXC -- a bin above pp.maxc rows.
+// Either way the block still writes ALL its rows to their dense place (unordered / in bin order): the output is a complete
+// permutation of the rows whatever the flag says -- the passes of a multi-pass count lay their rows behind each other this way
+// (one launch per pass, one flag for the job) and a raised flag only means "sort these dense rows globally after all".
+// (the tail block of a pass may read and write the same addresses: every row is in registers or copied 1:1 before it is stored)
 #pragma once
 #include "rowsort.h"
 #include "rowsort2.h"
 
+#ifndef PS_NT
 #define PS_NT 512
 #define PS_RPT 8
+#endif
 #define PS_CAP (PS_NT * PS_RPT)           // rows a block orders (4096: 48 KB of one-word rows; two blocks per CU)
 #define PS_BINS 4096
-#define PS_MAXC 48u                       // rows sharing a bin that are still ordered here
+#define PS_MAXC 4096u                     // rows sharing a bin that are still ordered here: all a block holds -- a bin of c rows costs every one of them c LDS
+                                          // reads (the poly-A variants of a partition share their first six bases: some hundred rows, a few microseconds)
 #define PS_MAXQ 512                       // most sub-partitions per output partition (the LDS slice of the scanned counts)
 
 struct PsParams { u32 qpp, nparts_sparse; int sh; u32 n_tail, maxc; };      // sh: value >> sh = bin (the top 12 of the 2k value bits); maxc <= PS_MAXC: rows of a bin ordered here
@@ -55,7 +62,20 @@ __global__ __launch_bounds__(PS_NT) void k_part_sort(RsSparse s, const u64* __re
         part_off[p] = r0;
         if (p + 1 == gridDim.x) part_off[p + 1] = r0 + n;
     }
-    if (n > PS_CAP) { if (tid == 0) *flag = 1u; return; }          // (block-uniform)
+    if (n > PS_CAP) {                                               // (block-uniform) more rows than a block orders: hand them on as they are, dense, and say so
+        if (tid == 0) *flag = 1u;
+        for (u32 i = tid; i < n; i += PS_NT) {
+            const u32 r = r0 + i;
+            if (is_tail) { ov[(u64)r] = tail_k[i]; oab[(u64)r] = tail_v[i]; }
+            else {
+                u32 lo = 0, hi = nq;
+                while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (lsoff[mid] <= r) lo = mid; else hi = mid; }
+                const u64 src = rs_sp_base(s, q0 + lo) + (u64)(r - lsoff[lo]);
+                ov[(u64)r] = kunmix(s.keys[src]); oab[(u64)r] = s.ab[src];
+            }
+        }
+        return;
+    }
     if (n == 0) return;
     u64 k[PS_RPT]; u32 a[PS_RPT], rb[PS_RPT];                       // rb = bin << 16 | rank inside the bin
 #pragma unroll
@@ -91,7 +111,7 @@ __global__ __launch_bounds__(PS_NT) void k_part_sort(RsSparse s, const u64* __re
         bool heavy = false;
 #pragma unroll
         for (int x = 0; x < CPT; ++x) { cnt[tid * CPT + x] = (run << 16) | c[x]; run += c[x]; heavy = heavy || c[x] > pp.maxc; }
-        if (heavy) *flag = 1u;                                       // (the rows are still written, in bin order: the host does not use them)
+        if (heavy) *flag = 1u;                                       // (the rows are still all written, a bin above PS_MAXC in the order its rows arrived)
     }
     __syncthreads();
     u32 pos[PS_RPT], cb[PS_RPT];
@@ -110,10 +130,10 @@ __global__ __launch_bounds__(PS_NT) void k_part_sort(RsSparse s, const u64* __re
 #pragma unroll
     for (int j = 0; j < PS_RPT; ++j) {
         const u32 c = cb[j] & 0xFFFFu;
-        if (rb[j] != 0xFFFFFFFFu && c > 1u) {
-            const u32 o = cb[j] >> 16, cc = c < PS_MAXC ? c : PS_MAXC;
+        if (rb[j] != 0xFFFFFFFFu && c > 1u && c <= PS_MAXC) {       // (a bin above PS_MAXC rows -- flagged -- keeps the order it was placed in: the rows stay a complete permutation)
+            const u32 o = cb[j] >> 16;
             u32 less = 0;
-            for (u32 x = 0; x < cc; ++x) less += lk[o + x] < k[j] ? 1u : 0u;
+            for (u32 x = 0; x < c; ++x) less += lk[o + x] < k[j] ? 1u : 0u;
             pos[j] = o + less; moved = true;
         }
     }
@@ -121,14 +141,16 @@ __global__ __launch_bounds__(PS_NT) void k_part_sort(RsSparse s, const u64* __re
     if (moved) {
 #pragma unroll
         for (int j = 0; j < PS_RPT; ++j)
-            if (rb[j] != 0xFFFFFFFFu && (cb[j] & 0xFFFFu) > 1u) { lk[pos[j]] = k[j]; la[pos[j]] = a[j]; }
+            if (rb[j] != 0xFFFFFFFFu && (cb[j] & 0xFFFFu) > 1u && (cb[j] & 0xFFFFu) <= PS_MAXC) { lk[pos[j]] = k[j]; la[pos[j]] = a[j]; }
     }
     __syncthreads();
     for (u32 i = tid; i < n; i += PS_NT) { ov[(u64)r0 + i] = lk[i]; oab[(u64)r0 + i] = la[i]; }
 }
 
 // ---- the same for two-word rows (33 <= k <= 64): (hi, lo, abundance) in three arrays, PS2_CAP rows per block
+#ifndef PS2_RPT
 #define PS2_RPT 4
+#endif
 #define PS2_CAP (PS_NT * PS2_RPT)         // 2048 rows: 40 KB of rows + 16 KB of bins, two blocks per CU
 __device__ __forceinline__ u32 ps2_bin(u64 hi, u64 lo, int sh) {      // the top 12 of the 2k value bits: (hi : lo) >> sh
     const u64 v = sh >= 64 ? hi >> (sh - 64) : sh == 0 ? lo : ((hi << (64 - sh)) | (lo >> sh));
@@ -154,7 +176,21 @@ __global__ __launch_bounds__(PS_NT) void k_part_sort2(Rs2Sparse s, Rows2C tail, 
         part_off[p] = r0;
         if (p + 1 == gridDim.x) part_off[p + 1] = r0 + n;
     }
-    if (n > PS2_CAP) { if (tid == 0) *flag = 1u; return; }
+    if (n > PS2_CAP) {
+        if (tid == 0) *flag = 1u;
+        for (u32 i = tid; i < n; i += PS_NT) {
+            const u32 r = r0 + i;
+            if (is_tail) { const u64 th = tail.hi[i], tl = tail.lo[i]; const u32 ta = tail.ab[i]; o.hi[(u64)r] = th; o.lo[(u64)r] = tl; o.ab[(u64)r] = ta; }
+            else {
+                u32 lo = 0, hi = nq;
+                while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (lsoff[mid] <= r) lo = mid; else hi = mid; }
+                const u64 src = rs2_sp_base(s, q0 + lo) + (u64)(r - lsoff[lo]);
+                K2 kx = s.keys[src]; kunmixN(kx);
+                o.hi[(u64)r] = kx.w[1]; o.lo[(u64)r] = kx.w[0]; o.ab[(u64)r] = s.ab[src];
+            }
+        }
+        return;
+    }
     if (n == 0) return;
     u64 kh[PS2_RPT], kl[PS2_RPT]; u32 a[PS2_RPT], rb[PS2_RPT];
 #pragma unroll
@@ -209,10 +245,10 @@ __global__ __launch_bounds__(PS_NT) void k_part_sort2(Rs2Sparse s, Rows2C tail, 
 #pragma unroll
     for (int j = 0; j < PS2_RPT; ++j) {
         const u32 c = cb[j] & 0xFFFFu;
-        if (rb[j] != 0xFFFFFFFFu && c > 1u) {
-            const u32 ob = cb[j] >> 16, cc = c < PS_MAXC ? c : PS_MAXC;
+        if (rb[j] != 0xFFFFFFFFu && c > 1u && c <= PS_MAXC) {
+            const u32 ob = cb[j] >> 16;
             u32 less = 0;
-            for (u32 x = 0; x < cc; ++x) { const u64 h = lh[ob + x], l = ll[ob + x]; less += (h < kh[j] || (h == kh[j] && l < kl[j])) ? 1u : 0u; }
+            for (u32 x = 0; x < c; ++x) { const u64 h = lh[ob + x], l = ll[ob + x]; less += (h < kh[j] || (h == kh[j] && l < kl[j])) ? 1u : 0u; }
             pos[j] = ob + less; moved = true;
         }
     }
@@ -220,7 +256,7 @@ __global__ __launch_bounds__(PS_NT) void k_part_sort2(Rs2Sparse s, Rows2C tail, 
     if (moved) {
 #pragma unroll
         for (int j = 0; j < PS2_RPT; ++j)
-            if (rb[j] != 0xFFFFFFFFu && (cb[j] & 0xFFFFu) > 1u) { lh[pos[j]] = kh[j]; ll[pos[j]] = kl[j]; la[pos[j]] = a[j]; }
+            if (rb[j] != 0xFFFFFFFFu && (cb[j] & 0xFFFFu) > 1u && (cb[j] & 0xFFFFu) <= PS_MAXC) { lh[pos[j]] = kh[j]; ll[pos[j]] = kl[j]; la[pos[j]] = a[j]; }
     }
     __syncthreads();
     for (u32 i = tid; i < n; i += PS_NT) { o.hi[(u64)r0 + i] = lh[i]; o.lo[(u64)r0 + i] = ll[i]; o.ab[(u64)r0 + i] = la[i]; }

@@ -87,7 +87,7 @@ EXPORTS = [
     "dskgpu_count", "dskgpu_mg_scatter", "dskgpu_mg_sample", "dskgpu_mg_make_table", "dskgpu_mg_set_table",
     "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_mg_sent_kmers", "dskgpu_mg_count_sized",
     "dskgpu_mg_slices_prepare", "dskgpu_mg_scatter_slice", "dskgpu_mg_slices_finish", "dskgpu_mg_count_sliced", "dskgpu_get_stats", "dskgpu_histogram",
-    "dskgpu_set_row_order", "dskgpu_num_partitions", "dskgpu_partition_size", "dskgpu_partition_copy", "dskgpu_result_device",
+    "dskgpu_set_row_order", "dskgpu_num_partitions", "dskgpu_partition_size", "dskgpu_partition_offsets", "dskgpu_partition_copy", "dskgpu_result_device",
     "dskgpu_stage_times", "dskgpu_k_encode", "dskgpu_k_enumerate", "dskgpu_k_minimizers",
     "dskgpu_group_create", "dskgpu_group_destroy", "dskgpu_group_last_error", "dskgpu_group_size", "dskgpu_group_ctx",
     "dskgpu_group_transport", "dskgpu_group_count", "dskgpu_group_exchanged_words", "dskgpu_group_sliced_steps", "dskgpu_group_histogram", "dskgpu_group_histogram2d",
@@ -154,6 +154,7 @@ def load_library():
     lib.dskgpu_num_partitions.restype = u32
     lib.dskgpu_set_row_order.argtypes = [vp, C.c_int]
     lib.dskgpu_partition_size.argtypes = [vp, u32]
+    lib.dskgpu_partition_offsets.argtypes = [vp, vp]
     lib.dskgpu_partition_size.restype = u64
     lib.dskgpu_partition_copy.argtypes = [vp, u32, vp, vp]
     lib.dskgpu_result_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
@@ -418,8 +419,13 @@ class KmerCounter:
     def set_row_order(self, partition_order: bool) -> None:
         self._ck(self._lib.dskgpu_set_row_order(self._h, 1 if partition_order else 0))
 
+    def partition_offsets(self) -> np.ndarray:
+        off = np.zeros(self.num_partitions() + 1, dtype=np.uint64)
+        self._ck(self._lib.dskgpu_partition_offsets(self._h, C.c_void_p(off.ctypes.data)))
+        return off
+
     def partition_sizes(self) -> np.ndarray:
-        return np.array([int(self._lib.dskgpu_partition_size(self._h, p)) for p in range(self.num_partitions())], dtype=np.int64)
+        return np.diff(self.partition_offsets().astype(np.int64))
 
     def rows(self) -> Tuple[np.ndarray, np.ndarray]:
         """All solid rows, partitions concatenated in index order (what dsk2ascii walks)."""

@@ -344,11 +344,19 @@ private:
         if (const char* e = getenv("DSK_PGZIP_CHUNK_BYTES")) pgz_chunk = (size_t)atoll(e);
         bool ok = false;
         try {
-            ok = pgz_inflate((const uint8_t*)m, size, std::min(nthreads, 64u), pgz_chunk, [&](const char* data, size_t len, bool last) {
-                slab.resize(carry.size() + len);
-                std::memcpy(slab.data(), carry.data(), carry.size());
-                std::memcpy(slab.data() + carry.size(), data, len);
-                const char* base = slab.data(); const char* end = base + slab.size(); const char* p = base;
+            // (the inflate is pure CPU work on independent chunks: it takes up to 64 threads where the parser is capped at 32)
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const size_t HEAD = 4u << 20;                        // room in front of every slab for the previous slab's cut-off record
+            ok = pgz_inflate((const uint8_t*)m, size, std::min(std::max(nthreads, std::min(hw, 64u)), 64u), pgz_chunk, HEAD, [&](char* data, size_t len, bool last) {
+                const char* base; const char* end;
+                if (carry.size() <= HEAD) { std::memcpy(data - carry.size(), carry.data(), carry.size()); base = data - carry.size(); end = data + len; }
+                else {                                           // (a record longer than the headroom: the slab is copied behind it)
+                    slab.resize(carry.size() + len);
+                    std::memcpy(slab.data(), carry.data(), carry.size());
+                    std::memcpy(slab.data() + carry.size(), data, len);
+                    base = slab.data(); end = base + slab.size();
+                }
+                const char* p = base;
                 if (first) { kind = record_kind(p, end); first = false; if (!kind) throw NotRecords{}; }
                 const char* stop = end;
                 if (!last) {                                     // keep the (possibly cut) last record for the next slab

@@ -12,6 +12,9 @@
 #include <cstring>
 #include <stdexcept>
 #include <thread>
+#include <new>
+
+#include <sys/mman.h>
 
 namespace dsk {
 namespace {
@@ -127,10 +130,29 @@ void fixed_codes(BlockCodes& bc) {
 inline bool texty(int c) { return c == '\n' || c == '\r' || c == '\t' || (c >= 32 && c < 127); }
 
 // One chunk's output: WIN marker slots, then the symbols
+// (raw storage, never zero-filled: a chunk's symbols are twice its inflated bytes, and value-initialising them -- plus the page faults of a
+//  fresh std::vector per chunk -- cost more than the inflate itself on a 64-thread host)
+struct RawBuf {
+    void* p = nullptr; size_t cap = 0;
+    ~RawBuf() { free(p); }
+    RawBuf() = default; RawBuf(const RawBuf&) = delete; RawBuf& operator=(const RawBuf&) = delete;
+    void reserve(size_t bytes, size_t keep) {              // grow to >= bytes, keeping the first `keep` bytes
+        if (bytes <= cap) return;
+        void* q = nullptr;
+        const size_t want = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        if (posix_memalign(&q, 2u << 20, want) != 0) throw std::bad_alloc();
+        madvise(q, want, MADV_HUGEPAGE);
+        if (keep && p) std::memcpy(q, p, keep);
+        free(p); p = q; cap = want;
+    }
+    void release() { free(p); p = nullptr; cap = 0; }
+};
 struct SymBuf {
-    std::vector<sym_t> v; size_t n = 0;                     // symbols written behind the WIN prefix
-    void init(size_t reserve) { v.resize(WIN + reserve); for (uint32_t j = 0; j < WIN; ++j) v[j] = (sym_t)(0x8000u | j); n = 0; }
-    inline void need(size_t more) { if (WIN + n + more > v.size()) v.resize(std::max(v.size() * 3 / 2, WIN + n + more + (1u << 20))); }
+    RawBuf b; sym_t* v = nullptr; size_t n = 0, cap = 0;    // symbols written behind the WIN prefix; cap = symbols of room (prefix included)
+    void init(size_t reserve) { b.reserve((WIN + reserve) * sizeof(sym_t), 0); v = (sym_t*)b.p; cap = b.cap / sizeof(sym_t); for (uint32_t j = 0; j < WIN; ++j) v[j] = (sym_t)(0x8000u | j); n = 0; }
+    inline void need(size_t more) {
+        if (WIN + n + more > cap) { b.reserve(std::max(cap * 3 / 2, WIN + n + more + (1u << 20)) * sizeof(sym_t), (WIN + n) * sizeof(sym_t)); v = (sym_t*)b.p; cap = b.cap / sizeof(sym_t); }
+    }
 };
 
 enum Stop { ST_OK = 0, ST_BAD = 1, ST_FINAL = 2 };
@@ -156,7 +178,7 @@ Stop inflate_blocks(Bits& br, SymBuf& out, uint64_t until_bit, uint64_t* end_bit
             else if (!read_dynamic(br, bc, probe)) return ST_BAD;
             for (;;) {
                 out.need(258 + 8);
-                sym_t* o = out.v.data() + WIN + out.n;
+                sym_t* o = out.v + WIN + out.n;
                 const int s = bc.lit.decode(br);
                 if (s < 0) return ST_BAD;
                 if (s < 256) { if (probe && !texty(s)) return ST_BAD; *o = (sym_t)s; ++out.n; continue; }
@@ -229,8 +251,8 @@ static size_t member_header(const uint8_t* file, size_t n, size_t off) {
     return h + 8 <= n ? h : 0;
 }
 
-bool pgz_inflate(const uint8_t* file, size_t n, unsigned nthreads, size_t chunk_bytes,
-                 const std::function<void(const char*, size_t, bool)>& consume) {
+bool pgz_inflate(const uint8_t* file, size_t n, unsigned nthreads, size_t chunk_bytes, size_t headroom,
+                 const std::function<void(char*, size_t, bool)>& consume) {
     const size_t h0 = member_header(file, n, 0);
     if (!h0) return false;
     if (!chunk_bytes) chunk_bytes = 2u << 20;
@@ -243,7 +265,7 @@ bool pgz_inflate(const uint8_t* file, size_t n, unsigned nthreads, size_t chunk_
     uint64_t at_bit = (uint64_t)h0 * 8;                      // exact position reached so far (inside the current member's deflate stream)
     std::vector<uint8_t> window(WIN, 0);                    // the 32 KB before it (resolved)
     uLong crc = crc32(0L, Z_NULL, 0); uint64_t total_out = 0;      // of the current member
-    std::vector<char> bytes;
+    RawBuf bytes;                                           // [headroom | the slab's inflated bytes]
     bool first_slab = true, file_done = false;
 
     // the member's deflate stream ended at byte `end_byte`: its trailer must match; -> true when another member follows (at_bit set)
@@ -307,18 +329,20 @@ bool pgz_inflate(const uint8_t* file, size_t n, unsigned nthreads, size_t chunk_
             size_t ib = (size_t)(at_bit >> 3);
             if (pre) { inflatePrime(&zs, 8 - pre, data[ib] >> pre); ++ib; }
             zs.next_in = const_cast<Bytef*>(data + ib); zs.avail_in = (uInt)std::min<size_t>(dn - ib, 1u << 30);
-            bytes.resize(64u << 20);
+            const size_t zbuf = 64u << 20;
+            bytes.reserve(headroom + zbuf, 0);
+            char* const zout = (char*)bytes.p + headroom;
             size_t end_byte = 0; bool more = false;
             for (;;) {
-                zs.next_out = (Bytef*)bytes.data(); zs.avail_out = (uInt)bytes.size();
+                zs.next_out = (Bytef*)zout; zs.avail_out = (uInt)zbuf;
                 if (zs.avail_in == 0) { const size_t used = (size_t)(zs.next_in - data); zs.avail_in = (uInt)std::min<size_t>(dn - used, 1u << 30); }
                 const int rc = inflate(&zs, Z_NO_FLUSH);
-                const size_t got = bytes.size() - zs.avail_out;
+                const size_t got = zbuf - zs.avail_out;
                 if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); throw std::runtime_error("corrupt gzip stream"); }
-                crc = crc32(crc, (const Bytef*)bytes.data(), (uInt)got); total_out += got;
+                crc = crc32(crc, (const Bytef*)zout, (uInt)got); total_out += got;
                 const bool end = rc == Z_STREAM_END;
                 if (end) { end_byte = (size_t)(zs.next_in - data); inflateEnd(&zs); more = next_member(end_byte); }
-                if (got || (end && !more)) consume(bytes.data(), got, end && !more);
+                if (got || (end && !more)) consume(zout, got, end && !more);
                 if (end) break;
                 if (got == 0 && zs.avail_in == 0 && (size_t)(zs.next_in - data) >= dn) { inflateEnd(&zs); throw std::runtime_error("truncated gzip stream"); }
             }
@@ -335,25 +359,38 @@ bool pgz_inflate(const uint8_t* file, size_t n, unsigned nthreads, size_t chunk_
             c.win_after.resize(WIN);
             const size_t take = std::min<size_t>(WIN, c.out.n);
             if (take < WIN) std::memcpy(c.win_after.data(), wprev.data() + take, WIN - take);
-            const sym_t* sy = c.out.v.data() + WIN + c.out.n - take;
+            const sym_t* sy = c.out.v + WIN + c.out.n - take;
             for (size_t i = 0; i < take; ++i) c.win_after[WIN - take + i] = sy[i] < 256 ? (uint8_t)sy[i] : wprev[sy[i] & 0x7FFFu];
         }
         // 4. symbols -> bytes + CRC per chunk (parallel)
-        bytes.resize(out_total);
+        bytes.reserve(headroom + out_total + 64, 0);
+        char* const out_base = (char*)bytes.p + headroom;
         run_pool(nthreads, good, [&](size_t li) {
             Chunk& c = ch[live[li]];
             const std::vector<uint8_t>& wprev = li == 0 ? window : ch[live[li - 1]].win_after;
-            const sym_t* sy = c.out.v.data() + WIN; char* o = bytes.data() + c.out_off;
-            for (size_t i = 0; i < c.out.n; ++i) o[i] = (char)(sy[i] < 256 ? (uint8_t)sy[i] : wprev[sy[i] & 0x7FFFu]);
+            const sym_t* sy = c.out.v + WIN; char* o = out_base + c.out_off;
+            size_t i = 0;
+            const size_t n8 = c.out.n & ~(size_t)7;
+            for (; i < n8; i += 8) {                          // eight symbols at a time when none of them is a marker (nearly always, past a chunk's first KBs)
+                uint64_t a, b2; std::memcpy(&a, sy + i, 8); std::memcpy(&b2, sy + i + 4, 8);
+                if (((a | b2) & 0xFF00FF00FF00FF00ull) == 0) {
+                    a = (a | (a >> 8)) & 0x0000FFFF0000FFFFull; a = (a | (a >> 16)) & 0xFFFFFFFFull;
+                    b2 = (b2 | (b2 >> 8)) & 0x0000FFFF0000FFFFull; b2 = (b2 | (b2 >> 16)) & 0xFFFFFFFFull;
+                    const uint64_t w = a | (b2 << 32);
+                    std::memcpy(o + i, &w, 8);
+                } else for (size_t x = i; x < i + 8; ++x) o[x] = (char)(sy[x] < 256 ? (uint8_t)sy[x] : wprev[sy[x] & 0x7FFFu]);
+            }
+            for (; i < c.out.n; ++i) o[i] = (char)(sy[i] < 256 ? (uint8_t)sy[i] : wprev[sy[i] & 0x7FFFu]);
             c.crc = crc32(crc32(0L, Z_NULL, 0), (const Bytef*)o, (uInt)c.out.n);
-            c.out.v.clear(); c.out.v.shrink_to_fit();
+            // (the symbol buffers are given back by the slab's destructor, after the bytes have been handed on: 25 MB munmaps from
+            //  64 threads at once serialise in the kernel)
         });
         for (size_t li = 0; li < good; ++li) { crc = crc32_combine(crc, ch[live[li]].crc, (z_off_t)ch[live[li]].out.n); total_out += ch[live[li]].out.n; }
         const Chunk& lastc = ch[live[good - 1]];
         at_bit = lastc.end_bit; window = lastc.win_after;
         if (trace) fprintf(stderr, "[pgzip]   resolve + bytes + crc %.1f ms, %zu bytes out\n", now() - tt2, out_total);
         if (ended) file_done = !next_member((size_t)((lastc.end_bit + 7) >> 3));      // (checks this member's CRC-32 and size before its last bytes are handed on)
-        consume(bytes.data(), out_total, file_done);
+        consume(out_base, out_total, file_done);
         first_slab = false;
     }
     return true;

@@ -11,10 +11,11 @@
 //      bytes (parallel)
 //   3. the windows are resolved chunk after chunk (32 KB each: the only serial step), then every chunk's symbols become bytes
 //      (parallel), the CRC-32 of the chunks is combined and checked against the member's trailer together with ISIZE.
-// Anything the scheme does not cover -- no dynamic block found in a chunk, a chunk that does not end on its successor's start,
-// several members in one file, a CRC mismatch -- makes the call return false BEFORE any byte is handed on (slab 0) or throw
-// (later slabs, where bytes have been consumed): the caller then inflates with zlib as before.  Exactness never rests on the
-// heuristics: every slab is verified by the running CRC-32 at the end.
+// What the scheme does not cover: a file whose first slab does not pass (no dynamic block found where one is searched, a chunk that
+// does not end on its successor's start -- e.g. data that is not text) makes the call return false BEFORE any byte is handed on, and
+// the caller inflates with zlib as before; a LATER slab that does not pass is inflated by zlib from the exact bit position and window
+// reached (inflatePrime + inflateSetDictionary).  Several members (`cat a.gz b.gz`) are handled: each member's trailer is checked
+// where the member ends.  Exactness never rests on the heuristics: every member is verified by its CRC-32 and size.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -24,10 +25,13 @@
 namespace dsk {
 
 // Inflate the gzip file image [file, file + n) slab by slab on `nthreads` threads.  For every slab, `consume(bytes, len, last)` is
-// called once, in stream order (the buffer is reused afterwards).  chunk_bytes = compressed bytes per chunk (0 = default 2 MB).
-// Returns false (and has called consume for NOTHING) when the file is not a single-member gzip this scheme handles or its first
-// slab does not pass; throws std::runtime_error when a later slab fails (corrupt file).
-bool pgz_inflate(const uint8_t* file, size_t n, unsigned nthreads, size_t chunk_bytes,
-                 const std::function<void(const char*, size_t, bool)>& consume);
+// called once, in stream order; `headroom` writable bytes lie in front of `bytes` (the caller's cut-off last record of the previous
+// slab goes there: one contiguous buffer to parse, no copy of the slab); the buffer is reused afterwards.  chunk_bytes = compressed
+// bytes per chunk (0 = default 2 MB).  Members that follow the first one are inflated the same way.
+// Returns false (and has called consume for NOTHING) when the file is not a gzip this scheme handles or its first slab does not
+// pass; a later slab that does not pass is inflated by zlib from the exact position and window reached; throws std::runtime_error
+// for a corrupt file (CRC-32 / size mismatch, truncation).
+bool pgz_inflate(const uint8_t* file, size_t n, unsigned nthreads, size_t chunk_bytes, size_t headroom,
+                 const std::function<void(char*, size_t, bool)>& consume);
 
 }  // namespace dsk

@@ -249,6 +249,9 @@ int dskgpu_histogram2d(const dskgpu_ctx* ctx, uint64_t* out, uint32_t nrows);
 int dskgpu_set_row_order(dskgpu_ctx* ctx, int partition_order);
 uint32_t dskgpu_num_partitions(const dskgpu_ctx* ctx);
 uint64_t dskgpu_partition_size(const dskgpu_ctx* ctx, uint32_t p);
+/* offsets[p] = first row of partition p in the result arrays (dskgpu_result_device), offsets[num_partitions] = all rows:
+ * what a caller of DSKGPU_F_PARTITION_ORDER walks (thousands of partitions: one call instead of one per partition). */
+int dskgpu_partition_offsets(const dskgpu_ctx* ctx, uint64_t* offsets /* [dskgpu_num_partitions + 1] */);
 /* kmers: size*words u64 (row-major, LSW first, words = ceil(k/32)); abundance: size u32. Host memory. */
 int dskgpu_partition_copy(const dskgpu_ctx* ctx, uint32_t p, uint64_t* kmers, uint32_t* abundance);
 /* Device pointers to the full sorted result (valid until the next count/destroy).  d_kmers = word 0 of

@@ -20,9 +20,10 @@ def valid_windows(reads, nr, rl, k):
     return n_valid
 
 
-def device_invariants(kc, st, hist, k, reads, nr, rl, dev, amin=2, n_valid=None):
+def device_invariants(kc, st, hist, k, reads, nr, rl, dev, amin=2, n_valid=None, partition_order=False):
     """sum(i * hist[i]) == n_kmers (nothing saturates), sum(hist) == n_distinct, sum(hist[amin:]) == n_solid == rows, rows strictly
-    ascending, histogram of the rows' abundances == hist tail, n_kmers == number of full ACGT windows (closed form: <= 1 'N' per read)."""
+    ascending (partition_order: inside every output partition, the partitions' sizes adding up to the rows), histogram of the rows'
+    abundances == hist tail, n_kmers == number of full ACGT windows (closed form: <= 1 'N' per read)."""
     h = hist.astype(np.int64)
     idx = np.arange(len(h), dtype=np.int64)
     sat = int(h[-1])
@@ -35,14 +36,29 @@ def device_invariants(kc, st, hist, k, reads, nr, rl, dev, amin=2, n_valid=None)
     bins = torch.zeros(len(h), dtype=torch.int64, device=dev)
     kbuf = torch.empty(step, dtype=torch.int64, device=dev); abuf = torch.empty(step, dtype=torch.int32, device=dev)
     last = None; ab_sum = 0
+    starts = None; n_partitions = None
+    if partition_order:          # first row of every partition but the first: the only places where a row may be smaller than its predecessor
+        sizes = kc.partition_sizes()
+        assert int(sizes.sum()) == n, "partition sizes do not add up to the rows"
+        n_partitions = int(len(sizes))
+        starts = torch.from_numpy(np.cumsum(sizes)[:-1].astype(np.int64)).to(dev)
     for r0 in range(0, n, step):
         m = min(step, n - r0)
         hip.hipMemcpy(ctypes.c_void_p(kbuf.data_ptr()), ctypes.c_void_p(kp + r0 * 8), ctypes.c_size_t(m * 8), 3)
         hip.hipMemcpy(ctypes.c_void_p(abuf.data_ptr()), ctypes.c_void_p(ap + r0 * 4), ctypes.c_size_t(m * 4), 3)
         kk = kbuf[:m]
-        assert bool((kk[1:] > kk[:-1]).all()), "rows not strictly ascending"          # (k <= 31: values < 2^62, signed compare is safe)
-        if last is not None:
-            assert int(kk[0]) > last
+        asc = kk[1:] > kk[:-1]                                                         # (k <= 31: values < 2^62, signed compare is safe)
+        if starts is not None:
+            inside = torch.ones(m - 1, dtype=torch.bool, device=dev) if m > 1 else torch.ones(0, dtype=torch.bool, device=dev)
+            loc = starts[(starts > r0) & (starts < r0 + m)] - r0 - 1               # asc[i] compares rows i and i + 1: a partition starting at row s excuses asc[s - 1]
+            inside[loc] = False
+            assert bool(asc[inside].all()), "a partition is not strictly ascending"
+            if last is not None and not bool(((starts == r0).any())):
+                assert int(kk[0]) > last
+        else:
+            assert bool(asc.all()), "rows not strictly ascending"
+            if last is not None:
+                assert int(kk[0]) > last
         last = int(kk[-1])
         a = abuf[:m].to(torch.int64)
         ab_sum += int(a.sum())
@@ -55,6 +71,9 @@ def device_invariants(kc, st, hist, k, reads, nr, rl, dev, amin=2, n_valid=None)
     if n_valid is None:          # (n_valid given: the reads themselves are gone -- released after dskgpu_encode_reads)
         n_valid = valid_windows(reads, nr, rl, k)
     assert n_valid == st["n_kmers"], (n_valid, st["n_kmers"])
-    return {"rows_checked": int(n), "saturated_histogram_rows": sat}
+    out = {"rows_checked": int(n), "saturated_histogram_rows": sat}
+    if n_partitions is not None:
+        out["partitions_checked"] = n_partitions
+    return out
 
 

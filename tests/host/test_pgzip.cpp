@@ -27,8 +27,9 @@ int main(int argc, char** argv) {
     std::vector<char> out; size_t slabs = 0; bool saw_last = false;
     bool ok = false;
     try {
-        ok = dsk::pgz_inflate(z.data(), z.size(), (unsigned)atoi(argv[2]), (size_t)atoll(argv[3]),
-                              [&](const char* d, size_t n, bool last) { out.insert(out.end(), d, d + n); ++slabs; if (saw_last) throw std::runtime_error("consume after last"); saw_last = last; });
+        ok = dsk::pgz_inflate(z.data(), z.size(), (unsigned)atoi(argv[2]), (size_t)atoll(argv[3]), 4096,
+                              [&](char* d, size_t n, bool last) { d[-1] = 'x'; d[-4096] = 'y';      // (the headroom is writable)
+                              out.insert(out.end(), d, d + n); ++slabs; if (saw_last) throw std::runtime_error("consume after last"); saw_last = last; });
     } catch (const std::exception& e) { printf("ERROR %s\n", e.what()); return 1; }
     auto t2 = std::chrono::steady_clock::now();
     if (!ok) { if (!out.empty()) { printf("ERROR declined after consuming\n"); return 1; } printf("NA\n"); return 0; }

@@ -1687,7 +1687,16 @@ def test_partition_order_is_the_reference_contract(oracle, golden_dir, dev, monk
     st = check(reads.cpu().numpy(), 31, 1, expect_parts=False)
     assert st["n_partitions"] == 4
     monkeypatch.delenv("DSKGPU_PS_MAXC")
-    check(reads.cpu().numpy(), 31, 1, expect_parts=False, max_pass_mkeys=2)      # several passes: dense accumulated rows, global order
+    # several passes: every pass orders its partitions on the way into the job's row arrays (one launch per pass instead of the compaction,
+    # no sort at the end); the partitions of the passes follow each other
+    st = check(reads.cpu().numpy(), 31, 1, expect_parts=True, max_pass_mkeys=2)
+    assert st["n_passes"] > 4
+    st = check(skew, 31, 2, expect_parts=None, max_pass_mkeys=2)  # (the poly-A variants of a pass share a value bin: a block gives up on its own, the job's rows are sorted globally)
+    assert st["n_passes"] > 4
+    monkeypatch.setenv("DSKGPU_PS_MAXC", "1")                      # ... and a block that gives up in one of the passes: the global sort over all passes' rows
+    st = check(reads.cpu().numpy(), 31, 1, expect_parts=False, max_pass_mkeys=2)
+    assert st["n_passes"] > 4 and st["n_partitions"] == 4
+    monkeypatch.delenv("DSKGPU_PS_MAXC")
     # two-word rows (33 <= k <= 64): 2048 rows per partition; every partition ascending on (high word, low word)
     for k, amin in ((63, 2), (63, 1), (33, 1), (40, 2), (64, 1)):
         kk, ab, sizes, hist, st = run(reads.cpu().numpy(), k, amin)
@@ -1701,6 +1710,10 @@ def test_partition_order_is_the_reference_contract(oracle, golden_dir, dev, monk
         inside = np.ones(len(asc), dtype=bool); inside[starts[(starts > 0) & (starts <= len(asc))] - 1] = False
         assert asc[inside].all() and not asc.all(), (k, amin)
     check(skew, 63, 1, expect_parts=None)
+    kk, ab, sizes, hist, st = run(reads.cpu().numpy(), 63, 1, max_pass_mkeys=2)          # two-word rows, several passes
+    ref = oracle.count(reads.cpu().numpy(), 63)
+    order = np.lexsort(kk.T)
+    assert st["n_passes"] > 4 and (kk[order] == ref.words()).all() and (ab[order] == ref.ab).all() and sizes.max() <= 2048 and len(sizes) > 4 * st["n_passes"]
     check(reads.cpu().numpy(), 101, 2, expect_parts=None)                        # four-word rows: not covered by the flag, global order
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The stand-in for BASELINE.json configs[4] (30x human: 3 Gbp repeat-rich genome, 600 M x 150 bp, k = 31, abundance-min 2) on ONE GPU,
 multi-pass, with the size-independent invariants checked on the device (the rows never leave HBM: 3 * 10^9 of them).
-   python tools/human_standin.py [reads_millions=600] [k=31] [steps=1] [abundance_min=2]
+   python tools/human_standin.py [reads_millions=600] [k=31] [steps=1] [abundance_min=2] [keep-ascii|-] [partition|global]
 reads_millions = 75 is the 1/8 shard of the same genome (what one of 8 GPUs holds)."""
 import json, sys, time
 import torch
@@ -28,7 +28,9 @@ def main():
     out = {"workload": f"c5_human30x stand-in: {nr} reads x {rl} bp of a repeat-rich 3 Gbp genome (1 % one 300 bp family, 4 tandem arrays, 0.2 % poly-A reads)",
            "kmer_size": k, "generate_s": round(t_gen, 1)}
     keep_ascii = len(sys.argv) > 5 and sys.argv[5] == "keep-ascii"          # (the round-4 way: the 90 GB of bytes stay in HBM during the count)
-    with KmerCounter(kmer_size=k, abundance_min=amin, timing=True) as kc:
+    part = not (len(sys.argv) > 6 and sys.argv[6] == "global")          # row order: the reference's contract (ascending inside every output partition) unless "global"
+    out["row_order"] = "partition" if part else "global"
+    with KmerCounter(kmer_size=k, abundance_min=amin, timing=True, partition_order=part) as kc:
         kc.set_reads_device(reads.data_ptr(), reads.numel())
         n_valid = None
         if not keep_ascii:
@@ -52,7 +54,8 @@ def main():
         free_b, total_b = torch.cuda.mem_get_info()
         out["hbm_used_gb"] = round((total_b - free_b) * 1e-9, 1)
         if k <= 31 and amin == 2:
-            out["invariants"] = device_invariants(kc, st, hist, k, reads, nr, rl, dev, n_valid=n_valid)
+            out["n_partitions"] = st["n_partitions"]
+            out["invariants"] = device_invariants(kc, st, hist, k, reads, nr, rl, dev, n_valid=n_valid, partition_order=part and st["n_partitions"] > 64)
     print(json.dumps(out))
 
 

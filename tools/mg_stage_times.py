@@ -3,7 +3,7 @@
 one context acts as rank 0 of `world`, scatters the bench shard (10 M x 150 bp) into records for all
 owners, then counts ALL of its own records -- the same number of k-mers a rank receives in the
 weak-scaling bench.  Prints stage times and the exchange volume per rank.
-   python tools/mg_stage_times.py [world=8] [k=31] [explicit=0] [workload=c2_10Mx150] [slices=0]
+   python tools/mg_stage_times.py [world=8] [k=31] [explicit=0] [workload=c2_10Mx150] [slices=0] [partition|global]
 slices >= 2: the step in that many slices (dskgpu_mg_slices_*: one sender launch and one level-1 launch per slice) -- the device
 work of a rank whose exchange is hidden behind it."""
 import os, sys, time
@@ -15,11 +15,12 @@ k = int(sys.argv[2]) if len(sys.argv) > 2 else 31
 explicit = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
 wl = sys.argv[4] if len(sys.argv) > 4 else "c2_10Mx150"
 slices = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+part = len(sys.argv) > 6 and sys.argv[6] == "partition"          # row order of the rank's result (default: global)
 dev = torch.device("cuda", 0)
 gl, nr, rl = synth.workload(wl)
 reads = synth.make_reads(synth.make_genome(gl, dev), nr, rl)
 torch.cuda.synchronize()
-kc = KmerCounter(kmer_size=k, abundance_min=2, world_size=world, rank=0, timing=True, mg_explicit=explicit,
+kc = KmerCounter(kmer_size=k, abundance_min=2, world_size=world, rank=0, timing=True, mg_explicit=explicit, partition_order=part,
                  stream=torch.cuda.current_stream().cuda_stream)
 kc.set_reads_device(reads.data_ptr(), reads.numel())
 send = None
