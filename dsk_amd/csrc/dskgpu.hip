@@ -159,9 +159,6 @@ struct Stage { const char* name; hipEvent_t ev; };
 struct Tuning {
     bool no_opt1 = false, no_opt2 = false;      // DSKGPU_NO_OPT1 / _NO_OPT2: exact histogram + scan path at level 1 / at both levels
     bool no_aligned = false;                    // DSKGPU_NO_ALIGNED: plain write-out for key-array scatters
-    bool fullsort = false;                      // DSKGPU_FULLSORT: full-width row sort
-    bool rows2_pairs = false;                   // DSKGPU_ROWS2_PAIRS: two-word rows as (top 63 bits, row index) pairs + gather + tie pass (the path before rowsort2.h)
-    bool lib_rowsort = false;                   // DSKGPU_LIB_ROWSORT: one-word rows through the library radix sort on a 32-bit prefix + run fix-up (the path before rowsort.h)
     u32 rs_heavy = 0;                           // DSKGPU_RS_HEAVY: rows of a first-digit bucket above which the row sort gives up (tests)
     u32 rs_bbits = 0;                           // DSKGPU_RS_BBITS: forced width of the row sort's second digit (8..10; tests)
     u32 rs_block_rows = 0;                      // DSKGPU_RS_BLOCK_ROWS: largest sub-bucket the hand-written row sort orders itself (tests: provoke its fallback)
@@ -180,21 +177,20 @@ struct Tuning {
     bool sk_generic = false;                    // DSKGPU_SK_GENERIC: the sender kernels with k and m at run time even for k = 31 / 63 (tests: both forms write the same records)
     bool l0_keys = false;                       // DSKGPU_L0_KEYS: level 0 as key arrays (k_level0) even where the record-based one applies (experiments, tests)
     u32 mp_pass_mkeys = 0;                      // DSKGPU_MP_PASS_MKEYS: keys (millions) per pass of an input that needs several passes (default 1000)
-    bool sort_compact = false;                  // DSKGPU_SORT_COMPACT: k_compact + dense step A (the path before r05: A/B runs; still the path of several passes and wide keys)
     u64 rs_slab_rows = 0;                       // DSKGPU_RS_SLAB_ROWS: rows per slab of the row sort for >= 2^32 rows (tests: forces that path, with small slabs, on a small input)
     void read() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         auto num = [](const char* n, u64 dflt) { const char* e = getenv(n); return e ? (u64)atoll(e) : dflt; };
         no_opt1 = on("DSKGPU_NO_OPT1"); no_opt2 = on("DSKGPU_NO_OPT2"); no_aligned = on("DSKGPU_NO_ALIGNED");
-        fullsort = on("DSKGPU_FULLSORT"); sk_exact = on("DSKGPU_SK_EXACT");
+        sk_exact = on("DSKGPU_SK_EXACT");
         no_recsrc = on("DSKGPU_NO_RECSRC");
         opt_cap = (u32)num("DSKGPU_OPT_CAP", 0) & ~7u; opt_slice = num("DSKGPU_OPT_SLICE", 0) & ~7ull;
         sk_slice = num("DSKGPU_SK_SLICE", 0); sk_minslice = num("DSKGPU_SK_MINSLICE", 2000);
         table_maxload = (u32)num("DSKGPU_TABLE_MAXLOAD", 0);
         max_ext = getenv("DSKGPU_MAX_EXT") ? atoll(getenv("DSKGPU_MAX_EXT")) : -1;
         no_sample = on("DSKGPU_NO_SAMPLE"); no_heavy = on("DSKGPU_NO_HEAVY"); verbose = on("DSKGPU_VERBOSE"); no_level0 = on("DSKGPU_NO_LEVEL0"); l0_passes = (u32)num("DSKGPU_L0_PASSES", 0); mp_pass_mkeys = (u32)num("DSKGPU_MP_PASS_MKEYS", 0); rs_max_rows = num("DSKGPU_RS_MAX_ROWS", 0); l0_keys = on("DSKGPU_L0_KEYS"); sk_generic = on("DSKGPU_SK_GENERIC"); ps_maxc = (u32)num("DSKGPU_PS_MAXC", 0);
-        rs_slab_rows = num("DSKGPU_RS_SLAB_ROWS", 0); sort_compact = on("DSKGPU_SORT_COMPACT");
-        lib_rowsort = on("DSKGPU_LIB_ROWSORT"); rows2_pairs = on("DSKGPU_ROWS2_PAIRS"); rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0); rs_heavy = (u32)num("DSKGPU_RS_HEAVY", 0);
+        rs_slab_rows = num("DSKGPU_RS_SLAB_ROWS", 0);
+        rs_block_rows = (u32)num("DSKGPU_RS_BLOCK_ROWS", 0); rs_bbits = (u32)num("DSKGPU_RS_BBITS", 0); rs_heavy = (u32)num("DSKGPU_RS_HEAVY", 0);
     }
 };
 
@@ -685,6 +681,7 @@ int sort_index_multiword(dskgpu_ctx* ctx, const u64* const* rows, u64 n, int W) 
     u32* idx = ctx->srt_idx.as<u32>(); u32* idx2 = ctx->srt_idx2.as<u32>();
     hipLaunchKernelGGL(k_iota, dim3(gb), dim3(256), 0, ctx->stream, idx, n);
     size_t tmp = 0, tmp2 = 0;
+    // LIBRARY SORT (rocprim), labelled FALLBACK: index permutation of multi-word rows in full-width order (W stable passes), behind a raised flag only
     CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->srt_k.as<u64>(), keys_sorted.as<u64>(), idx, idx2, (size_t)n, 0u, 64u, ctx->stream));
     CK(rocprim::radix_sort_pairs(nullptr, tmp2, ctx->srt_k.as<u64>(), keys_sorted.as<u64>(), idx, idx2, (size_t)n, 0u, top_bits, ctx->stream));
     CK(ctx->srt_tmp.ensure(std::max(tmp, tmp2)));
@@ -1301,6 +1298,7 @@ int sort_rows_huge(dskgpu_ctx* ctx, u64 n) {
         } else if (lib) {
             size_t tmp = 0;
             const unsigned end_bit = (unsigned)(total - sb);
+            // LIBRARY SORT (rocprim), labelled FALLBACK: one group of a >= 2^32-row set that the MSD kernels gave up on (or that exceeds them alone)
             CK(rocprim::radix_sort_pairs(nullptr, tmp, tk + b, k + b, tv + b, v + b, (size_t)m, 0u, end_bit, ctx->stream));
             CK(ctx->srt_tmp.ensure(tmp));
             CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, tk + b, k + b, tv + b, v + b, (size_t)m, 0u, end_bit, ctx->stream));
@@ -1400,50 +1398,27 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
     // 2^32 rows and more (or DSKGPU_RS_SLAB_ROWS: tests): step A slab by slab with 64-bit bucket offsets
     if ((n >= 0xFFFF0000ull || ctx->tune.rs_slab_rows) && W <= 2 && (W == 1 || 2u * ctx->cfg.kmer_size > 64u)) return W == 1 ? sort_rows_huge<1>(ctx, n) : sort_rows_huge<2>(ctx, n);
     if (n >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "row sort: 2^32 rows and more are supported for k <= 64");
-    if (W == 1 && !ctx->tune.fullsort && !ctx->tune.lib_rowsort && n > rs_max && n < 0xFFFF0000ull) return sort_rows_big(ctx, n);
+    if (W == 1 && n > rs_max && n < 0xFFFF0000ull) return sort_rows_big(ctx, n);
     CK(ctx->srt_w[0].ensure(n * 8));
     CK(ctx->srt_ab.ensure(n * 4));
     ctx->fb_src_k = ctx->srt_w[0].as<u64>(); ctx->fb_src_v = ctx->srt_ab.as<u32>(); ctx->fb_dst_k = ctx->out_w[0].as<u64>(); ctx->fb_dst_v = ctx->out_ab.as<u32>();
     size_t tmp = 0;
-    // hand-written MSD sort while its 10 + (8..10) + 8 bit digits leave sub-buckets a wave can order (mean <= ~380 rows); larger
-    // row sets keep the library sort
-    if (W == 1 && !ctx->tune.fullsort && !ctx->tune.lib_rowsort && n <= RS_MAX_ROWS) return sort_rows_msd(ctx, n);
-    if (W == 1) {
-        const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
-        // Sort on the top SORT_TOP_BITS of the value only (4 radix passes instead of 8), then fix the
-        // (rare, short) runs of equal prefix; exactness is kept by the full-width fallback in finish_sort().
-        // (k = 32 uses all 64 bits: rocPRIM's partial-range sort misbehaved with end_bit == 64 on ROCm 7.2, so it sorts full width)
-        const unsigned begin_bit = (end_bit > SORT_TOP_BITS && end_bit < 64u && !ctx->tune.fullsort) ? end_bit - SORT_TOP_BITS : 0u;
-        CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->out_w[0].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->out_ab.as<u32>(),
-                                     ctx->srt_ab.as<u32>(), (size_t)n, begin_bit, end_bit, ctx->stream));
-        CK(ctx->srt_tmp.ensure(tmp));
-        CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->out_w[0].as<u64>(), ctx->srt_w[0].as<u64>(), ctx->out_ab.as<u32>(),
-                                     ctx->srt_ab.as<u32>(), (size_t)n, begin_bit, end_bit, ctx->stream));
-        ctx->sort_partial = begin_bit != 0;
-        if (ctx->sort_partial) {
-            u32* flag = ctx->scalars.as<u32>() + SC_SORTFLAG;
-            CK(hipMemsetAsync(flag, 0, 4, ctx->stream));
-            hipLaunchKernelGGL(k_fix_runs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->srt_w[0].as<u64>(),
-                               ctx->srt_ab.as<u32>(), n, (int)begin_bit, flag);
-            CKL("k_fix_runs");
-            CK(hipMemcpyAsync(&ctx->h_back[3], flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-        }
-        ctx->res_w[0] = ctx->srt_w[0].as<u64>(); ctx->res_ab = ctx->srt_ab.as<u32>();
-        return DSKGPU_OK;
-    }
+    // one-word rows: the hand-written MSD sort (rowsort.h) -- in one piece here, group by group / slab by slab above
+    if (W == 1) return sort_rows_msd(ctx, n);
     // two-word rows: the rows themselves through the MSD sort (rowsort2.h)
-    if (W == 2 && !ctx->tune.fullsort && !ctx->tune.lib_rowsort && !ctx->tune.rows2_pairs && 2u * ctx->cfg.kmer_size > 64u && n < 0xFFFF0000ull)
+    if (W == 2 && n < 0xFFFF0000ull)
         return n <= rs_max ? sort_rows2_msd(ctx, n) : sort_rows2_big(ctx, n);
-    // multi-word rows: radix sort of (top 63 bits of the value, row index) on the key's top 32 bits, gather,
-    // then the runs of equal prefix are ordered in place by full comparison (exact fallback: sort_rows_full_multiword)
-    if (!ctx->tune.fullsort && 2u * ctx->cfg.kmer_size > 64u) {
+    // four-word rows (k > 64): (top 63 bits of the value, row index) pairs through the MSD sort, gather, then the runs of equal prefix are
+    // ordered in place by full comparison (exact fallback: sort_rows_full_multiword).  Row sets above RS_MAX_ROWS: the pairs through the
+    // LIBRARY radix sort on their top 32 bits instead (rocprim: the one library sort on a non-fallback path; 384 M four-word rows are 14 GB)
+    {
         CK(ctx->srt_k.ensure(n * 8)); CK(ctx->s_val.ensure(n * 8));
         CK(ctx->srt_idx.ensure(n * 4)); CK(ctx->srt_idx2.ensure(n * 4));
         const unsigned gb = (unsigned)((n + 255) / 256);
         RowsIn ri{}; RowsOut ro{};
         for (int x = 0; x < W; ++x) { CK(ctx->srt_w[x].ensure(n * 8)); ri.w[x] = ctx->out_w[x].as<u64>(); ro.w[x] = ctx->srt_w[x].as<u64>(); }
         const int bits = 2 * (int)ctx->cfg.kmer_size;
-        const bool msd = !ctx->tune.lib_rowsort && n <= RS_MAX_ROWS;
+        const bool msd = n <= RS_MAX_ROWS;
         u64* aos = nullptr;
         if (msd) {      // + one record per row for the gather (the full-width fallback buffers are free until then)
             CK(ctx->srt_k2.ensure(n * 8 * (size_t)(W == 2 ? AosRow<2>::WORDS : AosRow<4>::WORDS)));
@@ -1474,6 +1449,7 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
             idx = ctx->srt_idx.as<u32>(); skey = ctx->srt_k.as<u64>(); run_shift = 0; ties = ctx->scalars.as<u32>() + SC_RSTIES;
         } else {
             const unsigned begin_bit = 63u - SORT_TOP_BITS;
+            // LIBRARY SORT (rocprim), labelled: four-word rows (k > 64) above RS_MAX_ROWS = 384 M rows -- the (63-bit key, index) pairs on their top 32 bits
             CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->srt_k.as<u64>(), ctx->s_val.as<u64>(), ctx->srt_idx.as<u32>(), ctx->srt_idx2.as<u32>(),
                                          (size_t)n, begin_bit, 63u, ctx->stream));
             CK(ctx->srt_tmp.ensure(tmp));
@@ -1509,7 +1485,6 @@ int sort_rows(dskgpu_ctx* ctx, u64 n) {
         ctx->res_ab = ctx->srt_ab.as<u32>();
         return DSKGPU_OK;
     }
-    return sort_rows_full_multiword(ctx, n);
 }
 
 // k-mers per chunk of received records (k_sk_count) -> chunk bases for the expansion, and the total.  Needed up front only when
@@ -2194,8 +2169,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         bool sparse_sort = false;
         if constexpr (W == 1) {
             const u64 rs_max = ctx->tune.rs_max_rows ? std::min<u64>(ctx->tune.rs_max_rows, RS_MAX_ROWS) : RS_MAX_ROWS;
-            sparse_sort = npass == 1 && ctx->job_passes == 1 && ns > 0 && ns <= rs_max && !(ctx->cfg.flags & DSKGPU_F_NO_SORT) && !ctx->tune.fullsort && !ctx->tune.lib_rowsort &&
-                          !ctx->tune.rs_slab_rows && !ctx->tune.sort_compact && !ctx->bank_job.active;
+            sparse_sort = npass == 1 && ctx->job_passes == 1 && ns > 0 && ns <= rs_max && !(ctx->cfg.flags & DSKGPU_F_NO_SORT) &&
+                          !ctx->tune.rs_slab_rows && !ctx->bank_job.active;
             if (sparse_sort) {
                 ctx->sp_rows.valid = true;
                 ctx->sp_rows.s = RsSparse{(const u64*)solid_keys, (const u32*)solid_ab, (const u32*)ctx->nsolid.as<u32>(), (const u32*)ctx->fstart.as<u32>(), opt_cap, pl.F, 0u};
@@ -2207,8 +2182,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
         }
         if constexpr (W == 2) {      // (two-word rows: the same, through rowsort2.h's sparse step A -- sort_rows2_msd is what sort_rows picks under these conditions)
             const u64 rs_max = ctx->tune.rs_max_rows ? std::min<u64>(ctx->tune.rs_max_rows, RS_MAX_ROWS) : RS_MAX_ROWS;
-            sparse_sort = npass == 1 && ctx->job_passes == 1 && ns > 0 && ns <= rs_max && !(ctx->cfg.flags & DSKGPU_F_NO_SORT) && !ctx->tune.fullsort && !ctx->tune.lib_rowsort &&
-                          !ctx->tune.rows2_pairs && !ctx->tune.rs_slab_rows && !ctx->tune.sort_compact && !ctx->bank_job.active && 2u * ctx->cfg.kmer_size > 64u;
+            sparse_sort = npass == 1 && ctx->job_passes == 1 && ns > 0 && ns <= rs_max && !(ctx->cfg.flags & DSKGPU_F_NO_SORT) &&
+                          !ctx->tune.rs_slab_rows && !ctx->bank_job.active && 2u * ctx->cfg.kmer_size > 64u;
             if (sparse_sort) {
                 ctx->sp_rows2.valid = true;
                 ctx->sp_rows2.s = Rs2Sparse{(const K2*)solid_keys, (const u32*)solid_ab, (const u32*)ctx->nsolid.as<u32>(), (const u32*)ctx->fstart.as<u32>(), opt_cap, pl.F, 0u};
@@ -2748,6 +2723,7 @@ int run_pipeline(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             // (srt_* holds a permutation of the rows; sort it back into out_*)
             size_t tmp = 0;
             const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
+            // LIBRARY SORT (rocprim), labelled FALLBACK: the one-word row sort raised its flag (a value distribution no k-mer spectrum has): full-width order of all rows
             CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->fb_src_k, ctx->fb_dst_k, ctx->fb_src_v, ctx->fb_dst_v, (size_t)tot_rows, 0u, end_bit, ctx->stream));
             CK(ctx->srt_tmp.ensure(tmp));
             CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->fb_src_k, ctx->fb_dst_k, ctx->fb_src_v, ctx->fb_dst_v, (size_t)tot_rows, 0u, end_bit, ctx->stream));
@@ -3147,6 +3123,7 @@ int banks_finish(dskgpu_ctx* ctx) {
         size_t tmp = 0;
         if (W == 1) {
             const unsigned end_bit = std::min(64u, 2u * ctx->cfg.kmer_size);
+            // LIBRARY SORT (rocprim), labelled: bank merges (-solidity-kind other than sum / -histo2D) order (value, bank) pairs once per job -- not on the sum path
             CK(rocprim::radix_sort_pairs(nullptr, tmp, ctx->u_w[0].as<u64>(), ctx->s_w[0].as<u64>(), ctx->u_val.as<u64>(), ctx->s_val.as<u64>(), (size_t)nu, 0u, end_bit, ctx->stream));
             CK(ctx->srt_tmp.ensure(tmp));
             CK(rocprim::radix_sort_pairs(ctx->srt_tmp.p, tmp, ctx->u_w[0].as<u64>(), ctx->s_w[0].as<u64>(), ctx->u_val.as<u64>(), ctx->s_val.as<u64>(), (size_t)nu, 0u, end_bit, ctx->stream));

@@ -2400,30 +2400,7 @@ __global__ __launch_bounds__(256) void k_minimizers(const u64* __restrict__ pack
     }
 }
 
-// Row-sort helper: after a radix sort on the TOP bits of the k-mer value only (bits >= sh), runs of
-// rows sharing that prefix are put in order here (distinct random k-mers: almost all runs have
-// length 1, a few length 2).  One thread per row; the head of a run sorts it in place (insertion
-// sort, disjoint ranges).  A run longer than FIX_CAP raises *flag and the host falls back to a
-// full-width sort, so the result is exact for any input.
 #define FIX_CAP 32
-__global__ __launch_bounds__(256) void k_fix_runs(u64* __restrict__ lo, u32* __restrict__ ab, u64 n, int sh, u32* __restrict__ flag) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u64 p = lo[i] >> sh;
-    if (i > 0 && (lo[i - 1] >> sh) == p) return;            // not a run head
-    u64 e = i + 1;
-    while (e < n && e - i <= FIX_CAP && (lo[e] >> sh) == p) ++e;
-    const u64 L = e - i;
-    if (L == 1) return;
-    if (L > FIX_CAP) { *flag = 1; return; }
-    for (u64 a = i + 1; a < e; ++a) {
-        const u64 kv = lo[a]; const u32 av = ab[a];
-        u64 b = a;
-        while (b > i && lo[b - 1] > kv) { lo[b] = lo[b - 1]; ab[b] = ab[b - 1]; --b; }
-        lo[b] = kv; ab[b] = av;
-    }
-}
-
 // Multi-word rows: the same two-step order.  k_top_key builds the top 63 bits of every value (bit 63 stays clear:
 // rocPRIM's partial-range sort misbehaves when end_bit == 64) next to the identity permutation; after a radix sort
 // of (key, index) on the key's top 32 bits and a gather of the rows, k_fix_runs_multi orders the runs of equal

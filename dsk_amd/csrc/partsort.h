@@ -9,7 +9,7 @@
 // PS_CAP rows --, and ONE block orders it in LDS: the rows are read once where the count kernel left them (RsSparse: the regions,
 // keys still mixed) and written once, dense, partition after partition.
 //
-//   load   every thread takes PS_RPT rows of the partition into registers (the sub-partition of a row by bisection over the LDS
+//   load   every thread takes PS_RPT (4) rows of the partition into registers (the sub-partition of a row by bisection over the LDS
 //          slice of the scanned counts, as rowsort.h's RsSparseSrc), un-mixes the key
 //   bins   bin = the top 12 bits of the value; rank inside the bin from an LDS atomic; one block scan turns counts into offsets
 //   place  row -> LDS at offset[bin] + rank; a row that shares its bin (0.7 rows per bin on average) then counts the smaller values
@@ -28,8 +28,8 @@
 #include "rowsort2.h"
 
 #ifndef PS_NT
-#define PS_NT 512
-#define PS_RPT 8
+#define PS_NT 1024                        // (two blocks of 16 waves per CU; with 512 threads x 8 rows the same partition took 0.53 instead of 0.37 ms on the bench rows)
+#define PS_RPT 4
 #endif
 #define PS_CAP (PS_NT * PS_RPT)           // rows a block orders (4096: 48 KB of one-word rows; two blocks per CU)
 #define PS_BINS 4096
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(PS_NT) void k_part_sort(RsSparse s, const u64* __re
 
 // ---- the same for two-word rows (33 <= k <= 64): (hi, lo, abundance) in three arrays, PS2_CAP rows per block
 #ifndef PS2_RPT
-#define PS2_RPT 4
+#define PS2_RPT 2
 #endif
 #define PS2_CAP (PS_NT * PS2_RPT)         // 2048 rows: 40 KB of rows + 16 KB of bins, two blocks per CU
 __device__ __forceinline__ u32 ps2_bin(u64 hi, u64 lo, int sh) {      // the top 12 of the 2k value bits: (hi : lo) >> sh

@@ -1462,7 +1462,7 @@ def test_row_sort_fallback_on_shared_prefixes(oracle, dev):
 
 def test_row_sort_paths_agree(oracle, dev, monkeypatch):
     """One-word rows: the hand-written MSD sort, its large-sub-bucket fallback (forced: no sub-bucket above 512 rows is ordered
-    by a block) and the library prefix sort + run fix-up kept behind DSKGPU_LIB_ROWSORT give the same rows, at k = 31 and at
+    by a block) give the same rows, at k = 31 and at
     small k (fewer than 26 value bits: the lower digits are empty)."""
     from dsk_amd import synth
     g = synth.make_genome(200_000, dev)
@@ -1491,14 +1491,10 @@ def test_row_sort_paths_agree(oracle, dev, monkeypatch):
         for k, s in ((31, reads), (31, skew), (11, reads)):
             check_against_oracle(oracle, s, k, dev, amin=1)
     monkeypatch.delenv("DSKGPU_RS_BBITS")
-    monkeypatch.setenv("DSKGPU_LIB_ROWSORT", "1")
-    for k, s in ((31, skew), (11, reads)):
-        check_against_oracle(oracle, s, k, dev, amin=1)
-    monkeypatch.delenv("DSKGPU_LIB_ROWSORT")
-    # r05: the sort's first step reads the rows where the count kernel left them (default above); DSKGPU_SORT_COMPACT = the dense copy
-    # first (k_compact), as several passes and wide keys still do -- the same rows, through both region layouts (fixed-capacity regions
-    # and, with DSKGPU_NO_OPT2, exact offsets), with k-mers counted apart (the dense tail) and with the full-width fallback
-    for env in ({"DSKGPU_SORT_COMPACT": "1"}, {"DSKGPU_NO_OPT2": "1"}, {"DSKGPU_RS_HEAVY": "1000"}):
+    # r05: the sort's first step reads the rows where the count kernel left them (default above) -- the same rows through both region
+    # layouts (fixed-capacity regions and, with DSKGPU_NO_OPT2, exact offsets), with k-mers counted apart (the dense tail) and with the
+    # full-width fallback; the dense copy first (k_compact) is what several passes do (test_multi_pass_*)
+    for env in ({"DSKGPU_NO_OPT2": "1"}, {"DSKGPU_RS_HEAVY": "1000"}):
         for name, val in env.items():
             monkeypatch.setenv(name, val)
         for k, s in ((31, reads), (31, skew), (11, reads)):
@@ -1510,8 +1506,7 @@ def test_row_sort_paths_agree(oracle, dev, monkeypatch):
 def test_two_word_row_sort_paths_agree(oracle, dev, monkeypatch):
     """Two-word rows (k = 33..64) go through their own MSD sort as whole rows (rowsort2.h): uniform and skewed values, few value
     bits above the first word (k = 33, 35), sub-buckets that go round again (natural: poly-A variants; forced: every sub-bucket above
-    512 rows), the full-width fallback behind a 'heavy' first-digit bucket, the wider second digits, and the (63-bit key, index)
-    path kept behind DSKGPU_ROWS2_PAIRS -- all the same rows as the oracle."""
+    512 rows), the full-width fallback behind a 'heavy' first-digit bucket, the wider second digits -- all the same rows as the oracle."""
     from dsk_amd import synth
     g = synth.make_genome(200_000, dev)
     reads = synth.make_reads(g, 60_000, 150).cpu().numpy()
@@ -1539,14 +1534,10 @@ def test_two_word_row_sort_paths_agree(oracle, dev, monkeypatch):
         for k, s in ((63, reads), (63, skew), (35, reads)):
             check_against_oracle(oracle, s, k, dev, amin=1)
     monkeypatch.delenv("DSKGPU_RS_BBITS")
-    monkeypatch.setenv("DSKGPU_ROWS2_PAIRS", "1")
-    for k, s in ((63, skew), (35, reads)):
-        check_against_oracle(oracle, s, k, dev, amin=1)
-    monkeypatch.delenv("DSKGPU_ROWS2_PAIRS")
-    # r05: step A of the two-word sort reads the rows where the count kernel left them, like the one-word sort (default above);
-    # DSKGPU_SORT_COMPACT = the dense copy first (k_compact<2>) -- the same rows, through both region layouts (fixed-capacity regions and,
-    # with DSKGPU_NO_OPT2, exact offsets), with k-mers counted apart (the skewed input: the dense tail) and with the full-width fallback
-    for env in ({"DSKGPU_SORT_COMPACT": "1"}, {"DSKGPU_NO_OPT2": "1"}, {"DSKGPU_RS_HEAVY": "1000"}):
+    # r05: step A of the two-word sort reads the rows where the count kernel left them, like the one-word sort (default above) -- the
+    # same rows through both region layouts (fixed-capacity regions and, with DSKGPU_NO_OPT2, exact offsets), with k-mers counted apart
+    # (the skewed input: the dense tail) and with the full-width fallback
+    for env in ({"DSKGPU_NO_OPT2": "1"}, {"DSKGPU_RS_HEAVY": "1000"}):
         for name, val in env.items():
             monkeypatch.setenv(name, val)
         for k, s in ((63, reads), (63, skew), (35, reads), (47, skew)):

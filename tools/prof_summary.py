@@ -44,7 +44,7 @@ stage_of = [("k_encode", "encode"), ("k_hist<1, 0,", "sample1"), ("k_bin_moments
             ("k_hist<2, 0,", "sample1"), ("k_scatter<2, 0,", "scatter1"), ("k_scatter_al<2,", "scatter2"), ("k_count2v3<", "count"), ("k_count_mw<2", "count"),
             ("k_count_chained_mw", "count"), ("k_compact<2>", "compact"), ("k_top_key_aos<2>", "sort"), ("k_gather_aos<2>", "sort"), ("k_fix_runs_multi<2>", "sort"),
             ("k_fix_long_runs<2>", "sort"), ("k2_hist", "sort"), ("k2_scatter", "sort"), ("k2_split", "sort"), ("k2_cells", "sort"), ("k2_big", "sort"),
-            ("k_rs_hist_sp", "sort"), ("k_rs_scatter_sp", "sort"), ("k_rs_hist", "sort"), ("k_rs_scatter", "sort"), ("k_set_rs_scalars", "sort"), ("k_rs_split", "sort"), ("k_rs_cells", "sort"), ("k_rs_big", "sort")]
+            ("k_part_sort", "sort"), ("k_rs_hist_sp", "sort"), ("k_rs_scatter_sp", "sort"), ("k_rs_hist", "sort"), ("k_rs_scatter", "sort"), ("k_set_rs_scalars", "sort"), ("k_rs_split", "sort"), ("k_rs_cells", "sort"), ("k_rs_big", "sort")]
 summary = {}
 lines = [f"# PMC summary ({tag})", "",
          "rocprofv3 `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes (TCC slots), values are KiB per dispatch,",
