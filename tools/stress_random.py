@@ -65,17 +65,30 @@ def main():
         if os.environ.get("STRESS_K"):
             k = int(os.environ["STRESS_K"])              # (the same input counted at another k)
         t = torch.from_numpy(stream).to(dev)
-        with KmerCounter(kmer_size=k, abundance_min=amin, **kw) as kc:
+        part = bool(os.environ.get("STRESS_PARTITION"))      # rows in the reference's order (DSKGPU_F_PARTITION_ORDER): ascending inside every output partition
+        with KmerCounter(kmer_size=k, abundance_min=amin, partition_order=part, **kw) as kc:
             kc.set_reads_device(t.data_ptr(), t.numel())
             kc.count(); torch.cuda.synchronize()
             rows, ab = kc.rows(); hist = kc.histogram(); st = kc.stats()
+            off = kc.partition_offsets().astype(np.int64) if part else None
         ref = oracle.count(stream, k)
         keep = ref.ab >= amin
-        ok = (st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct and rows.shape[0] == int(keep.sum())
+        part_ok = True
+        if part and rows.shape[0] == int(keep.sum()) and rows.shape[0] > 1:
+            w = rows.shape[1]
+            asc = rows[1:, w - 1] > rows[:-1, w - 1]
+            for x in range(w - 2, -1, -1):
+                asc = asc | ((rows[1:, x + 1:] == rows[:-1, x + 1:]).all(axis=1) & (rows[1:, x] > rows[:-1, x]))
+            st_ = off[1:-1]; st_ = st_[(st_ > 0) & (st_ <= len(asc))]
+            asc[st_ - 1] = True
+            part_ok = bool(asc.all()) and int(off[-1]) == rows.shape[0] and bool((np.diff(off) >= 0).all())
+            order = np.lexsort(rows.T)
+            rows, ab = rows[order], ab[order]
+        ok = (part_ok and st["n_kmers"] == ref.total and st["n_distinct"] == ref.distinct and rows.shape[0] == int(keep.sum())
               and (rows == ref.words()[keep]).all() and (ab == ref.ab[keep]).all() and (hist == ref.histogram(10000)).all())
         bad += not ok
         print(f"seed {seed}: {desc} (counted at k {k}) passes {st['n_passes']} levels {st['n_levels']} retries {st['n_retries']} "
-              f"fallback {st['sort_fallback']} ext {st['n_ext_regions']} heavy {st['n_heavy']} kmers {ref.total} distinct {ref.distinct} {'ok' if ok else 'MISMATCH'}", flush=True)
+              f"fallback {st['sort_fallback']} partitions {st['n_partitions']} ext {st['n_ext_regions']} heavy {st['n_heavy']} kmers {ref.total} distinct {ref.distinct} {'ok' if ok else 'MISMATCH'}", flush=True)
     print("stress ok" if not bad else f"stress FAILED: {bad}")
     return 1 if bad else 0
 
