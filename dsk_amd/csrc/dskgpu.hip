@@ -16,6 +16,7 @@
 #include "rowsort.h"
 #include "rowsort2.h"
 #include "partsort.h"
+#include "rawparse.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -212,6 +213,9 @@ struct dskgpu_ctx {
     DevBuf reads_own; u64 reads_len = 0;
     void* pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_used[2] = {false, false}; int pin_next = 0;   // pinned H2D staging
     const uint8_t* d_reads = nullptr; u64 n_bytes = 0;
+    // dskgpu_push_raw: file text parsed on the device; the stream's length is on the device (RawState) until raw_finish reads it back
+    DevBuf raw_in, raw_blk, raw_boff, raw_bstate, raw_state;
+    bool raw_pending = false; u64 raw_base = 0, raw_ub = 0;      // the stream's length before the raw pushes / an upper bound of it now
 
     DevBuf packed, inval;          // K1 output
     DevBuf bufA, bufB;             // partition ping-pong
@@ -1508,7 +1512,7 @@ int sk_sizes(dskgpu_ctx* ctx, u64* total_out) {
     u64 rpc = (nrec + nch - 1) / nch;
     rpc = (rpc + SKX_NT - 1) / SKX_NT * SKX_NT;
     nch = (nrec + rpc - 1) / rpc;
-    if (rpc * 16 >= 0xFFFFFFFFull) return fail(ctx, DSKGPU_E_ARG, "too many records per chunk");
+    if (rpc * SK_MAXN >= 0xFFFFFFFFull) return fail(ctx, DSKGPU_E_ARG, "too many records per chunk");
     CK(ctx->sk_sums.ensure(nch * 4)); CK(ctx->sk_cbase.ensure(nch * 8));
     ctx->h_sk_sums.assign(nch, 0); ctx->h_sk_cbase.assign(nch, 0);
     hipLaunchKernelGGL(k_sk_count, dim3((unsigned)nch), dim3(SKX_NT), 0, ctx->stream, ctx->rec_src, nrec, R, (u32)rpc, ctx->sk_sums.as<u32>());
@@ -1749,7 +1753,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
             spread.assign(pl.P1, 0.0);
             bool sampled = false;
             // records (the multi-GPU receive side, the passes of a record-based multi-pass count): a positional sample of the records is
-            // expanded into a key array with pads (k_sk_sample_keys: 16 slots per candidate record) and sampled like any key array.
+            // expanded into a key array with pads (k_sk_sample_keys: SK_MAXN slots per candidate record) and sampled like any key array.
             // Records that arrive in slices: the sample comes from the first slice (the slices are positional cuts of every sender's
             // reads: alike), so only that slice has to have arrived.
             const Key* d_keys_s = d_keys_in;             // the key array the sample kernels read
@@ -1767,7 +1771,7 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                     { const int e = rec_gate_upto(ctx, 1); if (e) return e; }
                     std::vector<u64> cbeg(nchk);
                     for (u64 i = 0; i < nchk; ++i) cbeg[i] = (i * nchk_all / nchk) * NR;
-                    rec_units = nchk * NR * 16;
+                    rec_units = nchk * NR * SK_MAXN;
                     CK(ctx->smp_keys.ensure(rec_units * sizeof(Key) + nchk * 8 + 64));
                     u64* d_cbeg = reinterpret_cast<u64*>(ctx->smp_keys.as<char>() + rec_units * sizeof(Key));
                     CK(hipMemcpyAsync(d_cbeg, cbeg.data(), nchk * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -3213,6 +3217,18 @@ __attribute__((visibility("hidden"))) int dskgpu_i_banks_finish(dskgpu_ctx* ctx)
 }
 
 // =============================================================== C-ABI
+template <int FMT>
+static void launch_raw_chunk(dskgpu_ctx* ctx, u32 n, uint8_t* out) {
+    const u32 nb = (n + RP_BLOCK - 1) / RP_BLOCK;
+    const unsigned char* in = ctx->raw_in.as<unsigned char>();
+    RawState* st = ctx->raw_state.as<RawState>();
+    hipLaunchKernelGGL((k_rp_count<FMT>), dim3(nb), dim3(RP_NT), 0, ctx->stream, in, n, ctx->raw_blk.as<RpBlock>());
+    hipLaunchKernelGGL((k_rp_scan<FMT>), dim3(1), dim3(RP_NT), 0, ctx->stream, in, n, nb, ctx->raw_blk.as<RpBlock>(), st,
+                       ctx->raw_boff.as<unsigned long long>(), ctx->raw_bstate.as<u32>(), out);
+    hipLaunchKernelGGL((k_rp_write<FMT>), dim3(nb), dim3(RP_NT), 0, ctx->stream, in, n, ctx->raw_boff.as<unsigned long long>(),
+                       ctx->raw_bstate.as<u32>(), st, out);
+}
+
 extern "C" {
 
 const char* dskgpu_version(void) { return DSKGPU_VERSION; }
@@ -3268,7 +3284,7 @@ void dskgpu_destroy(dskgpu_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->reads_own, &ctx->packed, &ctx->inval, &ctx->bufA, &ctx->bufB, &ctx->mat1, &ctx->mat2, &ctx->sums,
+    DevBuf* bufs[] = {&ctx->reads_own, &ctx->raw_in, &ctx->raw_blk, &ctx->raw_boff, &ctx->raw_bstate, &ctx->raw_state, &ctx->packed, &ctx->inval, &ctx->bufA, &ctx->bufB, &ctx->mat1, &ctx->mat2, &ctx->sums,
                       &ctx->descs1, &ctx->descs2, &ctx->seg, &ctx->fstart, &ctx->nsolid, &ctx->scalars, &ctx->ghist, &ctx->gstats, &ctx->chain_next, &ctx->smp_mat, &ctx->smp_descs, &ctx->boff, &ctx->hv_lut, &ctx->hv_collect, &ctx->hv_buf, &ctx->dbg, &ctx->l0buf,
                       &ctx->out_ab, &ctx->srt_ab, &ctx->srt_tmp,
                       &ctx->srt_idx, &ctx->srt_idx2, &ctx->srt_k, &ctx->srt_k2, &ctx->abund2, &ctx->acc_ab, &ctx->u_val,
@@ -3310,9 +3326,11 @@ static int ensure_pinned(dskgpu_ctx* ctx) {      // the two pinned staging buffe
     return DSKGPU_OK;
 }
 
+static int raw_finish(dskgpu_ctx* ctx, u64* lines);
 int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
     if (!ctx || (!bytes && nbytes)) return DSKGPU_E_ARG;
     CK(hipSetDevice(ctx->cfg.device));
+    if (ctx->raw_pending) { const int e = raw_finish(ctx, nullptr); if (e) return e; }
     const u64 need = ctx->reads_len + nbytes + 1;
     if (need > ctx->reads_own.cap) {
         DevBuf nb;
@@ -3347,9 +3365,91 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
     return DSKGPU_OK;
 }
 
+// The raw pushes' result: the stream's length comes back from the device (the one synchronisation of a raw ingest), the terminator is set.
+static int raw_finish(dskgpu_ctx* ctx, u64* lines) {
+    if (!ctx->raw_pending) return DSKGPU_OK;
+    RawState s;
+    CK(hipMemcpyAsync(&s, ctx->raw_state.p, sizeof(RawState), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    ctx->raw_pending = false;
+    uint8_t* dst = ctx->reads_own.as<uint8_t>();
+    if (s.bad) {             // the text is not what the device parser handles: the raw pushes are dropped, the stream is what it was before them
+        ctx->reads_len = ctx->raw_base;
+        ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len;
+        return fail(ctx, DSKGPU_E_FORMAT, "dskgpu_push_raw: the text is not 4-line FASTQ / FASTA as declared (the raw pushes were dropped: parse on the host and push the reads)");
+    }
+    if (s.out_len + 1 > ctx->reads_own.cap) return fail(ctx, DSKGPU_E_STATE, "dskgpu_push_raw: stream longer than its bound");
+    CK(hipMemsetAsync(dst + s.out_len, '\n', 1, ctx->stream));
+    ctx->reads_len = s.out_len + 1;
+    if (lines) *lines = s.lines;
+    ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->enc_keep = false; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->mw_v3_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
+    return DSKGPU_OK;
+}
+#define RAW_SYNC(ctx) do { if ((ctx)->raw_pending) { const int e_ = raw_finish(ctx, nullptr); if (e_) return e_; } } while (0)
+
+int dskgpu_raw_finish(dskgpu_ctx* ctx, uint64_t* stream_bytes, uint64_t* lines) {
+    if (!ctx) return DSKGPU_E_ARG;
+    CK(hipSetDevice(ctx->cfg.device));
+    u64 ln = 0;
+    const int rc = raw_finish(ctx, &ln);
+    if (stream_bytes) *stream_bytes = ctx->reads_len;
+    if (lines) *lines = ln;
+    return rc;
+}
+
+int dskgpu_push_raw(dskgpu_ctx* ctx, const char* text, uint64_t nbytes, int format, int new_file) {
+    if (!ctx || (!text && nbytes) || (format != DSKGPU_RAW_FASTA && format != DSKGPU_RAW_FASTQ)) return DSKGPU_E_ARG;
+    CK(hipSetDevice(ctx->cfg.device));
+    if (!ctx->raw_pending) {
+        CK(ctx->raw_state.ensure(sizeof(RawState)));
+        CK(ctx->raw_in.ensure(PIN_CHUNK));
+        const u64 maxb = PIN_CHUNK / RP_BLOCK;
+        CK(ctx->raw_blk.ensure(maxb * sizeof(RpBlock)));
+        CK(ctx->raw_boff.ensure(maxb * 8));
+        CK(ctx->raw_bstate.ensure((maxb + 1) * 4));
+        ctx->raw_base = ctx->raw_ub = ctx->reads_len;
+        hipLaunchKernelGGL(k_rp_init, dim3(1), dim3(1), 0, ctx->stream, ctx->raw_state.as<RawState>(), (unsigned long long)ctx->reads_len);
+        CKL("k_rp_init");
+        ctx->raw_pending = true;
+    } else if (new_file) {
+        hipLaunchKernelGGL(k_rp_fresh, dim3(1), dim3(1), 0, ctx->stream, ctx->raw_state.as<RawState>());
+        CKL("k_rp_fresh");
+    }
+    // what the text can leave at most: every byte, the separator in front of a new file, the terminator
+    const u64 need = ctx->raw_ub + nbytes + 2;
+    if (need > ctx->reads_own.cap) {
+        DevBuf nb;
+        CK(nb.ensure(std::max<u64>(need, std::max<u64>(ctx->reads_own.cap * 2, (u64)256 << 20))));
+        if (ctx->raw_ub) CK(hipMemcpyAsync(nb.p, ctx->reads_own.p, ctx->raw_ub, hipMemcpyDeviceToDevice, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        ctx->reads_own.release();
+        ctx->reads_own = nb;
+    }
+    uint8_t* out = ctx->reads_own.as<uint8_t>();
+    if (nbytes) {
+        const size_t CH = PIN_CHUNK;
+        { const int e = ensure_pinned(ctx); if (e) return e; }
+        for (u64 off = 0; off < nbytes; off += CH, ctx->pin_next ^= 1) {
+            const int slot = ctx->pin_next;
+            const size_t len = (size_t)std::min<u64>(CH, nbytes - off);
+            if (ctx->pin_used[slot]) CK(hipEventSynchronize(ctx->pin_ev[slot]));
+            std::memcpy(ctx->pin[slot], text + off, len);
+            CK(hipMemcpyAsync(ctx->raw_in.p, ctx->pin[slot], len, hipMemcpyHostToDevice, ctx->stream));      // (one device buffer: the stream orders the next piece's DMA behind this piece's kernels, which take a fraction of the DMA's time)
+            CK(hipEventRecord(ctx->pin_ev[slot], ctx->stream));
+            ctx->pin_used[slot] = true;
+            if (format == DSKGPU_RAW_FASTQ) launch_raw_chunk<RP_FASTQ>(ctx, (u32)len, out);
+            else launch_raw_chunk<RP_FASTA>(ctx, (u32)len, out);
+            CKL("k_rp_write");
+        }
+    }
+    ctx->raw_ub += nbytes + 1;
+    return DSKGPU_OK;
+}
+
 int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes) {
     if (!ctx) return DSKGPU_E_ARG;
     CK(hipSetDevice(ctx->cfg.device));
+    RAW_SYNC(ctx);
     { const int e = ensure_pinned(ctx); if (e) return e; }
     if (nbytes + 1 <= ctx->reads_own.cap) return DSKGPU_OK;
     DevBuf nb;
@@ -3401,6 +3501,7 @@ int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbyte
     // intermittent failure of the multi-process test was exactly that, in the test's reference count).  Once per read set, not per count.
     CK(hipSetDevice(ctx->cfg.device));
     CK(hipDeviceSynchronize());
+    ctx->raw_pending = false;
     ctx->d_reads = static_cast<const uint8_t*>(d_bytes); ctx->enc_keep = false; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->mw_v3_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
     ctx->n_bytes = nbytes;
     ctx->reads_len = 0;
@@ -3411,6 +3512,7 @@ int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbyte
 int dskgpu_encode_reads(dskgpu_ctx* ctx) {
     if (!ctx) return DSKGPU_E_ARG;
     CK(hipSetDevice(ctx->cfg.device));
+    RAW_SYNC(ctx);
     if (ctx->enc_keep) return DSKGPU_OK;
     if (!ctx->d_reads && ctx->n_bytes) return fail(ctx, DSKGPU_E_STATE, "no reads to encode");
     u64 nwords = 0;
@@ -3427,6 +3529,7 @@ int dskgpu_count(dskgpu_ctx* ctx) {
     if (!ctx) return DSKGPU_E_ARG;
     if (ctx->cfg.world_size != 1) return fail(ctx, DSKGPU_E_STATE, "dskgpu_count needs world_size == 1; use dskgpu_mg_scatter/_mg_count");
     CK(hipSetDevice(ctx->cfg.device));
+    RAW_SYNC(ctx);
     ctx->stats = dskgpu_stats{};
     const bool banks = ctx->bank_ends.size() > 1 || (!ctx->bank_ends.empty() && ctx->bank_ends.back() < ctx->n_bytes);
     if (banks && (ctx->cfg.solidity_kind != DSKGPU_SOLIDITY_SUM || (ctx->cfg.flags & DSKGPU_F_HISTO2D)))
@@ -3439,6 +3542,7 @@ int dskgpu_count(dskgpu_ctx* ctx) {
 
 int dskgpu_next_bank(dskgpu_ctx* ctx) {
     if (!ctx) return DSKGPU_E_ARG;
+    if (ctx->raw_pending) { CK(hipSetDevice(ctx->cfg.device)); RAW_SYNC(ctx); }
     if (ctx->bank_ends.empty() || ctx->bank_ends.back() != ctx->reads_len) ctx->bank_ends.push_back(ctx->reads_len);
     return DSKGPU_OK;
 }
@@ -3461,6 +3565,7 @@ int dskgpu_histogram2d(const dskgpu_ctx* ctx, uint64_t* out, uint32_t nrows) {
 
 uint64_t dskgpu_mg_send_capacity_words(dskgpu_ctx* ctx) {
     if (!ctx) return 0;
+    if (ctx->raw_pending && (hipSetDevice(ctx->cfg.device) != hipSuccess || raw_finish(ctx, nullptr) != DSKGPU_OK)) return 0;
     if (!ctx->sk_mode) return (ctx->n_bytes + 1) * (u64)ctx->W;
     if (hipSetDevice(ctx->cfg.device) != hipSuccess) return 0;
     if (!ctx->sk_prepared && sk_prepare(ctx) != DSKGPU_OK) return 0;     // the error text stays in the ctx; dskgpu_mg_scatter reports it
@@ -3470,6 +3575,7 @@ uint64_t dskgpu_mg_send_capacity_words(dskgpu_ctx* ctx) {
 int dskgpu_mg_scatter(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint64_t* send_words) {
     if (!ctx || !d_send || !send_words) return DSKGPU_E_ARG;
     CK(hipSetDevice(ctx->cfg.device));
+    RAW_SYNC(ctx);
     if (ctx->sk_mode) return sk_scatter(ctx, d_send, capacity_words, send_words);
     // (explicit keys -- k < 20, k > 64 or DSKGPU_F_MG_EXPLICIT -- keep 32-bit key offsets in the send buffer: one key per byte at most)
     if (ctx->n_bytes >= 0xFFFF0000ull) return fail(ctx, DSKGPU_E_ARG, "explicit-key exchange: a rank's read shard must stay below 4.29 GB (super-k-mer records, 20 <= k <= 64, have no such limit)");
@@ -3484,6 +3590,7 @@ int dskgpu_mg_sample(dskgpu_ctx* ctx, uint64_t* loads) {
     std::memset(loads, 0, (size_t)SK_BUCKETS * 8);
     if (!ctx->sk_mode) return DSKGPU_OK;            // explicit keys: the owner is a bit field of the k-mer hash, balanced by construction
     CK(hipSetDevice(ctx->cfg.device));
+    RAW_SYNC(ctx);
     u64 nwords = 0;
     int rc = encode_current(ctx, &nwords);
     if (rc) return rc;
@@ -3560,6 +3667,7 @@ int dskgpu_mg_slices_prepare(dskgpu_ctx* ctx, uint32_t want_slices, uint32_t* ns
     *nslices = 0;
     if (!ctx->sk_mode) return DSKGPU_OK;                 // explicit keys: one piece
     CK(hipSetDevice(ctx->cfg.device));
+    RAW_SYNC(ctx);
     return sk_slices_prepare(ctx, want_slices, nslices, send_words, kmers_est);
 }
 int dskgpu_mg_scatter_slice(dskgpu_ctx* ctx, void* d_send, uint64_t capacity_words, uint32_t slice) {

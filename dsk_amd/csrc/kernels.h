@@ -420,7 +420,7 @@ template <> __device__ __forceinline__ KN<4> empty_key<4>() { KN<4> k; k.w[0] = 
 
 // SRC 2: super-k-mer records (superkmer.h) as the key source of the level-1 scatter on the multi-GPU receive side:
 // records -> mixed keys straight into the tile registers, no expanded key array in HBM.  A tile takes as many of
-// the next Tile<W>::KEYS / 8 records as fit Tile<W>::KEYS keys (a record holds <= 16), stages them in the (not yet
+// the next Tile<W>::KEYS / 8 records as fit Tile<W>::KEYS keys (a record holds <= SK_MAXN = 32), stages them in the (not yet
 // used) key staging area together with a slot map (slot -> record, k-mer index), and every thread then builds its
 // KPT keys with a funnel shift + rev_pairs.  Returns the validity mask; *taken = records consumed.
 __device__ __forceinline__ u64 sk_key1(const u64* r, int j, int k);
@@ -453,18 +453,18 @@ __device__ __forceinline__ u32 tile_keys_records(const RecPre<W>& pre, u32 R, u6
                                                  typename KeyT<W>::T (&h)[Tile<W>::KPT], char* scratch, u32* wsum, u32* taken) {
     constexpr int KPT = Tile<W>::KPT, KEYS = Tile<W>::KEYS, NR = RecTile<W>::NR, RPT = RecTile<W>::RPT, RS = RecTile<W>::RS;
     u64* srec = reinterpret_cast<u64*>(scratch);                             // NR * RS words
-    unsigned short* first = reinterpret_cast<unsigned short*>(srec + (size_t)NR * RS);   // KEYS / KPT = SC_NT entries
-    u32* info = reinterpret_cast<u32*>(first + SC_NT);                       // (records taken << 16) | keys of the tile
+    u32* first = reinterpret_cast<u32*>(srec + (size_t)NR * RS);             // KEYS / KPT = SC_NT entries: (staged record << 5) | k-mer index (a record holds <= SK_MAXN = 32)
+    u32* info = first + SC_NT;                                               // (records taken << 16) | keys of the tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 left = rend - r0;                                              // candidates that exist
-    u32 n[RPT], s = 0;                                                       // s = (records with keys << 16) | keys, over this thread's candidates
+    u32 n[RPT], s = 0;                                                       // s = (records with keys << 18) | keys, over this thread's candidates
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
         const u32 l = (u32)tid * RPT + u;
         n[u] = l < left ? (u32)(pre.w[u * RS + ((RS == 3 && R == 3) ? 2 : 1)] & 0xFFu) : 0u;
-        s += n[u] + (n[u] ? 0x10000u : 0u);
+        s += n[u] + (n[u] ? 0x40000u : 0u);
     }
-    // (sums: keys <= 16 * NR = 49152 < 2^16, records <= NR)
+    // (sums: keys <= 32 * NR = 98304 < 2^18, records <= NR = 3072 < 2^14)
     const u32 inc = wave_incl_scan(s);
     if (lane == 63) wsum[wave] = inc;
     lds_barrier();                                                           // ... and the previous tile's write-out is done with the staging area
@@ -476,7 +476,7 @@ __device__ __forceinline__ u32 tile_keys_records(const RecPre<W>& pre, u32 R, u6
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
         const u32 l = (u32)tid * RPT + u;
-        const u32 start = run & 0xFFFFu, dense = run >> 16;
+        const u32 start = run & 0x3FFFFu, dense = run >> 18;
         const bool exists = l < left;
         const bool fit = exists && start + n[u] <= (u32)KEYS;
         if (!fit && start <= (u32)KEYS && (exists || l == left)) *info = (l << 16) | start;
@@ -484,10 +484,10 @@ __device__ __forceinline__ u32 tile_keys_records(const RecPre<W>& pre, u32 R, u6
 #pragma unroll
             for (int x = 0; x < RS; ++x) srec[dense * RS + x] = pre.w[u * RS + x];
             const u32 bnd = (start + KPT - 1) & ~(u32)(KPT - 1);              // slot groups that begin inside this record
-            for (u32 q = bnd; q < start + n[u]; q += KPT) first[q / KPT] = (unsigned short)((dense << 4) | (q - start));
+            for (u32 q = bnd; q < start + n[u]; q += KPT) first[q / KPT] = (dense << 5) | (q - start);
         }
-        run += n[u] + (n[u] ? 0x10000u : 0u);
-        if (u == RPT - 1 && tid == SC_NT - 1 && fit) *info = ((u32)NR << 16) | (run & 0xFFFFu);
+        run += n[u] + (n[u] ? 0x40000u : 0u);
+        if (u == RPT - 1 && tid == SC_NT - 1 && fit) *info = ((u32)NR << 16) | (run & 0x3FFFFu);
     }
     lds_barrier();
     const u32 inf = *info;
@@ -497,7 +497,7 @@ __device__ __forceinline__ u32 tile_keys_records(const RecPre<W>& pre, u32 R, u6
     const u32 slot0 = (u32)tid * KPT;
     if (slot0 < nkeys) {
         const u32 e = first[tid];
-        u32 rl = e >> 4, jj = e & 15u;
+        u32 rl = e >> 5, jj = e & 31u;
         u64 r[3]; r[2] = 0ull;
 #pragma unroll
         for (int x = 0; x < RS; ++x) r[x] = srec[rl * RS + x];

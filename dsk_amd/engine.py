@@ -83,7 +83,7 @@ SOLIDITY = {"sum": 0, "min": 1, "max": 2, "one": 3, "all": 4, "custom": 5}
 # every symbol include/dskgpu.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "dskgpu_create", "dskgpu_destroy", "dskgpu_last_error", "dskgpu_version", "dskgpu_device_count", "dskgpu_set_stream",
-    "dskgpu_push_reads", "dskgpu_reserve_reads", "dskgpu_reserve_work", "dskgpu_set_reads_device", "dskgpu_encode_reads", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
+    "dskgpu_push_reads", "dskgpu_push_raw", "dskgpu_raw_finish", "dskgpu_reserve_reads", "dskgpu_reserve_work", "dskgpu_set_reads_device", "dskgpu_encode_reads", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
     "dskgpu_count", "dskgpu_mg_scatter", "dskgpu_mg_sample", "dskgpu_mg_make_table", "dskgpu_mg_set_table",
     "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_mg_sent_kmers", "dskgpu_mg_count_sized",
     "dskgpu_mg_slices_prepare", "dskgpu_mg_scatter_slice", "dskgpu_mg_slices_finish", "dskgpu_mg_count_sliced", "dskgpu_get_stats", "dskgpu_histogram",
@@ -126,6 +126,8 @@ def load_library():
     lib.dskgpu_version.restype = C.c_char_p
     lib.dskgpu_set_stream.argtypes = [vp, vp]
     lib.dskgpu_push_reads.argtypes = [vp, vp, u64]
+    lib.dskgpu_push_raw.argtypes = [vp, vp, u64, C.c_int, C.c_int]
+    lib.dskgpu_raw_finish.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     lib.dskgpu_reserve_reads.argtypes = [vp, u64]
     lib.dskgpu_reserve_work.argtypes = [vp, u64]
     lib.dskgpu_set_reads_device.argtypes = [vp, vp, u64]
@@ -282,6 +284,25 @@ class KmerCounter:
         else:
             arr = np.ascontiguousarray(data, dtype=np.uint8)
             self._ck(self._lib.dskgpu_push_reads(self._h, arr.ctypes.data, arr.size))
+
+    RAW_FASTA, RAW_FASTQ = 1, 2
+
+    def push_raw(self, text, fmt=None, new_file: bool = False) -> None:
+        """FASTA / FASTQ text as it lies in the file (cut anywhere between calls): parsed on the device (dskgpu_push_raw).
+        fmt: RAW_FASTA / RAW_FASTQ, or None = from the first byte ('>' / '@') of a text that starts a file."""
+        arr = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else np.ascontiguousarray(text, dtype=np.uint8)
+        if fmt is None:
+            if arr.size == 0 or arr[0] not in (ord(">"), ord("@")):
+                raise ValueError("push_raw: cannot tell the format from the first byte; pass fmt")
+            fmt = self.RAW_FASTA if arr[0] == ord(">") else self.RAW_FASTQ
+        self._ck(self._lib.dskgpu_push_raw(self._h, C.c_void_p(arr.ctypes.data if arr.size else 0), arr.size, int(fmt), int(bool(new_file))))
+
+    def raw_finish(self):
+        """-> (bytes of the read stream, text lines of the last file); raises DskGpuError(DSKGPU_E_FORMAT) when the text was not what
+        the device parser handles (the raw pushes are dropped then: parse on the host and push_reads)."""
+        nb, ln = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._lib.dskgpu_raw_finish(self._h, C.byref(nb), C.byref(ln)))
+        return nb.value, ln.value
 
     def reserve_reads(self, nbytes: int) -> None:
         self._ck(self._lib.dskgpu_reserve_reads(self._h, nbytes))

@@ -38,6 +38,7 @@ extern "C" {
 #define DSKGPU_E_NOMEM (-3)     /* device allocation failed                */
 #define DSKGPU_E_STATE (-4)     /* call out of order                       */
 #define DSKGPU_E_OVERFLOW (-5)  /* internal table overflow after retries   */
+#define DSKGPU_E_FORMAT (-6)    /* dskgpu_push_raw: the text is not what was declared (see there)            */
 #define DSKGPU_NOT_RESERVED 1   /* dskgpu_reserve_work only: nothing was reserved (the request exceeds 60 % of the free HBM) -- not an
                                    error: dskgpu_count sizes its own buffers, in several passes if need be; nothing was allocated */
 
@@ -109,6 +110,23 @@ int dskgpu_set_stream(dskgpu_ctx* ctx, void* hip_stream);
  * DMA to the device may still be in flight then: an asynchronous copy error is reported by the next call that synchronises
  * (dskgpu_count, dskgpu_encode_reads, dskgpu_set_stream, a buffer growth), not by this one. */
 int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes);
+/* Append FILE TEXT -- FASTA or FASTQ exactly as it lies in the (inflated) file, headers and quality lines included -- and let the
+ * device turn it into the read stream: replaces BankFasta's parser (gatb-core BankFasta behind src/DSK.cpp:51 Bank::open; the
+ * formats of README.md:52-61) together with dskgpu_push_reads' clean stream.  The text may be cut ANYWHERE between calls (mid
+ * line, mid record): the parser's state is kept on the device.  `new_file` != 0 says that `text` begins a new file (line
+ * counting restarts, the records of two files never join); the first raw push of a read set is a new file by itself.
+ *   DSKGPU_RAW_FASTQ  four lines per record ('@' header, sequence, '+' line, qualities): the sequence lines are kept
+ *   DSKGPU_RAW_FASTA  '>' header lines are dropped, all other lines are sequence, joined when a record is wrapped over lines
+ * Asynchronous like dskgpu_push_reads: nothing is known about the result until something needs the stream's length -- every
+ * call that reads the reads (dskgpu_count, dskgpu_encode_reads, dskgpu_mg_*, dskgpu_next_bank, dskgpu_push_reads) first does
+ * what dskgpu_raw_finish does.  A text the device parser does not handle (a FASTQ file with sequences wrapped over several
+ * lines or blanks inside them, text that is neither format) is DETECTED, never mis-parsed: dskgpu_raw_finish returns
+ * DSKGPU_E_FORMAT and the stream is what it was before the raw pushes -- the caller parses on the host and pushes the reads. */
+#define DSKGPU_RAW_FASTA 1
+#define DSKGPU_RAW_FASTQ 2
+int dskgpu_push_raw(dskgpu_ctx* ctx, const char* text, uint64_t nbytes, int format, int new_file);
+/* Wait for the raw pushes; -> the read stream's length in bytes and the number of text lines of the last file (both may be NULL). */
+int dskgpu_raw_finish(dskgpu_ctx* ctx, uint64_t* stream_bytes, uint64_t* lines);
 /* Optional: size the device-side read buffer once (e.g. from Bank::getSize) instead of growing it push by push. */
 int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes);
 /* Optional: allocate the partition buffers of a count over up to `nbytes` read-stream bytes now (tens of GB of HBM: 0.2 s of

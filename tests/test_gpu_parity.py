@@ -1260,7 +1260,7 @@ def _fmix32(h):
 @pytest.mark.parametrize("world,k,sliced", [(4, 31, False), (2, 63, False), (8, 27, False), (4, 31, True)])
 def test_super_kmer_record_invariants(oracle, golden_dir, dev, monkeypatch, world, k, sliced):
     """The wire format of the multi-GPU exchange, decoded on the host (superkmer.h; DSK v2's super-k-mers, CHANGELOG.md:13):
-    every record holds 1..16 k-mers as n + k - 1 packed bases; every k-mer of a record maps to the record's owner under an
+    every record holds 1..min(32, (64 R - 8) / 2 + 1 - k) k-mers as n + k - 1 packed bases; every k-mer of a record maps to the record's owner under an
     independent numpy restatement of the owner map (owner = hash of the window's minimizer, m-mers ordered by a 32-bit hash
     of their canonical value); zero-length records exist only as slice padding; the multiset of the canonical k-mers of all
     records of all ranks equals the oracle's enumeration of the input."""
@@ -1288,7 +1288,8 @@ def test_super_kmer_record_invariants(oracle, golden_dir, dev, monkeypatch, worl
             words = send[: sum(counts)].cpu().numpy().view(np.uint64).reshape(-1, R)
         dest = np.repeat(np.arange(world), [c // R for c in counts])
         n = (words[:, R - 1] & np.uint64(0xFF)).astype(np.int64)
-        assert n.max() <= 16
+        nmax = min(32, (64 * R - 8) // 2 + 1 - k)                 # the bases of n k-mers + the header fit the record; never more than one packed word's 32 windows
+        assert n.max() <= nmax and n.max() > 16                   # (r06: the two halves of a word join their runs)
         if not sliced:
             assert n.min() >= 1                                  # the exact layout has no padding
         keep = n > 0
@@ -1304,7 +1305,7 @@ def test_super_kmer_record_invariants(oracle, golden_dir, dev, monkeypatch, worl
             rv = rv | ((bases[:, i:i + npos].astype(np.uint64) ^ np.uint64(2)) << np.uint64(2 * i))
         hm = _fmix32(np.minimum(fw, rv))
         wlen = k - m + 1
-        for j in range(16):                                      # k-mer j of every record that has one
+        for j in range(32):                                      # k-mer j of every record that has one
             rows = np.nonzero(n > j)[0]
             if len(rows) == 0:
                 break
@@ -1318,7 +1319,7 @@ def test_super_kmer_record_invariants(oracle, golden_dir, dev, monkeypatch, worl
                     f = (f << np.uint64(2)) | b
                     rc = rc | ((b ^ np.uint64(2)) << np.uint64(2 * i))
                 got.append(np.minimum(f, rc))
-        # a record is cut where the owner changes, at an invalid base or at a 16-window border: never longer than 16
+        # a record is cut where the owner changes, at an invalid base, at the border of a packed word (32 windows) or where it is full
     if k <= 32:
         lo, hi, valid = oracle.enumerate(s, k)
         want = np.sort(lo[valid.astype(bool)])

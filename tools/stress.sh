@@ -12,4 +12,4 @@ tail -1 $out/one_word_seeds_10000_10249.log
 timeout 1500 python3 tools/stress_multi_random.py 11000 200 > $out/emulated_ranks_seeds_11000_11199.log 2>&1
 tail -1 $out/emulated_ranks_seeds_11000_11199.log
 DSK_BENCH_SHARE_GPU=1 python3 bench.py --gpus 2 --check-parity --steps 3 --warmup 1 2>$out/bench_n2.err | grep '^{"metric"' > $out/bench_n2_shared_gpu_development.json; cut -c1-400 $out/bench_n2_shared_gpu_development.json
-DSK_BENCH_SHARE_GPU=1 python3 bench.py --gpus 4 --check-parity --steps 2 --warmup 1 2>$out/bench_n4.err | grep '^{"metric"' > $out/bench_n4_shared_gpu_development.json; cut -c1-400 $out/bench_n4_shared_gpu_development.json
+DSK_BENCH_SHARE_GPU=1 python3 bench.py --gpus 4 --workload c2_10Mx150 --check-parity --steps 2 --warmup 1 2>$out/bench_n4.err | grep '^{"metric"' > $out/bench_n4_shared_gpu_development.json; cut -c1-400 $out/bench_n4_shared_gpu_development.json
