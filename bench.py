@@ -208,7 +208,7 @@ def e2e_block(k, amin, budget_s=150.0):
             if best is None or dt < best:
                 best = dt
                 for ln in p.stdout.decode(errors="replace").splitlines():
-                    for key in ("ingest_s", "count_s", "write_s", "total_s", "kmers_nb_valid", "kmers_nb_distinct", "kmers_nb_solid"):
+                    for key in ("ingest_s", "count_s", "write_s", "total_s", "kmers_nb_valid", "kmers_nb_distinct", "kmers_nb_solid", "banks_parsed_on_device"):
                         if key in ln:
                             info[key] = float(ln.split(":")[-1]) if key.endswith("_s") else int(ln.split(":")[-1])
             if time.perf_counter() - t_start > budget_s:
@@ -231,6 +231,7 @@ def e2e_block(k, amin, budget_s=150.0):
             del reads
             torch.cuda.empty_cache()
             blk = {"file_bytes": size, "plain": run_dsk(fq)}
+            blk["plain_device_parse"] = run_dsk(fq, ("-device-parse", "1"))       # the text goes to the GPU as it is (dskgpu_push_raw): no host parser
             if name == "ecoli50x":
                 data = open(fq, "rb").read()
                 with gzip.open(fq + ".gz", "wb", compresslevel=1) as f:
@@ -244,6 +245,7 @@ def e2e_block(k, amin, budget_s=150.0):
                         f.write(body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
                 del data
                 blk["gzip"] = run_dsk(fq + ".gz")
+                blk["gzip_device_parse"] = run_dsk(fq + ".gz", ("-device-parse", "1"))
                 blk["bgzf"] = run_dsk(fq + ".bgzf.gz")
                 if os.path.exists(cli):                       # the CPU restatement's own CLI on the same file
                     cpu = {}

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include <thread>
 #include "../../include/dskgpu.h"
 #include "kernels.h"
 #include "superkmer.h"
@@ -3258,7 +3259,7 @@ int dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out) {
     if (ctx->cfg.histo_max == 0) ctx->cfg.histo_max = 10000;
     if (ctx->cfg.abundance_max == 0) ctx->cfg.abundance_max = 0x7FFFFFFFu;
     if (ctx->cfg.minimizer_size == 0) ctx->cfg.minimizer_size = 10;
-    ctx->W = cfg->kmer_size <= 32 ? 1 : cfg->kmer_size <= 64 ? 2 : 4;     // device keys: 1, 2 or 4 words
+    ctx->W = cfg->kmer_size <= 32 ? 1 : cfg->kmer_size <= 64 ? 2 : 4;     // device keys: 1, 2 or 4 words (three-word keys for 65 <= k <= 96 were built and measured in r06: slower than the four-word path)
     ctx->words_out = (int)((cfg->kmer_size + 31) / 32);
     ctx->sentinel_ok = !sentinel_is_a_kmer(ctx->W, cfg->kmer_size);                   // words of a k-mer at the ABI (3 for k <= 96)
     ctx->max_keys_per_pass = (u64)cfg->max_pass_mkeys * 1000000ull;
@@ -3317,6 +3318,18 @@ int dskgpu_set_stream(dskgpu_ctx* ctx, void* hip_stream) {
 }
 
 #define PIN_CHUNK ((size_t)32 << 20)
+// pageable -> pinned: one thread copies ~10 GB/s on the host this was measured on, the link takes 55: big pieces are copied by up to eight (a memory-mapped file's pages are also faulted in by the copy)
+static void stage_copy(void* dst, const void* src, size_t n) {
+    const unsigned T = n >= ((size_t)16 << 20) ? 8u : n >= ((size_t)8 << 20) ? 4u : n >= ((size_t)2 << 20) ? 2u : 1u;
+    if (T == 1) { std::memcpy(dst, src, n); return; }
+    const size_t per = (((n + T - 1) / T) + 4095) & ~(size_t)4095;          // T * per >= n
+    std::thread th[7];
+    for (unsigned t = 1; t < T; ++t)
+        th[t - 1] = std::thread([=]() { const size_t a = (size_t)t * per; if (a < n) std::memcpy((char*)dst + a, (const char*)src + a, std::min(per, n - a)); });
+    std::memcpy(dst, src, std::min(per, n));
+    for (unsigned t = 1; t < T; ++t) th[t - 1].join();
+}
+
 static int ensure_pinned(dskgpu_ctx* ctx) {      // the two pinned staging buffers of dskgpu_push_reads (also set up by dskgpu_reserve_reads: off the first push's path)
     if (ctx->pin[0] && ctx->pin[1]) return DSKGPU_OK;
     for (int i = 0; i < 2; ++i) {
@@ -3350,7 +3363,7 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes) {
             const int slot = ctx->pin_next;       // (alternates ACROSS calls too: the copy of this call's first piece overlaps the DMA of the last call's last one)
             const size_t len = (size_t)std::min<u64>(CH, nbytes - off);
             if (ctx->pin_used[slot]) CK(hipEventSynchronize(ctx->pin_ev[slot]));
-            std::memcpy(ctx->pin[slot], bytes + off, len);
+            stage_copy(ctx->pin[slot], bytes + off, len);
             CK(hipMemcpyAsync(dst + ctx->reads_len + off, ctx->pin[slot], len, hipMemcpyHostToDevice, ctx->stream));
             CK(hipEventRecord(ctx->pin_ev[slot], ctx->stream));
             ctx->pin_used[slot] = true;
@@ -3381,19 +3394,19 @@ static int raw_finish(dskgpu_ctx* ctx, u64* lines) {
     if (s.out_len + 1 > ctx->reads_own.cap) return fail(ctx, DSKGPU_E_STATE, "dskgpu_push_raw: stream longer than its bound");
     CK(hipMemsetAsync(dst + s.out_len, '\n', 1, ctx->stream));
     ctx->reads_len = s.out_len + 1;
-    if (lines) *lines = s.lines;
+    if (lines) *lines = s.recs;
     ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len; ctx->enc_keep = false; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->mw_v3_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
     return DSKGPU_OK;
 }
 #define RAW_SYNC(ctx) do { if ((ctx)->raw_pending) { const int e_ = raw_finish(ctx, nullptr); if (e_) return e_; } } while (0)
 
-int dskgpu_raw_finish(dskgpu_ctx* ctx, uint64_t* stream_bytes, uint64_t* lines) {
+int dskgpu_raw_finish(dskgpu_ctx* ctx, uint64_t* stream_bytes, uint64_t* records) {
     if (!ctx) return DSKGPU_E_ARG;
     CK(hipSetDevice(ctx->cfg.device));
     u64 ln = 0;
     const int rc = raw_finish(ctx, &ln);
     if (stream_bytes) *stream_bytes = ctx->reads_len;
-    if (lines) *lines = ln;
+    if (records) *records = ln;
     return rc;
 }
 
@@ -3433,7 +3446,7 @@ int dskgpu_push_raw(dskgpu_ctx* ctx, const char* text, uint64_t nbytes, int form
             const int slot = ctx->pin_next;
             const size_t len = (size_t)std::min<u64>(CH, nbytes - off);
             if (ctx->pin_used[slot]) CK(hipEventSynchronize(ctx->pin_ev[slot]));
-            std::memcpy(ctx->pin[slot], text + off, len);
+            stage_copy(ctx->pin[slot], text + off, len);
             CK(hipMemcpyAsync(ctx->raw_in.p, ctx->pin[slot], len, hipMemcpyHostToDevice, ctx->stream));      // (one device buffer: the stream orders the next piece's DMA behind this piece's kernels, which take a fraction of the DMA's time)
             CK(hipEventRecord(ctx->pin_ev[slot], ctx->stream));
             ctx->pin_used[slot] = true;

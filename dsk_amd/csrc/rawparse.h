@@ -25,7 +25,7 @@
 #define RP_FASTA 1
 #define RP_FASTQ 2
 
-struct RawState { unsigned long long lines, out_len; u32 hdr, bad, prev_nl, fresh; };      // fresh: a new file starts with the next chunk
+struct RawState { unsigned long long lines, out_len, recs; u32 hdr, bad, prev_nl, fresh; };      // lines: of the current file; recs: records (header lines) since the raw pushes began      // fresh: a new file starts with the next chunk
 // what a block tells: newlines; FASTQ: kept bytes by (start line % 4); FASTA: kept[start in header ? 1 : 0], has a line start, header state at its end
 struct RpBlock { u32 nl; u32 kept[4]; u32 has_ls, end_hdr, pad; };
 
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(RP_NT) void k_rp_scan(const unsigned char* __restri
 
 // (a context's first raw push, or one behind dskgpu_push_reads: the stream so far is `out_len` bytes)
 __global__ void k_rp_init(RawState* st, unsigned long long out_len) {
-    RawState s; s.lines = 0; s.out_len = out_len; s.hdr = 0; s.bad = 0; s.prev_nl = 1; s.fresh = 1;
+    RawState s; s.lines = 0; s.out_len = out_len; s.recs = 0; s.hdr = 0; s.bad = 0; s.prev_nl = 1; s.fresh = 1;
     *st = s;
 }
 __global__ void k_rp_fresh(RawState* st) { st->fresh = 1; }
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(RP_NT) void k_rp_write(const unsigned char* __restr
     }
     __syncthreads();
     // count what the thread keeps, then place it
-    u32 keepm[2] = {0u, 0u}, cnt = 0, bad = 0;           // bit i: byte i is kept
+    u32 keepm[2] = {0u, 0u}, cnt = 0, bad = 0, recs = 0;           // bit i: byte i is kept
     {
         u32 state = s_start[tid];
         unsigned char prev = prev0;
@@ -206,11 +206,12 @@ __global__ __launch_bounds__(RP_NT) void k_rp_write(const unsigned char* __restr
                 bool k;
                 if (FMT == RP_FASTQ) {
                     if (ls && ((state == 0u && c != '@') || (state == 2u && c != '+')) && c != '\n' && c != '\r') bad = 1;      // (blank lines at the end of a file are let through)
+                    if (ls && state == 0u && c == '@') ++recs;
                     k = state == 1u && c != '\r';
                     if (state == 1u && (c == ' ' || c == '\t')) bad = 1;      // (the host parser drops blanks inside a sequence line: leave such a file to it)
                     if (c == '\n') state = (state + 1u) & 3u;
                 } else {
-                    if (ls) state = rp_hdr_char(c) ? 1u : 0u;
+                    if (ls) { state = rp_hdr_char(c) ? 1u : 0u; recs += state; }
                     k = state ? c == '\n' : !rp_blank(c);
                 }
                 if (k) { keepm[i >> 5] |= 1u << (i & 31); ++cnt; }
@@ -232,4 +233,6 @@ __global__ __launch_bounds__(RP_NT) void k_rp_write(const unsigned char* __restr
     unsigned char* dst = out + boff[blockIdx.x];
     for (u32 i = tid; i < total; i += RP_NT) dst[i] = stage[i];
     if (bad) atomicOr(&st->bad, 1u);
+    recs = wave_incl_scan(recs);            // (lane 63: the wave's sum)
+    if ((tid & 63u) == 63u && recs) atomicAdd(&st->recs, (unsigned long long)recs);
 }

@@ -298,7 +298,7 @@ class KmerCounter:
         self._ck(self._lib.dskgpu_push_raw(self._h, C.c_void_p(arr.ctypes.data if arr.size else 0), arr.size, int(fmt), int(bool(new_file))))
 
     def raw_finish(self):
-        """-> (bytes of the read stream, text lines of the last file); raises DskGpuError(DSKGPU_E_FORMAT) when the text was not what
+        """-> (bytes of the read stream, records in the raw pushes since the last finish); raises DskGpuError(DSKGPU_E_FORMAT) when the text was not what
         the device parser handles (the raw pushes are dropped then: parse on the host and push_reads)."""
         nb, ln = C.c_uint64(0), C.c_uint64(0)
         self._ck(self._lib.dskgpu_raw_finish(self._h, C.byref(nb), C.byref(ln)))

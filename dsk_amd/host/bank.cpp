@@ -162,6 +162,75 @@ public:
         }
         return stream_serial(chunkBytes, sink);
     }
+    bool streamRaw(const RawSink& sink) override {
+        const uint64_t size = file_size(path_);
+        if (size < 2) return false;
+        int fd = open(path_.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) return false;
+        const unsigned char* zb = (const unsigned char*)m;
+        const bool gz = zb[0] == 0x1f && zb[1] == 0x8b;
+        struct NotRecords {};
+        bool first = true; int fmt = 0;
+        // every piece of text goes on as it is; the first one decides the format (and whether this is text the device parser takes)
+        auto hand_on = [&](const char* data, size_t len) {
+            if (first) {
+                const char* p = data;
+                const char kind = record_kind(p, data + len);
+                if (!kind) throw NotRecords{};
+                fmt = kind == '>' ? 1 : 2;
+                len -= (size_t)(p - data); data = p;
+            }
+            const size_t PIECE = (size_t)64 << 20;
+            for (size_t off = 0; off < len || first; off += PIECE) {
+                sink(data + off, std::min(PIECE, len - off), fmt, first);
+                first = false;
+            }
+        };
+        bool ok = false;
+        try {
+            if (!gz) { hand_on((const char*)m, size); ok = true; }
+            else {
+                uint32_t cs = 0;
+                if (bgzf_block_at(zb, size, &cs)) { munmap(m, size); return false; }      // (BGZF: the member pool of stream() already inflates it in parallel)
+                const unsigned nthreads = Bank::parseThreads();
+                if (nthreads > 1 && !getenv("DSK_NO_PGZIP") && (size >= (1u << 20) || getenv("DSK_PGZIP_CHUNK_BYTES"))) {
+                    size_t pgz_chunk = 0;
+                    if (const char* e = getenv("DSK_PGZIP_CHUNK_BYTES")) pgz_chunk = (size_t)atoll(e);
+                    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+                    ok = pgz_inflate(zb, size, std::min(std::max(nthreads, std::min(hw, 64u)), 64u), pgz_chunk, 0,
+                                     [&](char* data, size_t len, bool) { hand_on(data, len); });
+                }
+                if (!ok) {                                  // one zlib stream
+                    gzFile f = gzopen(path_.c_str(), "rb");
+                    if (f) {
+                        gzbuffer(f, 1 << 20);
+                        std::vector<char> raw((size_t)8 << 20);
+                        try {
+                            for (;;) {
+                                const int got = gzread(f, raw.data(), (unsigned)raw.size());
+                                if (got < 0) throw Exception("read error in file '%s'", path_.c_str());
+                                if (got == 0) break;
+                                hand_on(raw.data(), (size_t)got);
+                            }
+                        } catch (...) { gzclose(f); throw; }
+                        gzclose(f);
+                        ok = !first;
+                    }
+                }
+            }
+        } catch (const NotRecords&) {
+            munmap(m, size);
+            return false;
+        } catch (const std::runtime_error& e) {
+            munmap(m, size);
+            throw Exception("%s: file '%s'", e.what(), path_.c_str());
+        } catch (...) { munmap(m, size); throw; }
+        munmap(m, size);
+        return ok;
+    }
 private:
     uint64_t stream_serial(size_t chunkBytes, const Sink& sink) {
         gzFile f = gzopen(path_.c_str(), "rb");

@@ -24,6 +24,12 @@ public:
     // Push the whole bank through `sink` in chunks of about chunkBytes, each
     // chunk a whole number of records.  Returns the number of sequences.
     virtual uint64_t stream(size_t chunkBytes, const Sink& sink) = 0;
+    // The bank's TEXT as it lies in the (inflated) file, headers and quality lines included, in pieces cut anywhere -- for an engine
+    // that parses on the device (dskgpu_push_raw).  format: 1 FASTA, 2 FASTQ (include/dskgpu.h DSKGPU_RAW_*); new_file: the piece
+    // begins a file.  Returns false -- and has handed on NOTHING -- when the bank does not do this (an album, a BGZF file, text that
+    // does not start like FASTA / FASTQ): the caller uses stream().
+    typedef std::function<void(const char* text, size_t nbytes, int format, bool new_file)> RawSink;
+    virtual bool streamRaw(const RawSink& sink) { (void)sink; return false; }
     // (number of sequences, total bases, longest sequence); exact, by a full pass
     virtual void estimate(uint64_t& number, uint64_t& totalSize, uint64_t& maxSize);
     // file names (flattened)

@@ -35,6 +35,11 @@ public:
     virtual void prepare(uint64_t nbytes) {}                  // optional: set up the work buffers of a count over that many bytes now (may run
                                                               // on another thread while push() is called; done before finish())
     virtual void push(const char* data, size_t nbytes) = 0;   // read-stream chunk, whole records
+    virtual bool parsesOnDevice() const { return false; }     // pushRaw / rawFinish are offered (with the configuration given)
+    // optional: file TEXT (FASTA 1 / FASTQ 2, cut anywhere) for an engine that parses on the device; false = not offered, use push()
+    virtual bool pushRaw(const char* text, size_t nbytes, int format, bool new_file) { (void)text; (void)nbytes; (void)format; (void)new_file; return false; }
+    // after the raw pushes of a bank: true + the number of records; false = the engine gave the text back (nothing of it was kept: parse on the host and push())
+    virtual bool rawFinish(uint64_t& records, uint64_t& stream_bytes) { records = 0; stream_bytes = 0; return false; }
     virtual void nextBank() = 0;                              // what was pushed so far is one bank (comma-separated input)
     virtual void finish() = 0;                                // run the count; results valid afterwards
     virtual void histogram(std::vector<uint64_t>& h) = 0;     // histo_max + 1 entries, h[0] == 0

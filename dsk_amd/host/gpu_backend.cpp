@@ -93,6 +93,22 @@ public:
         for (auto& t : th) t.join();
         for (Piece& pc : pieces) ckr(pc.rank, pc.rc);
     }
+    // one GPU: the file's text goes to the device as it is (dskgpu_push_raw); a group cuts its pushes at record separators, which
+    // only parsed reads have
+    bool parsesOnDevice() const override { return true; }       // (one GPU; the caller does not ask with -nb-gpus > 1)
+    bool pushRaw(const char* text, size_t n, int format, bool new_file) override {
+        if (grp_) return false;
+        ck(dskgpu_push_raw(ctx_, text, n, format, new_file ? 1 : 0));
+        return true;
+    }
+    bool rawFinish(uint64_t& records, uint64_t& stream_bytes) override {
+        records = 0; stream_bytes = 0;
+        if (grp_) return false;
+        const int rc = dskgpu_raw_finish(ctx_, &stream_bytes, &records);
+        if (rc == DSKGPU_E_FORMAT) return false;
+        ck(rc);
+        return true;
+    }
     void nextBank() override {
         if (!grp_) { ck(dskgpu_next_bank(ctx_)); return; }
         for (uint32_t r = 0; r < dskgpu_group_size(grp_); ++r) ckr(r, dskgpu_next_bank(dskgpu_group_ctx(grp_, r)));      // every rank's share of the bank ends here

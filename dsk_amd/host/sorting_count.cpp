@@ -50,6 +50,7 @@ IOptionsParser* SortingCountBase::makeOptionsParser() {
     p->push_back(new OptionOneParam("-repartition-type", "minimizer repartition; accepted, does not change results", false, "0", false));
     p->push_back(new OptionOneParam("-nb-partitions", "number of output partitions under dsk/solid (0 = default)", false, "0", false));
     p->push_back(new OptionOneParam("-device", "GPU ordinal (first one with -nb-gpus)", false, "0", false));
+    p->push_back(new OptionOneParam("-device-parse", "1: the files' text goes to the GPU as it is and is parsed there (one GPU; falls back to the host parser for text the device parser does not take)", false, "0", false));
     p->push_back(new OptionOneParam("-nb-gpus", "number of GPUs sharing the k-mer space (power of two; ranks share devices when the node has fewer)", false, "1", false));
     return p;
 }
@@ -179,9 +180,27 @@ void SortingCountBase::execute() {
     uint64_t nseq = 0;
     std::vector<IBank*> subs = bank_->banks();   // one bank per comma-separated input (README.md:52-58)
     const bool per_bank = cfg.solidity_kind != 0 || cfg.histo2d;
-    if (per_bank || subs.size() < 2) {           // bank boundaries matter: stream the banks in order
+    // -device-parse 1 (or DSK_DEVICE_PARSE=1): no host parser -- the text of every file is pushed as it is and the device leaves the
+    // read stream (dskgpu_push_raw).  A bank the device parser gives back (DSKGPU_E_FORMAT) is parsed here as before.
+    const bool dev_parse = cfg.nb_gpus == 1 && be->parsesOnDevice() && ((input_.has("-device-parse") && input_.getInt("-device-parse") != 0) || getenv("DSK_DEVICE_PARSE") != nullptr);
+    unsigned raw_banks = 0; uint64_t raw_text_bytes = 0;
+    if (per_bank || subs.size() < 2 || dev_parse) {           // bank boundaries matter: stream the banks in order
         for (IBank* sub : subs) {
-            nseq += sub->stream(chunk_bytes, push);
+            bool raw_done = false;
+            if (dev_parse) {
+                const uint64_t before = nbytes;
+                auto rawsink = [&](const char* d, size_t n, int fmt, bool nf) {
+                    if (!pushing) { startup.wait_push(); pushing = true; }
+                    if (!be->pushRaw(d, n, fmt, nf)) throw Exception("the engine does not parse on the device");
+                    raw_text_bytes += n;
+                };
+                if (sub->streamRaw(rawsink)) {
+                    uint64_t recs = 0, stream_bytes = 0;
+                    if (be->rawFinish(recs, stream_bytes)) { nseq += recs; nbytes = stream_bytes; raw_done = true; ++raw_banks; }
+                    else nbytes = before;
+                }
+            }
+            if (!raw_done) nseq += sub->stream(chunk_bytes, push);
             if (!pushing) { startup.wait_push(); pushing = true; }
             be->nextBank();
         }
@@ -311,6 +330,7 @@ void SortingCountBase::execute() {
     info_.add(2, "uri", bank_->getId());
     info_.add(2, "nb_sequences", "%llu", (unsigned long long)nseq);
     info_.add(2, "read_stream_bytes", "%llu", (unsigned long long)nbytes);
+    if (dev_parse) { info_.add(2, "banks_parsed_on_device", "%u", raw_banks); info_.add(2, "text_bytes_pushed", "%llu", (unsigned long long)raw_text_bytes); }
     info_.add(1, "stats");
     be->stats(info_, 2);
     info_.add(2, "solid_kmers_written", "%llu", (unsigned long long)nb_solid_);

@@ -125,8 +125,9 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes);
 #define DSKGPU_RAW_FASTA 1
 #define DSKGPU_RAW_FASTQ 2
 int dskgpu_push_raw(dskgpu_ctx* ctx, const char* text, uint64_t nbytes, int format, int new_file);
-/* Wait for the raw pushes; -> the read stream's length in bytes and the number of text lines of the last file (both may be NULL). */
-int dskgpu_raw_finish(dskgpu_ctx* ctx, uint64_t* stream_bytes, uint64_t* lines);
+/* Wait for the raw pushes; -> the read stream's length in bytes and the number of records (header lines) the raw pushes since the
+ * last finish held -- Bank::estimate's sequence count (both may be NULL). */
+int dskgpu_raw_finish(dskgpu_ctx* ctx, uint64_t* stream_bytes, uint64_t* records);
 /* Optional: size the device-side read buffer once (e.g. from Bank::getSize) instead of growing it push by push. */
 int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes);
 /* Optional: allocate the partition buffers of a count over up to `nbytes` read-stream bytes now (tens of GB of HBM: 0.2 s of

@@ -183,7 +183,42 @@ def test_messy_fastq_at_gb_scale(bins, tmp_path):
         kc.count()
         st, hist = kc.stats(), kc.histogram()
     del t
-    run_messy_case(bins["dsk"], tmp, n_reads, (st["n_kmers"], st["n_distinct"], st["n_solid"], hist))
+    want = (st["n_kmers"], st["n_distinct"], st["n_solid"], hist)
+    run_messy_case(bins["dsk"], tmp, n_reads, want)
+    run_messy_case(bins["dsk"], tmp, n_reads, want, {"DSK_DEVICE_PARSE": "1"})       # the same files, parsed on the device
+
+
+def test_device_parse_through_the_binary(bins, tmp_path, oracle, monkeypatch):
+    """-device-parse 1 / DSK_DEVICE_PARSE=1: no host parser -- the text of every file goes to the GPU as it is (dskgpu_push_raw).  The
+    reference's six black-box cases against its goldens, the messy files (plain, multi-member gzip through the parallel inflate,
+    two-line FASTA) against the oracle, and a FASTQ file with wrapped sequences, which the device parser gives back
+    (DSKGPU_E_FORMAT) and the host parser then takes -- same totals either way."""
+    import re
+    import numpy as np
+    from tests.test_host_cli import make_messy_inputs, run_messy_case, run_six_cases
+    monkeypatch.setenv("DSK_DEVICE_PARSE", "1")
+    tmp = str(tmp_path)
+    run_six_cases(bins["dsk"], bins["dsk2ascii"], tmp)
+    n_reads = 25_000
+    clean = make_messy_inputs(tmp, n_reads, 60_000)
+    ref = oracle.count(clean, 31)
+    want = (ref.total, ref.distinct, int((ref.ab >= 3).sum()), ref.histogram(10000))
+    run_messy_case(bins["dsk"], tmp, n_reads, want, {"DSK_DEVICE_PARSE": "1"})
+    run_messy_case(bins["dsk"], tmp, n_reads, want, {"DSK_DEVICE_PARSE": "1", "DSK_PGZIP_CHUNK_BYTES": "65536"})       # the gzip file through the parallel inflate
+    # wrapped FASTQ: given back, parsed on the host
+    rng = np.random.default_rng(4)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 120)) for _ in range(2000)]
+    with open(os.path.join(tmp, "wrapped.fastq"), "wb") as f:
+        for i, s in enumerate(seqs):
+            f.write(b"@r%d\n" % i + s[:60] + b"\n" + s[60:] + b"\n+\n" + b"I" * 60 + b"\n" + b"I" * 60 + b"\n")
+    ref = oracle.count(np.frombuffer(b"\n".join(seqs) + b"\n", dtype=np.uint8), 31)
+    for args in (["-device-parse", "1"], []):
+        r = subprocess.run([bins["dsk"], "-file", "wrapped.fastq", "-kmer-size", "31", "-abundance-min", "1", "-out", "w", "-verbose", "1"] + args,
+                           cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        info = r.stdout.decode()
+        got = tuple(int(re.search(key + r"\s*:\s*(\d+)", info).group(1)) for key in ("nb_sequences", "kmers_nb_valid", "kmers_nb_distinct", "banks_parsed_on_device"))
+        assert got == (2000, ref.total, ref.distinct, 0), got
 
 
 def test_bench_line_contract():

@@ -634,6 +634,17 @@ def test_push_reads_staging_and_reserve(oracle, dev):
             st = kc.stats()
         keep = ref.ab >= 3
         assert st["n_kmers"] == ref.total and (rows[:, 0] == ref.lo[keep]).all() and (ab == ref.ab[keep]).all(), mode
+    # piece sizes the staging copy splits over 2, 4 and 8 threads with a remainder: n = T * 4096 * q + 1 (r06: the last byte of such a
+    # piece was not copied -- one k-mer in 3 * 10^8 off on a sequencer-like file)
+    recs = [0, 15950, 15950 + 65102, 15950 + 65102 + 130638, 600_000]
+    assert [151 * (recs[i + 1] - recs[i]) - 1 for i in range(3)] == [2408449, 9830401, 19726337]
+    with KmerCounter(kmer_size=25, abundance_min=3) as kc:
+        for i in range(4):
+            kc.push_reads(reads[151 * recs[i]: 151 * recs[i + 1] - 1])          # (without the last separator: one is implied behind a push)
+        kc.count()
+        rows, ab = kc.rows()
+        st = kc.stats()
+    assert st["n_kmers"] == ref.total and (rows[:, 0] == ref.lo[keep]).all() and (ab == ref.ab[keep]).all()
 
 
 def test_encode_reads_lets_go_of_the_bytes(oracle, dev):

@@ -88,7 +88,7 @@ def check(oracle, files, k, rng=None, pieces=1):
     nbytes, lines, rows, ab, hist, st = count_raw(files, k, rng, pieces)
     model = model_stream(files)
     assert nbytes == len(model), (nbytes, len(model))
-    assert lines == files[-1][0].count(b"\n")
+    assert lines == sum(len(host_records(t, f).split(b"\n")) - 1 for t, f in files)          # records
     host = np.frombuffer(b"".join(host_records(t, f) for t, f in files), dtype=np.uint8)
     ref = oracle.count(host, k)
     assert oracle.count(np.frombuffer(model, dtype=np.uint8), k).total == ref.total          # the two statements of the rules agree
@@ -232,7 +232,7 @@ def test_raw_text_beyond_the_staging_chunk(oracle, dev):
         for i in range(3):
             kc.push_raw(text[cuts[i]: cuts[i + 1]], kc.RAW_FASTQ, new_file=i == 0)
         nbytes, lines = kc.raw_finish()
-        assert nbytes == nr * (rl + 1) + 1 and lines == 4 * nr
+        assert nbytes == nr * (rl + 1) + 1 and lines == nr
         kc.count()
         rows, ab = kc.rows()
         st = kc.stats()

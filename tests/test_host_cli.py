@@ -87,6 +87,8 @@ def run_messy_case(dsk, tmp, n_reads, want, extra_env=None):
         info = r.stdout.decode()
         got = tuple(int(re.search(key + r"\s*:\s*(\d+)", info).group(1)) for key in ("nb_sequences", "kmers_nb_valid", "kmers_nb_distinct", "kmers_nb_solid"))
         assert got == (n_reads, want[0], want[1], want[2]), (name, got, want[:3])
+        if (extra_env or {}).get("DSK_DEVICE_PARSE"):          # the text went to the GPU as it is and was parsed there (dskgpu_push_raw)
+            assert re.search(r"banks_parsed_on_device\s*:\s*1", info), (name, info[-1500:])
         assert h5_histo("m.h5", tmp) == want_histo, name
         os.remove(os.path.join(tmp, "m.h5"))
 
