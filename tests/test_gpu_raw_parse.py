@@ -38,7 +38,7 @@ def model_stream(files):
             elif ln.startswith(b">"):
                 out += b"\n" if nl else b""
             else:
-                out += bytes(c for c in ln if c not in b"\r \t")
+                out += ln.translate(None, b"\r \t")
     out += b"\n"
     return bytes(out)
 
@@ -56,7 +56,7 @@ def host_records(text, fmt):
                     recs.append(cur)
                 cur = b""
             elif cur is not None:
-                cur += bytes(c for c in ln if c not in b"\r \t")
+                cur += ln.translate(None, b"\r \t")
         if cur is not None:
             recs.append(cur)
     return b"".join(r + b"\n" for r in recs)
