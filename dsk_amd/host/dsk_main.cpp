@@ -43,6 +43,15 @@ int main(int argc, char* argv[]) {
     //  handle would otherwise leave the .h5 unflushed behind an exit code of 0)
     H5close();
     std::cout.flush(); std::cerr.flush(); fflush(nullptr);
-    if (getenv("DSK_PHASE_TIMES")) fprintf(stderr, "[dsk] main() took %.3f s\n", wall_s() - t0);
+    if (getenv("DSK_PHASE_TIMES")) {
+        fprintf(stderr, "[dsk] main() took %.3f s (entered at %.6f, leaves at %.6f: against the caller's clock around the process this tells start-up and exit apart)\n", wall_s() - t0, t0, wall_s());
+        if (FILE* f = fopen("/proc/self/status", "r")) {       // what the kernel still has to take apart after _exit (it is part of the wall clock a caller sees)
+            char line[256];
+            while (fgets(line, sizeof line, f))
+                if (!strncmp(line, "VmRSS", 5) || !strncmp(line, "RssAnon", 7) || !strncmp(line, "RssFile", 7) || !strncmp(line, "RssShmem", 8) || !strncmp(line, "VmPTE", 5) || !strncmp(line, "Threads", 7))
+                    fprintf(stderr, "[dsk] at exit: %s", line);
+            fclose(f);
+        }
+    }
     _exit(EXIT_SUCCESS);
 }
