@@ -133,6 +133,12 @@ const char* next_record_start(const char* base, const char* from, const char* en
 // One FASTA/FASTQ file.  gzip'ed: inflate overlapped with parsing, BGZF members inflated by a thread pool.  Plain and large: memory-mapped
 // and parsed by several threads on record-aligned ranges (the sink is serialised by a mutex;
 // counting does not depend on record order).
+// threads of the parallel inflate: pure CPU work on independent chunks -- it takes up to 64 where the parser is capped at 32
+static unsigned pgz_threads(unsigned nthreads, unsigned hw) {
+    const unsigned cap = 64;      // (r06, 81 MB E. coli .fastq.gz on 2 x 64 cores: 96 / 128 threads inflate in 26 / 13 ms instead of 42 and lose it again in the byte pass -- and the ingest waits for the device runtime either way)
+    return std::min(std::max(nthreads, std::min(hw, cap)), cap);
+}
+
 class BankFasta : public IBank {
 public:
     explicit BankFasta(const std::string& path) : path_(path) {
@@ -200,7 +206,7 @@ public:
                     size_t pgz_chunk = 0;
                     if (const char* e = getenv("DSK_PGZIP_CHUNK_BYTES")) pgz_chunk = (size_t)atoll(e);
                     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-                    ok = pgz_inflate(zb, size, std::min(std::max(nthreads, std::min(hw, 64u)), 64u), pgz_chunk, 0,
+                    ok = pgz_inflate(zb, size, pgz_threads(nthreads, hw), pgz_chunk, 0,
                                      [&](char* data, size_t len, bool) { hand_on(data, len); });
                 }
                 if (!ok) {                                  // one zlib stream
@@ -416,7 +422,7 @@ private:
             // (the inflate is pure CPU work on independent chunks: it takes up to 64 threads where the parser is capped at 32)
             const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
             const size_t HEAD = 4u << 20;                        // room in front of every slab for the previous slab's cut-off record
-            ok = pgz_inflate((const uint8_t*)m, size, std::min(std::max(nthreads, std::min(hw, 64u)), 64u), pgz_chunk, HEAD, [&](char* data, size_t len, bool last) {
+            ok = pgz_inflate((const uint8_t*)m, size, pgz_threads(nthreads, hw), pgz_chunk, HEAD, [&](char* data, size_t len, bool last) {
                 const char* base; const char* end;
                 if (carry.size() <= HEAD) { std::memcpy(data - carry.size(), carry.data(), carry.size()); base = data - carry.size(); end = data + len; }
                 else {                                           // (a record longer than the headroom: the slab is copied behind it)

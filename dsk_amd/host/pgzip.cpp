@@ -255,7 +255,13 @@ bool pgz_inflate(const uint8_t* file, size_t n, unsigned nthreads, size_t chunk_
                  const std::function<void(char*, size_t, bool)>& consume) {
     const size_t h0 = member_header(file, n, 0);
     if (!h0) return false;
-    if (!chunk_bytes) chunk_bytes = 2u << 20;
+    // chunk = the unit of parallel work.  2 MB of compressed text inflate to ~12 MB at ~160 MB/s per thread: a file of 80 MB cut that
+    // way keeps 39 threads busy for 80 ms each.  Files that do not fill the pool with 2 MB chunks are cut finer (not below 512 KB: a
+    // chunk's block start is searched in its first 256 KB).
+    if (!chunk_bytes) {
+        const size_t per_thread = ((n + nthreads - 1) / nthreads + 0xFFFF) & ~(size_t)0xFFFF;
+        chunk_bytes = std::min<size_t>(2u << 20, std::max<size_t>(512u << 10, per_thread));
+    }
     if (nthreads < 2 || n < h0 + 2 * chunk_bytes) return false;
     const size_t per_slab = std::min<size_t>(std::max<size_t>(2, (size_t)nthreads * 2), 128);          // chunks per slab
     const uint8_t* data = file; const size_t dn = n;         // bit positions are positions in the file
