@@ -11,6 +11,7 @@
 #include <vector>
 
 #include <thread>
+#include <system_error>
 #include "../../include/dskgpu.h"
 #include "kernels.h"
 #include "superkmer.h"
@@ -3323,11 +3324,14 @@ static void stage_copy(void* dst, const void* src, size_t n) {
     const unsigned T = n >= ((size_t)16 << 20) ? 8u : n >= ((size_t)8 << 20) ? 4u : n >= ((size_t)2 << 20) ? 2u : 1u;
     if (T == 1) { std::memcpy(dst, src, n); return; }
     const size_t per = (((n + T - 1) / T) + 4095) & ~(size_t)4095;          // T * per >= n
+    auto part = [=](unsigned t) { const size_t a = (size_t)t * per; if (a < n) std::memcpy((char*)dst + a, (const char*)src + a, std::min(per, n - a)); };
     std::thread th[7];
-    for (unsigned t = 1; t < T; ++t)
-        th[t - 1] = std::thread([=]() { const size_t a = (size_t)t * per; if (a < n) std::memcpy((char*)dst + a, (const char*)src + a, std::min(per, n - a)); });
-    std::memcpy(dst, src, std::min(per, n));
-    for (unsigned t = 1; t < T; ++t) th[t - 1].join();
+    unsigned started = 1;
+    try { for (; started < T; ++started) th[started - 1] = std::thread(part, started); }
+    catch (const std::system_error&) {}                      // (no more threads to be had: the parts that got none are copied here)
+    part(0);
+    for (unsigned t = started; t < T; ++t) part(t);
+    for (unsigned t = 1; t < started; ++t) th[t - 1].join();
 }
 
 static int ensure_pinned(dskgpu_ctx* ctx) {      // the two pinned staging buffers of dskgpu_push_reads (also set up by dskgpu_reserve_reads: off the first push's path)
