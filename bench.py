@@ -398,6 +398,7 @@ def main():
         args.workload = "c2_10Mx150" if args.gpus <= 1 else "c3_shard_25Mx150"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (what RCCL between processes needs on this pool): before the HIP runtime starts
     import torch
     import torch.distributed as dist
     from dsk_amd import KmerCounter, synth
