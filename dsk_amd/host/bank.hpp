@@ -26,7 +26,7 @@ public:
     virtual uint64_t stream(size_t chunkBytes, const Sink& sink) = 0;
     // The bank's TEXT as it lies in the (inflated) file, headers and quality lines included, in pieces cut anywhere -- for an engine
     // that parses on the device (dskgpu_push_raw).  format: 1 FASTA, 2 FASTQ (include/dskgpu.h DSKGPU_RAW_*); new_file: the piece
-    // begins a file.  Returns false -- and has handed on NOTHING -- when the bank does not do this (an album, a BGZF file, text that
+    // begins a file.  Returns false -- and has handed on NOTHING -- when the bank does not do this (a bank of several files, a BGZF file, text that
     // does not start like FASTA / FASTQ): the caller uses stream().
     typedef std::function<void(const char* text, size_t nbytes, int format, bool new_file)> RawSink;
     virtual bool streamRaw(const RawSink& sink) { (void)sink; return false; }

@@ -420,6 +420,57 @@ def test_solidity_kinds_and_histo2d_cli(bins, tmp_path, oracle):
     run_solidity_cases(bins["dsk"], bins["dsk2ascii"], str(tmp_path), oracle)
 
 
+def _fnv1a(data):
+    h = 1469598103934665603
+    for c in data:
+        h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_bank_hands_on_its_text(bins, tmp_path):
+    """IBank::streamRaw (what `dsk -device-parse 1` feeds to dskgpu_push_raw): the file's text as it is -- plain, gzip through zlib,
+    gzip through the parallel inflate, several members, a comma list -- from its first record on, the first piece of every file
+    flagged; and NOTHING for banks that keep the host parser (an album inside a list, BGZF, text that does not start like FASTA / FASTQ)."""
+    import gzip
+    exe = os.path.join(ROOT, "tests", "host", "test_stream_raw")
+    tmp = str(tmp_path)
+
+    def run(uri, env=None):
+        return subprocess.run([exe, uri], cwd=tmp, stdout=subprocess.PIPE, env=dict(os.environ, **(env or {}))).stdout.decode().split()
+
+    fa = open(f"{G}/longread.fasta", "rb").read()
+    assert run(f"{G}/longread.fasta") == ["RAW", "1", "1", str(len(fa)), "%016x" % _fnv1a(fa), "1"]
+    gz = gzip.open(f"{G}/c1.fasta.gz").read()
+    assert run(f"{G}/c1.fasta.gz") == ["RAW", "1", "1", str(len(gz)), "%016x" % _fnv1a(gz), "1"]                      # zlib (a small file)
+    out = run(f"{G}/c1.fasta.gz,{G}/longread.fasta")
+    assert out[:2] == ["RAW", "1"] and int(out[3]) == len(gz) + len(fa) and out[4] == "%016x" % _fnv1a(gz + fa) and out[5] == "1"
+    # FASTQ, blank lines in front (skipped), 3 MB: plain, one gzip member through the parallel inflate (small chunks), two members
+    import numpy as np
+    rng = np.random.default_rng(5)
+    recs = b"".join(b"@r%d\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 100)) + b"\n+\n" + b"I" * 100 + b"\n" for i in range(15000))
+    open(os.path.join(tmp, "a.fastq"), "wb").write(b"\n\n" + recs)
+    want = ["RAW", "2", "1", str(len(recs)), "%016x" % _fnv1a(recs), "1"]
+    assert run("a.fastq") == want
+    with gzip.open(os.path.join(tmp, "a.fastq.gz"), "wb", compresslevel=6) as f:
+        f.write(recs)
+    got = run("a.fastq.gz", {"DSK_PGZIP_CHUNK_BYTES": "65536"})
+    assert got[:2] == want[:2] and got[3:] == want[3:], got
+    with open(os.path.join(tmp, "two.fastq.gz"), "wb") as f:
+        f.write(gzip.compress(recs[: len(recs) // 2 // 212 * 212], 1) + gzip.compress(recs[len(recs) // 2 // 212 * 212:], 1))
+    got = run("two.fastq.gz", {"DSK_PGZIP_CHUNK_BYTES": "65536"})
+    assert got[:2] == want[:2] and got[3:] == want[3:], got
+    # banks that do not offer their text
+    open(os.path.join(tmp, "album.txt"), "w").write(f"{G}/c1.fasta.gz\n{G}/c2.fasta.gz\n")
+    c2 = gzip.open(f"{G}/c2.fasta.gz").read()
+    out = run("album.txt")                      # an album's files are banks of their own: each hands on its text
+    assert out[:3] == ["RAW", "1", "2"] and int(out[3]) == len(gz) + len(c2) and out[4] == "%016x" % _fnv1a(gz + c2) and out[5] == "1"
+    assert run(f"album.txt,{G}/c3.fasta.gz") == ["NO"]          # an album INSIDE a list is one bank of several files: host parser
+    write_bgzf(os.path.join(tmp, "b.fastq.gz"), recs)
+    assert run("b.fastq.gz") == ["NO"]
+    open(os.path.join(tmp, "junk.fa"), "wb").write(b"no header here\nACGT\n")
+    assert run("junk.fa") == ["NO"]
+
+
 def write_bgzf(path, data, block=60000):
     """BGZF writer (htslib's blocked gzip): independent <= 64 KB members with the 'BC' size field + the empty EOF member."""
     import struct, zlib
