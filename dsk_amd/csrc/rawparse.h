@@ -15,6 +15,7 @@
 // (RawState): no round trip per chunk.
 //   k_rp_count  per 16 KB block: newlines, kept bytes for every state the block could start in, the state it ends in
 //   k_rp_scan   one block: the blocks' start states and output offsets (<= 2048 blocks per chunk), the state after the chunk
+//               (prefix scans over the summaries: line counts, "the last line start before me", kept bytes)
 //   k_rp_write  per block: the kept bytes, staged in LDS, stored coalesced
 #pragma once
 #include "kmer_device.h"
@@ -50,9 +51,38 @@ __device__ __forceinline__ u32 rp_load(const unsigned char* __restrict__ in, u32
 }
 #define RP_BYTE(w, i) ((unsigned char)(((w)[(i) >> 2] >> (8 * ((i) & 3))) & 0xFFu))
 
+// ---- block-wide prefix helpers (RP_NT = 256 threads = 4 waves; every thread of the block calls them)
+// exclusive prefix sum of v over the block's threads; -> total
+__device__ __forceinline__ u32 rp_excl_sum(u32 v, u32* s_w, u32& total) {
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const u32 inc = wave_incl_scan(v);
+    __syncthreads();                                   // (s_w may still be read from the previous call)
+    if (lane == 63u) s_w[wave] = inc;
+    __syncthreads();
+    u32 base = 0; total = 0;
+#pragma unroll
+    for (u32 x = 0; x < RP_NT / 64; ++x) { const u32 t = s_w[x]; if (x < wave) base += t; total += t; }
+    return base + inc - v;
+}
+// "the last thread BEFORE me whose flag is set": -> its val (0 / 1), or 2 when there is none in the block.  last: the same seen from
+// behind the block's last thread
+__device__ __forceinline__ u32 rp_last_flagged(bool flag, u32 val, u32* s_w, u32& last) {
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long mask = __ballot(flag), vals = __ballot(flag && val);
+    __syncthreads();
+    if (lane == 0) s_w[wave] = mask ? (2u | (u32)((vals >> (63 - __clzll((long long)mask))) & 1ull)) : 0u;      // bit 1: the wave has one, bit 0: val of its last
+    __syncthreads();
+    u32 inh = 2u; last = 2u;
+#pragma unroll
+    for (u32 x = 0; x < RP_NT / 64; ++x) { const u32 t = s_w[x]; if (t & 2u) { if (x < wave) inh = t & 1u; last = t & 1u; } }
+    const unsigned long long prior = mask & ((1ull << lane) - 1ull);
+    return prior ? (u32)((vals >> (63 - __clzll((long long)prior))) & 1ull) : inh;
+}
+
 template <int FMT>
 __global__ __launch_bounds__(RP_NT) void k_rp_count(const unsigned char* __restrict__ in, u32 n, RpBlock* __restrict__ blk) {
-    __shared__ u32 s_nl[RP_NT], s_k[RP_NT][4], s_ls[RP_NT], s_eh[RP_NT];
+    __shared__ u32 s_w[RP_NT / 64];
+    __shared__ u32 s_sum[4];
     const u32 tid = threadIdx.x;
     const u32 b0 = blockIdx.x * RP_BLOCK + tid * RP_BPT;
     u32 w[16];
@@ -76,41 +106,41 @@ __global__ __launch_bounds__(RP_NT) void k_rp_count(const unsigned char* __restr
             prev = c;
         }
     }
-    s_nl[tid] = nl; s_ls[tid] = has_ls; s_eh[tid] = hdr;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) s_k[tid][x] = kq[x];
+    if (tid < 4) s_sum[tid] = 0;
+    // the threads' summaries composed in order: a prefix over the line counts (FASTQ) / "the last line start before me" (FASTA)
+    u32 nl_total = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, last = 2u;
+    if (FMT == RP_FASTQ) {
+        const u32 L = rp_excl_sum(nl, s_w, nl_total);                  // the thread's relative line x is the block's relative line L + x
+        const u32 r = L & 3u;
+        c0 = r == 0 ? kq[0] : r == 1 ? kq[3] : r == 2 ? kq[2] : kq[1];      // c[y] = kq[(y - r) & 3]
+        c1 = r == 0 ? kq[1] : r == 1 ? kq[0] : r == 2 ? kq[3] : kq[2];
+        c2 = r == 0 ? kq[2] : r == 1 ? kq[1] : r == 2 ? kq[0] : kq[3];
+        c3 = r == 0 ? kq[3] : r == 1 ? kq[2] : r == 2 ? kq[1] : kq[0];
+    } else {
+        (void)rp_excl_sum(nl, s_w, nl_total);
+        const u32 inh = rp_last_flagged(has_ls != 0, hdr, s_w, last);      // the state the thread's bytes before its own first line start continue
+        if (inh == 2u) { c0 = kq[0]; c1 = kq[1]; }                       // ... the block's own start state: kept for either
+        else c2 = inh ? kq[1] : kq[0];
+        c2 += kq[2];
+    }
+    c0 = wave_incl_scan(c0); c1 = wave_incl_scan(c1); c2 = wave_incl_scan(c2); c3 = wave_incl_scan(c3);      // (lane 63: the wave's sums)
     __syncthreads();
-    if (tid == 0) {          // compose the threads' summaries in order (256 short steps per 16 KB of text)
-        RpBlock r; r.nl = 0; r.kept[0] = r.kept[1] = r.kept[2] = r.kept[3] = 0; r.has_ls = 0; r.end_hdr = 0; r.pad = 0;
-        if (FMT == RP_FASTQ) {
-            for (u32 t = 0; t < RP_NT; ++t) {
-#pragma unroll
-                for (u32 x = 0; x < 4; ++x) r.kept[(r.nl + x) & 3u] += s_k[t][x];      // the thread's relative line x is the block's relative line nl + x
-                r.nl += s_nl[t];
-            }
-        } else {
-            u32 k0 = 0, k1 = 0, kd = 0;            // kept if the block starts outside / inside a header (until the block's first line start), kept after it
-            for (u32 t = 0; t < RP_NT; ++t) {
-                if (!r.has_ls) { k0 += s_k[t][0]; k1 += s_k[t][1]; }
-                else kd += r.end_hdr ? s_k[t][1] : s_k[t][0];      // (the part of a thread before its own first line start continues the state it inherits)
-                if (s_ls[t]) { kd += s_k[t][2]; r.has_ls = 1; r.end_hdr = s_eh[t]; }
-                r.nl += s_nl[t];
-            }
-            r.kept[0] = k0; r.kept[1] = k1; r.kept[2] = kd;
-        }
+    if ((tid & 63u) == 63u) { atomicAdd(&s_sum[0], c0); atomicAdd(&s_sum[1], c1); atomicAdd(&s_sum[2], c2); atomicAdd(&s_sum[3], c3); }
+    __syncthreads();
+    if (tid == 0) {
+        RpBlock r; r.nl = nl_total; r.kept[0] = s_sum[0]; r.kept[1] = s_sum[1]; r.kept[2] = s_sum[2]; r.kept[3] = s_sum[3];
+        r.has_ls = last != 2u ? 1u : 0u; r.end_hdr = last == 1u ? 1u : 0u; r.pad = 0;
         blk[blockIdx.x] = r;
     }
 }
 
-// one block: start state and output offset of every block (walked by one thread over LDS tiles the whole block loads); the state after
-// the chunk.  bstate[nblocks] = "the chunk's first byte starts a line"
-#define RP_SCAN_TILE 512
+// one block: start state and output offset of every block, the state after the chunk.  Thread t takes the RP_SCAN_PER consecutive
+// summaries from t * RP_SCAN_PER on (<= 2048 per chunk); three block-wide prefixes.  bstate[nblocks] = "the chunk's first byte starts a line"
+#define RP_SCAN_PER 8
 template <int FMT>
 __global__ __launch_bounds__(RP_NT) void k_rp_scan(const unsigned char* __restrict__ in, u32 n, u32 nblocks, const RpBlock* __restrict__ blk, RawState* __restrict__ st,
                                                    unsigned long long* __restrict__ boff, u32* __restrict__ bstate, unsigned char* __restrict__ out) {
-    __shared__ RpBlock s_b[RP_SCAN_TILE];
-    __shared__ unsigned long long s_o[RP_SCAN_TILE];
-    __shared__ u32 s_s[RP_SCAN_TILE];
+    __shared__ u32 s_w[RP_NT / 64];
     __shared__ RawState s;
     const u32 tid = threadIdx.x;
     if (tid == 0) {
@@ -122,30 +152,55 @@ __global__ __launch_bounds__(RP_NT) void k_rp_scan(const unsigned char* __restri
         bstate[nblocks] = s.prev_nl;
         if (FMT == RP_FASTA && n && s.prev_nl) s.hdr = rp_hdr_char(in[0]) ? 1u : 0u;      // (the chunk's first byte starts a line: k_rp_count could not see that)
     }
-    for (u32 base = 0; base < nblocks; base += RP_SCAN_TILE) {
-        const u32 cnt = nblocks - base < RP_SCAN_TILE ? nblocks - base : RP_SCAN_TILE;
-        __syncthreads();
-        for (u32 i = tid; i < cnt; i += RP_NT) s_b[i] = blk[base + i];
-        __syncthreads();
-        if (tid == 0) {
-            for (u32 b = 0; b < cnt; ++b) {
-                const RpBlock r = s_b[b];
-                s_o[b] = s.out_len;
-                if (FMT == RP_FASTQ) {
-                    s_s[b] = (u32)(s.lines & 3ull);
-                    s.out_len += r.kept[(1u - (u32)(s.lines & 3ull)) & 3u];      // relative line x is a sequence line iff (start + x) % 4 == 1
-                } else {
-                    s_s[b] = s.hdr;
-                    s.out_len += (s.hdr ? r.kept[1] : r.kept[0]) + r.kept[2];
-                    if (r.has_ls) s.hdr = r.end_hdr;
-                }
-                s.lines += r.nl;
+    __syncthreads();
+    const u32 line0 = (u32)(s.lines & 3ull), hdr0 = s.hdr;
+    const unsigned long long out0 = s.out_len;
+    RpBlock r[RP_SCAN_PER];
+    u32 mine = 0;                                        // how many of the summaries exist
+#pragma unroll
+    for (int x = 0; x < RP_SCAN_PER; ++x) {
+        const u32 b = tid * RP_SCAN_PER + x;
+        if (b < nblocks) { r[x] = blk[b]; mine = x + 1; }
+        else { r[x].nl = 0; r[x].kept[0] = r[x].kept[1] = r[x].kept[2] = r[x].kept[3] = 0; r[x].has_ls = 0; r[x].end_hdr = 0; }
+    }
+    u32 nls = 0, any = 0, endh = 0;
+#pragma unroll
+    for (int x = 0; x < RP_SCAN_PER; ++x) { nls += r[x].nl; if (r[x].has_ls) { any = 1; endh = r[x].end_hdr; } }
+    u32 nl_total = 0, lastf = 2u;
+    const u32 lbase = rp_excl_sum(nls, s_w, nl_total);                  // newlines before the thread's first block
+    u32 hstate = hdr0;
+    if (FMT == RP_FASTA) { const u32 inh = rp_last_flagged(any != 0, endh, s_w, lastf); if (inh != 2u) hstate = inh; }
+    // the blocks' start states and what each keeps
+    u32 stt[RP_SCAN_PER], kept[RP_SCAN_PER], ksum = 0;
+    {
+        u32 L = line0 + lbase, h = hstate;
+#pragma unroll
+        for (int x = 0; x < RP_SCAN_PER; ++x) {
+            if (FMT == RP_FASTQ) {
+                stt[x] = L & 3u;
+                const u32 sel = (1u - L) & 3u;                              // relative line x is a sequence line iff (start + x) % 4 == 1
+                kept[x] = sel == 0 ? r[x].kept[0] : sel == 1 ? r[x].kept[1] : sel == 2 ? r[x].kept[2] : r[x].kept[3];
+                L += r[x].nl;
+            } else {
+                stt[x] = h;
+                kept[x] = (h ? r[x].kept[1] : r[x].kept[0]) + r[x].kept[2];
+                if (r[x].has_ls) h = r[x].end_hdr;
             }
+            ksum += kept[x];
         }
-        __syncthreads();
-        for (u32 i = tid; i < cnt; i += RP_NT) { boff[base + i] = s_o[i]; bstate[base + i] = s_s[i]; }
+    }
+    u32 ktotal = 0;
+    u32 kbase = rp_excl_sum(ksum, s_w, ktotal);                          // (a chunk is <= 32 MB: 32 bits)
+#pragma unroll
+    for (int x = 0; x < RP_SCAN_PER; ++x) {
+        const u32 b = tid * RP_SCAN_PER + x;
+        if ((u32)x < mine) { boff[b] = out0 + kbase; bstate[b] = stt[x]; }
+        kbase += kept[x];
     }
     if (tid == 0) {
+        s.out_len = out0 + ktotal;
+        s.lines += nl_total;
+        if (FMT == RP_FASTA && lastf != 2u) s.hdr = lastf;
         if (n) s.prev_nl = in[n - 1] == '\n' ? 1u : 0u;
         *st = s;
     }
@@ -161,8 +216,8 @@ __global__ void k_rp_fresh(RawState* st) { st->fresh = 1; }
 template <int FMT>
 __global__ __launch_bounds__(RP_NT) void k_rp_write(const unsigned char* __restrict__ in, u32 n, const unsigned long long* __restrict__ boff,
                                                     const u32* __restrict__ bstate, RawState* __restrict__ st, unsigned char* __restrict__ out) {
-    __shared__ unsigned char stage[RP_BLOCK];
-    __shared__ u32 s_cnt[RP_NT], s_nl[RP_NT], s_ls[RP_NT], s_eh[RP_NT], s_off[RP_NT], s_start[RP_NT];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[RP_BLOCK + 16];
+    __shared__ u32 s_w[RP_NT / 64];
     const u32 tid = threadIdx.x;
     const u32 b0 = blockIdx.x * RP_BLOCK + tid * RP_BPT;
     u32 w[16];
@@ -182,21 +237,13 @@ __global__ __launch_bounds__(RP_NT) void k_rp_write(const unsigned char* __restr
             }
         }
     }
-    s_nl[tid] = nl; s_ls[tid] = has_ls; s_eh[tid] = eh;
-    __syncthreads();
-    if (tid == 0) {
-        u32 stt = bstate[blockIdx.x];            // FASTQ: line % 4 at the block's first byte; FASTA: inside a header line
-        for (u32 t = 0; t < RP_NT; ++t) {
-            s_start[t] = stt;
-            if (FMT == RP_FASTQ) stt = (stt + s_nl[t]) & 3u;
-            else if (s_ls[t]) stt = s_eh[t];
-        }
-    }
-    __syncthreads();
+    const u32 bst = bstate[blockIdx.x];                  // FASTQ: line % 4 at the block's first byte; FASTA: inside a header line
+    u32 state, tot, lastf;
+    if (FMT == RP_FASTQ) state = (bst + rp_excl_sum(nl, s_w, tot)) & 3u;
+    else { const u32 inh = rp_last_flagged(has_ls != 0, eh, s_w, lastf); state = inh == 2u ? bst : inh; }
     // count what the thread keeps, then place it
     u32 keepm[2] = {0u, 0u}, cnt = 0, bad = 0, recs = 0;           // bit i: byte i is kept
     {
-        u32 state = s_start[tid];
         unsigned char prev = prev0;
 #pragma unroll
         for (int i = 0; i < RP_BPT; ++i) {
@@ -219,20 +266,28 @@ __global__ __launch_bounds__(RP_NT) void k_rp_write(const unsigned char* __restr
             }
         }
     }
-    s_cnt[tid] = cnt;
-    __syncthreads();
-    if (tid == 0) { u32 run = 0; for (u32 t = 0; t < RP_NT; ++t) { s_off[t] = run; run += s_cnt[t]; } s_cnt[0] = run; }
-    __syncthreads();
-    const u32 total = s_cnt[0];
+    // staged at the offset the block's bytes have inside their 16-byte group of the output: whole groups then leave as 16-byte stores
+    const unsigned long long gb = boff[blockIdx.x];
+    const u32 a = (u32)(gb & 15ull);
+    u32 total = 0;
     {
-        u32 o = s_off[tid];
+        u32 o = a + rp_excl_sum(cnt, s_w, total);
 #pragma unroll
         for (int i = 0; i < RP_BPT; ++i) if ((keepm[i >> 5] >> (i & 31)) & 1u) stage[o++] = RP_BYTE(w, i);
     }
     __syncthreads();
-    unsigned char* dst = out + boff[blockIdx.x];
-    for (u32 i = tid; i < total; i += RP_NT) dst[i] = stage[i];
-    if (bad) atomicOr(&st->bad, 1u);
-    recs = wave_incl_scan(recs);            // (lane 63: the wave's sum)
-    if ((tid & 63u) == 63u && recs) atomicAdd(&st->recs, (unsigned long long)recs);
+    unsigned char* base = out + (gb - a);                     // 16-byte aligned (the stream's buffer is)
+    const u32 end = a + total, g0 = (a + 15u) >> 4, g1 = end >> 4;
+    for (u32 g = g0 + tid; g < g1; g += RP_NT) reinterpret_cast<uint4*>(base)[g] = reinterpret_cast<const uint4*>(stage)[g];
+    const u32 h_end = end < g0 * 16u ? end : g0 * 16u;          // the bytes in front of the first whole group ...
+    for (u32 i = a + tid; i < h_end; i += RP_NT) base[i] = stage[i];
+    const u32 t_beg = g1 * 16u > h_end ? g1 * 16u : h_end;      // ... and behind the last
+    for (u32 i = t_beg + tid; i < end; i += RP_NT) base[i] = stage[i];
+    // one atomic per block (8192 wave-level ones on one address were most of this kernel's time)
+    u32 rtotal = 0;
+    (void)rp_excl_sum(recs | (bad << 24), s_w, rtotal);         // (records of a block < 2^24: 16 KB of text; the bad flags ride in the top byte)
+    if (tid == 0) {
+        if (rtotal & 0xFFFFFFu) atomicAdd(&st->recs, (unsigned long long)(rtotal & 0xFFFFFFu));
+        if (rtotal >> 24) atomicOr(&st->bad, 1u);
+    }
 }
