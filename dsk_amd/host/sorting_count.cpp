@@ -144,7 +144,17 @@ void SortingCountBase::execute() {
         const std::string stem = gz ? f.substr(0, f.size() - 3) : f;
         const bool fq = (stem.size() > 6 && stem.compare(stem.size() - 6, 6, ".fastq") == 0) || (stem.size() > 3 && stem.compare(stem.size() - 3, 3, ".fq") == 0);
         std::unique_ptr<IBank> one(Bank::open(f));
-        const uint64_t b = one->getSize() * (gz ? 4 : 1);
+        uint64_t b = one->getSize() * (gz ? 4 : 1);
+        if (gz) {      // a gzip member's trailer holds its inflated size (mod 2^32): exact for an ordinary one-member file below 4 GB, a lower bound with several members
+            if (FILE* fp = fopen(f.c_str(), "rb")) {
+                unsigned char t[4];
+                if (fseek(fp, -4, SEEK_END) == 0 && fread(t, 1, 4, fp) == 4) {
+                    const uint64_t isize = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
+                    if (isize > b && isize < one->getSize() * 1100) b = isize + (isize >> 6);      // (deflate does not exceed ~1030 : 1)
+                }
+                fclose(fp);
+            }
+        }
         hint += b; seq_hint += fq ? b / 2 : b;
     }
     struct Startup {
@@ -172,7 +182,9 @@ void SortingCountBase::execute() {
     // (r05, measured and dropped: keeping what the parser threads produce before the engine is up in a host-side list -- so that the parse
     //  hides behind the device start-up -- costs a copy of every chunk under the sink's mutex: 0.1 s MORE on the 3 GB FASTQ file.)
     bool pushing = false;
-    auto push = [&](const char* d, size_t n) { if (!pushing) { startup.wait_push(); pushing = true; } be->push(d, n); nbytes += n; };      // (callers serialise the sink)
+    double t_first_push = 0, t_wait_engine = 0, t_in_push = 0;       // when the first chunk was ready (since t1), how long it waited for the engine, time inside the engine's push calls
+    auto gate = [&]() { if (!pushing) { const double a = now_s(); t_first_push = a - t1; startup.wait_push(); t_wait_engine = now_s() - a; pushing = true; } };
+    auto push = [&](const char* d, size_t n) { gate(); const double a = now_s(); be->push(d, n); t_in_push += now_s() - a; nbytes += n; };      // (callers serialise the sink)
     // chunk handed to the sink: a parser thread fills its own buffer of this size, so 32 threads first-touch 32 of them (64 MB chunks: 2 GB
     // of fresh pages for a 1.5 GB stream); small chunks stop the threads early while the engine starts up.  DSK_CHUNK_MB: experiments.
     size_t chunk_bytes = (size_t)8 << 20;        // (measured on the 3 GB FASTQ file, time from "engine up" to "all reads on the device": 8 MB 0.09 s, 16 MB 0.11, 32 MB 0.17, 64 MB 0.13)
@@ -190,8 +202,10 @@ void SortingCountBase::execute() {
             if (dev_parse) {
                 const uint64_t before = nbytes;
                 auto rawsink = [&](const char* d, size_t n, int fmt, bool nf) {
-                    if (!pushing) { startup.wait_push(); pushing = true; }
+                    gate();
+                    const double a = now_s();
                     if (!be->pushRaw(d, n, fmt, nf)) throw Exception("the engine does not parse on the device");
+                    t_in_push += now_s() - a;
                     raw_text_bytes += n;
                 };
                 if (sub->streamRaw(rawsink)) {
@@ -201,7 +215,7 @@ void SortingCountBase::execute() {
                 }
             }
             if (!raw_done) nseq += sub->stream(chunk_bytes, push);
-            if (!pushing) { startup.wait_push(); pushing = true; }
+            gate();
             be->nextBank();
         }
     } else {                                     // plain sum: inflate / parse the files concurrently (host thread pool)
@@ -338,6 +352,9 @@ void SortingCountBase::execute() {
     info_.add(1, "time");
     info_.add(2, "setup_s", "%.3f", t1 - t0);
     info_.add(2, "ingest_s", "%.3f", t2 - t1);
+    info_.add(3, "first_chunk_ready_s", "%.3f", t_first_push);
+    info_.add(3, "waited_for_engine_s", "%.3f", t_wait_engine);
+    info_.add(3, "inside_push_calls_s", "%.3f", t_in_push);
     info_.add(3, "engine_startup_s", "%.3f", startup.t_cfg);
     info_.add(3, "reserve_reads_s", "%.3f", startup.t_res);
     info_.add(3, "reserve_work_s", "%.3f", startup.t_prep);
