@@ -191,7 +191,7 @@ def e2e_block(k, amin, budget_s=150.0):
     t_start = time.perf_counter()
     tmp = tempfile.mkdtemp(prefix="dsk_e2e_")
     dev = torch.device("cuda", 0)
-    out = {"note": "wall clock of the dsk binary, file -> .h5 (HIP runtime start-up, ingest, count, HDF5 write), best of 3, page cache warm"}
+    out = {"note": "wall clock of the dsk binary, file -> .h5 (HIP runtime start-up, ingest, count, HDF5 write), best of 3 runs 0.4 s apart, page cache warm"}
 
     def run_dsk(path, extra=()):
         best, info = None, {}
@@ -199,6 +199,7 @@ def e2e_block(k, amin, budget_s=150.0):
             for stale in (os.path.join(tmp, "o.h5"),):          # (a fresh output every time: truncating the previous run's 0.7 GB file is not part of a run)
                 if os.path.exists(stale):
                     os.remove(stale)
+            time.sleep(0.4)          # (the driver takes the previous process's device context apart for up to 0.1 s after its exit, and the next start-up waits for it: runs are timed apart, as single invocations)
             t0 = time.perf_counter()
             p = subprocess.run([dsk, "-file", path, "-kmer-size", str(k), "-abundance-min", str(amin), "-out", os.path.join(tmp, "o"), "-verbose", "1", *extra],
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
