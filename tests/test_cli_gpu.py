@@ -195,10 +195,11 @@ def test_device_parse_through_the_binary(bins, tmp_path, oracle, monkeypatch):
     (DSKGPU_E_FORMAT) and the host parser then takes -- same totals either way."""
     import re
     import numpy as np
-    from tests.test_host_cli import make_messy_inputs, run_messy_case, run_six_cases
+    from tests.test_host_cli import make_messy_inputs, run_messy_case, run_six_cases, run_solidity_cases
     monkeypatch.setenv("DSK_DEVICE_PARSE", "1")
     tmp = str(tmp_path)
     run_six_cases(bins["dsk"], bins["dsk2ascii"], tmp)
+    run_solidity_cases(bins["dsk"], bins["dsk2ascii"], tmp, oracle)          # per-bank modes: every bank's text parsed on the device, bank ends where the text ends
     n_reads = 25_000
     clean = make_messy_inputs(tmp, n_reads, 60_000)
     ref = oracle.count(clean, 31)
