@@ -3273,8 +3273,7 @@ int dskgpu_create(const dskgpu_config* cfg, dskgpu_ctx** out) {
         ctx->sk_sp.m = std::min<u32>(std::min<u32>(ctx->cfg.minimizer_size, 16u), cfg->kmer_size - 15u);
         ctx->sk_sp.R = sk_record_words(cfg->kmer_size);
     }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) ctx->num_cu = cus; }      // (one attribute, not the whole property block)
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_create_err = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete ctx; return DSKGPU_E_DEVICE; }
     ctx->own_stream = true;
