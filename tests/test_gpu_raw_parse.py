@@ -212,6 +212,36 @@ def test_the_reference_fixtures_as_raw_text(oracle, golden_dir, dev):
         assert (hist == ref.histogram(10000)).all(), name
 
 
+def test_raw_pushes_that_outgrow_the_stream_buffer(dev):
+    """No reservation, 330 MB of FASTQ text in uneven pieces: the stream's buffer (256 MB at first) is grown while parsed text is
+    already in it and kernels of earlier pieces may still be running -- same rows as the clean stream handed over in HBM."""
+    from dsk_amd import KmerCounter, synth
+    nr, rl = 1_600_000, 100
+    reads_t = synth.make_reads(synth.make_genome(2_000_000, dev), nr, rl)
+    reads = reads_t.cpu().numpy().reshape(nr, rl + 1)
+    rec = np.empty((nr, 2 * rl + 7), dtype=np.uint8)
+    rec[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+    rec[:, 3: 3 + rl] = reads[:, :rl]
+    rec[:, 3 + rl: 6 + rl] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, 6 + rl: 6 + 2 * rl] = ord("I")
+    rec[:, 6 + 2 * rl] = ord("\n")
+    text = rec.reshape(-1)
+    assert text.size > 330_000_000
+    with KmerCounter(kmer_size=31, abundance_min=2) as kc:
+        kc.set_reads_device(reads_t.data_ptr(), reads_t.numel())
+        kc.count()
+        want = (kc.rows(), kc.stats()["n_kmers"], kc.histogram())
+    with KmerCounter(kmer_size=31, abundance_min=2) as kc:
+        cuts = [0, 100_000_003, 100_000_004, 260_000_000, 260_000_001, text.size]          # (the buffer grows at the third and at the last piece)
+        for i in range(len(cuts) - 1):
+            kc.push_raw(text[cuts[i]: cuts[i + 1]], kc.RAW_FASTQ, new_file=i == 0)
+        nbytes, recs = kc.raw_finish()
+        assert nbytes == nr * (rl + 1) + 1 and recs == nr
+        kc.count()
+        rows, ab = kc.rows()
+        assert kc.stats()["n_kmers"] == want[1] and (rows == want[0][0]).all() and (ab == want[0][1]).all() and (kc.histogram() == want[2]).all()
+
+
 def test_raw_text_beyond_the_staging_chunk(oracle, dev):
     """90 MB of FASTQ text in three pushes (pieces of 32 MB inside a push, 2048 blocks per piece): the count of the clean stream."""
     from dsk_amd import KmerCounter, synth
