@@ -16,7 +16,8 @@
  * of [ACGTacgt] is one sequence fragment; ANY other byte (N, IUPAC codes,
  * '\n' between reads) ends the current k-mer window (test/readN.fasta +
  * test/readN.histo).  A bank front-end therefore only has to concatenate the
- * sequence lines of its records separated by one non-ACGT byte.
+ * sequence lines of its records separated by one non-ACGT byte -- or hand over
+ * the file's text as it is and let the device do that (dskgpu_push_raw).
  *
  * K-mer value convention (README.md:104-112, utils/dsk2ascii.cpp:104): A=0,
  * C=1, T=2, G=3, first base most significant; canonical = min(fwd, revcomp).
