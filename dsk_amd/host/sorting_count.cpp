@@ -241,8 +241,15 @@ void SortingCountBase::execute() {
     }
     startup.wait_done();
     const double t2 = now_s();
+    const bool phase_rss = getenv("DSK_PHASE_TIMES") != nullptr;
+    auto rss = [&](const char* what) {       // (DSK_PHASE_TIMES: anonymous memory of the process after each phase -- what the kernel has to take apart after exit)
+        if (!phase_rss) return;
+        if (FILE* f = fopen("/proc/self/status", "r")) { char line[256]; while (fgets(line, sizeof line, f)) if (!strncmp(line, "RssAnon", 7)) fprintf(stderr, "[dsk] after %s: %s", what, line); fclose(f); }
+    };
+    rss("ingest");
     be->finish();
     const double t3 = now_s();
+    rss("count");
 
     be->histogram(histo_);
     unsigned cutoff = 0, firstPeak = 0;
@@ -310,6 +317,7 @@ void SortingCountBase::execute() {
     Group& dg = storage_->getGroup("dsk");
     dg.setProperty("kmer_size", std::to_string(k));
     const double t4 = now_s();
+    rss("write");
 
     if (cfg.histo2d) {   // README.md:98-102, utils/plot-histo2D.R:22-30: rows = abundance in the reads, columns = in the genome (0..10)
         std::vector<uint64_t> h2;
