@@ -233,7 +233,7 @@ struct dskgpu_ctx {
     DevBuf smp_mat, smp_descs, boff;   // sampled level-1 loads: chunk x bin matrix of the sample tiles, their descriptors; per-bin slice offsets
     DevBuf dbg, l0buf; DevBuf hv_lut, hv_collect, hv_buf; // heavy k-mers: bin -> collect slot, collected sample keys; [keys | counts | rows] of the k-mers counted apart
     std::vector<unsigned char> h_hv_lut; std::vector<u32> h_hv_cnt, h_hv_step; std::vector<u64> h_hv_coll, h_hv_keys;
-    std::vector<ChunkDesc> h_descs_s; std::vector<u32> h_boff; std::vector<u64> h_mom; std::vector<double> h_load, h_spread, h_seg_work;
+    std::vector<ChunkDesc> h_descs_s; std::vector<u64> h_cbeg; std::vector<u32> h_boff; std::vector<u64> h_mom; std::vector<double> h_load, h_spread, h_seg_work;
     DevBuf out_w[4], srt_w[4], acc_w[4];   // rows as struct-of-arrays: word i of every row in [i]
     DevBuf out_ab, srt_ab, srt_tmp, srt_idx, srt_idx2, srt_k, srt_k2, abund2, acc_ab;   // srt_k2: one record per row for the multi-word gather
     u64 max_keys_per_pass = 0;     // 0 = as many as 32-bit offsets allow
@@ -1771,7 +1771,8 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                 if (nchk == 0) rec_sample_ok = false;
                 else {
                     { const int e = rec_gate_upto(ctx, 1); if (e) return e; }
-                    std::vector<u64> cbeg(nchk);
+                    std::vector<u64>& cbeg = ctx->h_cbeg;        // (the context's: it outlives the asynchronous copy below; the next use is behind this pass's next synchronisation)
+                    cbeg.resize(nchk);
                     for (u64 i = 0; i < nchk; ++i) cbeg[i] = (i * nchk_all / nchk) * NR;
                     rec_units = nchk * NR * SK_MAXN;
                     CK(ctx->smp_keys.ensure(rec_units * sizeof(Key) + nchk * 8 + 64));
@@ -1780,7 +1781,6 @@ int run_one_pass(dskgpu_ctx* ctx, bool from_reads, const typename KeyT<W>::T* d_
                     hipLaunchKernelGGL(k_sk_sample_keys<W>, dim3((unsigned)nchk), dim3(SKX_NT), 0, ctx->stream, ctx->rec_src, ctx->rec_n, ctx->sk_sp.R, (int)ctx->cfg.kmer_size,
                                        (const u64*)d_cbeg, (u32)NR, ctx->smp_keys.as<Key>());
                     CKL("k_sk_sample_keys");
-                    CK(hipStreamSynchronize(ctx->stream));      // (cbeg is a local)
                     d_keys_s = ctx->smp_keys.as<Key>();
                 }
               }
