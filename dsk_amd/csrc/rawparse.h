@@ -285,9 +285,10 @@ __global__ __launch_bounds__(RP_NT) void k_rp_write(const unsigned char* __restr
     for (u32 i = t_beg + tid; i < end; i += RP_NT) base[i] = stage[i];
     // one atomic per block (8192 wave-level ones on one address were most of this kernel's time)
     u32 rtotal = 0;
-    (void)rp_excl_sum(recs | (bad << 24), s_w, rtotal);         // (records of a block < 2^24: 16 KB of text; the bad flags ride in the top byte)
+    (void)rp_excl_sum(recs, s_w, rtotal);
+    const int any_bad = __syncthreads_or((int)bad);
     if (tid == 0) {
-        if (rtotal & 0xFFFFFFu) atomicAdd(&st->recs, (unsigned long long)(rtotal & 0xFFFFFFu));
-        if (rtotal >> 24) atomicOr(&st->bad, 1u);
+        if (rtotal) atomicAdd(&st->recs, (unsigned long long)rtotal);
+        if (any_bad) atomicOr(&st->bad, 1u);
     }
 }

@@ -186,7 +186,8 @@ def test_text_the_device_parser_does_not_handle_is_reported(oracle, dev):
     fasta = make_fasta(rng, 20, 100, 500)
     keep = host_records(good, "fq")
     ref = oracle.count(np.frombuffer(keep + keep, dtype=np.uint8), 21)
-    for bad in (wrapped, blanks, fasta):
+    junk = b"\n".join(b"x" * 7 for _ in range(40000)) + b"\n"          # every thread of every block sees lines that are no FASTQ
+    for bad in (wrapped, blanks, fasta, junk):
         with KmerCounter(kmer_size=21, abundance_min=1) as kc:
             kc.push_reads(keep)
             kc.push_raw(good, kc.RAW_FASTQ, new_file=True)
