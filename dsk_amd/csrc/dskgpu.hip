@@ -3219,6 +3219,7 @@ __attribute__((visibility("hidden"))) int dskgpu_i_banks_finish(dskgpu_ctx* ctx)
 }
 
 // =============================================================== C-ABI
+static_assert(((size_t)32 << 20) / RP_BLOCK <= (size_t)RP_NT * RP_SCAN_PER, "k_rp_scan walks the block summaries of one staging piece (PIN_CHUNK) with RP_SCAN_PER per thread");
 template <int FMT>
 static void launch_raw_chunk(dskgpu_ctx* ctx, u32 n, uint8_t* out) {
     const u32 nb = (n + RP_BLOCK - 1) / RP_BLOCK;
@@ -3318,6 +3319,7 @@ int dskgpu_set_stream(dskgpu_ctx* ctx, void* hip_stream) {
 }
 
 #define PIN_CHUNK ((size_t)32 << 20)
+static_assert(PIN_CHUNK == ((size_t)32 << 20), "launch_raw_chunk's capacity check is written for 32 MB pieces");
 // pageable -> pinned: one thread copies ~10 GB/s on the host this was measured on, the link takes 55: big pieces are copied by up to eight (a memory-mapped file's pages are also faulted in by the copy)
 static void stage_copy(void* dst, const void* src, size_t n) {
     const unsigned T = n >= ((size_t)16 << 20) ? 8u : n >= ((size_t)8 << 20) ? 4u : n >= ((size_t)2 << 20) ? 2u : 1u;
