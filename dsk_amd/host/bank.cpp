@@ -139,6 +139,10 @@ static unsigned pgz_threads(unsigned nthreads, unsigned hw) {
     return std::min(std::max(nthreads, std::min(hw, cap)), cap);
 }
 
+// gzread returns 0 at a premature end of a gzip stream exactly as at its real end; only gzerror tells them apart (Z_BUF_ERROR: the
+// file ended in the middle of a stream, Z_DATA_ERROR: corrupt).  A truncated download must not count as a smaller input.
+static bool gz_ended_badly(gzFile f) { int err = Z_OK; (void)gzerror(f, &err); return err == Z_BUF_ERROR || err == Z_DATA_ERROR; }
+
 class BankFasta : public IBank {
 public:
     explicit BankFasta(const std::string& path) : path_(path) {
@@ -221,6 +225,7 @@ public:
                                 if (got == 0) break;
                                 hand_on(raw.data(), (size_t)got);
                             }
+                            if (gz_ended_badly(f)) throw Exception("truncated or corrupt gzip file '%s'", path_.c_str());
                         } catch (...) { gzclose(f); throw; }
                         gzclose(f);
                         ok = !first;
@@ -250,7 +255,9 @@ private:
             if (got == 0) break;
             ps.feed(raw.data(), (size_t)got);
         }
+        const bool bad_end = gz_ended_badly(f);
         gzclose(f);
+        if (bad_end) throw Exception("truncated or corrupt gzip file '%s'", path_.c_str());
         ps.finish();
         return ps.nseq;
     }
@@ -476,7 +483,7 @@ private:
                 const size_t slot = produced % NB;
                 const int got = gzread(f, bufs[slot].data(), (unsigned)BUF);
                 std::lock_guard<std::mutex> g(mu);
-                if (got <= 0) { failed = got < 0; done = true; cv.notify_all(); return; }
+                if (got <= 0) { failed = got < 0 || gz_ended_badly(f); done = true; cv.notify_all(); return; }
                 len[slot] = got; ++produced; cv.notify_all();
             }
         });
@@ -490,7 +497,7 @@ private:
             }
             producer.join();
             gzclose(f);
-            if (failed) throw Exception("read error in file '%s'", path_.c_str());
+            if (failed) throw Exception("read error, truncated or corrupt gzip file '%s'", path_.c_str());
             ps.finish();
         } catch (...) {                                // the sink threw: stop the inflate thread before this frame goes away
             if (producer.joinable()) { { std::lock_guard<std::mutex> g(mu); cancel = true; } cv.notify_all(); producer.join(); gzclose(f); }

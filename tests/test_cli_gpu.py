@@ -206,6 +206,14 @@ def test_device_parse_through_the_binary(bins, tmp_path, oracle, monkeypatch):
     want = (ref.total, ref.distinct, int((ref.ab >= 3).sum()), ref.histogram(10000))
     run_messy_case(bins["dsk"], tmp, n_reads, want, {"DSK_DEVICE_PARSE": "1"})
     run_messy_case(bins["dsk"], tmp, n_reads, want, {"DSK_DEVICE_PARSE": "1", "DSK_PGZIP_CHUNK_BYTES": "65536"})       # the gzip file through the parallel inflate
+    # a gzip file cut short is an error on this path too (one zlib stream and the parallel inflate)
+    import gzip
+    z = gzip.compress(open(os.path.join(tmp, "messy.fa"), "rb").read(), 6)
+    open(os.path.join(tmp, "cut.fa.gz"), "wb").write(z[: len(z) // 2])
+    for env in ({}, {"DSK_PGZIP_CHUNK_BYTES": "65536"}):
+        r = subprocess.run([bins["dsk"], "-file", "cut.fa.gz", "-kmer-size", "31", "-out", "c", "-device-parse", "1"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 1 and b"EXCEPTION" in r.stderr, r.stderr[-300:]
     # wrapped FASTQ: given back, parsed on the host
     rng = np.random.default_rng(4)
     seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 120)) for _ in range(2000)]

@@ -254,6 +254,22 @@ def test_error_paths(bins, tmp_path):
     assert r.returncode == 1 and r.stdout.startswith(b"EXCEPTION: ")           # utils/dsk2ascii.cpp:129-133 (stdout)
     r = subprocess.run([bins["dsk"], "-help"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0 and b"-kmer-size" in r.stdout
+    # a gzip file cut short (an interrupted download) is an error, not a smaller input: small (one zlib stream, serial and with the
+    # inflate thread) and large enough for the parallel inflate (its chunks end where the file does)
+    import gzip
+    import numpy as np
+    rng = np.random.default_rng(8)
+    recs = b"".join(b">s%d\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 200)) + b"\n" for i in range(30000))
+    z = gzip.compress(recs, 6)
+    for cut, env in ((len(z) // 2, {}), (len(z) // 2, {"DSK_PGZIP_CHUNK_BYTES": "65536"}), (len(z) - 5, {}), (len(z) - 5, {"DSK_PGZIP_CHUNK_BYTES": "65536"})):
+        open(os.path.join(tmp, "cut.fa.gz"), "wb").write(z[:cut])
+        for cores in ("1", "4"):
+            r = subprocess.run([bins["dsk"], "-file", "cut.fa.gz", "-kmer-size", "21", "-out", "c", "-nb-cores", cores], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               env=dict(os.environ, **env))
+            assert r.returncode == 1 and b"EXCEPTION" in r.stderr, (cut, env, cores, r.stderr[-300:])
+    open(os.path.join(tmp, "whole.fa.gz"), "wb").write(z)
+    r = subprocess.run([bins["dsk"], "-file", "whole.fa.gz", "-kmer-size", "21", "-out", "c", "-verbose", "0"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
 
 
 def test_dsk2ascii_variants(bins, tmp_path):
