@@ -3391,6 +3391,7 @@ static int raw_finish(dskgpu_ctx* ctx, u64* lines) {
     CK(hipStreamSynchronize(ctx->stream));
     ctx->raw_pending = false;
     uint8_t* dst = ctx->reads_own.as<uint8_t>();
+    if (!rp_file_ok(s)) s.bad = 1;      // (the last file, now that it is complete: its quality lines must add up to its sequence lines)
     if (s.bad) {             // the text is not what the device parser handles: the raw pushes are dropped, the stream is what it was before them
         ctx->reads_len = ctx->raw_base;
         ctx->d_reads = dst; ctx->n_bytes = ctx->reads_len;

@@ -9,6 +9,8 @@
 //          which line a byte lies on is a prefix count of '\n'.  Line 0 of a record must start with '@', line 2 with '+': anything
 //          else (a FASTQ whose sequences are wrapped over several lines) raises RawState::bad and the host falls back to its parser.
 //          (A quality line that starts with '@' or '>' is no problem here: lines are classified by their NUMBER, not their first byte.)
+//          A host parser reads as many quality characters as the record has bases (host/bank.cpp RecordParser, kseq): a file whose
+//          quality lines do not add up to its sequence lines would be read differently there -- it is given back as well (rp_file_ok).
 //   FASTA  a line that starts with '>' is a header: dropped but for its '\n', which separates the records; the bytes of all
 //          other lines are kept except '\n', '\r', ' ' and '\t', so that a sequence wrapped over lines is one run of bases (test/longread.fasta).
 // The state between chunks -- lines so far, "inside a header line", "the next byte starts a line", bytes written -- lives on the device
@@ -26,11 +28,18 @@
 #define RP_FASTA 1
 #define RP_FASTQ 2
 
-struct RawState { unsigned long long lines, out_len, recs; u32 hdr, bad, prev_nl, fresh; };      // lines: of the current file; recs: records (header lines) since the raw pushes began      // fresh: a new file starts with the next chunk
+struct RawState { unsigned long long lines, out_len, recs, seqb, qualb; u32 hdr, bad, prev_nl, fresh, fq, pad; };      // seqb / qualb: bytes on the sequence / quality lines of the current FASTQ file (fq): they must agree      // lines: of the current file; recs: records (header lines) since the raw pushes began      // fresh: a new file starts with the next chunk
 // what a block tells: newlines; FASTQ: kept bytes by (start line % 4); FASTA: kept[start in header ? 1 : 0], has a line start, header state at its end
 struct RpBlock { u32 nl; u32 kept[4]; u32 has_ls, end_hdr, pad; };
 
-__device__ __forceinline__ bool rp_hdr_char(unsigned char c) { return c == '>'; }
+__host__ __device__ __forceinline__ bool rp_hdr_char(unsigned char c) { return c == '>'; }
+// a FASTQ file at its end: as many characters on its quality lines as on its sequence lines.  seqb / qualb count the lines' '\n' too
+// (they are what is kept): of the `lines` newlines so far, those that end a line with index % 4 == c number (lines - c + 3) / 4
+__host__ __device__ __forceinline__ bool rp_file_ok(const RawState& s) {
+    if (!s.fq) return true;
+    const unsigned long long n1 = (s.lines + 2ull) / 4ull, n3 = s.lines / 4ull;
+    return s.seqb - n1 == s.qualb - n3;
+}
 __device__ __forceinline__ bool rp_blank(unsigned char c) { return c == '\n' || c == '\r' || c == ' ' || c == '\t'; }      // what the host parser drops from a sequence line (host/bank.cpp append_seq)
 
 // the thread's 64 bytes as 16 words (bytes past the end of the chunk read as '\n'); -> how many of them exist
@@ -146,8 +155,9 @@ __global__ __launch_bounds__(RP_NT) void k_rp_scan(const unsigned char* __restri
     if (tid == 0) {
         s = *st;
         if (s.fresh) {                                   // a new file: its first byte starts a line; a separator behind what came before
+            if (!rp_file_ok(s)) s.bad = 1;               // (the file before it, now that it is complete)
             if (s.out_len) out[s.out_len++] = '\n';
-            s.lines = 0; s.hdr = 0; s.prev_nl = 1; s.fresh = 0;
+            s.lines = 0; s.hdr = 0; s.prev_nl = 1; s.fresh = 0; s.seqb = 0; s.qualb = 0; s.fq = FMT == RP_FASTQ ? 1u : 0u;
         }
         bstate[nblocks] = s.prev_nl;
         if (FMT == RP_FASTA && n && s.prev_nl) s.hdr = rp_hdr_char(in[0]) ? 1u : 0u;      // (the chunk's first byte starts a line: k_rp_count could not see that)
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(RP_NT) void k_rp_scan(const unsigned char* __restri
     u32 hstate = hdr0;
     if (FMT == RP_FASTA) { const u32 inh = rp_last_flagged(any != 0, endh, s_w, lastf); if (inh != 2u) hstate = inh; }
     // the blocks' start states and what each keeps
-    u32 stt[RP_SCAN_PER], kept[RP_SCAN_PER], ksum = 0;
+    u32 stt[RP_SCAN_PER], kept[RP_SCAN_PER], ksum = 0, qsum = 0;      // qsum: bytes on quality lines (FASTQ)
     {
         u32 L = line0 + lbase, h = hstate;
 #pragma unroll
@@ -180,6 +190,8 @@ __global__ __launch_bounds__(RP_NT) void k_rp_scan(const unsigned char* __restri
                 stt[x] = L & 3u;
                 const u32 sel = (1u - L) & 3u;                              // relative line x is a sequence line iff (start + x) % 4 == 1
                 kept[x] = sel == 0 ? r[x].kept[0] : sel == 1 ? r[x].kept[1] : sel == 2 ? r[x].kept[2] : r[x].kept[3];
+                const u32 selq = (3u - L) & 3u;
+                qsum += selq == 0 ? r[x].kept[0] : selq == 1 ? r[x].kept[1] : selq == 2 ? r[x].kept[2] : r[x].kept[3];
                 L += r[x].nl;
             } else {
                 stt[x] = h;
@@ -197,8 +209,11 @@ __global__ __launch_bounds__(RP_NT) void k_rp_scan(const unsigned char* __restri
         if ((u32)x < mine) { boff[b] = out0 + kbase; bstate[b] = stt[x]; }
         kbase += kept[x];
     }
+    u32 qtotal = 0;
+    if (FMT == RP_FASTQ) (void)rp_excl_sum(qsum, s_w, qtotal);
     if (tid == 0) {
         s.out_len = out0 + ktotal;
+        s.seqb += ktotal; s.qualb += qtotal;
         s.lines += nl_total;
         if (FMT == RP_FASTA && lastf != 2u) s.hdr = lastf;
         if (n) s.prev_nl = in[n - 1] == '\n' ? 1u : 0u;
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(RP_NT) void k_rp_scan(const unsigned char* __restri
 
 // (a context's first raw push, or one behind dskgpu_push_reads: the stream so far is `out_len` bytes)
 __global__ void k_rp_init(RawState* st, unsigned long long out_len) {
-    RawState s; s.lines = 0; s.out_len = out_len; s.recs = 0; s.hdr = 0; s.bad = 0; s.prev_nl = 1; s.fresh = 1;
+    RawState s; s.lines = 0; s.out_len = out_len; s.recs = 0; s.seqb = 0; s.qualb = 0; s.hdr = 0; s.bad = 0; s.prev_nl = 1; s.fresh = 1; s.fq = 0; s.pad = 0;
     *st = s;
 }
 __global__ void k_rp_fresh(RawState* st) { st->fresh = 1; }

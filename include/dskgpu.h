@@ -121,7 +121,8 @@ int dskgpu_push_reads(dskgpu_ctx* ctx, const char* bytes, uint64_t nbytes);
  * Asynchronous like dskgpu_push_reads: nothing is known about the result until something needs the stream's length -- every
  * call that reads the reads (dskgpu_count, dskgpu_encode_reads, dskgpu_mg_*, dskgpu_next_bank, dskgpu_push_reads) first does
  * what dskgpu_raw_finish does.  A text the device parser does not handle (a FASTQ file with sequences wrapped over several
- * lines or blanks inside them, text that is neither format) is DETECTED, never mis-parsed: dskgpu_raw_finish returns
+ * lines or blanks inside them, one whose quality lines do not add up to its sequence lines -- a host parser reads as many
+ * quality characters as the record has bases --, text that is neither format) is DETECTED, never mis-parsed: dskgpu_raw_finish returns
  * DSKGPU_E_FORMAT and the stream is what it was before the raw pushes -- the caller parses on the host and pushes the reads. */
 #define DSKGPU_RAW_FASTA 1
 #define DSKGPU_RAW_FASTQ 2
