@@ -10,8 +10,9 @@
 //          else (a FASTQ whose sequences are wrapped over several lines) raises RawState::bad and the host falls back to its parser.
 //          (A quality line that starts with '@' or '>' is no problem here: lines are classified by their NUMBER, not their first byte.)
 //          A host parser reads as many quality characters as the record has bases (host/bank.cpp RecordParser, kseq): a file whose
-//          quality lines do not add up to its sequence lines would be read differently there -- it is given back as well (rp_file_ok).
-//   FASTA  a line that starts with '>' is a header: dropped but for its '\n', which separates the records; the bytes of all
+//          quality line is not as long as its sequence line would be read differently there -- it is given back as well (rp_file_ok).
+//   FASTA  a line that starts with '>' is a header: dropped but for its '\n', which separates the records (a line that starts with
+//          '@' or '+' -- FASTQ records in the same file -- raises RawState::bad); the bytes of all
 //          other lines are kept except '\n', '\r', ' ' and '\t', so that a sequence wrapped over lines is one run of bases (test/longread.fasta).
 // The state between chunks -- lines so far, "inside a header line", "the next byte starts a line", bytes written -- lives on the device
 // (RawState): no round trip per chunk.
@@ -28,18 +29,16 @@
 #define RP_FASTA 1
 #define RP_FASTQ 2
 
-struct RawState { unsigned long long lines, out_len, recs, seqb, qualb; u32 hdr, bad, prev_nl, fresh, fq, pad; };      // seqb / qualb: bytes on the sequence / quality lines of the current FASTQ file (fq): they must agree      // lines: of the current file; recs: records (header lines) since the raw pushes began      // fresh: a new file starts with the next chunk
+struct RawState { unsigned long long lines, out_len, recs, chk; u32 hdr, bad, prev_nl, fresh, fq, pad; };      // chk: FASTQ, sum over the records of w(record) * (sequence characters - quality characters): 0 iff every record has as many of one as of the other      // lines: of the current file; recs: records (header lines) since the raw pushes began      // fresh: a new file starts with the next chunk
 // what a block tells: newlines; FASTQ: kept bytes by (start line % 4); FASTA: kept[start in header ? 1 : 0], has a line start, header state at its end
 struct RpBlock { u32 nl; u32 kept[4]; u32 has_ls, end_hdr, pad; };
 
 __host__ __device__ __forceinline__ bool rp_hdr_char(unsigned char c) { return c == '>'; }
-// a FASTQ file at its end: as many characters on its quality lines as on its sequence lines.  seqb / qualb count the lines' '\n' too
-// (they are what is kept): of the `lines` newlines so far, those that end a line with index % 4 == c number (lines - c + 3) / 4
-__host__ __device__ __forceinline__ bool rp_file_ok(const RawState& s) {
-    if (!s.fq) return true;
-    const unsigned long long n1 = (s.lines + 2ull) / 4ull, n3 = s.lines / 4ull;
-    return s.seqb - n1 == s.qualb - n3;
-}
+// a FASTQ file at its end: every record has as many quality characters as bases.  Checked without pairing lines: every character of
+// a sequence line adds w(record), every character of a quality line subtracts it, w = a 64-bit mix of the record's number -- the sum
+// over the file is 0 iff the records balance one by one (two records that are off by +1 and -1 do not cancel)
+__host__ __device__ __forceinline__ unsigned long long rp_weight(u32 rec) { return kmix((unsigned long long)rec + 0x9e3779b97f4a7c15ULL) | 1ull; }
+__host__ __device__ __forceinline__ bool rp_file_ok(const RawState& s) { return !s.fq || s.chk == 0ull; }
 __device__ __forceinline__ bool rp_blank(unsigned char c) { return c == '\n' || c == '\r' || c == ' ' || c == '\t'; }      // what the host parser drops from a sequence line (host/bank.cpp append_seq)
 
 // the thread's 64 bytes as 16 words (bytes past the end of the chunk read as '\n'); -> how many of them exist
@@ -157,13 +156,13 @@ __global__ __launch_bounds__(RP_NT) void k_rp_scan(const unsigned char* __restri
         if (s.fresh) {                                   // a new file: its first byte starts a line; a separator behind what came before
             if (!rp_file_ok(s)) s.bad = 1;               // (the file before it, now that it is complete)
             if (s.out_len) out[s.out_len++] = '\n';
-            s.lines = 0; s.hdr = 0; s.prev_nl = 1; s.fresh = 0; s.seqb = 0; s.qualb = 0; s.fq = FMT == RP_FASTQ ? 1u : 0u;
+            s.lines = 0; s.hdr = 0; s.prev_nl = 1; s.fresh = 0; s.chk = 0; s.fq = FMT == RP_FASTQ ? 1u : 0u;
         }
         bstate[nblocks] = s.prev_nl;
         if (FMT == RP_FASTA && n && s.prev_nl) s.hdr = rp_hdr_char(in[0]) ? 1u : 0u;      // (the chunk's first byte starts a line: k_rp_count could not see that)
     }
     __syncthreads();
-    const u32 line0 = (u32)(s.lines & 3ull), hdr0 = s.hdr;
+    const u32 line0 = (u32)s.lines, hdr0 = s.hdr;      // (line numbers travel as their low 32 bits: the record weights repeat after 2^34 lines)
     const unsigned long long out0 = s.out_len;
     RpBlock r[RP_SCAN_PER];
     u32 mine = 0;                                        // how many of the summaries exist
@@ -181,17 +180,15 @@ __global__ __launch_bounds__(RP_NT) void k_rp_scan(const unsigned char* __restri
     u32 hstate = hdr0;
     if (FMT == RP_FASTA) { const u32 inh = rp_last_flagged(any != 0, endh, s_w, lastf); if (inh != 2u) hstate = inh; }
     // the blocks' start states and what each keeps
-    u32 stt[RP_SCAN_PER], kept[RP_SCAN_PER], ksum = 0, qsum = 0;      // qsum: bytes on quality lines (FASTQ)
+    u32 stt[RP_SCAN_PER], kept[RP_SCAN_PER], ksum = 0;
     {
         u32 L = line0 + lbase, h = hstate;
 #pragma unroll
         for (int x = 0; x < RP_SCAN_PER; ++x) {
             if (FMT == RP_FASTQ) {
-                stt[x] = L & 3u;
+                stt[x] = L;                                                 // (FASTQ: the line number at the block's first byte)
                 const u32 sel = (1u - L) & 3u;                              // relative line x is a sequence line iff (start + x) % 4 == 1
                 kept[x] = sel == 0 ? r[x].kept[0] : sel == 1 ? r[x].kept[1] : sel == 2 ? r[x].kept[2] : r[x].kept[3];
-                const u32 selq = (3u - L) & 3u;
-                qsum += selq == 0 ? r[x].kept[0] : selq == 1 ? r[x].kept[1] : selq == 2 ? r[x].kept[2] : r[x].kept[3];
                 L += r[x].nl;
             } else {
                 stt[x] = h;
@@ -209,11 +206,8 @@ __global__ __launch_bounds__(RP_NT) void k_rp_scan(const unsigned char* __restri
         if ((u32)x < mine) { boff[b] = out0 + kbase; bstate[b] = stt[x]; }
         kbase += kept[x];
     }
-    u32 qtotal = 0;
-    if (FMT == RP_FASTQ) (void)rp_excl_sum(qsum, s_w, qtotal);
     if (tid == 0) {
         s.out_len = out0 + ktotal;
-        s.seqb += ktotal; s.qualb += qtotal;
         s.lines += nl_total;
         if (FMT == RP_FASTA && lastf != 2u) s.hdr = lastf;
         if (n) s.prev_nl = in[n - 1] == '\n' ? 1u : 0u;
@@ -223,7 +217,7 @@ __global__ __launch_bounds__(RP_NT) void k_rp_scan(const unsigned char* __restri
 
 // (a context's first raw push, or one behind dskgpu_push_reads: the stream so far is `out_len` bytes)
 __global__ void k_rp_init(RawState* st, unsigned long long out_len) {
-    RawState s; s.lines = 0; s.out_len = out_len; s.recs = 0; s.seqb = 0; s.qualb = 0; s.hdr = 0; s.bad = 0; s.prev_nl = 1; s.fresh = 1; s.fq = 0; s.pad = 0;
+    RawState s; s.lines = 0; s.out_len = out_len; s.recs = 0; s.chk = 0; s.hdr = 0; s.bad = 0; s.prev_nl = 1; s.fresh = 1; s.fq = 0; s.pad = 0;
     *st = s;
 }
 __global__ void k_rp_fresh(RawState* st) { st->fresh = 1; }
@@ -252,12 +246,14 @@ __global__ __launch_bounds__(RP_NT) void k_rp_write(const unsigned char* __restr
             }
         }
     }
-    const u32 bst = bstate[blockIdx.x];                  // FASTQ: line % 4 at the block's first byte; FASTA: inside a header line
-    u32 state, tot, lastf;
-    if (FMT == RP_FASTQ) state = (bst + rp_excl_sum(nl, s_w, tot)) & 3u;
+    const u32 bst = bstate[blockIdx.x];                  // FASTQ: the line number at the block's first byte; FASTA: inside a header line
+    u32 state, tot, lastf, lineno = 0;
+    if (FMT == RP_FASTQ) { lineno = bst + rp_excl_sum(nl, s_w, tot); state = lineno & 3u; }
     else { const u32 inh = rp_last_flagged(has_ls != 0, eh, s_w, lastf); state = inh == 2u ? bst : inh; }
     // count what the thread keeps, then place it
     u32 keepm[2] = {0u, 0u}, cnt = 0, bad = 0, recs = 0;           // bit i: byte i is kept
+    unsigned long long wgt = FMT == RP_FASTQ ? rp_weight(lineno >> 2) : 0ull, chk = 0ull;      // (FASTQ) this record's weight; sequence minus quality characters, weighted
+    u32 cl = 0;
     {
         unsigned char prev = prev0;
 #pragma unroll
@@ -267,13 +263,18 @@ __global__ __launch_bounds__(RP_NT) void k_rp_write(const unsigned char* __restr
                 const bool ls = prev == '\n';
                 bool k;
                 if (FMT == RP_FASTQ) {
-                    if (ls && ((state == 0u && c != '@') || (state == 2u && c != '+')) && c != '\n' && c != '\r') bad = 1;      // (blank lines at the end of a file are let through)
+                    if (ls && ((state == 0u && c != '@' && c != '\n' && c != '\r') || (state == 2u && c != '+'))) bad = 1;      // (blank lines where a header would be -- the end of a file -- are let through, as a host parser skips them; a blank '+' line is not)
                     if (ls && state == 0u && c == '@') ++recs;
                     k = state == 1u && c != '\r';
                     if (state == 1u && (c == ' ' || c == '\t')) bad = 1;      // (the host parser drops blanks inside a sequence line: leave such a file to it)
-                    if (c == '\n') state = (state + 1u) & 3u;
+                    cl += (c != '\n' && c != '\r') ? 1u : 0u;              // characters of the current line seen by this thread
+                    if (c == '\n') {
+                        if (state == 1u) chk += wgt * cl; else if (state == 3u) chk -= wgt * cl;
+                        cl = 0; ++lineno; state = lineno & 3u;
+                        if (state == 0u) wgt = rp_weight(lineno >> 2);
+                    }
                 } else {
-                    if (ls) { state = rp_hdr_char(c) ? 1u : 0u; recs += state; }
+                    if (ls) { state = rp_hdr_char(c) ? 1u : 0u; recs += state; if (c == '@' || c == '+') bad = 1; }      // (FASTQ records inside a FASTA file: a host parser switches per record, this one is told one format per file)
                     k = state ? c == '\n' : !rp_blank(c);
                 }
                 if (k) { keepm[i >> 5] |= 1u << (i & 31); ++cnt; }
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(RP_NT) void k_rp_write(const unsigned char* __restr
             }
         }
     }
+    if (FMT == RP_FASTQ) { if (state == 1u) chk += wgt * cl; else if (state == 3u) chk -= wgt * cl; }      // (the line the thread ends in)
     // staged at the offset the block's bytes have inside their 16-byte group of the output: whole groups then leave as 16-byte stores
     const unsigned long long gb = boff[blockIdx.x];
     const u32 a = (u32)(gb & 15ull);
@@ -305,5 +307,13 @@ __global__ __launch_bounds__(RP_NT) void k_rp_write(const unsigned char* __restr
     if (tid == 0) {
         if (rtotal) atomicAdd(&st->recs, (unsigned long long)rtotal);
         if (any_bad) atomicOr(&st->bad, 1u);
+    }
+    if (FMT == RP_FASTQ) {                               // the block's share of the file's checksum (wrapping 64-bit sums: order does not matter)
+        __shared__ unsigned long long s_chk[RP_NT / 64];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) chk += __shfl_down(chk, d);
+        if ((tid & 63u) == 0) s_chk[tid >> 6] = chk;
+        __syncthreads();
+        if (tid == 0) { unsigned long long t = 0; for (u32 x = 0; x < RP_NT / 64; ++x) t += s_chk[x]; if (t) atomicAdd(&st->chk, t); }
     }
 }

@@ -190,7 +190,10 @@ def test_text_the_device_parser_does_not_handle_is_reported(oracle, dev):
     # four lines per record, but one quality line is shorter than its sequence: a host parser (kseq's rule: as many quality characters
     # as bases) would read on into the next record -- not the same records, so not taken either
     shortq = make_fastq(rng, 20, 50, 150) + b"@s\nACGTACGTACGTACGTACGTACGTACGTAC\n+\nIIIIIIIIII\n" + make_fastq(rng, 50, 50, 150)
-    for bad in (wrapped, blanks, fasta, junk, shortq):
+    # ... and two records that are off by -1 and +1 do not cancel
+    offset = make_fastq(rng, 20, 50, 150) + b"@a\nACGTACGTACGTACGTACGTACGTACGTAC\n+\n" + b"I" * 29 + b"\n@b\nACGTACGTACGTACGTACGTACGTACGTAC\n+\n" + b"I" * 31 + b"\n" + make_fastq(rng, 20, 50, 150)
+    noplus = make_fastq(rng, 20, 50, 150, crlf=True) + b"@c\r\nACGTACGTACGTACGTACGTACGTACGTAC\r\n\r\n" + b"I" * 30 + b"\r\n" + make_fastq(rng, 20, 50, 150, crlf=True)      # a '+' line that lost its '+'
+    for bad in (wrapped, blanks, fasta, junk, shortq, offset, noplus):
         with KmerCounter(kmer_size=21, abundance_min=1) as kc:
             kc.push_reads(keep)
             kc.push_raw(good, kc.RAW_FASTQ, new_file=True)
