@@ -29,16 +29,16 @@
 #define RP_FASTA 1
 #define RP_FASTQ 2
 
-struct RawState { unsigned long long lines, out_len, recs, chk; u32 hdr, bad, prev_nl, fresh, fq, pad; };      // chk: FASTQ, sum over the records of w(record) * (sequence characters - quality characters): 0 iff every record has as many of one as of the other      // lines: of the current file; recs: records (header lines) since the raw pushes began      // fresh: a new file starts with the next chunk
+struct RawState { unsigned long long lines, out_len, recs; u32 chk, hdr, bad, prev_nl, fresh, fq; };      // chk: FASTQ, sum over the records of w(record) * (sequence characters - quality characters): 0 iff every record has as many of one as of the other      // lines: of the current file; recs: records (header lines) since the raw pushes began      // fresh: a new file starts with the next chunk
 // what a block tells: newlines; FASTQ: kept bytes by (start line % 4); FASTA: kept[start in header ? 1 : 0], has a line start, header state at its end
 struct RpBlock { u32 nl; u32 kept[4]; u32 has_ls, end_hdr, pad; };
 
 __host__ __device__ __forceinline__ bool rp_hdr_char(unsigned char c) { return c == '>'; }
 // a FASTQ file at its end: every record has as many quality characters as bases.  Checked without pairing lines: every character of
-// a sequence line adds w(record), every character of a quality line subtracts it, w = a 64-bit mix of the record's number -- the sum
-// over the file is 0 iff the records balance one by one (two records that are off by +1 and -1 do not cancel)
-__host__ __device__ __forceinline__ unsigned long long rp_weight(u32 rec) { return kmix((unsigned long long)rec + 0x9e3779b97f4a7c15ULL) | 1ull; }
-__host__ __device__ __forceinline__ bool rp_file_ok(const RawState& s) { return !s.fq || s.chk == 0ull; }
+// a sequence line adds w(record), every character of a quality line subtracts it, w = a 32-bit mix of the record's number -- the sum
+// over the file (wrapping in 32 bits) is 0 iff the records balance one by one (two records that are off by +1 and -1 do not cancel)
+__host__ __device__ __forceinline__ u32 rp_weight(u32 rec) { u32 h = rec + 0x9e3779b9u; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h | 1u; }      // (a 32-bit mix: the sums below wrap in 32 bits -- a damaged file passes with probability 2^-32)
+__host__ __device__ __forceinline__ bool rp_file_ok(const RawState& s) { return !s.fq || s.chk == 0u; }
 __device__ __forceinline__ bool rp_blank(unsigned char c) { return c == '\n' || c == '\r' || c == ' ' || c == '\t'; }      // what the host parser drops from a sequence line (host/bank.cpp append_seq)
 
 // the thread's 64 bytes as 16 words (bytes past the end of the chunk read as '\n'); -> how many of them exist
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(RP_NT) void k_rp_scan(const unsigned char* __restri
 
 // (a context's first raw push, or one behind dskgpu_push_reads: the stream so far is `out_len` bytes)
 __global__ void k_rp_init(RawState* st, unsigned long long out_len) {
-    RawState s; s.lines = 0; s.out_len = out_len; s.recs = 0; s.chk = 0; s.hdr = 0; s.bad = 0; s.prev_nl = 1; s.fresh = 1; s.fq = 0; s.pad = 0;
+    RawState s; s.lines = 0; s.out_len = out_len; s.recs = 0; s.chk = 0; s.hdr = 0; s.bad = 0; s.prev_nl = 1; s.fresh = 1; s.fq = 0;
     *st = s;
 }
 __global__ void k_rp_fresh(RawState* st) { st->fresh = 1; }
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(RP_NT) void k_rp_write(const unsigned char* __restr
     else { const u32 inh = rp_last_flagged(has_ls != 0, eh, s_w, lastf); state = inh == 2u ? bst : inh; }
     // count what the thread keeps, then place it
     u32 keepm[2] = {0u, 0u}, cnt = 0, bad = 0, recs = 0;           // bit i: byte i is kept
-    unsigned long long wgt = FMT == RP_FASTQ ? rp_weight(lineno >> 2) : 0ull, chk = 0ull;      // (FASTQ) this record's weight; sequence minus quality characters, weighted
+    u32 wgt = FMT == RP_FASTQ ? rp_weight(lineno >> 2) : 0u, chk = 0u;      // (FASTQ) this record's weight; sequence minus quality characters, weighted
     u32 cl = 0;
     {
         unsigned char prev = prev0;
@@ -309,11 +309,8 @@ __global__ __launch_bounds__(RP_NT) void k_rp_write(const unsigned char* __restr
         if (any_bad) atomicOr(&st->bad, 1u);
     }
     if (FMT == RP_FASTQ) {                               // the block's share of the file's checksum (wrapping 64-bit sums: order does not matter)
-        __shared__ unsigned long long s_chk[RP_NT / 64];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) chk += __shfl_down(chk, d);
-        if ((tid & 63u) == 0) s_chk[tid >> 6] = chk;
-        __syncthreads();
-        if (tid == 0) { unsigned long long t = 0; for (u32 x = 0; x < RP_NT / 64; ++x) t += s_chk[x]; if (t) atomicAdd(&st->chk, t); }
+        u32 ctotal = 0;
+        (void)rp_excl_sum(chk, s_w, ctotal);
+        if (tid == 0 && ctotal) atomicAdd(&st->chk, ctotal);
     }
 }
