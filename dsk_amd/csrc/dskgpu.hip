@@ -3465,6 +3465,26 @@ int dskgpu_push_raw(dskgpu_ctx* ctx, const char* text, uint64_t nbytes, int form
     return DSKGPU_OK;
 }
 
+int dskgpu_stream_bytes(dskgpu_ctx* ctx, uint64_t* stream_bytes) {
+    if (!ctx || !stream_bytes) return DSKGPU_E_ARG;
+    CK(hipSetDevice(ctx->cfg.device));
+    RAW_SYNC(ctx);
+    *stream_bytes = ctx->reads_len;
+    return DSKGPU_OK;
+}
+
+int dskgpu_rewind_reads(dskgpu_ctx* ctx, uint64_t stream_bytes) {
+    if (!ctx) return DSKGPU_E_ARG;
+    CK(hipSetDevice(ctx->cfg.device));
+    RAW_SYNC(ctx);
+    if (ctx->enc_keep) return fail(ctx, DSKGPU_E_STATE, "dskgpu_rewind_reads: the reads were encoded and released (dskgpu_encode_reads)");
+    if (stream_bytes > ctx->reads_len) return fail(ctx, DSKGPU_E_ARG, "dskgpu_rewind_reads: the stream is shorter than that");
+    ctx->reads_len = stream_bytes;
+    while (!ctx->bank_ends.empty() && ctx->bank_ends.back() > stream_bytes) ctx->bank_ends.pop_back();
+    ctx->d_reads = ctx->reads_own.as<uint8_t>(); ctx->n_bytes = ctx->reads_len; ctx->enc_fresh = false; ctx->sk_prepared = false; ctx->sk_exact = false; ctx->opt2_off = false; ctx->opt1_off = false; ctx->mw_v3_off = false; ctx->rec_l0_off = false; ctx->last_rows = 0;
+    return DSKGPU_OK;
+}
+
 int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes) {
     if (!ctx) return DSKGPU_E_ARG;
     CK(hipSetDevice(ctx->cfg.device));

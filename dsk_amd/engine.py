@@ -83,7 +83,7 @@ SOLIDITY = {"sum": 0, "min": 1, "max": 2, "one": 3, "all": 4, "custom": 5}
 # every symbol include/dskgpu.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "dskgpu_create", "dskgpu_destroy", "dskgpu_last_error", "dskgpu_version", "dskgpu_device_count", "dskgpu_set_stream",
-    "dskgpu_push_reads", "dskgpu_push_raw", "dskgpu_raw_finish", "dskgpu_reserve_reads", "dskgpu_reserve_work", "dskgpu_set_reads_device", "dskgpu_encode_reads", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
+    "dskgpu_push_reads", "dskgpu_push_raw", "dskgpu_raw_finish", "dskgpu_stream_bytes", "dskgpu_rewind_reads", "dskgpu_reserve_reads", "dskgpu_reserve_work", "dskgpu_set_reads_device", "dskgpu_encode_reads", "dskgpu_next_bank", "dskgpu_set_banks", "dskgpu_histogram2d",
     "dskgpu_count", "dskgpu_mg_scatter", "dskgpu_mg_sample", "dskgpu_mg_make_table", "dskgpu_mg_set_table",
     "dskgpu_mg_send_capacity_words", "dskgpu_mg_count", "dskgpu_mg_sent_kmers", "dskgpu_mg_count_sized",
     "dskgpu_mg_slices_prepare", "dskgpu_mg_scatter_slice", "dskgpu_mg_slices_finish", "dskgpu_mg_count_sliced", "dskgpu_get_stats", "dskgpu_histogram",
@@ -128,6 +128,8 @@ def load_library():
     lib.dskgpu_push_reads.argtypes = [vp, vp, u64]
     lib.dskgpu_push_raw.argtypes = [vp, vp, u64, C.c_int, C.c_int]
     lib.dskgpu_raw_finish.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    lib.dskgpu_stream_bytes.argtypes = [vp, C.POINTER(u64)]
+    lib.dskgpu_rewind_reads.argtypes = [vp, u64]
     lib.dskgpu_reserve_reads.argtypes = [vp, u64]
     lib.dskgpu_reserve_work.argtypes = [vp, u64]
     lib.dskgpu_set_reads_device.argtypes = [vp, vp, u64]
@@ -303,6 +305,15 @@ class KmerCounter:
         nb, ln = C.c_uint64(0), C.c_uint64(0)
         self._ck(self._lib.dskgpu_raw_finish(self._h, C.byref(nb), C.byref(ln)))
         return nb.value, ln.value
+
+    def stream_bytes(self) -> int:
+        n = C.c_uint64(0)
+        self._ck(self._lib.dskgpu_stream_bytes(self._h, C.byref(n)))
+        return n.value
+
+    def rewind_reads(self, stream_bytes: int) -> None:
+        """Cut the pushed read stream back to its first stream_bytes bytes (dskgpu_rewind_reads)."""
+        self._ck(self._lib.dskgpu_rewind_reads(self._h, stream_bytes))
 
     def reserve_reads(self, nbytes: int) -> None:
         self._ck(self._lib.dskgpu_reserve_reads(self._h, nbytes))

@@ -101,6 +101,10 @@ struct RecordParser {
         end_record();
         flush();
     }
+    // Is the parser between two records?  A range of a file cut at record starts ends here exactly when the parser was in step with the
+    // cutter: then the next range, parsed from scratch, continues as this parser would have (so all ranges together = one serial parse).
+    // (kind = what the cutter cuts at: a FASTA record also ends where the next '>' line begins, and only there)
+    bool at_record_border(char kind) const { return line.empty() && ((st == HEADER && !open_rec) || (kind == '>' && st == SEQ_FA)); }
 };
 
 // First record start at or after `from` in an uncompressed buffer (used to cut a file into
@@ -152,22 +156,24 @@ public:
     uint64_t getSize() const override { return file_size(path_); }
     std::vector<std::string> files() const override { return {path_}; }
 
-    uint64_t stream(size_t chunkBytes, const Sink& sink) override {
+    uint64_t streamSerial(size_t chunkBytes, const Sink& sink) override { return stream_impl(chunkBytes, sink, 1, nullptr); }
+    uint64_t stream(size_t chunkBytes, const Sink& sink, bool* exact = nullptr) override { return stream_impl(chunkBytes, sink, Bank::parseThreads(), exact); }
+    uint64_t stream_impl(size_t chunkBytes, const Sink& sink, unsigned nthreads, bool* exact) {
+        if (exact) *exact = true;
         const uint64_t size = file_size(path_);
         unsigned char magic[2] = {0, 0};
         { FILE* f = fopen(path_.c_str(), "rb"); if (f) { size_t got = fread(magic, 1, 2, f); (void)got; fclose(f); } }
         const bool gz = magic[0] == 0x1f && magic[1] == 0x8b;
-        unsigned nthreads = Bank::parseThreads();
         uint64_t min_bytes = 16u << 20;                       // below this a single thread is as fast
         if (const char* e = getenv("DSK_PARSE_MIN_BYTES")) min_bytes = (uint64_t)atoll(e);
         if (!gz && size >= min_bytes && nthreads > 1) {
             uint64_t n = 0;
-            if (stream_parallel(chunkBytes, sink, size, nthreads, n)) return n;
+            if (stream_parallel(chunkBytes, sink, size, nthreads, n, exact)) return n;
         }
         if (gz && (size >= (1u << 20) || getenv("DSK_PGZIP_CHUNK_BYTES"))) {      // (the switch: tests run the parallel gzip path on small files)
             uint64_t n = 0;
-            if (nthreads > 1 && stream_bgzf(chunkBytes, sink, size, nthreads, n)) return n;
-            if (nthreads > 1 && !getenv("DSK_NO_PGZIP") && stream_pgz(chunkBytes, sink, size, nthreads, n)) return n;
+            if (nthreads > 1 && stream_bgzf(chunkBytes, sink, size, nthreads, n, exact)) return n;
+            if (nthreads > 1 && !getenv("DSK_NO_PGZIP") && stream_pgz(chunkBytes, sink, size, nthreads, n, exact)) return n;
             return stream_gz_pipelined(chunkBytes, sink);
         }
         return stream_serial(chunkBytes, sink);
@@ -262,13 +268,17 @@ private:
         return ps.nseq;
     }
     // Parse [p, end) of an uncompressed buffer with several threads on record-aligned ranges.
-    static uint64_t parse_parallel(const char* base, const char* p, const char* end, char kind, size_t chunkBytes, const Sink& sink, unsigned nthreads) {
+    // more: the text goes on behind `end` (a slab of a longer file): the LAST range must end between two records as well.
+    // *exact &= every range that has a successor ended between two records (RecordParser::at_record_border)
+    static uint64_t parse_parallel(const char* base, const char* p, const char* end, char kind, size_t chunkBytes, const Sink& sink, unsigned nthreads,
+                                   bool more = false, bool* exact = nullptr) {
         const uint64_t size = (uint64_t)(end - p);
         nthreads = (unsigned)std::min<uint64_t>(nthreads, std::max<uint64_t>(1, size / std::max<uint64_t>(1, std::min<uint64_t>(8u << 20, size / 4 + 1))));
         std::vector<const char*> cut(nthreads + 1);
         cut[0] = p; cut[nthreads] = end;
         for (unsigned t = 1; t < nthreads; ++t) cut[t] = next_record_start(base, p + size * t / nthreads, end, kind);
         std::mutex mu; std::vector<uint64_t> counts(nthreads, 0); std::vector<std::thread> th;
+        std::vector<char> border(nthreads, 1);
         // An exception of the sink (e.g. the engine running out of HBM) must not leave a worker thread: the first one
         // is kept, the other workers' chunks are dropped from then on, and it is thrown again after the join, so the
         // tool reports `EXCEPTION: <msg>` and exits with a failure code (src/main.cpp:42-46) instead of aborting.
@@ -280,6 +290,7 @@ private:
                 try {
                     RecordParser ps(chunkBytes, &guarded, &mu);
                     ps.feed(cut[t], (size_t)(cut[t + 1] - cut[t]));
+                    if (t + 1 < nthreads || more) border[t] = ps.at_record_border(kind) ? 1 : 0;
                     ps.finish();
                     counts[t] = ps.nseq;
                 } catch (...) {
@@ -291,6 +302,7 @@ private:
         for (auto& x : th) x.join();
         if (failure) std::rethrow_exception(failure);
         uint64_t nseq = 0; for (auto c : counts) nseq += c;
+        if (exact) for (char b : border) if (!b) *exact = false;
         return nseq;
     }
     // '>' / '@' if the buffer starts with a FASTA record / a 4-line FASTQ record (what the range cutter assumes), else 0
@@ -305,7 +317,7 @@ private:
         }
         return kind;
     }
-    bool stream_parallel(size_t chunkBytes, const Sink& sink, uint64_t size, unsigned nthreads, uint64_t& nseq) {
+    bool stream_parallel(size_t chunkBytes, const Sink& sink, uint64_t size, unsigned nthreads, uint64_t& nseq, bool* exact) {
         int fd = open(path_.c_str(), O_RDONLY);
         if (fd < 0) return false;
         void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -315,7 +327,7 @@ private:
         const char* p = base;
         const char kind = record_kind(p, end);
         if (!kind) { munmap(m, size); return false; }
-        nseq = parse_parallel(base, p, end, kind, chunkBytes, sink, nthreads);
+        nseq = parse_parallel(base, p, end, kind, chunkBytes, sink, nthreads, false, exact);
         munmap(m, size);
         return true;
     }
@@ -338,7 +350,7 @@ private:
         }
         return false;
     }
-    bool stream_bgzf(size_t chunkBytes, const Sink& sink, uint64_t size, unsigned nthreads, uint64_t& nseq) {
+    bool stream_bgzf(size_t chunkBytes, const Sink& sink, uint64_t size, unsigned nthreads, uint64_t& nseq, bool* exact) {
         int fd = open(path_.c_str(), O_RDONLY);
         if (fd < 0) return false;
         void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -401,7 +413,7 @@ private:
                 if (q < end) for (;;) { const char* r = next_record_start(base, q + 1, end, kind); if (r >= end) break; q = r; }
                 stop = q < end ? q : p;
             }
-            if (stop > p) nseq += parse_parallel(base, p, stop, kind, chunkBytes, sink, nthreads);
+            if (stop > p) nseq += parse_parallel(base, p, stop, kind, chunkBytes, sink, nthreads, b1 < blocks.size(), exact);
             carry.assign(stop, (size_t)(end - stop));
             b0 = b1;
         }
@@ -413,7 +425,7 @@ private:
     // block starts searched inside the stream, chunks inflated with a symbolic window, windows resolved in order --, slab by slab;
     // every slab is parsed like a memory-mapped plain file, the cut last record carried into the next one.  Returns false when the
     // file is not such a gzip (several members, no dynamic blocks, a first slab that does not pass): nothing was consumed then.
-    bool stream_pgz(size_t chunkBytes, const Sink& sink, uint64_t size, unsigned nthreads, uint64_t& nseq) {
+    bool stream_pgz(size_t chunkBytes, const Sink& sink, uint64_t size, unsigned nthreads, uint64_t& nseq, bool* exact) {
         int fd = open(path_.c_str(), O_RDONLY);
         if (fd < 0) return false;
         void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -453,7 +465,7 @@ private:
                     if (q < end) for (;;) { const char* r = next_record_start(base, q + 1, end, kind); if (r >= end) break; q = r; }
                     stop = q < end ? q : p;
                 }
-                if (stop > p) nseq += parse_parallel(base, p, stop, kind, chunkBytes, sink, nthreads);
+                if (stop > p) nseq += parse_parallel(base, p, stop, kind, chunkBytes, sink, nthreads, !last, exact);
                 carry.assign(stop, (size_t)(end - stop));
             });
         } catch (const NotRecords&) {
@@ -519,9 +531,13 @@ public:
     std::vector<std::string> files() const override {
         std::vector<std::string> v; for (auto* b : banks_) { auto f = b->files(); v.insert(v.end(), f.begin(), f.end()); } return v;
     }
-    uint64_t stream(size_t chunkBytes, const Sink& sink) override {
-        uint64_t n = 0; for (auto* b : banks_) n += b->stream(chunkBytes, sink); return n;
+    uint64_t stream(size_t chunkBytes, const Sink& sink, bool* exact = nullptr) override {
+        if (exact) *exact = true;
+        uint64_t n = 0;
+        for (auto* b : banks_) { bool e = true; n += b->stream(chunkBytes, sink, exact ? &e : nullptr); if (exact && !e) *exact = false; }
+        return n;
     }
+    uint64_t streamSerial(size_t chunkBytes, const Sink& sink) override { uint64_t n = 0; for (auto* b : banks_) n += b->streamSerial(chunkBytes, sink); return n; }
     std::vector<IBank*> banks() override { return banks_; }
 private:
     std::string id_; std::vector<IBank*> banks_;

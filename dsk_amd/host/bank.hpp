@@ -23,7 +23,11 @@ public:
     virtual uint64_t getSize() const = 0;
     // Push the whole bank through `sink` in chunks of about chunkBytes, each
     // chunk a whole number of records.  Returns the number of sequences.
-    virtual uint64_t stream(size_t chunkBytes, const Sink& sink) = 0;
+    // exact (optional): set to false when the bank parsed in parallel and cannot vouch that a serial parse would have handed on the
+    // same records -- a damaged FASTQ file, on which a parser that reads qualities by count is not where the range cutter believes it
+    // to be.  The caller then drops what it was given and calls streamSerial (the reference's parser is serial: its result is the one).
+    virtual uint64_t stream(size_t chunkBytes, const Sink& sink, bool* exact = nullptr) = 0;
+    virtual uint64_t streamSerial(size_t chunkBytes, const Sink& sink) { return stream(chunkBytes, sink, nullptr); }
     // The bank's TEXT as it lies in the (inflated) file, headers and quality lines included, in pieces cut anywhere -- for an engine
     // that parses on the device (dskgpu_push_raw).  format: 1 FASTA, 2 FASTQ (include/dskgpu.h DSKGPU_RAW_*); new_file: the piece
     // begins a file.  Returns false -- and has handed on NOTHING -- when the bank does not do this (a bank of several files, a BGZF file, text that

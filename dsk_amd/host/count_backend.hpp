@@ -40,6 +40,10 @@ public:
     virtual bool pushRaw(const char* text, size_t nbytes, int format, bool new_file) { (void)text; (void)nbytes; (void)format; (void)new_file; return false; }
     // after the raw pushes of a bank: true + the number of records; false = the engine gave the text back (nothing of it was kept: parse on the host and push())
     virtual bool rawFinish(uint64_t& records, uint64_t& stream_bytes) { records = 0; stream_bytes = 0; return false; }
+    // markBank: remember where the read stream stands; rewindBank: forget what was pushed since (the bank parsed a damaged file in
+    // parallel and a serial parse would differ: it is pushed again) -- false when the backend cannot
+    virtual void markBank() {}
+    virtual bool rewindBank() { return false; }
     virtual void nextBank() = 0;                              // what was pushed so far is one bank (comma-separated input)
     virtual void finish() = 0;                                // run the count; results valid afterwards
     virtual void histogram(std::vector<uint64_t>& h) = 0;     // histo_max + 1 entries, h[0] == 0

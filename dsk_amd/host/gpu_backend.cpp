@@ -68,6 +68,7 @@ public:
         for (uint32_t r = 0; r < N; ++r) ckr(r, soft(dskgpu_reserve_work(dskgpu_group_ctx(grp_, r), n / N + n / (8 * N) + 4096)));
     }
     void push(const char* data, size_t n) override {
+        if (mark_pending_) take_mark();
         if (!grp_) { ck(dskgpu_push_reads(ctx_, data, n)); return; }
         // N pieces cut at record separators; the rank that has received least so far gets the first (largest) one
         const uint32_t N = dskgpu_group_size(grp_);
@@ -95,9 +96,26 @@ public:
     }
     // one GPU: the file's text goes to the device as it is (dskgpu_push_raw); a group cuts its pushes at record separators, which
     // only parsed reads have
+    // (the mark is taken at the first push behind it: the engine may still be starting up when the bank begins to parse)
+    void markBank() override { mark_pending_ = true; }
+    void take_mark() {
+        mark_pending_ = false;
+        if (!grp_) { ck(dskgpu_stream_bytes(ctx_, &mark_)); return; }
+        const uint32_t N = dskgpu_group_size(grp_);
+        marks_.assign(N, 0); pushed_mark_ = pushed_;
+        for (uint32_t r = 0; r < N; ++r) ckr(r, dskgpu_stream_bytes(dskgpu_group_ctx(grp_, r), &marks_[r]));
+    }
+    bool rewindBank() override {
+        if (mark_pending_) { mark_pending_ = false; return true; }      // nothing was pushed since the mark
+        if (!grp_) { ck(dskgpu_rewind_reads(ctx_, mark_)); return true; }
+        for (uint32_t r = 0; r < dskgpu_group_size(grp_); ++r) ckr(r, dskgpu_rewind_reads(dskgpu_group_ctx(grp_, r), marks_[r]));
+        pushed_ = pushed_mark_;
+        return true;
+    }
     bool parsesOnDevice() const override { return true; }       // (one GPU; the caller does not ask with -nb-gpus > 1)
     bool pushRaw(const char* text, size_t n, int format, bool new_file) override {
         if (grp_) return false;
+        if (mark_pending_) take_mark();
         ck(dskgpu_push_raw(ctx_, text, n, format, new_file ? 1 : 0));
         return true;
     }
@@ -175,6 +193,7 @@ private:
     void ck(int rc) { if (rc != DSKGPU_OK) throw Exception("GPU engine: %s (code %d)", dskgpu_last_error(ctx_), rc); }
     void ckr(uint32_t r, int rc) { if (rc != DSKGPU_OK) throw Exception("GPU engine, rank %u: %s (code %d)", r, dskgpu_last_error(dskgpu_group_ctx(grp_, r)), rc); }
     dskgpu_ctx* ctx_; dskgpu_group* grp_; CountConfig cfg_; std::vector<uint64_t> pushed_;
+    uint64_t mark_ = 0; std::vector<uint64_t> marks_, pushed_mark_; bool mark_pending_ = false;      // markBank / rewindBank
 };
 }  // namespace
 

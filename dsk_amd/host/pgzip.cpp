@@ -123,8 +123,8 @@ bool read_dynamic(Bits& br, BlockCodes& bc, bool strict) {
 void fixed_codes(BlockCodes& bc) {
     uint8_t l[288]; for (int i = 0; i < 144; ++i) l[i] = 8; for (int i = 144; i < 256; ++i) l[i] = 9; for (int i = 256; i < 280; ++i) l[i] = 7; for (int i = 280; i < 288; ++i) l[i] = 8;
     bc.lit.build(l, 288, 11, false);
-    uint8_t d[30]; for (int i = 0; i < 30; ++i) d[i] = 5;
-    bc.dist.build(d, 30, 9, true); bc.has_dist = true;
+    uint8_t d[32]; for (int i = 0; i < 32; ++i) d[i] = 5;      // RFC 1951 3.2.6: distance codes 0-31 in 5 bits (30 and 31 never occur: the decoder rejects them)
+    bc.dist.build(d, 32, 9, false); bc.has_dist = true;          // (as 30 codes the set is incomplete and build() refused it: a fixed block then decoded its distances with the previous block's table)
 }
 
 inline bool texty(int c) { return c == '\n' || c == '\r' || c == '\t' || (c >= 32 && c < 127); }
@@ -320,6 +320,7 @@ bool pgz_inflate(const uint8_t* file, size_t n, unsigned nthreads, size_t chunk_
             c.ok = st == ST_FINAL || (st == ST_OK && (last || e == until));
         });
         const double tt2 = now();
+        if (trace) for (size_t li = 0; li < live.size(); ++li) { const Chunk& c = ch[live[li]]; fprintf(stderr, "[pgzip]     chunk %zu: start %llu end %llu out %zu ok %d final %d\n", live[li], (unsigned long long)c.start_bit, (unsigned long long)c.end_bit, c.out.n, (int)c.ok, (int)c.final_block); }
         size_t good = 0;
         while (good < live.size() && ch[live[good]].ok) { ++good; if (ch[live[good - 1]].final_block) break; }
         const bool ended = good > 0 && ch[live[good - 1]].final_block;

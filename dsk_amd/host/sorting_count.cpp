@@ -196,6 +196,18 @@ void SortingCountBase::execute() {
     // read stream (dskgpu_push_raw).  A bank the device parser gives back (DSKGPU_E_FORMAT) is parsed here as before.
     const bool dev_parse = cfg.nb_gpus == 1 && be->parsesOnDevice() && ((input_.has("-device-parse") && input_.getInt("-device-parse") != 0) || getenv("DSK_DEVICE_PARSE") != nullptr);
     unsigned raw_banks = 0; uint64_t raw_text_bytes = 0;
+    // A bank that parsed in parallel says whether a serial parse would have handed on the same records (IBank::stream's `exact`: a
+    // damaged FASTQ file on which the range cutter and a parser that reads qualities by count part ways).  If not, what it pushed is
+    // dropped and the bank is parsed again by ONE thread: the reference's parser is serial, its reading of a damaged file is the one.
+    unsigned serial_reparses = 0;
+    auto stream_exact = [&](IBank* sub) -> uint64_t {
+        be->markBank();
+        const uint64_t before = nbytes;
+        bool exact = true;
+        uint64_t n = sub->stream(chunk_bytes, push, &exact);
+        if (!exact && be->rewindBank()) { nbytes = before; ++serial_reparses; n = sub->streamSerial(chunk_bytes, push); }
+        return n;
+    };
     if (per_bank || subs.size() < 2 || dev_parse) {           // bank boundaries matter: stream the banks in order
         for (IBank* sub : subs) {
             bool raw_done = false;
@@ -214,30 +226,38 @@ void SortingCountBase::execute() {
                     else nbytes = before;
                 }
             }
-            if (!raw_done) nseq += sub->stream(chunk_bytes, push);
+            if (!raw_done) nseq += stream_exact(sub);
             gate();
             be->nextBank();
         }
     } else {                                     // plain sum: inflate / parse the files concurrently (host thread pool)
-        std::mutex mu; std::atomic<size_t> next(0); std::atomic<uint64_t> seqs(0);
+        std::mutex mu; std::atomic<size_t> next(0); std::atomic<uint64_t> seqs(0); std::atomic<bool> all_exact(true);
         std::string err;
         auto worker = [&]() {
             for (;;) {
                 const size_t i = next.fetch_add(1);
                 if (i >= subs.size()) return;
                 try {
-                    seqs += subs[i]->stream(chunk_bytes, [&](const char* d, size_t n) { std::lock_guard<std::mutex> g(mu); push(d, n); });
+                    bool exact = true;
+                    seqs += subs[i]->stream(chunk_bytes, [&](const char* d, size_t n) { std::lock_guard<std::mutex> g(mu); push(d, n); }, &exact);
+                    if (!exact) all_exact = false;
                 } catch (Exception& e) { std::lock_guard<std::mutex> g(mu); if (err.empty()) err = e.getMessage(); next = subs.size(); }
                 catch (std::exception& e) { std::lock_guard<std::mutex> g(mu); if (err.empty()) err = e.what(); next = subs.size(); }
                 catch (...) { std::lock_guard<std::mutex> g(mu); if (err.empty()) err = "unknown failure while reading the input"; next = subs.size(); }
             }
         };
         const unsigned nt = (unsigned)std::min<size_t>(subs.size(), std::max(1u, Bank::parseThreads()));
+        be->markBank();
+        const uint64_t before = nbytes;
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; ++t) th.emplace_back(worker);
         for (auto& x : th) x.join();
         if (!err.empty()) throw Exception(err);
         nseq = seqs;
+        if (!all_exact.load() && be->rewindBank()) {      // (the files' chunks are interleaved in the stream: all of them again, one after the other, one thread each)
+            nbytes = before; ++serial_reparses; nseq = 0;
+            for (IBank* sub : subs) nseq += sub->streamSerial(chunk_bytes, push);
+        }
     }
     startup.wait_done();
     const double t2 = now_s();
@@ -352,6 +372,7 @@ void SortingCountBase::execute() {
     info_.add(2, "uri", bank_->getId());
     info_.add(2, "nb_sequences", "%llu", (unsigned long long)nseq);
     info_.add(2, "read_stream_bytes", "%llu", (unsigned long long)nbytes);
+    if (serial_reparses) info_.add(2, "banks_parsed_again_by_one_thread", "%u", serial_reparses);
     if (dev_parse) { info_.add(2, "banks_parsed_on_device", "%u", raw_banks); info_.add(2, "text_bytes_pushed", "%llu", (unsigned long long)raw_text_bytes); }
     info_.add(1, "stats");
     be->stats(info_, 2);

@@ -130,6 +130,11 @@ int dskgpu_push_raw(dskgpu_ctx* ctx, const char* text, uint64_t nbytes, int form
 /* Wait for the raw pushes; -> the read stream's length in bytes and the number of records (header lines) the raw pushes since the
  * last finish held -- Bank::estimate's sequence count (both may be NULL). */
 int dskgpu_raw_finish(dskgpu_ctx* ctx, uint64_t* stream_bytes, uint64_t* records);
+/* The length of the pushed read stream in bytes (waits for raw pushes), and its rewind: the stream is cut back to its first
+ * `stream_bytes` bytes -- what was pushed behind them is forgotten (a bank front-end that parsed a damaged file in parallel and
+ * found out that a serial parse would differ pushes that file again; src/DSK.cpp:51: the reference's parser is serial). */
+int dskgpu_stream_bytes(dskgpu_ctx* ctx, uint64_t* stream_bytes);
+int dskgpu_rewind_reads(dskgpu_ctx* ctx, uint64_t stream_bytes);
 /* Optional: size the device-side read buffer once (e.g. from Bank::getSize) instead of growing it push by push. */
 int dskgpu_reserve_reads(dskgpu_ctx* ctx, uint64_t nbytes);
 /* Optional: allocate the partition buffers of a count over up to `nbytes` read-stream bytes now (tens of GB of HBM: 0.2 s of

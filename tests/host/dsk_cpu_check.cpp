@@ -24,6 +24,8 @@ public:
         if (const char* e = getenv("DSK_TEST_FAIL_AFTER_BYTES")) if (stream_.size() + n > (size_t)atoll(e)) throw dsk::Exception("test backend: out of memory after %zu bytes", stream_.size());
         stream_.insert(stream_.end(), d, d + n); stream_.push_back('\n');
     }
+    void markBank() override { mark_ = stream_.size(); }
+    bool rewindBank() override { stream_.resize(mark_); return true; }
     void nextBank() override { if (ends_.empty() || ends_.back() != stream_.size()) ends_.push_back(stream_.size()); }
     void finish() override {
         words_ = (cfg_.kmer_size + 31) / 32;
@@ -99,6 +101,7 @@ public:
         info.add(d, "kmers_nb_solid", "%llu", (unsigned long long)a_.size());
     }
 private:
+    size_t mark_ = 0;
     dsk::CountConfig cfg_; std::vector<char> stream_; dsko_result* r_ = nullptr;
     std::vector<uint64_t> k_; std::vector<uint32_t> a_; size_t words_ = 1;
     std::vector<size_t> ends_; std::vector<uint64_t> hist_, h2_; uint64_t total_ = 0, distinct_ = 0;

@@ -230,6 +230,37 @@ def test_device_parse_through_the_binary(bins, tmp_path, oracle, monkeypatch):
         assert got == (2000, ref.total, ref.distinct, 0), got
 
 
+def test_damaged_files_on_gpu_are_read_as_one_thread_reads_them(bins, tmp_path, oracle):
+    """The parallel parser's give-away (IBank::stream's `exact`) against the real engine: the chunks of a damaged file are dropped from
+    the device's read stream (dskgpu_rewind_reads) and the file is pushed again from one thread -- on one GPU and on a group of two."""
+    import re
+    import numpy as np
+    from tests.test_host_cli import test_damaged_files_are_read_as_one_thread_reads_them
+    from tests.raw_text_model import base_text, damage, host_parser
+    test_damaged_files_are_read_as_one_thread_reads_them(bins, tmp_path, oracle)
+    tmp = str(tmp_path)
+    done = 0
+    for seed in range(400):
+        rng = np.random.default_rng(seed)
+        fmt = "fq" if rng.random() < 0.6 else "fa"
+        text = damage(rng, base_text(rng, fmt), fmt)
+        if text[:1] not in (b"@", b">"):
+            continue
+        open(os.path.join(tmp, "x.txt"), "wb").write(text)
+        r = subprocess.run([bins["dsk"], "-file", "x.txt", "-kmer-size", "21", "-abundance-min", "1", "-out", "o", "-verbose", "1", "-nb-cores", "4", "-nb-gpus", "2"],
+                           cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, DSK_PARSE_MIN_BYTES="1"))
+        assert r.returncode == 0, (seed, r.stderr[-300:])
+        info = r.stdout.decode()
+        if "banks_parsed_again_by_one_thread" not in info:
+            continue
+        want = oracle.count(np.frombuffer(host_parser(text) + b"\n", dtype=np.uint8).copy(), 21).total
+        assert int(re.search(r"kmers_nb_valid\s*:\s*(\d+)", info).group(1)) == want, (seed, fmt)
+        done += 1
+        if done == 4:
+            break
+    assert done == 4
+
+
 def test_bench_line_contract():
     """`python bench.py` prints ONE JSON line with the fields the driver reads (metric / value / unit / n_gpus / steps / warmup /
     ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus the `roofline` and `cpu_baseline`

@@ -487,6 +487,75 @@ def test_bank_hands_on_its_text(bins, tmp_path):
     assert run("junk.fa") == ["NO"]
 
 
+def test_damaged_files_are_read_as_one_thread_reads_them(bins, tmp_path, oracle):
+    """FASTA / FASTQ text with lines deleted, doubled, split, joined, bytes inserted and removed, records of the other format spliced
+    in (tests/raw_text_model.py): whatever the thread count -- the parallel parser cuts a file at record starts it recognises by
+    their looks -- `dsk` counts what ONE thread reads (the reference's parser is serial: gatb-core BankFasta behind src/DSK.cpp:51), which
+    is what the restatement of the parser's state machine reads.  A range that does not end between two records gives the parallel
+    parse away: its chunks are dropped from the engine and the file is parsed again by one thread."""
+    import re
+    import numpy as np
+    from tests.raw_text_model import base_text, damage, host_parser
+    tmp = str(tmp_path)
+    reparsed = 0
+    for seed in range(160):
+        rng = np.random.default_rng(seed)
+        fmt = "fq" if rng.random() < 0.6 else "fa"
+        text = damage(rng, base_text(rng, fmt), fmt)
+        if text[:1] not in (b"@", b">"):
+            continue
+        want = oracle.count(np.frombuffer(host_parser(text) + b"\n", dtype=np.uint8).copy(), 21).total
+        open(os.path.join(tmp, "x.txt"), "wb").write(text)
+        for cores in ("1", "4"):
+            r = subprocess.run([bins["dsk"], "-file", "x.txt", "-kmer-size", "21", "-abundance-min", "1", "-out", "o", "-verbose", "1", "-nb-cores", cores],
+                               cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, DSK_PARSE_MIN_BYTES="1"))
+            assert r.returncode == 0, (seed, r.stderr[-300:])
+            info = r.stdout.decode()
+            assert int(re.search(r"kmers_nb_valid\s*:\s*(\d+)", info).group(1)) == want, (seed, fmt, cores)
+            reparsed += "banks_parsed_again_by_one_thread" in info
+    assert reparsed >= 5          # (the damage does reach the case this test is about)
+
+
+def test_parallel_inflate_block_types(bins, tmp_path):
+    """host/pgzip.cpp against zlib (tests/host/test_pgzip) on streams that hold what an ordinary FASTQ .gz rarely does: short blocks
+    coded with the FIXED Huffman codes that carry back-references (a sync flush, then a short tail: r06 -- the fixed distance code was
+    built from 30 lengths, refused as incomplete, and such a block decoded its distances with the previous block's table: a valid
+    file was reported as corrupt by the CRC check), empty stored blocks (the flush markers), stored blocks of random bytes."""
+    import zlib
+    import numpy as np
+    exe = os.path.join(ROOT, "tests", "host", "test_pgzip")
+    rng = np.random.default_rng(12)
+    recs = [b"@r%d\n" % i + bytes(rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), 90)) + b"\n+\n" + bytes(rng.integers(33, 74, 90, dtype=np.uint8)) + b"\n" for i in range(4000)]
+    body = b"".join(recs)
+    for case in range(6):
+        c = zlib.compressobj(6, zlib.DEFLATED, 31)
+        z = c.compress(body[: 500_000 + 1111 * case]) + c.flush(zlib.Z_SYNC_FLUSH)
+        if case % 2:
+            z += c.compress(rng.integers(0, 256, 30_000, dtype=np.uint8).tobytes()) + c.flush(zlib.Z_SYNC_FLUSH)      # (incompressible: stored blocks)
+        z += c.compress(b"".join(recs[:3])[: 150 + 40 * case]) + c.flush()                                          # a short tail that repeats earlier text: one fixed block with matches
+        path = os.path.join(str(tmp_path), "f%d.gz" % case)
+        open(path, "wb").write(z)
+        for chunk in ("16384", "65536"):
+            out = subprocess.run([exe, path, "4", chunk], stdout=subprocess.PIPE).stdout.decode()
+            assert out.startswith("OK "), (case, chunk, out)
+    # the file on which the bug was found (tools: differential checks of damaged text through gzip, seed 26): 171 KB of text whose
+    # deflate stream ends in a fixed block with matches that the parallel path decodes itself
+    import gzip
+    from tests.raw_text_model import base_text, damage
+    rng = np.random.default_rng(26)
+    fmt = "fq" if rng.random() < 0.7 else "fa"
+    parts = []
+    for _ in range(40):
+        t = damage(rng, base_text(rng, fmt), fmt) if rng.random() < 0.15 else b"".join(base_text(rng, fmt))
+        parts.append(t if t.endswith(b"\n") else t + b"\n")
+    path = os.path.join(str(tmp_path), "s26.gz")
+    open(path, "wb").write(gzip.compress(b"".join(parts), 6, mtime=0))
+    for chunk in ("8192", "16384", "32768"):
+        for threads in ("2", "4", "8"):
+            out = subprocess.run([exe, path, threads, chunk], stdout=subprocess.PIPE).stdout.decode()
+            assert out.startswith("OK 171199 "), (threads, chunk, out)
+
+
 def write_bgzf(path, data, block=60000):
     """BGZF writer (htslib's blocked gzip): independent <= 64 KB members with the 'BC' size field + the empty EOF member."""
     import struct, zlib
