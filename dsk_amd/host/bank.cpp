@@ -24,13 +24,16 @@ namespace dsk {
 
 void IBank::estimate(uint64_t& number, uint64_t& totalSize, uint64_t& maxSize) {
     uint64_t bases = 0, longest = 0;
-    uint64_t n = stream(1 << 24, [&](const char* d, size_t nb) {
+    const Sink sink = [&](const char* d, size_t nb) {
         size_t run = 0;
         for (size_t i = 0; i < nb; ++i) {
             if (d[i] == '\n') { longest = std::max<uint64_t>(longest, run); run = 0; }
             else { ++run; ++bases; }
         }
-    });
+    };
+    bool exact = true;
+    uint64_t n = stream(1 << 24, sink, &exact);
+    if (!exact) { bases = longest = 0; n = streamSerial(1 << 24, sink); }      // (a damaged file: what ONE thread reads, see IBank::stream)
     number = n; totalSize = bases; maxSize = longest;
 }
 
