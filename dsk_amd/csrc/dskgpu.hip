@@ -3582,7 +3582,10 @@ int dskgpu_count(dskgpu_ctx* ctx) {
 int dskgpu_next_bank(dskgpu_ctx* ctx) {
     if (!ctx) return DSKGPU_E_ARG;
     if (ctx->raw_pending) { CK(hipSetDevice(ctx->cfg.device)); RAW_SYNC(ctx); }
-    if (ctx->bank_ends.empty() || ctx->bank_ends.back() != ctx->reads_len) ctx->bank_ends.push_back(ctx->reads_len);
+    // (every call ends a bank, an empty one too: a rank of a group that was handed nothing of a small bank must count as many banks as
+    //  the others -- until r06 a bank that added no bytes was not recorded: the ranks of `dsk -nb-gpus 4 -solidity-kind min` then ran
+    //  different numbers of per-bank steps and waited for each other for ever; on one GPU an empty input file was not a bank at all)
+    ctx->bank_ends.push_back(ctx->reads_len);
     return DSKGPU_OK;
 }
 

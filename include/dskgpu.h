@@ -162,7 +162,8 @@ int dskgpu_set_reads_device(dskgpu_ctx* ctx, const void* d_bytes, uint64_t nbyte
 int dskgpu_encode_reads(dskgpu_ctx* ctx);
 
 /* Banks: the comma-separated inputs of `-file` are separate banks (README.md:52-58).  Call
- * dskgpu_next_bank between the pushes of two banks, or give the end offset of every bank of a
+ * dskgpu_next_bank between the pushes of two banks (or behind every bank, the last one too: a bank may be EMPTY -- a file without
+ * reads, a rank's empty share of a small bank -- and is only known to exist by its call), or give the end offset of every bank of a
  * device-resident stream.  Only needed for -solidity-kind != sum and -histo2D; at most 32 banks. */
 int dskgpu_next_bank(dskgpu_ctx* ctx);
 int dskgpu_set_banks(dskgpu_ctx* ctx, const uint64_t* end_offsets, uint32_t n_banks);

@@ -26,7 +26,7 @@ public:
     }
     void markBank() override { mark_ = stream_.size(); }
     bool rewindBank() override { stream_.resize(mark_); return true; }
-    void nextBank() override { if (ends_.empty() || ends_.back() != stream_.size()) ends_.push_back(stream_.size()); }
+    void nextBank() override { ends_.push_back(stream_.size()); }          // (an empty bank is a bank)
     void finish() override {
         words_ = (cfg_.kmer_size + 31) / 32;
         const bool banked = ends_.size() > 1 && (cfg_.solidity_kind != 0 || cfg_.histo2d);

@@ -261,6 +261,12 @@ def test_damaged_files_on_gpu_are_read_as_one_thread_reads_them(bins, tmp_path, 
     assert done == 2
 
 
+@pytest.mark.parametrize("extra", [(), ("-nb-gpus", "2"), ("-nb-gpus", "4"), ("-device-parse", "1")])
+def test_empty_and_tiny_banks_on_gpu(bins, tmp_path, oracle, extra):
+    from tests.test_host_cli import run_empty_bank_cases
+    run_empty_bank_cases(bins["dsk"], bins["dsk2ascii"], str(tmp_path), oracle, extra)
+
+
 def test_bench_line_contract():
     """`python bench.py` prints ONE JSON line with the fields the driver reads (metric / value / unit / n_gpus / steps / warmup /
     ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus the `roofline` and `cpu_baseline`

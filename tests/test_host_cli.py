@@ -556,6 +556,42 @@ def test_parallel_inflate_block_types(bins, tmp_path):
             assert out.startswith("OK 171199 "), (threads, chunk, out)
 
 
+def run_empty_bank_cases(dsk, dsk2ascii, tmp, oracle, extra=()):
+    """An input file without reads is still a bank: with -solidity-kind min no k-mer is solid (its count there is 0), with max / sum
+    the other banks decide; the same with the empty file first, and with a bank of ONE read (a group of 4 ranks hands most ranks
+    nothing of it: until r06 those ranks counted one bank less than the others and the job hung)."""
+    import numpy as np
+    rng = np.random.default_rng(21)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 120)) for _ in range(60)]
+    open(os.path.join(tmp, "a.fa"), "wb").write(b"".join(b">s%d\n" % i + s + b"\n" for i, s in enumerate(seqs * 2)))
+    open(os.path.join(tmp, "empty.fa"), "wb").write(b"")
+    open(os.path.join(tmp, "one.fa"), "wb").write(b">only\n" + seqs[0] + b"\n")
+    k = 25
+    ra = oracle.count(np.frombuffer(b"\n".join(seqs * 2) + b"\n", dtype=np.uint8).copy(), k)
+    r1 = oracle.count(np.frombuffer(seqs[0] + b"\n", dtype=np.uint8).copy(), k)
+
+    def rows(uri, kind):
+        r = subprocess.run([dsk, "-file", uri, "-kmer-size", str(k), "-abundance-min", "1", "-solidity-kind", kind, "-out", "e", "-verbose", "0", *extra],
+                           cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 0, (uri, kind, r.stderr[-300:])
+        subprocess.check_call([dsk2ascii, "-file", "e", "-out", "e.txt", "-verbose", "0"], cwd=tmp)
+        return sorted(open(os.path.join(tmp, "e.txt")).read().splitlines())          # (a group writes its ranks' partitions one after the other: ascending inside each)
+
+    all_a = sorted(f"{oracle.kmer_to_string(int(v), 0, k)} {int(c)}" for v, c in zip(ra.lo, ra.ab))
+    for uri in ("a.fa,empty.fa", "empty.fa,a.fa"):
+        assert rows(uri, "min") == []
+        assert rows(uri, "max") == all_a
+        assert rows(uri, "sum") == all_a
+    in_one = set(int(v) for v in r1.lo)
+    want = sorted(f"{oracle.kmer_to_string(int(v), 0, k)} {int(c) + 1}" for v, c in zip(ra.lo, ra.ab) if int(v) in in_one)
+    assert rows("a.fa,one.fa", "min") == want            # (min >= 1 in both banks: the k-mers of the one read; printed with the sum)
+    assert rows("one.fa,a.fa", "all") == want
+
+
+def test_empty_and_tiny_banks(bins, tmp_path, oracle):
+    run_empty_bank_cases(bins["dsk"], bins["dsk2ascii"], str(tmp_path), oracle)
+
+
 def write_bgzf(path, data, block=60000):
     """BGZF writer (htslib's blocked gzip): independent <= 64 KB members with the 'BC' size field + the empty EOF member."""
     import struct, zlib

@@ -2,7 +2,7 @@
 """Differential fuzz of the two `dsk` binaries: dsk_amd/host/bin/dsk (the HIP engine behind the C-ABI) against tests/host/dsk_cpu_check
 (the same host layer on the CPU oracle), on random small inputs and random combinations of the options that change results --
 1-4 input files (FASTA / FASTQ, plain / gzip, an album), k in 9..128, -abundance-min (numbers and `auto`) / -abundance-max, -histo-max,
--solidity-kind (+ -solidity-custom), -histo2D, -nb-partitions, -nb-gpus, -device-parse.  Compared: the dump of `dsk2ascii` (rows in
+-solidity-kind (+ -solidity-custom), -histo2D, -nb-partitions, -out-compress, -nb-gpus, -device-parse.  Compared: the dump of `dsk2ascii` (rows in
 the tool's order, then sorted), the histogram dataset, the .histo / .histo2D files.
    python tools/fuzz_cli.py [seed=0] [n=100]"""
 import gzip
@@ -47,7 +47,11 @@ def make_file(rng, tmp, name, genome):
 
 
 def run(binary, args, cwd):
-    return subprocess.run([binary] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        return subprocess.run([binary] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    except subprocess.TimeoutExpired:
+        print(f"HANG (120 s): {os.path.basename(binary)} {args} in {cwd}", flush=True)
+        sys.exit(2)
 
 
 def outputs(cwd, name):
@@ -99,6 +103,8 @@ def main():
             args += ["-histo", "1"]
         if rng.random() < 0.3:
             args += ["-nb-partitions", str(int(rng.choice([1, 3, 16])))]
+        if rng.random() < 0.2:
+            args += ["-out-compress", str(int(rng.choice([1, 6, 9])))]
         gpu_only = []
         if rng.random() < 0.25:
             gpu_only += ["-nb-gpus", str(int(rng.choice([2, 4])))]
