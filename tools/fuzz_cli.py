@@ -21,7 +21,7 @@ D2A = os.path.join(ROOT, "dsk_amd", "host", "bin", "dsk2ascii")
 
 def make_file(rng, tmp, name, genome):
     fq = rng.random() < 0.5
-    n = int(rng.integers(1, 400))
+    n = int(rng.choice([0, 1, 2])) if rng.random() < 0.15 else int(rng.integers(1, 400))          # (sometimes a file without reads, or with one)
     out = []
     for i in range(n):
         L = int(rng.integers(0, 260))
