@@ -4,7 +4,7 @@
 1-4 input files (FASTA / FASTQ, plain / gzip, an album), k in 9..128, -abundance-min (numbers and `auto`) / -abundance-max, -histo-max,
 -solidity-kind (+ -solidity-custom), -histo2D, -nb-partitions, -out-compress, -nb-gpus, -device-parse.  Compared: the dump of `dsk2ascii` (rows in
 the tool's order, then sorted), the histogram dataset, the .histo / .histo2D files.
-   python tools/fuzz_cli.py [seed=0] [n=100]"""
+   python tools/fuzz_cli.py [seed=0] [n=100]          (FUZZ_GROUP=1: every run with -nb-gpus 2 / 4 / 8 and several input files)"""
 import gzip
 import os
 import subprocess
@@ -77,7 +77,8 @@ def main():
         rng = np.random.default_rng(seed)
         tmp = tempfile.mkdtemp(prefix="dskfuzz_")
         genome = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(rng.integers(300, 20000))))
-        nfiles = int(rng.choice([1, 1, 2, 3, 4]))
+        group_focus = os.environ.get("FUZZ_GROUP") == "1"          # every run on a group of ranks, several banks, mostly per-bank modes
+        nfiles = int(rng.choice([2, 3, 4])) if group_focus else int(rng.choice([1, 1, 2, 3, 4]))
         files = [make_file(rng, tmp, "in%d" % i, genome) for i in range(nfiles)]
         uri = ",".join(files)
         if nfiles > 1 and rng.random() < 0.25:
@@ -106,8 +107,8 @@ def main():
         if rng.random() < 0.2:
             args += ["-out-compress", str(int(rng.choice([1, 6, 9])))]
         gpu_only = []
-        if rng.random() < 0.25:
-            gpu_only += ["-nb-gpus", str(int(rng.choice([2, 4])))]
+        if group_focus or rng.random() < 0.25:
+            gpu_only += ["-nb-gpus", str(int(rng.choice([2, 4, 8] if group_focus else [2, 4])))]
         elif rng.random() < 0.4:
             gpu_only += ["-device-parse", "1"]
         if rng.random() < 0.3:
