@@ -263,7 +263,13 @@ __global__ __launch_bounds__(RP_NT) void k_rp_write(const unsigned char* __restr
                 const bool ls = prev == '\n';
                 bool k;
                 if (FMT == RP_FASTQ) {
-                    if (ls && ((state == 0u && c != '@' && c != '\n' && c != '\r') || (state == 2u && c != '+'))) bad = 1;      // (blank lines where a header would be -- the end of a file -- are let through, as a host parser skips them; a blank '+' line is not)
+                    if (ls && state == 2u && c != '+') bad = 1;
+                    if (ls && state == 0u && c != '@' && c != '\n') {      // where a header would be: only a BLANK line is let through (the end of a file; a host parser skips it) --
+                        // empty, or a lone '\r' in front of its '\n'.  (What follows a '\r' at the very end of a piece is not known here: given back.)
+                        const u32 nxi = b0 + (u32)i + 1u;
+                        const unsigned char nx = (i + 1 < RP_BPT && (u32)(i + 1) < m) ? RP_BYTE(w, (i + 1) & (RP_BPT - 1)) : (nxi < n ? in[nxi] : (unsigned char)0);
+                        if (c != '\r' || nx != '\n') bad = 1;
+                    }
                     if (ls && state == 0u && c == '@') ++recs;
                     k = state == 1u && c != '\r';
                     if (state == 1u && (c == ' ' || c == '\t')) bad = 1;      // (the host parser drops blanks inside a sequence line: leave such a file to it)
