@@ -8,6 +8,7 @@ commands run against the real GPU `dsk` binary in tests/test_cli_gpu.py.
 import hashlib
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -590,6 +591,12 @@ def run_empty_bank_cases(dsk, dsk2ascii, tmp, oracle, extra=()):
 
 def test_empty_and_tiny_banks(bins, tmp_path, oracle):
     run_empty_bank_cases(bins["dsk"], bins["dsk2ascii"], str(tmp_path), oracle)
+
+
+def test_parallel_inflate_on_random_valid_files(bins):
+    """A short run of tools/fuzz_pgzip.py (valid gzip files of many shapes through the parallel inflate against zlib)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_pgzip.py"), "5", "60"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and b"bad 0" in r.stdout, r.stdout[-600:] + r.stderr[-300:]
 
 
 def write_bgzf(path, data, block=60000):
